@@ -1,0 +1,196 @@
+"""Seeded synthetic frame pairs for tests, golden vectors and bench.py.
+
+No dataset ships with the build, so every input is rendered
+analytically: a slanted textured plane seen from a source camera and from a
+target camera displaced by a known SE(3) motion.  Because both images are ray
+cast against the same plane, the ground-truth relative pose and the per-segment
+keypoint log-depths are known exactly, which is what the convergence tests of
+the Adam and Gauss-Newton drivers check against.
+
+Everything is generated with ``numpy.random.default_rng(seed)`` (PCG64 is
+stable across numpy versions and machines) in float64 and cast to float32 at
+the end, so the same seed gives bit-identical inputs in this container and on
+the GPU box.
+
+Conventions follow the reference data model (``image/keyframe.py:20-75``):
+``image`` (3,H,W) in [0,1]; ``K`` (3,3); ``logdepth_perseg`` (N,H,W), zero
+outside each mask; ``keypoints`` (N,2) normalised (row, col) in [-1,1];
+``keypoint_regions`` (N,H,W) bool.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+# ----------------------------------------------------------------------------
+# tiny float64 SE(3) helpers (host side only; tangent order [tau, phi] like the
+# pose parameter the reference optimises)
+# ----------------------------------------------------------------------------
+def hat(w):
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+def se3_exp_np(xi):
+    """Exp of a twist ``xi = [tau(3), phi(3)]`` -> 4x4 float64."""
+    xi = np.asarray(xi, dtype=np.float64)
+    tau, phi = xi[:3], xi[3:]
+    th = float(np.linalg.norm(phi))
+    W = hat(phi)
+    if th < 1e-8:
+        A, B, C = 1.0 - th * th / 6.0, 0.5 - th * th / 24.0, 1.0 / 6.0 - th * th / 120.0
+    else:
+        A = math.sin(th) / th
+        B = (1.0 - math.cos(th)) / (th * th)
+        C = (th - math.sin(th)) / (th ** 3)
+    R = np.eye(3) + A * W + B * (W @ W)
+    V = np.eye(3) + B * W + C * (W @ W)
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = V @ tau
+    return T
+
+
+# ----------------------------------------------------------------------------
+@dataclass
+class SynthPair:
+    """One synthetic source keyframe + target (supporting) frame."""
+    H: int
+    W: int
+    N: int
+    K: np.ndarray                 # (3,3) f32
+    src_image: np.ndarray         # (3,H,W) f32
+    trg_image: np.ndarray         # (3,H,W) f32
+    depth: np.ndarray             # (H,W) f32 source depth (ground truth)
+    logdepth_perseg: np.ndarray   # (N,H,W) f32
+    keypoints: np.ndarray         # (N,2) f32 normalised (row, col)
+    keypoint_regions: np.ndarray  # (N,H,W) bool
+    kld_gt: np.ndarray            # (N,) f32 log-depth at the keypoints
+    kld_init: np.ndarray          # (N,) f32  log(2 + 2*rand)
+    pose_gt: np.ndarray           # (4,4) f32  target <- source
+    pose_init: np.ndarray         # (4,4) f32  perturbed start
+    meta: dict = field(default_factory=dict)
+
+
+def _texture(X, rng_tex, base_omega):
+    """Band-limited RGB texture evaluated at 3-D points X (...,3) -> (3,...)."""
+    out = []
+    for ch in range(3):
+        acc = np.full(X.shape[:-1], 0.5)
+        for k in range(6):
+            direction = rng_tex[ch, k, :3]
+            omega = base_omega * rng_tex[ch, k, 3]
+            phase = rng_tex[ch, k, 4]
+            amp = rng_tex[ch, k, 5]
+            acc = acc + amp * np.sin(omega * (X @ direction) + phase)
+        out.append(acc)
+    return np.clip(np.stack(out, 0), 0.0, 1.0)
+
+
+def _grid_shape(N):
+    gh = int(math.floor(math.sqrt(N)))
+    while N % gh:
+        gh -= 1
+    return gh, N // gh
+
+
+def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
+              motion_scale=1.0, init_sigma=0.02, texture_period_px=14.0,
+              drop_border=0):
+    """Render one seeded source/target pair.
+
+    ``shape``: 'grid' = gh x gw rectangular tiling; 'blobs' =
+    random overlapping ellipses (emulates SAM masks, rho > 1, ragged sizes).
+    ``overlap``: grow each grid tile by this many pixels on every side.
+    ``drop_border``: leave an unsegmented band of this many pixels.
+    """
+    rng = np.random.default_rng(seed)
+    fx = fy = 0.8 * W
+    cx, cy = W / 2.0, H / 2.0
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+
+    # plane n.X = h in the source camera frame
+    n = np.array([0.22, -0.12, 1.0]) + 0.05 * rng.standard_normal(3)
+    n /= np.linalg.norm(n)
+    h = 3.0
+
+    cols, rows = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    rays = np.stack([(cols - cx) / fx, (rows - cy) / fy, np.ones_like(cols)], -1)
+
+    depth = h / (rays @ n)
+    Xs = rays * depth[..., None]
+
+    base_omega = 2.0 * math.pi / (texture_period_px * h / fx)
+    tex = np.empty((3, 6, 6))
+    d = rng.standard_normal((3, 6, 3))
+    tex[:, :, :3] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    tex[:, :, 3] = rng.uniform(0.35, 1.0, (3, 6))
+    tex[:, :, 4] = rng.uniform(0, 2 * math.pi, (3, 6))
+    tex[:, :, 5] = rng.uniform(0.04, 0.11, (3, 6))
+    src_image = _texture(Xs, tex, base_omega)
+
+    # ground-truth motion target <- source
+    xi_gt = motion_scale * np.array([0.06, -0.035, 0.025, 0.012, -0.02, 0.015])
+    xi_gt = xi_gt * (1.0 + 0.2 * rng.standard_normal(6))
+    T_gt = se3_exp_np(xi_gt)
+    R, t = T_gt[:3, :3], T_gt[:3, 3]
+    # target rays -> plane (expressed in the source frame)
+    num = h + n @ (R.T @ t)
+    den = (rays @ R) @ n          # n . R^T ray_t
+    d_t = num / den
+    Xt = rays * d_t[..., None]
+    Xs_from_t = (Xt - t) @ R      # R^T (X_t - t)
+    trg_image = _texture(Xs_from_t, tex, base_omega)
+
+    # segments
+    masks = np.zeros((N, H, W), dtype=bool)
+    kp_rc = np.zeros((N, 2), dtype=np.int64)
+    if shape == "grid":
+        gh, gw = _grid_shape(N)
+        b = drop_border
+        r_edges = np.linspace(b, H - b, gh + 1).round().astype(int)
+        c_edges = np.linspace(b, W - b, gw + 1).round().astype(int)
+        k = 0
+        for i in range(gh):
+            for j in range(gw):
+                r0, r1 = max(r_edges[i] - overlap, 0), min(r_edges[i + 1] + overlap, H)
+                c0, c1 = max(c_edges[j] - overlap, 0), min(c_edges[j + 1] + overlap, W)
+                masks[k, r0:r1, c0:c1] = True
+                kp_rc[k] = ((r_edges[i] + r_edges[i + 1]) // 2, (c_edges[j] + c_edges[j + 1]) // 2)
+                k += 1
+    elif shape == "blobs":
+        for k in range(N):
+            cr, cc = rng.uniform(0.1 * H, 0.9 * H), rng.uniform(0.1 * W, 0.9 * W)
+            ar, ac = rng.uniform(0.08 * H, 0.3 * H), rng.uniform(0.08 * W, 0.3 * W)
+            ang = rng.uniform(0, math.pi)
+            dr, dc = rows - cr, cols - cc
+            a = (dc * math.cos(ang) + dr * math.sin(ang)) / ac
+            bb = (-dc * math.sin(ang) + dr * math.cos(ang)) / ar
+            masks[k] = (a * a + bb * bb) <= 1.0
+            kp_rc[k] = (int(round(cr)), int(round(cc)))
+            kp_rc[k, 0] = min(max(kp_rc[k, 0], 0), H - 1)
+            kp_rc[k, 1] = min(max(kp_rc[k, 1], 0), W - 1)
+            masks[k, kp_rc[k, 0], kp_rc[k, 1]] = True
+    else:
+        raise ValueError(shape)
+
+    logD = np.log(depth)
+    offs = rng.uniform(-0.7, 0.7, N)     # per-segment unknown scale of the integrated depth
+    L = (logD[None] - offs[:, None, None]) * masks
+    keypoints = np.stack([2.0 * kp_rc[:, 0] / (H - 1) - 1.0, 2.0 * kp_rc[:, 1] / (W - 1) - 1.0], 1)
+    kld_gt = logD[kp_rc[:, 0], kp_rc[:, 1]]
+    kld_init = np.log(2.0 + 2.0 * rng.uniform(size=N))      # odometery/two_frame_sfm.py:103-105
+    T_init = se3_exp_np(init_sigma * rng.standard_normal(6)) @ T_gt
+
+    f32 = np.float32
+    return SynthPair(
+        H=H, W=W, N=N, K=K.astype(f32),
+        src_image=src_image.astype(f32), trg_image=trg_image.astype(f32),
+        depth=depth.astype(f32), logdepth_perseg=L.astype(f32),
+        keypoints=keypoints.astype(f32), keypoint_regions=masks,
+        kld_gt=kld_gt.astype(f32), kld_init=kld_init.astype(f32),
+        pose_gt=T_gt.astype(f32), pose_init=T_init.astype(f32),
+        meta=dict(seed=seed, shape=shape, overlap=overlap, xi_gt=xi_gt, kp_rc=kp_rc),
+    )

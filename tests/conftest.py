@@ -1,0 +1,29 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def unpack_masks(g):
+    H, W, N = (int(v) for v in g["in_HWN"])
+    return np.unpackbits(g["in_masks"], axis=-1, count=W).astype(bool).reshape(N, H, W)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
