@@ -79,12 +79,14 @@ def pair_inputs(pair):
                 in_masks=np.packbits(pair.keypoint_regions, axis=-1), in_HWN=np.array([pair.H, pair.W, pair.N]))
 
 
-def big_rotation_pose(pair, frac):
-    """Camera pushed forward through the slanted plane: part of the points end up behind the target
-    camera (z' < 0), part project outside the frame, the rest stay valid."""
-    zcut = float(pair.depth.min() + frac * (pair.depth.max() - pair.depth.min()))
-    xi = np.array([0.02, -0.01, -zcut, 0.0, 0.05, 0.0])
-    return synth.se3_exp_np(xi).astype(np.float32)
+def big_rotation_pose(pair, pitch):
+    """Target camera pitched by ~80 degrees: part of the points end up behind it (z' < 0), part project
+    outside the frame, the rest stay valid (696 / 2376 / 480 of 3072 for the committed case)."""
+    T = np.eye(4, dtype=np.float32)
+    c, s = np.cos(pitch), np.sin(pitch)
+    T[:3, :3] = [[1, 0, 0], [0, c, -s], [0, s, c]]
+    T[:3, 3] = [0.05, 2.6, 0.3]
+    return T
 
 
 # ----------------------------------------------------------------------------
@@ -396,7 +398,7 @@ def main():
     golden_cost(ref, "g1_pyramid_72x96", p, p.pose_init, levels=(0, 3))
 
     p = synth.make_pair(48, 64, 6, seed=4)
-    golden_cost(ref, "g1_behind_camera_48x64", p, big_rotation_pose(p, 0.3))
+    golden_cost(ref, "g1_behind_camera_48x64", p, big_rotation_pose(p, 1.4))
 
     p = synth.make_pair(45, 67, 5, seed=5, drop_border=2)
     golden_cost(ref, "g1_odd_45x67", p, p.pose_init, levels=(1, 3),
