@@ -1,0 +1,199 @@
+/*
+ * sp_hip.h -- C ABI of libsp_hip.so: the MI355X (gfx950) implementation of SuperPrimitive's
+ * per-segment photometric pose-and-depth optimisation hot path.
+ *
+ * The reference (makezur/super_primitive) is 100 % Python: the interface this library sits behind is a set
+ * of module-level Python functions, not an FFI.  Each entry point below names the reference function(s)
+ * whose arithmetic it replaces (paths relative to the reference tree); the Python wrappers in
+ * super_primitive_amd/ keep those functions' names and signatures and call these symbols through ctypes.
+ * INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless it says "host";
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); nothing here synchronises the host;
+ *   - every function returns 0 on success, a hipError_t (>0) from the runtime, or a negative SP_E* code;
+ *   - all arithmetic is fp32 (fp64 only inside the small per-pair finalise / solve kernels);
+ *   - the library allocates nothing: workspaces are caller-owned (sizes via sp_*_workspace_floats()).
+ *
+ * Data layout of a compacted source keyframe ("segment table", built once per keyframe):
+ *   pix[P]      uint32  bit31 = source-pixel validity, bits 30..16 = row, bits 15..0 = col; points ordered
+ *                       (segment, row, col) exactly like torch.where(keypoint_regions) in
+ *                       core/dense_optim.py:103
+ *   seg_off[N+1] int32  CSR offsets of the segments into pix / src4
+ *   src4[P]     float4  {I_src.r, I_src.g, I_src.b, L}: the source image of ONE pyramid level sampled at the
+ *                       point's own pixel (core/dense_optim.py:315-317) and the base log-depth
+ *                       logdepth_perseg[n,row,col]
+ *   kp_L[N]     float   logdepth_perseg[n, kp_row, kp_col] (core/dense_optim.py:51-64)
+ *   tiles[T]    int32x4 {pair, segment, first point, point count}; a tile never straddles two segments
+ *   seg_tile_off[N+1]   CSR offsets of the segments into tiles
+ * Target images are packed HWC4 (r,g,b,0) per pyramid level so one bilinear tap is one 16-byte load.
+ */
+#ifndef SP_HIP_H
+#define SP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_ABI_VERSION 1
+
+#define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
+#define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
+
+/* number of floats one tile writes in each mode (partials workspace = n_tiles * B * this) */
+#define SP_GRAD_PARTIAL_FLOATS 16
+#define SP_GN_PARTIAL_FLOATS   40
+
+int sp_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Segment table construction (replaces the per-iteration torch.where / dense (N,H,W) passes of
+ * core/dense_optim.py:38-114 by a once-per-keyframe compaction).
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Pass 1: row_counts[N*H] = exclusive per-segment scan of the per-row mask counts (scratch kept for pass 2),
+ * counts[N] = pixels per segment, seg_off[N+1] = exclusive scan of counts (seg_off[N] = P, which the host
+ * reads once to size the table).  masks: N*H*W bytes (torch.bool). */
+int sp_mask_count(const uint8_t* masks, int N, int H, int W, int32_t* row_counts, int32_t* counts,
+                  int32_t* seg_off, void* stream);
+
+/* Pass 2: fill pix (row/col, validity bit cleared), base log-depth baseL[P] and kp_L[N].  row_off = the
+ * row_counts array produced by sp_mask_count.  keypoints: (N,2) normalised (row,col) as in
+ * image/keyframe.py:20-75; the keypoint pixel is round_half_even(0.5*(dim-1)*(kp+1))
+ * (tool/point_utils.py:37-40).  Order inside a segment is row-major, like torch.where. */
+int sp_table_fill(const uint8_t* masks, const float* logdepth, const float* keypoints, int N, int H, int W,
+                  const int32_t* seg_off, const int32_t* row_off, uint32_t* pix, float* baseL, float* kp_L,
+                  void* stream);
+
+/* Sample one source pyramid level at every table point and pack {rgb, L}; also (re)computes the source
+ * validity bit of pix with the reference's formula (core/dense_optim.py:143-162 applied to the source
+ * frame, :315-317).  img: planar (3,Hl,Wl) f32.  K: 9 floats row-major. */
+int sp_table_sample_source(uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                           const float* kld, int N, int P, int H, int W, const float* img, int Hl, int Wl,
+                           const float* K, float* src4, void* stream);
+
+/* planar (B,3,H,W) f32 -> packed (B,H,W,4) f32 */
+int sp_pack_rgba(const float* chw, int B, int H, int W, float* hwc4, void* stream);
+
+/* One pyramid step of image/gaussian_pyramid.py:53-85: reflect-pad 1, 3x3 binomial /16, keep even rows and
+ * columns.  in: planar (C,H,W); out: planar (C,ceil(H/2),ceil(W/2)). */
+int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * The cost: one source keyframe against B target frames (B = 1: core/dense_optim.py:265-363
+ * photomeric_cost and :365-403 photomeric_cost_precomputed; B >= 1: core/dense_optim_batch.py:50-147).
+ * One fused pass computes residual[b] = mean_{ch,pt} |(I_src - I_trg')*mask| AND its first-order information.
+ *
+ *   mode 0 (gradient): d residual[b] / d {kld (N), pose rows 0..2 (3x4), affine (a_s,b_s,a_t,b_t)}
+ *                      -- what autograd produces in the reference's Adam loops;
+ *   mode 1 (Gauss-Newton): IRLS-weighted normal equations of the same residuals over the left SE(3) tangent
+ *                      [tau,phi] and the per-segment log-depths (arrow structure); see sp_gn_* below.
+ *
+ * K_src: 9 floats. K_trg: B*9. pose: B*16 row-major (target <- source). aff_src: 2 floats or NULL,
+ * aff_trg: B*2 or NULL (both or neither).  zmin: 1e-7 for the single-target functions, 1e-6 for the batch
+ * function (dense_optim.py:146 vs dense_optim_batch.py:15).
+ * Outputs (mode 0): residual[B], g_kld[B*N], g_pose[B*16] (row 3 = 0), g_aff[B*4].
+ * ---------------------------------------------------------------------------------------------------- */
+int sp_photo_cost_grad(const uint32_t* pix, const float* src4, const int32_t* seg_off, const float* kp_L,
+                       const int32_t* tiles, const int32_t* seg_tile_off, int n_tiles, int N, int P, int H, int W,
+                       const float* K_src, const float* kld, const float* trg4, int Hl, int Wl,
+                       const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
+                       float zmin, float* workspace, float* residual, float* g_kld, float* g_pose, float* g_aff,
+                       void* stream);
+
+/* Per-point diagnostics of the same pass (collect_stats > 0 in the reference, core/dense_optim.py:347-361).
+ * Any output pointer may be NULL.  Shapes: src_pts (P,3); trg_pts (B,P,3); src_rgb (3,P); trg_rgb (B,3,P)
+ * after brightness compensation; raw (B,3,P) = (I_src - I_trg')*mask; src_valid (P) u8; trg_valid (B,P) u8;
+ * seg_ids (P) int64. */
+int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_off, const float* kp_L, int N, int P,
+                   int H, int W, const float* K_src, const float* kld, const float* trg4, int Hl, int Wl,
+                   const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
+                   float zmin, float* src_pts, float* trg_pts, float* src_rgb, float* trg_rgb, float* raw,
+                   uint8_t* src_valid, uint8_t* trg_valid, int64_t* seg_ids, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Many independent frame pairs per launch (BASELINE.json configs 2 and 5; the throughput path).  Each pair
+ * has its own segment table, target image, intrinsics, pose and log-depths, described by one SpPair record
+ * in device memory; tiles[].x selects the pair.  No host synchronisation anywhere: one optimiser iteration
+ * is sp_pairs_cost + one sp_pairs_*_step launch and can be captured in a hipGraph.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct SpPair {
+    const uint32_t* pix;      /* [P] */
+    const float*    src4;     /* [P*4] for the level being optimised */
+    const float*    kp_L;     /* [N] */
+    const float*    trg4;     /* [Hl*Wl*4] for the level being optimised */
+    float*          kld;      /* [N]  optimisation variable */
+    float*          pose;     /* [16] optimisation variable (target <- source) */
+    float*          aff;      /* [4]  {a_s,b_s,a_t,b_t} or NULL */
+    const int32_t*  seg_tile_off; /* [N+1] offsets into this pair's tiles, relative to tile0 */
+    float K_src[4];           /* fx fy cx cy */
+    float K_trg[4];
+    int32_t N, P, H, W, Hl, Wl;
+    int32_t tile0;            /* first tile of this pair in the global tile array */
+    int32_t n_tiles;
+    float zmin;
+    int32_t pad_;
+} SpPair;
+
+/* mode 0 / 1 as above.  partials: n_tiles * (SP_GRAD_PARTIAL_FLOATS | SP_GN_PARTIAL_FLOATS) floats. */
+int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int mode, float irls_eps,
+                  float* partials, void* stream);
+
+/* Adam step on {kld, left SE(3) tangent, affine} of every pair from the mode-0 partials: reduces the tile
+ * partials (fixed order, fp64), loss = |residual| like odometery/two_frame_sfm.py:201-206, maps d/dpose to the
+ * tangent of Exp(a)*T, applies torch.optim.Adam semantics (betas 0.9/0.999, eps 1e-8, bias correction) with
+ * per-group learning rates, retracts pose <- Exp(step)*pose.  state: per pair (2*(N+6+2)+2) floats, zeroed
+ * by the caller before the first step.  losses: [n_pairs] written every step. */
+int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, float lr_kld,
+                       float lr_pose, float lr_aff, float* state, float* losses, void* stream);
+
+/* Gauss-Newton / Levenberg-Marquardt step from the mode-1 partials: per pair, reduce tiles, eliminate the
+ * N diagonal log-depth unknowns (Schur complement onto the 6x6 pose block), solve in fp64, update
+ * pose <- Exp(delta)*pose and kld += delta_d.  lm_state: per pair SP_LM_STATE_FLOATS floats {lambda, cost of
+ * the last accepted point (init -1), n accepted, n rejected, rejected-last-call flag, last cost seen, 0, 0};
+ * lambda adapts on device (cost up -> step undone from the backup, lambda*=lm_up, re-evaluated next call;
+ * cost down -> lambda = max(lambda*lm_down, lm_min)).  backup: per pair (16+max_N) floats.  costs: [n_pairs]. */
+#define SP_LM_STATE_FLOATS 8
+int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, float lm_up,
+                     float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Helpers around the path
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* Dense (N,H,W) seeded depths.  log_space = 1: (L + shift_n) * mask  (core/dense_optim.py:38-80
+ * infer_depth_seeds);  log_space = 0: exp of that  (core/dense_optim.py:164-174 unproject_kf_to_depths). */
+int sp_depth_expand(const uint8_t* masks, const float* logdepth, const float* keypoints, const float* kld, int N,
+                    int H, int W, int log_space, float* out, void* stream);
+
+/* core/ops.py:59-96 estimate_depth_diff (mean=False) on table points moved by pose: last-writer-wins z splat
+ * at truncated (v,u); ties resolved by highest point index (deterministic, one of the orders the reference's
+ * scatter_ may produce).  out: (H,W) zero-initialised by this call.  keys: H*W uint64 scratch. */
+int sp_depth_splat(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                   const float* kld, int N, int P, int H, int W, const float* K, const float* pose,
+                   unsigned long long* keys, float* out, void* stream);
+
+/* odometery/depth_init.py:10-67 segment_based_depth_reinit.  mode 0 = mean, 1 = median (lower middle for
+ * even counts, like torch.median).  est_depth (H,W).  scratch: P floats.  out_kld[N], out_visible[N] u8.
+ * Invisible segments receive the (lower) median of the visible segments' values. */
+int sp_segment_reinit(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L, int N,
+                      int P, int H, int W, const float* est_depth, int mode, float* scratch, float* out_kld,
+                      uint8_t* out_visible, void* stream);
+
+/* depth_completion/segment_based_completion.py:21-27 render_depth_avg fused with the expansion and the
+ * visible-segment filter: per-pixel mean over covering visible segments of exp(L + shift_n)
+ * (visible may be NULL = all).  out_depth (H,W), out_invalid (H,W) u8.  acc: 12*H*W bytes of scratch
+ * (32.32 fixed-point sums + counts: the accumulation is order-independent, hence reproducible). */
+int sp_depth_average(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                     const float* kld, const uint8_t* visible, int N, int P, int H, int W, void* acc,
+                     float* out_depth, uint8_t* out_invalid, void* stream);
+
+/* lie/lie_algebra.py:41-47 renormalise_se3 on n row-major 4x4 matrices, in place. */
+int sp_renormalise_se3(float* T, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SP_HIP_H */

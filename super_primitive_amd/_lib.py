@@ -1,0 +1,105 @@
+"""ctypes binding of libsp_hip.so (the C ABI declared in include/sp_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C super_primitive_amd/csrc``.  There is
+no fallback: if the shared object is missing or a symbol cannot be resolved, importing a compute entry point
+raises -- the product path never routes through a CPU or pure-PyTorch implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsp_hip.so")
+
+P = c_void_p
+I = c_int
+F = c_float
+
+# name -> argtypes (restype is always int); mirrors include/sp_hip.h one to one
+SIGNATURES = {
+    "sp_abi_version": [],
+    "sp_mask_count": [P, I, I, I, P, P, P, P],
+    "sp_table_fill": [P, P, P, I, I, I, P, P, P, P, P, P],
+    "sp_table_sample_source": [P, P, P, P, P, I, I, I, I, P, I, I, P, P, P],
+    "sp_pack_rgba": [P, I, I, I, P, P],
+    "sp_blur_decimate": [P, I, I, I, P, P],
+    "sp_photo_cost_grad": [P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P],
+    "sp_photo_stats": [P, P, P, P, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P, P, P, P],
+    "sp_pairs_cost": [P, P, I, I, F, P, P],
+    "sp_pairs_adam_step": [P, I, I, P, F, F, F, P, P, P],
+    "sp_pairs_gn_step": [P, I, I, P, F, F, F, P, P, P, P],
+    "sp_depth_expand": [P, P, P, P, I, I, I, I, P, P],
+    "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
+    "sp_segment_reinit": [P, P, P, P, I, I, I, I, P, I, P, P, P, P],
+    "sp_depth_average": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],
+    "sp_renormalise_se3": [P, I, P],
+}
+
+SP_ABI_VERSION = 1
+SP_GRAD_PARTIAL_FLOATS = 16
+SP_GN_PARTIAL_FLOATS = 40
+SP_LM_STATE_FLOATS = 8
+
+
+class SpPair(ctypes.Structure):
+    """Mirror of ``struct SpPair`` (include/sp_hip.h); 128 bytes."""
+    _fields_ = [
+        ("pix", c_void_p), ("src4", c_void_p), ("kp_L", c_void_p), ("trg4", c_void_p),
+        ("kld", c_void_p), ("pose", c_void_p), ("aff", c_void_p), ("seg_tile_off", c_void_p),
+        ("K_src", c_float * 4), ("K_trg", c_float * 4),
+        ("N", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("Hl", c_int), ("Wl", c_int),
+        ("tile0", c_int), ("n_tiles", c_int), ("zmin", c_float), ("pad_", c_int),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load (once) and type the library.  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU / PyTorch fallback for the hot path.")
+    try:
+        import torch  # noqa: F401  -- make sure torch's HIP runtime (libamdhip64.so.7) is the one already mapped
+    except Exception:  # pragma: no cover - torch is a hard dependency of the package anyway
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header / library mismatch: fail loudly
+        fn.argtypes = args
+        fn.restype = c_int
+    if lib.sp_abi_version() != SP_ABI_VERSION:
+        raise RuntimeError("libsp_hip.so ABI version mismatch; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "SP_EINVAL (bad argument)", -2: "SP_ELIMIT (size not supported)"}.get(rc, f"hipError_t {rc}")
+        raise RuntimeError(f"{what} failed: {kind}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_device(*tensors):
+    """The hot path runs on the GPU only; refuse host tensors instead of silently computing elsewhere."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("super_primitive_amd: the photometric hot path is HIP-only; got a CPU tensor. "
+                               "Move the keyframe to a cuda device (no CPU fallback exists).")

@@ -1,0 +1,291 @@
+// Helpers either side of the cost pass: dense depth expansion (VOID path), depth splat render (keyframe
+// decision / new-keyframe init), per-segment mean/median log-depth re-initialisation, per-pixel depth average.
+#include "sp_device.h"
+
+namespace {
+
+__device__ __forceinline__ int segment_of(const int32_t* __restrict__ seg_off, int N, int i) {
+    int lo = 0, hi = N;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_off[mid] <= i) lo = mid; else hi = mid; }
+    while (lo + 1 < N && seg_off[lo + 1] <= i) ++lo;
+    return lo;
+}
+
+__device__ __forceinline__ float keypoint_L(const float* __restrict__ logdepth, const float* __restrict__ keypoints,
+                                            int n, int H, int W) {
+    int r = (int)rintf(0.5f * (float)(H - 1) * (keypoints[2 * n] + 1.f));
+    int c = (int)rintf(0.5f * (float)(W - 1) * (keypoints[2 * n + 1] + 1.f));
+    if (r < 0) r += H;
+    if (c < 0) c += W;
+    r = min(max(r, 0), H - 1);
+    c = min(max(c, 0), W - 1);
+    return logdepth[((size_t)n * H + r) * W + c];
+}
+
+// core/dense_optim.py:38-86,164-174: out = exp((L + (kld[n] - L[n,kp])) * mask), dense
+__global__ __launch_bounds__(SP_BLOCK) void k_depth_expand(const uint8_t* __restrict__ masks, const float* __restrict__ logdepth,
+                                                           const float* __restrict__ keypoints, const float* __restrict__ kld,
+                                                           int H, int W, int log_space, float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int HW = H * W;
+    const float shift = kld[n] - keypoint_L(logdepth, keypoints, n, H, W);
+    const size_t base = (size_t)n * HW;
+    for (int i = blockIdx.x * SP_BLOCK + threadIdx.x; i < HW; i += gridDim.x * SP_BLOCK) {
+        const float m = masks[base + i] ? 1.f : 0.f;
+        const float l = (logdepth[base + i] + shift) * m;
+        out[base + i] = log_space ? l : expf(l);
+    }
+}
+
+// table point -> source-camera 3-D point
+__device__ __forceinline__ void table_point(const uint32_t* __restrict__ pix, const float* __restrict__ baseL,
+                                            const int32_t* __restrict__ seg_off, const float* __restrict__ kp_L,
+                                            const float* __restrict__ kld, int N, int i, const float* __restrict__ K9,
+                                            float& x, float& y, float& d, int& n) {
+    n = segment_of(seg_off, N, i);
+    const uint32_t pw = pix[i] & 0x7fffffffu;
+    const float col = (float)(pw & 0xffffu), row = (float)(pw >> 16);
+    d = expf(baseL[i] + (kld[n] - kp_L[n]));
+    x = __fdiv_rn(__fmul_rn(col - K9[2], d), K9[0]);
+    y = __fdiv_rn(__fmul_rn(row - K9[5], d), K9[4]);
+}
+
+// core/ops.py:59-96 (mean=False): key = (point index + 1) << 32 | z bits, atomicMax => highest index wins,
+// i.e. the result of a sequential scatter_
+__global__ __launch_bounds__(SP_BLOCK) void k_splat_keys(const uint32_t* __restrict__ pix, const float* __restrict__ baseL,
+                                                         const int32_t* __restrict__ seg_off, const float* __restrict__ kp_L,
+                                                         const float* __restrict__ kld, int N, int P, int H, int W,
+                                                         const float* __restrict__ K9, const float* __restrict__ T16,
+                                                         unsigned long long* __restrict__ keys) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    float x, y, d; int n;
+    table_point(pix, baseL, seg_off, kp_L, kld, N, i, K9, x, y, d, n);
+    const float qx = fmaf(T16[0], x, fmaf(T16[1], y, T16[2] * d)) + T16[3];
+    const float qy = fmaf(T16[4], x, fmaf(T16[5], y, T16[6] * d)) + T16[7];
+    const float qz = fmaf(T16[8], x, fmaf(T16[9], y, T16[10] * d)) + T16[11];
+    const float zinv = (fabsf(qz) > 1e-6f) ? __fdiv_rn(1.0f, qz) : 1e-6f;
+    const float u = qx * K9[0] * zinv + K9[2];
+    const float v = qy * K9[4] * zinv + K9[5];
+    if (!(qz > 1e-6f) || !isfinite(u) || !isfinite(v)) return;
+    if (fabsf(u) > 1e9f || fabsf(v) > 1e9f) return;
+    const long long c = (long long)u, r = (long long)v;   // truncation toward zero, like .long()
+    if (r < 0 || r >= H || c < 0 || c >= W) return;
+    const unsigned long long key = ((unsigned long long)(i + 1) << 32) | (unsigned long long)__float_as_uint(qz);
+    atomicMax(&keys[(size_t)r * W + c], key);
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_splat_decode(const unsigned long long* __restrict__ keys, int HW,
+                                                           float* __restrict__ out) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= HW) return;
+    const unsigned long long k = keys[i];
+    out[i] = k ? __uint_as_float((uint32_t)(k & 0xffffffffull)) : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// odometery/depth_init.py:10-67
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t orderable(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_orderable(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// k-th smallest (0-based) of vals[0..cnt) by 4 x 8-bit radix select; whole block cooperates
+__device__ float block_select(const float* __restrict__ vals, int cnt, int k, uint32_t* hist /* 256 */) {
+    uint32_t prefix = 0, mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int b = threadIdx.x; b < 256; b += SP_BLOCK) hist[b] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += SP_BLOCK) {
+            const uint32_t key = orderable(vals[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+        }
+        __syncthreads();
+        __shared__ uint32_t chosen, remaining;
+        if (threadIdx.x == 0) {
+            uint32_t run = 0; int b = 0;
+            for (; b < 256; ++b) { if (run + hist[b] > (uint32_t)k) break; run += hist[b]; }
+            chosen = (uint32_t)b; remaining = (uint32_t)k - run;
+        }
+        __syncthreads();
+        prefix |= chosen << shift;
+        mask |= 0xffu << shift;
+        k = (int)remaining;
+        __syncthreads();
+    }
+    return from_orderable(prefix);
+}
+
+// one block per segment
+__global__ __launch_bounds__(SP_BLOCK) void k_segment_reinit(const uint32_t* __restrict__ pix, const float* __restrict__ baseL,
+                                                             const int32_t* __restrict__ seg_off, const float* __restrict__ kp_L,
+                                                             int W, const float* __restrict__ est, int mode,
+                                                             float* __restrict__ scratch, float* __restrict__ out_val,
+                                                             uint8_t* __restrict__ out_visible) {
+    __shared__ uint32_t hist[256];
+    __shared__ int cursor;
+    __shared__ double wsum[SP_WAVES];
+    const int n = blockIdx.x;
+    const int s0 = seg_off[n], s1 = seg_off[n + 1];
+    float* vals = scratch + s0;
+    if (threadIdx.x == 0) cursor = 0;
+    __syncthreads();
+    double sum = 0.0;
+    // compaction order does not matter for mean/median
+    for (int i = s0 + threadIdx.x; i < s1; i += SP_BLOCK) {
+        const uint32_t pw = pix[i] & 0x7fffffffu;
+        const float e = est[(size_t)(pw >> 16) * W + (pw & 0xffffu)];
+        if (!(e < 1e-6f)) {
+            const float v = logf(e) - baseL[i];
+            vals[atomicAdd(&cursor, 1)] = v;
+            sum += (double)v;
+        }
+    }
+    __syncthreads();
+    const int cnt = cursor;
+    if (cnt == 0) {
+        if (threadIdx.x == 0) { out_visible[n] = 0; out_val[n] = 0.f; }
+        return;
+    }
+    float res;
+    if (mode == 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+        __syncthreads();
+        double t = 0.0;
+        for (int w = 0; w < SP_WAVES; ++w) t += wsum[w];
+        res = (float)(t / (double)cnt);
+    } else {
+        __threadfence_block();
+        res = block_select(vals, cnt, (cnt - 1) / 2, hist);   // lower middle, like torch.median
+    }
+    if (threadIdx.x == 0) { out_visible[n] = 1; out_val[n] = res + kp_L[n]; }
+}
+
+// invisible segments <- lower median of the visible segments' values (single block, rank counting)
+__global__ __launch_bounds__(SP_BLOCK) void k_fill_invisible(float* __restrict__ val, const uint8_t* __restrict__ visible, int N) {
+    __shared__ int nvis;
+    __shared__ float med;
+    if (threadIdx.x == 0) { nvis = 0; med = 0.f; }
+    __syncthreads();
+    int c = 0;
+    for (int n = threadIdx.x; n < N; n += SP_BLOCK) c += visible[n] != 0;
+    atomicAdd(&nvis, c);
+    __syncthreads();
+    if (nvis == 0 || nvis == N) return;
+    const int k = (nvis - 1) / 2;
+    for (int n = threadIdx.x; n < N; n += SP_BLOCK) {
+        if (!visible[n]) continue;
+        const float v = val[n];
+        int rank = 0;
+        for (int j = 0; j < N; ++j)
+            if (visible[j]) rank += (val[j] < v) || (val[j] == v && j < n);
+        if (rank == k) med = v;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < N; n += SP_BLOCK)
+        if (!visible[n]) val[n] = med;
+}
+
+// depth_completion/segment_based_completion.py:21-27 + :45-52, fused: 32.32 fixed-point sums make the
+// per-pixel accumulation order-independent (bitwise reproducible) and more accurate than fp32 adds
+__global__ __launch_bounds__(SP_BLOCK) void k_average_scatter(const uint32_t* __restrict__ pix, const float* __restrict__ baseL,
+                                                              const int32_t* __restrict__ seg_off, const float* __restrict__ kp_L,
+                                                              const float* __restrict__ kld, const uint8_t* __restrict__ visible,
+                                                              int N, int P, int W, unsigned long long* __restrict__ sums,
+                                                              uint32_t* __restrict__ counts) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const int n = segment_of(seg_off, N, i);
+    if (visible && !visible[n]) return;
+    const float d = expf(baseL[i] + (kld[n] - kp_L[n]));
+    if (!(d > 1e-6f)) return;
+    const uint32_t pw = pix[i] & 0x7fffffffu;
+    const size_t o = (size_t)(pw >> 16) * W + (pw & 0xffffu);
+    atomicAdd(&sums[o], (unsigned long long)((double)d * 4294967296.0));
+    atomicAdd(&counts[o], 1u);
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_average_finish(const unsigned long long* __restrict__ sums,
+                                                             const uint32_t* __restrict__ counts, int HW,
+                                                             float* __restrict__ out, uint8_t* __restrict__ invalid) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= HW) return;
+    const float total = (float)((double)sums[i] * (1.0 / 4294967296.0));
+    const uint32_t c = counts[i];
+    out[i] = total / ((float)c + 1e-6f);
+    invalid[i] = c == 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sp_depth_expand(const uint8_t* masks, const float* logdepth, const float* keypoints, const float* kld, int N,
+                    int H, int W, int log_space, float* out, void* stream) {
+    if (!masks || !logdepth || !keypoints || !kld || !out || N <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
+    const int HW = H * W;
+    int gx = (HW + SP_BLOCK - 1) / SP_BLOCK;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_depth_expand, dim3(gx, N), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), masks, logdepth,
+                       keypoints, kld, H, W, log_space, out);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_depth_splat(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                   const float* kld, int N, int P, int H, int W, const float* K, const float* pose,
+                   unsigned long long* keys, float* out, void* stream) {
+    if (!pix || !baseL || !seg_off || !kp_L || !kld || !K || !pose || !keys || !out) return SP_EINVAL;
+    if (N <= 0 || P <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)H * W, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_splat_keys, dim3((P + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0, s, pix, baseL, seg_off, kp_L,
+                       kld, N, P, H, W, K, pose, keys);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_splat_decode, dim3((H * W + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0, s, keys, H * W, out);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_segment_reinit(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L, int N,
+                      int P, int H, int W, const float* est_depth, int mode, float* scratch, float* out_kld,
+                      uint8_t* out_visible, void* stream) {
+    if (!pix || !baseL || !seg_off || !kp_L || !est_depth || !scratch || !out_kld || !out_visible) return SP_EINVAL;
+    if (N <= 0 || P <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_segment_reinit, dim3(N), dim3(SP_BLOCK), 0, s, pix, baseL, seg_off, kp_L, W, est_depth, mode,
+                       scratch, out_kld, out_visible);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_fill_invisible, dim3(1), dim3(SP_BLOCK), 0, s, out_kld, out_visible, N);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_depth_average(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                     const float* kld, const uint8_t* visible, int N, int P, int H, int W, void* acc,
+                     float* out_depth, uint8_t* out_invalid, void* stream) {
+    if (!pix || !baseL || !seg_off || !kp_L || !kld || !acc || !out_depth || !out_invalid) return SP_EINVAL;
+    if (N <= 0 || P <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t HW = (size_t)H * W;
+    hipError_t e = hipMemsetAsync(acc, 0, 12 * HW, s);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long* sums = static_cast<unsigned long long*>(acc);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(sums + HW);
+    hipLaunchKernelGGL(k_average_scatter, dim3((P + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0, s, pix, baseL, seg_off,
+                       kp_L, kld, visible, N, P, W, sums, counts);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_average_finish, dim3((unsigned)((HW + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), 0, s, sums, counts,
+                       (int)HW, out_depth, out_invalid);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,156 @@
+// Device-side building blocks shared by the libsp_hip.so kernels (gfx950 / CDNA4 only).
+// Numeric conventions are the reference's; each helper cites the lines it restates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sp_hip.h"
+
+#define SP_BLOCK 256            // 4 wavefronts of 64
+#define SP_WAVES (SP_BLOCK / 64)
+
+#define SP_CHECK_LAUNCH()                          \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// wave64 / block reductions (fixed order -> bitwise reproducible run to run)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Reduce NV per-thread accumulators over the block; thread k < NV ends up holding the total of value k.
+template <int NV>
+__device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* lds /* SP_WAVES*NV floats */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float s = wave_sum(acc[k]);
+        if (lane == 0) lds[wave * NV + k] = s;
+    }
+    __syncthreads();
+    float total = 0.f;
+    if (threadIdx.x < NV) {
+#pragma unroll
+        for (int w = 0; w < SP_WAVES; ++w) total += lds[w * NV + threadIdx.x];
+    }
+    return total;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// XCD-aware tile order: the dispatcher places block b on XCD b % 8 (MI355X_MICROARCH.md, observed, used for
+// speed only).  Give every XCD one contiguous chunk of the tile list so that the tiles of one frame pair --
+// which gather from the same target image -- share a single XCD's L2 instead of pulling that image into
+// all eight.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_chunked_tile(int b, int n) {
+    const int per = (n + 7) >> 3;
+    const int t = (b & 7) * per + (b >> 3);
+    return t;  // caller checks t < n
+}
+
+// ---------------------------------------------------------------------------------------------------
+// geometry of one table point
+// ---------------------------------------------------------------------------------------------------
+struct Cam {
+    float fx, fy, cx, cy;
+};
+
+struct PointGeom {
+    float px, py, pz;   // point in the source camera
+    float qx, qy, qz;   // point in the target camera
+    float zinv;         // guarded 1/qz
+    bool  zguard;       // |qz| > 1e-6 (gradient flows through 1/z only then, core/ops.py:33-34)
+    float ix, iy;       // sampling position in LEVEL pixels
+    bool  valid;        // target validity & source validity
+};
+
+// pix word: bit31 source validity, bits 30..16 row, bits 15..0 col
+__device__ __forceinline__ void decode_pix(uint32_t w, float& col, float& row, bool& src_ok) {
+    col = (float)(w & 0xffffu);
+    row = (float)((w >> 16) & 0x7fffu);
+    src_ok = (w >> 31) != 0u;
+}
+
+// core/dense_optim.py:19-35 with the depth of :38-86:  d = exp(L + (kld[n] - L[n,kp])).
+__device__ __forceinline__ void backproject(float col, float row, float d, const Cam& K, float ifx, float ify,
+                                            float& x, float& y) {
+    x = ((col - K.cx) * d) * ifx;
+    y = ((row - K.cy) * d) * ify;
+}
+
+struct Warp {
+    float R[9], t[3];
+    Cam Kt;
+    float invWm1, invHm1;   // 1/(W-1), 1/(H-1) of the GEOMETRY grid
+    float sx, sy;           // 0.5*(Wl-1), 0.5*(Hl-1)
+    float zmin;
+};
+
+// core/dense_optim.py:117-122 (rigid), core/ops.py:19-40 (guarded projection), tool/point_utils.py:31-35
+// (normalise with geometry dims), core/dense_optim.py:128-130,146,160 (validity), grid_sample's
+// align_corners un-normalisation ((x+1)/2*(size-1)).
+__device__ __forceinline__ void warp_point(const Warp& w, float px, float py, float pz, PointGeom& g) {
+    g.px = px; g.py = py; g.pz = pz;
+    g.qx = fmaf(w.R[0], px, fmaf(w.R[1], py, w.R[2] * pz)) + w.t[0];
+    g.qy = fmaf(w.R[3], px, fmaf(w.R[4], py, w.R[5] * pz)) + w.t[1];
+    g.qz = fmaf(w.R[6], px, fmaf(w.R[7], py, w.R[8] * pz)) + w.t[2];
+    g.zguard = fabsf(g.qz) > 1e-6f;
+    g.zinv = g.zguard ? __builtin_amdgcn_rcpf(g.qz) : 1e-6f;
+    const float u = g.qx * w.Kt.fx * g.zinv + w.Kt.cx;
+    const float v = g.qy * w.Kt.fy * g.zinv + w.Kt.cy;
+    const float xn = 2.f * u * w.invWm1 - 1.f;
+    const float yn = 2.f * v * w.invHm1 - 1.f;
+    g.valid = (fabsf(xn) <= 0.99f) && (fabsf(yn) <= 0.99f) && (g.qz > w.zmin);
+    g.ix = (xn + 1.f) * w.sx;
+    g.iy = (yn + 1.f) * w.sy;
+}
+
+// One bilinear footprint of a packed HWC4 image.  Taps outside the image are zero (grid_sample
+// padding_mode='zeros'); for valid points (0.99 band) all four taps are inside whenever Wl,Hl >= 2.
+struct Taps {
+    float4 t00, t10, t01, t11;
+    float wx, wy;
+};
+
+__device__ __forceinline__ void fetch_taps(const float4* __restrict__ img, int Wl, int Hl, float ix, float iy,
+                                           Taps& tp) {
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    tp.wx = ix - fx0;
+    tp.wy = iy - fy0;
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool inx0 = (x0 >= 0) & (x0 < Wl), inx1 = (x1 >= 0) & (x1 < Wl);
+    const bool iny0 = (y0 >= 0) & (y0 < Hl), iny1 = (y1 >= 0) & (y1 < Hl);
+    const int cx0 = min(max(x0, 0), Wl - 1), cx1 = min(max(x1, 0), Wl - 1);
+    const int cy0 = min(max(y0, 0), Hl - 1), cy1 = min(max(y1, 0), Hl - 1);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 a = img[cy0 * Wl + cx0], b = img[cy0 * Wl + cx1];
+    const float4 c = img[cy1 * Wl + cx0], d = img[cy1 * Wl + cx1];
+    tp.t00 = (inx0 & iny0) ? a : z;
+    tp.t10 = (inx1 & iny0) ? b : z;
+    tp.t01 = (inx0 & iny1) ? c : z;
+    tp.t11 = (inx1 & iny1) ? d : z;
+}
+
+__device__ __forceinline__ float bilerp(float a00, float a10, float a01, float a11, float wx, float wy) {
+    const float top = fmaf(wx, a10 - a00, a00);
+    const float bot = fmaf(wx, a11 - a01, a01);
+    return fmaf(wy, bot - top, top);
+}
+
+__device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+__device__ __forceinline__ void load_cam(const float* __restrict__ K9, Cam& c) {
+    c.fx = K9[0]; c.cx = K9[2]; c.fy = K9[4]; c.cy = K9[5];
+}
+
+__device__ __forceinline__ void load_pose(const float* __restrict__ T16, float (&R)[9], float (&t)[3]) {
+    R[0] = T16[0]; R[1] = T16[1]; R[2] = T16[2];  t[0] = T16[3];
+    R[3] = T16[4]; R[4] = T16[5]; R[5] = T16[6];  t[1] = T16[7];
+    R[6] = T16[8]; R[7] = T16[9]; R[8] = T16[10]; t[2] = T16[11];
+}

@@ -1,0 +1,255 @@
+// Once-per-keyframe / once-per-level preparation kernels: mask compaction into the per-segment point table,
+// source-image sampling, image packing and the 3x3 binomial pyramid step.
+#include "sp_device.h"
+
+namespace {
+
+// one wave per (segment,row): number of set mask bytes in that row
+__global__ __launch_bounds__(SP_BLOCK) void k_row_counts(const uint8_t* __restrict__ masks, int rows_total, int W,
+                                                         int32_t* __restrict__ row_counts) {
+    const int row = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (row >= rows_total) return;
+    const int lane = threadIdx.x & 63;
+    const uint8_t* m = masks + (size_t)row * W;
+    int c = 0;
+    for (int x = lane; x < W; x += 64) c += m[x] != 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) row_counts[row] = c;
+}
+
+// one block per segment: exclusive scan of its H row counts in place, total to counts[n]
+__global__ __launch_bounds__(SP_BLOCK) void k_segment_row_scan(int32_t* __restrict__ row_counts, int H,
+                                                               int32_t* __restrict__ counts) {
+    __shared__ int32_t part[SP_BLOCK];
+    int32_t* rc = row_counts + (size_t)blockIdx.x * H;
+    const int per = (H + SP_BLOCK - 1) / SP_BLOCK;
+    const int r0 = threadIdx.x * per, r1 = min(r0 + per, H);
+    int s = 0;
+    for (int r = r0; r < r1; ++r) s += rc[r];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < SP_BLOCK; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        counts[blockIdx.x] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int r = r0; r < r1; ++r) { const int v = rc[r]; rc[r] = run; run += v; }
+}
+
+// single block: seg_off = exclusive scan of counts (N+1 entries)
+__global__ __launch_bounds__(SP_BLOCK) void k_segment_offsets(const int32_t* __restrict__ counts, int N,
+                                                              int32_t* __restrict__ seg_off) {
+    __shared__ int32_t part[SP_BLOCK];
+    const int per = (N + SP_BLOCK - 1) / SP_BLOCK;
+    const int n0 = threadIdx.x * per, n1 = min(n0 + per, N);
+    int s = 0;
+    for (int n = n0; n < n1; ++n) s += counts[n];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < SP_BLOCK; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        seg_off[N] = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int n = n0; n < n1; ++n) { seg_off[n] = run; run += counts[n]; }
+}
+
+// one wave per (segment,row): ordered compaction of the row (ballot + prefix popcount)
+__global__ __launch_bounds__(SP_BLOCK) void k_table_fill(const uint8_t* __restrict__ masks,
+                                                         const float* __restrict__ logdepth, int N, int H, int W,
+                                                         const int32_t* __restrict__ seg_off,
+                                                         const int32_t* __restrict__ row_off,
+                                                         uint32_t* __restrict__ pix, float* __restrict__ baseL) {
+    const int row_id = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (row_id >= N * H) return;
+    const int lane = threadIdx.x & 63;
+    const int n = row_id / H, r = row_id - n * H;
+    const uint8_t* m = masks + (size_t)row_id * W;
+    const float* L = logdepth + (size_t)row_id * W;
+    int base = seg_off[n] + row_off[row_id];
+    for (int x0 = 0; x0 < W; x0 += 64) {
+        const int x = x0 + lane;
+        const bool on = (x < W) && (m[x] != 0);
+        const unsigned long long bal = __ballot(on);
+        if (on) {
+            const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
+            pix[k] = ((uint32_t)r << 16) | (uint32_t)x;
+            baseL[k] = L[x];
+        }
+        base += __popcll(bal);
+    }
+}
+
+// tool/point_utils.py:37-40 + core/dense_optim.py:51-59: L at the rounded keypoint pixel
+__global__ void k_keypoint_L(const float* __restrict__ logdepth, const float* __restrict__ keypoints, int N, int H,
+                             int W, float* __restrict__ kp_L) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float kr = rintf(0.5f * (float)(H - 1) * (keypoints[2 * n] + 1.f));      // rintf = half-to-even
+    const float kc = rintf(0.5f * (float)(W - 1) * (keypoints[2 * n + 1] + 1.f));
+    int r = (int)kr, c = (int)kc;
+    // torch advanced indexing wraps negative indices once; anything else is an error upstream -- clamp here
+    if (r < 0) r += H;
+    if (c < 0) c += W;
+    r = min(max(r, 0), H - 1);
+    c = min(max(c, 0), W - 1);
+    kp_L[n] = logdepth[((size_t)n * H + r) * W + c];
+}
+
+__device__ __forceinline__ int segment_of(const int32_t* __restrict__ seg_off, int N, int i) {
+    int lo = 0, hi = N;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (seg_off[mid] <= i) lo = mid; else hi = mid; }
+    while (lo + 1 < N && seg_off[lo + 1] <= i) ++lo;
+    return lo;
+}
+
+__device__ __forceinline__ float planar_tap(const float* __restrict__ img, int Wl, int Hl, int x, int y) {
+    return (x >= 0 && x < Wl && y >= 0 && y < Hl) ? img[(size_t)y * Wl + x] : 0.f;
+}
+
+// Source-side sampling exactly as the reference does it (get_pixels on the source's own points,
+// core/dense_optim.py:143-162,315-317): IEEE divisions, same operation order, so the validity bit matches.
+__global__ __launch_bounds__(SP_BLOCK) void k_sample_source(uint32_t* __restrict__ pix, const float* __restrict__ baseL,
+                                                            const int32_t* __restrict__ seg_off,
+                                                            const float* __restrict__ kp_L, const float* __restrict__ kld,
+                                                            int N, int P, int H, int W, const float* __restrict__ img,
+                                                            int Hl, int Wl, const float* __restrict__ K9,
+                                                            float4* __restrict__ src4) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const int n = segment_of(seg_off, N, i);
+    const float fx = K9[0], cx = K9[2], fy = K9[4], cy = K9[5];
+    const uint32_t pw = pix[i] & 0x7fffffffu;
+    const float col = (float)(pw & 0xffffu), row = (float)(pw >> 16);
+    const float L = baseL[i];
+    const float d = expf(L + (kld[n] - kp_L[n]));
+    const float x = __fdiv_rn(__fmul_rn(__fsub_rn(col, cx), d), fx);
+    const float y = __fdiv_rn(__fmul_rn(__fsub_rn(row, cy), d), fy);
+    const float zinv = (fabsf(d) > 1e-6f) ? __fdiv_rn(1.0f, d) : 1e-6f;
+    const float u = __fadd_rn(__fmul_rn(__fmul_rn(x, fx), zinv), cx);
+    const float v = __fadd_rn(__fmul_rn(__fmul_rn(y, fy), zinv), cy);
+    const float invW = __fdiv_rn(1.0f, (float)(W - 1)), invH = __fdiv_rn(1.0f, (float)(H - 1));
+    const float xn = __fsub_rn(__fmul_rn(__fmul_rn(2.f, u), invW), 1.f);
+    const float yn = __fsub_rn(__fmul_rn(__fmul_rn(2.f, v), invH), 1.f);
+    const bool ok = (fabsf(xn) <= 0.99f) && (fabsf(yn) <= 0.99f) && (d > 1e-7f);
+    const float ix = __fmul_rn(__fmul_rn(__fadd_rn(xn, 1.f), 0.5f), (float)(Wl - 1));
+    const float iy = __fmul_rn(__fmul_rn(__fadd_rn(yn, 1.f), 0.5f), (float)(Hl - 1));
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float wx = ix - fx0, wy = iy - fy0;
+    float rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* pl = img + (size_t)ch * Hl * Wl;
+        // same weight products and summation order as ATen's grid_sampler_2d (nw, ne, sw, se)
+        const float nw = planar_tap(pl, Wl, Hl, x0, y0), ne = planar_tap(pl, Wl, Hl, x0 + 1, y0);
+        const float sw = planar_tap(pl, Wl, Hl, x0, y0 + 1), se = planar_tap(pl, Wl, Hl, x0 + 1, y0 + 1);
+        float acc = nw * ((1.f - wx) * (1.f - wy));
+        acc += ne * (wx * (1.f - wy));
+        acc += sw * ((1.f - wx) * wy);
+        acc += se * (wx * wy);
+        rgb[ch] = acc;
+    }
+    src4[i] = make_float4(rgb[0], rgb[1], rgb[2], L);
+    pix[i] = pw | (ok ? 0x80000000u : 0u);
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_pack_rgba(const float* __restrict__ chw, int HW, float4* __restrict__ out) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= HW) return;
+    const float* p = chw + (size_t)blockIdx.y * 3 * HW;
+    out[(size_t)blockIdx.y * HW + i] = make_float4(p[i], p[HW + i], p[2 * (size_t)HW + i], 0.f);
+}
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// image/gaussian_pyramid.py:53-85: reflect pad 1, depthwise [1 2 1;2 4 2;1 2 1]/16, keep [::2, ::2]
+__global__ __launch_bounds__(SP_BLOCK) void k_blur_decimate(const float* __restrict__ in, int H, int W, int Ho, int Wo,
+                                                            float* __restrict__ out) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    const int yo = i / Wo, xo = i - yo * Wo;
+    const float* p = in + (size_t)blockIdx.y * H * W;
+    const float wgt[3] = {1.f, 2.f, 1.f};
+    float acc = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int y = reflect1(2 * yo + dy - 1, H);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int x = reflect1(2 * xo + dx - 1, W);
+            acc = fmaf(wgt[dy] * wgt[dx] * (1.f / 16.f), p[(size_t)y * W + x], acc);
+        }
+    }
+    out[(size_t)blockIdx.y * Ho * Wo + i] = acc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sp_mask_count(const uint8_t* masks, int N, int H, int W, int32_t* row_counts, int32_t* counts, int32_t* seg_off,
+                  void* stream) {
+    if (!masks || !row_counts || !counts || !seg_off || N <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
+    if (H > 32767 || W > 65535) return SP_ELIMIT;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows = N * H;
+    hipLaunchKernelGGL(k_row_counts, dim3((rows + SP_WAVES - 1) / SP_WAVES), dim3(SP_BLOCK), 0, s, masks, rows, W, row_counts);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_segment_row_scan, dim3(N), dim3(SP_BLOCK), 0, s, row_counts, H, counts);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_segment_offsets, dim3(1), dim3(SP_BLOCK), 0, s, counts, N, seg_off);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_table_fill(const uint8_t* masks, const float* logdepth, const float* keypoints, int N, int H, int W,
+                  const int32_t* seg_off, const int32_t* row_off, uint32_t* pix, float* baseL, float* kp_L,
+                  void* stream) {
+    if (!masks || !logdepth || !keypoints || !seg_off || !row_off || !pix || !baseL || !kp_L) return SP_EINVAL;
+    if (N <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int rows = N * H;
+    hipLaunchKernelGGL(k_table_fill, dim3((rows + SP_WAVES - 1) / SP_WAVES), dim3(SP_BLOCK), 0, s, masks, logdepth, N, H, W,
+                       seg_off, row_off, pix, baseL);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_keypoint_L, dim3((N + 63) / 64), dim3(64), 0, s, logdepth, keypoints, N, H, W, kp_L);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_table_sample_source(uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                           const float* kld, int N, int P, int H, int W, const float* img, int Hl, int Wl,
+                           const float* K, float* src4, void* stream) {
+    if (!pix || !baseL || !seg_off || !kp_L || !kld || !img || !K || !src4) return SP_EINVAL;
+    if (N <= 0 || P <= 0 || H < 2 || W < 2 || Hl < 1 || Wl < 1) return SP_EINVAL;
+    hipLaunchKernelGGL(k_sample_source, dim3((P + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0,
+                       static_cast<hipStream_t>(stream), pix, baseL, seg_off, kp_L, kld, N, P, H, W, img, Hl, Wl, K,
+                       reinterpret_cast<float4*>(src4));
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_pack_rgba(const float* chw, int B, int H, int W, float* hwc4, void* stream) {
+    if (!chw || !hwc4 || B <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
+    hipLaunchKernelGGL(k_pack_rgba, dim3((H * W + SP_BLOCK - 1) / SP_BLOCK, B), dim3(SP_BLOCK), 0,
+                       static_cast<hipStream_t>(stream), chw, H * W, reinterpret_cast<float4*>(hwc4));
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* stream) {
+    if (!in || !out || C <= 0 || H < 2 || W < 2) return SP_EINVAL;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    hipLaunchKernelGGL(k_blur_decimate, dim3((Ho * Wo + SP_BLOCK - 1) / SP_BLOCK, C), dim3(SP_BLOCK), 0,
+                       static_cast<hipStream_t>(stream), in, H, W, Ho, Wo, out);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // extern "C"

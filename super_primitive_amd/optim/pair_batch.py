@@ -1,0 +1,202 @@
+"""Many independent frame pairs optimised side by side on one GPU (BASELINE.json configs 2 and 5).
+
+Each pair is one two-frame problem of the reference (``odometery/two_frame_sfm.py``): a source keyframe with N
+segments, a target frame, unknowns = relative pose (SE(3)) + one log-depth per segment.  Pairs never interact,
+so M of them are packed into flat device arrays, described by one ``SpPair`` record each, and every optimiser
+iteration is exactly two launches for the WHOLE batch, with no host synchronisation:
+
+    sp_pairs_cost   (grid = all tiles of all pairs; fused cost + gradient | Gauss-Newton normal equations)
+    sp_pairs_*_step (grid = M; fixed-order tile reduction, Adam+SE(3) retraction | Schur-complement LM solve)
+
+This is the configuration the HBM-roofline number is measured on: one 640x480x64 pair is ~10 MB of algorithmic
+traffic and lives in the 256 MB Infinity Cache, M >= 64 pairs stream from HBM.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..image import gaussian_pyramid
+from ..segment_table import SegmentTable, make_tiles
+
+DEFAULT_BATCH_TILE_POINTS = 2048
+
+
+def _level_images(img, max_level):
+    """[(3,H,W) at level 0, level 1, ...] through the HIP blur+decimate kernel."""
+    out, cur = [img], img[None]
+    for _ in range(max_level):
+        cur = gaussian_pyramid.blur_decimate(cur)
+        out.append(cur[0])
+    return out
+
+
+class PairBatch:
+    def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
+                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7):
+        """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
+        device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
+        klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
+        ``config['aligment']`` (max exclusive)."""
+        lib = _lib.load()
+        self.lib = lib
+        M = len(src_frames)
+        assert M == len(trg_images) == len(trg_Ks) == len(klds) and poses.shape[0] == M
+        dev = src_frames[0].image.device
+        _lib.require_device(src_frames[0].image)
+        self.M, self.device = M, dev
+        self.level_ids = list(range(levels[0], levels[1]))
+        max_level = levels[1] - 1
+        self.tile_points = tile_points
+
+        tables = [SegmentTable(f.keypoint_regions, f.logdepth_perseg, f.keypoints, tile_points) for f in src_frames]
+        self.Ns = [t.N for t in tables]
+        self.Ps = [t.P for t in tables]
+        self.max_N = max(self.Ns)
+        n_off = np.concatenate(([0], np.cumsum(self.Ns)))
+        p_off = np.concatenate(([0], np.cumsum(self.Ps)))
+        self.n_off, self.p_off = n_off, p_off
+        cat = torch.cat
+        # flat, pair-major device arrays
+        self.kp_L = cat([t.kp_L for t in tables])
+        self.kld = cat([k.detach().float().to(dev) for k in klds]).contiguous()
+        self.pose = poses.detach().float().to(dev).reshape(M, 16).contiguous()
+        self.aff = torch.zeros(M, 4, dtype=torch.float32, device=dev) if use_affine else None
+        # per-level source samples + packed targets
+        self.src4, self.trg4, self.level_hw = {}, {}, {}
+        pix_list = [t.pix for t in tables]
+        for m, (f, tab) in enumerate(zip(src_frames, tables)):
+            s_lv = _level_images(f.image[:3].float(), max_level)
+            t_lv = _level_images(trg_images[m][:3].float().to(dev), max_level)
+            for l in self.level_ids:
+                self.src4.setdefault(l, []).append(tab.source_level(s_lv[l], f.K, klds[m].to(dev)))
+                Hl, Wl = t_lv[l].shape[-2:]
+                packed = torch.empty(1, Hl, Wl, 4, dtype=torch.float32, device=dev)
+                _lib.check(lib.sp_pack_rgba(_lib.ptr(t_lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(packed), _lib.stream_ptr()),
+                           "sp_pack_rgba")
+                self.trg4.setdefault(l, []).append(packed.reshape(-1))
+                self.level_hw.setdefault(l, []).append((Hl, Wl))
+        self.pix = cat(pix_list)          # after source_level(): validity bits are set
+        self.src4 = {l: cat(v) for l, v in self.src4.items()}
+        trg_off = {l: np.concatenate(([0], np.cumsum([x.numel() for x in v]))) for l, v in self.trg4.items()}
+        self.trg4 = {l: cat(v) for l, v in self.trg4.items()}
+
+        # work list
+        tiles, stos, t_off = [], [], [0]
+        for m, tab in enumerate(tables):
+            tl, sto = make_tiles(tab.counts, tile_points, pair=m, first_point=0)
+            tiles.append(tl)
+            stos.append(sto)
+            t_off.append(t_off[-1] + tl.shape[0])
+        self.n_tiles = t_off[-1]
+        self.tiles = torch.from_numpy(np.concatenate(tiles)).to(dev)
+        sto_off = np.concatenate(([0], np.cumsum([len(s) for s in stos])))
+        self.seg_tile_off = torch.from_numpy(np.concatenate(stos)).to(dev)
+
+        # descriptors, one array per level
+        self.desc = {}
+        for l in self.level_ids:
+            arr = (_lib.SpPair * M)()
+            for m, (f, tab) in enumerate(zip(src_frames, tables)):
+                d = arr[m]
+                d.pix = self.pix.data_ptr() + 4 * int(p_off[m])
+                d.src4 = self.src4[l].data_ptr() + 16 * int(p_off[m])
+                d.kp_L = self.kp_L.data_ptr() + 4 * int(n_off[m])
+                d.trg4 = self.trg4[l].data_ptr() + 4 * int(trg_off[l][m])
+                d.kld = self.kld.data_ptr() + 4 * int(n_off[m])
+                d.pose = self.pose.data_ptr() + 64 * m
+                d.aff = (self.aff.data_ptr() + 16 * m) if use_affine else None
+                d.seg_tile_off = self.seg_tile_off.data_ptr() + 4 * int(sto_off[m])
+                Ks = f.K.detach().float().cpu().numpy()
+                Kt = trg_Ks[m].detach().float().cpu().numpy()
+                d.K_src = (ctypes.c_float * 4)(Ks[0, 0], Ks[1, 1], Ks[0, 2], Ks[1, 2])
+                d.K_trg = (ctypes.c_float * 4)(Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
+                d.N, d.P, d.H, d.W = tab.N, tab.P, tab.H, tab.W
+                d.Hl, d.Wl = self.level_hw[l][m]
+                d.tile0, d.n_tiles = t_off[m], t_off[m + 1] - t_off[m]
+                d.zmin = zmin
+            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+            self.desc[l] = torch.from_numpy(raw).to(dev)
+
+        # optimiser state / workspaces
+        self.partials = torch.empty(self.n_tiles * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+        self._costs = torch.zeros(M, dtype=torch.float32, device=dev)
+        self.adam_state = torch.zeros(M, 2 + 2 * (self.max_N + 8), dtype=torch.float32, device=dev)
+        self.lm_state = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
+        self.backup = torch.zeros(M, 16 + self.max_N, dtype=torch.float32, device=dev)
+        self.reset_lm()
+        self._keep = (tables,)
+
+    # ------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_synth(cls, pairs, levels=(0, 3), device="cuda:0", **kw):
+        from ..image.keyframe import KeyFrame
+        dev = torch.device(device)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in pairs]
+        return cls(src, [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs],
+                   torch.stack([t(p.pose_init) for p in pairs]), [t(p.kld_init) for p in pairs], levels=levels, **kw)
+
+    def reset_lm(self, lam=1e-4):
+        self.lm_state.zero_()
+        self.lm_state[:, 0] = lam
+        self.lm_state[:, 1] = -1.0
+
+    # ------------------------------------------------------------------------------------------------
+    def cost_pass(self, level, mode, irls_eps=1e-3):
+        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.tiles), self.n_tiles, mode,
+                                          float(irls_eps), _lib.ptr(self.partials), _lib.stream_ptr()), "sp_pairs_cost")
+
+    def gn_step(self, level=0, irls_eps=1e-3, lm_up=8.0, lm_down=0.5, lm_min=1e-7):
+        """One Gauss-Newton/LM iteration of every pair at pyramid ``level`` (2 launches).  Returns the (M,) device
+        tensor of costs (= the reference's residual) evaluated at the parameters BEFORE this step."""
+        self.cost_pass(level, 1, irls_eps)
+        _lib.check(self.lib.sp_pairs_gn_step(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials),
+                                             float(lm_up), float(lm_down), float(lm_min), _lib.ptr(self.lm_state),
+                                             _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.stream_ptr()),
+                   "sp_pairs_gn_step")
+        return self._costs
+
+    def adam_step(self, level=0, lr_kld=1e-3, lr_pose=1e-2, lr_aff=5e-3):
+        """One Adam iteration (reset-tangent flavour of the reference's tracking/mapping loops) of every pair."""
+        self.cost_pass(level, 0)
+        _lib.check(self.lib.sp_pairs_adam_step(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials),
+                                               float(lr_kld), float(lr_pose), float(lr_aff), _lib.ptr(self.adam_state),
+                                               _lib.ptr(self._costs), _lib.stream_ptr()), "sp_pairs_adam_step")
+        return self._costs
+
+    def evaluate(self, level=0):
+        """Residual of every pair at the current parameters (no update): (M,) device tensor."""
+        self.cost_pass(level, 0)
+        p = self.partials[: self.n_tiles * _lib.SP_GRAD_PARTIAL_FLOATS].reshape(self.n_tiles, _lib.SP_GRAD_PARTIAL_FLOATS)
+        per_tile = p[:, 0].double()
+        pair_of_tile = self.tiles[:, 0].long()
+        sums = torch.zeros(self.M, dtype=torch.float64, device=self.device).index_add_(0, pair_of_tile, per_tile)
+        P = torch.tensor(self.Ps, dtype=torch.float64, device=self.device)
+        return (sums / (3.0 * P)).float()
+
+    def run(self, iters_per_level, mode="gn", **kw):
+        """Coarse-to-fine schedule like ``two_frame_sfm.py:150-155``: ``iters_per_level`` iterations at each level."""
+        for level in reversed(self.level_ids):
+            if mode == "gn":
+                self.lm_state[:, 1] = -1.0      # costs of different levels are not comparable
+                self.lm_state[:, 4] = 0.0
+            for _ in range(iters_per_level):
+                (self.gn_step if mode == "gn" else self.adam_step)(level, **kw)
+
+    # ------------------------------------------------------------------------------------------------
+    def costs(self):
+        return self._costs
+
+    def poses(self):
+        return self.pose.reshape(self.M, 4, 4)
+
+    def klds(self):
+        return [self.kld[self.n_off[m]: self.n_off[m + 1]] for m in range(self.M)]
+
+    def algorithmic_bytes(self, level):
+        """20 B per segment pixel + 12 B per target-image pixel, per pair per iteration."""
+        return sum(20 * P + 12 * h * w for P, (h, w) in zip(self.Ps, self.level_hw[level]))

@@ -1,0 +1,151 @@
+"""Compact per-segment point table of a source keyframe (device resident).
+
+The reference re-derives the point list from dense (N,H,W) tensors on every iteration
+(``core/dense_optim.py:38-114``: three dense passes, ``torch.where`` with a host sync, 3xP int64 indices).
+Masks and base log-depths never change after a keyframe is built, so the build compacts them ONCE into
+
+    pix[P] (row/col/validity), baseL[P], kp_L[N], seg_off[N+1]       -- level independent
+    src4[P] = {source rgb at this pyramid level, baseL}              -- one per level, made on first use
+    tiles[T] = {pair, segment, start, count}, seg_tile_off[N+1]      -- the work list of the cost kernel
+
+(20 B per point per iteration instead of >= 5 dense N*H*W*4-byte passes).  The table is attached to the
+``keypoint_regions`` tensor object, which ``keyframe_pyramid(geo_down=False)`` shares between all levels, and is
+rebuilt whenever masks / log-depths / keypoints are replaced or modified (tensor identity + version counters).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DEFAULT_TILE_POINTS = 1024
+
+
+def _ident(t):
+    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+
+
+def make_tiles(counts, tile_points, pair=0, first_point=0):
+    """Host-side work list: split every segment into runs of at most ``tile_points`` points.
+
+    Returns (tiles int32 (T,4) = {pair, segment, start, count}, seg_tile_off int32 (N+1,))."""
+    counts = np.asarray(counts, dtype=np.int64)
+    n_t = (counts + tile_points - 1) // tile_points
+    seg_tile_off = np.zeros(len(counts) + 1, dtype=np.int32)
+    np.cumsum(n_t, out=seg_tile_off[1:])
+    T = int(seg_tile_off[-1])
+    tiles = np.zeros((T, 4), dtype=np.int32)
+    if T:
+        seg = np.repeat(np.arange(len(counts)), n_t)
+        within = np.arange(T) - np.repeat(seg_tile_off[:-1], n_t)
+        seg_start = np.concatenate(([0], np.cumsum(counts)[:-1]))
+        start = within * tile_points
+        tiles[:, 0] = pair
+        tiles[:, 1] = seg
+        tiles[:, 2] = first_point + seg_start[seg] + start
+        tiles[:, 3] = np.minimum(tile_points, counts[seg] - start)
+    return tiles, seg_tile_off
+
+
+class SegmentTable:
+    def __init__(self, masks, logdepth, keypoints, tile_points=DEFAULT_TILE_POINTS):
+        _lib.require_device(masks, logdepth, keypoints)
+        lib = _lib.load()
+        assert masks.dtype == torch.bool and masks.dim() == 3
+        N, H, W = masks.shape
+        assert logdepth.shape == masks.shape and keypoints.shape == (N, 2)
+        dev = masks.device
+        self.N, self.H, self.W, self.device = N, H, W, dev
+        masks_c = masks.contiguous()
+        L_c = logdepth.detach().contiguous().float()
+        kp_c = keypoints.detach().contiguous().float()
+        row_counts = torch.empty(N * H, dtype=torch.int32, device=dev)
+        counts = torch.empty(N, dtype=torch.int32, device=dev)
+        self.seg_off = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        s = _lib.stream_ptr()
+        _lib.check(lib.sp_mask_count(_lib.ptr(masks_c), N, H, W, _lib.ptr(row_counts), _lib.ptr(counts),
+                                     _lib.ptr(self.seg_off), s), "sp_mask_count")
+        counts_h = counts.cpu().numpy()            # the one host sync of the table build (sizes the arrays)
+        self.counts = counts_h
+        self.P = int(counts_h.sum())
+        if self.P == 0:
+            raise ValueError("keyframe has no segment pixels")
+        self.pix = torch.empty(self.P, dtype=torch.int32, device=dev)
+        self.baseL = torch.empty(self.P, dtype=torch.float32, device=dev)
+        self.kp_L = torch.empty(N, dtype=torch.float32, device=dev)
+        _lib.check(lib.sp_table_fill(_lib.ptr(masks_c), _lib.ptr(L_c), _lib.ptr(kp_c), N, H, W, _lib.ptr(self.seg_off),
+                                     _lib.ptr(row_counts), _lib.ptr(self.pix), _lib.ptr(self.baseL), _lib.ptr(self.kp_L),
+                                     s), "sp_table_fill")
+        self.set_tile_points(tile_points)
+        self._levels = {}
+        self._key = None
+
+    def set_tile_points(self, tile_points):
+        tiles, sto = make_tiles(self.counts, tile_points)
+        self.tile_points = tile_points
+        self.n_tiles = tiles.shape[0]
+        self.tiles = torch.from_numpy(tiles).to(self.device)
+        self.seg_tile_off = torch.from_numpy(sto).to(self.device)
+
+    # -- per-level source samples ---------------------------------------------------------------
+    def source_level(self, image, K, kld):
+        """{rgb at this level, baseL} per point, cached per (image, K) identity."""
+        key = (_ident(image), _ident(K))
+        hit = self._levels.get(key)
+        if hit is not None:
+            return hit
+        _lib.require_device(image, K, kld)
+        lib = _lib.load()
+        img = image[:3].detach().contiguous().float()
+        Hl, Wl = img.shape[-2:]
+        src4 = torch.empty(self.P, 4, dtype=torch.float32, device=self.device)
+        Kc = K.detach().contiguous().float()
+        kc = kld.detach().contiguous().float()
+        _lib.check(lib.sp_table_sample_source(_lib.ptr(self.pix), _lib.ptr(self.baseL), _lib.ptr(self.seg_off),
+                                              _lib.ptr(self.kp_L), _lib.ptr(kc), self.N, self.P, self.H, self.W,
+                                              _lib.ptr(img), Hl, Wl, _lib.ptr(Kc), _lib.ptr(src4), _lib.stream_ptr()),
+                   "sp_table_sample_source")
+        if len(self._levels) > 16:
+            self._levels.clear()
+        self._levels[key] = src4
+        return src4
+
+
+def table_of(kf, tile_points=None):
+    """The (cached) SegmentTable of a keyframe-like object with the reference's attribute names."""
+    masks, L, kp = kf.keypoint_regions, kf.get_logdepth() if hasattr(kf, "get_logdepth") else kf.logdepth_perseg, kf.keypoints
+    key = (_ident(masks), _ident(L), _ident(kp))
+    tab = getattr(masks, "_sp_table", None)
+    if tab is None or tab._key != key:
+        tab = SegmentTable(masks, L, kp, tile_points or DEFAULT_TILE_POINTS)
+        tab._key = key
+        try:
+            masks._sp_table = tab
+        except Exception:  # pragma: no cover
+            pass
+    elif tile_points is not None and tab.tile_points != tile_points:
+        tab.set_tile_points(tile_points)
+    return tab
+
+
+def packed_target(images):
+    """(3,H,W) or (B,3,H,W) planar f32 -> (B,H,W,4) packed, cached on the tensor object."""
+    _lib.require_device(images)
+    key = _ident(images)
+    hit = getattr(images, "_sp_rgba", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    lib = _lib.load()
+    img = images.detach()
+    if img.dim() == 3:
+        img = img[None]
+    img = img[:, :3].contiguous().float()
+    B, _, H, W = img.shape
+    out = torch.empty(B, H, W, 4, dtype=torch.float32, device=img.device)
+    _lib.check(lib.sp_pack_rgba(_lib.ptr(img), B, H, W, _lib.ptr(out), _lib.stream_ptr()), "sp_pack_rgba")
+    try:
+        images._sp_rgba = (key, out)
+    except Exception:  # pragma: no cover
+        pass
+    return out
