@@ -1,0 +1,230 @@
+#!/usr/bin/env python
+"""Headline benchmark: Gauss-Newton iterations/sec on 640x480, 64-segment synthetic frame pairs (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One STEP = one Gauss-Newton/LM iteration (fused cost + Jacobian/normal-equation pass over every segment pixel,
+then the per-pair Schur solve and SE(3) (+) log-depth update) of EVERY frame pair resident on the GPU, at pyramid
+level 0 (full resolution, the heaviest level).  Each rank holds --pairs independent pairs (weak scaling: frame
+pairs shard embarrassingly, there is no data-path collective; the only exchange is the final gather of poses and
+log-depths, done once after the timed region).  `value` = pair-iterations per second over all ranks with every
+input already resident in HBM.
+
+Extra objects on the JSON line:
+  roofline      HBM roofline of the dominant kernel (k_cost_pairs<GN>): algorithmic bytes per launch
+                (20 B/segment pixel + 12 B/target pixel) / its mean duration measured with HIP events
+                on the launch stream inside the timed region; peak 8000 GB/s (MI355X_MICROARCH.md).
+  cpu_baseline  the oracle's dense PyTorch-CPU restatement of the reference loop (cost + backward + Adam.step) on
+                the host cores of this box, rank 0 / N=1 only, on a bounded sample.  Baseline only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+H, W, N_SEG = 480, 640, 64
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=96, help="frame pairs resident per GPU")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
+    ap.add_argument("--tile-points", type=int, default=2048)
+    ap.add_argument("--mode", choices=["gn", "adam"], default="gn")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-pair and full-schedule side measurements")
+    return ap.parse_args()
+
+
+def build_batch(args, rank, dev):
+    from super_primitive_amd import synth
+    from super_primitive_amd.optim.pair_batch import PairBatch
+    G = max(1, min(args.distinct, args.pairs))
+    R = max(1, args.pairs // G)
+    pairs = [synth.make_pair(H, W, N_SEG, seed=1000 * rank + s, overlap=4, init_sigma=0.004) for s in range(G)]
+    rng = np.random.default_rng(rank)
+    poses = []
+    for r in range(R):
+        for p in pairs:
+            poses.append((synth.se3_exp_np(0.002 * rng.standard_normal(6)) @ p.pose_init.astype(np.float64)).astype(np.float32))
+    poses = torch.from_numpy(np.stack(poses))
+    from super_primitive_amd.image.keyframe import KeyFrame
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in pairs]
+    batch = PairBatch(src, [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs], poses,
+                      [t(p.kld_init) for p in pairs], levels=(0, 3), tile_points=args.tile_points, replicate=R)
+    return batch, pairs
+
+
+def cpu_baseline(pair, iters):
+    """Reference algorithm on the host: dense (N,H,W) seeding -> gather -> grid_sample -> L1 -> backward -> Adam."""
+    from oracle import photometric_oracle as orc
+    src, trg = orc.frames_from_synth(pair)
+    kld = torch.nn.Parameter(torch.from_numpy(pair.kld_init.copy()))
+    a = torch.nn.Parameter(torch.zeros(1, 6))
+    T0 = torch.from_numpy(pair.pose_init.copy())
+    opt = torch.optim.Adam([{"params": [kld], "lr": 1e-3}, {"params": [a], "lr": 1e-2}], lr=1e-3)
+
+    def one():
+        pose = orc.se3_exp(a)[0] @ T0
+        out = orc.photometric_cost(src, trg, kld, pose)
+        loss = out["residual"].abs().mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    dt = time.perf_counter() - t0
+    return iters / dt
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (HIP path only, no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    batch, pairs = build_batch(args, rank, dev)
+    M = batch.M
+    step = (lambda: batch.gn_step(level=0)) if args.mode == "gn" else (lambda: batch.adam_step(level=0))
+    mode_id = 1 if args.mode == "gn" else 0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    K = args.steps
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        ev[k][0].record()
+        batch.cost_pass(0, mode_id)
+        ev[k][1].record()
+        if args.mode == "gn":
+            # the second launch of the step (solver); gn_step() = cost_pass + this
+            from super_primitive_amd import _lib
+            _lib.check(batch.lib.sp_pairs_gn_step(_lib.ptr(batch.desc[0]), M, batch.max_N, _lib.ptr(batch.partials), 8.0, 0.5,
+                                                  1e-7, _lib.ptr(batch.lm_state), _lib.ptr(batch.backup),
+                                                  _lib.ptr(batch._costs), _lib.stream_ptr()), "sp_pairs_gn_step")
+        else:
+            from super_primitive_amd import _lib
+            _lib.check(batch.lib.sp_pairs_adam_step(_lib.ptr(batch.desc[0]), M, batch.max_N, _lib.ptr(batch.partials), 1e-3,
+                                                    1e-2, 5e-3, _lib.ptr(batch.adam_state), _lib.ptr(batch._costs),
+                                                    _lib.stream_ptr()), "sp_pairs_adam_step")
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    k_max = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
+        # the one exchange of the path: final gather of poses and log-depths (a few KB per rank, RCCL over xGMI)
+        poses_all = [torch.empty_like(batch.pose) for _ in range(world)]
+        klds_all = [torch.empty_like(batch.kld) for _ in range(world)]
+        dist.all_gather(poses_all, batch.pose)
+        dist.all_gather(klds_all, batch.kld)
+        torch.cuda.synchronize()
+    elapsed = float(t_max.item())
+    kern_ms = float(k_max.item())
+
+    alg_bytes = batch.algorithmic_bytes(0)
+    value = world * M * K / elapsed
+    line = {
+        "metric": "GN iters/sec (640x480x64-seg frame pairs)" if args.mode == "gn" else "Adam iters/sec (640x480x64-seg frame pairs)",
+        "value": value, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Replica-shaped two-frame SfM, 640x480, 64 segments (8x8 grid, 4 px overlap), pyramid "
+                               "level 0 of a 3-level pyramid; BASELINE.json configs[1]",
+                   "pairs_per_gpu": M, "segment_pixels_per_pair": int(batch.Ps[0]), "optimiser": args.mode,
+                   "tile_points": args.tile_points, "sharding": f"{world} x independent pair batches, final all_gather only"},
+        "roofline": {"bound": "hbm", "kernel": f"k_cost_pairs<{mode_id}>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
+                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
+    }
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            rec = json.load(open(pmc))
+            if rec.get("pairs_per_gpu") == M and rec.get("mode") == args.mode and rec.get("tile_points") == args.tile_points:
+                line["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    if rank == 0 and not args.no_extras:
+        # side measurements outside the timed region: (a) one pair alone (launch/latency bound, lives in the
+        # Infinity Cache), (b) full coarse-to-fine schedule -> frame pairs per second
+        from super_primitive_amd.optim.pair_batch import PairBatch
+        from super_primitive_amd.image.keyframe import KeyFrame
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        p0 = pairs[0]
+        one = PairBatch([KeyFrame(t(p0.src_image), t(p0.K), t(p0.logdepth_perseg), t(p0.keypoints), t(p0.keypoint_regions))],
+                        [t(p0.trg_image)], [t(p0.K)], t(p0.pose_init)[None], [t(p0.kld_init)], levels=(0, 3), tile_points=512)
+        for _ in range(5):
+            one.gn_step(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(200):
+            one.gn_step(0)
+        torch.cuda.synchronize()
+        line["single_pair_gn_iters_per_sec"] = 200 / (time.perf_counter() - t1)
+        iters = 10
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        batch.run(iters, mode=args.mode)
+        torch.cuda.synchronize()
+        line["frame_pairs_per_sec"] = world * M / (time.perf_counter() - t1)
+        line["frame_pair_schedule"] = f"3 levels (coarse to fine) x {iters} {args.mode} iterations"
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = torch.get_num_threads()
+        v = cpu_baseline(pairs[0], args.cpu_iters)
+        line["cpu_baseline"] = {"value": v, "unit": "iters/s", "cores": threads, "kind": "port",
+                                "sample": f"{args.cpu_iters} Adam iterations (dense-layout cost + autograd backward + "
+                                          f"Adam.step, the reference's algorithm restated in oracle/) of ONE 640x480x64 "
+                                          f"pair at level 0, torch CPU, {threads} threads, after 1 warm-up"}
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,7 @@ SP_LM_STATE_FLOATS = 8
 
 
 class SpPair(ctypes.Structure):
-    """Mirror of ``struct SpPair`` (include/sp_hip.h); 128 bytes."""
+    """Mirror of ``struct SpPair`` (include/sp_hip.h); 136 bytes."""
     _fields_ = [
         ("pix", c_void_p), ("src4", c_void_p), ("kp_L", c_void_p), ("trg4", c_void_p),
         ("kld", c_void_p), ("pose", c_void_p), ("aff", c_void_p), ("seg_tile_off", c_void_p),

@@ -36,23 +36,32 @@ def _level_images(img, max_level):
 
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
-                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7):
+                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1):
         """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
         device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
-        ``config['aligment']`` (max exclusive)."""
+        ``config['aligment']`` (max exclusive).  ``replicate`` = R > 1 lays the M0 given pairs out R times in
+        device memory (distinct copies of every array, poses/klds = ``poses[r*M0+m]`` when (R*M0,4,4) poses are
+        given): bench.py uses it to build a large streaming batch without uploading R*M0 dense keyframes."""
         lib = _lib.load()
         self.lib = lib
-        M = len(src_frames)
-        assert M == len(trg_images) == len(trg_Ks) == len(klds) and poses.shape[0] == M
+        M0 = len(src_frames)
+        R = int(replicate)
+        M = M0 * R
+        assert M0 == len(trg_images) == len(trg_Ks) == len(klds) and poses.shape[0] in (M0, M)
+        if poses.shape[0] == M0 and R > 1:
+            poses = poses.repeat(R, 1, 1)
         dev = src_frames[0].image.device
         _lib.require_device(src_frames[0].image)
         self.M, self.device = M, dev
+        base = list(range(M0)) * R              # pair m of the batch is a copy of base pair base[m]
         self.level_ids = list(range(levels[0], levels[1]))
         max_level = levels[1] - 1
         self.tile_points = tile_points
 
-        tables = [SegmentTable(f.keypoint_regions, f.logdepth_perseg, f.keypoints, tile_points) for f in src_frames]
+        tables0 = [SegmentTable(f.keypoint_regions, f.logdepth_perseg, f.keypoints, tile_points) for f in src_frames]
+        tables = [tables0[b] for b in base]
+        frames = [src_frames[b] for b in base]
         self.Ns = [t.N for t in tables]
         self.Ps = [t.P for t in tables]
         self.max_N = max(self.Ns)
@@ -62,27 +71,28 @@ class PairBatch:
         cat = torch.cat
         # flat, pair-major device arrays
         self.kp_L = cat([t.kp_L for t in tables])
-        self.kld = cat([k.detach().float().to(dev) for k in klds]).contiguous()
+        self.kld = cat([klds[b].detach().float().to(dev) for b in base]).contiguous()
         self.pose = poses.detach().float().to(dev).reshape(M, 16).contiguous()
         self.aff = torch.zeros(M, 4, dtype=torch.float32, device=dev) if use_affine else None
         # per-level source samples + packed targets
         self.src4, self.trg4, self.level_hw = {}, {}, {}
-        pix_list = [t.pix for t in tables]
-        for m, (f, tab) in enumerate(zip(src_frames, tables)):
+        src4_0, trg4_0, hw_0 = {}, {}, {}
+        for m, (f, tab) in enumerate(zip(src_frames, tables0)):
             s_lv = _level_images(f.image[:3].float(), max_level)
             t_lv = _level_images(trg_images[m][:3].float().to(dev), max_level)
             for l in self.level_ids:
-                self.src4.setdefault(l, []).append(tab.source_level(s_lv[l], f.K, klds[m].to(dev)))
+                src4_0.setdefault(l, []).append(tab.source_level(s_lv[l], f.K, klds[m].to(dev)))
                 Hl, Wl = t_lv[l].shape[-2:]
                 packed = torch.empty(1, Hl, Wl, 4, dtype=torch.float32, device=dev)
                 _lib.check(lib.sp_pack_rgba(_lib.ptr(t_lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(packed), _lib.stream_ptr()),
                            "sp_pack_rgba")
-                self.trg4.setdefault(l, []).append(packed.reshape(-1))
-                self.level_hw.setdefault(l, []).append((Hl, Wl))
-        self.pix = cat(pix_list)          # after source_level(): validity bits are set
-        self.src4 = {l: cat(v) for l, v in self.src4.items()}
-        trg_off = {l: np.concatenate(([0], np.cumsum([x.numel() for x in v]))) for l, v in self.trg4.items()}
-        self.trg4 = {l: cat(v) for l, v in self.trg4.items()}
+                trg4_0.setdefault(l, []).append(packed.reshape(-1))
+                hw_0.setdefault(l, []).append((Hl, Wl))
+        self.pix = cat([t.pix for t in tables])          # after source_level(): validity bits are set
+        self.src4 = {l: cat([v[b] for b in base]) for l, v in src4_0.items()}
+        trg_off = {l: np.concatenate(([0], np.cumsum([v[b].numel() for b in base]))) for l, v in trg4_0.items()}
+        self.trg4 = {l: cat([v[b] for b in base]) for l, v in trg4_0.items()}
+        self.level_hw = {l: [v[b] for b in base] for l, v in hw_0.items()}
 
         # work list
         tiles, stos, t_off = [], [], [0]
@@ -100,7 +110,7 @@ class PairBatch:
         self.desc = {}
         for l in self.level_ids:
             arr = (_lib.SpPair * M)()
-            for m, (f, tab) in enumerate(zip(src_frames, tables)):
+            for m, (f, tab) in enumerate(zip(frames, tables)):
                 d = arr[m]
                 d.pix = self.pix.data_ptr() + 4 * int(p_off[m])
                 d.src4 = self.src4[l].data_ptr() + 16 * int(p_off[m])
@@ -111,7 +121,7 @@ class PairBatch:
                 d.aff = (self.aff.data_ptr() + 16 * m) if use_affine else None
                 d.seg_tile_off = self.seg_tile_off.data_ptr() + 4 * int(sto_off[m])
                 Ks = f.K.detach().float().cpu().numpy()
-                Kt = trg_Ks[m].detach().float().cpu().numpy()
+                Kt = trg_Ks[base[m]].detach().float().cpu().numpy()
                 d.K_src = (ctypes.c_float * 4)(Ks[0, 0], Ks[1, 1], Ks[0, 2], Ks[1, 2])
                 d.K_trg = (ctypes.c_float * 4)(Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
                 d.N, d.P, d.H, d.W = tab.N, tab.P, tab.H, tab.W
@@ -128,7 +138,7 @@ class PairBatch:
         self.lm_state = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
         self.backup = torch.zeros(M, 16 + self.max_N, dtype=torch.float32, device=dev)
         self.reset_lm()
-        self._keep = (tables,)
+        self._keep = (tables0,)
 
     # ------------------------------------------------------------------------------------------------
     @classmethod
