@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=96, help="frame pairs resident per GPU")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
-    ap.add_argument("--tile-points", type=int, default=2048)
+    ap.add_argument("--tile-points", type=int, default=8192)
     ap.add_argument("--mode", choices=["gn", "adam"], default="gn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8)

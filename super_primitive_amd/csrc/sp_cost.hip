@@ -12,55 +12,133 @@ namespace {
 
 // Everything a tile needs; filled from kernel arguments (single source, B targets) or from an SpPair record.
 struct TileCtx {
-    const uint32_t* __restrict__ pix;
-    const float4* __restrict__ src4;
-    const float4* __restrict__ trg4;
+    gptr_u32 pix;
+    gptr_f4 src4;
+    gptr_f4 trg4;
     Cam Ks;
     Warp w;
     float shift;      // kld[n] - kp_L[n]
     float gain, bias; // exp(-(a_t-a_s)), b_t-b_s
+    float ax, ay;     // level pixels per geometry pixel: (Wl-1)/(W-1), (Hl-1)/(H-1)
     int Wl, Hl;
     int start, count;
 };
 
 // -----------------------------------------------------------------------------------------------------
+// The tile loop is a three-stage software pipeline; one trip handles three different points:
+//
+//     top     issue the (pix, src4) stream of point j+1           (HBM, read once, non-temporal)
+//             issue the four bilinear taps of point j             (target image; L1/L2, first touch from HBM)
+//     middle  fold point j-1 into the accumulators                (pure arithmetic, covers the loads above)
+//     bottom  finish point j: channel mixing of its taps  ->  a handful of scalars carried to the next trip
+//             geometry of point j+1: exp, unproject, SE(3), project, validity, tap offsets
+//
+// Every load is consumed in the trip that issued it, *after* the arithmetic of the previous point, so a wave
+// does not sit in s_waitcnt right behind its own gathers and the compiler has no reason to sink the loads.
+// All loads are buffer loads (32-bit offsets, SGPR descriptors): out-of-range lanes -- the tail of a tile --
+// read zeros, i.e. a pix word whose validity bit is clear, so the loop needs neither clamps nor branches.
+// Invalid points (outside the 0.99 band, behind the camera, masked source pixel) sample texel (0,0) and carry
+// zinv = 0, m = 0: they add exact zeros.
+// -----------------------------------------------------------------------------------------------------
+struct Geo {               // what the accumulation of a point needs from its geometry
+    float qx, qy, qz;      // point in the target camera
+    float zinv, zi;        // m * guarded 1/qz ; m * (1/qz or 0 on the guarded branch, where d(1/z) = 0)
+    float px, py, pz;      // point in the source camera (gradient mode: dq/dR)
+};
+
+struct Pending {           // a point whose taps are about to be / have just been issued
+    Geo g;
+    float wx, wy, m;
+    float sr, sg, sb;      // source colour
+    uint32_t off0, off1;   // byte offsets of texels (x0,y0) and (x0,y1)
+};
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void __attribute__((address_space(1)))* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+template <int AUX>
+__device__ __forceinline__ f32x4 buf_load4(rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX));
+}
+
+__device__ __forceinline__ void prepare(const TileCtx& c, float ifx, float ify, uint32_t pw, const f32x4 s, Pending& p) {
+    float col, row; bool src_ok;
+    decode_pix(pw, col, row, src_ok);
+    const float d = expf(s.w + c.shift);
+    float x, y;
+    backproject(col, row, d, c.Ks, ifx, ify, x, y);
+    PointGeom g;
+    warp_point(c.w, x, y, d, g);
+    const bool ok = g.valid && src_ok && (d > 1e-7f);
+    p.m = ok ? 1.f : 0.f;
+    p.g.px = x; p.g.py = y; p.g.pz = d;
+    p.g.qx = g.qx; p.g.qy = g.qy; p.g.qz = g.qz;
+    p.g.zinv = ok ? g.zinv : 0.f;
+    p.g.zi = (ok && g.zguard) ? g.zinv : 0.f;
+    p.sr = s.x; p.sg = s.y; p.sb = s.z;
+    const float ix = ok ? g.ix : 0.f, iy = ok ? g.iy : 0.f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    p.wx = ix - fx0;
+    p.wy = iy - fy0;
+    // valid => 0 <= x0 <= Wl-2, 0 <= y0 <= Hl-2 (0.99 band, Wl,Hl >= 2 checked on the host)
+    p.off0 = ((uint32_t)(int)fy0 * (uint32_t)c.Wl + (uint32_t)(int)fx0) * 16u;
+    p.off1 = p.off0 + (uint32_t)c.Wl * 16u;
+}
+
+// bilinear value and both slopes of one channel from its four taps
+__device__ __forceinline__ void tap_mix(float a, float b, float cc, float d, float wx, float wy, float& it, float& Ix,
+                                        float& Iy) {
+    const float e1 = b - a, e2 = cc - a, e3 = (d - cc) - e1;
+    Iy = fmaf(wx, e3, e2);
+    Ix = fmaf(wy, e3, e1);
+    it = fmaf(wy, Iy, fmaf(wx, e1, a));
+}
+
+// -----------------------------------------------------------------------------------------------------
 // mode 0: gradient accumulators
 //   [0] sum |r|      [1..3] g_t      [4..12] g_R (row-major)     [13] g_kld(segment of the tile)
 //   [14] d/da_t      [15] d/db_t          (all still to be scaled by 1/(3P))
+// carried per point: Mix0 = {sum_ch s_ch Ix_ch, sum_ch s_ch Iy_ch, sum_ch s_ch I_ch, sum_ch s_ch}, s_ch = sign(r_ch)
 // -----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void accumulate_grad(const TileCtx& c, const PointGeom& g, const float4 s,
-                                                float (&acc)[SP_GRAD_PARTIAL_FLOATS]) {
-    Taps tp;
-    fetch_taps(c.trg4, c.Wl, c.Hl, g.ix, g.iy, tp);
-    const float itr = bilerp(tp.t00.x, tp.t10.x, tp.t01.x, tp.t11.x, tp.wx, tp.wy);
-    const float itg = bilerp(tp.t00.y, tp.t10.y, tp.t01.y, tp.t11.y, tp.wx, tp.wy);
-    const float itb = bilerp(tp.t00.z, tp.t10.z, tp.t01.z, tp.t11.z, tp.wx, tp.wy);
-    const float dr = s.x - fmaf(c.gain, itr, c.bias);
-    const float dg = s.y - fmaf(c.gain, itg, c.bias);
-    const float db = s.z - fmaf(c.gain, itb, c.bias);
-    acc[0] += fabsf(dr) + fabsf(dg) + fabsf(db);
-    const float sr = sgn(dr), sg = sgn(dg), sb = sgn(db);
-    // sign-weighted channel mix of each tap, then the two bilinear slopes of the mix
-    const float m00 = sr * tp.t00.x + sg * tp.t00.y + sb * tp.t00.z;
-    const float m10 = sr * tp.t10.x + sg * tp.t10.y + sb * tp.t10.z;
-    const float m01 = sr * tp.t01.x + sg * tp.t01.y + sb * tp.t01.z;
-    const float m11 = sr * tp.t11.x + sg * tp.t11.y + sb * tp.t11.z;
-    const float mx = fmaf(tp.wy, (m11 - m01) - (m10 - m00), m10 - m00);
-    const float my = fmaf(tp.wx, (m11 - m10) - (m01 - m00), m01 - m00);
-    // d|r|/d(u,v): -gain * slope * (level px per geometry px)
-    const float gu = -c.gain * mx * (2.f * c.w.sx * c.w.invWm1);
-    const float gv = -c.gain * my * (2.f * c.w.sy * c.w.invHm1);
-    const float a = gu * c.w.Kt.fx * g.zinv, b = gv * c.w.Kt.fy * g.zinv;
-    const float gqx = a, gqy = b;
-    const float gqz = g.zguard ? -(a * g.qx + b * g.qy) * g.zinv : 0.f;
-    acc[1] += gqx; acc[2] += gqy; acc[3] += gqz;
-    acc[4] = fmaf(gqx, g.px, acc[4]);  acc[5] = fmaf(gqx, g.py, acc[5]);  acc[6] = fmaf(gqx, g.pz, acc[6]);
-    acc[7] = fmaf(gqy, g.px, acc[7]);  acc[8] = fmaf(gqy, g.py, acc[8]);  acc[9] = fmaf(gqy, g.pz, acc[9]);
+struct Mix0 { float gx, gy, s1, s0; };
+
+__device__ __forceinline__ void finish_grad(const TileCtx& c, const Pending& p, const f32x4 a, const f32x4 b,
+                                            const f32x4 cc, const f32x4 d, Mix0& o, float& cost_acc) {
+    const float ta[3] = {a.x, a.y, a.z}, tb[3] = {b.x, b.y, b.z}, tc[3] = {cc.x, cc.y, cc.z}, td[3] = {d.x, d.y, d.z};
+    const float sv[3] = {p.sr, p.sg, p.sb};
+    float gx = 0.f, gy = 0.f, s1 = 0.f, s0 = 0.f, cost = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float it, Ix, Iy;
+        tap_mix(ta[ch], tb[ch], tc[ch], td[ch], p.wx, p.wy, it, Ix, Iy);
+        const float r = sv[ch] - fmaf(c.gain, it, c.bias);
+        cost += fabsf(r);
+        const float sg = sgn(r);
+        gx = fmaf(sg, Ix, gx);
+        gy = fmaf(sg, Iy, gy);
+        s1 = fmaf(sg, it, s1);
+        s0 += sg;
+    }
+    cost_acc = fmaf(p.m, cost, cost_acc);
+    o.gx = gx; o.gy = gy; o.s1 = p.m * s1; o.s0 = p.m * s0;
+}
+
+__device__ __forceinline__ void fold_grad(const TileCtx& c, const Geo& g, const Mix0& w,
+                                          float (&acc)[SP_GRAD_PARTIAL_FLOATS]) {
+    // d|r|/dq through  I_trg' = gain * I(ix,iy) + bias,  ix = (u ...) * ax,  u = fx qx / qz + cx
+    const float a = -(c.gain * c.ax * c.w.Kt.fx) * w.gx * g.zinv;
+    const float b = -(c.gain * c.ay * c.w.Kt.fy) * w.gy * g.zinv;
+    const float gqz = -(a * g.qx + b * g.qy) * g.zi;
+    acc[1] += a; acc[2] += b; acc[3] += gqz;
+    acc[4] = fmaf(a, g.px, acc[4]);    acc[5] = fmaf(a, g.py, acc[5]);    acc[6] = fmaf(a, g.pz, acc[6]);
+    acc[7] = fmaf(b, g.px, acc[7]);    acc[8] = fmaf(b, g.py, acc[8]);    acc[9] = fmaf(b, g.pz, acc[9]);
     acc[10] = fmaf(gqz, g.px, acc[10]); acc[11] = fmaf(gqz, g.py, acc[11]); acc[12] = fmaf(gqz, g.pz, acc[12]);
     // d p / d kld_n = p  =>  d q / d kld_n = R p = q - t
-    acc[13] += gqx * (g.qx - c.w.t[0]) + gqy * (g.qy - c.w.t[1]) + gqz * (g.qz - c.w.t[2]);
-    acc[14] += c.gain * (sr * itr + sg * itg + sb * itb);
-    acc[15] -= sr + sg + sb;
+    acc[13] += a * (g.qx - c.w.t[0]) + b * (g.qy - c.w.t[1]) + gqz * (g.qz - c.w.t[2]);
+    acc[14] = fmaf(c.gain, w.s1, acc[14]);
+    acc[15] -= w.s0;
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -69,86 +147,151 @@ __device__ __forceinline__ void accumulate_grad(const TileCtx& c, const PointGeo
 //   [36] number of valid points   [37..39] unused
 // r_ch = I_src - I_trg';  J_ch = c_ch * A,  A (2x7) shared by the channels,  c_ch = -gain*[dI/dix, dI/diy];
 // IRLS weight of the L1 cost w_ch = 1/max(|r_ch|, eps)  =>  b = J^T sign(r) for |r| > eps.
+// carried per point: Mix1 = {sum w Ix Ix, sum w Ix Iy, sum w Iy Iy, sum w r Ix, sum w r Iy}
+// A = diag(ga, gb) * Ahat with Ahat0 = [1, 0, -ux, -ux qy, qz + ux qx, -qy, ex - ux ez],
+//                              Ahat1 = [0, 1, -vy, -(qz + vy qy), vy qx, qx, ey - vy ez]   (ux = qx/qz, vy = qy/qz):
+// the two unit columns make rows 0 and 1 of H plain sums of B = W' Ahat.
 // -----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void accumulate_gn(const TileCtx& c, const PointGeom& g, const float4 s, float eps,
-                                              float (&acc)[SP_GN_PARTIAL_FLOATS]) {
-    Taps tp;
-    fetch_taps(c.trg4, c.Wl, c.Hl, g.ix, g.iy, tp);
-    const float tr[3][4] = {{tp.t00.x, tp.t10.x, tp.t01.x, tp.t11.x},
-                            {tp.t00.y, tp.t10.y, tp.t01.y, tp.t11.y},
-                            {tp.t00.z, tp.t10.z, tp.t01.z, tp.t11.z}};
-    const float sv[3] = {s.x, s.y, s.z};
+struct Mix1 { float w00, w01, w11, v0, v1; };
+
+__device__ __forceinline__ void finish_gn(const TileCtx& c, const Pending& p, const f32x4 a, const f32x4 b,
+                                          const f32x4 cc, const f32x4 d, float eps, Mix1& o, float& cost_acc, float& n_acc) {
+    const float ta[3] = {a.x, a.y, a.z}, tb[3] = {b.x, b.y, b.z}, tc[3] = {cc.x, cc.y, cc.z}, td[3] = {d.x, d.y, d.z};
+    const float sv[3] = {p.sr, p.sg, p.sb};
     float w00 = 0.f, w01 = 0.f, w11 = 0.f, v0 = 0.f, v1 = 0.f, cost = 0.f;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const float dx0 = tr[ch][1] - tr[ch][0], dx1 = tr[ch][3] - tr[ch][2];
-        const float dy0 = tr[ch][2] - tr[ch][0], dy1 = tr[ch][3] - tr[ch][1];
-        const float it = bilerp(tr[ch][0], tr[ch][1], tr[ch][2], tr[ch][3], tp.wx, tp.wy);
-        const float Ix = fmaf(tp.wy, dx1 - dx0, dx0);
-        const float Iy = fmaf(tp.wx, dy1 - dy0, dy0);
+        float it, Ix, Iy;
+        tap_mix(ta[ch], tb[ch], tc[ch], td[ch], p.wx, p.wy, it, Ix, Iy);
         const float r = sv[ch] - fmaf(c.gain, it, c.bias);
         const float ar = fabsf(r);
         cost += ar;
         const float wgt = __builtin_amdgcn_rcpf(fmaxf(ar, eps));
-        w00 = fmaf(wgt * Ix, Ix, w00);
-        w01 = fmaf(wgt * Ix, Iy, w01);
-        w11 = fmaf(wgt * Iy, Iy, w11);
-        v0 = fmaf(wgt * r, Ix, v0);
-        v1 = fmaf(wgt * r, Iy, v1);
+        const float wx_ = wgt * Ix, wy_ = wgt * Iy;
+        w00 = fmaf(wx_, Ix, w00);
+        w01 = fmaf(wx_, Iy, w01);
+        w11 = fmaf(wy_, Iy, w11);
+        v0 = fmaf(wx_, r, v0);
+        v1 = fmaf(wy_, r, v1);
     }
-    const float g2 = c.gain * c.gain;
-    w00 *= g2; w01 *= g2; w11 *= g2;
-    v0 *= -c.gain; v1 *= -c.gain;
-    // A = diag(alpha) * Jproj * [I | -[q]x | q - t]
-    const float zi = g.zguard ? g.zinv : 0.f;   // d(1/z) vanishes on the guarded branch
-    const float a = (2.f * c.w.sx * c.w.invWm1) * c.w.Kt.fx * g.zinv;
-    const float b = (2.f * c.w.sy * c.w.invHm1) * c.w.Kt.fy * g.zinv;
-    const float ux = g.qx * zi, vy = g.qy * zi;
-    const float ex = g.qx - c.w.t[0], ey = g.qy - c.w.t[1], ez = g.qz - c.w.t[2];
-    const float A0[7] = {a, 0.f, -a * ux, -a * ux * g.qy, a * (g.qz + ux * g.qx), -a * g.qy, a * (ex - ux * ez)};
-    const float A1[7] = {0.f, b, -b * vy, -b * (g.qz + vy * g.qy), b * vy * g.qx, b * g.qx, b * (ey - vy * ez)};
-    float B0[7], B1[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j) {
-        B0[j] = fmaf(w00, A0[j], w01 * A1[j]);
-        B1[j] = fmaf(w01, A0[j], w11 * A1[j]);
-    }
-    acc[0] += cost;
-    int k = 1;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) { acc[k] = fmaf(A0[i], B0[j], fmaf(A1[i], B1[j], acc[k])); ++k; }
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[22 + i] = fmaf(A0[i], v0, fmaf(A1[i], v1, acc[22 + i]));
-#pragma unroll
-    for (int i = 0; i < 6; ++i) acc[28 + i] = fmaf(A0[i], B0[6], fmaf(A1[i], B1[6], acc[28 + i]));
-    acc[34] = fmaf(A0[6], B0[6], fmaf(A1[6], B1[6], acc[34]));
-    acc[35] = fmaf(A0[6], v0, fmaf(A1[6], v1, acc[35]));
-    acc[36] += 1.f;
+    cost_acc = fmaf(p.m, cost, cost_acc);
+    n_acc += p.m;
+    o.w00 = w00; o.w01 = w01; o.w11 = w11; o.v0 = v0; o.v1 = v1;
 }
 
-template <int MODE>
+__device__ __forceinline__ void fold_gn(const TileCtx& c, const Geo& g, const Mix1& w, float (&acc)[SP_GN_PARTIAL_FLOATS]) {
+    const float ga = (c.gain * c.ax * c.w.Kt.fx) * g.zinv;     // zinv carries the validity mask
+    const float gb = (c.gain * c.ay * c.w.Kt.fy) * g.zinv;
+    const float W00 = w.w00 * (ga * ga), W01 = w.w01 * (ga * gb), W11 = w.w11 * (gb * gb);
+    const float V0 = -w.v0 * ga, V1 = -w.v1 * gb;
+    const float ux = g.qx * g.zi, vy = g.qy * g.zi;
+    const float ex = g.qx - c.w.t[0], ey = g.qy - c.w.t[1], ez = g.qz - c.w.t[2];
+    // columns 2..6 of Ahat
+    const float A0[5] = {-ux, -ux * g.qy, fmaf(ux, g.qx, g.qz), -g.qy, fmaf(-ux, ez, ex)};
+    const float A1[5] = {-vy, -fmaf(vy, g.qy, g.qz), vy * g.qx, g.qx, fmaf(-vy, ez, ey)};
+    float B0[5], B1[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        B0[j] = fmaf(W00, A0[j], W01 * A1[j]);
+        B1[j] = fmaf(W01, A0[j], W11 * A1[j]);
+    }
+    // H_pp upper triangle, row-major: (0,0..5) = acc[1..6], (1,1..5) = acc[7..11], (2,2..5) = acc[12..15],
+    // (3,3..5) = acc[16..18], (4,4..5) = acc[19..20], (5,5) = acc[21]
+    acc[1] += W00; acc[2] += W01;
+    acc[3] += B0[0]; acc[4] += B0[1]; acc[5] += B0[2]; acc[6] += B0[3];
+    acc[7] += W11;
+    acc[8] += B1[0]; acc[9] += B1[1]; acc[10] += B1[2]; acc[11] += B1[3];
+    int k = 12;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = i; j < 4; ++j) { acc[k] = fmaf(A0[i], B0[j], fmaf(A1[i], B1[j], acc[k])); ++k; }
+    // b_p
+    acc[22] += V0; acc[23] += V1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[24 + i] = fmaf(A0[i], V0, fmaf(A1[i], V1, acc[24 + i]));
+    // coupling with the segment's log-depth (column 6), its diagonal and right-hand side
+    acc[28] += B0[4]; acc[29] += B1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[30 + i] = fmaf(A0[i], B0[4], fmaf(A1[i], B1[4], acc[30 + i]));
+    acc[34] = fmaf(A0[4], B0[4], fmaf(A1[4], B1[4], acc[34]));
+    acc[35] = fmaf(A0[4], V0, fmaf(A1[4], V1, acc[35]));
+}
+
+// ABL (developer ablation, only reachable through mode >= 10 of sp_pairs_cost): 0 = product kernel,
+// 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation)
+template <int MODE, int ABL = 0>
 __device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float* __restrict__ out, float* lds) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
     const float ifx = 1.f / c.Ks.fx, ify = 1.f / c.Ks.fy;
-    for (int i = threadIdx.x; i < c.count; i += SP_BLOCK) {
-        const uint32_t pw = c.pix[c.start + i];
-        const float4 s = c.src4[c.start + i];
-        float col, row; bool src_ok;
-        decode_pix(pw, col, row, src_ok);
-        const float d = expf(s.w + c.shift);
-        float x, y;
-        backproject(col, row, d, c.Ks, ifx, ify, x, y);
-        PointGeom g;
-        warp_point(c.w, x, y, d, g);
-        if (g.valid && src_ok && d > 1e-7f) {
-            if (MODE == 0) accumulate_grad(c, g, s, reinterpret_cast<float(&)[SP_GRAD_PARTIAL_FLOATS]>(acc));
-            else accumulate_gn(c, g, s, irls_eps, reinterpret_cast<float(&)[SP_GN_PARTIAL_FLOATS]>(acc));
+    const rsrc_t r_pix = make_rsrc(c.pix + c.start, (uint32_t)c.count * 4u);
+    const rsrc_t r_src = make_rsrc(c.src4 + c.start, (uint32_t)c.count * 16u);
+    const rsrc_t r_trg = make_rsrc(c.trg4, (uint32_t)c.Wl * (uint32_t)c.Hl * 16u);
+    const int n_iter = (c.count + SP_BLOCK - 1) / SP_BLOCK;
+    uint32_t i = threadIdx.x;
+    constexpr int NT = 2;   // aux: non-temporal
+    // prologue: geometry of point 0
+    Pending nx;
+    {
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)(i * 4u), 0, NT);
+        const f32x4 s = buf_load4<NT>(r_src, i * 16u);
+        prepare(c, ifx, ify, pw, s, nx);
+    }
+    Geo cur = nx.g;
+    cur.zinv = 0.f; cur.zi = 0.f;      // "point -1": contributes exact zeros
+    Mix0 m0{0.f, 0.f, 0.f, 0.f};
+    Mix1 m1{0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < n_iter; ++j) {
+        // ---- top: issue everything this trip will need -------------------------------------------
+        i += SP_BLOCK;
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)(i * 4u), 0, NT);
+        const f32x4 s = buf_load4<NT>(r_src, i * 16u);
+        f32x4 ta, tb, tc, td;
+        if (ABL == 1) { ta = tb = tc = td = f32x4{nx.sr, nx.sg, nx.sb, 0.f}; }
+        else {
+            ta = buf_load4<0>(r_trg, nx.off0);
+            tb = buf_load4<0>(r_trg, nx.off0 + 16u);
+            tc = buf_load4<0>(r_trg, nx.off1);
+            td = buf_load4<0>(r_trg, nx.off1 + 16u);
         }
+        // The machine scheduler otherwise sinks the gathers below the arithmetic to shorten their live range
+        // (register pressure heuristics): pin the three sections in source order.
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- middle: fold the previous point (arithmetic only) ----------------------------------
+        if (ABL != 2) {
+            if (MODE == 0) fold_grad(c, cur, m0, reinterpret_cast<float(&)[SP_GRAD_PARTIAL_FLOATS]>(acc));
+            else fold_gn(c, cur, m1, reinterpret_cast<float(&)[SP_GN_PARTIAL_FLOATS]>(acc));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- bottom: finish this point's channel mixing, geometry of the next -------------------
+        // An empty asm that "rewrites" the tap registers: the only place their wait (s_waitcnt) may land, and
+        // a data dependency that keeps instruction selection from starting the channel mixing before the fold.
+        // The accumulators the fold just updated are operands too, so the fold cannot drift below this point.
+        if (ABL != 1) {
+            if (MODE == 0)
+                asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                             "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]));
+            else
+                asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]),
+                             "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[24]),
+                             "+v"(acc[25]), "+v"(acc[26]), "+v"(acc[27]), "+v"(acc[30 % NV]), "+v"(acc[31 % NV]), "+v"(acc[32 % NV]),
+                             "+v"(acc[33 % NV]), "+v"(acc[34 % NV]), "+v"(acc[35 % NV]));
+        }
+        if (ABL == 2) acc[0] += ta.x + tb.y + tc.z + td.x + nx.wx + nx.wy + nx.m;
+        else if (MODE == 0) finish_grad(c, nx, ta, tb, tc, td, m0, acc[0]);
+        else finish_gn(c, nx, ta, tb, tc, td, irls_eps, m1, acc[0], acc[NV - 4]);
+        cur = nx.g;
+        uint32_t pw_ = pw;
+        f32x4 s_ = s;
+        asm volatile("" : "+v"(pw_), "+v"(s_));
+        prepare(c, ifx, ify, pw_, s_, nx);
+    }
+    if (ABL != 2) {
+        if (MODE == 0) fold_grad(c, cur, m0, reinterpret_cast<float(&)[SP_GRAD_PARTIAL_FLOATS]>(acc));
+        else fold_gn(c, cur, m1, reinterpret_cast<float(&)[SP_GN_PARTIAL_FLOATS]>(acc));
     }
     const float total = block_sum_to_thread<NV>(acc, lds);
     if (threadIdx.x < NV) out[threadIdx.x] = total;
@@ -164,6 +307,8 @@ __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const C
     c.w.sy = 0.5f * (float)(Hl - 1);
     c.w.zmin = zmin;
     c.Wl = Wl; c.Hl = Hl;
+    c.ax = 2.f * c.w.sx * c.w.invWm1;
+    c.ay = 2.f * c.w.sy * c.w.invHm1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -184,8 +329,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_single_grad(SingleArgs a, flo
     const int b = blockIdx.y;
     const int4 tile = a.tiles[t];   // {pair(unused), segment, start, count}
     TileCtx c;
-    c.pix = a.pix; c.src4 = a.src4;
-    c.trg4 = a.trg4 + (size_t)b * a.Hl * a.Wl;
+    c.pix = (gptr_u32)a.pix; c.src4 = (gptr_f4)a.src4;
+    c.trg4 = (gptr_f4)(a.trg4 + (size_t)b * a.Hl * a.Wl);
     load_cam(a.K_src, c.Ks);
     Cam Kt; load_cam(a.K_trg + 9 * b, Kt);
     fill_warp(c, a.pose + 16 * b, Kt, a.H, a.W, a.Hl, a.Wl, a.zmin);
@@ -235,7 +380,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_finalise_single(const float* __res
 // ------------------------------------------------------------------------------------------------
 // many independent pairs: grid = n_tiles_total
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int ABL = 0>
 __global__ __launch_bounds__(SP_BLOCK) void k_cost_pairs(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
                                                          int n_tiles, float irls_eps, float* __restrict__ partials) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
@@ -245,9 +390,9 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_pairs(const SpPair* __restric
     const int4 tile = tiles[t];
     const SpPair& pr = pairs[tile.x];
     TileCtx c;
-    c.pix = pr.pix;
-    c.src4 = reinterpret_cast<const float4*>(pr.src4);
-    c.trg4 = reinterpret_cast<const float4*>(pr.trg4);
+    c.pix = (gptr_u32)pr.pix;
+    c.src4 = (gptr_f4)pr.src4;
+    c.trg4 = (gptr_f4)pr.trg4;
     c.Ks = Cam{pr.K_src[0], pr.K_src[1], pr.K_src[2], pr.K_src[3]};
     const Cam Kt{pr.K_trg[0], pr.K_trg[1], pr.K_trg[2], pr.K_trg[3]};
     fill_warp(c, pr.pose, Kt, pr.H, pr.W, pr.Hl, pr.Wl, pr.zmin);
@@ -258,7 +403,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_pairs(const SpPair* __restric
         c.bias = pr.aff[3] - pr.aff[1];
     }
     c.start = tile.z; c.count = tile.w;
-    run_tile<MODE>(c, irls_eps, partials + (size_t)t * NV, lds);
+    run_tile<MODE, ABL>(c, irls_eps, partials + (size_t)t * NV, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -312,7 +457,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_stats(StatsArgs a) {
     PointGeom g;
     warp_point(c.w, x, y, d, g);
     Taps tp;
-    fetch_taps(a.trg4 + (size_t)b * a.Hl * a.Wl, a.Wl, a.Hl, g.ix, g.iy, tp);
+    fetch_taps((gptr_f4)(a.trg4 + (size_t)b * a.Hl * a.Wl), a.Wl, a.Hl, g.ix, g.iy, tp);
     const float it[3] = {fmaf(gain, bilerp(tp.t00.x, tp.t10.x, tp.t01.x, tp.t11.x, tp.wx, tp.wy), bias),
                          fmaf(gain, bilerp(tp.t00.y, tp.t10.y, tp.t01.y, tp.t11.y, tp.wx, tp.wy), bias),
                          fmaf(gain, bilerp(tp.t00.z, tp.t10.z, tp.t01.z, tp.t11.z, tp.wx, tp.wy), bias)};
@@ -379,14 +524,23 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
 
 int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int mode, float irls_eps,
                   float* partials, void* stream) {
-    if (!pairs || !tiles || !partials || n_tiles_total <= 0 || (mode != 0 && mode != 1)) return SP_EINVAL;
+    if (!pairs || !tiles || !partials || n_tiles_total <= 0) return SP_EINVAL;
+    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_tiles_total + 7) / 8) * 8;
     const int4* t4 = reinterpret_cast<const int4*>(tiles);
     if (mode == 0)
         hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
-    else
+    else if (mode == 1)
         hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+    else if (mode == 10)   /* developer ablations, see run_tile */
+        hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+    else if (mode == 11)
+        hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+    else if (mode == 12)
+        hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+    else
+        hipLaunchKernelGGL((k_cost_pairs<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -8,6 +8,19 @@
 #define SP_BLOCK 256            // 4 wavefronts of 64
 #define SP_WAVES (SP_BLOCK / 64)
 
+// Explicit global (address space 1) pointers: pointers that reach a kernel through a struct in memory are
+// otherwise treated as generic and compile to flat_load (slower path, also occupies the LDS counter).
+typedef const uint32_t __attribute__((address_space(1)))* gptr_u32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: loadable straight from address space 1
+typedef const f32x4 __attribute__((address_space(1)))* gptr_f4;
+typedef const float __attribute__((address_space(1)))* gptr_f32;
+
+// streaming (read-once) 16-byte load: non-temporal so the source stream does not evict the target images from L2
+__device__ __forceinline__ float4 ntload4(gptr_f4 p) {
+    const f32x4 v = __builtin_nontemporal_load(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 #define SP_CHECK_LAUNCH()                          \
     do {                                           \
         hipError_t e__ = hipGetLastError();        \
@@ -24,14 +37,45 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // Reduce NV per-thread accumulators over the block; thread k < NV ends up holding the total of value k.
+//
+// Wave stage = recursive halving ("reduce-scatter" over lanes): at lane distance 32, 16, ... 1 the two halves
+// of every lane pair split the surviving values between them, swap the halves they give up and add -- NV/2 +
+// NV/4 + ... cross-lane moves in total (41 for NV = 40) instead of 6 per value (240) for a butterfly per value.
+// The order of additions is fixed by the lane numbering, so results stay bitwise reproducible.
+template <int N, int OFF>
+__device__ __forceinline__ void halve_step(float* v, bool upper) {
+    constexpr int H = (N + 1) / 2;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        const float lo = v[k];
+        const float hi = (k + H < N) ? v[k + H] : 0.f;
+        const float keep = upper ? hi : lo;
+        const float give = upper ? lo : hi;
+        v[k] = keep + __shfl_xor(give, OFF, 64);
+    }
+}
+
 template <int NV>
 __device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* lds /* SP_WAVES*NV floats */) {
+    static_assert(NV <= 64, "one value per lane at most");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        float s = wave_sum(acc[k]);
-        if (lane == 0) lds[wave * NV + k] = s;
-    }
+    constexpr int N0 = NV, N1 = (N0 + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
+    halve_step<N0, 32>(acc, lane & 32);
+    halve_step<N1, 16>(acc, lane & 16);
+    halve_step<N2, 8>(acc, lane & 8);
+    halve_step<N3, 4>(acc, lane & 4);
+    halve_step<N4, 2>(acc, lane & 2);
+    halve_step<N5, 1>(acc, lane & 1);
+    // which of the NV values this lane now holds in acc[0] (walk the levels backwards), if any
+    int pos = 0;
+    bool ok = true;
+    if (lane & 1)  { pos += (N5 + 1) / 2; ok = ok && pos < N5; }
+    if (lane & 2)  { pos += (N4 + 1) / 2; ok = ok && pos < N4; }
+    if (lane & 4)  { pos += (N3 + 1) / 2; ok = ok && pos < N3; }
+    if (lane & 8)  { pos += (N2 + 1) / 2; ok = ok && pos < N2; }
+    if (lane & 16) { pos += (N1 + 1) / 2; ok = ok && pos < N1; }
+    if (lane & 32) { pos += (N0 + 1) / 2; ok = ok && pos < N0; }
+    if (ok) lds[wave * NV + pos] = acc[0];
     __syncthreads();
     float total = 0.f;
     if (threadIdx.x < NV) {
@@ -117,8 +161,7 @@ struct Taps {
     float wx, wy;
 };
 
-__device__ __forceinline__ void fetch_taps(const float4* __restrict__ img, int Wl, int Hl, float ix, float iy,
-                                           Taps& tp) {
+__device__ __forceinline__ void fetch_taps(gptr_f4 img, int Wl, int Hl, float ix, float iy, Taps& tp) {
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     tp.wx = ix - fx0;
     tp.wy = iy - fy0;
@@ -128,13 +171,14 @@ __device__ __forceinline__ void fetch_taps(const float4* __restrict__ img, int W
     const bool iny0 = (y0 >= 0) & (y0 < Hl), iny1 = (y1 >= 0) & (y1 < Hl);
     const int cx0 = min(max(x0, 0), Wl - 1), cx1 = min(max(x1, 0), Wl - 1);
     const int cy0 = min(max(y0, 0), Hl - 1), cy1 = min(max(y1, 0), Hl - 1);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 a = img[cy0 * Wl + cx0], b = img[cy0 * Wl + cx1];
-    const float4 c = img[cy1 * Wl + cx0], d = img[cy1 * Wl + cx1];
-    tp.t00 = (inx0 & iny0) ? a : z;
-    tp.t10 = (inx1 & iny0) ? b : z;
-    tp.t01 = (inx0 & iny1) ? c : z;
-    tp.t11 = (inx1 & iny1) ? d : z;
+    const f32x4 a = img[cy0 * Wl + cx0], b = img[cy0 * Wl + cx1];
+    const f32x4 c = img[cy1 * Wl + cx0], d = img[cy1 * Wl + cx1];
+    const float m00 = (inx0 & iny0) ? 1.f : 0.f, m10 = (inx1 & iny0) ? 1.f : 0.f;
+    const float m01 = (inx0 & iny1) ? 1.f : 0.f, m11 = (inx1 & iny1) ? 1.f : 0.f;
+    tp.t00 = make_float4(a.x * m00, a.y * m00, a.z * m00, 0.f);
+    tp.t10 = make_float4(b.x * m10, b.y * m10, b.z * m10, 0.f);
+    tp.t01 = make_float4(c.x * m01, c.y * m01, c.z * m01, 0.f);
+    tp.t11 = make_float4(d.x * m11, d.y * m11, d.z * m11, 0.f);
 }
 
 __device__ __forceinline__ float bilerp(float a00, float a10, float a01, float a11, float wx, float wy) {

@@ -22,7 +22,7 @@ from .. import _lib
 from ..image import gaussian_pyramid
 from ..segment_table import SegmentTable, make_tiles
 
-DEFAULT_BATCH_TILE_POINTS = 2048
+DEFAULT_BATCH_TILE_POINTS = 8192   # one workgroup per segment up to 8192 px: amortises the tile prologue/epilogue
 
 
 def _level_images(img, max_level):

@@ -26,8 +26,10 @@ def _ident(t):
     return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
 
 
-def make_tiles(counts, tile_points, pair=0, first_point=0):
-    """Host-side work list: split every segment into runs of at most ``tile_points`` points.
+def make_tiles(counts, tile_points, pair=0, first_point=0, granule=256):
+    """Host-side work list: split every segment into ceil(count / tile_points) runs of (nearly) EQUAL length,
+    each a multiple of ``granule`` (= the workgroup size, so every trip of the tile loop is full) except the
+    last.  Equal runs matter: one workgroup per tile, and a 4096 + 1733 split costs as much as two 4096 tiles.
 
     Returns (tiles int32 (T,4) = {pair, segment, start, count}, seg_tile_off int32 (N+1,))."""
     counts = np.asarray(counts, dtype=np.int64)
@@ -40,11 +42,13 @@ def make_tiles(counts, tile_points, pair=0, first_point=0):
         seg = np.repeat(np.arange(len(counts)), n_t)
         within = np.arange(T) - np.repeat(seg_tile_off[:-1], n_t)
         seg_start = np.concatenate(([0], np.cumsum(counts)[:-1]))
-        start = within * tile_points
+        size = (counts + np.maximum(n_t, 1) - 1) // np.maximum(n_t, 1)          # ceil(count / n_t)
+        size = (size + granule - 1) // granule * granule
+        start = within * size[seg]
         tiles[:, 0] = pair
         tiles[:, 1] = seg
         tiles[:, 2] = first_point + seg_start[seg] + start
-        tiles[:, 3] = np.minimum(tile_points, counts[seg] - start)
+        tiles[:, 3] = np.clip(counts[seg] - start, 0, size[seg])
     return tiles, seg_tile_off
 
 

@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Kernel micro-bench (developer tool): times sp_pairs_cost (both modes) on a streaming batch with HIP events.
+
+    python tools/kbench.py [--pairs 64] [--tile-points 2048] [--reps 20]
+"""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=64)
+    ap.add_argument("--distinct", type=int, default=2)
+    ap.add_argument("--tile-points", type=int, default=2048)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--levels", default="0")
+    ap.add_argument("--modes", default="0,1")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    batch, _ = bench.build_batch(a, 0, dev)
+    for _ in range(3):
+        batch.gn_step(0)
+    for level in [int(x) for x in a.levels.split(",")]:
+        for mode in [int(x) for x in a.modes.split(",")]:
+            for _ in range(3):
+                batch.cost_pass(level, mode)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+            torch.cuda.synchronize()
+            for e0, e1 in ev:
+                e0.record(); batch.cost_pass(level, mode); e1.record()
+            torch.cuda.synchronize()
+            ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
+            by = batch.algorithmic_bytes(level)
+            print(f"level {level} mode {mode} pairs {batch.M} tiles {batch.n_tiles}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
+                  f"alg {by/1e6:.1f} MB -> {by/np.median(ms)/1e6:.0f} GB/s ({by/np.median(ms)/1e6/8000*100:.1f}% of 8 TB/s)  "
+                  f"{sum(batch.Ps)/np.median(ms)/1e6:.2f} Gpt/s")
+
+
+if __name__ == "__main__":
+    main()
