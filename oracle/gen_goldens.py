@@ -47,7 +47,8 @@ from oracle import photometric_oracle as orc  # noqa: E402  (only for se3_exp in
 
 
 def T(a, dtype=torch.float32):
-    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    # always a private copy: optimisers below update tensors in place and must not touch the arrays that get saved
+    return torch.from_numpy(np.array(a, copy=True)).to(dtype)
 
 
 def ref_frames(ref, pair, level_images=None):

@@ -166,3 +166,55 @@ def test_se3_exp_matches_matrix_exponential():
         M[:3, 3] = xi[:3]
         got = orc.se3_exp(torch.from_numpy(xi)[None])[0].numpy()
         np.testing.assert_allclose(got, expm(M), rtol=1e-9, atol=1e-12)
+
+
+# ---- G9: K-step Adam trajectories of the three caller loop shapes, replayed with the oracle cost ------------
+def test_traj_sfm_loop():
+    g = load_golden("g9a_traj_sfm")
+    src, trg = frames(g)
+    sp, tp = orc.frame_pyramid(src, 0, 2), orc.frame_pyramid(trg, 0, 2)
+    kld = torch.nn.Parameter(T(g["in_kld"]).clone())
+    a = torch.nn.Parameter(torch.zeros(1, 6))
+    T0 = T(g["in_pose_init"])
+    opt = torch.optim.Adam([{"params": kld, "lr": 1e-3}, {"params": [a], "lr": 1e-2}], lr=1e-3)
+    losses, count = [], 0
+    for s, t in zip(sp, tp):
+        for _ in range(int(g["steps"])):
+            out = orc.photometric_cost(s, t, kld, orc.se3_exp(a)[0] @ T0)
+            loss = out["residual"].abs().mean()
+            losses.append(float(loss.detach()))
+            if count > 0:
+                loss.backward()
+                opt.step()
+                opt.zero_grad()
+            count += 1
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3)
+    np.testing.assert_allclose(kld.detach().numpy(), g["final_kld"], atol=1e-4)
+    np.testing.assert_allclose((orc.se3_exp(a.detach())[0] @ T0).numpy(), g["final_pose"], atol=1e-4)
+
+
+def test_traj_tracking_loop():
+    g = load_golden("g9b_traj_track")
+    src, trg = frames(g)
+    with torch.no_grad():
+        pre = orc.unproject_keyframe(src, T(g["in_kld"]))
+    delta = torch.nn.Parameter(torch.zeros(1, 6))
+    aff = torch.nn.Parameter(torch.zeros(2))
+    opt = torch.optim.Adam([{"params": [delta], "lr": 5e-3}, {"params": [aff], "lr": 5e-3}], lr=5e-3)
+    supp_T = orc.invert_se3(T(g["in_pose_init"]))
+    losses = []
+    for _ in range(int(g["steps"])):
+        pose = orc.se3_exp(delta)[0] @ orc.invert_se3(supp_T) @ torch.eye(4)
+        out = orc.photometric_cost_precomputed(pre, trg, pose, affine=(torch.zeros(2), aff))
+        loss = out["residual"].mean()
+        losses.append(float(loss.detach()))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        with torch.no_grad():
+            supp_T = supp_T @ orc.invert_se3(orc.se3_exp(delta.detach())[0])
+            delta.data.zero_()
+    supp_T = orc.renormalise_se3(supp_T)
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-3)
+    np.testing.assert_allclose(supp_T.numpy(), g["final_supp_T"], atol=1e-4)
+    np.testing.assert_allclose(aff.detach().numpy(), g["final_aff"], atol=1e-4)
