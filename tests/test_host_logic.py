@@ -1,0 +1,194 @@
+"""CPU-only: host-side logic (work-list construction, synthetic scenes, SE(3) glue, API surface) and the C ABI
+library: it loads and exports every symbol include/sp_hip.h declares.  No compute kernel is called."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from super_primitive_amd import _lib
+    header = open(os.path.join(ROOT, "include", "sp_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\bint\s+(sp_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no prototypes parsed"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.sp_abi_version() == _lib.SP_ABI_VERSION
+    # argument counts of the ctypes table match the prototypes
+    for name in declared:
+        proto = re.search(r"\bint\s+" + name + r"\s*\((.*?)\)\s*;", header, flags=re.S).group(1).strip()
+        n = 0 if proto in ("void", "") else proto.count(",") + 1
+        assert n == len(_lib.SIGNATURES[name]), name
+
+
+def test_abi_constants_and_struct_layout_match_header():
+    from super_primitive_amd import _lib
+    header = open(os.path.join(ROOT, "include", "sp_hip.h")).read()
+    for macro in ("SP_ABI_VERSION", "SP_GRAD_PARTIAL_FLOATS", "SP_GN_PARTIAL_FLOATS", "SP_LM_STATE_FLOATS"):
+        val = int(re.search(r"#define\s+" + macro + r"\s+(\d+)", header).group(1))
+        assert getattr(_lib, macro) == val, macro
+    assert ctypes.sizeof(_lib.SpPair) == 136
+    assert _lib.SpPair.K_src.offset == 64 and _lib.SpPair.N.offset == 96 and _lib.SpPair.zmin.offset == 128
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation happens before any HIP call, so it can be exercised here."""
+    from super_primitive_amd import _lib
+    lib = _lib.load()
+    assert lib.sp_pairs_cost(None, None, 0, 0, 0.0, None, None) == -1
+    assert lib.sp_blur_decimate(None, 3, 10, 10, None, None) == -1
+    assert lib.sp_renormalise_se3(None, 1, None) == -1
+    with pytest.raises(RuntimeError, match="SP_EINVAL"):
+        _lib.check(-1, "x")
+
+
+def test_cpu_tensors_are_refused_by_the_product_path():
+    from super_primitive_amd import synth
+    from super_primitive_amd.core import dense_optim, dense_optim_batch
+    from super_primitive_amd.core.depth_render import estimate_depth_kf_native
+    from super_primitive_amd.image.keyframe import KeyFrame
+    pair = synth.make_pair(24, 32, 2, seed=1)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    src = KeyFrame(c(pair.src_image), c(pair.K), c(pair.logdepth_perseg), c(pair.keypoints), c(pair.keypoint_regions))
+    trg = KeyFrame(c(pair.trg_image), c(pair.K))
+    cfg = {"mode": "colour", "collect_stats": 0}
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        dense_optim.photomeric_cost(src, trg, c(pair.kld_init), c(pair.pose_init), cfg)
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        dense_optim_batch.photomeric_cost_batch(src, c(pair.trg_image)[None], c(pair.K)[None], c(pair.kld_init),
+                                                c(pair.pose_init)[None], cfg)
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        dense_optim.unproject_kf(src, c(pair.kld_init))
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        estimate_depth_kf_native(src, c(pair.kld_init))
+    with pytest.raises(NotImplementedError):
+        dense_optim.photomeric_cost(src, trg, c(pair.kld_init), c(pair.pose_init), {"mode": "colour_norm", "collect_stats": 0})
+
+
+def test_product_path_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under super_primitive_amd/ may import it."""
+    pkg = os.path.join(ROOT, "super_primitive_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+@pytest.mark.parametrize("counts,tp", [([5829, 0, 100, 4096, 4097, 513], 4096), ([1], 256), ([300000, 7], 8192), ([0, 0, 5], 1024)])
+def test_make_tiles_partitions_every_segment(counts, tp):
+    from super_primitive_amd.segment_table import make_tiles
+    tiles, off = make_tiles(counts, tp, pair=3, first_point=10)
+    assert off[0] == 0 and off[-1] == len(tiles) and len(off) == len(counts) + 1
+    pos = 10
+    for n, c in enumerate(counts):
+        mine = tiles[off[n]:off[n + 1]]
+        assert (mine[:, 0] == 3).all() and (mine[:, 1] == n).all()
+        assert (mine[:, 3] > 0).all() and (mine[:, 3] <= tp).all()
+        assert mine[:, 3].sum() == c
+        if len(mine):
+            assert mine[0, 2] == pos and np.array_equal(mine[1:, 2], mine[:-1, 2] + mine[:-1, 3])
+            assert (mine[:-1, 3] % 256 == 0).all()
+            assert mine[:, 3].max() - mine[:, 3].min() <= 256 + (mine[:, 3].max() - mine[-1, 3])
+        pos += c
+
+
+def test_synth_pair_is_deterministic_and_consistent():
+    from super_primitive_amd import synth
+    a, b = synth.make_pair(40, 56, 6, seed=5, shape="blobs"), synth.make_pair(40, 56, 6, seed=5, shape="blobs")
+    for f in ("src_image", "trg_image", "logdepth_perseg", "keypoints", "kld_gt", "pose_gt", "pose_init"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert a.keypoint_regions.dtype == bool and a.keypoint_regions.shape == (6, 40, 56)
+    assert np.all(a.logdepth_perseg[~a.keypoint_regions] == 0)
+    rc = np.round(0.5 * (np.array([40, 56]) - 1) * (a.keypoints + 1)).astype(int)
+    for n in range(6):
+        assert a.keypoint_regions[n, rc[n, 0], rc[n, 1]]
+    R = a.pose_gt[:3, :3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+    assert 0 <= a.src_image.min() and a.src_image.max() <= 1
+
+
+def test_se3_parameter_matches_matrix_exponential_and_autograd():
+    from scipy.linalg import expm
+    from super_primitive_amd.lie.se3 import SE3, LieGroupParameter, se3_exp_matrix
+    rng = np.random.default_rng(0)
+    for scale in (0.0, 1e-5, 0.2, 1.5):
+        xi = rng.standard_normal(6) * scale
+        M = np.zeros((4, 4))
+        M[:3, :3] = [[0, -xi[5], xi[4]], [xi[5], 0, -xi[3]], [-xi[4], xi[3], 0]]
+        M[:3, 3] = xi[:3]
+        np.testing.assert_allclose(se3_exp_matrix(torch.from_numpy(xi)[None])[0].numpy(), expm(M), rtol=1e-9, atol=1e-12)
+    X = SE3.exp(torch.tensor([[0.1, -0.2, 0.3, 0.2, 0.1, -0.3]]))
+    p = LieGroupParameter(X)
+    assert p.is_leaf and p.requires_grad and tuple(p.shape) == (1, 6) and float(p.abs().sum()) == 0
+    T = p.retr().matrix()[0]
+    np.testing.assert_allclose(T.detach().numpy(), X.matrix()[0].numpy(), atol=1e-7)      # Exp(0) * X
+    T[:3, 3].sum().backward()
+    assert torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+    # left retraction: d t / d tau = I at a = 0
+    np.testing.assert_allclose(p.grad[0, :3].numpy(), np.ones(3), atol=1e-6)
+    # group round trips
+    Y = SE3.InitFromVec(X.vec())
+    np.testing.assert_allclose(Y.matrix().numpy(), X.matrix().numpy(), atol=1e-6)
+    np.testing.assert_allclose(X.mul(X.inv()).matrix()[0].numpy(), np.eye(4), atol=1e-6)
+
+
+def test_reference_module_surface_is_present():
+    """Names the reference's drivers import."""
+    import super_primitive_amd.core.dense_optim as do
+    import super_primitive_amd.core.dense_optim_batch as dob
+    import super_primitive_amd.core.ops as ops
+    import super_primitive_amd.core.depth_render as dr
+    import super_primitive_amd.image.gaussian_pyramid as gp
+    import super_primitive_amd.image.keyframe as kf
+    import super_primitive_amd.lie.lie_algebra as la
+    import super_primitive_amd.lie.lietorch_utils as lu
+    import super_primitive_amd.tool.point_utils as pu
+    import super_primitive_amd.odometery.depth_init as di
+    for mod, names in [
+        (do, "photomeric_cost photomeric_cost_precomputed unproject_kf unproject_kf_to_depths infer_depth_seeds expdepth "
+             "unproject_segments unproject_points transform_points img_interp get_pixels affine_compensation_batch_v2 "
+             "calculate_residual project_points infer_spatial_size"),
+        (dob, "photomeric_cost_batch get_pixels_batch"),
+        (ops, "transform_points_batch project_points_batch project_points transform_points unproject_points_mat estimate_depth_diff"),
+        (dr, "estimate_depth_kf_native"),
+        (gp, "GaussianBlurModule ImagePyramidModule DepthPyramidModule IntrinsicsPyramidModule pyr_depth resize_intrinsics resize_depth"),
+        (kf, "KeyFrame keyframe_pyramid put_keypoints_back put_keypoints_back_kf infer_spatial_size"),
+        (la, "quaternion_to_matrix renormalise_se3 torch_pose_to_tq matrix_to_q_torch pose_to_tq tq_to_pose se3_exp batch_se3 "
+             "invertSE3 normalizeSE3_inplace SO3_expmap SO3_logmap skew_symmetric SE3_logmap"),
+        (lu, "lietorch_detach lietorch_new_param zero_out_lietorch_tensor mat_to_lie print_pose"),
+        (pu, "normalise_coordinates denormalise_coordinates normalise_coordinates_np denormalise_coordinates_np"),
+        (di, "segment_based_depth_reinit"),
+    ]:
+        for n in names.split():
+            assert hasattr(mod, n), f"{mod.__name__}.{n}"
+
+
+def test_install_as_reference_modules_aliases_the_packages():
+    import importlib
+    import sys
+    import super_primitive_amd
+    saved = {k: sys.modules.get(k) for k in ("core", "core.dense_optim", "image", "lie", "tool", "odometery", "depth_completion")}
+    try:
+        super_primitive_amd.install_as_reference_modules()
+        import core.dense_optim as do
+        from super_primitive_amd.core import dense_optim
+        assert do is dense_optim
+        assert importlib.import_module("image.keyframe").KeyFrame is super_primitive_amd.image.keyframe.KeyFrame
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        for k in list(sys.modules):
+            if k.split(".")[0] in ("core", "image", "lie", "tool", "odometery", "depth_completion") and k not in saved:
+                sys.modules.pop(k, None)
