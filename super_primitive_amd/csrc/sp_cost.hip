@@ -66,7 +66,7 @@ __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, uint32_t off) {
 __device__ __forceinline__ void prepare(const TileCtx& c, float ifx, float ify, uint32_t pw, const f32x4 s, Pending& p) {
     float col, row; bool src_ok;
     decode_pix(pw, col, row, src_ok);
-    const float d = expf(s.w + c.shift);
+    const float d = fast_exp(s.w + c.shift);
     float x, y;
     backproject(col, row, d, c.Ks, ifx, ify, x, y);
     PointGeom g;
