@@ -195,7 +195,7 @@ def main():
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         p0 = pairs[0]
         one = PairBatch([KeyFrame(t(p0.src_image), t(p0.K), t(p0.logdepth_perseg), t(p0.keypoints), t(p0.keypoint_regions))],
-                        [t(p0.trg_image)], [t(p0.K)], t(p0.pose_init)[None], [t(p0.kld_init)], levels=(0, 3), tile_points=512)
+                        [t(p0.trg_image)], [t(p0.K)], t(p0.pose_init)[None], [t(p0.kld_init)], levels=(0, 3), tile_points=2048)
         for _ in range(5):
             one.gn_step(0)
         torch.cuda.synchronize()
@@ -204,6 +204,14 @@ def main():
             one.gn_step(0)
         torch.cuda.synchronize()
         line["single_pair_gn_iters_per_sec"] = 200 / (time.perf_counter() - t1)
+        g = one.graph(0, "gn", iters=20)          # same loop as a hipGraph: 20 iterations per replay
+        g.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            g.replay()
+        torch.cuda.synchronize()
+        line["single_pair_gn_iters_per_sec_hipgraph"] = 200 / (time.perf_counter() - t1)
         iters = 10
         torch.cuda.synchronize()
         t1 = time.perf_counter()

@@ -33,6 +33,29 @@ __device__ __forceinline__ double reduce_column(const float* __restrict__ p, int
     return block_sum_d(s, lds);
 }
 
+// All NV columns of the pair's tile partials summed over its tiles, into out[NV] (LDS).  Thread (g, c) = (tid / NV,
+// tid % NV) walks tiles g, g+G, ... of column c: neighbouring threads read neighbouring floats of one 4*NV-byte
+// tile record (coalesced), every thread's loads are independent (pipelined), and the G group partials are added
+// in fixed order -- one barrier, bitwise reproducible.
+template <int NV>
+__device__ __forceinline__ void reduce_columns(const float* __restrict__ p, int n_tiles, double* out, double* scratch) {
+    constexpr int G = SP_BLOCK / NV;
+    const int g = threadIdx.x / NV, c = threadIdx.x - g * NV;
+    if (g < G) {
+        double s = 0.0;
+        for (int t = g; t < n_tiles; t += G) s += (double)p[(size_t)t * NV + c];
+        scratch[g * NV + c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < G; ++k) s += scratch[k * NV + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
 // Exp of a twist [tau, phi] (left-multiplied onto T in place): T <- Exp(xi) * T, all in fp64.
 __device__ void se3_retract_left(const double xi[6], float* T16) {
     const double wx = xi[3], wy = xi[4], wz = xi[5];
@@ -40,9 +63,15 @@ __device__ void se3_retract_left(const double xi[6], float* T16) {
     double A, B, C;
     if (th2 < 1e-12) {
         A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; C = 1.0 / 6.0 - th2 / 120.0;
+    } else if (th2 < 1e-4) {
+        // 3-term series: exact to < 1e-12 for theta < 0.01 and immune to the cancellation in 1-cos, th-sin
+        A = 1.0 - th2 / 6.0 * (1.0 - th2 / 20.0);
+        B = 0.5 - th2 / 24.0 * (1.0 - th2 / 30.0);
+        C = 1.0 / 6.0 - th2 / 120.0 * (1.0 - th2 / 42.0);
     } else {
         const double th = sqrt(th2);
-        A = sin(th) / th; B = (1.0 - cos(th)) / th2; C = (th - sin(th)) / (th2 * th);
+        const double sn = sin(th), cs = cos(th);
+        A = sn / th; B = (1.0 - cs) / th2; C = (th - sn) / (th2 * th);
     }
     const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
     double W2[9];
@@ -81,16 +110,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_adam(const SpPair* __restric
                                                          const float* __restrict__ partials, float lr_kld, float lr_pose,
                                                          float lr_aff, float* __restrict__ state, float* __restrict__ losses) {
     constexpr int NV = SP_GRAD_PARTIAL_FLOATS;
-    __shared__ double lds[SP_WAVES];
     __shared__ double sums[NV];
+    __shared__ double scratch[(SP_BLOCK / NV) * NV];
     const SpPair& pr = pairs[blockIdx.x];
     const float* p = partials + (size_t)pr.tile0 * NV;
-    for (int k = 0; k < NV; ++k) {
-        if (k == 13) continue;
-        const double s = reduce_column<NV>(p, pr.n_tiles, k, lds);
-        if (threadIdx.x == 0) sums[k] = s;
-    }
-    __syncthreads();
+    reduce_columns<NV>(p, pr.n_tiles, sums, scratch);      // (column 13 is per segment: its global sum is unused)
     const double scale = 1.0 / (3.0 * (double)pr.P);
     const float residual = (float)(sums[0] * scale);
     // loss = |residual| (two_frame_sfm.py:201): d loss / d residual = sign(residual)
@@ -143,31 +167,55 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_adam(const SpPair* __restric
 //                               [2] #accepted  [3] #rejected  [4] 1 if the previous call rejected  [5] last cost seen
 #define SP_LM_STRIDE SP_LM_STATE_FLOATS
 
-__device__ bool cholesky6_solve(double S[36], double rhs[6]) {
-    // in-place lower Cholesky of the symmetric 6x6 S, then solve S x = rhs (x returned in rhs)
+// Solve the symmetric positive definite 6x6 system S x = rhs by LDL^T (no square roots, six reciprocals);
+// x is returned in rhs.  false if a pivot is not positive.
+__device__ bool ldlt6_solve(double S[36], double rhs[6]) {
+    double dinv[6];
     for (int j = 0; j < 6; ++j) {
         double d = S[7 * j];
-        for (int k = 0; k < j; ++k) d -= S[6 * j + k] * S[6 * j + k];
+        for (int k = 0; k < j; ++k) d -= S[6 * j + k] * S[6 * j + k] * S[7 * k];
         if (!(d > 0.0)) return false;
-        d = sqrt(d);
         S[7 * j] = d;
+        dinv[j] = 1.0 / d;
         for (int i = j + 1; i < 6; ++i) {
             double v = S[6 * i + j];
-            for (int k = 0; k < j; ++k) v -= S[6 * i + k] * S[6 * j + k];
-            S[6 * i + j] = v / d;
+            for (int k = 0; k < j; ++k) v -= S[6 * i + k] * S[6 * j + k] * S[7 * k];
+            S[6 * i + j] = v * dinv[j];
         }
     }
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 6; ++i) {            // L y = rhs
         double v = rhs[i];
         for (int k = 0; k < i; ++k) v -= S[6 * i + k] * rhs[k];
-        rhs[i] = v / S[7 * i];
+        rhs[i] = v;
     }
-    for (int i = 5; i >= 0; --i) {
+    for (int i = 0; i < 6; ++i) rhs[i] *= dinv[i];
+    for (int i = 5; i >= 0; --i) {           // L^T x = y
         double v = rhs[i];
         for (int k = i + 1; k < 6; ++k) v -= S[6 * k + i] * rhs[k];
-        rhs[i] = v / S[7 * i];
+        rhs[i] = v;
     }
     return true;
+}
+
+#define SP_SEG_CACHE 256     // segments whose reduced {h(6), 1/D', b_d} live in LDS; beyond that they are recomputed
+
+// {h_pd(6), D, b_d} of segment n summed over its tiles; lam -> {h, 1/(D(1+lam)) or 0, b_d}
+__device__ __forceinline__ void segment_system(const float* __restrict__ p, const int32_t* __restrict__ seg_tile_off, int n,
+                                               double lam, double (&o)[8]) {
+    constexpr int NV = SP_GN_PARTIAL_FLOATS;
+    double h[6] = {0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
+    for (int t = seg_tile_off[n]; t < seg_tile_off[n + 1]; ++t) {
+        const float* q = p + (size_t)t * NV;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) h[i] += (double)q[28 + i];
+        D += (double)q[34];
+        bd += (double)q[35];
+    }
+    const double Dd = D * (1.0 + lam);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = h[i];
+    o[6] = Dd > 1e-12 ? 1.0 / Dd : 0.0;
+    o[7] = bd;
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict__ pairs, int max_N,
@@ -175,8 +223,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
                                                        float lm_min, float* __restrict__ lm_state, float* __restrict__ backup,
                                                        float* __restrict__ costs) {
     constexpr int NV = SP_GN_PARTIAL_FLOATS;
-    __shared__ double lds[SP_WAVES];
-    __shared__ double sums[28];      // [0] cost, [1..21] Hpp upper, [22..27] b_p
+    __shared__ double sums[NV];      // [0] cost, [1..21] Hpp upper, [22..27] b_p (columns >= 28 are per segment)
+    __shared__ double scratch[(SP_BLOCK / NV) * NV];
+    __shared__ double seg[SP_SEG_CACHE][8];
+    __shared__ double schur_part[8][27];
     __shared__ double schur[27];     // 21 + 6
     __shared__ double dxi[6];
     __shared__ int decision;         // 0 = step, 1 = rejected (restore)
@@ -184,11 +234,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
     const float* p = partials + (size_t)pr.tile0 * NV;
     float* ls = lm_state + (size_t)blockIdx.x * SP_LM_STRIDE;
     float* bk = backup + (size_t)blockIdx.x * (16 + max_N);
-    for (int k = 0; k < 28; ++k) {
-        const double s = reduce_column<NV>(p, pr.n_tiles, k, lds);
-        if (threadIdx.x == 0) sums[k] = s;
-    }
-    __syncthreads();
+    reduce_columns<NV>(p, pr.n_tiles, sums, scratch);
     const double cost = sums[0] / (3.0 * (double)pr.P);
     if (threadIdx.x == 0) {
         const float last = ls[1];
@@ -212,34 +258,42 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
     // back up the point we are about to leave
     for (int i = threadIdx.x; i < 16; i += SP_BLOCK) bk[i] = pr.pose[i];
     for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) bk[16 + n] = pr.kld[n];
-    // Schur complement of the diagonal depth block
-    double sc[27];
+    // per-segment reduced systems into LDS
+    const int n_cached = min(pr.N, SP_SEG_CACHE);
+    for (int n = threadIdx.x; n < n_cached; n += SP_BLOCK) {
+        double o[8];
+        segment_system(p, pr.seg_tile_off, n, lam, o);
 #pragma unroll
-    for (int k = 0; k < 27; ++k) sc[k] = 0.0;
-    for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
-        double h[6] = {0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
-        for (int t = pr.seg_tile_off[n]; t < pr.seg_tile_off[n + 1]; ++t) {
-            const float* q = p + (size_t)t * NV;
+        for (int i = 0; i < 8; ++i) seg[n][i] = o[i];
+    }
+    __syncthreads();
+    // Schur complement of the diagonal depth block: 27 sums over the segments, thread (k, j) takes value k over
+    // segments j, j+8, ... ; the 8 partials per value are combined in fixed order
+    {
+        const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
+        if (k < 27) {
+            // upper-triangle index k -> (a, b); k >= 21 -> (k - 21, "b_d")
+            int a = 0, b = 0;
+            if (k < 21) { int rem = k, row = 0; while (rem >= 6 - row) { rem -= 6 - row; ++row; } a = row; b = row + rem; }
+            else a = k - 21;
+            double acc = 0.0;
+            for (int n = j; n < pr.N; n += 8) {
+                double o[8];
+                if (n < SP_SEG_CACHE) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) h[i] += (double)q[28 + i];
-            D += (double)q[34];
-            bd += (double)q[35];
-        }
-        const double Dd = D * (1.0 + lam);
-        if (Dd > 1e-12) {
-            const double inv = 1.0 / Dd;
-            int k = 0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-#pragma unroll
-                for (int j = i; j < 6; ++j) sc[k++] += h[i] * h[j] * inv;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) sc[21 + i] += h[i] * bd * inv;
+                    for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
+                } else segment_system(p, pr.seg_tile_off, n, lam, o);
+                acc += o[a] * (k < 21 ? o[b] : o[7]) * o[6];
+            }
+            schur_part[j][k] = acc;
         }
     }
-    for (int k = 0; k < 27; ++k) {
-        const double s = block_sum_d(sc[k], lds);
-        if (threadIdx.x == 0) schur[k] = s;
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += schur_part[j][threadIdx.x];
+        schur[threadIdx.x] = v;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -253,31 +307,27 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
                 ++k;
             }
         for (int i = 0; i < 6; ++i) rhs[i] = -(sums[22 + i] - schur[21 + i]);
-        const bool ok = cholesky6_solve(S, rhs);
+        const bool ok = ldlt6_solve(S, rhs);
         for (int i = 0; i < 6; ++i) dxi[i] = ok ? rhs[i] : 0.0;
         ls[0] = lambda; ls[1] = (float)cost; ls[2] += 1.f; ls[4] = 0.f;
     }
     __syncthreads();
     for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
-        double h[6] = {0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
-        for (int t = pr.seg_tile_off[n]; t < pr.seg_tile_off[n + 1]; ++t) {
-            const float* q = p + (size_t)t * NV;
+        double o[8];
+        if (n < SP_SEG_CACHE) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) h[i] += (double)q[28 + i];
-            D += (double)q[34];
-            bd += (double)q[35];
-        }
-        const double Dd = D * (1.0 + lam);
-        if (Dd > 1e-12) {
-            double r = -bd;
+            for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
+        } else segment_system(p, pr.seg_tile_off, n, lam, o);
+        if (o[6] > 0.0) {
+            double r = -o[7];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) r -= h[i] * dxi[i];
-            double dd = r / Dd;
+            for (int i = 0; i < 6; ++i) r -= o[i] * dxi[i];
+            double dd = r * o[6];
             dd = fmin(fmax(dd, -0.5), 0.5);   // trust region on one log-depth step (factor e^0.5 in depth)
             pr.kld[n] += (float)dd;
         }
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 64) {                  // a different wave than the one that just solved: no reason, just parallel
         double xi[6];
         for (int i = 0; i < 6; ++i) xi[i] = dxi[i];
         se3_retract_left(xi, pr.pose);

@@ -138,6 +138,7 @@ class PairBatch:
         self.lm_state = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
         self.backup = torch.zeros(M, 16 + self.max_N, dtype=torch.float32, device=dev)
         self.reset_lm()
+        self._graphs = {}
         self._keep = (tables0,)
 
     # ------------------------------------------------------------------------------------------------
@@ -188,14 +189,39 @@ class PairBatch:
         P = torch.tensor(self.Ps, dtype=torch.float64, device=self.device)
         return (sums / (3.0 * P)).float()
 
-    def run(self, iters_per_level, mode="gn", **kw):
-        """Coarse-to-fine schedule like ``two_frame_sfm.py:150-155``: ``iters_per_level`` iterations at each level."""
+    def graph(self, level, mode="gn", iters=1, **kw):
+        """Capture ``iters`` optimiser iterations at ``level`` (2 launches each, no host interaction) into a hipGraph
+        and return it; ``g.replay()`` re-runs them.  The graph bakes in device pointers only -- poses, log-depths,
+        LM / Adam state all live in device memory -- so it stays valid until the batch is rebuilt."""
+        step = self.gn_step if mode == "gn" else self.adam_step
+        step(level, **kw)                      # warm-up outside capture (module load, lazy init)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                step(level, **kw)
+        return g
+
+    def run(self, iters_per_level, mode="gn", use_graph=False, **kw):
+        """Coarse-to-fine schedule like ``two_frame_sfm.py:150-155``: ``iters_per_level`` iterations at each level.
+        ``use_graph``: replay one captured iteration per level instead of issuing 2 launches per iteration from
+        Python (the captured warm-up iteration counts towards ``iters_per_level``)."""
         for level in reversed(self.level_ids):
             if mode == "gn":
                 self.lm_state[:, 1] = -1.0      # costs of different levels are not comparable
                 self.lm_state[:, 4] = 0.0
-            for _ in range(iters_per_level):
-                (self.gn_step if mode == "gn" else self.adam_step)(level, **kw)
+            if use_graph:
+                key = (level, mode, tuple(sorted(kw.items())))
+                g = self._graphs.get(key)
+                done = 0
+                if g is None:
+                    g = self._graphs[key] = self.graph(level, mode, 1, **kw)
+                    done = 1                     # graph() ran one real warm-up iteration; capturing executes nothing
+                for _ in range(iters_per_level - done):
+                    g.replay()
+            else:
+                for _ in range(iters_per_level):
+                    (self.gn_step if mode == "gn" else self.adam_step)(level, **kw)
 
     # ------------------------------------------------------------------------------------------------
     def costs(self):

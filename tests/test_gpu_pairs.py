@@ -211,3 +211,16 @@ def test_full_size_bitwise_determinism_and_descent(full_size):
     s = np.exp(np.median(klds[0] - pair.kld_gt))
     assert rot_angle(poses[0][:3, :3] @ pair.pose_gt[:3, :3].T) < 1e-3
     np.testing.assert_allclose(klds[0] - np.log(s), pair.kld_gt, atol=3e-3)
+
+
+def test_hipgraph_replay_matches_eager_iterations():
+    """The two-launch iteration captured in a hipGraph gives bitwise the same trajectory as eager launches."""
+    from super_primitive_amd import synth
+    pairs = [synth.make_pair(60, 80, 6, seed=90 + k, init_sigma=0.02) for k in range(3)]
+    a = make_batch(pairs, levels=(0, 2))
+    b = make_batch(pairs, levels=(0, 2))
+    a.run(6, mode="gn")
+    b.run(6, mode="gn", use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a.pose, b.pose) and torch.equal(a.kld, b.kld)
+    assert torch.equal(a.lm_state, b.lm_state)
