@@ -190,6 +190,11 @@ int sp_depth_average(const uint32_t* pix, const float* baseL, const int32_t* seg
                      const float* kld, const uint8_t* visible, int N, int P, int H, int W, void* acc,
                      float* out_depth, uint8_t* out_invalid, void* stream);
 
+/* The pose parameter of the reference's drivers, T[b] = Exp(a[b]) * X[b]  (a = [tau, phi] (n,6); X, T (n,4,4)):
+ * lietorch's LieGroupParameter.retr().matrix() at odometery/two_frame_sfm.py:83-84, odometery/odometery.py:224-228.
+ * grad_T == NULL: forward, writes T.  grad_T != NULL: backward, writes grad_a[b] = (dT/da)^T grad_T[b] (n,6). */
+int sp_se3_retract(const float* a, const float* X, int n, float* T, const float* grad_T, float* grad_a, void* stream);
+
 /* lie/lie_algebra.py:41-47 renormalise_se3 on n row-major 4x4 matrices, in place. */
 int sp_renormalise_se3(float* T, int n, void* stream);
 

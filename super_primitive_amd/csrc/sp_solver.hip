@@ -356,6 +356,96 @@ __global__ void k_renormalise(float* __restrict__ T, int n) {
     M[8] = s * (x * z - y * r);       M[9] = s * (y * z + x * r);       M[10] = 1.f - s * (x * x + y * y);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Pose parameter of the reference's drivers: T = Exp(a) * X with a = [tau, phi] (lietorch LieGroupParameter.retr()
+// followed by .matrix(), odometery/two_frame_sfm.py:83-84, odometery/odometery.py:224-228).  As eager torch code
+// the exponential and its autograd graph are ~100 tiny launches (1.5 ms per iteration measured); here forward
+// and backward are one launch each.  The backward pass differentiates the very same code with forward-mode dual
+// numbers (6 tangents at once), so value and derivative cannot drift apart, also at a = 0.
+// ---------------------------------------------------------------------------------------------------
+template <int ND>
+struct Dual {
+    float v;
+    float d[ND];
+};
+template <int ND> __device__ __forceinline__ Dual<ND> dconst(float c) { Dual<ND> r; r.v = c; for (int i = 0; i < ND; ++i) r.d[i] = 0.f; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator+(const Dual<ND>& a, const Dual<ND>& b) { Dual<ND> r; r.v = a.v + b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND>& a, const Dual<ND>& b) { Dual<ND> r; r.v = a.v - b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND>& a) { Dual<ND> r; r.v = -a.v; for (int i = 0; i < ND; ++i) r.d[i] = -a.d[i]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND>& a, const Dual<ND>& b) { Dual<ND> r; r.v = a.v * b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> operator*(float a, const Dual<ND>& b) { Dual<ND> r; r.v = a * b.v; for (int i = 0; i < ND; ++i) r.d[i] = a * b.d[i]; return r; }
+template <int ND> __device__ __forceinline__ Dual<ND> chain(const Dual<ND>& a, float f, float df) { Dual<ND> r; r.v = f; for (int i = 0; i < ND; ++i) r.d[i] = df * a.d[i]; return r; }
+
+// T(3x4) = Exp(a) * X(3x4) on dual numbers; the three coefficient functions are evaluated in theta^2
+template <int ND>
+__device__ void se3_exp_times(const Dual<ND> (&a)[6], const float* __restrict__ X16, Dual<ND> (&T)[12]) {
+    const Dual<ND> th2 = a[3] * a[3] + a[4] * a[4] + a[5] * a[5];
+    const float t2 = th2.v;
+    float A, B, C, dA, dB, dC;     // values and derivatives with respect to theta^2
+    {   // evaluated in fp64: the closed forms cancel badly in fp32 for theta < ~0.5 (1 - cos, theta - sin)
+        const double t = (double)t2;
+        double a_, b_, c_, da_, db_, dc_;
+        if (t < 1e-6) {
+            a_ = 1.0 - t / 6.0 * (1.0 - t / 20.0);           da_ = -1.0 / 6.0 + t / 60.0;
+            b_ = 0.5 - t / 24.0 * (1.0 - t / 30.0);           db_ = -1.0 / 24.0 + t / 360.0;
+            c_ = 1.0 / 6.0 - t / 120.0 * (1.0 - t / 42.0);    dc_ = -1.0 / 120.0 + t / 2520.0;
+        } else {
+            const double th = sqrt(t), sn = sin(th), cs = cos(th);
+            a_ = sn / th; b_ = (1.0 - cs) / t; c_ = (th - sn) / (t * th);
+            // d/d(theta^2) = (1 / (2 theta)) d/dtheta
+            da_ = (cs * th - sn) / (2.0 * t * th);
+            db_ = (sn * th - 2.0 * (1.0 - cs)) / (2.0 * t * t);
+            dc_ = ((1.0 - cs) * th - 3.0 * (th - sn)) / (2.0 * t * t * th);
+        }
+        A = (float)a_; B = (float)b_; C = (float)c_; dA = (float)da_; dB = (float)db_; dC = (float)dc_;
+    }
+    const Dual<ND> dA_ = chain(th2, A, dA), dB_ = chain(th2, B, dB), dC_ = chain(th2, C, dC);
+    const Dual<ND> z = dconst<ND>(0.f), one = dconst<ND>(1.f);
+    const Dual<ND> W[9] = {z, -a[5], a[4], a[5], z, -a[3], -a[4], a[3], z};
+    Dual<ND> W2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+    Dual<ND> E[9], V[9];
+    for (int i = 0; i < 9; ++i) {
+        const Dual<ND> I = (i % 4 == 0) ? one : z;
+        E[i] = I + dA_ * W[i] + dB_ * W2[i];
+        V[i] = I + dB_ * W[i] + dC_ * W2[i];
+    }
+    for (int i = 0; i < 3; ++i) {
+        const Dual<ND> dt = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];
+        for (int j = 0; j < 3; ++j)
+            T[4 * i + j] = X16[j] * E[3 * i] + X16[4 + j] * E[3 * i + 1] + X16[8 + j] * E[3 * i + 2];
+        T[4 * i + 3] = X16[3] * E[3 * i] + X16[7] * E[3 * i + 1] + X16[11] * E[3 * i + 2] + dt;
+    }
+}
+
+// one thread per pose; G = nullptr: forward (writes T), else backward (writes ga = (dT/da)^T G)
+__global__ void k_se3_retract(const float* __restrict__ a6, const float* __restrict__ X, int n, float* __restrict__ T,
+                              const float* __restrict__ G, float* __restrict__ ga) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const float* a = a6 + 6 * (size_t)b;
+    const float* Xb = X + 16 * (size_t)b;
+    if (!G) {
+        Dual<1> ad[6], out[12];
+        for (int i = 0; i < 6; ++i) { ad[i].v = a[i]; ad[i].d[0] = 0.f; }
+        se3_exp_times<1>(ad, Xb, out);
+        float* Tb = T + 16 * (size_t)b;
+        for (int i = 0; i < 12; ++i) Tb[i] = out[i].v;
+        Tb[12] = 0.f; Tb[13] = 0.f; Tb[14] = 0.f; Tb[15] = 1.f;
+    } else {
+        Dual<6> ad[6], out[12];
+        for (int i = 0; i < 6; ++i) { ad[i].v = a[i]; for (int k = 0; k < 6; ++k) ad[i].d[k] = (i == k) ? 1.f : 0.f; }
+        se3_exp_times<6>(ad, Xb, out);
+        const float* Gb = G + 16 * (size_t)b;
+        for (int k = 0; k < 6; ++k) {
+            float s = 0.f;
+            for (int i = 0; i < 12; ++i) s = fmaf(out[i].d[k], Gb[i], s);
+            ga[6 * (size_t)b + k] = s;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -381,6 +471,15 @@ int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* p
 int sp_renormalise_se3(float* T, int n, void* stream) {
     if (!T || n <= 0) return SP_EINVAL;
     hipLaunchKernelGGL(k_renormalise, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), T, n);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_se3_retract(const float* a, const float* X, int n, float* T, const float* grad_T, float* grad_a, void* stream) {
+    if (!a || !X || n <= 0) return SP_EINVAL;
+    if (grad_T ? !grad_a : !T) return SP_EINVAL;
+    hipLaunchKernelGGL(k_se3_retract, dim3((n + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), a, X, n, T, grad_T,
+                       grad_a);
     SP_CHECK_LAUNCH();
     return 0;
 }

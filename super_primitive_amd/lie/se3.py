@@ -52,6 +52,33 @@ def _quat_xyzw_to_R(q):
                         s * (x * z - y * w), s * (y * z + x * w), 1 - s * (x * x + y * y)), -1).reshape(q.shape[:-1] + (3, 3))
 
 
+class _FusedRetract(torch.autograd.Function):
+    """T = Exp(a) * X as one HIP launch forward and one backward (``sp_se3_retract``); cuda fp32 only."""
+
+    @staticmethod
+    def forward(ctx, a, X):
+        from .. import _lib
+        lib = _lib.load()
+        a_c, X_c = a.detach().contiguous().float(), X.detach().contiguous().float()
+        n = a_c.shape[0]
+        T = torch.empty(n, 4, 4, dtype=torch.float32, device=a.device)
+        _lib.check(lib.sp_se3_retract(_lib.ptr(a_c), _lib.ptr(X_c), n, _lib.ptr(T), None, None, _lib.stream_ptr()),
+                   "sp_se3_retract")
+        ctx.save_for_backward(a_c, X_c)
+        return T
+
+    @staticmethod
+    def backward(ctx, grad_T):
+        from .. import _lib
+        lib = _lib.load()
+        a_c, X_c = ctx.saved_tensors
+        g = grad_T.contiguous().float()
+        ga = torch.empty_like(a_c)
+        _lib.check(lib.sp_se3_retract(_lib.ptr(a_c), _lib.ptr(X_c), a_c.shape[0], None, _lib.ptr(g), _lib.ptr(ga),
+                                      _lib.stream_ptr()), "sp_se3_retract(backward)")
+        return ga, None
+
+
 class SE3:
     """Batch of rigid transforms stored as (B,4,4) matrices."""
     tangent_dim = 6
@@ -97,8 +124,12 @@ class SE3:
         return SE3(M)
 
     def retr(self, a):
-        """Left retraction Exp(a) * X."""
-        return SE3(se3_exp_matrix(a.reshape(-1, 6)) @ self.mat)
+        """Left retraction Exp(a) * X.  On a cuda device this is the fused HIP forward/backward pair; elsewhere
+        (CPU tests of the host glue) the differentiable torch expression."""
+        a = a.reshape(-1, 6)
+        if a.is_cuda and self.mat.dtype == torch.float32:
+            return SE3(_FusedRetract.apply(a, self.mat))
+        return SE3(se3_exp_matrix(a) @ self.mat)
 
     def matrix(self):
         return self.mat

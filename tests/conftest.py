@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the C-ABI library is a build artefact (git-ignored): make sure it exists before any test imports it
+    lib = os.path.join(ROOT, "super_primitive_amd", "csrc", "libsp_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.dirname(lib), "-j8"], check=True)
 
 
 def load_golden(name):

@@ -99,3 +99,27 @@ def test_lie_helpers_match_reference():
     np.testing.assert_allclose(npy(la.torch_pose_to_tq(T(g["in_T"]))), g["tq"], rtol=0, atol=1e-6)
     for i in range(4):
         np.testing.assert_allclose(npy(la.SE3_logmap(T(g["in_T"][i:i + 1])))[0], g["logmap"][i], rtol=1e-4, atol=1e-5)
+
+
+def test_fused_se3_retraction_forward_and_backward():
+    """sp_se3_retract vs the differentiable torch expression (itself checked against scipy expm on CPU)."""
+    from super_primitive_amd.lie.se3 import SE3, LieGroupParameter, se3_exp_matrix
+    rng = np.random.default_rng(3)
+    for scale in (0.0, 1e-4, 3e-3, 0.05, 0.7, 2.5):
+        n = 5
+        a_np = (rng.standard_normal((n, 6)) * scale).astype(np.float32)
+        X = SE3.exp(T((rng.standard_normal((n, 6)) * 0.5).astype(np.float32)))
+        G = T(rng.standard_normal((n, 4, 4)).astype(np.float32))
+        a1 = T(a_np, True)
+        out1 = X.retr(a1).matrix()                       # fused
+        (out1 * G).sum().backward()
+        a2 = T(a_np, True).double()
+        a2.retain_grad()
+        out2 = se3_exp_matrix(a2) @ X.matrix().double()  # reference expression in fp64
+        (out2 * G.double()).sum().backward()
+        np.testing.assert_allclose(npy(out1), npy(out2), rtol=0, atol=3e-6)
+        np.testing.assert_allclose(npy(a1.grad), npy(a2.grad), rtol=2e-5, atol=2e-5 * float(np.abs(npy(a2.grad)).max() + 1))
+    p = LieGroupParameter(SE3.Identity(1, device="cuda:0"))
+    m = p.retr().matrix()[0]
+    m[:3, 3].sum().backward()
+    np.testing.assert_allclose(npy(p.grad)[0, :3], np.ones(3), atol=1e-6)
