@@ -123,3 +123,27 @@ def test_fused_se3_retraction_forward_and_backward():
     m = p.retr().matrix()[0]
     m[:3, 3].sum().backward()
     np.testing.assert_allclose(npy(p.grad)[0, :3], np.ones(3), atol=1e-6)
+
+
+def test_idempotence_properties():
+    """renormalise_se3 is a projection; rebuilding the segment table gives identical arrays; packing is stable."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.lie import lie_algebra as la
+    from super_primitive_amd.segment_table import SegmentTable
+    from gpu_util import frames_from_synth
+    g = load_golden("g8_lie")
+    once = la.renormalise_se3(T(g["in_noisy"]).clone())
+    twice = la.renormalise_se3(once.clone())
+    np.testing.assert_allclose(npy(twice), npy(once), atol=2e-7)
+    pair = synth.make_pair(50, 70, 9, seed=4, shape="blobs")
+    src, _ = frames_from_synth(pair)
+    a = SegmentTable(src.keypoint_regions, src.logdepth_perseg, src.keypoints)
+    b = SegmentTable(src.keypoint_regions, src.logdepth_perseg, src.keypoints)
+    for f in ("pix", "baseL", "kp_L", "seg_off", "tiles", "seg_tile_off"):
+        assert torch.equal(getattr(a, f), getattr(b, f)), f
+    # table order is torch.where order
+    seg, row, col = torch.where(src.keypoint_regions)
+    assert torch.equal((a.pix & 0xffff).long(), col) and torch.equal(((a.pix >> 16) & 0x7fff).long(), row)
+    assert torch.equal(a.baseL, src.logdepth_perseg[seg, row, col])
+    counts = torch.bincount(seg, minlength=9)
+    assert torch.equal(a.seg_off[1:].long() - a.seg_off[:-1].long(), counts)

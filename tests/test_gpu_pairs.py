@@ -224,3 +224,60 @@ def test_hipgraph_replay_matches_eager_iterations():
     torch.cuda.synchronize()
     assert torch.equal(a.pose, b.pose) and torch.equal(a.kld, b.kld)
     assert torch.equal(a.lm_state, b.lm_state)
+
+
+def test_full_size_segment_permutation_and_tile_size_invariance():
+    """Size-independent properties at 640x480x64: relabelling the segments permutes d/dkld and leaves residual and
+    d/dpose unchanged (up to fp32 summation order); so does changing the tile size of the work list."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.core import dense_optim
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.segment_table import table_of
+    pair = synth.make_pair(480, 640, 64, seed=8, overlap=4, init_sigma=0.004)
+    cfg = {"mode": "colour", "collect_stats": 0}
+    perm = np.random.default_rng(0).permutation(64)
+
+    def run(order, tile_points):
+        src = KeyFrame(T(pair.src_image), T(pair.K), T(pair.logdepth_perseg[order]), T(pair.keypoints[order]),
+                       T(pair.keypoint_regions[order]))
+        trg = KeyFrame(T(pair.trg_image), T(pair.K))
+        table_of(src, tile_points=tile_points)
+        kld, pose = T(pair.kld_init[order], True), T(pair.pose_init, True)
+        out = dense_optim.photomeric_cost(src, trg, kld, pose, cfg)
+        out["residual"].sum().backward()
+        return npy(out["residual"])[0], npy(kld.grad), npy(pose.grad)
+
+    ident = np.arange(64)
+    r0, gk0, gp0 = run(ident, 1024)
+    r1, gk1, gp1 = run(perm, 1024)
+    r2, gk2, gp2 = run(ident, 4096)
+    for r, gk, gp, order in ((r1, gk1, gp1, perm), (r2, gk2, gp2, ident)):
+        np.testing.assert_allclose(r, r0, rtol=3e-6)
+        assert np.abs(gk - gk0[order]).max() <= 1e-4 * np.abs(gk0).max()
+        assert np.abs(gp - gp0).max() <= 1e-4 * np.abs(gp0).max()
+
+
+def test_backward_is_linear_in_the_upstream_gradient():
+    """loss = sum_b w_b * residual_b: gradients must be the w-weighted sums of the per-target gradients."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.core import dense_optim_batch
+    from gpu_util import frames_from_synth
+    pair = synth.make_pair(60, 80, 6, seed=33)
+    other = synth.make_pair(60, 80, 6, seed=33, motion_scale=1.7)
+    src, _ = frames_from_synth(pair)
+    imgs, Ks = T(np.stack([pair.trg_image, other.trg_image])), T(np.stack([pair.K, pair.K]))
+    poses0 = np.stack([pair.pose_init, other.pose_init])
+    cfg = {"mode": "colour", "collect_stats": 0}
+
+    def grads(w):
+        kld, P = T(pair.kld_init, True), T(poses0, True)
+        out = dense_optim_batch.photomeric_cost_batch(src, imgs, Ks, kld, P, cfg)
+        (out["residual"] * T(np.asarray(w, np.float32))).sum().backward()
+        return npy(kld.grad), npy(P.grad)
+
+    k10, p10 = grads([1, 0])
+    k01, p01 = grads([0, 1])
+    k, p = grads([0.3, -2.0])
+    np.testing.assert_allclose(k, 0.3 * k10 - 2.0 * k01, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(p, 0.3 * p10 - 2.0 * p01, rtol=1e-5, atol=1e-9)
+    assert np.all(p10[1] == 0) and np.all(p01[0] == 0)
