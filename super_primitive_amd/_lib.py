@@ -11,7 +11,7 @@ import os
 from ctypes import c_float, c_int, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsp_hip.so")
+LIB_PATH = os.environ.get("SP_HIP_LIB") or os.path.join(_HERE, "csrc", "libsp_hip.so")   # SP_HIP_LIB: developer A/B builds
 
 P = c_void_p
 I = c_int

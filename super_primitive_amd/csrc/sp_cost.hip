@@ -62,6 +62,11 @@ template <int AUX>
 __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, uint32_t off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX));
 }
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+// rgb of one packed texel (the 4th float of the 16-byte texel is padding and is never fetched)
+__device__ __forceinline__ f32x3 buf_load3(rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, 0, 0));
+}
 
 __device__ __forceinline__ void prepare(const TileCtx& c, float ifx, float ify, uint32_t pw, const f32x4 s, Pending& p) {
     float col, row; bool src_ok;
@@ -104,8 +109,8 @@ __device__ __forceinline__ void tap_mix(float a, float b, float cc, float d, flo
 // -----------------------------------------------------------------------------------------------------
 struct Mix0 { float gx, gy, s1, s0; };
 
-__device__ __forceinline__ void finish_grad(const TileCtx& c, const Pending& p, const f32x4 a, const f32x4 b,
-                                            const f32x4 cc, const f32x4 d, Mix0& o, float& cost_acc) {
+__device__ __forceinline__ void finish_grad(const TileCtx& c, const Pending& p, const f32x3 a, const f32x3 b,
+                                            const f32x3 cc, const f32x3 d, Mix0& o, float& cost_acc) {
     const float ta[3] = {a.x, a.y, a.z}, tb[3] = {b.x, b.y, b.z}, tc[3] = {cc.x, cc.y, cc.z}, td[3] = {d.x, d.y, d.z};
     const float sv[3] = {p.sr, p.sg, p.sb};
     float gx = 0.f, gy = 0.f, s1 = 0.f, s0 = 0.f, cost = 0.f;
@@ -154,8 +159,8 @@ __device__ __forceinline__ void fold_grad(const TileCtx& c, const Geo& g, const 
 // -----------------------------------------------------------------------------------------------------
 struct Mix1 { float w00, w01, w11, v0, v1; };
 
-__device__ __forceinline__ void finish_gn(const TileCtx& c, const Pending& p, const f32x4 a, const f32x4 b,
-                                          const f32x4 cc, const f32x4 d, float eps, Mix1& o, float& cost_acc, float& n_acc) {
+__device__ __forceinline__ void finish_gn(const TileCtx& c, const Pending& p, const f32x3 a, const f32x3 b,
+                                          const f32x3 cc, const f32x3 d, float eps, Mix1& o, float& cost_acc, float& n_acc) {
     const float ta[3] = {a.x, a.y, a.z}, tb[3] = {b.x, b.y, b.z}, tc[3] = {cc.x, cc.y, cc.z}, td[3] = {d.x, d.y, d.z};
     const float sv[3] = {p.sr, p.sg, p.sb};
     float w00 = 0.f, w01 = 0.f, w11 = 0.f, v0 = 0.f, v1 = 0.f, cost = 0.f;
@@ -249,13 +254,13 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float
         i += SP_BLOCK;
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)(i * 4u), 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, i * 16u);
-        f32x4 ta, tb, tc, td;
-        if (ABL == 1) { ta = tb = tc = td = f32x4{nx.sr, nx.sg, nx.sb, 0.f}; }
+        f32x3 ta, tb, tc, td;
+        if (ABL == 1) { ta = tb = tc = td = f32x3{nx.sr, nx.sg, nx.sb}; }
         else {
-            ta = buf_load4<0>(r_trg, nx.off0);
-            tb = buf_load4<0>(r_trg, nx.off0 + 16u);
-            tc = buf_load4<0>(r_trg, nx.off1);
-            td = buf_load4<0>(r_trg, nx.off1 + 16u);
+            ta = buf_load3(r_trg, nx.off0);
+            tb = buf_load3(r_trg, nx.off0 + 16u);
+            tc = buf_load3(r_trg, nx.off1);
+            td = buf_load3(r_trg, nx.off1 + 16u);
         }
         // The machine scheduler otherwise sinks the gathers below the arithmetic to shorten their live range
         // (register pressure heuristics): pin the three sections in source order.
