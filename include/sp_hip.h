@@ -159,6 +159,17 @@ int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float*
 int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, float lm_up,
                      float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream);
 
+/* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last tile of a pair
+ * runs that pair's update in place (same arithmetic, same fixed reduction order as sp_pairs_cost followed by
+ * sp_pairs_adam_step / sp_pairs_gn_step -- results are bitwise identical).  arrivals: n_pairs int32, zeroed once by
+ * the caller (the kernel leaves it zeroed).  Other arguments as in the two-launch forms. */
+int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int n_pairs, int max_N,
+                          float* partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
+                          float* losses, void* stream);
+int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int n_pairs, int max_N,
+                        float irls_eps, float* partials, int32_t* arrivals, float lm_up, float lm_down, float lm_min,
+                        float* lm_state, float* backup, float* costs, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Helpers around the path
  * ---------------------------------------------------------------------------------------------------- */

@@ -30,6 +30,8 @@ SIGNATURES = {
     "sp_pairs_cost": [P, P, I, I, F, P, P],
     "sp_pairs_adam_step": [P, I, I, P, F, F, F, P, P, P],
     "sp_pairs_gn_step": [P, I, I, P, F, F, F, P, P, P, P],
+    "sp_pairs_adam_iterate": [P, P, I, I, I, P, P, F, F, F, P, P, P],
+    "sp_pairs_gn_iterate": [P, P, I, I, I, F, P, P, F, F, F, P, P, P, P],
     "sp_depth_expand": [P, P, P, P, I, I, I, I, P, P],
     "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_segment_reinit": [P, P, P, P, I, I, I, I, P, I, P, P, P, P],

@@ -6,7 +6,7 @@
 //
 // Replaces core/dense_optim.py:265-403 and core/dense_optim_batch.py:50-147 of the reference (about 150 ATen
 // launches forward + the autograd backward) -- see include/sp_hip.h for the ABI and DESIGN.md for the layout.
-#include "sp_device.h"
+#include "sp_solve_device.h"
 
 namespace {
 
@@ -225,7 +225,7 @@ __device__ __forceinline__ void fold_gn(const TileCtx& c, const Geo& g, const Mi
 
 // ABL (developer ablation, only reachable through mode >= 10 of sp_pairs_cost): 0 = product kernel,
 // 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation)
-template <int MODE, int ABL = 0>
+template <int MODE, int ABL = 0, bool WRITE_THROUGH = false>
 __device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float* __restrict__ out, float* lds) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
     float acc[NV];
@@ -299,7 +299,11 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float
         else fold_gn(c, cur, m1, reinterpret_cast<float(&)[SP_GN_PARTIAL_FLOATS]>(acc));
     }
     const float total = block_sum_to_thread<NV>(acc, lds);
-    if (threadIdx.x < NV) out[threadIdx.x] = total;
+    if (threadIdx.x < NV) {
+        // fused cost+solve: the partial is read by ANOTHER workgroup of this launch -> write-through (sc1) store
+        if (WRITE_THROUGH) __hip_atomic_store(out + threadIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[threadIdx.x] = total;
+    }
 }
 
 __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const Cam& Kt, int H, int W, int Hl, int Wl,
@@ -385,9 +389,22 @@ __global__ __launch_bounds__(SP_BLOCK) void k_finalise_single(const float* __res
 // ------------------------------------------------------------------------------------------------
 // many independent pairs: grid = n_tiles_total
 // ------------------------------------------------------------------------------------------------
-template <int MODE, int ABL = 0>
+// FUSED = 0: cost pass only.  FUSED = 1 / 2: the workgroup that finishes the LAST tile of a frame pair also runs
+// that pair's Adam / Gauss-Newton update (solve_adam / solve_gn), so one optimiser iteration of the whole batch is a
+// single launch and solver work overlaps with other pairs' tiles.  Hand-off protocol (cdna_hip_programming.md
+// Guideline 16, write-through form): partial stores are sc1, every storing lane drains them (s_waitcnt vmcnt(0)),
+// workgroup barrier, one relaxed agent-scope fetch-add on the pair's arrival counter; the last arriver performs one
+// agent-scope acquire (invalidates its CU's L1), barrier, then reads the partials with plain loads.  The counter is
+// reset by the last arriver, so the buffer stays all-zero between launches.
+struct FuseArgs {
+    int32_t* arrivals;
+    AdamArgs adam;
+    GnArgs gn;
+};
+
+template <int MODE, int ABL = 0, int FUSED = 0>
 __global__ __launch_bounds__(SP_BLOCK) void k_cost_pairs(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
-                                                         int n_tiles, float irls_eps, float* __restrict__ partials) {
+                                                         int n_tiles, float irls_eps, float* __restrict__ partials, FuseArgs f) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
     __shared__ float lds[SP_WAVES * NV];
     const int t = xcd_chunked_tile(blockIdx.x, n_tiles);
@@ -408,7 +425,26 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_pairs(const SpPair* __restric
         c.bias = pr.aff[3] - pr.aff[1];
     }
     c.start = tile.z; c.count = tile.w;
-    run_tile<MODE, ABL>(c, irls_eps, partials + (size_t)t * NV, lds);
+    run_tile<MODE, ABL, FUSED != 0>(c, irls_eps, partials + (size_t)t * NV, lds);
+    if (FUSED != 0) {
+        __shared__ int is_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(f.arrivals + tile.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == pr.n_tiles - 1;
+            if (last) {
+                __hip_atomic_store(f.arrivals + tile.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            is_last = last;
+        }
+        __syncthreads();
+        if (is_last) {
+            if (FUSED == 1) solve_adam(pairs, tile.x, partials, f.adam);
+            else solve_gn(pairs, tile.x, partials, f.gn);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -534,18 +570,49 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_tiles_total + 7) / 8) * 8;
     const int4* t4 = reinterpret_cast<const int4*>(tiles);
+    const FuseArgs nofuse{};
     if (mode == 0)
-        hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+        hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+        hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else if (mode == 10)   /* developer ablations, see run_tile */
-        hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+        hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else if (mode == 11)
-        hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+        hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else if (mode == 12)
-        hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+        hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else
-        hipLaunchKernelGGL((k_cost_pairs<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+        hipLaunchKernelGGL((k_cost_pairs<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int n_pairs, int max_N,
+                          float* partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
+                          float* losses, void* stream) {
+    if (!pairs || !tiles || !partials || !arrivals || !state || !losses) return SP_EINVAL;
+    if (n_tiles_total <= 0 || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+    FuseArgs f{};
+    f.arrivals = arrivals;
+    f.adam = AdamArgs{max_N, lr_kld, lr_pose, lr_aff, state, losses};
+    const int gx = ((n_tiles_total + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_cost_pairs<0, 0, 1>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
+                       reinterpret_cast<const int4*>(tiles), n_tiles_total, 0.f, partials, f);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int n_pairs, int max_N,
+                        float irls_eps, float* partials, int32_t* arrivals, float lm_up, float lm_down, float lm_min,
+                        float* lm_state, float* backup, float* costs, void* stream) {
+    if (!pairs || !tiles || !partials || !arrivals || !lm_state || !backup || !costs) return SP_EINVAL;
+    if (n_tiles_total <= 0 || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+    FuseArgs f{};
+    f.arrivals = arrivals;
+    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs};
+    const int gx = ((n_tiles_total + 7) / 8) * 8;
+    hipLaunchKernelGGL((k_cost_pairs<1, 0, 2>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
+                       reinterpret_cast<const int4*>(tiles), n_tiles_total, irls_eps, partials, f);
     SP_CHECK_LAUNCH();
     return 0;
 }

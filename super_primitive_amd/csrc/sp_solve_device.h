@@ -1,0 +1,357 @@
+// Device-side solver bodies shared by the stand-alone solver kernels (sp_solver.hip) and the fused
+// cost+solve kernels (sp_cost.hip): per-pair tile-partial reduction (fixed order, fp64), Adam step with SE(3)
+// retraction, Gauss-Newton / Levenberg-Marquardt step.  See sp_solver.hip for the reference lines they replace.
+#pragma once
+#include "sp_device.h"
+
+#define SP_LM_STRIDE SP_LM_STATE_FLOATS
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum over the block of one double per thread; result valid in every thread.
+__device__ __forceinline__ double block_sum_d(double v, double* lds /* SP_WAVES */) {
+    const double w = wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = w;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < SP_WAVES; ++i) t += lds[i];
+    return t;
+}
+
+// Column k of the pair's tile partials summed over all its tiles (strided over the block, fixed order).
+template <int NV>
+__device__ __forceinline__ double reduce_column(const float* __restrict__ p, int n_tiles, int k, double* lds) {
+    double s = 0.0;
+    for (int t = threadIdx.x; t < n_tiles; t += SP_BLOCK) s += (double)p[(size_t)t * NV + k];
+    return block_sum_d(s, lds);
+}
+
+// All NV columns of the pair's tile partials summed over its tiles, into out[NV] (LDS).  Thread (g, c) = (tid / NV,
+// tid % NV) walks tiles g, g+G, ... of column c: neighbouring threads read neighbouring floats of one 4*NV-byte
+// tile record (coalesced), every thread's loads are independent (pipelined), and the G group partials are added
+// in fixed order -- one barrier, bitwise reproducible.
+template <int NV>
+__device__ __forceinline__ void reduce_columns(const float* __restrict__ p, int n_tiles, double* out, double* scratch) {
+    constexpr int G = SP_BLOCK / NV;
+    const int g = threadIdx.x / NV, c = threadIdx.x - g * NV;
+    if (g < G) {
+        double s = 0.0;
+        for (int t = g; t < n_tiles; t += G) s += (double)p[(size_t)t * NV + c];
+        scratch[g * NV + c] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < G; ++k) s += scratch[k * NV + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+// Exp of a twist [tau, phi] (left-multiplied onto T in place): T <- Exp(xi) * T, all in fp64.
+__device__ void se3_retract_left(const double xi[6], float* T16) {
+    const double wx = xi[3], wy = xi[4], wz = xi[5];
+    const double th2 = wx * wx + wy * wy + wz * wz;
+    double A, B, C;
+    if (th2 < 1e-12) {
+        A = 1.0 - th2 / 6.0; B = 0.5 - th2 / 24.0; C = 1.0 / 6.0 - th2 / 120.0;
+    } else if (th2 < 1e-4) {
+        // 3-term series: exact to < 1e-12 for theta < 0.01 and immune to the cancellation in 1-cos, th-sin
+        A = 1.0 - th2 / 6.0 * (1.0 - th2 / 20.0);
+        B = 0.5 - th2 / 24.0 * (1.0 - th2 / 30.0);
+        C = 1.0 / 6.0 - th2 / 120.0 * (1.0 - th2 / 42.0);
+    } else {
+        const double th = sqrt(th2);
+        const double sn = sin(th), cs = cos(th);
+        A = sn / th; B = (1.0 - cs) / th2; C = (th - sn) / (th2 * th);
+    }
+    const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    double W2[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
+    double E[9], V[9];
+    for (int i = 0; i < 9; ++i) {
+        const double I = (i % 4 == 0) ? 1.0 : 0.0;
+        E[i] = I + A * W[i] + B * W2[i];
+        V[i] = I + B * W[i] + C * W2[i];
+    }
+    double dt[3];
+    for (int i = 0; i < 3; ++i) dt[i] = V[3 * i] * xi[0] + V[3 * i + 1] * xi[1] + V[3 * i + 2] * xi[2];
+    double R[9], t[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = T16[4 * i + j];
+        t[i] = T16[4 * i + 3];
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            T16[4 * i + j] = (float)(E[3 * i] * R[j] + E[3 * i + 1] * R[3 + j] + E[3 * i + 2] * R[6 + j]);
+        T16[4 * i + 3] = (float)(E[3 * i] * t[0] + E[3 * i + 1] * t[1] + E[3 * i + 2] * t[2] + dt[i]);
+    }
+    T16[12] = 0.f; T16[13] = 0.f; T16[14] = 0.f; T16[15] = 1.f;
+}
+
+// torch.optim.Adam (amsgrad=False, weight_decay=0), one scalar parameter; returns the step to ADD.
+__device__ __forceinline__ float adam_delta(float g, float& m, float& v, float lr, float bc1, float bc2_sqrt) {
+    m = 0.9f * m + 0.1f * g;
+    v = 0.999f * v + 0.001f * g * g;
+    const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
+    return -(lr / bc1) * (m / denom);
+}
+
+struct AdamArgs {
+    int max_N;
+    float lr_kld, lr_pose, lr_aff;
+    float* state;
+    float* losses;
+};
+
+// One workgroup: tile-partial reduction + Adam update of pair `pi` (see include/sp_hip.h sp_pairs_adam_step).
+__device__ __forceinline__ void solve_adam(const SpPair* __restrict__ pairs, int pi, const float* __restrict__ partials,
+                                           const AdamArgs& h) {
+    const int max_N = h.max_N;
+    const float lr_kld = h.lr_kld, lr_pose = h.lr_pose, lr_aff = h.lr_aff;
+    float* __restrict__ state = h.state;
+    float* __restrict__ losses = h.losses;
+    constexpr int NV = SP_GRAD_PARTIAL_FLOATS;
+    __shared__ double sums[NV];
+    __shared__ double scratch[(SP_BLOCK / NV) * NV];
+    const SpPair& pr = pairs[pi];
+    const float* p = partials + (size_t)pr.tile0 * NV;
+    reduce_columns<NV>(p, pr.n_tiles, sums, scratch);      // (column 13 is per segment: its global sum is unused)
+    const double scale = 1.0 / (3.0 * (double)pr.P);
+    const float residual = (float)(sums[0] * scale);
+    // loss = |residual| (two_frame_sfm.py:201): d loss / d residual = sign(residual)
+    const double up = residual > 0.f ? scale : (residual < 0.f ? -scale : 0.0);
+    float* st = state + (size_t)pi * (2 + 2 * (max_N + 8));
+    float* m_kld = st + 2; float* v_kld = m_kld + max_N;
+    float* m_xi = v_kld + max_N; float* v_xi = m_xi + 6;
+    float* m_af = v_xi + 6; float* v_af = m_af + 2;
+    const float step = st[0] + 1.f;
+    const float bc1 = 1.f - powf(0.9f, step);
+    const float bc2s = sqrtf(1.f - powf(0.999f, step));
+    // per-segment log-depths
+    for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
+        double s = 0.0;
+        for (int t = pr.seg_tile_off[n]; t < pr.seg_tile_off[n + 1]; ++t) s += (double)p[(size_t)t * NV + 13];
+        const float g = (float)(s * up);
+        pr.kld[n] += adam_delta(g, m_kld[n], v_kld[n], lr_kld, bc1, bc2s);
+    }
+    if (threadIdx.x == 0) {
+        // gradient wrt the left tangent at identity: d/dtau = g_t ; d/dphi = vee(A - A^T), A = R g_R^T + t g_t^T
+        double gR[9], gt[3], R[9], t[3];
+        for (int i = 0; i < 3; ++i) {
+            gt[i] = sums[1 + i] * up;
+            for (int j = 0; j < 3; ++j) { gR[3 * i + j] = sums[4 + 3 * i + j] * up; R[3 * i + j] = pr.pose[4 * i + j]; }
+            t[i] = pr.pose[4 * i + 3];
+        }
+        double A[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                A[3 * i + j] = R[3 * i] * gR[3 * j] + R[3 * i + 1] * gR[3 * j + 1] + R[3 * i + 2] * gR[3 * j + 2] + t[i] * gt[j];
+        const float g6[6] = {(float)gt[0], (float)gt[1], (float)gt[2],
+                             (float)(A[5] - A[7]), (float)(A[6] - A[2]), (float)(A[1] - A[3])};
+        double xi[6];
+        for (int i = 0; i < 6; ++i) xi[i] = adam_delta(g6[i], m_xi[i], v_xi[i], lr_pose, bc1, bc2s);
+        se3_retract_left(xi, pr.pose);
+        if (pr.aff) {
+            const float ga = (float)(sums[14] * up), gb = (float)(sums[15] * up);
+            pr.aff[2] += adam_delta(ga, m_af[0], v_af[0], lr_aff, bc1, bc2s);
+            pr.aff[3] += adam_delta(gb, m_af[1], v_af[1], lr_aff, bc1, bc2s);
+        }
+        st[0] = step;
+        losses[pi] = fabsf(residual);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Gauss-Newton / LM
+// ---------------------------------------------------------------------------------------------------
+// lm_state per pair (8 floats): [0] lambda  [1] cost of the last accepted point (<0: none yet)
+//                               [2] #accepted  [3] #rejected  [4] 1 if the previous call rejected  [5] last cost seen
+
+// Solve the symmetric positive definite 6x6 system S x = rhs by LDL^T (no square roots, six reciprocals);
+// x is returned in rhs.  false if a pivot is not positive.
+__device__ bool ldlt6_solve(double S[36], double rhs[6]) {
+    double dinv[6];
+    for (int j = 0; j < 6; ++j) {
+        double d = S[7 * j];
+        for (int k = 0; k < j; ++k) d -= S[6 * j + k] * S[6 * j + k] * S[7 * k];
+        if (!(d > 0.0)) return false;
+        S[7 * j] = d;
+        dinv[j] = 1.0 / d;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = S[6 * i + j];
+            for (int k = 0; k < j; ++k) v -= S[6 * i + k] * S[6 * j + k] * S[7 * k];
+            S[6 * i + j] = v * dinv[j];
+        }
+    }
+    for (int i = 0; i < 6; ++i) {            // L y = rhs
+        double v = rhs[i];
+        for (int k = 0; k < i; ++k) v -= S[6 * i + k] * rhs[k];
+        rhs[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) rhs[i] *= dinv[i];
+    for (int i = 5; i >= 0; --i) {           // L^T x = y
+        double v = rhs[i];
+        for (int k = i + 1; k < 6; ++k) v -= S[6 * k + i] * rhs[k];
+        rhs[i] = v;
+    }
+    return true;
+}
+
+#define SP_SEG_CACHE 256     // segments whose reduced {h(6), 1/D', b_d} live in LDS; beyond that they are recomputed
+
+// {h_pd(6), D, b_d} of segment n summed over its tiles; lam -> {h, 1/(D(1+lam)) or 0, b_d}
+__device__ __forceinline__ void segment_system(const float* __restrict__ p, const int32_t* __restrict__ seg_tile_off, int n,
+                                               double lam, double (&o)[8]) {
+    constexpr int NV = SP_GN_PARTIAL_FLOATS;
+    double h[6] = {0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
+    for (int t = seg_tile_off[n]; t < seg_tile_off[n + 1]; ++t) {
+        const float* q = p + (size_t)t * NV;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) h[i] += (double)q[28 + i];
+        D += (double)q[34];
+        bd += (double)q[35];
+    }
+    const double Dd = D * (1.0 + lam);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) o[i] = h[i];
+    o[6] = Dd > 1e-12 ? 1.0 / Dd : 0.0;
+    o[7] = bd;
+}
+
+struct GnArgs {
+    int max_N;
+    float lm_up, lm_down, lm_min;
+    float* lm_state;
+    float* backup;
+    float* costs;
+};
+
+// One workgroup: tile-partial reduction + Schur-complement LM step of pair `pi` (include/sp_hip.h sp_pairs_gn_step).
+__device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int pi, const float* __restrict__ partials,
+                                         const GnArgs& h) {
+    const int max_N = h.max_N;
+    const float lm_up = h.lm_up, lm_down = h.lm_down, lm_min = h.lm_min;
+    float* __restrict__ lm_state = h.lm_state;
+    float* __restrict__ backup = h.backup;
+    float* __restrict__ costs = h.costs;
+    constexpr int NV = SP_GN_PARTIAL_FLOATS;
+    __shared__ double sums[NV];      // [0] cost, [1..21] Hpp upper, [22..27] b_p (columns >= 28 are per segment)
+    __shared__ double scratch[(SP_BLOCK / NV) * NV];
+    __shared__ double seg[SP_SEG_CACHE][8];
+    __shared__ double schur_part[8][27];
+    __shared__ double schur[27];     // 21 + 6
+    __shared__ double dxi[6];
+    __shared__ int decision;         // 0 = step, 1 = rejected (restore)
+    const SpPair& pr = pairs[pi];
+    const float* p = partials + (size_t)pr.tile0 * NV;
+    float* ls = lm_state + (size_t)pi * SP_LM_STRIDE;
+    float* bk = backup + (size_t)pi * (16 + max_N);
+    reduce_columns<NV>(p, pr.n_tiles, sums, scratch);
+    const double cost = sums[0] / (3.0 * (double)pr.P);
+    if (threadIdx.x == 0) {
+        const float last = ls[1];
+        int rej = 0;
+        if (last >= 0.f && (float)cost > last * (1.f + 1e-6f) && ls[4] == 0.f) rej = 1;
+        decision = rej;
+        ls[5] = (float)cost;
+        costs[pi] = (float)cost;
+    }
+    __syncthreads();
+    if (decision == 1) {
+        // undo the previous step; the next cost pass re-evaluates at the restored point with a larger lambda
+        for (int i = threadIdx.x; i < 16; i += SP_BLOCK) pr.pose[i] = bk[i];
+        for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) pr.kld[n] = bk[16 + n];
+        if (threadIdx.x == 0) { ls[0] *= lm_up; ls[3] += 1.f; ls[4] = 1.f; }
+        return;
+    }
+    float lambda = ls[0];
+    if (ls[4] == 0.f) lambda = fmaxf(lambda * lm_down, lm_min);
+    const double lam = (double)lambda;
+    // back up the point we are about to leave
+    for (int i = threadIdx.x; i < 16; i += SP_BLOCK) bk[i] = pr.pose[i];
+    for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) bk[16 + n] = pr.kld[n];
+    // per-segment reduced systems into LDS
+    const int n_cached = min(pr.N, SP_SEG_CACHE);
+    for (int n = threadIdx.x; n < n_cached; n += SP_BLOCK) {
+        double o[8];
+        segment_system(p, pr.seg_tile_off, n, lam, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) seg[n][i] = o[i];
+    }
+    __syncthreads();
+    // Schur complement of the diagonal depth block: 27 sums over the segments, thread (k, j) takes value k over
+    // segments j, j+8, ... ; the 8 partials per value are combined in fixed order
+    {
+        const int k = threadIdx.x >> 3, j = threadIdx.x & 7;
+        if (k < 27) {
+            // upper-triangle index k -> (a, b); k >= 21 -> (k - 21, "b_d")
+            int a = 0, b = 0;
+            if (k < 21) { int rem = k, row = 0; while (rem >= 6 - row) { rem -= 6 - row; ++row; } a = row; b = row + rem; }
+            else a = k - 21;
+            double acc = 0.0;
+            for (int n = j; n < pr.N; n += 8) {
+                double o[8];
+                if (n < SP_SEG_CACHE) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
+                } else segment_system(p, pr.seg_tile_off, n, lam, o);
+                acc += o[a] * (k < 21 ? o[b] : o[7]) * o[6];
+            }
+            schur_part[j][k] = acc;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += schur_part[j][threadIdx.x];
+        schur[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S[36], rhs[6];
+        int k = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) {
+                double v = sums[1 + k] - schur[k];
+                if (i == j) v += lam * sums[1 + k] + 1e-12;
+                S[6 * i + j] = v; S[6 * j + i] = v;
+                ++k;
+            }
+        for (int i = 0; i < 6; ++i) rhs[i] = -(sums[22 + i] - schur[21 + i]);
+        const bool ok = ldlt6_solve(S, rhs);
+        for (int i = 0; i < 6; ++i) dxi[i] = ok ? rhs[i] : 0.0;
+        ls[0] = lambda; ls[1] = (float)cost; ls[2] += 1.f; ls[4] = 0.f;
+    }
+    __syncthreads();
+    for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
+        double o[8];
+        if (n < SP_SEG_CACHE) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
+        } else segment_system(p, pr.seg_tile_off, n, lam, o);
+        if (o[6] > 0.0) {
+            double r = -o[7];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) r -= o[i] * dxi[i];
+            double dd = r * o[6];
+            dd = fmin(fmax(dd, -0.5), 0.5);   // trust region on one log-depth step (factor e^0.5 in depth)
+            pr.kld[n] += (float)dd;
+        }
+    }
+    if (threadIdx.x == 64) {                  // a different wave than the one that just solved: no reason, just parallel
+        double xi[6];
+        for (int i = 0; i < 6; ++i) xi[i] = dxi[i];
+        se3_retract_left(xi, pr.pose);
+    }
+}
+

@@ -281,3 +281,25 @@ def test_backward_is_linear_in_the_upstream_gradient():
     np.testing.assert_allclose(k, 0.3 * k10 - 2.0 * k01, rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(p, 0.3 * p10 - 2.0 * p01, rtol=1e-5, atol=1e-9)
     assert np.all(p10[1] == 0) and np.all(p01[0] == 0)
+
+
+@pytest.mark.parametrize("mode", ["gn", "adam"])
+def test_fused_single_launch_iteration_is_bitwise_the_two_launch_one(mode):
+    """sp_pairs_*_iterate (last-arriver solves inside the cost launch) vs sp_pairs_cost + sp_pairs_*_step.  Also the
+    inter-workgroup hand-off check: with many pairs of uneven size in flight, any stale partial would change bits."""
+    from super_primitive_amd import synth
+    pairs = [synth.make_pair(60 + 12 * (k % 3), 80 + 8 * (k % 4), 4 + k % 5, seed=100 + k, init_sigma=0.02,
+                             shape="blobs" if k % 2 else "grid") for k in range(24)]
+    a = make_batch(pairs, levels=(0, 1), tile_points=512)
+    b = make_batch(pairs, levels=(0, 1), tile_points=512)
+    for it in range(15):
+        if mode == "gn":
+            ca, cb = a.gn_step(0, fused=True), b.gn_step(0, fused=False)
+        else:
+            ca, cb = a.adam_step(0, fused=True), b.adam_step(0, fused=False)
+        assert torch.equal(ca, cb), it
+    torch.cuda.synchronize()
+    assert torch.equal(a.pose, b.pose) and torch.equal(a.kld, b.kld)
+    assert int(a.arrivals.abs().sum()) == 0, "arrival counters must be left zeroed"
+    if mode == "gn":
+        assert torch.equal(a.lm_state, b.lm_state)

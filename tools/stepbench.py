@@ -32,3 +32,19 @@ for _ in range(20):
 torch.cuda.synchronize()
 c = np.median([r[0].elapsed_time(r[1]) for r in rows]) * 1e3; s = np.median([r[1].elapsed_time(r[2]) for r in rows]) * 1e3
 print(f"Adam: cost kernel {c:.1f} us, solver {s:.1f} us")
+
+import itertools
+variants = (("GN fused", lambda: batch.gn_step(0, fused=True)), ("GN 2-launch", lambda: batch.gn_step(0, fused=False)),
+            ("Adam fused", lambda: batch.adam_step(0, fused=True)), ("Adam 2-launch", lambda: batch.adam_step(0, fused=False)))
+res = {n: [] for n, _ in variants}
+for rnd in range(4):
+    for name, fn in variants:
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
+        for _ in range(40): fn()
+        torch.cuda.synchronize()
+        res[name].append((time.perf_counter() - t0) / 40 * 1e6)
+for n, v in res.items():
+    print(f"{n}: " + " ".join(f"{x:.1f}" for x in v) + f"  us/iter (median {np.median(v):.1f})")
