@@ -42,7 +42,18 @@ __device__ __forceinline__ void reduce_columns(const float* __restrict__ p, int 
     const int g = threadIdx.x / NV, c = threadIdx.x - g * NV;
     if (g < G) {
         double s = 0.0;
-        for (int t = g; t < n_tiles; t += G) s += (double)p[(size_t)t * NV + c];
+        // 8 independent loads in flight per trip (the additions keep their fixed order)
+        for (int t = g; t < n_tiles; t += 8 * G) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int tt = t + u * G;
+                const float x = p[(size_t)min(tt, n_tiles - 1) * NV + c];      // unconditional load (clamped address):
+                v[u] = tt < n_tiles ? x : 0.f;                                 // a branch here would serialise the loads
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (double)v[u];
+        }
         scratch[g * NV + c] = s;
     }
     __syncthreads();
@@ -139,7 +150,14 @@ __device__ __forceinline__ void solve_adam(const SpPair* __restrict__ pairs, int
     // per-segment log-depths
     for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
         double s = 0.0;
-        for (int t = pr.seg_tile_off[n]; t < pr.seg_tile_off[n + 1]; ++t) s += (double)p[(size_t)t * NV + 13];
+        const int t0 = pr.seg_tile_off[n], t1 = pr.seg_tile_off[n + 1];
+        for (int t = t0; t < t1; t += 8) {       // eight tiles in flight per trip, added in tile order
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(t + u, t1 - 1) * NV + 13];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += (t + u < t1) ? (double)v[u] : 0.0;
+        }
         const float g = (float)(s * up);
         pr.kld[n] += adam_delta(g, m_kld[n], v_kld[n], lr_kld, bc1, bc2s);
     }
@@ -213,12 +231,24 @@ __device__ __forceinline__ void segment_system(const float* __restrict__ p, cons
                                                double lam, double (&o)[8]) {
     constexpr int NV = SP_GN_PARTIAL_FLOATS;
     double h[6] = {0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
-    for (int t = seg_tile_off[n]; t < seg_tile_off[n + 1]; ++t) {
-        const float* q = p + (size_t)t * NV;
+    const int t0 = seg_tile_off[n], t1 = seg_tile_off[n + 1];
+    for (int t = t0; t < t1; t += 4) {          // four tiles' records in flight per trip, summed in tile order
+        float v[4][8];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) h[i] += (double)q[28 + i];
-        D += (double)q[34];
-        bd += (double)q[35];
+        for (int u = 0; u < 4; ++u) {
+            const float* q = p + (size_t)min(t + u, t1 - 1) * NV + 28;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[u][i] = q[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (t + u < t1) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) h[i] += (double)v[u][i];
+                D += (double)v[u][6];
+                bd += (double)v[u][7];
+            }
+        }
     }
     const double Dd = D * (1.0 + lam);
 #pragma unroll
