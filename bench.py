@@ -35,7 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-H, W, N_SEG = 480, 640, 64
+H, W = 480, 640
 
 
 def parse():
@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=96, help="frame pairs resident per GPU")
+    ap.add_argument("--segments", type=int, default=64, help="segments per source keyframe (BASELINE config 5 uses 128)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
     ap.add_argument("--tile-points", type=int, default=8192)
     ap.add_argument("--mode", choices=["gn", "adam"], default="gn")
@@ -58,7 +59,7 @@ def build_batch(args, rank, dev):
     from super_primitive_amd.optim.pair_batch import PairBatch
     G = max(1, min(args.distinct, args.pairs))
     R = max(1, args.pairs // G)
-    pairs = [synth.make_pair(H, W, N_SEG, seed=1000 * rank + s, overlap=4, init_sigma=0.004) for s in range(G)]
+    pairs = [synth.make_pair(H, W, args.segments, seed=1000 * rank + s, overlap=4, init_sigma=0.004) for s in range(G)]
     rng = np.random.default_rng(rank)
     poses = []
     for r in range(R):
@@ -166,11 +167,11 @@ def main():
     alg_bytes = batch.algorithmic_bytes(0)
     value = world * M * K / elapsed
     line = {
-        "metric": "GN iters/sec (640x480x64-seg frame pairs)" if args.mode == "gn" else "Adam iters/sec (640x480x64-seg frame pairs)",
+        "metric": f"GN iters/sec (640x480x{args.segments}-seg frame pairs)" if args.mode == "gn" else f"Adam iters/sec (640x480x{args.segments}-seg frame pairs)",
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Replica-shaped two-frame SfM, 640x480, 64 segments (8x8 grid, 4 px overlap), pyramid "
+        "config": {"workload": f"Replica-shaped two-frame SfM, 640x480, {args.segments} segments (grid, 4 px overlap), pyramid "
                                "level 0 of a 3-level pyramid; BASELINE.json configs[1]",
                    "pairs_per_gpu": M, "segment_pixels_per_pair": int(batch.Ps[0]), "optimiser": args.mode,
                    "tile_points": args.tile_points, "sharding": f"{world} x independent pair batches, final all_gather only"},

@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Synthetic stand-ins for the five BASELINE.json configurations (no dataset ships with the build), run through
+the HIP path on one GPU.  Prints one line per configuration; numbers are quoted in DESIGN.md.
+
+  1  320x240, 8 segments           -- the reference's CPU-runnable case: oracle (CPU) next to the HIP API loop
+  2  640x480, 64 segments, 3 levels -- bench.py (headline)
+  3  TUM-shaped MonoVO inner loops  -- 224x288 keyframe, tracking [0,0,300] Adam steps / frame, windowed mapping
+  4  VOID-shaped depth completion   -- 480x640, ~1200 sparse-point segments: per-segment median + per-pixel average
+  5  many pairs x 128 segments      -- bench.py --segments 128 (per-GPU slice of the 1024-pair / 8-GPU case)
+"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from super_primitive_amd import synth
+from super_primitive_amd.core import dense_optim
+from super_primitive_amd.image.keyframe import KeyFrame, keyframe_pyramid
+from super_primitive_amd.odometery.two_frame_sfm import SfM
+from super_primitive_amd.odometery.loops import track_frame, map_source_against_targets
+from super_primitive_amd.odometery.depth_init import segment_based_depth_reinit
+from super_primitive_amd.depth_completion.segment_based_completion import average_visible_segments
+from super_primitive_amd.lie.lie_algebra import invertSE3
+from super_primitive_amd.optim.pair_batch import PairBatch
+
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+def frames(p):
+    return (KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)),
+            KeyFrame(t(p.trg_image), t(p.K)))
+def sync_time(f, n=1):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
+def rot_err(A, B):
+    return float(np.arccos(np.clip((np.trace(A[:3, :3] @ B[:3, :3].T) - 1) / 2, -1, 1)))
+
+# ---- config 1 -------------------------------------------------------------------------------------------
+p = synth.make_pair(240, 320, 8, seed=1, init_sigma=0.01)
+src, trg = frames(p)
+cfg = {"aligment": {"pyramid_min": 0, "pyramid_max": 3, "cost_params": {}}}
+sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=5); sfm.init_optimisation(kld_init=t(p.kld_init)); sfm.run()
+sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=200); sfm.init_optimisation(kld_init=t(p.kld_init))
+dt = sync_time(sfm.run)
+from oracle import photometric_oracle as orc          # CPU baseline leg only
+osrc, otrg = orc.frames_from_synth(p)
+okld = torch.nn.Parameter(torch.from_numpy(p.kld_init.copy())); oa = torch.nn.Parameter(torch.zeros(1, 6)); T0 = torch.from_numpy(p.pose_init.copy())
+oopt = torch.optim.Adam([{"params": [okld], "lr": 1e-3}, {"params": [oa], "lr": 1e-2}], lr=1e-3)
+def ostep():
+    out = orc.photometric_cost(osrc, otrg, okld, orc.se3_exp(oa)[0] @ T0); out["residual"].abs().mean().backward(); oopt.step(); oopt.zero_grad()
+ostep(); t0 = time.perf_counter()
+for _ in range(20): ostep()
+cpu_its = 20 / (time.perf_counter() - t0)
+print(f"config 1  320x240x8: HIP drop-in API loop {600/dt:.0f} Adam it/s (3 levels x 200) | oracle CPU ({torch.get_num_threads()} threads) {cpu_its:.1f} it/s "
+      f"| final loss {float(sfm.losses[-1]):.4f} from {float(sfm.losses[0]):.4f}")
+
+# ---- config 3: TUM-shaped tracking + mapping ------------------------------------------------------------
+H, W, N = 224, 288, 40
+p = synth.make_pair(H, W, N, seed=3, init_sigma=0.01, overlap=3)
+src, trg = frames(p)
+levels = (0, 3)
+src_pyr, trg_pyr = keyframe_pyramid(src, *levels), keyframe_pyramid(trg, *levels)
+with torch.no_grad():
+    pre = [dense_optim.unproject_kf(s, t(p.kld_gt)) for s in src_pyr]
+supp_T0 = invertSE3(t(p.pose_init))
+args = (pre, trg_pyr, supp_T0, torch.eye(4, device=dev), [0, 0, 300])
+track_frame(pre, trg_pyr, supp_T0, torch.eye(4, device=dev), [0, 0, 5])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+supp_T, _, losses = track_frame(*args, lr=5e-3, prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+est = invertSE3(supp_T).cpu().numpy()
+print(f"config 3  tracking 224x288x{N}, 300 Adam steps/frame through the API: {dt*1e3:.0f} ms/frame ({300/dt:.0f} it/s), "
+      f"loss {float(losses[0]):.4f} -> {float(losses[-1]):.4f}, rot err {rot_err(est, p.pose_gt):.2e} rad, t err {np.abs(est[:3,3]-p.pose_gt[:3,3]).max():.2e}")
+# the same frame-to-keyframe problem for a whole batch of frames on device (pose + affine, depths fixed)
+B = 64
+pb = PairBatch([src] * 1, [t(p.trg_image)], [t(p.K)], t(p.pose_init)[None].repeat(B, 1, 1), [t(p.kld_gt)], levels=levels, use_affine=True,
+               replicate=B, tile_points=4096)
+for _ in range(3): pb.adam_step(0, lr_kld=0.0, lr_pose=5e-3, lr_aff=5e-3)
+dt = sync_time(lambda: pb.adam_step(0, lr_kld=0.0, lr_pose=5e-3, lr_aff=5e-3), 300)
+print(f"config 3  tracking, {B} frames side by side on device: {B/ (300*dt):.0f} frames/s at 300 steps/frame ({B/dt:.0f} Adam it/s)")
+other = synth.make_pair(H, W, N, seed=3, init_sigma=0.01, overlap=3, motion_scale=1.7)
+imgs, Ks = t(np.stack([p.trg_image, other.trg_image])), t(np.stack([p.K, p.K]))
+map_source_against_targets(src, imgs, Ks, t(p.kld_init), t(np.stack([p.pose_init, other.pose_init])), 3)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+kld, poses, _, losses = map_source_against_targets(src, imgs, Ks, t(p.kld_init), t(np.stack([p.pose_init, other.pose_init])), 500)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"config 3  mapping 1 KF x 2 targets, {len(losses)} Adam steps through the API: {dt*1e3:.0f} ms ({len(losses)/dt:.0f} it/s), loss {float(losses[0]):.4f} -> {float(losses[-1]):.4f}")
+
+# ---- config 4: VOID-shaped depth completion --------------------------------------------------------------
+p = synth.make_pair(480, 640, 1200, seed=4, shape="blobs")
+src, _ = frames(p)
+rng = np.random.default_rng(0)
+sparse = np.zeros_like(p.depth); rc = p.meta["kp_rc"]; sparse[rc[:, 0], rc[:, 1]] = p.depth[rc[:, 0], rc[:, 1]]
+sp = t(sparse)
+def complete():
+    kld, vis = segment_based_depth_reinit(sp.clone(), src, mode='median', return_info=True)
+    return average_visible_segments(src, kld, vis)
+depth, invalid = complete()
+dt = sync_time(complete, 20)
+ok = ~invalid.cpu().numpy()
+err = np.abs(depth.cpu().numpy()[ok] - p.depth[ok]) / p.depth[ok]
+from super_primitive_amd.segment_table import table_of
+print(f"config 4  VOID-shaped 480x640, {p.N} segments (P = {table_of(src).P} points): {dt*1e3:.2f} ms/image ({1/dt:.0f} images/s), "
+      f"coverage {ok.mean():.2f}, median rel err {np.median(err):.2e}")
+print("config 2 / 5: see bench.py (--segments 128 for config 5's per-GPU slice)")
