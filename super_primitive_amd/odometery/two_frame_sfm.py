@@ -89,6 +89,36 @@ class SfM:
                 count += 1
         return self
 
+    def run_on_device(self, mode="adam", iters_per_level=None, use_graph=True, **kw):
+        """The same coarse-to-fine schedule with the whole loop on the GPU (``optim.PairBatch``: 2 launches per
+        iteration, no autograd graph, no torch optimizer) -- ~30x the iteration rate of ``run()``.
+
+        ``mode='adam'``: Adam with the reset-tangent pose parameterisation of the reference's tracking / mapping
+        loops (``odometery/odometery.py:394-403``); it differs from ``run()``'s accumulated tangent only in the
+        second-order terms of Exp and in not skipping the very first update.  ``mode='gn'``: Gauss-Newton / LM on the
+        same L1 cost (IRLS).  One supporting frame only (several frames share the log-depths and are not
+        independent pairs).  Results are written back so ``poses()`` / ``keypoint_logdepths()`` work as after ``run()``."""
+        from ..optim.pair_batch import PairBatch
+        if len(self.supp_frames) != 1:
+            raise NotImplementedError("run_on_device handles one supporting frame; use run() for several")
+        al = self.config['aligment']
+        frame, current_T, pose_to_mat = self.supp_frames[0]
+        with torch.no_grad():
+            pose0 = pose_to_mat(current_T).detach().clone()
+        batch = PairBatch([self.src_keyframe], [frame.image], [frame.K], pose0[None], [self.src_depth_keypoints_opt.detach()],
+                          levels=(al['pyramid_min'], al['pyramid_max']), tile_points=2048)
+        batch.run(iters_per_level or self.num_iters, mode=mode, use_graph=use_graph, **kw)
+        self.losses.append(batch.evaluate(al['pyramid_min'])[0].detach())
+        with torch.no_grad():
+            self.src_depth_keypoints_opt.data.copy_(batch.klds()[0])
+            final = batch.poses()[0].clone()
+            if self.opt_pose:
+                from ..lie.se3 import SE3, LieGroupParameter
+                self.supp_frames[0] = (frame, LieGroupParameter(SE3(final[None])), pose_to_mat)
+            else:
+                self.supp_frames[0] = (frame, final, pose_to_mat)
+        return self
+
     # -- results -------------------------------------------------------------------------------------
     def poses(self):
         with torch.no_grad():
