@@ -26,7 +26,8 @@
  *   kp_L[N]     float   logdepth_perseg[n, kp_row, kp_col] (core/dense_optim.py:51-64)
  *   tiles[T]    int32x4 {pair, segment, first point, point count}; a tile never straddles two segments
  *   seg_tile_off[N+1]   CSR offsets of the segments into tiles
- * Target images are packed HWC4 (r,g,b,0) per pyramid level so one bilinear tap is one 16-byte load.
+ * Target images are packed HWC3 (r,g,b adjacent, 12 bytes per texel) per pyramid level so one bilinear tap is one
+ * 12-byte load and a level costs exactly the algorithmic 12 B per pixel of HBM traffic.
  */
 #ifndef SP_HIP_H
 #define SP_HIP_H
@@ -74,8 +75,8 @@ int sp_table_sample_source(uint32_t* pix, const float* baseL, const int32_t* seg
                            const float* kld, int N, int P, int H, int W, const float* img, int Hl, int Wl,
                            const float* K, float* src4, void* stream);
 
-/* planar (B,3,H,W) f32 -> packed (B,H,W,4) f32 */
-int sp_pack_rgba(const float* chw, int B, int H, int W, float* hwc4, void* stream);
+/* planar (B,3,H,W) f32 -> packed (B,H,W,3) f32 */
+int sp_pack_rgb(const float* chw, int B, int H, int W, float* hwc3, void* stream);
 
 /* One pyramid step of image/gaussian_pyramid.py:53-85: reflect-pad 1, 3x3 binomial /16, keep even rows and
  * columns.  in: planar (C,H,W); out: planar (C,ceil(H/2),ceil(W/2)). */
@@ -98,7 +99,7 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
  * ---------------------------------------------------------------------------------------------------- */
 int sp_photo_cost_grad(const uint32_t* pix, const float* src4, const int32_t* seg_off, const float* kp_L,
                        const int32_t* tiles, const int32_t* seg_tile_off, int n_tiles, int N, int P, int H, int W,
-                       const float* K_src, const float* kld, const float* trg4, int Hl, int Wl,
+                       const float* K_src, const float* kld, const float* trg3, int Hl, int Wl,
                        const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
                        float zmin, float* workspace, float* residual, float* g_kld, float* g_pose, float* g_aff,
                        void* stream);
@@ -108,7 +109,7 @@ int sp_photo_cost_grad(const uint32_t* pix, const float* src4, const int32_t* se
  * after brightness compensation; raw (B,3,P) = (I_src - I_trg')*mask; src_valid (P) u8; trg_valid (B,P) u8;
  * seg_ids (P) int64. */
 int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_off, const float* kp_L, int N, int P,
-                   int H, int W, const float* K_src, const float* kld, const float* trg4, int Hl, int Wl,
+                   int H, int W, const float* K_src, const float* kld, const float* trg3, int Hl, int Wl,
                    const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
                    float zmin, float* src_pts, float* trg_pts, float* src_rgb, float* trg_rgb, float* raw,
                    uint8_t* src_valid, uint8_t* trg_valid, int64_t* seg_ids, void* stream);
@@ -123,7 +124,7 @@ typedef struct SpPair {
     const uint32_t* pix;      /* [P] */
     const float*    src4;     /* [P*4] for the level being optimised */
     const float*    kp_L;     /* [N] */
-    const float*    trg4;     /* [Hl*Wl*4] for the level being optimised */
+    const float*    trg3;     /* [Hl*Wl*3] packed HWC3, for the level being optimised */
     float*          kld;      /* [N]  optimisation variable */
     float*          pose;     /* [16] optimisation variable (target <- source) */
     float*          aff;      /* [4]  {a_s,b_s,a_t,b_t} or NULL */

@@ -23,7 +23,7 @@ SIGNATURES = {
     "sp_mask_count": [P, I, I, I, P, P, P, P],
     "sp_table_fill": [P, P, P, I, I, I, P, P, P, P, P, P],
     "sp_table_sample_source": [P, P, P, P, P, I, I, I, I, P, I, I, P, P, P],
-    "sp_pack_rgba": [P, I, I, I, P, P],
+    "sp_pack_rgb": [P, I, I, I, P, P],
     "sp_blur_decimate": [P, I, I, I, P, P],
     "sp_photo_cost_grad": [P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P],
     "sp_photo_stats": [P, P, P, P, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P, P, P, P],
@@ -49,7 +49,7 @@ SP_LM_STATE_FLOATS = 8
 class SpPair(ctypes.Structure):
     """Mirror of ``struct SpPair`` (include/sp_hip.h); 136 bytes."""
     _fields_ = [
-        ("pix", c_void_p), ("src4", c_void_p), ("kp_L", c_void_p), ("trg4", c_void_p),
+        ("pix", c_void_p), ("src4", c_void_p), ("kp_L", c_void_p), ("trg3", c_void_p),
         ("kld", c_void_p), ("pose", c_void_p), ("aff", c_void_p), ("seg_tile_off", c_void_p),
         ("K_src", c_float * 4), ("K_trg", c_float * 4),
         ("N", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("Hl", c_int), ("Wl", c_int),

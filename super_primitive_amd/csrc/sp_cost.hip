@@ -14,7 +14,7 @@ namespace {
 struct TileCtx {
     gptr_u32 pix;
     gptr_f4 src4;
-    gptr_f4 trg4;
+    gptr_f32 trg;         // packed HWC3 target level
     Cam Ks;
     Warp w;
     float shift;      // kld[n] - kp_L[n]
@@ -63,7 +63,7 @@ __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, uint32_t off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, AUX));
 }
 typedef float f32x3 __attribute__((ext_vector_type(3)));
-// rgb of one packed texel (the 4th float of the 16-byte texel is padding and is never fetched)
+// rgb of one packed HWC3 texel (12 bytes, dword aligned)
 __device__ __forceinline__ f32x3 buf_load3(rsrc_t r, uint32_t off) {
     return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, 0, 0));
 }
@@ -88,8 +88,8 @@ __device__ __forceinline__ void prepare(const TileCtx& c, float ifx, float ify, 
     p.wx = ix - fx0;
     p.wy = iy - fy0;
     // valid => 0 <= x0 <= Wl-2, 0 <= y0 <= Hl-2 (0.99 band, Wl,Hl >= 2 checked on the host)
-    p.off0 = ((uint32_t)(int)fy0 * (uint32_t)c.Wl + (uint32_t)(int)fx0) * 16u;
-    p.off1 = p.off0 + (uint32_t)c.Wl * 16u;
+    p.off0 = ((uint32_t)(int)fy0 * (uint32_t)c.Wl + (uint32_t)(int)fx0) * (4u * SP_TEXEL_FLOATS);
+    p.off1 = p.off0 + (uint32_t)c.Wl * (4u * SP_TEXEL_FLOATS);
 }
 
 // bilinear value and both slopes of one channel from its four taps
@@ -234,7 +234,7 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float
     const float ifx = 1.f / c.Ks.fx, ify = 1.f / c.Ks.fy;
     const rsrc_t r_pix = make_rsrc(c.pix + c.start, (uint32_t)c.count * 4u);
     const rsrc_t r_src = make_rsrc(c.src4 + c.start, (uint32_t)c.count * 16u);
-    const rsrc_t r_trg = make_rsrc(c.trg4, (uint32_t)c.Wl * (uint32_t)c.Hl * 16u);
+    const rsrc_t r_trg = make_rsrc(c.trg, (uint32_t)c.Wl * (uint32_t)c.Hl * (4u * SP_TEXEL_FLOATS));
     const int n_iter = (c.count + SP_BLOCK - 1) / SP_BLOCK;
     uint32_t i = threadIdx.x;
     constexpr int NT = 2;   // aux: non-temporal
@@ -258,9 +258,9 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float
         if (ABL == 1) { ta = tb = tc = td = f32x3{nx.sr, nx.sg, nx.sb}; }
         else {
             ta = buf_load3(r_trg, nx.off0);
-            tb = buf_load3(r_trg, nx.off0 + 16u);
+            tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
             tc = buf_load3(r_trg, nx.off1);
-            td = buf_load3(r_trg, nx.off1 + 16u);
+            td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
         }
         // The machine scheduler otherwise sinks the gathers below the arithmetic to shorten their live range
         // (register pressure heuristics): pin the three sections in source order.
@@ -325,7 +325,7 @@ __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const C
 // ------------------------------------------------------------------------------------------------
 struct SingleArgs {
     const uint32_t* pix; const float4* src4; const float* kp_L; const int4* tiles;
-    const float* K_src; const float* kld; const float4* trg4; const float* K_trg; const float* pose;
+    const float* K_src; const float* kld; const float* trg; const float* K_trg; const float* pose;
     const float* aff_src; const float* aff_trg;
     int n_tiles, H, W, Hl, Wl;
     float zmin;
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_single_grad(SingleArgs a, flo
     const int4 tile = a.tiles[t];   // {pair(unused), segment, start, count}
     TileCtx c;
     c.pix = (gptr_u32)a.pix; c.src4 = (gptr_f4)a.src4;
-    c.trg4 = (gptr_f4)(a.trg4 + (size_t)b * a.Hl * a.Wl);
+    c.trg = (gptr_f32)(a.trg + (size_t)b * a.Hl * a.Wl * SP_TEXEL_FLOATS);
     load_cam(a.K_src, c.Ks);
     Cam Kt; load_cam(a.K_trg + 9 * b, Kt);
     fill_warp(c, a.pose + 16 * b, Kt, a.H, a.W, a.Hl, a.Wl, a.zmin);
@@ -403,7 +403,7 @@ struct FuseArgs {
 };
 
 template <int MODE, int ABL = 0, int FUSED = 0>
-__global__ __launch_bounds__(SP_BLOCK) void k_cost_pairs(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
+__global__ __launch_bounds__(SP_BLOCK, (MODE == 0 && FUSED == 0) ? 5 : 1) void k_cost_pairs(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
                                                          int n_tiles, float irls_eps, float* __restrict__ partials, FuseArgs f) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
     __shared__ float lds[SP_WAVES * NV];
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_pairs(const SpPair* __restric
     TileCtx c;
     c.pix = (gptr_u32)pr.pix;
     c.src4 = (gptr_f4)pr.src4;
-    c.trg4 = (gptr_f4)pr.trg4;
+    c.trg = (gptr_f32)pr.trg3;
     c.Ks = Cam{pr.K_src[0], pr.K_src[1], pr.K_src[2], pr.K_src[3]};
     const Cam Kt{pr.K_trg[0], pr.K_trg[1], pr.K_trg[2], pr.K_trg[3]};
     fill_warp(c, pr.pose, Kt, pr.H, pr.W, pr.Hl, pr.Wl, pr.zmin);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_pairs(const SpPair* __restric
 // ------------------------------------------------------------------------------------------------
 struct StatsArgs {
     const uint32_t* pix; const float4* src4; const int32_t* seg_off; const float* kp_L;
-    const float* K_src; const float* kld; const float4* trg4; const float* K_trg; const float* pose;
+    const float* K_src; const float* kld; const float* trg; const float* K_trg; const float* pose;
     const float* aff_src; const float* aff_trg;
     int N, P, H, W, Hl, Wl;
     float zmin;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_stats(StatsArgs a) {
     const int n = lo;
     TileCtx c;
     load_cam(a.K_src, c.Ks);
-    if (a.trg4) {
+    if (a.trg) {
         Cam Kt; load_cam(a.K_trg + 9 * b, Kt);
         fill_warp(c, a.pose + 16 * b, Kt, a.H, a.W, a.Hl, a.Wl, a.zmin);
     }
@@ -494,11 +494,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_stats(StatsArgs a) {
         if (a.src_valid) a.src_valid[i] = src_ok;
         if (a.seg_ids) a.seg_ids[i] = n;
     }
-    if (!a.trg4) return;   // source-only query (unproject_kf)
+    if (!a.trg) return;   // source-only query (unproject_kf)
     PointGeom g;
     warp_point(c.w, x, y, d, g);
     Taps tp;
-    fetch_taps((gptr_f4)(a.trg4 + (size_t)b * a.Hl * a.Wl), a.Wl, a.Hl, g.ix, g.iy, tp);
+    fetch_taps((gptr_f32)(a.trg + (size_t)b * a.Hl * a.Wl * SP_TEXEL_FLOATS), a.Wl, a.Hl, g.ix, g.iy, tp);
     const float it[3] = {fmaf(gain, bilerp(tp.t00.x, tp.t10.x, tp.t01.x, tp.t11.x, tp.wx, tp.wy), bias),
                          fmaf(gain, bilerp(tp.t00.y, tp.t10.y, tp.t01.y, tp.t11.y, tp.wx, tp.wy), bias),
                          fmaf(gain, bilerp(tp.t00.z, tp.t10.z, tp.t01.z, tp.t11.z, tp.wx, tp.wy), bias)};
@@ -521,19 +521,19 @@ int sp_abi_version(void) { return SP_ABI_VERSION; }
 
 int sp_photo_cost_grad(const uint32_t* pix, const float* src4, const int32_t* seg_off, const float* kp_L,
                        const int32_t* tiles, const int32_t* seg_tile_off, int n_tiles, int N, int P, int H, int W,
-                       const float* K_src, const float* kld, const float* trg4, int Hl, int Wl,
+                       const float* K_src, const float* kld, const float* trg3, int Hl, int Wl,
                        const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
                        float zmin, float* workspace, float* residual, float* g_kld, float* g_pose, float* g_aff,
                        void* stream) {
     (void)seg_off;
-    if (!pix || !src4 || !kp_L || !tiles || !seg_tile_off || !K_src || !kld || !trg4 || !K_trg || !pose ||
+    if (!pix || !src4 || !kp_L || !tiles || !seg_tile_off || !K_src || !kld || !trg3 || !K_trg || !pose ||
         !workspace || !residual || !g_kld || !g_pose || !g_aff)
         return SP_EINVAL;
     if (n_tiles <= 0 || N <= 0 || P <= 0 || B <= 0 || H < 2 || W < 2 || Hl < 1 || Wl < 1) return SP_EINVAL;
     if ((aff_src == nullptr) != (aff_trg == nullptr)) return SP_EINVAL;
     if (H > 32767 || W > 65535 || B > 65535) return SP_ELIMIT;
     SingleArgs a{pix, reinterpret_cast<const float4*>(src4), kp_L, reinterpret_cast<const int4*>(tiles),
-                 K_src, kld, reinterpret_cast<const float4*>(trg4), K_trg, pose, aff_src, aff_trg,
+                 K_src, kld, trg3, K_trg, pose, aff_src, aff_trg,
                  n_tiles, H, W, Hl, Wl, zmin};
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_tiles + 7) / 8) * 8;
@@ -546,16 +546,16 @@ int sp_photo_cost_grad(const uint32_t* pix, const float* src4, const int32_t* se
 }
 
 int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_off, const float* kp_L, int N, int P,
-                   int H, int W, const float* K_src, const float* kld, const float* trg4, int Hl, int Wl,
+                   int H, int W, const float* K_src, const float* kld, const float* trg3, int Hl, int Wl,
                    const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
                    float zmin, float* src_pts, float* trg_pts, float* src_rgb, float* trg_rgb, float* raw,
                    uint8_t* src_valid, uint8_t* trg_valid, int64_t* seg_ids, void* stream) {
     if (!pix || !src4 || !seg_off || !kp_L || !K_src || !kld) return SP_EINVAL;
-    if (trg4 && (!K_trg || !pose)) return SP_EINVAL;      /* trg4 == NULL: source-side outputs only */
+    if (trg3 && (!K_trg || !pose)) return SP_EINVAL;      /* trg3 == NULL: source-side outputs only */
     if (N <= 0 || P <= 0 || B <= 0 || H < 2 || W < 2) return SP_EINVAL;
     if ((aff_src == nullptr) != (aff_trg == nullptr)) return SP_EINVAL;
     StatsArgs a{pix, reinterpret_cast<const float4*>(src4), seg_off, kp_L, K_src, kld,
-                reinterpret_cast<const float4*>(trg4), K_trg, pose, aff_src, aff_trg, N, P, H, W, Hl, Wl, zmin,
+                trg3, K_trg, pose, aff_src, aff_trg, N, P, H, W, Hl, Wl, zmin,
                 src_pts, trg_pts, src_rgb, trg_rgb, raw, src_valid, trg_valid, seg_ids};
     hipLaunchKernelGGL(k_stats, dim3((P + SP_BLOCK - 1) / SP_BLOCK, B), dim3(SP_BLOCK), 0,
                        static_cast<hipStream_t>(stream), a);

@@ -164,14 +164,16 @@ __device__ __forceinline__ void warp_point(const Warp& w, float px, float py, fl
     g.iy = (yn + 1.f) * w.sy;
 }
 
-// One bilinear footprint of a packed HWC4 image.  Taps outside the image are zero (grid_sample
+#define SP_TEXEL_FLOATS 3      // target images are packed HWC3: r,g,b of one pixel adjacent, 12 bytes per texel
+
+// One bilinear footprint of a packed HWC3 image.  Taps outside the image are zero (grid_sample
 // padding_mode='zeros'); for valid points (0.99 band) all four taps are inside whenever Wl,Hl >= 2.
 struct Taps {
     float4 t00, t10, t01, t11;
     float wx, wy;
 };
 
-__device__ __forceinline__ void fetch_taps(gptr_f4 img, int Wl, int Hl, float ix, float iy, Taps& tp) {
+__device__ __forceinline__ void fetch_taps(gptr_f32 img, int Wl, int Hl, float ix, float iy, Taps& tp) {
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     tp.wx = ix - fx0;
     tp.wy = iy - fy0;
@@ -181,8 +183,10 @@ __device__ __forceinline__ void fetch_taps(gptr_f4 img, int Wl, int Hl, float ix
     const bool iny0 = (y0 >= 0) & (y0 < Hl), iny1 = (y1 >= 0) & (y1 < Hl);
     const int cx0 = min(max(x0, 0), Wl - 1), cx1 = min(max(x1, 0), Wl - 1);
     const int cy0 = min(max(y0, 0), Hl - 1), cy1 = min(max(y1, 0), Hl - 1);
-    const f32x4 a = img[cy0 * Wl + cx0], b = img[cy0 * Wl + cx1];
-    const f32x4 c = img[cy1 * Wl + cx0], d = img[cy1 * Wl + cx1];
+    struct Rgb { float x, y, z; };
+    auto texel = [&](int yy, int xx) { gptr_f32 q = img + (size_t)(yy * Wl + xx) * SP_TEXEL_FLOATS; return Rgb{q[0], q[1], q[2]}; };
+    const Rgb a = texel(cy0, cx0), b = texel(cy0, cx1);
+    const Rgb c = texel(cy1, cx0), d = texel(cy1, cx1);
     const float m00 = (inx0 & iny0) ? 1.f : 0.f, m10 = (inx1 & iny0) ? 1.f : 0.f;
     const float m01 = (inx0 & iny1) ? 1.f : 0.f, m11 = (inx1 & iny1) ? 1.f : 0.f;
     tp.t00 = make_float4(a.x * m00, a.y * m00, a.z * m00, 0.f);

@@ -159,11 +159,12 @@ __global__ __launch_bounds__(SP_BLOCK) void k_sample_source(uint32_t* __restrict
     pix[i] = pw | (ok ? 0x80000000u : 0u);
 }
 
-__global__ __launch_bounds__(SP_BLOCK) void k_pack_rgba(const float* __restrict__ chw, int HW, float4* __restrict__ out) {
+__global__ __launch_bounds__(SP_BLOCK) void k_pack_rgb(const float* __restrict__ chw, int HW, float* __restrict__ out) {
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
     if (i >= HW) return;
     const float* p = chw + (size_t)blockIdx.y * 3 * HW;
-    out[(size_t)blockIdx.y * HW + i] = make_float4(p[i], p[HW + i], p[2 * (size_t)HW + i], 0.f);
+    float* q = out + ((size_t)blockIdx.y * HW + i) * SP_TEXEL_FLOATS;
+    q[0] = p[i]; q[1] = p[HW + i]; q[2] = p[2 * (size_t)HW + i];
 }
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -235,10 +236,10 @@ int sp_table_sample_source(uint32_t* pix, const float* baseL, const int32_t* seg
     return 0;
 }
 
-int sp_pack_rgba(const float* chw, int B, int H, int W, float* hwc4, void* stream) {
-    if (!chw || !hwc4 || B <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
-    hipLaunchKernelGGL(k_pack_rgba, dim3((H * W + SP_BLOCK - 1) / SP_BLOCK, B), dim3(SP_BLOCK), 0,
-                       static_cast<hipStream_t>(stream), chw, H * W, reinterpret_cast<float4*>(hwc4));
+int sp_pack_rgb(const float* chw, int B, int H, int W, float* hwc3, void* stream) {
+    if (!chw || !hwc3 || B <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
+    hipLaunchKernelGGL(k_pack_rgb, dim3((H * W + SP_BLOCK - 1) / SP_BLOCK, B), dim3(SP_BLOCK), 0,
+                       static_cast<hipStream_t>(stream), chw, H * W, hwc3);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -83,9 +83,9 @@ class PairBatch:
             for l in self.level_ids:
                 src4_0.setdefault(l, []).append(tab.source_level(s_lv[l], f.K, klds[m].to(dev)))
                 Hl, Wl = t_lv[l].shape[-2:]
-                packed = torch.empty(1, Hl, Wl, 4, dtype=torch.float32, device=dev)
-                _lib.check(lib.sp_pack_rgba(_lib.ptr(t_lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(packed), _lib.stream_ptr()),
-                           "sp_pack_rgba")
+                packed = torch.empty(1, Hl, Wl, 3, dtype=torch.float32, device=dev)
+                _lib.check(lib.sp_pack_rgb(_lib.ptr(t_lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(packed), _lib.stream_ptr()),
+                           "sp_pack_rgb")
                 trg4_0.setdefault(l, []).append(packed.reshape(-1))
                 hw_0.setdefault(l, []).append((Hl, Wl))
         self.pix = cat([t.pix for t in tables])          # after source_level(): validity bits are set
@@ -115,7 +115,7 @@ class PairBatch:
                 d.pix = self.pix.data_ptr() + 4 * int(p_off[m])
                 d.src4 = self.src4[l].data_ptr() + 16 * int(p_off[m])
                 d.kp_L = self.kp_L.data_ptr() + 4 * int(n_off[m])
-                d.trg4 = self.trg4[l].data_ptr() + 4 * int(trg_off[l][m])
+                d.trg3 = self.trg4[l].data_ptr() + 4 * int(trg_off[l][m])
                 d.kld = self.kld.data_ptr() + 4 * int(n_off[m])
                 d.pose = self.pose.data_ptr() + 64 * m
                 d.aff = (self.aff.data_ptr() + 16 * m) if use_affine else None

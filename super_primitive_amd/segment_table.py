@@ -134,7 +134,7 @@ def table_of(kf, tile_points=None):
 
 
 def packed_target(images):
-    """(3,H,W) or (B,3,H,W) planar f32 -> (B,H,W,4) packed, cached on the tensor object."""
+    """(3,H,W) or (B,3,H,W) planar f32 -> (B,H,W,3) packed (HWC3), cached on the tensor object."""
     _lib.require_device(images)
     key = _ident(images)
     hit = getattr(images, "_sp_rgba", None)
@@ -146,8 +146,8 @@ def packed_target(images):
         img = img[None]
     img = img[:, :3].contiguous().float()
     B, _, H, W = img.shape
-    out = torch.empty(B, H, W, 4, dtype=torch.float32, device=img.device)
-    _lib.check(lib.sp_pack_rgba(_lib.ptr(img), B, H, W, _lib.ptr(out), _lib.stream_ptr()), "sp_pack_rgba")
+    out = torch.empty(B, H, W, 3, dtype=torch.float32, device=img.device)
+    _lib.check(lib.sp_pack_rgb(_lib.ptr(img), B, H, W, _lib.ptr(out), _lib.stream_ptr()), "sp_pack_rgb")
     try:
         images._sp_rgba = (key, out)
     except Exception:  # pragma: no cover

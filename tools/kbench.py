@@ -14,6 +14,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=64)
     ap.add_argument("--distinct", type=int, default=2)
     ap.add_argument("--tile-points", type=int, default=2048)
+    ap.add_argument("--segments", type=int, default=64)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--levels", default="0")
     ap.add_argument("--modes", default="0,1")
