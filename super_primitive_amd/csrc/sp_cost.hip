@@ -20,6 +20,7 @@ struct TileCtx {
     float shift;      // kld[n] - kp_L[n]
     float gain, bias; // exp(-(a_t-a_s)), b_t-b_s
     float ax, ay;     // level pixels per geometry pixel: (Wl-1)/(W-1), (Hl-1)/(H-1)
+    uint32_t row_bytes;   // Wl * 12: byte distance between vertically adjacent target texels
     int Wl, Hl;
     int start, count;
 };
@@ -88,8 +89,13 @@ __device__ __forceinline__ void prepare(const TileCtx& c, float ifx, float ify, 
     p.wx = ix - fx0;
     p.wy = iy - fy0;
     // valid => 0 <= x0 <= Wl-2, 0 <= y0 <= Hl-2 (0.99 band, Wl,Hl >= 2 checked on the host)
-    p.off0 = ((uint32_t)(int)fy0 * (uint32_t)c.Wl + (uint32_t)(int)fx0) * (4u * SP_TEXEL_FLOATS);
-    p.off1 = p.off0 + (uint32_t)c.Wl * (4u * SP_TEXEL_FLOATS);
+    // 24-bit integer multiplies, forced (hipcc otherwise re-associates this into v_mad_u64_u32 + v_mul_lo_u32, both
+    // quarter rate): texel index < 2^24 for any level up to 4096 x 4096, byte offset < 2^32.
+    uint32_t texel, off0;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(texel) : "v"((uint32_t)(int)fy0), "s"((uint32_t)c.Wl), "v"((uint32_t)(int)fx0));
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(off0) : "v"(texel), "s"(4u * SP_TEXEL_FLOATS));
+    p.off0 = off0;
+    p.off1 = off0 + c.row_bytes;
 }
 
 // bilinear value and both slopes of one channel from its four taps
@@ -316,6 +322,7 @@ __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const C
     c.w.sy = 0.5f * (float)(Hl - 1);
     c.w.zmin = zmin;
     c.Wl = Wl; c.Hl = Hl;
+    c.row_bytes = (uint32_t)Wl * (4u * SP_TEXEL_FLOATS);
     c.ax = 2.f * c.w.sx * c.w.invWm1;
     c.ay = 2.f * c.w.sy * c.w.invHm1;
 }
