@@ -210,6 +210,37 @@ int sp_se3_retract(const float* a, const float* X, int n, float* T, const float*
 /* lie/lie_algebra.py:41-47 renormalise_se3 on n row-major 4x4 matrices, in place. */
 int sp_renormalise_se3(float* T, int n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------
+ * Keyframe post-processing: frontend/segment/post_processer.py without cupy.
+ * ---------------------------------------------------------------------------------------------------- */
+
+/* post_processer.py:13-36 depth_discontinuity + mask_by_depth_discontinuity: depth = exp(logdepth) (-1 where
+ * !valid), filter_size x filter_size max-pool (stride 1), Scharr/32 gradient magnitude (reflect padding) > threshold.
+ * split = valid & !discontinuity (N,H,W) u8; disc (optional) = valid & discontinuity.  scratch: N*H*W floats. */
+int sp_depth_discontinuity(const float* logdepth, const uint8_t* valid, int N, int H, int W, int filter_size,
+                           float threshold, float* scratch, uint8_t* split, uint8_t* disc, void* stream);
+
+/* post_processer.py:57-64 connected_components_batch (ndimage.label with the per-slice 4-connectivity structure):
+ * labels[i] = 1 + (smallest linear index of i's component), 0 for background -- sorting components by label gives
+ * scipy's scan-order numbering.  parent: N*H*W int32 scratch; sizes (optional, N*H*W int32): sizes[root] = pixels. */
+int sp_label_components(const uint8_t* fg, int N, int H, int W, int32_t* parent, int32_t* labels, int32_t* sizes,
+                        void* stream);
+
+/* Compact list of components {slice, root, size} (unordered, at most cap entries; *n_parts = how many exist) and
+ * bg_sizes[n] = |mask_n & !split_n| (the label-0 part post_process_kf forms, post_processer.py:127-133). */
+int sp_collect_parts(const int32_t* labels, const int32_t* sizes, const uint8_t* masks, const uint8_t* split, int N, int H,
+                     int W, int cap, int32_t* parts, int32_t* n_parts, int32_t* bg_sizes, void* stream);
+
+/* Materialise K part masks (K,H,W) u8.  parts[k] = {slice, kind, root}: kind 0 = component `root` of that slice,
+ * 1 = mask & !split, 2 = the original mask of the slice (post_processer.py:138-146). */
+int sp_build_part_masks(const uint8_t* masks, const uint8_t* split, const int32_t* labels, int H, int W,
+                        const int32_t* parts, int K, uint8_t* out, void* stream);
+
+/* (row, col) of the kth[k]-th set pixel of mask k in raster order, i.e. torch.where(mask)[kth] as used by
+ * sample_pts_in_mask (post_processer.py:67-84).  row_off: the row_counts output of sp_mask_count for these masks. */
+int sp_kth_mask_pixel(const uint8_t* masks, const int32_t* row_off, int K, int H, int W, const int32_t* kth,
+                      int32_t* out_rc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

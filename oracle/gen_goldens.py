@@ -30,6 +30,12 @@ def import_reference():
             sys.modules[name] = types.ModuleType(name)
     sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
     sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    # frontend/segment/post_processer.py needs cupy only for asarray/asnumpy and cupyx.scipy.ndimage.label, which
+    # mirrors scipy.ndimage.label: stub them with numpy / scipy so the REAL module runs on the CPU
+    import scipy.ndimage
+    cp = types.ModuleType("cupy"); cp.asarray = np.asarray; cp.asnumpy = np.asarray
+    cpx = types.ModuleType("cupyx"); cps = types.ModuleType("cupyx.scipy"); cps.ndimage = scipy.ndimage; cpx.scipy = cps
+    sys.modules.update({"cupy": cp, "cupyx": cpx, "cupyx.scipy": cps, "cupyx.scipy.ndimage": scipy.ndimage})
     sys.path.insert(0, REF)
     import core.dense_optim as rdo
     import core.dense_optim_batch as rdob
@@ -38,7 +44,8 @@ def import_reference():
     import lie.lie_algebra as rla
     import odometery.depth_init as rdi
     import tool.point_utils as rpu
-    return types.SimpleNamespace(do=rdo, dob=rdob, dr=rdr, kf=rkf, la=rla, di=rdi, pu=rpu)
+    import frontend.segment.post_processer as rpp
+    return types.SimpleNamespace(do=rdo, dob=rdob, dr=rdr, kf=rkf, la=rla, di=rdi, pu=rpu, pp=rpp)
 
 
 sys.path.insert(0, ROOT)
@@ -380,6 +387,30 @@ def golden_traj_map(ref, name, steps=30):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_post_process(ref, name):
+    """N2: depth_discontinuity, mask_by_depth_discontinuity, connected_components_batch and
+    kf_fix_disconnected_regions (torch seed 123 for the re-seeded keypoints) on keyframes with depth steps."""
+    save = {}
+    for tag, (H, W, N, shape, seed) in {"grid": (60, 80, 6, "grid", 5), "blobs": (72, 96, 9, "blobs", 6)}.items():
+        pair = synth.make_pair(H, W, N, seed=seed, shape=shape)
+        L = synth.stepped_logdepth(pair, seed=seed)
+        kf = ref.kf.KeyFrame(T(pair.src_image), T(pair.K), T(L), T(pair.keypoints), torch.from_numpy(pair.keypoint_regions.copy()))
+        disc = ref.pp.depth_discontinuity(T(L), torch.from_numpy(pair.keypoint_regions.copy()))
+        split = ref.pp.mask_by_depth_discontinuity(T(L), torch.from_numpy(pair.keypoint_regions.copy()))
+        torch.set_grad_enabled(True)
+        lab, n_lab = ref.pp.connected_components_batch(split.numpy())
+        torch.manual_seed(123)
+        new = ref.pp.kf_fix_disconnected_regions(kf)
+        torch.set_grad_enabled(True)
+        save.update({f"{tag}_HWN": np.array([H, W, N]), f"{tag}_L": L, f"{tag}_keypoints": pair.keypoints,
+                     f"{tag}_masks": np.packbits(pair.keypoint_regions, axis=-1), f"{tag}_disc": np.packbits(disc.numpy(), axis=-1),
+                     f"{tag}_split": np.packbits(split.numpy(), axis=-1), f"{tag}_labels": lab.astype(np.int32),
+                     f"{tag}_n_labels": np.array(n_lab), f"{tag}_new_masks": np.packbits(new.keypoint_regions.numpy(), axis=-1),
+                     f"{tag}_new_K": np.array(new.keypoint_regions.shape[0]), f"{tag}_new_logdepth_sum": new.logdepth_perseg.double().sum((1, 2)).numpy(),
+                     f"{tag}_new_keypoints": new.keypoints.numpy()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -419,6 +450,7 @@ def main():
     golden_traj_sfm(ref, "g9a_traj_sfm")
     golden_traj_track(ref, "g9b_traj_track")
     golden_traj_map(ref, "g9c_traj_map")
+    golden_post_process(ref, "g10_post_process")
     print("wrote", sorted(os.listdir(OUT)))
 
 

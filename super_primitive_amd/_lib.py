@@ -38,6 +38,11 @@ SIGNATURES = {
     "sp_depth_average": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],
     "sp_se3_retract": [P, P, I, P, P, P, P],
     "sp_renormalise_se3": [P, I, P],
+    "sp_depth_discontinuity": [P, P, I, I, I, I, F, P, P, P, P],
+    "sp_label_components": [P, I, I, I, P, P, P, P],
+    "sp_collect_parts": [P, P, P, P, I, I, I, I, P, P, P, P],
+    "sp_build_part_masks": [P, P, P, I, I, P, I, P, P],
+    "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
 SP_ABI_VERSION = 1

@@ -194,3 +194,16 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
         pose_gt=T_gt.astype(f32), pose_init=T_init.astype(f32),
         meta=dict(seed=seed, shape=shape, overlap=overlap, xi_gt=xi_gt, kp_rc=kp_rc),
     )
+
+
+def stepped_logdepth(pair, seed=0, n_boxes=3, factor=(0.55, 0.75)):
+    """Per-segment log-depths of ``pair`` after pulling a few axis-aligned boxes towards the camera: depth steps
+    inside segments, the situation ``frontend/segment/post_processer.py`` exists for.  Returns (N,H,W) f32."""
+    rng = np.random.default_rng(seed)
+    d = pair.depth.astype(np.float64).copy()
+    H, W = d.shape
+    for _ in range(n_boxes):
+        r0, c0 = int(rng.uniform(0.05, 0.6) * H), int(rng.uniform(0.05, 0.6) * W)
+        r1, c1 = r0 + int(rng.uniform(0.15, 0.35) * H), c0 + int(rng.uniform(0.15, 0.35) * W)
+        d[r0:r1, c0:c1] *= rng.uniform(*factor)
+    return (np.log(d)[None] * pair.keypoint_regions).astype(np.float32)

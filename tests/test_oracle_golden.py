@@ -218,3 +218,33 @@ def test_traj_tracking_loop():
     np.testing.assert_allclose(losses, g["losses"], rtol=1e-3)
     np.testing.assert_allclose(supp_T.numpy(), g["final_supp_T"], atol=1e-4)
     np.testing.assert_allclose(aff.detach().numpy(), g["final_aff"], atol=1e-4)
+
+
+# ---- G10: keyframe post-processing (N2) -- frontend oracle vs the real reference module (cupy stubbed by scipy) ----
+def _g10_case(g, tag):
+    H, W, N = (int(v) for v in g[f"{tag}_HWN"])
+    unpack = lambda a, n: np.unpackbits(a, axis=-1, count=W).astype(bool).reshape(n, H, W)
+    return H, W, N, unpack
+
+
+@pytest.mark.parametrize("tag", ["grid", "blobs"])
+def test_post_process_oracle(tag):
+    from oracle import frontend_oracle as fo
+    g = load_golden("g10_post_process")
+    H, W, N, unpack = _g10_case(g, tag)
+    masks = T(unpack(g[f"{tag}_masks"], N))
+    L = T(g[f"{tag}_L"])
+    disc, split = fo.discontinuity(L.clone(), masks)
+    assert np.array_equal(disc.numpy(), unpack(g[f"{tag}_disc"], N))
+    assert np.array_equal(split.numpy(), unpack(g[f"{tag}_split"], N))
+    assert disc.any() and split.any()
+    labels, n_lab = fo.label_slices(split)
+    assert n_lab == int(g[f"{tag}_n_labels"]) and np.array_equal(labels, g[f"{tag}_labels"])
+    frame = orc.OracleFrame(torch.zeros(3, H, W), torch.eye(3), L, T(g[f"{tag}_keypoints"]), masks)
+    torch.manual_seed(123)
+    nm, nL, nk = fo.fix_disconnected(frame)
+    K = int(g[f"{tag}_new_K"])
+    assert nm.shape[0] == K and K > N
+    assert np.array_equal(nm.numpy(), unpack(g[f"{tag}_new_masks"], K))
+    np.testing.assert_allclose(nL.double().sum((1, 2)).numpy(), g[f"{tag}_new_logdepth_sum"], rtol=1e-12)
+    np.testing.assert_allclose(nk.numpy(), g[f"{tag}_new_keypoints"], rtol=0, atol=1e-7)
