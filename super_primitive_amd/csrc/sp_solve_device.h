@@ -6,32 +6,6 @@
 
 #define SP_LM_STRIDE SP_LM_STATE_FLOATS
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-
-// Sum over the block of one double per thread; result valid in every thread.
-__device__ __forceinline__ double block_sum_d(double v, double* lds /* SP_WAVES */) {
-    const double w = wave_sum_d(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = w;
-    __syncthreads();
-    double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < SP_WAVES; ++i) t += lds[i];
-    return t;
-}
-
-// Column k of the pair's tile partials summed over all its tiles (strided over the block, fixed order).
-template <int NV>
-__device__ __forceinline__ double reduce_column(const float* __restrict__ p, int n_tiles, int k, double* lds) {
-    double s = 0.0;
-    for (int t = threadIdx.x; t < n_tiles; t += SP_BLOCK) s += (double)p[(size_t)t * NV + k];
-    return block_sum_d(s, lds);
-}
-
 // All NV columns of the pair's tile partials summed over its tiles, into out[NV] (LDS).  Thread (g, c) = (tid / NV,
 // tid % NV) walks tiles g, g+G, ... of column c: neighbouring threads read neighbouring floats of one 4*NV-byte
 // tile record (coalesced), every thread's loads are independent (pipelined), and the G group partials are added

@@ -4,7 +4,8 @@ import torch
 
 
 def dict_cpu(d):
-    return {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in d.items()}
+    # keys starting with "_sp" are device-side handles of this package (segment table etc.): not for the GUI process
+    return {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in d.items() if not str(k).startswith("_sp")}
 
 
 def list_cpu(items):
