@@ -327,6 +327,8 @@ __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const C
     c.ay = 2.f * c.w.sy * c.w.invHm1;
 }
 
+#include "sp_cost_packed.h"
+
 // ------------------------------------------------------------------------------------------------
 // single source keyframe, B targets: grid = (n_tiles, B)
 // ------------------------------------------------------------------------------------------------
@@ -454,6 +456,33 @@ __global__ __launch_bounds__(SP_BLOCK, (MODE == 0 && FUSED == 0) ? 5 : 1) void k
     }
 }
 
+// developer A/B kernel: two points per lane, packed fp32 (sp_cost_packed.h)
+template <int MODE, int WAVES>
+__global__ __launch_bounds__(SP_BLOCK, WAVES) void k_cost_pairs_pk(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
+                                                                   int n_tiles, float irls_eps, float* __restrict__ partials) {
+    constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
+    __shared__ float lds[SP_WAVES * NV];
+    const int t = xcd_chunked_tile(blockIdx.x, n_tiles);
+    if (t >= n_tiles) return;
+    const int4 tile = tiles[t];
+    const SpPair& pr = pairs[tile.x];
+    TileCtx c;
+    c.pix = (gptr_u32)pr.pix;
+    c.src4 = (gptr_f4)pr.src4;
+    c.trg = (gptr_f32)pr.trg3;
+    c.Ks = Cam{pr.K_src[0], pr.K_src[1], pr.K_src[2], pr.K_src[3]};
+    const Cam Kt{pr.K_trg[0], pr.K_trg[1], pr.K_trg[2], pr.K_trg[3]};
+    fill_warp(c, pr.pose, Kt, pr.H, pr.W, pr.Hl, pr.Wl, pr.zmin);
+    c.shift = pr.kld[tile.y] - pr.kp_L[tile.y];
+    c.gain = 1.f; c.bias = 0.f;
+    if (pr.aff) {
+        c.gain = expf(-(pr.aff[2] - pr.aff[0]));
+        c.bias = pr.aff[3] - pr.aff[1];
+    }
+    c.start = tile.z; c.count = tile.w;
+    pk::run_tile_pk<MODE, 0>(c, irls_eps, partials + (size_t)t * NV, lds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-point diagnostics (collect_stats > 0): grid = (ceil(P/256), B)
 // ------------------------------------------------------------------------------------------------
@@ -573,7 +602,7 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
 int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int mode, float irls_eps,
                   float* partials, void* stream) {
     if (!pairs || !tiles || !partials || n_tiles_total <= 0) return SP_EINVAL;
-    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13)) return SP_EINVAL;
+    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13) && !(mode >= 20 && mode <= 21)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_tiles_total + 7) / 8) * 8;
     const int4* t4 = reinterpret_cast<const int4*>(tiles);
@@ -582,6 +611,10 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, 
         hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else if (mode == 1)
         hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
+    else if (mode == 20)   /* developer A/B: packed two-points-per-lane kernels (192 / 232 VGPRs, 2 waves per SIMD) */
+        hipLaunchKernelGGL((k_cost_pairs_pk<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+    else if (mode == 21)
+        hipLaunchKernelGGL((k_cost_pairs_pk<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
     else if (mode == 10)   /* developer ablations, see run_tile */
         hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else if (mode == 11)
