@@ -303,3 +303,19 @@ def test_fused_single_launch_iteration_is_bitwise_the_two_launch_one(mode):
     assert int(a.arrivals.abs().sum()) == 0, "arrival counters must be left zeroed"
     if mode == "gn":
         assert torch.equal(a.lm_state, b.lm_state)
+
+
+def test_packed_developer_kernels_agree_with_the_shipped_ones():
+    """Modes 20/21 of sp_pairs_cost (two points per lane, packed fp32; kept for A/B measurements) must produce the
+    same tile sums as modes 0/1 up to summation order."""
+    from super_primitive_amd import _lib, synth
+    pairs = [synth.make_pair(72, 96, 7, seed=120 + k, init_sigma=0.01, shape="blobs" if k else "grid") for k in range(3)]
+    batch = make_batch(pairs, levels=(0, 1), tile_points=1024)
+    for ship, dev, nv in ((0, 20, _lib.SP_GRAD_PARTIAL_FLOATS), (1, 21, _lib.SP_GN_PARTIAL_FLOATS)):
+        n = batch.n_tiles * nv
+        batch.cost_pass(0, ship)
+        a = batch.partials[:n].clone().reshape(-1, nv).double().sum(0)
+        batch.cost_pass(0, dev)
+        b = batch.partials[:n].reshape(-1, nv).double().sum(0)
+        scale = a.abs().max()
+        assert float((a - b).abs().max()) <= 1e-4 * float(scale)
