@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: Gauss-Newton iterations/sec on 640x480, 64-segment synthetic frame pairs (BASELINE.json).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 100
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -41,8 +41,11 @@ H, W = 480, 640
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--settle-ms", type=float, default=150.0,
+                    help="untimed steps run for this long before the W warm-up steps, so the clocks of a box that was idle "
+                         "have ramped to their steady state (DESIGN.md §6); 0 disables")
     ap.add_argument("--pairs", type=int, default=96, help="frame pairs resident per GPU")
     ap.add_argument("--segments", type=int, default=64, help="segments per source keyframe (BASELINE config 5 uses 128)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
@@ -125,6 +128,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.settle_ms > 0:          # power management: an idle MI355X needs ~30 ms of load to reach steady-state clocks
+        t_end = time.perf_counter() + 1e-3 * args.settle_ms
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     K = args.steps
@@ -168,7 +177,7 @@ def main():
     value = world * M * K / elapsed
     line = {
         "metric": f"GN iters/sec (640x480x{args.segments}-seg frame pairs)" if args.mode == "gn" else f"Adam iters/sec (640x480x{args.segments}-seg frame pairs)",
-        "value": value, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "value": value, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "settle_ms": args.settle_ms,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Replica-shaped two-frame SfM, 640x480, {args.segments} segments (grid, 4 px overlap), pyramid "

@@ -312,6 +312,210 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float
     }
 }
 
+// -----------------------------------------------------------------------------------------------------
+// mode 1, register-pair formulation.  The same sums as fold_gn / finish_gn, arranged so that almost every
+// multiply-add is a v_pk_fma_f32 on an aligned register pair (wave64 issues a packed fp32 op in the same four
+// cycles as a scalar one):
+//   * the red and green channels of a tap are the two halves of one pair, blue is scalar;
+//   * the columns of Ahat are kept as pairs along the column index (A0p[k] = {Ahat0[2+2k], Ahat0[3+2k]}), so
+//     B = W' Ahat, the 4x4 block of H_pp, b_p and h_pd are all "pair += scalar * pair".
+// Two entries of the 4x4 block are accumulated twice ((1,0) next to (1,1), (3,2) next to (3,3)); they are dropped
+// when the pairs are written back to the SP_GN_PARTIAL_FLOATS layout.
+// -----------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pfma(float a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(f32x2{a, a}, b, c); }
+
+struct GnAcc {
+    f32x2 h00;        // acc[1], acc[2]
+    f32x2 h0[2];      // acc[3..6]
+    f32x2 h1[2];      // acc[8..11]
+    f32x2 blk[6];     // rows (0,k0) (0,k1) (1,k0) (1,k1) (2,k1) (3,k1) of the 4x4 block
+    f32x2 bp01;       // acc[22], acc[23]
+    f32x2 bp[2];      // acc[24..27]
+    f32x2 hd01;       // acc[28], acc[29]
+    f32x2 hd[2];      // acc[30..33]
+    float h11;        // acc[7]
+    float D, bd;      // acc[34], acc[35]
+    float cost, n;    // acc[0], acc[36]
+};
+
+struct Pending2 {          // Pending, with the x/y quantities as register pairs
+    f32x2 qxy; float qz, zinv, zi;
+    f32x2 wxy; float m;
+    f32x2 srg; float sb;
+    uint32_t off0, off1;
+};
+
+// prepare() on pairs: same operations in the same order per component (sp_device.h backproject / warp_point)
+__device__ __forceinline__ void prepare2(const TileCtx& c, f32x2 ifxy, uint32_t pw, const f32x4 s, Pending2& p) {
+    const f32x2 colrow{(float)(pw & 0xffffu), (float)((pw >> 16) & 0x7fffu)};
+    const bool src_ok = (int32_t)pw < 0;
+    const float d = fast_exp(s.w + c.shift);
+    const Warp& w = c.w;
+    const f32x2 xy = ((colrow - f32x2{c.Ks.cx, c.Ks.cy}) * d) * ifxy;
+    const f32x2 qxy = pfma(f32x2{w.R[0], w.R[3]}, f32x2{xy.x, xy.x},
+                           pfma(f32x2{w.R[1], w.R[4]}, f32x2{xy.y, xy.y}, f32x2{w.R[2], w.R[5]} * d)) + f32x2{w.t[0], w.t[1]};
+    const float qz = fmaf(w.R[6], xy.x, fmaf(w.R[7], xy.y, w.R[8] * d)) + w.t[2];
+    const bool zguard = fabsf(qz) > 1e-6f;
+    const float zinv = zguard ? __builtin_amdgcn_rcpf(qz) : 1e-6f;
+    const f32x2 uv = qxy * f32x2{w.Kt.fx, w.Kt.fy} * zinv + f32x2{w.Kt.cx, w.Kt.cy};
+    const f32x2 n = 2.f * uv * f32x2{w.invWm1, w.invHm1} - 1.f;
+    const bool ok = (fabsf(n.x) <= 0.99f) && (fabsf(n.y) <= 0.99f) && (qz > w.zmin) && src_ok && (d > 1e-7f);
+    p.m = ok ? 1.f : 0.f;
+    p.qxy = qxy; p.qz = qz;
+    p.zinv = ok ? zinv : 0.f;
+    p.zi = (ok && zguard) ? zinv : 0.f;
+    p.srg = f32x2{s.x, s.y}; p.sb = s.z;
+    const f32x2 i0 = (n + 1.f) * f32x2{w.sx, w.sy};
+    const f32x2 ixy{ok ? i0.x : 0.f, ok ? i0.y : 0.f};
+    const f32x2 fl{floorf(ixy.x), floorf(ixy.y)};
+    p.wxy = ixy - fl;
+    uint32_t texel, off0;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(texel) : "v"((uint32_t)(int)fl.y), "s"((uint32_t)c.Wl), "v"((uint32_t)(int)fl.x));
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(off0) : "v"(texel), "s"(4u * SP_TEXEL_FLOATS));
+    p.off0 = off0;
+    p.off1 = off0 + c.row_bytes;
+}
+
+struct Mix2 { f32x2 wa, v; float w11; };      // {w00, w01}, {v0, v1}, w11
+
+__device__ __forceinline__ void finish_gn2(const TileCtx& c, const Pending2& p, const f32x3 a, const f32x3 b,
+                                           const f32x3 cc, const f32x3 d, float eps, Mix2& o, float& cost_acc, float& n_acc) {
+    // red+green as a pair
+    const f32x2 a2{a.x, a.y}, b2{b.x, b.y}, c2{cc.x, cc.y}, d2{d.x, d.y};
+    const f32x2 e1 = b2 - a2, e2 = c2 - a2, e3 = (d2 - c2) - e1;
+    const f32x2 Iy2 = pfma(p.wxy.x, e3, e2);
+    const f32x2 Ix2 = pfma(p.wxy.y, e3, e1);
+    const f32x2 it2 = pfma(p.wxy.y, Iy2, pfma(p.wxy.x, e1, a2));
+    const f32x2 r2 = p.srg - pfma(c.gain, it2, f32x2{c.bias, c.bias});
+    // blue
+    float itb, Ixb, Iyb;
+    tap_mix(a.z, b.z, cc.z, d.z, p.wxy.x, p.wxy.y, itb, Ixb, Iyb);
+    const float rb = p.sb - fmaf(c.gain, itb, c.bias);
+    const float ar0 = fabsf(r2.x), ar1 = fabsf(r2.y), arb = fabsf(rb);
+    const f32x2 wg2{__builtin_amdgcn_rcpf(fmaxf(ar0, eps)), __builtin_amdgcn_rcpf(fmaxf(ar1, eps))};
+    const float wgb = __builtin_amdgcn_rcpf(fmaxf(arb, eps));
+    const f32x2 wx2 = wg2 * Ix2, wy2 = wg2 * Iy2;
+    const float wxb = wgb * Ixb, wyb = wgb * Iyb;
+    const f32x2 w00p = wx2 * Ix2, w01p = wx2 * Iy2, w11p = wy2 * Iy2, v0p = wx2 * r2, v1p = wy2 * r2;
+    o.wa = f32x2{fmaf(wxb, Ixb, w00p.x) + w00p.y, fmaf(wxb, Iyb, w01p.x) + w01p.y};
+    o.w11 = fmaf(wyb, Iyb, w11p.x) + w11p.y;
+    o.v = f32x2{fmaf(wxb, rb, v0p.x) + v0p.y, fmaf(wyb, rb, v1p.x) + v1p.y};
+    cost_acc = fmaf(p.m, (ar0 + ar1) + arb, cost_acc);
+    n_acc += p.m;
+}
+
+struct GeoGn { f32x2 qxy; float qz, zinv, zi; };
+__device__ __forceinline__ void fold_gn2(const TileCtx& c, const GeoGn g, const Mix2 w, GnAcc& A) {
+    const f32x2 g2 = f32x2{c.gain * c.ax * c.w.Kt.fx, c.gain * c.ay * c.w.Kt.fy} * g.zinv;   // {ga, gb}; zinv carries the mask
+    const f32x2 Wa = w.wa * (g2 * g2.x);                 // {W00, W01}
+    const float W11 = w.w11 * (g2.y * g2.y);
+    const f32x2 V = -(w.v * g2);
+    const f32x2 qxy = g.qxy;
+    const f32x2 u = qxy * g.zi;                          // {ux, vy}
+    const float ez = g.qz - c.w.t[2];
+    const f32x2 Q = pfma(-ez, u, qxy - f32x2{c.w.t[0], c.w.t[1]});   // column 6 of Ahat: {A0[4], A1[4]}
+    // columns 2..5 of Ahat as pairs along the column index
+    const f32x2 A00{-u.x, -u.x * qxy.y}, A01{fmaf(u.x, qxy.x, g.qz), -qxy.y};
+    const f32x2 A10{-u.y, -fmaf(u.y, qxy.y, g.qz)}, A11{u.y * qxy.x, qxy.x};
+    const f32x2 B00 = pfma(Wa.x, A00, Wa.y * A10), B01 = pfma(Wa.x, A01, Wa.y * A11);
+    const f32x2 B10 = pfma(Wa.y, A00, W11 * A10), B11 = pfma(Wa.y, A01, W11 * A11);
+    const f32x2 P = pfma(Q.x, Wa, Q.y * f32x2{Wa.y, W11});          // {B0[4], B1[4]}
+    A.h00 += Wa; A.h11 += W11;
+    A.h0[0] += B00; A.h0[1] += B01;
+    A.h1[0] += B10; A.h1[1] += B11;
+    A.blk[0] = pfma(A00.x, B00, pfma(A10.x, B10, A.blk[0]));
+    A.blk[1] = pfma(A00.x, B01, pfma(A10.x, B11, A.blk[1]));
+    A.blk[2] = pfma(A00.y, B00, pfma(A10.y, B10, A.blk[2]));
+    A.blk[3] = pfma(A00.y, B01, pfma(A10.y, B11, A.blk[3]));
+    A.blk[4] = pfma(A01.x, B01, pfma(A11.x, B11, A.blk[4]));
+    A.blk[5] = pfma(A01.y, B01, pfma(A11.y, B11, A.blk[5]));
+    A.bp01 += V;
+    A.hd01 += P;
+    A.bp[0] = pfma(V.x, A00, pfma(V.y, A10, A.bp[0]));
+    A.bp[1] = pfma(V.x, A01, pfma(V.y, A11, A.bp[1]));
+    A.hd[0] = pfma(P.x, A00, pfma(P.y, A10, A.hd[0]));
+    A.hd[1] = pfma(P.x, A01, pfma(P.y, A11, A.hd[1]));
+    A.D = fmaf(Q.x, P.x, fmaf(Q.y, P.y, A.D));
+    A.bd = fmaf(Q.x, V.x, fmaf(Q.y, V.y, A.bd));
+}
+
+template <bool WRITE_THROUGH = false>
+__device__ __forceinline__ void run_tile_gn2(const TileCtx& c, float irls_eps, float* __restrict__ out, float* lds) {
+    constexpr int NV = SP_GN_PARTIAL_FLOATS;
+    GnAcc A;
+    {
+        const f32x2 z{0.f, 0.f};
+        A.h00 = z; A.bp01 = z; A.hd01 = z;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { A.h0[k] = z; A.h1[k] = z; A.bp[k] = z; A.hd[k] = z; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) A.blk[k] = z;
+        A.h11 = A.D = A.bd = A.cost = A.n = 0.f;
+    }
+    const f32x2 ifxy{1.f / c.Ks.fx, 1.f / c.Ks.fy};
+    const rsrc_t r_pix = make_rsrc(c.pix + c.start, (uint32_t)c.count * 4u);
+    const rsrc_t r_src = make_rsrc(c.src4 + c.start, (uint32_t)c.count * 16u);
+    const rsrc_t r_trg = make_rsrc(c.trg, (uint32_t)c.Wl * (uint32_t)c.Hl * (4u * SP_TEXEL_FLOATS));
+    const int n_iter = (c.count + SP_BLOCK - 1) / SP_BLOCK;
+    uint32_t op = threadIdx.x * 4u;     // byte offset of this lane's word in the tile's pix run (x4: its src4 record)
+    constexpr int NT = 2;
+    Pending2 nx;
+    {
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
+        const f32x4 s = buf_load4<NT>(r_src, op * 4u);
+        prepare2(c, ifxy, pw, s, nx);
+    }
+    GeoGn cur{nx.qxy, nx.qz, 0.f, 0.f};
+    Mix2 m{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, 0.f};
+    for (int j = 0; j < n_iter; ++j) {
+        op += 4u * SP_BLOCK;
+        asm volatile("" : "+v"(op));        // one induction register; the src4 offset is a shift of it
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
+        const f32x4 s = buf_load4<NT>(r_src, op * 4u);
+        f32x3 ta = buf_load3(r_trg, nx.off0);
+        f32x3 tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
+        f32x3 tc = buf_load3(r_trg, nx.off1);
+        f32x3 td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
+        __builtin_amdgcn_sched_barrier(0);
+        fold_gn2(c, cur, m, A);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(A.blk[0]), "+v"(A.blk[1]), "+v"(A.blk[2]),
+                     "+v"(A.blk[3]), "+v"(A.blk[4]), "+v"(A.blk[5]), "+v"(A.bp[0]), "+v"(A.bp[1]), "+v"(A.hd[0]),
+                     "+v"(A.hd[1]), "+v"(A.D), "+v"(A.bd));
+        finish_gn2(c, nx, ta, tb, tc, td, irls_eps, m, A.cost, A.n);
+        cur = GeoGn{nx.qxy, nx.qz, nx.zinv, nx.zi};
+        uint32_t pw_ = pw;
+        f32x4 s_ = s;
+        asm volatile("" : "+v"(pw_), "+v"(s_));
+        prepare2(c, ifxy, pw_, s_, nx);
+    }
+    fold_gn2(c, cur, m, A);
+    float acc[NV];
+    acc[0] = A.cost;
+    acc[1] = A.h00.x; acc[2] = A.h00.y;
+    acc[3] = A.h0[0].x; acc[4] = A.h0[0].y; acc[5] = A.h0[1].x; acc[6] = A.h0[1].y;
+    acc[7] = A.h11;
+    acc[8] = A.h1[0].x; acc[9] = A.h1[0].y; acc[10] = A.h1[1].x; acc[11] = A.h1[1].y;
+    acc[12] = A.blk[0].x; acc[13] = A.blk[0].y; acc[14] = A.blk[1].x; acc[15] = A.blk[1].y;
+    acc[16] = A.blk[2].y; acc[17] = A.blk[3].x; acc[18] = A.blk[3].y;
+    acc[19] = A.blk[4].x; acc[20] = A.blk[4].y; acc[21] = A.blk[5].y;
+    acc[22] = A.bp01.x; acc[23] = A.bp01.y;
+    acc[24] = A.bp[0].x; acc[25] = A.bp[0].y; acc[26] = A.bp[1].x; acc[27] = A.bp[1].y;
+    acc[28] = A.hd01.x; acc[29] = A.hd01.y;
+    acc[30] = A.hd[0].x; acc[31] = A.hd[0].y; acc[32] = A.hd[1].x; acc[33] = A.hd[1].y;
+    acc[34] = A.D; acc[35] = A.bd; acc[36] = A.n; acc[37] = acc[38] = acc[39] = 0.f;
+    // op still knows the thread index (op = 4 * (threadIdx.x + trips * SP_BLOCK)): nothing derived from threadIdx.x
+    // has to stay live, or be spilled, across the loop for the sake of this epilogue
+    const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
+    const float total = block_sum_to_thread<NV>(acc, lds, tid);
+    if (tid < NV) {
+        if (WRITE_THROUGH) __hip_atomic_store(out + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[tid] = total;
+    }
+}
+
 __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const Cam& Kt, int H, int W, int Hl, int Wl,
                                           float zmin) {
     load_pose(pose, c.w.R, c.w.t);
@@ -412,7 +616,7 @@ struct FuseArgs {
 };
 
 template <int MODE, int ABL = 0, int FUSED = 0>
-__global__ __launch_bounds__(SP_BLOCK, (MODE == 0 && FUSED == 0) ? 5 : 1) void k_cost_pairs(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
+__global__ __launch_bounds__(SP_BLOCK, (MODE == 0 && FUSED == 0) ? 5 : (MODE == 1 && ABL == 0 && FUSED == 0) ? 4 : 1) void k_cost_pairs(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
                                                          int n_tiles, float irls_eps, float* __restrict__ partials, FuseArgs f) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
     __shared__ float lds[SP_WAVES * NV];
@@ -434,7 +638,8 @@ __global__ __launch_bounds__(SP_BLOCK, (MODE == 0 && FUSED == 0) ? 5 : 1) void k
         c.bias = pr.aff[3] - pr.aff[1];
     }
     c.start = tile.z; c.count = tile.w;
-    run_tile<MODE, ABL, FUSED != 0>(c, irls_eps, partials + (size_t)t * NV, lds);
+    if (MODE == 1 && ABL == 0) run_tile_gn2<FUSED != 0>(c, irls_eps, partials + (size_t)t * NV, lds);
+    else run_tile<MODE, ABL == 3 ? 0 : ABL, FUSED != 0>(c, irls_eps, partials + (size_t)t * NV, lds);
     if (FUSED != 0) {
         __shared__ int is_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -602,7 +807,7 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
 int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int mode, float irls_eps,
                   float* partials, void* stream) {
     if (!pairs || !tiles || !partials || n_tiles_total <= 0) return SP_EINVAL;
-    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13) && !(mode >= 20 && mode <= 21)) return SP_EINVAL;
+    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13) && !(mode >= 20 && mode <= 23)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_tiles_total + 7) / 8) * 8;
     const int4* t4 = reinterpret_cast<const int4*>(tiles);
@@ -615,6 +820,8 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, 
         hipLaunchKernelGGL((k_cost_pairs_pk<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
     else if (mode == 21)
         hipLaunchKernelGGL((k_cost_pairs_pk<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
+    else if (mode == 23)   /* developer A/B: the one-scalar-per-register Gauss-Newton fold (fold_gn / finish_gn) */
+        hipLaunchKernelGGL((k_cost_pairs<1, 3>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else if (mode == 10)   /* developer ablations, see run_tile */
         hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
     else if (mode == 11)

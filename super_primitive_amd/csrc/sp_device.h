@@ -66,9 +66,9 @@ __device__ __forceinline__ void halve_step(float* v, bool upper) {
 }
 
 template <int NV>
-__device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* lds /* SP_WAVES*NV floats */) {
+__device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* lds /* SP_WAVES*NV floats */, int tid) {
     static_assert(NV <= 64, "one value per lane at most");
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
     constexpr int N0 = NV, N1 = (N0 + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
     halve_step<N0, 32>(acc, lane & 32);
     halve_step<N1, 16>(acc, lane & 16);
@@ -88,11 +88,15 @@ __device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* ld
     if (ok) lds[wave * NV + pos] = acc[0];
     __syncthreads();
     float total = 0.f;
-    if (threadIdx.x < NV) {
+    if (tid < NV) {
 #pragma unroll
-        for (int w = 0; w < SP_WAVES; ++w) total += lds[w * NV + threadIdx.x];
+        for (int w = 0; w < SP_WAVES; ++w) total += lds[w * NV + tid];
     }
     return total;
+}
+template <int NV>
+__device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* lds) {
+    return block_sum_to_thread<NV>(acc, lds, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -311,7 +311,8 @@ def test_packed_developer_kernels_agree_with_the_shipped_ones():
     from super_primitive_amd import _lib, synth
     pairs = [synth.make_pair(72, 96, 7, seed=120 + k, init_sigma=0.01, shape="blobs" if k else "grid") for k in range(3)]
     batch = make_batch(pairs, levels=(0, 1), tile_points=1024)
-    for ship, dev, nv in ((0, 20, _lib.SP_GRAD_PARTIAL_FLOATS), (1, 21, _lib.SP_GN_PARTIAL_FLOATS)):
+    for ship, dev, nv in ((0, 20, _lib.SP_GRAD_PARTIAL_FLOATS), (1, 21, _lib.SP_GN_PARTIAL_FLOATS),
+                          (1, 23, _lib.SP_GN_PARTIAL_FLOATS)):
         n = batch.n_tiles * nv
         batch.cost_pass(0, ship)
         a = batch.partials[:n].clone().reshape(-1, nv).double().sum(0)

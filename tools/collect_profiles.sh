@@ -7,13 +7,17 @@ R=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out/$R
 mkdir -p $OUT
-python bench.py --steps 20 --warmup 3 > $OUT/bench_n1.json 2>/dev/null
-python bench.py --steps 20 --warmup 3 --mode adam --no-cpu-baseline --no-extras > $OUT/bench_n1_adam.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2>/dev/null
+python bench.py > $OUT/bench_n1.json 2>/dev/null
+python bench.py --mode adam --no-cpu-baseline --no-extras > $OUT/bench_n1_adam.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2>/dev/null
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$tag -o bench -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$tag -o bench -- python bench.py --settle-ms 0 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 done
-python tools/kbench.py --pairs 64 --tile-points 8192 --modes 0,1,10,11,12,13 --reps 30 2>/dev/null | grep level > $OUT/kbench_ablation.txt
+python tools/kbench.py --pairs 96 --tile-points 8192 --modes 1,0,1,23,21,10,11,12,13 --reps 40 2>/dev/null | grep level > $OUT/kbench_ablation.txt
 python tools/run_configs.py 2>/dev/null | grep config > $OUT/configs.txt
-ls -R $OUT | head -40
+# package power and shader clock, sampled once a second across a 16 s run of the bench step
+(python bench.py --steps 60000 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_long.json 2>/dev/null &)
+for i in $(seq 1 24); do sleep 1; rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|Package Power" | sed "s/.*: //" | tr "\n" " "; echo; done > $OUT/power_clock_trace.txt
+wait
+ls $OUT
