@@ -241,6 +241,14 @@ int sp_build_part_masks(const uint8_t* masks, const uint8_t* split, const int32_
 int sp_kth_mask_pixel(const uint8_t* masks, const int32_t* row_off, int K, int H, int W, const int32_t* kth,
                       int32_t* out_rc, void* stream);
 
+/* odometery/kf_criteria.py:7-21 translation_difference, :23-34 rotation_difference and the depth-validity ratio of
+ * odometery/odometery.py:1003-1004, in one launch without a host sync.  depth: n floats (the rendered depth of the
+ * latest keyframe); poses row-major 4x4.  out[4] = {#(depth > thresh)/n, scale = lower median of the valid depths
+ * (torch.median; NaN when none is valid), |t_src - t_trg| / (scale + 1e-6), rotation angle of
+ * inv(pose_src) pose_trg in degrees}. */
+int sp_kf_criterion(const float* depth, int n, float thresh, const float* pose_src, const float* pose_trg, float* out,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,7 +45,8 @@ def import_reference():
     import odometery.depth_init as rdi
     import tool.point_utils as rpu
     import frontend.segment.post_processer as rpp
-    return types.SimpleNamespace(do=rdo, dob=rdob, dr=rdr, kf=rkf, la=rla, di=rdi, pu=rpu, pp=rpp)
+    import odometery.kf_criteria as rkc
+    return types.SimpleNamespace(do=rdo, dob=rdob, dr=rdr, kf=rkf, la=rla, di=rdi, pu=rpu, pp=rpp, kc=rkc)
 
 
 sys.path.insert(0, ROOT)
@@ -411,6 +412,35 @@ def golden_post_process(ref, name):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_kf_criteria(ref, name):
+    """N3: translation_difference / rotation_difference on rendered-depth-like images: holes (zeros), even and odd valid
+    counts, a single valid pixel, large and tiny rotations."""
+    rng = np.random.default_rng(2024)
+    save = {}
+    cases = {"odd": (37, 53, 0.3), "even": (48, 64, 0.25), "dense": (60, 80, 0.0), "one": (8, 9, None)}
+    for tag, (H, W, holes) in cases.items():
+        depth = rng.uniform(0.4, 6.0, (H, W)).astype(np.float32)
+        if holes is None:
+            depth[:] = 0.0
+            depth[3, 4] = 2.5
+        else:
+            depth[rng.uniform(size=(H, W)) < holes] = 0.0
+            if tag == "even" and (depth > 1e-6).sum() % 2:
+                depth[np.argwhere(depth > 1e-6)[0][0], np.argwhere(depth > 1e-6)[0][1]] = 0.0
+            if tag == "odd" and (depth > 1e-6).sum() % 2 == 0:
+                depth[np.argwhere(depth > 1e-6)[0][0], np.argwhere(depth > 1e-6)[0][1]] = 0.0
+        scale_rot = {"odd": 0.05, "even": 1.2, "dense": 1e-4, "one": 2.9}[tag]
+        a = synth.se3_exp_np(np.concatenate([rng.standard_normal(3), 0.3 * rng.standard_normal(3)])).astype(np.float32)
+        b = (synth.se3_exp_np(np.concatenate([0.4 * rng.standard_normal(3), scale_rot * np.array([0.6, -0.48, 0.64])]))
+             @ a.astype(np.float64)).astype(np.float32)
+        diff, scale = ref.kc.translation_difference(T(a), T(b), T(depth))
+        ang = ref.kc.rotation_difference(T(a), T(b))
+        save.update({f"{tag}_depth": depth, f"{tag}_pose_src": a, f"{tag}_pose_trg": b, f"{tag}_diff": np.float32(diff.item()),
+                     f"{tag}_scale": np.float32(scale.item()), f"{tag}_angle_deg": np.float64(ang),
+                     f"{tag}_n_valid": np.int64((depth > 1e-6).sum())})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -451,6 +481,7 @@ def main():
     golden_traj_track(ref, "g9b_traj_track")
     golden_traj_map(ref, "g9c_traj_map")
     golden_post_process(ref, "g10_post_process")
+    golden_kf_criteria(ref, "g11_kf_criteria")
     print("wrote", sorted(os.listdir(OUT)))
 
 

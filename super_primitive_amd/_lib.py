@@ -36,6 +36,7 @@ SIGNATURES = {
     "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_segment_reinit": [P, P, P, P, I, I, I, I, P, I, P, P, P, P],
     "sp_depth_average": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],
+    "sp_kf_criterion": [P, I, F, P, P, P, P],
     "sp_se3_retract": [P, P, I, P, P, P, P],
     "sp_renormalise_se3": [P, I, P],
     "sp_depth_discontinuity": [P, P, I, I, I, I, F, P, P, P, P],

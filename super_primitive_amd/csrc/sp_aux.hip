@@ -222,6 +222,72 @@ __global__ __launch_bounds__(SP_BLOCK) void k_average_finish(const unsigned long
     invalid[i] = c == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// odometery/kf_criteria.py:7-34 + the validity ratio of odometery/odometery.py:1003-1004, one launch, no host sync:
+//   out[0] = #(depth > thresh) / n            out[1] = scale = lower median of the valid depths (torch.median)
+//   out[2] = |t_src - t_trg| / (scale + 1e-6) out[3] = rotation angle of inv(pose_src) pose_trg in degrees
+// Single workgroup: one counting pass + 4 radix passes over an image that sits in L2.
+// ---------------------------------------------------------------------------------------------------
+constexpr int KF_BLOCK = 1024;
+__global__ __launch_bounds__(KF_BLOCK) void k_kf_criterion(const float* __restrict__ depth, int n, float thresh,
+                                                           const float* __restrict__ pose_src,
+                                                           const float* __restrict__ pose_trg, float* __restrict__ out) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t chosen, remaining;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+    __syncthreads();
+    // pass 0: the valid count and the top-byte histogram together (depth > thresh > 0 => raw bits are orderable)
+    for (int i = threadIdx.x; i < n; i += KF_BLOCK) {
+        const float v = depth[i];
+        if (v > thresh) atomicAdd(&hist[__float_as_uint(v) >> 24], 1u);
+    }
+    __syncthreads();
+    uint32_t cnt = 0;
+    for (int b = 0; b < 256; ++b) cnt += hist[b];           // every thread: same value, LDS broadcast reads
+    uint32_t prefix = 0, mask = 0;
+    uint32_t k = cnt ? (cnt - 1u) / 2u : 0u;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (shift != 24) {
+            __syncthreads();
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += KF_BLOCK) {
+                const float v = depth[i];
+                const uint32_t key = __float_as_uint(v);
+                if (v > thresh && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            uint32_t run = 0; int b = 0;
+            for (; b < 255; ++b) { if (run + hist[b] > k) break; run += hist[b]; }
+            chosen = (uint32_t)b; remaining = k - run;
+        }
+        __syncthreads();
+        prefix |= chosen << shift;
+        mask |= 0xffu << shift;
+        k = remaining;
+    }
+    if (threadIdx.x == 0) {
+        const float scale = cnt ? __uint_as_float(prefix) : __builtin_nanf("");     // torch.median of nothing raises
+        out[0] = (float)cnt / (float)n;
+        out[1] = scale;
+        const float dx = pose_src[3] - pose_trg[3], dy = pose_src[7] - pose_trg[7], dz = pose_src[11] - pose_trg[11];
+        out[2] = sqrtf(dx * dx + dy * dy + dz * dz) / (scale + 1e-6f);
+        // rotation part of inv(pose_src) @ pose_trg = R_s^T R_t; angle = atan2(|axis part|, (trace - 1) / 2), in fp64
+        double D[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double a = 0.0;
+                for (int m = 0; m < 3; ++m) a += (double)pose_src[4 * m + i] * (double)pose_trg[4 * m + j];
+                D[3 * i + j] = a;
+            }
+        const double ax = D[7] - D[5], ay = D[2] - D[6], az = D[3] - D[1];
+        const double sn = 0.5 * sqrt(ax * ax + ay * ay + az * az), cs = 0.5 * (D[0] + D[4] + D[8] - 1.0);
+        out[3] = (float)(atan2(sn, cs) * 57.29577951308232);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -284,6 +350,15 @@ int sp_depth_average(const uint32_t* pix, const float* baseL, const int32_t* seg
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_average_finish, dim3((unsigned)((HW + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), 0, s, sums, counts,
                        (int)HW, out_depth, out_invalid);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_kf_criterion(const float* depth, int n, float thresh, const float* pose_src, const float* pose_trg, float* out,
+                    void* stream) {
+    if (!depth || !pose_src || !pose_trg || !out || n <= 0 || !(thresh >= 0.f)) return SP_EINVAL;
+    hipLaunchKernelGGL(k_kf_criterion, dim3(1), dim3(KF_BLOCK), 0, static_cast<hipStream_t>(stream), depth, n, thresh,
+                       pose_src, pose_trg, out);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -74,6 +74,41 @@ def test_segment_reinit_and_average_match_reference():
     np.testing.assert_allclose(npy(avg2), g["avg_depth"], rtol=2e-6, atol=1e-7)
 
 
+def test_kf_criteria_match_reference():
+    """odometery/kf_criteria.py on the HIP path: the median is an element of the image (bit-exact), the translation
+    ratio fp32, the angle within 1e-4 deg of scipy's (fp32 poses enter an fp64 atan2)."""
+    from oracle import kf_oracle
+    from super_primitive_amd.odometery.kf_criteria import keyframe_criterion, rotation_difference, translation_difference
+    g = load_golden("g11_kf_criteria")
+    for tag in ("odd", "even", "dense", "one"):
+        a, b, d = T(g[f"{tag}_pose_src"]), T(g[f"{tag}_pose_trg"]), T(g[f"{tag}_depth"])
+        diff, scale = translation_difference(a, b, d)
+        assert diff.ndim == 0 and scale.ndim == 0 and diff.is_cuda
+        assert float(scale) == float(g[f"{tag}_scale"])
+        np.testing.assert_allclose(float(diff), float(g[f"{tag}_diff"]), rtol=2e-6)
+        ang = rotation_difference(a, b)
+        assert isinstance(ang, np.float64)
+        np.testing.assert_allclose(ang, float(g[f"{tag}_angle_deg"]), rtol=2e-5, atol=1e-4)
+        out = npy(keyframe_criterion(a, b, d))
+        np.testing.assert_allclose(out[0], int(g[f"{tag}_n_valid"]) / d.numel(), rtol=1e-6)
+    # full-size image with duplicates, holes and denormal-ish junk below the threshold, against the oracle
+    rng = np.random.default_rng(9)
+    depth = rng.uniform(0.2, 9.0, (480, 640)).astype(np.float32)
+    depth[rng.uniform(size=depth.shape) < 0.4] = 0.0
+    depth[rng.uniform(size=depth.shape) < 0.05] = 5e-7
+    depth[100:200, 100:300] = 1.25                                        # a large plateau of equal values
+    d = T(depth)
+    a, b = T(g["odd_pose_src"]), T(g["odd_pose_trg"])
+    want_diff, want_scale = kf_oracle.translation_difference(a.cpu(), b.cpu(), d.cpu())
+    out = npy(keyframe_criterion(a, b, d))
+    assert out[1] == float(want_scale)
+    np.testing.assert_allclose(out[2], float(want_diff), rtol=2e-6)
+    np.testing.assert_allclose(out[0], float(kf_oracle.validity_ratio(d.cpu())), rtol=1e-6)
+    # nothing valid: the reference's torch.median raises on an empty tensor; the kernel reports NaN without syncing
+    out = npy(keyframe_criterion(a, b, torch.zeros(64, 64, device=d.device)))
+    assert out[0] == 0.0 and np.isnan(out[1]) and np.isnan(out[2])
+
+
 def test_infer_depth_seeds_matches_oracle():
     from oracle import photometric_oracle as orc
     from super_primitive_amd import synth

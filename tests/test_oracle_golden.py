@@ -142,6 +142,18 @@ def test_segment_stats():
     np.testing.assert_allclose(avg.numpy(), g["avg_depth"], rtol=1e-6, atol=1e-7)
 
 
+def test_kf_criteria():
+    from oracle import kf_oracle
+    g = load_golden("g11_kf_criteria")
+    for tag in ("odd", "even", "dense", "one"):
+        a, b, d = T(g[f"{tag}_pose_src"]), T(g[f"{tag}_pose_trg"]), T(g[f"{tag}_depth"])
+        diff, scale = kf_oracle.translation_difference(a, b, d)
+        assert float(scale) == float(g[f"{tag}_scale"])                      # an element of the image: exact
+        np.testing.assert_allclose(float(diff), float(g[f"{tag}_diff"]), rtol=1e-6)
+        np.testing.assert_allclose(kf_oracle.rotation_difference(a, b), float(g[f"{tag}_angle_deg"]), rtol=1e-9, atol=1e-12)
+        assert int((d > 1e-6).sum()) == int(g[f"{tag}_n_valid"])
+
+
 def test_lie():
     g = load_golden("g8_lie")
     np.testing.assert_allclose(orc.renormalise_se3(T(g["in_noisy"]).clone()).numpy(), g["renorm"], rtol=1e-6, atol=1e-7)
