@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 1
+#define SP_ABI_VERSION 2
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -105,14 +105,15 @@ int sp_photo_cost_grad(const uint32_t* pix, const float* src4, const int32_t* se
                        void* stream);
 
 /* Per-point diagnostics of the same pass (collect_stats > 0 in the reference, core/dense_optim.py:347-361).
- * Any output pointer may be NULL.  Shapes: src_pts (P,3); trg_pts (B,P,3); src_rgb (3,P); trg_rgb (B,3,P)
- * after brightness compensation; raw (B,3,P) = (I_src - I_trg')*mask; src_valid (P) u8; trg_valid (B,P) u8;
- * seg_ids (P) int64. */
+ * Any output pointer may be NULL.  Only every stride-th table point is reported (stride 1 = the reference's
+ * tensors; > 1 = the down-sampled channel for a visualiser): with Q = ceil(P / stride) rows the
+ * shapes are src_pts (Q,3); trg_pts (B,Q,3); src_rgb (3,Q); trg_rgb (B,3,Q) after brightness compensation;
+ * raw (B,3,Q) = (I_src - I_trg')*mask; src_valid (Q) u8; trg_valid (B,Q) u8; seg_ids (Q) int64. */
 int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_off, const float* kp_L, int N, int P,
                    int H, int W, const float* K_src, const float* kld, const float* trg3, int Hl, int Wl,
                    const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
                    float zmin, float* src_pts, float* trg_pts, float* src_rgb, float* trg_rgb, float* raw,
-                   uint8_t* src_valid, uint8_t* trg_valid, int64_t* seg_ids, void* stream);
+                   uint8_t* src_valid, uint8_t* trg_valid, int64_t* seg_ids, int stride, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Many independent frame pairs per launch (BASELINE.json configs 2 and 5; the throughput path).  Each pair

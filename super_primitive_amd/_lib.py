@@ -26,7 +26,7 @@ SIGNATURES = {
     "sp_pack_rgb": [P, I, I, I, P, P],
     "sp_blur_decimate": [P, I, I, I, P, P],
     "sp_photo_cost_grad": [P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P],
-    "sp_photo_stats": [P, P, P, P, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P, P, P, P],
+    "sp_photo_stats": [P, P, P, P, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P, P, P, I, P],
     "sp_pairs_cost": [P, P, I, I, F, P, P],
     "sp_pairs_adam_step": [P, I, I, P, F, F, F, P, P, P],
     "sp_pairs_gn_step": [P, I, I, P, F, F, F, P, P, P, P],
@@ -46,7 +46,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 1
+SP_ABI_VERSION = 2
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 40
 SP_LM_STATE_FLOATS = 8

@@ -98,11 +98,12 @@ def _debug_finite(t, what):
         raise AssertionError(f"non-finite {what}")
 
 
-def _run_stats(table, src4, kld, K_src, trg4, K_trg, poses, aff, zmin, want_target=True):
-    """Per-point diagnostics via sp_photo_stats; returns a dict of raw device tensors."""
+def _run_stats(table, src4, kld, K_src, trg4, K_trg, poses, aff, zmin, want_target=True, stride=1):
+    """Per-point diagnostics via sp_photo_stats; returns a dict of raw device tensors (every ``stride``-th table point)."""
     lib = _lib.load()
     dev = table.device
-    P = table.P
+    stride = max(1, int(stride))
+    P = (table.P + stride - 1) // stride
     B = 1 if poses is None else poses.shape[0]
     out = dict(src_pts=torch.empty(P, 3, dtype=torch.float32, device=dev),
                src_rgb=torch.empty(1, 3, P, dtype=torch.float32, device=dev),
@@ -121,12 +122,90 @@ def _run_stats(table, src4, kld, K_src, trg4, K_trg, poses, aff, zmin, want_targ
     if aff is not None and want_target:
         a_s, a_t = _f32c(aff[0]), _f32c(aff[1]).reshape(B, 2).contiguous()
     rc = lib.sp_photo_stats(
-        _lib.ptr(table.pix), _lib.ptr(src4), _lib.ptr(table.seg_off), _lib.ptr(table.kp_L), table.N, P, table.H, table.W,
+        _lib.ptr(table.pix), _lib.ptr(src4), _lib.ptr(table.seg_off), _lib.ptr(table.kp_L), table.N, table.P, table.H, table.W,
         _lib.ptr(K_src), _lib.ptr(_f32c(kld)), _lib.ptr(trg4) if want_target else None, Hl, Wl,
         _lib.ptr(K_trg) if want_target else None, _lib.ptr(_f32c(poses)) if want_target else None, B, _lib.ptr(a_s),
         _lib.ptr(a_t), float(zmin), _lib.ptr(out['src_pts']), _lib.ptr(trg_pts), _lib.ptr(out['src_rgb']), _lib.ptr(trg_rgb),
-        _lib.ptr(raw), _lib.ptr(out['src_valid']), _lib.ptr(trg_valid), _lib.ptr(out['seg_ids']), _lib.stream_ptr())
+        _lib.ptr(raw), _lib.ptr(out['src_valid']), _lib.ptr(trg_valid), _lib.ptr(out['seg_ids']), stride, _lib.stream_ptr())
     _lib.check(rc, "sp_photo_stats")
+    return out
+
+
+class LazyStats(dict):
+    """The dict ``photomeric_cost*`` returns when ``collect_stats > 0``.
+
+    ``'residual'`` is there from the start; the per-point diagnostic tensors (``src_pts``, ``residual_raw``, ... --
+    26 MB per call at 640x480x64) are produced by ONE extra launch the first time anything else is looked at
+    (``d['src_pts']``, ``d.items()``, ``dict_cpu(d)`` ...).  A driver that configures ``collect_stats`` like the
+    reference's (always 2) but whose visualiser is not attached therefore never pays for them.  The inputs that
+    define the diagnostics (log-depths, poses, affine pairs) are snapshotted at call time, so looking later -- after
+    ``optimizer.step()`` has moved the parameters in place -- still shows the state the residual was computed at.
+    ``cost_config['stats_stride'] = s`` reports every s-th table point only (the down-sampled channel for a GUI);
+    ``cost_config['stats_lazy'] = False`` restores eager evaluation."""
+
+    def __init__(self, residual, producer):
+        super().__init__(residual=residual)
+        self._producer = producer
+
+    def materialise(self):
+        producer, self._producer = self._producer, None
+        if producer is not None:
+            super().update(producer())
+        return self
+
+    def __getitem__(self, key):
+        if key != 'residual':
+            self.materialise()
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        if key != 'residual':
+            self.materialise()
+        return super().get(key, default)
+
+    def __contains__(self, key):
+        if key != 'residual':
+            self.materialise()
+        return super().__contains__(key)
+
+    def __iter__(self):
+        return iter(self.materialise().keys())
+
+    def __len__(self):
+        self.materialise()
+        return super().__len__()
+
+    def keys(self):
+        self.materialise()
+        return super().keys()
+
+    def items(self):
+        self.materialise()
+        return super().items()
+
+    def values(self):
+        self.materialise()
+        return super().values()
+
+    def copy(self):
+        return dict(self.materialise())
+
+    def __repr__(self):
+        return dict.__repr__(self.materialise())
+
+    def __reduce__(self):               # pickles (multiprocessing queues) as the plain dict it stands for
+        return (dict, (dict(self.materialise()),))
+
+
+def _snap(t):
+    return None if t is None else t.detach().clone()
+
+
+def _with_stats(residual, cost_config, producer):
+    if cost_config.get('stats_lazy', True):
+        return LazyStats(residual, producer)
+    out = {'residual': residual}
+    out.update(producer())
     return out
 
 
@@ -160,17 +239,22 @@ def photomeric_cost(src_keyframe, trg_keyframe, src_keypoint_logdepth, pose, cos
             assert aff_t is None
     residual = _FusedPhotoCost.apply(src_keypoint_logdepth, pose[None], aff_s, aff_t, table, src4, trg4, K_src, K_trg,
                                      Z_MIN_SINGLE)
-    result = {'residual': residual}
-    if collect_stats > 0:
-        aff = None if aff_s is None else (aff_s, aff_t)
-        st = _run_stats(table, src4, src_keypoint_logdepth, K_src, trg4, K_trg, pose[None], aff, Z_MIN_SINGLE)
+    if collect_stats <= 0:
+        return {'residual': residual}
+    kld_s, pose_s, aff = _snap(src_keypoint_logdepth), _snap(pose), None if aff_s is None else (_snap(aff_s), _snap(aff_t))
+    stride = cost_config.get('stats_stride', 1)
+
+    def producer():
+        st = _run_stats(table, src4, kld_s, K_src, trg4, K_trg, pose_s[None], aff, Z_MIN_SINGLE, stride=stride)
         full = (st['trg_valid'] & st['src_valid'])[:, None].long()
-        result.update(segm_ids=st['seg_ids'], src_pixels=st['src_rgb'], src_in_trg_pixels=st['trg_rgb'],
-                      src_valid_mask=st['src_valid'], trg_valid_mask=st['trg_valid'], full_mask=full,
-                      src_pts=st['src_pts'], src_in_trg_pts=st['trg_pts'][0], residual_raw=st['raw'], median_depth=None)
+        out = dict(segm_ids=st['seg_ids'], src_pixels=st['src_rgb'], src_in_trg_pixels=st['trg_rgb'],
+                   src_valid_mask=st['src_valid'], trg_valid_mask=st['trg_valid'], full_mask=full,
+                   src_pts=st['src_pts'], src_in_trg_pts=st['trg_pts'][0], residual_raw=st['raw'], median_depth=None)
         if collect_stats > 1:
-            result.update(_keypoint_stats(src_keyframe, trg_keyframe, src_keypoint_logdepth, pose))
-    return result
+            out.update(_keypoint_stats(src_keyframe, trg_keyframe, kld_s, pose_s))
+        return out
+
+    return _with_stats(residual, cost_config, producer)
 
 
 def _keypoint_stats(src_kf, trg_kf, kld, pose):

@@ -48,21 +48,27 @@ def photomeric_cost_batch(src_keyframe, trg_images, trg_Ks, src_keypoint_logdept
     if affine_comp is not None:
         aff_s, aff_t = affine_comp
     residual = _FusedPhotoCost.apply(src_keypoint_logdepth, poses, aff_s, aff_t, table, src4, trg4, K_src, K_trg, Z_MIN_BATCH)
-    result = {'residual': residual}
-    if collect_stats > 0:
-        aff = None if aff_s is None else (aff_s, aff_t)
-        st = _run_stats(table, src4, src_keypoint_logdepth, K_src, trg4, K_trg, poses, aff, Z_MIN_BATCH)
+    if collect_stats <= 0:
+        return {'residual': residual}
+    kld_s, poses_s = _do._snap(src_keypoint_logdepth), _do._snap(poses)
+    aff = None if aff_s is None else (_do._snap(aff_s), _do._snap(aff_t))
+    stride = cost_config.get('stats_stride', 1)
+
+    def producer():
+        st = _run_stats(table, src4, kld_s, K_src, trg4, K_trg, poses_s, aff, Z_MIN_BATCH, stride=stride)
         full = (st['trg_valid'] & st['src_valid'])[:, None].long()
-        result.update(segm_ids=st['seg_ids'], src_pixels=st['src_rgb'], src_in_trg_pixels=st['trg_rgb'],
-                      src_valid_mask=st['src_valid'], trg_valid_mask=st['trg_valid'], full_mask=full,
-                      src_pts=st['src_pts'], src_in_trg_pts=st['trg_pts'], residual_raw=st['raw'], median_depth=None)
+        out = dict(segm_ids=st['seg_ids'], src_pixels=st['src_rgb'], src_in_trg_pixels=st['trg_rgb'],
+                   src_valid_mask=st['src_valid'], trg_valid_mask=st['trg_valid'], full_mask=full,
+                   src_pts=st['src_pts'], src_in_trg_pts=st['trg_pts'], residual_raw=st['raw'], median_depth=None)
         if collect_stats > 1:
             with torch.no_grad():
                 H, W = src_keyframe.geo_spatial_dim()
                 kp_cr = point_utils.denormalise_coordinates(src_keyframe.keypoints, (H, W)).flip(-1)
-                kp3 = _do.unproject_points(kp_cr, torch.exp(src_keypoint_logdepth.detach()), src_keyframe.K)
-                kp3 = transform_points_batch(kp3, poses.detach())
+                kp3 = _do.unproject_points(kp_cr, torch.exp(kld_s), src_keyframe.K)
+                kp3 = transform_points_batch(kp3, poses_s)
                 _, ok = get_pixels_batch(trg_images, kp3, trg_Ks, spatial_dim=(H, W))
-                result.update(src_in_trg_keypoints=project_points_batch(kp3, trg_Ks), src_in_trg_keypoints_z=kp3[..., 2],
-                              src_in_trg_keypoints_valid_mask=ok)
-    return result
+                out.update(src_in_trg_keypoints=project_points_batch(kp3, trg_Ks), src_in_trg_keypoints_z=kp3[..., 2],
+                           src_in_trg_keypoints_valid_mask=ok)
+        return out
+
+    return _do._with_stats(residual, cost_config, producer)

@@ -696,6 +696,7 @@ struct StatsArgs {
     const float* K_src; const float* kld; const float* trg; const float* K_trg; const float* pose;
     const float* aff_src; const float* aff_trg;
     int N, P, H, W, Hl, Wl;
+    int stride, Pout;   // every stride-th table point is reported; Pout = ceil(P / stride) rows per output
     float zmin;
     float *src_pts, *trg_pts, *src_rgb, *trg_rgb, *raw;
     uint8_t *src_valid, *trg_valid;
@@ -703,8 +704,9 @@ struct StatsArgs {
 };
 
 __global__ __launch_bounds__(SP_BLOCK) void k_stats(StatsArgs a) {
-    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
-    if (i >= a.P) return;
+    const int o = blockIdx.x * SP_BLOCK + threadIdx.x;       // output row
+    if (o >= a.Pout) return;
+    const int i = o * a.stride;                              // table point
     const int b = blockIdx.y;
     // segment of point i: binary search in seg_off
     int lo = 0, hi = a.N;
@@ -728,12 +730,12 @@ __global__ __launch_bounds__(SP_BLOCK) void k_stats(StatsArgs a) {
     src_ok = src_ok && d > 1e-7f;
     float x, y;
     backproject(col, row, d, c.Ks, 1.f / c.Ks.fx, 1.f / c.Ks.fy, x, y);
-    const size_t P = a.P;
+    const size_t P = a.Pout;
     if (b == 0) {
-        if (a.src_pts) { a.src_pts[3 * i] = x; a.src_pts[3 * i + 1] = y; a.src_pts[3 * i + 2] = d; }
-        if (a.src_rgb) { a.src_rgb[i] = s.x; a.src_rgb[P + i] = s.y; a.src_rgb[2 * P + i] = s.z; }
-        if (a.src_valid) a.src_valid[i] = src_ok;
-        if (a.seg_ids) a.seg_ids[i] = n;
+        if (a.src_pts) { a.src_pts[3 * o] = x; a.src_pts[3 * o + 1] = y; a.src_pts[3 * o + 2] = d; }
+        if (a.src_rgb) { a.src_rgb[o] = s.x; a.src_rgb[P + o] = s.y; a.src_rgb[2 * P + o] = s.z; }
+        if (a.src_valid) a.src_valid[o] = src_ok;
+        if (a.seg_ids) a.seg_ids[o] = n;
     }
     if (!a.trg) return;   // source-only query (unproject_kf)
     PointGeom g;
@@ -745,12 +747,12 @@ __global__ __launch_bounds__(SP_BLOCK) void k_stats(StatsArgs a) {
                          fmaf(gain, bilerp(tp.t00.z, tp.t10.z, tp.t01.z, tp.t11.z, tp.wx, tp.wy), bias)};
     const float sv[3] = {s.x, s.y, s.z};
     const float m = (g.valid && src_ok) ? 1.f : 0.f;
-    if (a.trg_pts) { float* q = a.trg_pts + ((size_t)b * P + i) * 3; q[0] = g.qx; q[1] = g.qy; q[2] = g.qz; }
-    if (a.trg_valid) a.trg_valid[(size_t)b * P + i] = g.valid;
+    if (a.trg_pts) { float* q = a.trg_pts + ((size_t)b * P + o) * 3; q[0] = g.qx; q[1] = g.qy; q[2] = g.qz; }
+    if (a.trg_valid) a.trg_valid[(size_t)b * P + o] = g.valid;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        if (a.trg_rgb) a.trg_rgb[((size_t)b * 3 + ch) * P + i] = it[ch];
-        if (a.raw) a.raw[((size_t)b * 3 + ch) * P + i] = (sv[ch] - it[ch]) * m;
+        if (a.trg_rgb) a.trg_rgb[((size_t)b * 3 + ch) * P + o] = it[ch];
+        if (a.raw) a.raw[((size_t)b * 3 + ch) * P + o] = (sv[ch] - it[ch]) * m;
     }
 }
 
@@ -790,15 +792,15 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
                    int H, int W, const float* K_src, const float* kld, const float* trg3, int Hl, int Wl,
                    const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
                    float zmin, float* src_pts, float* trg_pts, float* src_rgb, float* trg_rgb, float* raw,
-                   uint8_t* src_valid, uint8_t* trg_valid, int64_t* seg_ids, void* stream) {
-    if (!pix || !src4 || !seg_off || !kp_L || !K_src || !kld) return SP_EINVAL;
+                   uint8_t* src_valid, uint8_t* trg_valid, int64_t* seg_ids, int stride, void* stream) {
+    if (!pix || !src4 || !seg_off || !kp_L || !K_src || !kld || stride < 1) return SP_EINVAL;
     if (trg3 && (!K_trg || !pose)) return SP_EINVAL;      /* trg3 == NULL: source-side outputs only */
     if (N <= 0 || P <= 0 || B <= 0 || H < 2 || W < 2) return SP_EINVAL;
     if ((aff_src == nullptr) != (aff_trg == nullptr)) return SP_EINVAL;
     StatsArgs a{pix, reinterpret_cast<const float4*>(src4), seg_off, kp_L, K_src, kld,
-                trg3, K_trg, pose, aff_src, aff_trg, N, P, H, W, Hl, Wl, zmin,
+                trg3, K_trg, pose, aff_src, aff_trg, N, P, H, W, Hl, Wl, stride, (P + stride - 1) / stride, zmin,
                 src_pts, trg_pts, src_rgb, trg_rgb, raw, src_valid, trg_valid, seg_ids};
-    hipLaunchKernelGGL(k_stats, dim3((P + SP_BLOCK - 1) / SP_BLOCK, B), dim3(SP_BLOCK), 0,
+    hipLaunchKernelGGL(k_stats, dim3((a.Pout + SP_BLOCK - 1) / SP_BLOCK, B), dim3(SP_BLOCK), 0,
                        static_cast<hipStream_t>(stream), a);
     SP_CHECK_LAUNCH();
     return 0;

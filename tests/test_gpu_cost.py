@@ -154,6 +154,51 @@ def test_bitwise_reproducible_and_tile_size_invariant():
         close_rel_max(other[2], res[0][2], 1e-4, "g_pose vs tile size")
 
 
+def test_stats_channel_is_lazy_snapshotted_and_strided():
+    """the diagnostics dict costs nothing until it is looked at, shows the state the residual was computed
+    at even when read after the parameters moved, and can be down-sampled on the device."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.core import dense_optim, dense_optim_batch
+    from super_primitive_amd.tool.etc import dict_cpu
+    pair = synth.make_pair(60, 80, 7, seed=31, shape="blobs")
+    src, trg = frames_from_synth(pair)
+    kld = T(pair.kld_init, requires_grad=True)
+    pose = T(pair.pose_init, requires_grad=True)
+    aff = (T(np.array([0.01, -0.02], np.float32)), T(np.array([0.03, 0.01], np.float32)))
+    eager = dense_optim.photomeric_cost(src, trg, kld, pose, {"mode": "colour", "collect_stats": 2, "stats_lazy": False},
+                                        affine_comp=aff)
+    assert type(eager) is dict
+    lazy = dense_optim.photomeric_cost(src, trg, kld, pose, CFG2, affine_comp=aff)
+    assert isinstance(lazy, dense_optim.LazyStats) and lazy._producer is not None
+    assert float(lazy["residual"]) == float(eager["residual"]) and lazy._producer is not None     # still not produced
+    lazy["residual"].backward()
+    with torch.no_grad():                                        # an optimiser step moves the parameters in place
+        kld -= 0.3
+        pose[:3, 3] += 0.05
+        aff[1].add_(0.2)
+    got = dict_cpu(lazy)                                         # first look: one launch, on the snapshots
+    assert lazy._producer is None and set(got) == set(eager)
+    for k, v in eager.items():
+        if torch.is_tensor(v):
+            assert torch.equal(got[k], v.detach().cpu()), k
+    # down-sampled channel: every 5th table point
+    kld2, pose2 = T(pair.kld_init), T(pair.pose_init)
+    full = dense_optim.photomeric_cost(src, trg, kld2, pose2, {"mode": "colour", "collect_stats": 1})
+    thin = dense_optim.photomeric_cost(src, trg, kld2, pose2, {"mode": "colour", "collect_stats": 1, "stats_stride": 5})
+    P = full["src_pts"].shape[0]
+    assert thin["src_pts"].shape[0] == (P + 4) // 5
+    assert torch.equal(thin["src_pts"], full["src_pts"][::5]) and torch.equal(thin["segm_ids"], full["segm_ids"][::5])
+    assert torch.equal(thin["src_in_trg_pts"], full["src_in_trg_pts"][::5])
+    for k in ("src_pixels", "src_in_trg_pixels", "residual_raw", "src_valid_mask", "trg_valid_mask", "full_mask"):
+        assert torch.equal(thin[k], full[k][..., ::5]), k
+    # the batched form goes through the same channel
+    P3 = torch.stack([pose2, pose2, pose2])
+    imgs, Ks = torch.stack([trg.image] * 3), torch.stack([trg.K] * 3)
+    fb = dense_optim_batch.photomeric_cost_batch(src, imgs, Ks, kld2, P3, {"mode": "colour", "collect_stats": 1})
+    tb = dense_optim_batch.photomeric_cost_batch(src, imgs, Ks, kld2, P3, {"mode": "colour", "collect_stats": 1, "stats_stride": 7})
+    assert torch.equal(tb["src_in_trg_pts"], fb["src_in_trg_pts"][:, ::7]) and torch.equal(tb["residual_raw"], fb["residual_raw"][..., ::7])
+
+
 def test_host_tensors_are_refused():
     """No CPU fallback: the product path must fail loudly rather than compute somewhere else."""
     from super_primitive_amd import synth

@@ -192,3 +192,24 @@ def test_install_as_reference_modules_aliases_the_packages():
         for k in list(sys.modules):
             if k.split(".")[0] in ("core", "image", "lie", "tool", "odometery", "depth_completion") and k not in saved:
                 sys.modules.pop(k, None)
+
+
+def test_lazy_stats_dict_semantics():
+    """LazyStats behaves like the plain dict it stands for; the producer runs once, on first look."""
+    import pickle
+    from super_primitive_amd.core.dense_optim import LazyStats
+    calls = []
+
+    def producer():
+        calls.append(1)
+        return {"src_pts": torch.arange(6.).reshape(2, 3), "median_depth": None}
+
+    d = LazyStats(torch.tensor([0.25]), producer)
+    assert float(d["residual"]) == 0.25 and d.get("residual") is not None and "residual" in d and not calls
+    assert "src_pts" in d and calls == [1]
+    assert set(d.keys()) == {"residual", "src_pts", "median_depth"} and len(d) == 3 and d["median_depth"] is None
+    assert {k for k, _ in d.items()} == set(d) and len(list(d.values())) == 3 and calls == [1]
+    e = LazyStats(torch.tensor([0.5]), producer)
+    back = pickle.loads(pickle.dumps(e))
+    assert type(back) is dict and set(back) == {"residual", "src_pts", "median_depth"} and calls == [1, 1]
+    assert type(LazyStats(torch.tensor([1.0]), producer).copy()) is dict
