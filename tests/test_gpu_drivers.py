@@ -1,9 +1,11 @@
 """-m gpu: the reference's three optimiser loop shapes, driven through the drop-in Python API on the HIP cost,
 against K-step golden trajectories recorded with the real reference cost functions (G9-a/b/c).
 
-Adam's update m/sqrt(v) is sign-like in the first steps, so fp32-noise-level gradient differences become O(lr)
-parameter differences; tolerances below are therefore stated at lr scale, while the first loss values (before any
-amplification) are required to agree tightly."""
+Adam's update m/sqrt(v) is sign-like in the first steps, so fp32-noise-level gradient differences can be amplified
+along the trajectory; the first loss values (before any amplification) are required to agree tightly, the final
+parameters to about 5x the deviation measured on MI355X (tools/traj_deviation.py):
+two-frame SfM after 80 steps 8.5e-5 rad / 1.1e-4 t / 3.2e-5 log-depth; tracking 9.8e-6 rad / 1.2e-5 t; mapping
+4.8e-6 rad / 1.2e-5 t / 1.2e-5 log-depth."""
 import numpy as np
 import pytest
 import torch
@@ -28,8 +30,8 @@ def test_two_frame_sfm_loop_matches_reference_trajectory():
     np.testing.assert_allclose(losses[:3], want[:3], rtol=2e-5)
     assert losses[0] == losses[1], "no update on the very first iteration (count > 0)"
     np.testing.assert_allclose(losses, want, rtol=2e-2)
-    np.testing.assert_allclose(npy(sfm.keypoint_logdepths()), g["final_kld"], atol=3e-3)
-    np.testing.assert_allclose(npy(sfm.poses()[0]), g["final_pose"], atol=3e-3)
+    np.testing.assert_allclose(npy(sfm.keypoint_logdepths()), g["final_kld"], atol=2e-4)
+    np.testing.assert_allclose(npy(sfm.poses()[0]), g["final_pose"], atol=5e-4)
 
 
 def test_tracking_loop_matches_reference_trajectory():
@@ -46,9 +48,9 @@ def test_tracking_loop_matches_reference_trajectory():
                                       prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
     losses = np.array([float(l) for l in losses])
     np.testing.assert_allclose(losses[:3], g["losses"][:3], rtol=2e-5)
-    np.testing.assert_allclose(losses, g["losses"], rtol=2e-2)
-    np.testing.assert_allclose(npy(supp_T), g["final_supp_T"], atol=2e-3)
-    np.testing.assert_allclose(npy(aff), g["final_aff"], atol=2e-3)
+    np.testing.assert_allclose(losses, g["losses"], rtol=1e-2)
+    np.testing.assert_allclose(npy(supp_T), g["final_supp_T"], atol=1e-4)
+    np.testing.assert_allclose(npy(aff), g["final_aff"], atol=5e-5)
     R = npy(supp_T)[:3, :3]
     np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)          # renormalised at the end
 
@@ -64,10 +66,10 @@ def test_mapping_loop_matches_reference_trajectory():
         aff_src=torch.zeros(2, device=dev), affs=[torch.zeros(2, device=dev) for _ in range(2)])
     losses = np.array([float(l) for l in losses])
     np.testing.assert_allclose(losses[:3], g["losses"][:3], rtol=2e-5)
-    np.testing.assert_allclose(losses, g["losses"], rtol=2e-2)
-    np.testing.assert_allclose(npy(kld), g["final_kld"], atol=2e-2)
-    np.testing.assert_allclose(npy(poses), g["final_poses"], atol=5e-3)
-    np.testing.assert_allclose(npy(torch.stack(affs)), g["final_affs"], atol=1e-4)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+    np.testing.assert_allclose(npy(kld), g["final_kld"], atol=1e-4)
+    np.testing.assert_allclose(npy(poses), g["final_poses"], atol=1e-4)
+    np.testing.assert_allclose(npy(torch.stack(affs)), g["final_affs"], atol=1e-6)
 
 
 def test_depth_completion_driver_with_plugged_frontend():
