@@ -322,6 +322,43 @@ def golden_traj_sfm(ref, name, steps=40):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_converged(ref, name, steps=350):
+    """The minimiser of the REAL reference cost, for the Gauss-Newton/LM solver (which the reference does not have) to be
+    pinned against: the two-frame SfM loop of golden_traj_sfm run to convergence over 3 levels, then polished at the
+    finest level with the learning rates divided by 10 and by 100 so that Adam's fixed-step jitter is below 1e-5."""
+    pair = synth.make_pair(60, 80, 8, seed=41, init_sigma=0.01)
+    src, trg = ref_frames(ref, pair)
+    sp = ref.kf.keyframe_pyramid(src, 0, 3)
+    tp = ref.kf.keyframe_pyramid(trg, 0, 3)
+    kld = torch.nn.Parameter(T(pair.kld_init))
+    a = torch.nn.Parameter(torch.zeros(1, 6))
+    T0 = T(pair.pose_init)
+    cfg = {"mode": "colour", "collect_stats": 0}
+    losses = []
+
+    def run(s, t, n, scale):
+        opt = torch.optim.Adam([{"params": kld, "lr": 1e-3 * scale}, {"params": [a], "lr": 1e-2 * scale}], lr=1e-3)
+        for _ in range(n):
+            pose = orc.se3_exp(a)[0] @ T0
+            loss = torch.mean(torch.abs(ref.do.photomeric_cost(s, t, kld, pose, cfg)["residual"]))
+            losses.append(float(loss))
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+
+    for s, t in zip(sp, tp):
+        run(s, t, steps, 1.0)
+    for scale in (0.1, 0.01):
+        run(sp[-1], tp[-1], steps, scale)
+    with torch.no_grad():
+        pose = orc.se3_exp(a)[0] @ T0
+        final = float(torch.mean(torch.abs(ref.do.photomeric_cost(sp[-1], tp[-1], kld, pose, cfg)["residual"])))
+    save = pair_inputs(pair)
+    save.update(in_pose_init=pair.pose_init, in_kld=pair.kld_init, losses=np.array(losses), final_loss=np.array(final),
+                final_kld=kld.detach().numpy(), final_pose=pose.numpy(), pose_gt=pair.pose_gt, kld_gt=pair.kld_gt)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def golden_traj_track(ref, name, steps=40):
     pair = synth.make_pair(48, 64, 6, seed=32, init_sigma=0.01)
     src, trg = ref_frames(ref, pair)
@@ -482,6 +519,7 @@ def main():
     golden_traj_map(ref, "g9c_traj_map")
     golden_post_process(ref, "g10_post_process")
     golden_kf_criteria(ref, "g11_kf_criteria")
+    golden_converged(ref, "g12_converged_sfm")
     print("wrote", sorted(os.listdir(OUT)))
 
 
