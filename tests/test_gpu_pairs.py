@@ -114,9 +114,7 @@ def test_gn_reaches_the_minimiser_of_the_reference_cost():
     g = load_golden("g12_converged_sfm")
     src, trg = frames_from_golden(g)
     batch = PairBatch([src], [trg.image], [trg.K], T(g["in_pose_init"])[None].clone(), [T(g["in_kld"]).clone()], levels=(0, 3))
-    batch.run(15, mode="gn")
-    for _ in range(40):
-        batch.gn_step(0, irls_eps=1e-5)
+    batch.run(15, mode="gn", polish_iters=40, polish_eps=1e-5)
     cost = float(batch.evaluate(0)[0])
     assert cost <= float(g["final_loss"]) * (1 + 2e-5), (cost, float(g["final_loss"]))
     P, k = npy(batch.poses())[0].astype(np.float64), npy(batch.klds()[0]).astype(np.float64)
