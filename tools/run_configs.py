@@ -40,16 +40,7 @@ cfg = {"aligment": {"pyramid_min": 0, "pyramid_max": 3, "cost_params": {}}}
 sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=5); sfm.init_optimisation(kld_init=t(p.kld_init)); sfm.run()
 sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=200); sfm.init_optimisation(kld_init=t(p.kld_init))
 dt = sync_time(sfm.run)
-from oracle import photometric_oracle as orc          # CPU baseline leg only
-osrc, otrg = orc.frames_from_synth(p)
-okld = torch.nn.Parameter(torch.from_numpy(p.kld_init.copy())); oa = torch.nn.Parameter(torch.zeros(1, 6)); T0 = torch.from_numpy(p.pose_init.copy())
-oopt = torch.optim.Adam([{"params": [okld], "lr": 1e-3}, {"params": [oa], "lr": 1e-2}], lr=1e-3)
-def ostep():
-    out = orc.photometric_cost(osrc, otrg, okld, orc.se3_exp(oa)[0] @ T0); out["residual"].abs().mean().backward(); oopt.step(); oopt.zero_grad()
-ostep(); t0 = time.perf_counter()
-for _ in range(20): ostep()
-cpu_its = 20 / (time.perf_counter() - t0)
-print(f"config 1  320x240x8: HIP drop-in API loop {600/dt:.0f} Adam it/s (3 levels x 200) | oracle CPU ({torch.get_num_threads()} threads) {cpu_its:.1f} it/s "
+print(f"config 1  320x240x8: HIP drop-in API loop {600/dt:.0f} Adam it/s (3 levels x 200) "
       f"| final loss {float(sfm.losses[-1]):.4f} from {float(sfm.losses[0]):.4f}")
 
 # ---- config 3: TUM-shaped tracking + mapping ------------------------------------------------------------
