@@ -49,7 +49,8 @@ def parse():
     ap.add_argument("--pairs", type=int, default=96, help="frame pairs resident per GPU")
     ap.add_argument("--segments", type=int, default=64, help="segments per source keyframe (BASELINE config 5 uses 128)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
-    ap.add_argument("--tile-points", type=int, default=8192)
+    ap.add_argument("--tile-points", type=int, default=8192, help="longest chunk (piece of one segment)")
+    ap.add_argument("--span-points", type=int, default=None, help="points per workgroup (run of consecutive chunks); default: PairBatch's")
     ap.add_argument("--mode", choices=["gn", "adam"], default="gn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=8)
@@ -73,7 +74,8 @@ def build_batch(args, rank, dev):
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in pairs]
     batch = PairBatch(src, [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs], poses,
-                      [t(p.kld_init) for p in pairs], levels=(0, 3), tile_points=args.tile_points, replicate=R)
+                      [t(p.kld_init) for p in pairs], levels=(0, 3), tile_points=args.tile_points, replicate=R,
+                      **({} if getattr(args, 'span_points', None) is None else {'span_points': args.span_points}))
     return batch, pairs
 
 
@@ -183,7 +185,7 @@ def main():
         "config": {"workload": f"Replica-shaped two-frame SfM, 640x480, {args.segments} segments (grid, 4 px overlap), pyramid "
                                "level 0 of a 3-level pyramid; BASELINE.json configs[1]",
                    "pairs_per_gpu": M, "segment_pixels_per_pair": int(batch.Ps[0]), "optimiser": args.mode,
-                   "tile_points": args.tile_points, "sharding": f"{world} x independent pair batches, final all_gather only"},
+                   "tile_points": args.tile_points, "span_points": batch.span_points, "sharding": f"{world} x independent pair batches, final all_gather only"},
         "roofline": {"bound": "hbm", "kernel": f"k_cost_pairs<{mode_id}>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 2
+#define SP_ABI_VERSION 3
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -118,29 +118,42 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
 /* ------------------------------------------------------------------------------------------------------
  * Many independent frame pairs per launch (BASELINE.json configs 2 and 5; the throughput path).  Each pair
  * has its own segment table, target image, intrinsics, pose and log-depths, described by one SpPair record
- * in device memory; tiles[].x selects the pair.  No host synchronisation anywhere: one optimiser iteration
- * is sp_pairs_cost + one sp_pairs_*_step launch and can be captured in a hipGraph.
+ * in device memory.  No host synchronisation anywhere: one optimiser iteration is sp_pairs_cost + one
+ * sp_pairs_*_step launch and can be captured in a hipGraph.
+ *
+ * Work list.  The tables of this path are PADDED: every segment's run of points in pix / src4 is extended to a
+ * multiple of 256 with invalid points (pix word 0, src4 zeros; they contribute exact zeros).
+ *   chunks[C] int32x4 {pair, segment, start, count}: a run of `count` (multiple of 256) points of one segment,
+ *             `start` = index of its first point in the pair's padded arrays; chunks of a pair are consecutive
+ *             and contiguous in memory (segment-major, like the table);
+ *   spans[S]  int32x4 {first chunk, number of chunks, points, pair}: what one workgroup processes -- a run of
+ *             consecutive chunks of one pair; pair-level sums are reduced once per span, segment-level sums once
+ *             per chunk and wave.
+ * Partials: one record of (SP_GRAD_PARTIAL_FLOATS | SP_GN_PARTIAL_FLOATS) floats per (chunk, wave): record
+ * 4 * chunk + wave.  The solvers below sum records in index order; they only need, per pair, the index of its first
+ * record (SpPair.tile0 = 4 * first chunk), the number of its records (n_tiles = 4 * chunks) and, per segment, the
+ * record range of its chunks (seg_tile_off, relative to tile0).
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct SpPair {
-    const uint32_t* pix;      /* [P] */
-    const float*    src4;     /* [P*4] for the level being optimised */
+    const uint32_t* pix;      /* [P_padded] */
+    const float*    src4;     /* [P_padded*4] for the level being optimised */
     const float*    kp_L;     /* [N] */
     const float*    trg3;     /* [Hl*Wl*3] packed HWC3, for the level being optimised */
     float*          kld;      /* [N]  optimisation variable */
     float*          pose;     /* [16] optimisation variable (target <- source) */
     float*          aff;      /* [4]  {a_s,b_s,a_t,b_t} or NULL */
-    const int32_t*  seg_tile_off; /* [N+1] offsets into this pair's tiles, relative to tile0 */
+    const int32_t*  seg_tile_off; /* [N+1] offsets into this pair's partial records, relative to tile0 */
     float K_src[4];           /* fx fy cx cy */
     float K_trg[4];
-    int32_t N, P, H, W, Hl, Wl;
-    int32_t tile0;            /* first tile of this pair in the global tile array */
-    int32_t n_tiles;
+    int32_t N, P, H, W, Hl, Wl;   /* P = number of REAL points (the cost is a mean over 3 P values) */
+    int32_t tile0;            /* first partial record of this pair */
+    int32_t n_tiles;          /* number of partial records of this pair */
     float zmin;
-    int32_t pad_;
+    int32_t n_spans;          /* workgroups (spans) of this pair: the single-launch forms count their arrivals */
 } SpPair;
 
-/* mode 0 / 1 as above.  partials: n_tiles * (SP_GRAD_PARTIAL_FLOATS | SP_GN_PARTIAL_FLOATS) floats. */
-int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int mode, float irls_eps,
+/* mode 0 / 1 as above.  partials: 4 * C records. */
+int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                   float* partials, void* stream);
 
 /* Adam step on {kld, left SE(3) tangent, affine} of every pair from the mode-0 partials: reduces the tile
@@ -161,14 +174,14 @@ int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float*
 int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, float lm_up,
                      float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream);
 
-/* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last tile of a pair
+/* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last span of a pair
  * runs that pair's update in place (same arithmetic, same fixed reduction order as sp_pairs_cost followed by
  * sp_pairs_adam_step / sp_pairs_gn_step -- results are bitwise identical).  arrivals: n_pairs int32, zeroed once by
  * the caller (the kernel leaves it zeroed).  Other arguments as in the two-launch forms. */
-int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int n_pairs, int max_N,
+int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
                           float* partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
                           float* losses, void* stream);
-int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int n_pairs, int max_N,
+int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
                         float irls_eps, float* partials, int32_t* arrivals, float lm_up, float lm_down, float lm_min,
                         float* lm_state, float* backup, float* costs, void* stream);
 

@@ -69,10 +69,10 @@ __device__ __forceinline__ f32x3 buf_load3(rsrc_t r, uint32_t off) {
     return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, 0, 0));
 }
 
-__device__ __forceinline__ void prepare(const TileCtx& c, float ifx, float ify, uint32_t pw, const f32x4 s, Pending& p) {
+__device__ __forceinline__ void prepare(const TileCtx& c, float shift, float ifx, float ify, uint32_t pw, const f32x4 s, Pending& p) {
     float col, row; bool src_ok;
     decode_pix(pw, col, row, src_ok);
-    const float d = fast_exp(s.w + c.shift);
+    const float d = fast_exp(s.w + shift);
     float x, y;
     backproject(col, row, d, c.Ks, ifx, ify, x, y);
     PointGeom g;
@@ -152,88 +152,10 @@ __device__ __forceinline__ void fold_grad(const TileCtx& c, const Geo& g, const 
     acc[15] -= w.s0;
 }
 
-// -----------------------------------------------------------------------------------------------------
-// mode 1: Gauss-Newton accumulators over x = [tau(3), phi(3), kld_n] (left perturbation Exp(xi)*T)
-//   [0] sum |r|   [1..21] H_pp upper triangle (row-major)   [22..27] b_p   [28..33] h_pd   [34] D   [35] b_d
-//   [36] number of valid points   [37..39] unused
-// r_ch = I_src - I_trg';  J_ch = c_ch * A,  A (2x7) shared by the channels,  c_ch = -gain*[dI/dix, dI/diy];
-// IRLS weight of the L1 cost w_ch = 1/max(|r_ch|, eps)  =>  b = J^T sign(r) for |r| > eps.
-// carried per point: Mix1 = {sum w Ix Ix, sum w Ix Iy, sum w Iy Iy, sum w r Ix, sum w r Iy}
-// A = diag(ga, gb) * Ahat with Ahat0 = [1, 0, -ux, -ux qy, qz + ux qx, -qy, ex - ux ez],
-//                              Ahat1 = [0, 1, -vy, -(qz + vy qy), vy qx, qx, ey - vy ez]   (ux = qx/qz, vy = qy/qz):
-// the two unit columns make rows 0 and 1 of H plain sums of B = W' Ahat.
-// -----------------------------------------------------------------------------------------------------
-struct Mix1 { float w00, w01, w11, v0, v1; };
-
-__device__ __forceinline__ void finish_gn(const TileCtx& c, const Pending& p, const f32x3 a, const f32x3 b,
-                                          const f32x3 cc, const f32x3 d, float eps, Mix1& o, float& cost_acc, float& n_acc) {
-    const float ta[3] = {a.x, a.y, a.z}, tb[3] = {b.x, b.y, b.z}, tc[3] = {cc.x, cc.y, cc.z}, td[3] = {d.x, d.y, d.z};
-    const float sv[3] = {p.sr, p.sg, p.sb};
-    float w00 = 0.f, w01 = 0.f, w11 = 0.f, v0 = 0.f, v1 = 0.f, cost = 0.f;
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        float it, Ix, Iy;
-        tap_mix(ta[ch], tb[ch], tc[ch], td[ch], p.wx, p.wy, it, Ix, Iy);
-        const float r = sv[ch] - fmaf(c.gain, it, c.bias);
-        const float ar = fabsf(r);
-        cost += ar;
-        const float wgt = __builtin_amdgcn_rcpf(fmaxf(ar, eps));
-        const float wx_ = wgt * Ix, wy_ = wgt * Iy;
-        w00 = fmaf(wx_, Ix, w00);
-        w01 = fmaf(wx_, Iy, w01);
-        w11 = fmaf(wy_, Iy, w11);
-        v0 = fmaf(wx_, r, v0);
-        v1 = fmaf(wy_, r, v1);
-    }
-    cost_acc = fmaf(p.m, cost, cost_acc);
-    n_acc += p.m;
-    o.w00 = w00; o.w01 = w01; o.w11 = w11; o.v0 = v0; o.v1 = v1;
-}
-
-__device__ __forceinline__ void fold_gn(const TileCtx& c, const Geo& g, const Mix1& w, float (&acc)[SP_GN_PARTIAL_FLOATS]) {
-    const float ga = (c.gain * c.ax * c.w.Kt.fx) * g.zinv;     // zinv carries the validity mask
-    const float gb = (c.gain * c.ay * c.w.Kt.fy) * g.zinv;
-    const float W00 = w.w00 * (ga * ga), W01 = w.w01 * (ga * gb), W11 = w.w11 * (gb * gb);
-    const float V0 = -w.v0 * ga, V1 = -w.v1 * gb;
-    const float ux = g.qx * g.zi, vy = g.qy * g.zi;
-    const float ex = g.qx - c.w.t[0], ey = g.qy - c.w.t[1], ez = g.qz - c.w.t[2];
-    // columns 2..6 of Ahat
-    const float A0[5] = {-ux, -ux * g.qy, fmaf(ux, g.qx, g.qz), -g.qy, fmaf(-ux, ez, ex)};
-    const float A1[5] = {-vy, -fmaf(vy, g.qy, g.qz), vy * g.qx, g.qx, fmaf(-vy, ez, ey)};
-    float B0[5], B1[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        B0[j] = fmaf(W00, A0[j], W01 * A1[j]);
-        B1[j] = fmaf(W01, A0[j], W11 * A1[j]);
-    }
-    // H_pp upper triangle, row-major: (0,0..5) = acc[1..6], (1,1..5) = acc[7..11], (2,2..5) = acc[12..15],
-    // (3,3..5) = acc[16..18], (4,4..5) = acc[19..20], (5,5) = acc[21]
-    acc[1] += W00; acc[2] += W01;
-    acc[3] += B0[0]; acc[4] += B0[1]; acc[5] += B0[2]; acc[6] += B0[3];
-    acc[7] += W11;
-    acc[8] += B1[0]; acc[9] += B1[1]; acc[10] += B1[2]; acc[11] += B1[3];
-    int k = 12;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = i; j < 4; ++j) { acc[k] = fmaf(A0[i], B0[j], fmaf(A1[i], B1[j], acc[k])); ++k; }
-    // b_p
-    acc[22] += V0; acc[23] += V1;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[24 + i] = fmaf(A0[i], V0, fmaf(A1[i], V1, acc[24 + i]));
-    // coupling with the segment's log-depth (column 6), its diagonal and right-hand side
-    acc[28] += B0[4]; acc[29] += B1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[30 + i] = fmaf(A0[i], B0[4], fmaf(A1[i], B1[4], acc[30 + i]));
-    acc[34] = fmaf(A0[4], B0[4], fmaf(A1[4], B1[4], acc[34]));
-    acc[35] = fmaf(A0[4], V0, fmaf(A1[4], V1, acc[35]));
-}
-
-// ABL (developer ablation, only reachable through mode >= 10 of sp_pairs_cost): 0 = product kernel,
-// 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation)
-template <int MODE, int ABL = 0, bool WRITE_THROUGH = false>
-__device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float* __restrict__ out, float* lds) {
-    constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
+// One tile = one run of points of ONE segment (the single-pair path: sp_photo_cost_grad over the keyframe's own,
+// unpadded segment table).  Gradient mode only; the many-pairs path uses the span loops further down.
+__device__ __forceinline__ void run_tile(const TileCtx& c, float* __restrict__ out, float* lds) {
+    constexpr int NV = SP_GRAD_PARTIAL_FLOATS;
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
@@ -249,69 +171,55 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float irls_eps, float
     {
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)(i * 4u), 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, i * 16u);
-        prepare(c, ifx, ify, pw, s, nx);
+        prepare(c, c.shift, ifx, ify, pw, s, nx);
     }
     Geo cur = nx.g;
     cur.zinv = 0.f; cur.zi = 0.f;      // "point -1": contributes exact zeros
     Mix0 m0{0.f, 0.f, 0.f, 0.f};
-    Mix1 m1{0.f, 0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < n_iter; ++j) {
         // ---- top: issue everything this trip will need -------------------------------------------
         i += SP_BLOCK;
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)(i * 4u), 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, i * 16u);
-        f32x3 ta, tb, tc, td;
-        if (ABL == 1) { ta = tb = tc = td = f32x3{nx.sr, nx.sg, nx.sb}; }
-        else {
-            ta = buf_load3(r_trg, nx.off0);
-            tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
-            tc = buf_load3(r_trg, nx.off1);
-            td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
-        }
+        f32x3 ta = buf_load3(r_trg, nx.off0);
+        f32x3 tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
+        f32x3 tc = buf_load3(r_trg, nx.off1);
+        f32x3 td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
         // The machine scheduler otherwise sinks the gathers below the arithmetic to shorten their live range
         // (register pressure heuristics): pin the three sections in source order.
         __builtin_amdgcn_sched_barrier(0);
         // ---- middle: fold the previous point (arithmetic only) ----------------------------------
-        if (ABL != 2) {
-            if (MODE == 0) fold_grad(c, cur, m0, reinterpret_cast<float(&)[SP_GRAD_PARTIAL_FLOATS]>(acc));
-            else fold_gn(c, cur, m1, reinterpret_cast<float(&)[SP_GN_PARTIAL_FLOATS]>(acc));
-        }
+        fold_grad(c, cur, m0, acc);
         __builtin_amdgcn_sched_barrier(0);
         // ---- bottom: finish this point's channel mixing, geometry of the next -------------------
         // An empty asm that "rewrites" the tap registers: the only place their wait (s_waitcnt) may land, and
         // a data dependency that keeps instruction selection from starting the channel mixing before the fold.
         // The accumulators the fold just updated are operands too, so the fold cannot drift below this point.
-        if (ABL != 1) {
-            if (MODE == 0)
-                asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-                             "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]));
-            else
-                asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(acc[12]), "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]),
-                             "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]), "+v"(acc[21]), "+v"(acc[24]),
-                             "+v"(acc[25]), "+v"(acc[26]), "+v"(acc[27]), "+v"(acc[30 % NV]), "+v"(acc[31 % NV]), "+v"(acc[32 % NV]),
-                             "+v"(acc[33 % NV]), "+v"(acc[34 % NV]), "+v"(acc[35 % NV]));
-        }
-        if (ABL == 2) acc[0] += ta.x + tb.y + tc.z + td.x + nx.wx + nx.wy + nx.m;
-        else if (MODE == 0) finish_grad(c, nx, ta, tb, tc, td, m0, acc[0]);
-        else finish_gn(c, nx, ta, tb, tc, td, irls_eps, m1, acc[0], acc[NV - 4]);
+        asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                     "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]));
+        finish_grad(c, nx, ta, tb, tc, td, m0, acc[0]);
         cur = nx.g;
         uint32_t pw_ = pw;
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
-        prepare(c, ifx, ify, pw_, s_, nx);
+        prepare(c, c.shift, ifx, ify, pw_, s_, nx);
     }
-    if (ABL != 2) {
-        if (MODE == 0) fold_grad(c, cur, m0, reinterpret_cast<float(&)[SP_GRAD_PARTIAL_FLOATS]>(acc));
-        else fold_gn(c, cur, m1, reinterpret_cast<float(&)[SP_GN_PARTIAL_FLOATS]>(acc));
-    }
+    fold_grad(c, cur, m0, acc);
     const float total = block_sum_to_thread<NV>(acc, lds);
-    if (threadIdx.x < NV) {
-        // fused cost+solve: the partial is read by ANOTHER workgroup of this launch -> write-through (sc1) store
-        if (WRITE_THROUGH) __hip_atomic_store(out + threadIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else out[threadIdx.x] = total;
-    }
+    if (threadIdx.x < NV) out[threadIdx.x] = total;
 }
 
+// -----------------------------------------------------------------------------------------------------
+// mode 1: Gauss-Newton accumulators over x = [tau(3), phi(3), kld_n] (left perturbation Exp(xi)*T)
+//   [0] sum |r|   [1..21] H_pp upper triangle (row-major)   [22..27] b_p   [28..33] h_pd   [34] D   [35] b_d
+//   [36] number of valid points   [37..39] unused
+// r_ch = I_src - I_trg';  J_ch = c_ch * A,  A (2x7) shared by the channels,  c_ch = -gain*[dI/dix, dI/diy];
+// IRLS weight of the L1 cost w_ch = 1/max(|r_ch|, eps)  =>  b = J^T sign(r) for |r| > eps.
+// carried per point: {sum w Ix Ix, sum w Ix Iy, sum w Iy Iy, sum w r Ix, sum w r Iy} (Mix2 below)
+// A = diag(ga, gb) * Ahat with Ahat0 = [1, 0, -ux, -ux qy, qz + ux qx, -qy, ex - ux ez],
+//                              Ahat1 = [0, 1, -vy, -(qz + vy qy), vy qx, qx, ey - vy ez]   (ux = qx/qz, vy = qy/qz):
+// the two unit columns make rows 0 and 1 of H plain sums of B = W' Ahat.
+// -----------------------------------------------------------------------------------------------------
 // -----------------------------------------------------------------------------------------------------
 // mode 1, register-pair formulation.  The same sums as fold_gn / finish_gn, arranged so that almost every
 // multiply-add is a v_pk_fma_f32 on an aligned register pair (wave64 issues a packed fp32 op in the same four
@@ -348,10 +256,10 @@ struct Pending2 {          // Pending, with the x/y quantities as register pairs
 };
 
 // prepare() on pairs: same operations in the same order per component (sp_device.h backproject / warp_point)
-__device__ __forceinline__ void prepare2(const TileCtx& c, f32x2 ifxy, uint32_t pw, const f32x4 s, Pending2& p) {
+__device__ __forceinline__ void prepare2(const TileCtx& c, float shift, f32x2 ifxy, uint32_t pw, const f32x4 s, Pending2& p) {
     const f32x2 colrow{(float)(pw & 0xffffu), (float)((pw >> 16) & 0x7fffu)};
     const bool src_ok = (int32_t)pw < 0;
-    const float d = fast_exp(s.w + c.shift);
+    const float d = fast_exp(s.w + shift);
     const Warp& w = c.w;
     const f32x2 xy = ((colrow - f32x2{c.Ks.cx, c.Ks.cy}) * d) * ifxy;
     const f32x2 qxy = pfma(f32x2{w.R[0], w.R[3]}, f32x2{xy.x, xy.x},
@@ -441,8 +349,97 @@ __device__ __forceinline__ void fold_gn2(const TileCtx& c, const GeoGn g, const 
     A.bd = fmaf(Q.x, V.x, fmaf(Q.y, V.y, A.bd));
 }
 
-template <bool WRITE_THROUGH = false>
-__device__ __forceinline__ void run_tile_gn2(const TileCtx& c, float irls_eps, float* __restrict__ out, float* lds) {
+// =====================================================================================================
+// The many-pairs path: span loops.
+//
+// A workgroup processes a SPAN: a run of consecutive chunks of one frame pair; a chunk is a run of points of one
+// segment whose length is a multiple of SP_BLOCK (PairBatch pads every segment of its tables with invalid points, which
+// contribute exact zeros).  Chunks are contiguous in memory, so the three-stage pipeline of run_tile() simply keeps
+// streaming across chunk boundaries: only the segment's depth shift changes (a scalar, fetched one chunk ahead), and
+// the few accumulators that belong to the SEGMENT (mode 1: h_pd, D, b_d; mode 0: d/dkld) are flushed -- per wave, no
+// barrier -- right after the fold of the chunk's last point.  The accumulators that belong to the PAIR run through
+// the whole span and go through the block reduction once.  The pipeline fill/drain, the tile set-up and the 40-value
+// block reduction (about 530 instructions per wave, 12 % of a 23-trip tile) are thus paid once per span, not once
+// per segment.
+//
+// Partials: one record of NV floats per (chunk, wave) -- record 4*chunk + wave, same column layout as before.  A
+// wave writes the segment columns of its record at every flush and zeros elsewhere; the pair columns of the span
+// land in the record (last chunk of the span, wave 0).  The solvers sum records, so they need not know about spans.
+// =====================================================================================================
+typedef const float __attribute__((address_space(4)))* cptr_f32;       // constant address space: scalar (s_load) reads
+struct ChunkRec { int pair, seg, start, count; };                       // one int32x4 entry of the chunk list
+typedef const ChunkRec __attribute__((address_space(4)))* cptr_i4;
+
+struct SpanCursor {            // all wave-uniform
+    cptr_i4 chunks;            // {pair, seg, start, count}
+    cptr_f32 kld, kp_L;
+    int q, q_end;              // chunk being PREPARED, end of the span
+    int left;                  // trips of chunk q not yet prepared
+    float shift;               // kld[seg] - kp_L[seg] of chunk q
+    int nq_left;               // chunk q + 1, fetched one chunk ahead so that no wait lands in the trip loop
+    float nq_kld, nq_kpl;
+};
+
+__device__ __forceinline__ void cursor_fetch_next(SpanCursor& k) {
+    if (k.q + 1 < k.q_end) {
+        const int seg = k.chunks[k.q + 1].seg;
+        k.nq_left = k.chunks[k.q + 1].count / SP_BLOCK;
+        k.nq_kld = k.kld[seg];
+        k.nq_kpl = k.kp_L[seg];
+    }
+}
+
+__device__ __forceinline__ void cursor_init(SpanCursor& k, const SpPair& pr, const int4* chunks, int q0, int n) {
+    k.chunks = (cptr_i4)chunks;
+    k.kld = (cptr_f32)pr.kld;
+    k.kp_L = (cptr_f32)pr.kp_L;
+    k.q = q0; k.q_end = q0 + n;
+    const int seg0 = k.chunks[q0].seg;
+    k.left = k.chunks[q0].count / SP_BLOCK;
+    k.shift = k.kld[seg0] - k.kp_L[seg0];
+    k.nq_left = 0; k.nq_kld = 0.f; k.nq_kpl = 0.f;
+    cursor_fetch_next(k);
+}
+
+// Account one prepared trip.  Returns true if that trip was the last of its chunk (whose index is written to `done_q`).
+__device__ __forceinline__ bool cursor_advance(SpanCursor& k, int& done_q) {
+    done_q = k.q;
+    if (--k.left > 0) return false;
+    ++k.q;
+    k.left = k.nq_left;
+    k.shift = k.nq_kld - k.nq_kpl;
+    cursor_fetch_next(k);
+    return true;
+}
+
+template <bool WT>
+__device__ __forceinline__ void store_partial(float* p, float v) {
+    // fused cost+solve: the record is read by ANOTHER workgroup of this launch -> write-through (sc1) store
+    if (WT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// mode 1: flush {h_pd(6), D, b_d} of the chunk this wave just finished into its record (columns 28..35; zeros elsewhere)
+template <bool WT>
+__device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ rec) {
+    constexpr int NV = SP_GN_PARTIAL_FLOATS;
+    float v[8] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D, A.bd};
+    const int lane = lane_id();
+    int pos; bool ok;
+    wave_sum_to_lanes<8>(v, lane, pos, ok);
+    if (lane < NV && (lane < 28 || lane >= 36)) store_partial<WT>(rec + lane, 0.f);
+    if (ok) store_partial<WT>(rec + 28 + pos, v[0]);
+    const f32x2 z{0.f, 0.f};
+    A.hd01 = z; A.hd[0] = z; A.hd[1] = z; A.D = 0.f; A.bd = 0.f;
+}
+
+// ABL (developer ablation, only reachable through mode >= 10 of sp_pairs_cost): 0 = product kernel,
+// 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation)
+template <int ABL, bool WT>
+__device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
+                                            int n_chunks, int total, float irls_eps, float* __restrict__ partials, float* lds) {
     constexpr int NV = SP_GN_PARTIAL_FLOATS;
     GnAcc A;
     {
@@ -454,18 +451,25 @@ __device__ __forceinline__ void run_tile_gn2(const TileCtx& c, float irls_eps, f
         for (int k = 0; k < 6; ++k) A.blk[k] = z;
         A.h11 = A.D = A.bd = A.cost = A.n = 0.f;
     }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SpanCursor k;
+    cursor_init(k, pr, chunks, q0, n_chunks);
+    const int start = k.chunks[q0].start;
     const f32x2 ifxy{1.f / c.Ks.fx, 1.f / c.Ks.fy};
-    const rsrc_t r_pix = make_rsrc(c.pix + c.start, (uint32_t)c.count * 4u);
-    const rsrc_t r_src = make_rsrc(c.src4 + c.start, (uint32_t)c.count * 16u);
+    const rsrc_t r_pix = make_rsrc(c.pix + start, (uint32_t)total * 4u);
+    const rsrc_t r_src = make_rsrc(c.src4 + start, (uint32_t)total * 16u);
     const rsrc_t r_trg = make_rsrc(c.trg, (uint32_t)c.Wl * (uint32_t)c.Hl * (4u * SP_TEXEL_FLOATS));
-    const int n_iter = (c.count + SP_BLOCK - 1) / SP_BLOCK;
-    uint32_t op = threadIdx.x * 4u;     // byte offset of this lane's word in the tile's pix run (x4: its src4 record)
+    const int n_iter = total / SP_BLOCK;
+    uint32_t op = threadIdx.x * 4u;     // byte offset of this lane's word in the span's pix run (x4: its src4 record)
     constexpr int NT = 2;
     Pending2 nx;
+    int nx_q, cur_q = q0;                // chunk of the trip in flight / of the trip waiting for its fold
+    bool nx_last, cur_last = false;      // ... and whether that trip is the last of its chunk
     {
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
-        prepare2(c, ifxy, pw, s, nx);
+        prepare2(c, k.shift, ifxy, pw, s, nx);
+        nx_last = cursor_advance(k, nx_q);
     }
     GeoGn cur{nx.qxy, nx.qz, 0.f, 0.f};
     Mix2 m{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, 0.f};
@@ -474,24 +478,34 @@ __device__ __forceinline__ void run_tile_gn2(const TileCtx& c, float irls_eps, f
         asm volatile("" : "+v"(op));        // one induction register; the src4 offset is a shift of it
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
-        f32x3 ta = buf_load3(r_trg, nx.off0);
-        f32x3 tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
-        f32x3 tc = buf_load3(r_trg, nx.off1);
-        f32x3 td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
+        f32x3 ta, tb, tc, td;
+        if (ABL == 1) { ta = tb = tc = td = f32x3{nx.srg.x, nx.srg.y, nx.sb}; }
+        else {
+            ta = buf_load3(r_trg, nx.off0);
+            tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
+            tc = buf_load3(r_trg, nx.off1);
+            td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        fold_gn2(c, cur, m, A);
+        if (ABL != 2) fold_gn2(c, cur, m, A);
+        if (cur_last) flush_segment_gn<WT>(A, partials + (size_t)(4 * cur_q + wave) * NV);
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(A.blk[0]), "+v"(A.blk[1]), "+v"(A.blk[2]),
-                     "+v"(A.blk[3]), "+v"(A.blk[4]), "+v"(A.blk[5]), "+v"(A.bp[0]), "+v"(A.bp[1]), "+v"(A.hd[0]),
-                     "+v"(A.hd[1]), "+v"(A.D), "+v"(A.bd));
-        finish_gn2(c, nx, ta, tb, tc, td, irls_eps, m, A.cost, A.n);
+        if (ABL != 1)
+            asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(A.blk[0]), "+v"(A.blk[1]), "+v"(A.blk[2]),
+                         "+v"(A.blk[3]), "+v"(A.blk[4]), "+v"(A.blk[5]), "+v"(A.bp[0]), "+v"(A.bp[1]), "+v"(A.hd[0]),
+                         "+v"(A.hd[1]), "+v"(A.D), "+v"(A.bd));
+        if (ABL == 2) A.cost += ta.x + tb.y + tc.z + td.x + nx.wxy.x + nx.wxy.y + nx.m;
+        else finish_gn2(c, nx, ta, tb, tc, td, irls_eps, m, A.cost, A.n);
         cur = GeoGn{nx.qxy, nx.qz, nx.zinv, nx.zi};
+        cur_q = nx_q; cur_last = nx_last;
         uint32_t pw_ = pw;
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
-        prepare2(c, ifxy, pw_, s_, nx);
+        prepare2(c, k.shift, ifxy, pw_, s_, nx);      // (the trip past the end reads zeros and is never used)
+        nx_last = cursor_advance(k, nx_q);
     }
-    fold_gn2(c, cur, m, A);
+    if (ABL != 2) fold_gn2(c, cur, m, A);
+    flush_segment_gn<WT>(A, partials + (size_t)(4 * cur_q + wave) * NV);      // the span ends with its last chunk
     float acc[NV];
     acc[0] = A.cost;
     acc[1] = A.h00.x; acc[2] = A.h00.y;
@@ -503,17 +517,90 @@ __device__ __forceinline__ void run_tile_gn2(const TileCtx& c, float irls_eps, f
     acc[19] = A.blk[4].x; acc[20] = A.blk[4].y; acc[21] = A.blk[5].y;
     acc[22] = A.bp01.x; acc[23] = A.bp01.y;
     acc[24] = A.bp[0].x; acc[25] = A.bp[0].y; acc[26] = A.bp[1].x; acc[27] = A.bp[1].y;
-    acc[28] = A.hd01.x; acc[29] = A.hd01.y;
-    acc[30] = A.hd[0].x; acc[31] = A.hd[0].y; acc[32] = A.hd[1].x; acc[33] = A.hd[1].y;
-    acc[34] = A.D; acc[35] = A.bd; acc[36] = A.n; acc[37] = acc[38] = acc[39] = 0.f;
+#pragma unroll
+    for (int i = 28; i < 36; ++i) acc[i] = 0.f;         // segment columns: flushed per chunk above
+    acc[36] = A.n; acc[37] = acc[38] = acc[39] = 0.f;
     // op still knows the thread index (op = 4 * (threadIdx.x + trips * SP_BLOCK)): nothing derived from threadIdx.x
     // has to stay live, or be spilled, across the loop for the sake of this epilogue
     const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
-    const float total = block_sum_to_thread<NV>(acc, lds, tid);
-    if (tid < NV) {
-        if (WRITE_THROUGH) __hip_atomic_store(out + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else out[tid] = total;
+    const float tot = block_sum_to_thread<NV>(acc, lds, tid);
+    // pair columns of the span: into the record (last chunk, wave 0), after wave 0's own flush of that record
+    if (tid < NV && (tid < 28 || tid >= 36)) store_partial<WT>(partials + (size_t)(4 * cur_q) * NV + tid, tot);
+}
+
+// mode 0: the segment column is 13 (d/dkld)
+template <int ABL, bool WT>
+__device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
+                                              int n_chunks, int total, float* __restrict__ partials, float* lds) {
+    constexpr int NV = SP_GRAD_PARTIAL_FLOATS;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    SpanCursor k;
+    cursor_init(k, pr, chunks, q0, n_chunks);
+    const int start = k.chunks[q0].start;
+    const float ifx = 1.f / c.Ks.fx, ify = 1.f / c.Ks.fy;
+    const rsrc_t r_pix = make_rsrc(c.pix + start, (uint32_t)total * 4u);
+    const rsrc_t r_src = make_rsrc(c.src4 + start, (uint32_t)total * 16u);
+    const rsrc_t r_trg = make_rsrc(c.trg, (uint32_t)c.Wl * (uint32_t)c.Hl * (4u * SP_TEXEL_FLOATS));
+    const int n_iter = total / SP_BLOCK;
+    uint32_t op = threadIdx.x * 4u;
+    constexpr int NT = 2;
+    Pending nx;
+    int nx_q, cur_q = q0;
+    bool nx_last, cur_last = false;
+    {
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
+        const f32x4 s = buf_load4<NT>(r_src, op * 4u);
+        prepare(c, k.shift, ifx, ify, pw, s, nx);
+        nx_last = cursor_advance(k, nx_q);
     }
+    Geo cur = nx.g;
+    cur.zinv = 0.f; cur.zi = 0.f;
+    Mix0 m0{0.f, 0.f, 0.f, 0.f};
+    auto flush = [&](int q) {
+        float* rec = partials + (size_t)(4 * q + wave) * NV;
+        const float tot = wave_sum(acc[13]);
+        const int lane = lane_id();
+        if (lane < NV) store_partial<WT>(rec + lane, lane == 13 ? tot : 0.f);
+        acc[13] = 0.f;
+    };
+    for (int j = 0; j < n_iter; ++j) {
+        op += 4u * SP_BLOCK;
+        asm volatile("" : "+v"(op));
+        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
+        const f32x4 s = buf_load4<NT>(r_src, op * 4u);
+        f32x3 ta, tb, tc, td;
+        if (ABL == 1) { ta = tb = tc = td = f32x3{nx.sr, nx.sg, nx.sb}; }
+        else {
+            ta = buf_load3(r_trg, nx.off0);
+            tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
+            tc = buf_load3(r_trg, nx.off1);
+            td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 2) fold_grad(c, cur, m0, acc);
+        if (cur_last) flush(cur_q);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 1)
+            asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                         "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]));
+        if (ABL == 2) acc[0] += ta.x + tb.y + tc.z + td.x + nx.wx + nx.wy + nx.m;
+        else finish_grad(c, nx, ta, tb, tc, td, m0, acc[0]);
+        cur = nx.g;
+        cur_q = nx_q; cur_last = nx_last;
+        uint32_t pw_ = pw;
+        f32x4 s_ = s;
+        asm volatile("" : "+v"(pw_), "+v"(s_));
+        prepare(c, k.shift, ifx, ify, pw_, s_, nx);
+        nx_last = cursor_advance(k, nx_q);
+    }
+    if (ABL != 2) fold_grad(c, cur, m0, acc);
+    flush(cur_q);
+    const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
+    const float tot = block_sum_to_thread<NV>(acc, lds, tid);
+    if (tid < NV && tid != 13) store_partial<WT>(partials + (size_t)(4 * cur_q) * NV + tid, tot);
 }
 
 __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const Cam& Kt, int H, int W, int Hl, int Wl,
@@ -531,7 +618,6 @@ __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const C
     c.ay = 2.f * c.w.sy * c.w.invHm1;
 }
 
-#include "sp_cost_packed.h"
 
 // ------------------------------------------------------------------------------------------------
 // single source keyframe, B targets: grid = (n_tiles, B)
@@ -563,7 +649,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_single_grad(SingleArgs a, flo
         c.bias = a.aff_trg[2 * b + 1] - a.aff_src[1];
     }
     c.start = tile.z; c.count = tile.w;
-    run_tile<0>(c, 0.f, partials + ((size_t)b * a.n_tiles + t) * SP_GRAD_PARTIAL_FLOATS, lds);
+    run_tile(c, partials + ((size_t)b * a.n_tiles + t) * SP_GRAD_PARTIAL_FLOATS, lds);
 }
 
 // Fixed-order fp64 combination of the tile partials of one target b.
@@ -616,14 +702,15 @@ struct FuseArgs {
 };
 
 template <int MODE, int ABL = 0, int FUSED = 0>
-__global__ __launch_bounds__(SP_BLOCK, (MODE == 0 && FUSED == 0) ? 5 : (MODE == 1 && ABL == 0 && FUSED == 0) ? 4 : 1) void k_cost_pairs(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
-                                                         int n_tiles, float irls_eps, float* __restrict__ partials, FuseArgs f) {
+__global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
+        const SpPair* __restrict__ pairs, const int4* __restrict__ chunks, const int4* __restrict__ spans, int n_spans,
+        float irls_eps, float* __restrict__ partials, FuseArgs f) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
     __shared__ float lds[SP_WAVES * NV];
-    const int t = xcd_chunked_tile(blockIdx.x, n_tiles);
-    if (t >= n_tiles) return;
-    const int4 tile = tiles[t];
-    const SpPair& pr = pairs[tile.x];
+    const int w = xcd_chunked_tile(blockIdx.x, n_spans);
+    if (w >= n_spans) return;
+    const int4 span = spans[w];             // {first chunk, number of chunks, points, pair}
+    const SpPair& pr = pairs[span.w];
     TileCtx c;
     c.pix = (gptr_u32)pr.pix;
     c.src4 = (gptr_f4)pr.src4;
@@ -631,61 +718,34 @@ __global__ __launch_bounds__(SP_BLOCK, (MODE == 0 && FUSED == 0) ? 5 : (MODE == 
     c.Ks = Cam{pr.K_src[0], pr.K_src[1], pr.K_src[2], pr.K_src[3]};
     const Cam Kt{pr.K_trg[0], pr.K_trg[1], pr.K_trg[2], pr.K_trg[3]};
     fill_warp(c, pr.pose, Kt, pr.H, pr.W, pr.Hl, pr.Wl, pr.zmin);
-    c.shift = pr.kld[tile.y] - pr.kp_L[tile.y];
+    c.shift = 0.f;
     c.gain = 1.f; c.bias = 0.f;
     if (pr.aff) {
         c.gain = expf(-(pr.aff[2] - pr.aff[0]));
         c.bias = pr.aff[3] - pr.aff[1];
     }
-    c.start = tile.z; c.count = tile.w;
-    if (MODE == 1 && ABL == 0) run_tile_gn2<FUSED != 0>(c, irls_eps, partials + (size_t)t * NV, lds);
-    else run_tile<MODE, ABL == 3 ? 0 : ABL, FUSED != 0>(c, irls_eps, partials + (size_t)t * NV, lds);
+    c.start = 0; c.count = 0;
+    if (MODE == 1) run_span_gn<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials, lds);
+    else run_span_grad<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, partials, lds);
     if (FUSED != 0) {
         __shared__ int is_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int old = __hip_atomic_fetch_add(f.arrivals + tile.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == pr.n_tiles - 1;
+            const int old = __hip_atomic_fetch_add(f.arrivals + span.w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = old == pr.n_spans - 1;
             if (last) {
-                __hip_atomic_store(f.arrivals + tile.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(f.arrivals + span.w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             is_last = last;
         }
         __syncthreads();
         if (is_last) {
-            if (FUSED == 1) solve_adam(pairs, tile.x, partials, f.adam);
-            else solve_gn(pairs, tile.x, partials, f.gn);
+            if (FUSED == 1) solve_adam(pairs, span.w, partials, f.adam);
+            else solve_gn(pairs, span.w, partials, f.gn);
         }
     }
-}
-
-// developer A/B kernel: two points per lane, packed fp32 (sp_cost_packed.h)
-template <int MODE, int WAVES>
-__global__ __launch_bounds__(SP_BLOCK, WAVES) void k_cost_pairs_pk(const SpPair* __restrict__ pairs, const int4* __restrict__ tiles,
-                                                                   int n_tiles, float irls_eps, float* __restrict__ partials) {
-    constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
-    __shared__ float lds[SP_WAVES * NV];
-    const int t = xcd_chunked_tile(blockIdx.x, n_tiles);
-    if (t >= n_tiles) return;
-    const int4 tile = tiles[t];
-    const SpPair& pr = pairs[tile.x];
-    TileCtx c;
-    c.pix = (gptr_u32)pr.pix;
-    c.src4 = (gptr_f4)pr.src4;
-    c.trg = (gptr_f32)pr.trg3;
-    c.Ks = Cam{pr.K_src[0], pr.K_src[1], pr.K_src[2], pr.K_src[3]};
-    const Cam Kt{pr.K_trg[0], pr.K_trg[1], pr.K_trg[2], pr.K_trg[3]};
-    fill_warp(c, pr.pose, Kt, pr.H, pr.W, pr.Hl, pr.Wl, pr.zmin);
-    c.shift = pr.kld[tile.y] - pr.kp_L[tile.y];
-    c.gain = 1.f; c.bias = 0.f;
-    if (pr.aff) {
-        c.gain = expf(-(pr.aff[2] - pr.aff[0]));
-        c.bias = pr.aff[3] - pr.aff[1];
-    }
-    c.start = tile.z; c.count = tile.w;
-    pk::run_tile_pk<MODE, 0>(c, irls_eps, partials + (size_t)t * NV, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -806,62 +866,58 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
     return 0;
 }
 
-int sp_pairs_cost(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int mode, float irls_eps,
+int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                   float* partials, void* stream) {
-    if (!pairs || !tiles || !partials || n_tiles_total <= 0) return SP_EINVAL;
-    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13) && !(mode >= 20 && mode <= 23)) return SP_EINVAL;
+    if (!pairs || !chunks || !spans || !partials || n_spans <= 0) return SP_EINVAL;
+    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int gx = ((n_tiles_total + 7) / 8) * 8;
-    const int4* t4 = reinterpret_cast<const int4*>(tiles);
+    const int gx = ((n_spans + 7) / 8) * 8;
+    const int4* c4 = reinterpret_cast<const int4*>(chunks);
+    const int4* s4 = reinterpret_cast<const int4*>(spans);
     const FuseArgs nofuse{};
     if (mode == 0)
-        hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
-    else if (mode == 20)   /* developer A/B: packed two-points-per-lane kernels (192 / 232 VGPRs, 2 waves per SIMD) */
-        hipLaunchKernelGGL((k_cost_pairs_pk<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
-    else if (mode == 21)
-        hipLaunchKernelGGL((k_cost_pairs_pk<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials);
-    else if (mode == 23)   /* developer A/B: the one-scalar-per-register Gauss-Newton fold (fold_gn / finish_gn) */
-        hipLaunchKernelGGL((k_cost_pairs<1, 3>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
-    else if (mode == 10)   /* developer ablations, see run_tile */
-        hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
+    else if (mode == 10)   /* developer ablations, see run_span_gn */
+        hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
     else if (mode == 11)
-        hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
     else if (mode == 12)
-        hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
     else
-        hipLaunchKernelGGL((k_cost_pairs<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, t4, n_tiles_total, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL((k_cost_pairs<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
     SP_CHECK_LAUNCH();
     return 0;
 }
 
-int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int n_pairs, int max_N,
+int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
                           float* partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
                           float* losses, void* stream) {
-    if (!pairs || !tiles || !partials || !arrivals || !state || !losses) return SP_EINVAL;
-    if (n_tiles_total <= 0 || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+    if (!pairs || !chunks || !spans || !partials || !arrivals || !state || !losses || n_spans <= 0 || n_pairs <= 0 || max_N <= 0)
+        return SP_EINVAL;
     FuseArgs f{};
     f.arrivals = arrivals;
     f.adam = AdamArgs{max_N, lr_kld, lr_pose, lr_aff, state, losses};
-    const int gx = ((n_tiles_total + 7) / 8) * 8;
+    const int gx = ((n_spans + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cost_pairs<0, 0, 1>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
-                       reinterpret_cast<const int4*>(tiles), n_tiles_total, 0.f, partials, f);
+                       reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, 0.f, partials, f);
     SP_CHECK_LAUNCH();
     return 0;
 }
 
-int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* tiles, int n_tiles_total, int n_pairs, int max_N,
+int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
                         float irls_eps, float* partials, int32_t* arrivals, float lm_up, float lm_down, float lm_min,
                         float* lm_state, float* backup, float* costs, void* stream) {
-    if (!pairs || !tiles || !partials || !arrivals || !lm_state || !backup || !costs) return SP_EINVAL;
-    if (n_tiles_total <= 0 || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+    if (!pairs || !chunks || !spans || !partials || !arrivals || !lm_state || !backup || !costs || n_spans <= 0 || n_pairs <= 0 ||
+        max_N <= 0)
+        return SP_EINVAL;
     FuseArgs f{};
     f.arrivals = arrivals;
     f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs};
-    const int gx = ((n_tiles_total + 7) / 8) * 8;
+    const int gx = ((n_spans + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cost_pairs<1, 0, 2>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
-                       reinterpret_cast<const int4*>(tiles), n_tiles_total, irls_eps, partials, f);
+                       reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, f);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -65,10 +65,11 @@ __device__ __forceinline__ void halve_step(float* v, bool upper) {
     }
 }
 
+// Wave stage: reduce NV per-lane values over the 64 lanes.  Afterwards lane `lane` holds the total of value `pos` in
+// acc[0] if `ok` (each of the NV totals lives in exactly one lane).
 template <int NV>
-__device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* lds /* SP_WAVES*NV floats */, int tid) {
+__device__ __forceinline__ void wave_sum_to_lanes(float (&acc)[NV], int lane, int& pos, bool& ok) {
     static_assert(NV <= 64, "one value per lane at most");
-    const int lane = tid & 63, wave = tid >> 6;
     constexpr int N0 = NV, N1 = (N0 + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
     halve_step<N0, 32>(acc, lane & 32);
     halve_step<N1, 16>(acc, lane & 16);
@@ -77,14 +78,22 @@ __device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* ld
     halve_step<N4, 2>(acc, lane & 2);
     halve_step<N5, 1>(acc, lane & 1);
     // which of the NV values this lane now holds in acc[0] (walk the levels backwards), if any
-    int pos = 0;
-    bool ok = true;
+    pos = 0;
+    ok = true;
     if (lane & 1)  { pos += (N5 + 1) / 2; ok = ok && pos < N5; }
     if (lane & 2)  { pos += (N4 + 1) / 2; ok = ok && pos < N4; }
     if (lane & 4)  { pos += (N3 + 1) / 2; ok = ok && pos < N3; }
     if (lane & 8)  { pos += (N2 + 1) / 2; ok = ok && pos < N2; }
     if (lane & 16) { pos += (N1 + 1) / 2; ok = ok && pos < N1; }
     if (lane & 32) { pos += (N0 + 1) / 2; ok = ok && pos < N0; }
+}
+
+template <int NV>
+__device__ __forceinline__ float block_sum_to_thread(float (&acc)[NV], float* lds /* SP_WAVES*NV floats */, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    int pos;
+    bool ok;
+    wave_sum_to_lanes<NV>(acc, lane, pos, ok);
     if (ok) lds[wave * NV + pos] = acc[0];
     __syncthreads();
     float total = 0.f;

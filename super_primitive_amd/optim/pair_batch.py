@@ -20,9 +20,11 @@ import torch
 
 from .. import _lib
 from ..image import gaussian_pyramid
-from ..segment_table import SegmentTable, make_tiles
+from ..segment_table import SegmentTable
 
-DEFAULT_BATCH_TILE_POINTS = 8192   # one workgroup per segment up to 8192 px: amortises the tile prologue/epilogue
+DEFAULT_BATCH_TILE_POINTS = 8192   # longest chunk (run of one segment's points between two segment-level flushes)
+DEFAULT_SPAN_POINTS = 16384        # points per workgroup: consecutive chunks of a pair are grouped up to this many
+GRANULE = 256                      # SP_BLOCK: every segment is padded to a multiple of it in the batch's tables
 
 
 def _level_images(img, max_level):
@@ -36,13 +38,18 @@ def _level_images(img, max_level):
 
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
-                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1):
+                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=DEFAULT_SPAN_POINTS):
         """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
         device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
         ``config['aligment']`` (max exclusive).  ``replicate`` = R > 1 lays the M0 given pairs out R times in
         device memory (distinct copies of every array, poses/klds = ``poses[r*M0+m]`` when (R*M0,4,4) poses are
-        given): bench.py uses it to build a large streaming batch without uploading R*M0 dense keyframes."""
+        given): bench.py uses it to build a large streaming batch without uploading R*M0 dense keyframes.
+
+        Layout (include/sp_hip.h, "Work list"): the batch keeps its own PADDED copy of every table -- each segment's
+        run of points extended to a multiple of 256 with invalid points -- so that a workgroup can stream through a SPAN
+        of several consecutive chunks (segments, or pieces of at most ``tile_points`` points of a long segment) of up
+        to ``span_points`` points without any trip mixing two segments."""
         lib = _lib.load()
         self.lib = lib
         M0 = len(src_frames)
@@ -58,6 +65,7 @@ class PairBatch:
         self.level_ids = list(range(levels[0], levels[1]))
         max_level = levels[1] - 1
         self.tile_points = tile_points
+        self.span_points = max(int(span_points), GRANULE)
 
         tables0 = [SegmentTable(f.keypoint_regions, f.logdepth_perseg, f.keypoints, tile_points) for f in src_frames]
         tables = [tables0[b] for b in base]
@@ -65,10 +73,27 @@ class PairBatch:
         self.Ns = [t.N for t in tables]
         self.Ps = [t.P for t in tables]
         self.max_N = max(self.Ns)
+        # padded layout of every base table: segment n occupies [pseg_off[n], pseg_off[n] + counts[n]) + padding
+        pads0 = []
+        for tab in tables0:
+            counts = np.asarray(tab.counts, dtype=np.int64)
+            pc = (counts + GRANULE - 1) // GRANULE * GRANULE
+            pseg_off = np.concatenate(([0], np.cumsum(pc)))
+            seg_off = np.concatenate(([0], np.cumsum(counts)))
+            dst = torch.from_numpy(np.repeat(pseg_off[:-1] - seg_off[:-1], counts) + np.arange(int(counts.sum()))).to(dev)
+            pads0.append(dict(pc=pc, pseg_off=pseg_off, Ppad=int(pseg_off[-1]), dst=dst))
+        pads = [pads0[b] for b in base]
+        self.Ppads = [pd['Ppad'] for pd in pads]
         n_off = np.concatenate(([0], np.cumsum(self.Ns)))
-        p_off = np.concatenate(([0], np.cumsum(self.Ps)))
+        p_off = np.concatenate(([0], np.cumsum(self.Ppads)))
         self.n_off, self.p_off = n_off, p_off
         cat = torch.cat
+
+        def padded(x, pd):
+            out = torch.zeros((pd['Ppad'],) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
+            out[pd['dst']] = x
+            return out
+
         # flat, pair-major device arrays
         self.kp_L = cat([t.kp_L for t in tables])
         self.kld = cat([klds[b].detach().float().to(dev) for b in base]).contiguous()
@@ -81,30 +106,59 @@ class PairBatch:
             s_lv = _level_images(f.image[:3].float(), max_level)
             t_lv = _level_images(trg_images[m][:3].float().to(dev), max_level)
             for l in self.level_ids:
-                src4_0.setdefault(l, []).append(tab.source_level(s_lv[l], f.K, klds[m].to(dev)))
+                src4_0.setdefault(l, []).append(padded(tab.source_level(s_lv[l], f.K, klds[m].to(dev)).reshape(-1, 4), pads0[m]))
                 Hl, Wl = t_lv[l].shape[-2:]
                 packed = torch.empty(1, Hl, Wl, 3, dtype=torch.float32, device=dev)
                 _lib.check(lib.sp_pack_rgb(_lib.ptr(t_lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(packed), _lib.stream_ptr()),
                            "sp_pack_rgb")
                 trg4_0.setdefault(l, []).append(packed.reshape(-1))
                 hw_0.setdefault(l, []).append((Hl, Wl))
-        self.pix = cat([t.pix for t in tables])          # after source_level(): validity bits are set
-        self.src4 = {l: cat([v[b] for b in base]) for l, v in src4_0.items()}
+        pix0 = [padded(t.pix, pd) for t, pd in zip(tables0, pads0)]        # after source_level(): validity bits are set
+        self.pix = cat([pix0[b] for b in base])
+        self.src4 = {l: cat([v[b] for b in base]).reshape(-1) for l, v in src4_0.items()}
         trg_off = {l: np.concatenate(([0], np.cumsum([v[b].numel() for b in base]))) for l, v in trg4_0.items()}
         self.trg4 = {l: cat([v[b] for b in base]) for l, v in trg4_0.items()}
         self.level_hw = {l: [v[b] for b in base] for l, v in hw_0.items()}
 
-        # work list
-        tiles, stos, t_off = [], [], [0]
-        for m, tab in enumerate(tables):
-            tl, sto = make_tiles(tab.counts, tile_points, pair=m, first_point=0)
-            tiles.append(tl)
-            stos.append(sto)
-            t_off.append(t_off[-1] + tl.shape[0])
-        self.n_tiles = t_off[-1]
-        self.tiles = torch.from_numpy(np.concatenate(tiles)).to(dev)
-        sto_off = np.concatenate(([0], np.cumsum([len(s) for s in stos])))
-        self.seg_tile_off = torch.from_numpy(np.concatenate(stos)).to(dev)
+        # work list: chunks {pair, seg, start, count} and spans {first chunk, n chunks, points, pair}
+        chunk_max = max(GRANULE, tile_points // GRANULE * GRANULE)
+        chunks, spans, seg_rec_offs, c_off, spans_per_pair = [], [], [], [0], []
+        for m, pd in enumerate(pads):
+            first = len(chunks)
+            sto = [0]
+            for n, (pc, off) in enumerate(zip(pd['pc'], pd['pseg_off'][:-1])):
+                k = int(-(-pc // chunk_max))                       # pieces of (nearly) equal, granule-aligned length
+                if k:
+                    per = int(-(-(pc // GRANULE) // k)) * GRANULE
+                    done = 0
+                    while done < pc:
+                        cnt = int(min(per, pc - done))
+                        chunks.append((m, n, int(off + done), cnt))
+                        done += cnt
+                sto.append(4 * (len(chunks) - first))              # records: 4 per chunk (one per wave)
+            seg_rec_offs.append(np.asarray(sto, dtype=np.int32))
+            c_off.append(len(chunks))
+            # spans: greedy runs of consecutive chunks
+            ns, q = 0, first
+            while q < len(chunks):
+                q1, pts = q, 0
+                while q1 < len(chunks) and (q1 == q or pts + chunks[q1][3] <= self.span_points):
+                    pts += chunks[q1][3]
+                    q1 += 1
+                spans.append((q, q1 - q, pts, m))
+                ns += 1
+                q = q1
+            spans_per_pair.append(ns)
+        self.n_chunks, self.n_spans = len(chunks), len(spans)
+        self.chunks = torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 4)).to(dev)
+        self.spans = torch.from_numpy(np.asarray(spans, dtype=np.int32).reshape(-1, 4)).to(dev)
+        # one partial record per (chunk, wave); `tiles` lists (pair, segment) of every record for host-side consumers
+        rec = np.repeat(np.asarray(chunks, dtype=np.int32).reshape(-1, 4), 4, axis=0)
+        rec[:, 2:] = 0
+        self.n_tiles = 4 * self.n_chunks
+        self.tiles = torch.from_numpy(rec).to(dev)
+        sto_off = np.concatenate(([0], np.cumsum([len(s) for s in seg_rec_offs])))
+        self.seg_tile_off = torch.from_numpy(np.concatenate(seg_rec_offs)).to(dev)
 
         # descriptors, one array per level
         self.desc = {}
@@ -126,8 +180,9 @@ class PairBatch:
                 d.K_trg = (ctypes.c_float * 4)(Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
                 d.N, d.P, d.H, d.W = tab.N, tab.P, tab.H, tab.W
                 d.Hl, d.Wl = self.level_hw[l][m]
-                d.tile0, d.n_tiles = t_off[m], t_off[m + 1] - t_off[m]
+                d.tile0, d.n_tiles = 4 * c_off[m], 4 * (c_off[m + 1] - c_off[m])
                 d.zmin = zmin
+                d.n_spans = spans_per_pair[m]
             raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
             self.desc[l] = torch.from_numpy(raw).to(dev)
 
@@ -159,7 +214,7 @@ class PairBatch:
 
     # ------------------------------------------------------------------------------------------------
     def cost_pass(self, level, mode, irls_eps=1e-3):
-        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.tiles), self.n_tiles, mode,
+        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, mode,
                                           float(irls_eps), _lib.ptr(self.partials), _lib.stream_ptr()), "sp_pairs_cost")
 
     def gn_step(self, level=0, irls_eps=1e-3, lm_up=8.0, lm_down=0.5, lm_min=1e-7, fused=False):
@@ -169,7 +224,7 @@ class PairBatch:
         pair's last tile also solves that pair -- bitwise the same results; measured 0-4 % slower on MI355X (the
         solver's register/LDS footprint costs the cost kernel one wave per SIMD), kept for launch-bound hosts."""
         if fused:
-            _lib.check(self.lib.sp_pairs_gn_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.tiles), self.n_tiles, self.M,
+            _lib.check(self.lib.sp_pairs_gn_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, self.M,
                                                     self.max_N, float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.arrivals),
                                                     float(lm_up), float(lm_down), float(lm_min), _lib.ptr(self.lm_state),
                                                     _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.stream_ptr()),
@@ -185,7 +240,7 @@ class PairBatch:
     def adam_step(self, level=0, lr_kld=1e-3, lr_pose=1e-2, lr_aff=5e-3, fused=False):
         """One Adam iteration (reset-tangent flavour of the reference's tracking/mapping loops) of every pair."""
         if fused:
-            _lib.check(self.lib.sp_pairs_adam_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.tiles), self.n_tiles, self.M,
+            _lib.check(self.lib.sp_pairs_adam_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, self.M,
                                                       self.max_N, _lib.ptr(self.partials), _lib.ptr(self.arrivals),
                                                       float(lr_kld), float(lr_pose), float(lr_aff), _lib.ptr(self.adam_state),
                                                       _lib.ptr(self._costs), _lib.stream_ptr()), "sp_pairs_adam_iterate")

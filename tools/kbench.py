@@ -34,7 +34,7 @@ def main():
             torch.cuda.synchronize()
             ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
             by = batch.algorithmic_bytes(level)
-            print(f"level {level} mode {mode} pairs {batch.M} tiles {batch.n_tiles}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
+            print(f"level {level} mode {mode} pairs {batch.M} spans {batch.n_spans}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
                   f"alg {by/1e6:.1f} MB -> {by/np.median(ms)/1e6:.0f} GB/s ({by/np.median(ms)/1e6/8000*100:.1f}% of 8 TB/s)  "
                   f"{sum(batch.Ps)/np.median(ms)/1e6:.2f} Gpt/s")
 
