@@ -149,12 +149,12 @@ def main():
         if args.mode == "gn":
             # the second launch of the step (solver); gn_step() = cost_pass + this
             from super_primitive_amd import _lib
-            _lib.check(batch.lib.sp_pairs_gn_step(_lib.ptr(batch.desc[0]), M, batch.max_N, _lib.ptr(batch.partials), 8.0, 0.5,
+            _lib.check(batch.lib.sp_pairs_gn_step(_lib.ptr(batch.desc[0]), M, batch.max_N, _lib.ptr(batch.partials), _lib.ptr(batch.seg_partials), 8.0, 0.5,
                                                   1e-7, _lib.ptr(batch.lm_state), _lib.ptr(batch.backup),
                                                   _lib.ptr(batch._costs), _lib.stream_ptr()), "sp_pairs_gn_step")
         else:
             from super_primitive_amd import _lib
-            _lib.check(batch.lib.sp_pairs_adam_step(_lib.ptr(batch.desc[0]), M, batch.max_N, _lib.ptr(batch.partials), 1e-3,
+            _lib.check(batch.lib.sp_pairs_adam_step(_lib.ptr(batch.desc[0]), M, batch.max_N, _lib.ptr(batch.partials), _lib.ptr(batch.seg_partials), 1e-3,
                                                     1e-2, 5e-3, _lib.ptr(batch.adam_state), _lib.ptr(batch._costs),
                                                     _lib.stream_ptr()), "sp_pairs_adam_step")
     barrier()

@@ -45,7 +45,7 @@ extern "C" {
 
 /* number of floats one tile writes in each mode (partials workspace = n_tiles * B * this) */
 #define SP_GRAD_PARTIAL_FLOATS 16
-#define SP_GN_PARTIAL_FLOATS   40
+#define SP_GN_PARTIAL_FLOATS   32
 
 int sp_abi_version(void);
 
@@ -129,11 +129,17 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
  *   spans[S]  int32x4 {first chunk, number of chunks, points, pair}: what one workgroup processes -- a run of
  *             consecutive chunks of one pair; pair-level sums are reduced once per span, segment-level sums once
  *             per chunk and wave.
- * Partials: one record of (SP_GRAD_PARTIAL_FLOATS | SP_GN_PARTIAL_FLOATS) floats per (chunk, wave): record
- * 4 * chunk + wave.  The solvers below sum records in index order; they only need, per pair, the index of its first
- * record (SpPair.tile0 = 4 * first chunk), the number of its records (n_tiles = 4 * chunks) and, per segment, the
- * record range of its chunks (seg_tile_off, relative to tile0).
+ * Partials, two arrays:
+ *   span_partials[S]      one record of (SP_GRAD_PARTIAL_FLOATS | SP_GN_PARTIAL_FLOATS) floats per span: the sums that
+ *                         belong to the PAIR (mode 0: as sp_photo_cost_grad's tile record with column 13 unused;
+ *                         mode 1: [0] sum|r|, [1..21] H_pp upper triangle, [22..27] b_p, [28] valid points);
+ *   seg_partials[4 * C]   one record of (SP_GRAD_SEG_FLOATS | SP_GN_SEG_FLOATS) floats per (chunk, wave), record
+ *                         4 * chunk + wave: the sums that belong to the SEGMENT (mode 0: d/dkld; mode 1: h_pd(6), D, b_d).
+ * The solvers sum records in index order.  Per pair they need its span range (SpPair.tile0, n_tiles), the index of
+ * its first segment record (rec0) and, per segment, the record range of its chunks (seg_tile_off, relative to rec0).
  * ---------------------------------------------------------------------------------------------------- */
+#define SP_GRAD_SEG_FLOATS 1
+#define SP_GN_SEG_FLOATS 8
 typedef struct SpPair {
     const uint32_t* pix;      /* [P_padded] */
     const float*    src4;     /* [P_padded*4] for the level being optimised */
@@ -142,27 +148,27 @@ typedef struct SpPair {
     float*          kld;      /* [N]  optimisation variable */
     float*          pose;     /* [16] optimisation variable (target <- source) */
     float*          aff;      /* [4]  {a_s,b_s,a_t,b_t} or NULL */
-    const int32_t*  seg_tile_off; /* [N+1] offsets into this pair's partial records, relative to tile0 */
+    const int32_t*  seg_tile_off; /* [N+1] offsets into this pair's segment records, relative to rec0 */
     float K_src[4];           /* fx fy cx cy */
     float K_trg[4];
     int32_t N, P, H, W, Hl, Wl;   /* P = number of REAL points (the cost is a mean over 3 P values) */
-    int32_t tile0;            /* first partial record of this pair */
-    int32_t n_tiles;          /* number of partial records of this pair */
+    int32_t tile0;            /* first span of this pair */
+    int32_t n_tiles;          /* number of spans (workgroups) of this pair */
     float zmin;
-    int32_t n_spans;          /* workgroups (spans) of this pair: the single-launch forms count their arrivals */
+    int32_t rec0;             /* first segment record of this pair (= 4 * its first chunk) */
 } SpPair;
 
-/* mode 0 / 1 as above.  partials: 4 * C records. */
+/* mode 0 / 1 as above. */
 int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
-                  float* partials, void* stream);
+                  float* span_partials, float* seg_partials, void* stream);
 
 /* Adam step on {kld, left SE(3) tangent, affine} of every pair from the mode-0 partials: reduces the tile
  * partials (fixed order, fp64), loss = |residual| like odometery/two_frame_sfm.py:201-206, maps d/dpose to the
  * tangent of Exp(a)*T, applies torch.optim.Adam semantics (betas 0.9/0.999, eps 1e-8, bias correction) with
  * per-group learning rates, retracts pose <- Exp(step)*pose.  state: per pair (2*(N+6+2)+2) floats, zeroed
  * by the caller before the first step.  losses: [n_pairs] written every step. */
-int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, float lr_kld,
-                       float lr_pose, float lr_aff, float* state, float* losses, void* stream);
+int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float* span_partials, const float* seg_partials,
+                       float lr_kld, float lr_pose, float lr_aff, float* state, float* losses, void* stream);
 
 /* Gauss-Newton / Levenberg-Marquardt step from the mode-1 partials: per pair, reduce tiles, eliminate the
  * N diagonal log-depth unknowns (Schur complement onto the 6x6 pose block), solve in fp64, update
@@ -171,18 +177,19 @@ int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float*
  * lambda adapts on device (cost up -> step undone from the backup, lambda*=lm_up, re-evaluated next call;
  * cost down -> lambda = max(lambda*lm_down, lm_min)).  backup: per pair (16+max_N) floats.  costs: [n_pairs]. */
 #define SP_LM_STATE_FLOATS 8
-int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, float lm_up,
-                     float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream);
+int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* span_partials, const float* seg_partials,
+                     float lm_up, float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream);
 
 /* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last span of a pair
  * runs that pair's update in place (same arithmetic, same fixed reduction order as sp_pairs_cost followed by
  * sp_pairs_adam_step / sp_pairs_gn_step -- results are bitwise identical).  arrivals: n_pairs int32, zeroed once by
  * the caller (the kernel leaves it zeroed).  Other arguments as in the two-launch forms. */
 int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
-                          float* partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
+                          float* span_partials, float* seg_partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
                           float* losses, void* stream);
 int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
-                        float irls_eps, float* partials, int32_t* arrivals, float lm_up, float lm_down, float lm_min,
+                        float irls_eps, float* span_partials, float* seg_partials, int32_t* arrivals, float lm_up, float lm_down,
+                        float lm_min,
                         float* lm_state, float* backup, float* costs, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -27,11 +27,11 @@ SIGNATURES = {
     "sp_blur_decimate": [P, I, I, I, P, P],
     "sp_photo_cost_grad": [P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P],
     "sp_photo_stats": [P, P, P, P, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P, P, P, I, P],
-    "sp_pairs_cost": [P, P, P, I, I, F, P, P],
-    "sp_pairs_adam_step": [P, I, I, P, F, F, F, P, P, P],
-    "sp_pairs_gn_step": [P, I, I, P, F, F, F, P, P, P, P],
-    "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, F, F, F, P, P, P],
-    "sp_pairs_gn_iterate": [P, P, P, I, I, I, F, P, P, F, F, F, P, P, P, P],
+    "sp_pairs_cost": [P, P, P, I, I, F, P, P, P],
+    "sp_pairs_adam_step": [P, I, I, P, P, F, F, F, P, P, P],
+    "sp_pairs_gn_step": [P, I, I, P, P, F, F, F, P, P, P, P],
+    "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, P, F, F, F, P, P, P],
+    "sp_pairs_gn_iterate": [P, P, P, I, I, I, F, P, P, P, F, F, F, P, P, P, P],
     "sp_depth_expand": [P, P, P, P, I, I, I, I, P, P],
     "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_segment_reinit": [P, P, P, P, I, I, I, I, P, I, P, P, P, P],
@@ -48,7 +48,9 @@ SIGNATURES = {
 
 SP_ABI_VERSION = 3
 SP_GRAD_PARTIAL_FLOATS = 16
-SP_GN_PARTIAL_FLOATS = 40
+SP_GN_PARTIAL_FLOATS = 32
+SP_GRAD_SEG_FLOATS = 1
+SP_GN_SEG_FLOATS = 8
 SP_LM_STATE_FLOATS = 8
 
 
@@ -59,7 +61,7 @@ class SpPair(ctypes.Structure):
         ("kld", c_void_p), ("pose", c_void_p), ("aff", c_void_p), ("seg_tile_off", c_void_p),
         ("K_src", c_float * 4), ("K_trg", c_float * 4),
         ("N", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("Hl", c_int), ("Wl", c_int),
-        ("tile0", c_int), ("n_tiles", c_int), ("zmin", c_float), ("n_spans", c_int),
+        ("tile0", c_int), ("n_tiles", c_int), ("zmin", c_float), ("rec0", c_int),
     ]
 
 

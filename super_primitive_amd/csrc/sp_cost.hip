@@ -212,7 +212,8 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float* __restrict__ o
 // -----------------------------------------------------------------------------------------------------
 // mode 1: Gauss-Newton accumulators over x = [tau(3), phi(3), kld_n] (left perturbation Exp(xi)*T)
 //   [0] sum |r|   [1..21] H_pp upper triangle (row-major)   [22..27] b_p   [28..33] h_pd   [34] D   [35] b_d
-//   [36] number of valid points   [37..39] unused
+//   [36] number of valid points      (the span loops keep [28..35] per segment and write [0..27] + the count as
+//   column 28 of a 32-float pair record, include/sp_hip.h)
 // r_ch = I_src - I_trg';  J_ch = c_ch * A,  A (2x7) shared by the channels,  c_ch = -gain*[dI/dix, dI/diy];
 // IRLS weight of the L1 cost w_ch = 1/max(|r_ch|, eps)  =>  b = J^T sign(r) for |r| > eps.
 // carried per point: {sum w Ix Ix, sum w Ix Iy, sum w Iy Iy, sum w r Ix, sum w r Iy} (Mix2 below)
@@ -362,9 +363,8 @@ __device__ __forceinline__ void fold_gn2(const TileCtx& c, const GeoGn g, const 
 // block reduction (about 530 instructions per wave, 12 % of a 23-trip tile) are thus paid once per span, not once
 // per segment.
 //
-// Partials: one record of NV floats per (chunk, wave) -- record 4*chunk + wave, same column layout as before.  A
-// wave writes the segment columns of its record at every flush and zeros elsewhere; the pair columns of the span
-// land in the record (last chunk of the span, wave 0).  The solvers sum records, so they need not know about spans.
+// Partials: pair sums -> one record per span (span_partials); segment sums -> one record per (chunk, wave)
+// (seg_partials, record 4*chunk + wave).  The solvers sum records in index order, so they need not know about spans.
 // =====================================================================================================
 typedef const float __attribute__((address_space(4)))* cptr_f32;       // constant address space: scalar (s_load) reads
 struct ChunkRec { int pair, seg, start, count; };                       // one int32x4 entry of the chunk list
@@ -421,16 +421,14 @@ __device__ __forceinline__ void store_partial(float* p, float v) {
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// mode 1: flush {h_pd(6), D, b_d} of the chunk this wave just finished into its record (columns 28..35; zeros elsewhere)
+// mode 1: flush {h_pd(6), D, b_d} of the chunk this wave just finished into its segment record
 template <bool WT>
 __device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ rec) {
-    constexpr int NV = SP_GN_PARTIAL_FLOATS;
     float v[8] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D, A.bd};
     const int lane = lane_id();
     int pos; bool ok;
     wave_sum_to_lanes<8>(v, lane, pos, ok);
-    if (lane < NV && (lane < 28 || lane >= 36)) store_partial<WT>(rec + lane, 0.f);
-    if (ok) store_partial<WT>(rec + 28 + pos, v[0]);
+    if (ok) store_partial<WT>(rec + pos, v[0]);
     const f32x2 z{0.f, 0.f};
     A.hd01 = z; A.hd[0] = z; A.hd[1] = z; A.D = 0.f; A.bd = 0.f;
 }
@@ -439,8 +437,9 @@ __device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ r
 // 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation)
 template <int ABL, bool WT>
 __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
-                                            int n_chunks, int total, float irls_eps, float* __restrict__ partials, float* lds) {
-    constexpr int NV = SP_GN_PARTIAL_FLOATS;
+                                            int n_chunks, int total, float irls_eps, float* __restrict__ span_rec,
+                                            float* __restrict__ seg_partials, float* lds) {
+    constexpr int NV = SP_GN_PARTIAL_FLOATS, NS = SP_GN_SEG_FLOATS;
     GnAcc A;
     {
         const f32x2 z{0.f, 0.f};
@@ -488,7 +487,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 2) fold_gn2(c, cur, m, A);
-        if (cur_last) flush_segment_gn<WT>(A, partials + (size_t)(4 * cur_q + wave) * NV);
+        if (cur_last) flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * cur_q + wave) * NS);
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 1)
             asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(A.blk[0]), "+v"(A.blk[1]), "+v"(A.blk[2]),
@@ -505,7 +504,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         nx_last = cursor_advance(k, nx_q);
     }
     if (ABL != 2) fold_gn2(c, cur, m, A);
-    flush_segment_gn<WT>(A, partials + (size_t)(4 * cur_q + wave) * NV);      // the span ends with its last chunk
+    flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * cur_q + wave) * NS);      // the span ends with its last chunk
     float acc[NV];
     acc[0] = A.cost;
     acc[1] = A.h00.x; acc[2] = A.h00.y;
@@ -517,21 +516,19 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     acc[19] = A.blk[4].x; acc[20] = A.blk[4].y; acc[21] = A.blk[5].y;
     acc[22] = A.bp01.x; acc[23] = A.bp01.y;
     acc[24] = A.bp[0].x; acc[25] = A.bp[0].y; acc[26] = A.bp[1].x; acc[27] = A.bp[1].y;
-#pragma unroll
-    for (int i = 28; i < 36; ++i) acc[i] = 0.f;         // segment columns: flushed per chunk above
-    acc[36] = A.n; acc[37] = acc[38] = acc[39] = 0.f;
+    acc[28] = A.n; acc[29] = acc[30] = acc[31] = 0.f;
     // op still knows the thread index (op = 4 * (threadIdx.x + trips * SP_BLOCK)): nothing derived from threadIdx.x
     // has to stay live, or be spilled, across the loop for the sake of this epilogue
     const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
     const float tot = block_sum_to_thread<NV>(acc, lds, tid);
-    // pair columns of the span: into the record (last chunk, wave 0), after wave 0's own flush of that record
-    if (tid < NV && (tid < 28 || tid >= 36)) store_partial<WT>(partials + (size_t)(4 * cur_q) * NV + tid, tot);
+    if (tid < NV) store_partial<WT>(span_rec + tid, tot);
 }
 
 // mode 0: the segment column is 13 (d/dkld)
 template <int ABL, bool WT>
 __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
-                                              int n_chunks, int total, float* __restrict__ partials, float* lds) {
+                                              int n_chunks, int total, float* __restrict__ span_rec,
+                                              float* __restrict__ seg_partials, float* lds) {
     constexpr int NV = SP_GRAD_PARTIAL_FLOATS;
     float acc[NV];
 #pragma unroll
@@ -560,10 +557,8 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
     cur.zinv = 0.f; cur.zi = 0.f;
     Mix0 m0{0.f, 0.f, 0.f, 0.f};
     auto flush = [&](int q) {
-        float* rec = partials + (size_t)(4 * q + wave) * NV;
         const float tot = wave_sum(acc[13]);
-        const int lane = lane_id();
-        if (lane < NV) store_partial<WT>(rec + lane, lane == 13 ? tot : 0.f);
+        if (lane_id() == 0) store_partial<WT>(seg_partials + (size_t)(4 * q + wave) * SP_GRAD_SEG_FLOATS, tot);
         acc[13] = 0.f;
     };
     for (int j = 0; j < n_iter; ++j) {
@@ -599,8 +594,8 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
     if (ABL != 2) fold_grad(c, cur, m0, acc);
     flush(cur_q);
     const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
-    const float tot = block_sum_to_thread<NV>(acc, lds, tid);
-    if (tid < NV && tid != 13) store_partial<WT>(partials + (size_t)(4 * cur_q) * NV + tid, tot);
+    const float tot = block_sum_to_thread<NV>(acc, lds, tid);      // (column 13 is zero here: flushed per chunk)
+    if (tid < NV) store_partial<WT>(span_rec + tid, tot);
 }
 
 __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const Cam& Kt, int H, int W, int Hl, int Wl,
@@ -704,7 +699,7 @@ struct FuseArgs {
 template <int MODE, int ABL = 0, int FUSED = 0>
 __global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
         const SpPair* __restrict__ pairs, const int4* __restrict__ chunks, const int4* __restrict__ spans, int n_spans,
-        float irls_eps, float* __restrict__ partials, FuseArgs f) {
+        float irls_eps, float* __restrict__ partials, float* __restrict__ seg_partials, FuseArgs f) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
     __shared__ float lds[SP_WAVES * NV];
     const int w = xcd_chunked_tile(blockIdx.x, n_spans);
@@ -725,15 +720,15 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
         c.bias = pr.aff[3] - pr.aff[1];
     }
     c.start = 0; c.count = 0;
-    if (MODE == 1) run_span_gn<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials, lds);
-    else run_span_grad<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, partials, lds);
+    if (MODE == 1) run_span_gn<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials + (size_t)w * NV, seg_partials, lds);
+    else run_span_grad<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, partials + (size_t)w * NV, seg_partials, lds);
     if (FUSED != 0) {
         __shared__ int is_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0) {
             const int old = __hip_atomic_fetch_add(f.arrivals + span.w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = old == pr.n_spans - 1;
+            const int last = old == pr.n_tiles - 1;
             if (last) {
                 __hip_atomic_store(f.arrivals + span.w, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -742,8 +737,8 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
         }
         __syncthreads();
         if (is_last) {
-            if (FUSED == 1) solve_adam(pairs, span.w, partials, f.adam);
-            else solve_gn(pairs, span.w, partials, f.gn);
+            if (FUSED == 1) solve_adam(pairs, span.w, partials, seg_partials, f.adam);
+            else solve_gn(pairs, span.w, partials, seg_partials, f.gn);
         }
     }
 }
@@ -867,8 +862,8 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
 }
 
 int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
-                  float* partials, void* stream) {
-    if (!pairs || !chunks || !spans || !partials || n_spans <= 0) return SP_EINVAL;
+                  float* partials, float* seg_partials, void* stream) {
+    if (!pairs || !chunks || !spans || !partials || !seg_partials || n_spans <= 0) return SP_EINVAL;
     if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_spans + 7) / 8) * 8;
@@ -876,40 +871,41 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spa
     const int4* s4 = reinterpret_cast<const int4*>(spans);
     const FuseArgs nofuse{};
     if (mode == 0)
-        hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 1)
-        hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 10)   /* developer ablations, see run_span_gn */
-        hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 11)
-        hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 12)
-        hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else
-        hipLaunchKernelGGL((k_cost_pairs<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, nofuse);
+        hipLaunchKernelGGL((k_cost_pairs<1, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     SP_CHECK_LAUNCH();
     return 0;
 }
 
 int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
-                          float* partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
+                          float* partials, float* seg_partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
                           float* losses, void* stream) {
-    if (!pairs || !chunks || !spans || !partials || !arrivals || !state || !losses || n_spans <= 0 || n_pairs <= 0 || max_N <= 0)
+    if (!pairs || !chunks || !spans || !partials || !seg_partials || !arrivals || !state || !losses || n_spans <= 0 || n_pairs <= 0 ||
+        max_N <= 0)
         return SP_EINVAL;
     FuseArgs f{};
     f.arrivals = arrivals;
     f.adam = AdamArgs{max_N, lr_kld, lr_pose, lr_aff, state, losses};
     const int gx = ((n_spans + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cost_pairs<0, 0, 1>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
-                       reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, 0.f, partials, f);
+                       reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, 0.f, partials, seg_partials, f);
     SP_CHECK_LAUNCH();
     return 0;
 }
 
 int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
-                        float irls_eps, float* partials, int32_t* arrivals, float lm_up, float lm_down, float lm_min,
-                        float* lm_state, float* backup, float* costs, void* stream) {
-    if (!pairs || !chunks || !spans || !partials || !arrivals || !lm_state || !backup || !costs || n_spans <= 0 || n_pairs <= 0 ||
+                        float irls_eps, float* partials, float* seg_partials, int32_t* arrivals, float lm_up, float lm_down,
+                        float lm_min, float* lm_state, float* backup, float* costs, void* stream) {
+    if (!pairs || !chunks || !spans || !partials || !seg_partials || !arrivals || !lm_state || !backup || !costs || n_spans <= 0 || n_pairs <= 0 ||
         max_N <= 0)
         return SP_EINVAL;
     FuseArgs f{};
@@ -917,7 +913,7 @@ int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_
     f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs};
     const int gx = ((n_spans + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cost_pairs<1, 0, 2>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
-                       reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, f);
+                       reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, f);
     SP_CHECK_LAUNCH();
     return 0;
 }

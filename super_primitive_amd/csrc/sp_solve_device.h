@@ -99,7 +99,7 @@ struct AdamArgs {
 
 // One workgroup: tile-partial reduction + Adam update of pair `pi` (see include/sp_hip.h sp_pairs_adam_step).
 __device__ __forceinline__ void solve_adam(const SpPair* __restrict__ pairs, int pi, const float* __restrict__ partials,
-                                           const AdamArgs& h) {
+                                           const float* __restrict__ seg_partials, const AdamArgs& h) {
     const int max_N = h.max_N;
     const float lr_kld = h.lr_kld, lr_pose = h.lr_pose, lr_aff = h.lr_aff;
     float* __restrict__ state = h.state;
@@ -109,7 +109,7 @@ __device__ __forceinline__ void solve_adam(const SpPair* __restrict__ pairs, int
     __shared__ double scratch[(SP_BLOCK / NV) * NV];
     const SpPair& pr = pairs[pi];
     const float* p = partials + (size_t)pr.tile0 * NV;
-    reduce_columns<NV>(p, pr.n_tiles, sums, scratch);      // (column 13 is per segment: its global sum is unused)
+    reduce_columns<NV>(p, pr.n_tiles, sums, scratch);      // span records (column 13 is unused: d/dkld is per segment)
     const double scale = 1.0 / (3.0 * (double)pr.P);
     const float residual = (float)(sums[0] * scale);
     // loss = |residual| (two_frame_sfm.py:201): d loss / d residual = sign(residual)
@@ -124,11 +124,12 @@ __device__ __forceinline__ void solve_adam(const SpPair* __restrict__ pairs, int
     // per-segment log-depths
     for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
         double s = 0.0;
+        const float* sp = seg_partials + (size_t)pr.rec0 * SP_GRAD_SEG_FLOATS;
         const int t0 = pr.seg_tile_off[n], t1 = pr.seg_tile_off[n + 1];
-        for (int t = t0; t < t1; t += 8) {       // eight tiles in flight per trip, added in tile order
+        for (int t = t0; t < t1; t += 8) {       // eight records in flight per trip, added in record order
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)min(t + u, t1 - 1) * NV + 13];
+            for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)min(t + u, t1 - 1) * SP_GRAD_SEG_FLOATS];
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += (t + u < t1) ? (double)v[u] : 0.0;
         }
@@ -200,17 +201,17 @@ __device__ bool ldlt6_solve(double S[36], double rhs[6]) {
 
 #define SP_SEG_CACHE 256     // segments whose reduced {h(6), 1/D', b_d} live in LDS; beyond that they are recomputed
 
-// {h_pd(6), D, b_d} of segment n summed over its tiles; lam -> {h, 1/(D(1+lam)) or 0, b_d}
+// {h_pd(6), D, b_d} of segment n summed over its (chunk, wave) records; lam -> {h, 1/(D(1+lam)) or 0, b_d}
 __device__ __forceinline__ void segment_system(const float* __restrict__ p, const int32_t* __restrict__ seg_tile_off, int n,
                                                double lam, double (&o)[8]) {
-    constexpr int NV = SP_GN_PARTIAL_FLOATS;
+    constexpr int NV = SP_GN_SEG_FLOATS;
     double h[6] = {0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
     const int t0 = seg_tile_off[n], t1 = seg_tile_off[n + 1];
-    for (int t = t0; t < t1; t += 4) {          // four tiles' records in flight per trip, summed in tile order
+    for (int t = t0; t < t1; t += 4) {          // four records in flight per trip, summed in record order
         float v[4][8];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const float* q = p + (size_t)min(t + u, t1 - 1) * NV + 28;
+            const float* q = p + (size_t)min(t + u, t1 - 1) * NV;
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[u][i] = q[i];
         }
@@ -241,14 +242,14 @@ struct GnArgs {
 
 // One workgroup: tile-partial reduction + Schur-complement LM step of pair `pi` (include/sp_hip.h sp_pairs_gn_step).
 __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int pi, const float* __restrict__ partials,
-                                         const GnArgs& h) {
+                                         const float* __restrict__ seg_partials, const GnArgs& h) {
     const int max_N = h.max_N;
     const float lm_up = h.lm_up, lm_down = h.lm_down, lm_min = h.lm_min;
     float* __restrict__ lm_state = h.lm_state;
     float* __restrict__ backup = h.backup;
     float* __restrict__ costs = h.costs;
     constexpr int NV = SP_GN_PARTIAL_FLOATS;
-    __shared__ double sums[NV];      // [0] cost, [1..21] Hpp upper, [22..27] b_p (columns >= 28 are per segment)
+    __shared__ double sums[NV];      // [0] cost, [1..21] Hpp upper, [22..27] b_p, [28] valid points
     __shared__ double scratch[(SP_BLOCK / NV) * NV];
     __shared__ double seg[SP_SEG_CACHE][8];
     __shared__ double schur_part[8][27];
@@ -257,6 +258,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
     __shared__ int decision;         // 0 = step, 1 = rejected (restore)
     const SpPair& pr = pairs[pi];
     const float* p = partials + (size_t)pr.tile0 * NV;
+    const float* sp = seg_partials + (size_t)pr.rec0 * SP_GN_SEG_FLOATS;
     float* ls = lm_state + (size_t)pi * SP_LM_STRIDE;
     float* bk = backup + (size_t)pi * (16 + max_N);
     reduce_columns<NV>(p, pr.n_tiles, sums, scratch);
@@ -287,7 +289,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
     const int n_cached = min(pr.N, SP_SEG_CACHE);
     for (int n = threadIdx.x; n < n_cached; n += SP_BLOCK) {
         double o[8];
-        segment_system(p, pr.seg_tile_off, n, lam, o);
+        segment_system(sp, pr.seg_tile_off, n, lam, o);
 #pragma unroll
         for (int i = 0; i < 8; ++i) seg[n][i] = o[i];
     }
@@ -307,7 +309,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
                 if (n < SP_SEG_CACHE) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
-                } else segment_system(p, pr.seg_tile_off, n, lam, o);
+                } else segment_system(sp, pr.seg_tile_off, n, lam, o);
                 acc += o[a] * (k < 21 ? o[b] : o[7]) * o[6];
             }
             schur_part[j][k] = acc;
@@ -342,7 +344,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         if (n < SP_SEG_CACHE) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
-        } else segment_system(p, pr.seg_tile_off, n, lam, o);
+        } else segment_system(sp, pr.seg_tile_off, n, lam, o);
         if (o[6] > 0.0) {
             double r = -o[7];
 #pragma unroll

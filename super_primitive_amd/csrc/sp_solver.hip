@@ -8,12 +8,13 @@
 namespace {
 
 __global__ __launch_bounds__(SP_BLOCK) void k_pairs_adam(const SpPair* __restrict__ pairs, const float* __restrict__ partials,
-                                                         AdamArgs h) {
-    solve_adam(pairs, blockIdx.x, partials, h);
+                                                         const float* __restrict__ seg_partials, AdamArgs h) {
+    solve_adam(pairs, blockIdx.x, partials, seg_partials, h);
 }
 
-__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict__ pairs, const float* __restrict__ partials, GnArgs h) {
-    solve_gn(pairs, blockIdx.x, partials, h);
+__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict__ pairs, const float* __restrict__ partials,
+                                                       const float* __restrict__ seg_partials, GnArgs h) {
+    solve_gn(pairs, blockIdx.x, partials, seg_partials, h);
 }
 
 
@@ -133,20 +134,20 @@ __global__ void k_se3_retract(const float* __restrict__ a6, const float* __restr
 
 extern "C" {
 
-int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, float lr_kld,
-                       float lr_pose, float lr_aff, float* state, float* losses, void* stream) {
-    if (!pairs || !partials || !state || !losses || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, const float* seg_partials,
+                       float lr_kld, float lr_pose, float lr_aff, float* state, float* losses, void* stream) {
+    if (!pairs || !partials || !seg_partials || !state || !losses || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
     hipLaunchKernelGGL(k_pairs_adam, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs, partials,
-                       AdamArgs{max_N, lr_kld, lr_pose, lr_aff, state, losses});
+                       seg_partials, AdamArgs{max_N, lr_kld, lr_pose, lr_aff, state, losses});
     SP_CHECK_LAUNCH();
     return 0;
 }
 
-int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, float lm_up, float lm_down,
-                     float lm_min, float* lm_state, float* backup, float* costs, void* stream) {
-    if (!pairs || !partials || !lm_state || !backup || !costs || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, const float* seg_partials,
+                     float lm_up, float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream) {
+    if (!pairs || !partials || !seg_partials || !lm_state || !backup || !costs || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
     hipLaunchKernelGGL(k_pairs_gn, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs, partials,
-                       GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs});
+                       seg_partials, GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs});
     SP_CHECK_LAUNCH();
     return 0;
 }

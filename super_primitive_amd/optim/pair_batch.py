@@ -23,7 +23,8 @@ from ..image import gaussian_pyramid
 from ..segment_table import SegmentTable
 
 DEFAULT_BATCH_TILE_POINTS = 8192   # longest chunk (run of one segment's points between two segment-level flushes)
-DEFAULT_SPAN_POINTS = 16384        # points per workgroup: consecutive chunks of a pair are grouped up to this many
+DEFAULT_SPAN_POINTS = 16384        # most points per workgroup: consecutive chunks of a pair are grouped up to this many
+MIN_SPANS = 2304                   # ... but a launch should still have about this many workgroups (256 CUs x 4 x 2.25)
 GRANULE = 256                      # SP_BLOCK: every segment is padded to a multiple of it in the batch's tables
 
 
@@ -38,7 +39,7 @@ def _level_images(img, max_level):
 
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
-                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=DEFAULT_SPAN_POINTS):
+                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None):
         """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
         device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
@@ -49,7 +50,8 @@ class PairBatch:
         Layout (include/sp_hip.h, "Work list"): the batch keeps its own PADDED copy of every table -- each segment's
         run of points extended to a multiple of 256 with invalid points -- so that a workgroup can stream through a SPAN
         of several consecutive chunks (segments, or pieces of at most ``tile_points`` points of a long segment) of up
-        to ``span_points`` points without any trip mixing two segments."""
+        to ``span_points`` points without any trip mixing two segments.  ``span_points=None``: 16384, reduced for small
+        batches so that a launch keeps about 2300 workgroups (a single pair then runs one chunk per workgroup)."""
         lib = _lib.load()
         self.lib = lib
         M0 = len(src_frames)
@@ -65,7 +67,6 @@ class PairBatch:
         self.level_ids = list(range(levels[0], levels[1]))
         max_level = levels[1] - 1
         self.tile_points = tile_points
-        self.span_points = max(int(span_points), GRANULE)
 
         tables0 = [SegmentTable(f.keypoint_regions, f.logdepth_perseg, f.keypoints, tile_points) for f in src_frames]
         tables = [tables0[b] for b in base]
@@ -120,6 +121,9 @@ class PairBatch:
         self.trg4 = {l: cat([v[b] for b in base]) for l, v in trg4_0.items()}
         self.level_hw = {l: [v[b] for b in base] for l, v in hw_0.items()}
 
+        if span_points is None:
+            span_points = min(DEFAULT_SPAN_POINTS, int(p_off[-1]) // MIN_SPANS)
+        self.span_points = max(int(span_points), GRANULE)
         # work list: chunks {pair, seg, start, count} and spans {first chunk, n chunks, points, pair}
         chunk_max = max(GRANULE, tile_points // GRANULE * GRANULE)
         chunks, spans, seg_rec_offs, c_off, spans_per_pair = [], [], [], [0], []
@@ -150,13 +154,15 @@ class PairBatch:
                 q = q1
             spans_per_pair.append(ns)
         self.n_chunks, self.n_spans = len(chunks), len(spans)
+        s_off = np.concatenate(([0], np.cumsum(spans_per_pair)))
         self.chunks = torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 4)).to(dev)
         self.spans = torch.from_numpy(np.asarray(spans, dtype=np.int32).reshape(-1, 4)).to(dev)
-        # one partial record per (chunk, wave); `tiles` lists (pair, segment) of every record for host-side consumers
-        rec = np.repeat(np.asarray(chunks, dtype=np.int32).reshape(-1, 4), 4, axis=0)
-        rec[:, 2:] = 0
-        self.n_tiles = 4 * self.n_chunks
-        self.tiles = torch.from_numpy(rec).to(dev)
+        # partial records: one per span (pair-level sums) and one per (chunk, wave) (segment-level sums);
+        # span_pair / seg_records list the owner of every record for host-side consumers (tests, evaluate())
+        self.span_pair = self.spans[:, 3].long()
+        rec = np.repeat(np.asarray(chunks, dtype=np.int32).reshape(-1, 4)[:, :2], 4, axis=0)
+        self.n_seg_records = 4 * self.n_chunks
+        self.seg_records = torch.from_numpy(rec.copy()).to(dev)          # (pair, segment) of every segment record
         sto_off = np.concatenate(([0], np.cumsum([len(s) for s in seg_rec_offs])))
         self.seg_tile_off = torch.from_numpy(np.concatenate(seg_rec_offs)).to(dev)
 
@@ -180,14 +186,15 @@ class PairBatch:
                 d.K_trg = (ctypes.c_float * 4)(Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
                 d.N, d.P, d.H, d.W = tab.N, tab.P, tab.H, tab.W
                 d.Hl, d.Wl = self.level_hw[l][m]
-                d.tile0, d.n_tiles = 4 * c_off[m], 4 * (c_off[m + 1] - c_off[m])
+                d.tile0, d.n_tiles = s_off[m], s_off[m + 1] - s_off[m]
                 d.zmin = zmin
-                d.n_spans = spans_per_pair[m]
+                d.rec0 = 4 * c_off[m]
             raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
             self.desc[l] = torch.from_numpy(raw).to(dev)
 
         # optimiser state / workspaces
-        self.partials = torch.empty(self.n_tiles * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+        self.partials = torch.empty(self.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+        self.seg_partials = torch.empty(self.n_seg_records * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
         self._costs = torch.zeros(M, dtype=torch.float32, device=dev)
         self.adam_state = torch.zeros(M, 2 + 2 * (self.max_N + 8), dtype=torch.float32, device=dev)
         self.lm_state = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
@@ -215,7 +222,7 @@ class PairBatch:
     # ------------------------------------------------------------------------------------------------
     def cost_pass(self, level, mode, irls_eps=1e-3):
         _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, mode,
-                                          float(irls_eps), _lib.ptr(self.partials), _lib.stream_ptr()), "sp_pairs_cost")
+                                          float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.stream_ptr()), "sp_pairs_cost")
 
     def gn_step(self, level=0, irls_eps=1e-3, lm_up=8.0, lm_down=0.5, lm_min=1e-7, fused=False):
         """One Gauss-Newton/LM iteration of every pair at pyramid ``level``.  Returns the (M,) device tensor of costs
@@ -225,13 +232,13 @@ class PairBatch:
         solver's register/LDS footprint costs the cost kernel one wave per SIMD), kept for launch-bound hosts."""
         if fused:
             _lib.check(self.lib.sp_pairs_gn_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, self.M,
-                                                    self.max_N, float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.arrivals),
+                                                    self.max_N, float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(self.arrivals),
                                                     float(lm_up), float(lm_down), float(lm_min), _lib.ptr(self.lm_state),
                                                     _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.stream_ptr()),
                        "sp_pairs_gn_iterate")
             return self._costs
         self.cost_pass(level, 1, irls_eps)
-        _lib.check(self.lib.sp_pairs_gn_step(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials),
+        _lib.check(self.lib.sp_pairs_gn_step(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials), _lib.ptr(self.seg_partials),
                                              float(lm_up), float(lm_down), float(lm_min), _lib.ptr(self.lm_state),
                                              _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.stream_ptr()),
                    "sp_pairs_gn_step")
@@ -241,12 +248,12 @@ class PairBatch:
         """One Adam iteration (reset-tangent flavour of the reference's tracking/mapping loops) of every pair."""
         if fused:
             _lib.check(self.lib.sp_pairs_adam_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, self.M,
-                                                      self.max_N, _lib.ptr(self.partials), _lib.ptr(self.arrivals),
+                                                      self.max_N, _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(self.arrivals),
                                                       float(lr_kld), float(lr_pose), float(lr_aff), _lib.ptr(self.adam_state),
                                                       _lib.ptr(self._costs), _lib.stream_ptr()), "sp_pairs_adam_iterate")
             return self._costs
         self.cost_pass(level, 0)
-        _lib.check(self.lib.sp_pairs_adam_step(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials),
+        _lib.check(self.lib.sp_pairs_adam_step(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials), _lib.ptr(self.seg_partials),
                                                float(lr_kld), float(lr_pose), float(lr_aff), _lib.ptr(self.adam_state),
                                                _lib.ptr(self._costs), _lib.stream_ptr()), "sp_pairs_adam_step")
         return self._costs
@@ -254,10 +261,8 @@ class PairBatch:
     def evaluate(self, level=0):
         """Residual of every pair at the current parameters (no update): (M,) device tensor."""
         self.cost_pass(level, 0)
-        p = self.partials[: self.n_tiles * _lib.SP_GRAD_PARTIAL_FLOATS].reshape(self.n_tiles, _lib.SP_GRAD_PARTIAL_FLOATS)
-        per_tile = p[:, 0].double()
-        pair_of_tile = self.tiles[:, 0].long()
-        sums = torch.zeros(self.M, dtype=torch.float64, device=self.device).index_add_(0, pair_of_tile, per_tile)
+        p = self.partials[: self.n_spans * _lib.SP_GRAD_PARTIAL_FLOATS].reshape(self.n_spans, _lib.SP_GRAD_PARTIAL_FLOATS)
+        sums = torch.zeros(self.M, dtype=torch.float64, device=self.device).index_add_(0, self.span_pair, p[:, 0].double())
         P = torch.tensor(self.Ps, dtype=torch.float64, device=self.device)
         return (sums / (3.0 * P)).float()
 

@@ -22,35 +22,35 @@ def make_batch(pairs, **kw):
 
 
 def assemble_gn(batch, level=0, eps=1e-3):
-    """Host-side reduction of the mode-1 tile partials into per-pair dense (6+N) systems (float64)."""
+    """Host-side reduction of the mode-1 partials (span records + segment records) into per-pair dense (6+N) systems
+    (float64)."""
     from super_primitive_amd import _lib
     batch.cost_pass(level, 1, eps)
     torch.cuda.synchronize()
-    NV = _lib.SP_GN_PARTIAL_FLOATS
-    part = npy(batch.partials[: batch.n_tiles * NV]).reshape(-1, NV).astype(np.float64)
-    tiles = npy(batch.tiles)
+    NV, NS = _lib.SP_GN_PARTIAL_FLOATS, _lib.SP_GN_SEG_FLOATS
+    span = npy(batch.partials[: batch.n_spans * NV]).reshape(-1, NV).astype(np.float64)
+    span_pair = npy(batch.span_pair)
+    segp = npy(batch.seg_partials[: batch.n_seg_records * NS]).reshape(-1, NS).astype(np.float64)
+    seg_rec = npy(batch.seg_records)
     out = []
     iu = np.triu_indices(6)
     for m in range(batch.M):
         N = batch.Ns[m]
         H = np.zeros((6 + N, 6 + N))
         b = np.zeros(6 + N)
-        cost = 0.0
-        nv = 0.0
-        for t in np.nonzero(tiles[:, 0] == m)[0]:
-            seg = tiles[t, 1]
-            p = part[t]
-            Hpp = np.zeros((6, 6))
-            Hpp[iu] = p[1:22]
-            H[:6, :6] += Hpp + np.triu(Hpp, 1).T
-            b[:6] += p[22:28]
-            H[:6, 6 + seg] += p[28:34]
-            H[6 + seg, :6] += p[28:34]
-            H[6 + seg, 6 + seg] += p[34]
-            b[6 + seg] += p[35]
-            cost += p[0]
-            nv += p[36]
-        out.append(dict(H=H, b=b, cost=cost / (3.0 * batch.Ps[m]), n_valid=nv))
+        p = span[span_pair == m].sum(0)
+        Hpp = np.zeros((6, 6))
+        Hpp[iu] = p[1:22]
+        H[:6, :6] = Hpp + np.triu(Hpp, 1).T
+        b[:6] = p[22:28]
+        for r in np.nonzero(seg_rec[:, 0] == m)[0]:
+            seg = seg_rec[r, 1]
+            q = segp[r]
+            H[:6, 6 + seg] += q[0:6]
+            H[6 + seg, :6] += q[0:6]
+            H[6 + seg, 6 + seg] += q[6]
+            b[6 + seg] += q[7]
+        out.append(dict(H=H, b=b, cost=p[0] / (3.0 * batch.Ps[m]), n_valid=p[28]))
     return out
 
 
@@ -219,11 +219,12 @@ def test_full_size_residual_matches_oracle(full_size):
 def test_full_size_bitwise_determinism_and_descent(full_size):
     from super_primitive_amd import _lib
     pair, batch = full_size
-    n = batch.n_tiles * _lib.SP_GN_PARTIAL_FLOATS
+    n = batch.n_spans * _lib.SP_GN_PARTIAL_FLOATS
     batch.cost_pass(0, 1)
-    a = batch.partials[:n].clone()
+    a, sa = batch.partials[:n].clone(), batch.seg_partials.clone()
     batch.cost_pass(0, 1)
-    assert torch.equal(a, batch.partials[:n]), "two launches on the same inputs must be bitwise identical"
+    assert torch.equal(a, batch.partials[:n]) and torch.equal(sa, batch.seg_partials), \
+        "two launches on the same inputs must be bitwise identical"
     c0 = batch.evaluate(0).clone()
     batch.reset_lm()
     batch.run(6, mode="gn")
@@ -335,19 +336,18 @@ def test_results_do_not_depend_on_how_chunks_are_grouped_into_spans():
     short chunks exercise a flush in almost every trip, ragged blob segments the padding."""
     from super_primitive_amd import _lib, synth
     pairs = [synth.make_pair(72, 96, 7, seed=150 + k, init_sigma=0.01, shape="blobs" if k else "grid") for k in range(3)]
-    NV = _lib.SP_GN_PARTIAL_FLOATS
     want = None
     for span_points in (256, 2048, 1 << 20):
         batch = make_batch(pairs, levels=(0, 1), tile_points=512, span_points=span_points)
         systems = assemble_gn(batch)
         batch.cost_pass(0, 1, 1e-3)
-        seg_cols = batch.partials[: batch.n_tiles * NV].reshape(-1, NV)[:, 28:36].clone()
+        seg_cols = batch.seg_partials.clone()
         g = batch.evaluate(0).clone()
         if want is None:
             want = (systems, seg_cols, g)
             assert batch.n_spans == batch.n_chunks
             continue
-        assert batch.n_spans < batch.n_chunks and batch.n_chunks * 4 == batch.n_tiles
+        assert batch.n_spans < batch.n_chunks and batch.n_chunks * 4 == batch.n_seg_records
         assert torch.equal(seg_cols, want[1])
         np.testing.assert_allclose(npy(g), npy(want[2]), rtol=2e-6)
         for a, b in zip(systems, want[0]):

@@ -43,7 +43,7 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     """Argument validation happens before any HIP call, so it can be exercised here."""
     from super_primitive_amd import _lib
     lib = _lib.load()
-    assert lib.sp_pairs_cost(None, None, None, 0, 0, 0.0, None, None) == -1
+    assert lib.sp_pairs_cost(None, None, None, 0, 0, 0.0, None, None, None) == -1
     assert lib.sp_blur_decimate(None, 3, 10, 10, None, None) == -1
     assert lib.sp_renormalise_se3(None, 1, None) == -1
     with pytest.raises(RuntimeError, match="SP_EINVAL"):

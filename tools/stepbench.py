@@ -16,7 +16,7 @@ rows = []
 for _ in range(20):
     e = [E() for _ in range(3)]
     e[0].record(); batch.cost_pass(0, 1); e[1].record()
-    _lib.check(batch.lib.sp_pairs_gn_step(_lib.ptr(batch.desc[0]), batch.M, batch.max_N, _lib.ptr(batch.partials), 8.0, 0.5, 1e-7,
+    _lib.check(batch.lib.sp_pairs_gn_step(_lib.ptr(batch.desc[0]), batch.M, batch.max_N, _lib.ptr(batch.partials), _lib.ptr(batch.seg_partials), 8.0, 0.5, 1e-7,
                _lib.ptr(batch.lm_state), _lib.ptr(batch.backup), _lib.ptr(batch._costs), _lib.stream_ptr()), "gn"); e[2].record()
     rows.append(e)
 torch.cuda.synchronize()
@@ -26,7 +26,7 @@ rows = []
 for _ in range(20):
     e = [E() for _ in range(3)]
     e[0].record(); batch.cost_pass(0, 0); e[1].record()
-    _lib.check(batch.lib.sp_pairs_adam_step(_lib.ptr(batch.desc[0]), batch.M, batch.max_N, _lib.ptr(batch.partials), 1e-3, 1e-2, 5e-3,
+    _lib.check(batch.lib.sp_pairs_adam_step(_lib.ptr(batch.desc[0]), batch.M, batch.max_N, _lib.ptr(batch.partials), _lib.ptr(batch.seg_partials), 1e-3, 1e-2, 5e-3,
                _lib.ptr(batch.adam_state), _lib.ptr(batch._costs), _lib.stream_ptr()), "adam"); e[2].record()
     rows.append(e)
 torch.cuda.synchronize()
