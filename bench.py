@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed steps run for this long before the W warm-up steps, so the clocks of a box that was idle "
                          "have ramped to their steady state (DESIGN.md §6); 0 disables")
-    ap.add_argument("--pairs", type=int, default=96, help="frame pairs resident per GPU")
+    ap.add_argument("--pairs", type=int, default=384, help="frame pairs resident per GPU (4.8 GB of tables and images)")
     ap.add_argument("--segments", type=int, default=64, help="segments per source keyframe (BASELINE config 5 uses 128)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
     ap.add_argument("--tile-points", type=int, default=8192, help="longest chunk (piece of one segment)")

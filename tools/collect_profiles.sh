@@ -14,10 +14,10 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum
   tag=$(echo $grp | cut -d' ' -f1)
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pmc_$tag -o bench -- python bench.py --settle-ms 0 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
 done
-python tools/kbench.py --pairs 96 --tile-points 8192 --modes 1,0,1,0,10,11,12,13 --reps 40 2>/dev/null | grep level > $OUT/kbench_ablation.txt
+python tools/kbench.py --pairs 384 --tile-points 8192 --modes 1,0,1,0,10,11,12,13 --reps 40 2>/dev/null | grep level > $OUT/kbench_ablation.txt
 python tools/run_configs.py 2>/dev/null | grep config > $OUT/configs.txt
-# package power and shader clock, sampled once a second across a 16 s run of the bench step
-(python bench.py --steps 60000 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_long.json 2>/dev/null &)
+# package power and shader clock, sampled once a second across a 16 s run (16000 steps of 384 pairs) of the bench step
+(python bench.py --steps 16000 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_long.json 2>/dev/null &)
 for i in $(seq 1 24); do sleep 1; rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|Package Power" | sed "s/.*: //" | tr "\n" " "; echo; done > $OUT/power_clock_trace.txt
 wait
 ls $OUT

@@ -62,7 +62,7 @@ for a, b in [("bench_n1.json", "bench_n1.json"), ("bench_n1_adam.json", "bench_n
              ("configs.txt", "configs.txt")]:
     shutil.copy(f"{R}/{a}", f"{P}/{rnd}_{b}")
 with open(f"{P}/{rnd}_power_clock_trace.txt", "w") as f:
-    f.write("# sclk and socket package power (W), sampled once a second with rocm-smi across `python bench.py --steps 60000`\n"
+    f.write("# sclk and socket package power (W), sampled once a second with rocm-smi across `python bench.py --steps 16000`\n"
             "# (16 s of GN steps, idle before and after)\n")
     f.write(open(f"{R}/power_clock_trace.txt").read())
 print(f"hbm/alg = {hbm / alg:.4f}; " + "  ".join(f"{n} {mean(sq, n):.3g}" for n in names))
