@@ -207,16 +207,17 @@ __device__ __forceinline__ void segment_system(const float* __restrict__ p, cons
     constexpr int NV = SP_GN_SEG_FLOATS;
     double h[6] = {0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
     const int t0 = seg_tile_off[n], t1 = seg_tile_off[n + 1];
-    for (int t = t0; t < t1; t += 4) {          // four records in flight per trip, summed in record order
-        float v[4][8];
+    for (int t = t0; t < t1; t += 8) {          // eight records in flight per trip, summed in record order
+        float v[8][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float* q = p + (size_t)min(t + u, t1 - 1) * NV;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[u][i] = q[i];
+        for (int u = 0; u < 8; ++u) {
+            const float4* q = reinterpret_cast<const float4*>(p + (size_t)min(t + u, t1 - 1) * NV);     // 32-byte records
+            const float4 a = q[0], b = q[1];
+            v[u][0] = a.x; v[u][1] = a.y; v[u][2] = a.z; v[u][3] = a.w;
+            v[u][4] = b.x; v[u][5] = b.y; v[u][6] = b.z; v[u][7] = b.w;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             if (t + u < t1) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) h[i] += (double)v[u][i];
