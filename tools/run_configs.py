@@ -31,7 +31,9 @@ def sync_time(f, n=1):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 def rot_err(A, B):
-    return float(np.arccos(np.clip((np.trace(A[:3, :3] @ B[:3, :3].T) - 1) / 2, -1, 1)))
+    D = A[:3, :3].astype(np.float64) @ B[:3, :3].astype(np.float64).T
+    w = 0.5 * np.array([D[2, 1] - D[1, 2], D[0, 2] - D[2, 0], D[1, 0] - D[0, 1]])      # exact for small angles
+    return float(np.arctan2(np.linalg.norm(w), (np.trace(D) - 1) / 2))
 
 # ---- config 1 -------------------------------------------------------------------------------------------
 p = synth.make_pair(240, 320, 8, seed=1, init_sigma=0.01)
