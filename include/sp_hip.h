@@ -43,7 +43,8 @@ extern "C" {
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
 
-/* number of floats one tile writes in each mode (partials workspace = n_tiles * B * this) */
+/* floats per partial record: mode 0 -- one tile of sp_photo_cost_grad (workspace = n_tiles * B * 16) or one span of
+ * sp_pairs_cost; mode 1 -- one span of sp_pairs_cost */
 #define SP_GRAD_PARTIAL_FLOATS 16
 #define SP_GN_PARTIAL_FLOATS   32
 
