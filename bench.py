@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--span-points", type=int, default=None, help="points per workgroup (run of consecutive chunks); default: PairBatch's")
     ap.add_argument("--mode", choices=["gn", "adam"], default="gn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=16)
     ap.add_argument("--no-extras", action="store_true", help="skip the single-pair and full-schedule side measurements")
     return ap.parse_args()
 
