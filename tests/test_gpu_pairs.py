@@ -81,6 +81,46 @@ def test_gn_normal_equations_match_oracle_jacobian(shape, seed):
         assert np.abs(got[m]["b"][6:] - b[6:]).max() <= 3e-3 * np.abs(b[6:]).max()
 
 
+def test_spans_over_tiny_single_pixel_and_empty_segments():
+    """The padded tables and span loops on a VOID-like keyframe: 150 segments, some of one pixel (255 padding points per
+    real one), some empty (no chunk at all), most a few hundred pixels, so that one workgroup streams through dozens of
+    segments: residual and GN system against the oracle, empty segments untouched by an LM step."""
+    from oracle import gn_oracle, photometric_oracle as orc
+    from super_primitive_amd import synth
+    p = synth.make_pair(60, 88, 150, seed=12, shape="blobs")
+    m = p.keypoint_regions
+    m &= np.random.default_rng(5).uniform(size=m.shape) < 0.25          # thin the ellipses out: a few hundred pixels each
+    for n in range(150):
+        m[n, p.meta["kp_rc"][n, 0], p.meta["kp_rc"][n, 1]] = True
+    for n in range(0, 150, 7):
+        m[n] = False
+        m[n, p.meta["kp_rc"][n, 0], p.meta["kp_rc"][n, 1]] = True          # single pixel
+    empty = list(range(3, 150, 25))
+    for n in empty:
+        m[n] = False
+    p.logdepth_perseg[~m] = 0
+    batch = make_batch([p, p], levels=(0, 1), tile_points=512, span_points=16384)
+    assert batch.n_spans < batch.n_chunks / 8 and batch.Ppads[0] > 1.5 * batch.Ps[0]
+    got = assemble_gn(batch)
+    src, trg = orc.frames_from_synth(p)
+    want = gn_oracle.normal_equations(src, trg, torch.from_numpy(p.kld_init), torch.from_numpy(p.pose_init), eps=1e-3)
+    H, b = want["H"].numpy(), want["b"].numpy()
+    for g in got:
+        assert abs(g["n_valid"] - want["n_valid"]) <= 2
+        np.testing.assert_allclose(g["cost"], want["cost"], rtol=2e-5)
+        for sl, name in ((np.s_[:6, :6], "H_pp"), (np.s_[:6, 6:], "H_pd"), (np.s_[6:, 6:], "H_dd")):
+            assert np.abs(g["H"][sl] - H[sl]).max() <= 3e-3 * np.abs(H[sl]).max(), name
+        assert np.abs(g["b"] - b).max() <= 3e-3 * np.abs(b).max()
+        assert np.all(g["H"][6 + np.array(empty)] == 0) and np.all(g["b"][6 + np.array(empty)] == 0)
+    np.testing.assert_allclose(npy(batch.evaluate(0)), [want["cost"]] * 2, rtol=2e-5)
+    k0 = torch.cat(batch.klds()).clone()
+    for _ in range(3):
+        batch.gn_step(0)
+    k1 = torch.cat(batch.klds())
+    idx = torch.tensor(empty + [150 + e for e in empty], device=k1.device)
+    assert torch.equal(k1[idx], k0[idx]) and not torch.equal(k1, k0)
+
+
 def test_gn_converges_to_ground_truth():
     """Coarse-to-fine LM on rendered pairs: cost drops by > 10x, pose and keypoint depths reach the ground truth."""
     from super_primitive_amd import synth
