@@ -5,8 +5,8 @@ segments, a target frame, unknowns = relative pose (SE(3)) + one log-depth per s
 so M of them are packed into flat device arrays, described by one ``SpPair`` record each, and every optimiser
 iteration is exactly two launches for the WHOLE batch, with no host synchronisation:
 
-    sp_pairs_cost   (grid = all tiles of all pairs; fused cost + gradient | Gauss-Newton normal equations)
-    sp_pairs_*_step (grid = M; fixed-order tile reduction, Adam+SE(3) retraction | Schur-complement LM solve)
+    sp_pairs_cost   (grid = all spans of all pairs; fused cost + gradient | Gauss-Newton normal equations)
+    sp_pairs_*_step (grid = M; fixed-order reduction of the partial records, Adam+SE(3) retraction | Schur-complement LM solve)
 
 This is the configuration the HBM-roofline number is measured on: one 640x480x64 pair is ~10 MB of algorithmic
 traffic and lives in the 256 MB Infinity Cache, M >= 64 pairs stream from HBM.
