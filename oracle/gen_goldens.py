@@ -46,7 +46,10 @@ def import_reference():
     import tool.point_utils as rpu
     import frontend.segment.post_processer as rpp
     import odometery.kf_criteria as rkc
-    return types.SimpleNamespace(do=rdo, dob=rdob, dr=rdr, kf=rkf, la=rla, di=rdi, pu=rpu, pp=rpp, kc=rkc)
+    import image.gaussian_pyramid as rgp
+    import core.normal_cost as rnc
+    import tool.etc as retc
+    return types.SimpleNamespace(do=rdo, dob=rdob, dr=rdr, kf=rkf, la=rla, di=rdi, pu=rpu, pp=rpp, kc=rkc, gp=rgp, nc=rnc, etc=retc)
 
 
 sys.path.insert(0, ROOT)
@@ -478,6 +481,38 @@ def golden_kf_criteria(ref, name):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_helpers(ref, name):
+    """Thin helpers whose mirrors are plain tensor expressions: depth pyramid steps in every mode, the depth / intrinsics
+    pyramid modules' level selection, normal-channel rotation, host-conversion helpers."""
+    rng = np.random.default_rng(99)
+    depth = rng.uniform(0.5, 4.0, (2, 1, 9, 12)).astype(np.float32)
+    holes = depth.copy()
+    holes[rng.uniform(size=holes.shape) < 0.4] = np.nan
+    holes[0, 0, :2, :2] = np.nan
+    save = {"depth": depth, "holes": holes}
+    for mode in ("bilinear", "nearest_neighbor", "max", "min"):
+        save[f"pyr_{mode}"] = ref.gp.pyr_depth(T(depth), mode, 2).numpy()
+    save["pyr_masked_bilinear"] = ref.gp.pyr_depth(T(holes), "masked_bilinear", 2).numpy()
+    for (s0, e0) in ((0, 3), (1, 4), (2, 3), (0, 1)):
+        lv = ref.gp.DepthPyramidModule(s0, e0, "nearest_neighbor", "cpu")(T(np.tile(depth, (1, 1, 4, 4))))
+        save[f"dpyr_{s0}_{e0}_n"] = np.array(len(lv))
+        for i, l in enumerate(lv):
+            save[f"dpyr_{s0}_{e0}_{i}"] = l.numpy()
+        Ks = ref.gp.IntrinsicsPyramidModule(s0, e0, "cpu")(T(np.array([[500., 0, 320], [0, 510., 240], [0, 0, 1]], np.float32)), [1.0, 0.5])
+        save[f"kpyr_{s0}_{e0}"] = torch.stack(Ks).numpy()
+    px = rng.standard_normal((1, 7, 11)).astype(np.float32)
+    poses = np.stack([synth.se3_exp_np(0.3 * rng.standard_normal(6)) for _ in range(3)]).astype(np.float32)
+    save.update(px=px, poses=poses)
+    for mode, C in (("colour", 3), ("colour_norm", 6), ("colour_norm_kappa", 7)):
+        save[f"nrm_{mode}"] = ref.nc.transform_normals_batch(T(px[:, :C]), T(poses), mode).numpy()
+        save[f"nrm1_{mode}"] = ref.nc.transform_normals(T(px[:, :C]), T(poses[1]), mode).numpy()
+    img = rng.uniform(0, 1, (3, 5, 7)).astype(np.float32)
+    u8 = (rng.uniform(0, 255, (5, 7, 3))).astype(np.uint8)
+    save.update(img=img, u8=u8, to_img=ref.etc.to_img(T(img)), to_img_np=ref.etc.to_img_np(T(img)),
+                image_tt=ref.etc.image_tt(u8, device="cpu").numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
@@ -520,6 +555,7 @@ def main():
     golden_post_process(ref, "g10_post_process")
     golden_kf_criteria(ref, "g11_kf_criteria")
     golden_converged(ref, "g12_converged_sfm")
+    golden_helpers(ref, "g13_helpers")
     print("wrote", sorted(os.listdir(OUT)))
 
 

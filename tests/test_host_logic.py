@@ -213,3 +213,41 @@ def test_lazy_stats_dict_semantics():
     back = pickle.loads(pickle.dumps(e))
     assert type(back) is dict and set(back) == {"residual", "src_pts", "median_depth"} and calls == [1, 1]
     assert type(LazyStats(torch.tensor([1.0]), producer).copy()) is dict
+
+
+def test_thin_helpers_match_the_reference():
+    """Mirrors that are plain tensor expressions (depth pyramid steps, pyramid level selection, normal-channel rotation,
+    host conversions) against outputs of the real reference modules (golden g13)."""
+    import numpy as np
+    from conftest import load_golden
+    from super_primitive_amd.core import normal_cost
+    from super_primitive_amd.image import gaussian_pyramid as gp
+    from super_primitive_amd.tool import etc
+    g = load_golden("g13_helpers")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    for mode in ("bilinear", "nearest_neighbor", "max", "min"):
+        np.testing.assert_array_equal(gp.pyr_depth(T(g["depth"]), mode, 2).numpy(), g[f"pyr_{mode}"])
+    np.testing.assert_allclose(gp.pyr_depth(T(g["holes"]), "masked_bilinear", 2).numpy(), g["pyr_masked_bilinear"], rtol=1e-6)
+    with pytest.raises(ValueError):
+        gp.pyr_depth(T(g["depth"]), "cubic", 2)
+    big = T(np.tile(g["depth"], (1, 1, 4, 4)))
+    K = T(np.array([[500., 0, 320], [0, 510., 240], [0, 0, 1]], np.float32))
+    for (s0, e0) in ((0, 3), (1, 4), (2, 3), (0, 1)):
+        lv = gp.DepthPyramidModule(s0, e0, "nearest_neighbor", "cpu")(big)
+        assert len(lv) == int(g[f"dpyr_{s0}_{e0}_n"])
+        for i, l in enumerate(lv):
+            np.testing.assert_array_equal(l.numpy(), g[f"dpyr_{s0}_{e0}_{i}"])
+        Ks = torch.stack(gp.IntrinsicsPyramidModule(s0, e0, "cpu")(K, [1.0, 0.5]))
+        np.testing.assert_allclose(Ks.numpy(), g[f"kpyr_{s0}_{e0}"], rtol=1e-6)
+    for mode, C in (("colour", 3), ("colour_norm", 6), ("colour_norm_kappa", 7)):
+        got = normal_cost.transform_normals_batch(T(g["px"][:, :C]), T(g["poses"]), mode)
+        np.testing.assert_allclose(got.numpy(), g[f"nrm_{mode}"], rtol=1e-6, atol=1e-7)
+        got = normal_cost.transform_normals(T(g["px"][:, :C]), T(g["poses"][1]), mode)
+        np.testing.assert_allclose(got.numpy(), g[f"nrm1_{mode}"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_array_equal(etc.to_img(T(g["img"])), g["to_img"])
+    np.testing.assert_array_equal(etc.to_img_np(T(g["img"])), g["to_img_np"])
+    np.testing.assert_array_equal(etc.image_tt(g["u8"], device="cpu").numpy(), g["image_tt"])
+    arr = g["img"]
+    assert etc.to_np(arr) is arr and torch.equal(etc.from_np(arr), T(arr)) and etc.from_np(arr).data_ptr() != arr.ctypes.data
+    d = etc.dict_cpu({"a": T(g["img"]), "_sp": object(), "n": None})
+    assert set(d) == {"a", "n"} and d["n"] is None
