@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 3
+#define SP_ABI_VERSION 4
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -69,12 +69,13 @@ int sp_table_fill(const uint8_t* masks, const float* logdepth, const float* keyp
                   const int32_t* seg_off, const int32_t* row_off, uint32_t* pix, float* baseL, float* kp_L,
                   void* stream);
 
-/* Sample one source pyramid level at every table point and pack {rgb, L}; also (re)computes the source
- * validity bit of pix with the reference's formula (core/dense_optim.py:143-162 applied to the source
- * frame, :315-317).  img: planar (3,Hl,Wl) f32.  K: 9 floats row-major. */
+/* Sample one source pyramid level at every table point and pack {rgb, L}.  set_validity != 0: also compute the
+ * source validity bit of pix with the reference's formula (core/dense_optim.py:143-162 applied to the source
+ * frame, :315-317); it depends on the geometry grid only (not on the level), so it is set by the first sampling
+ * after the table is built and pix is read-only afterwards.  img: planar (3,Hl,Wl) f32.  K: 9 floats row-major. */
 int sp_table_sample_source(uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
                            const float* kld, int N, int P, int H, int W, const float* img, int Hl, int Wl,
-                           const float* K, float* src4, void* stream);
+                           const float* K, float* src4, int set_validity, void* stream);
 
 /* planar (B,3,H,W) f32 -> packed (B,H,W,3) f32 */
 int sp_pack_rgb(const float* chw, int B, int H, int W, float* hwc3, void* stream);
@@ -104,6 +105,19 @@ int sp_photo_cost_grad(const uint32_t* pix, const float* src4, const int32_t* se
                        const float* K_trg, const float* pose, int B, const float* aff_src, const float* aff_trg,
                        float zmin, float* workspace, float* residual, float* g_kld, float* g_pose, float* g_aff,
                        void* stream);
+
+/* The same cost for an EXPLICIT list of source points -- core/dense_optim.py:365-403 photomeric_cost_precomputed fed
+ * with a dict that did not come from this library's table (built by hand, filtered, or round-tripped through
+ * tool/etc.py dict_cpu / a queue / a checkpoint): xyz (n,3) = src_pts and rgb (n,3) = src_pixels^T of the points whose
+ * src_valid_mask is set (the caller compacts; invalid source points contribute exact zeros in the reference), 24 bytes
+ * per point (tracking variant).  P_total = the ORIGINAL number of points: the residual is a mean
+ * over 3 * P_total values (core/dense_optim.py:249-253).  No log-depth unknowns: outputs residual[B], g_pose[B*16],
+ * g_aff[B*4].  workspace: sp_points_workspace_floats(n_points, B) floats. */
+int sp_points_workspace_floats(int n_points, int B);
+int sp_points_cost_grad(const float* xyz, const float* rgb, int n_points, int P_total, int H, int W, const float* trg3,
+                        int Hl, int Wl, const float* K_trg, const float* pose, int B, const float* aff_src,
+                        const float* aff_trg, float zmin, float* workspace, float* residual, float* g_pose, float* g_aff,
+                        void* stream);
 
 /* Per-point diagnostics of the same pass (collect_stats > 0 in the reference, core/dense_optim.py:347-361).
  * Any output pointer may be NULL.  Only every stride-th table point is reported (stride 1 = the reference's
@@ -192,6 +206,66 @@ int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_
                         float irls_eps, float* span_partials, float* seg_partials, int32_t* arrivals, float lm_up, float lm_down,
                         float lm_min,
                         float* lm_state, float* backup, float* costs, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Fused SE(3)-Adam optimiser of the reference's driver loops (SURVEY.md section 8(b) "sp_adam_se3_step", 8(f) N1):
+ * torch.optim.Adam + lietorch retr()/matrix() + the pose bookkeeping around one cost evaluation, for
+ *   odometery/two_frame_sfm.py:116-123,150-207 (persistent tangent, pose = Exp(a) X, no update on the very first
+ *   iteration), odometery/odometery.py:300-312,375-407 (tracking: zero-reset tangent, T_supp <- T_supp inv(Exp(d))) and
+ *   odometery/odometery.py:576-648,756-915 (windowed mapping: several source keyframes, relative poses
+ *   D_trg inv(T_trg) T_src inv(D_src), first keyframe fixed, oldest keyframe's depths frozen when the window is full,
+ *   fold-in + renormalise_se3 + tangent reset every iteration, relative-loss early stop).
+ *
+ * The window is a graph.  NODES = poses; BLOCKS = per-keyframe log-depth vectors; EDGES = photometric terms
+ * (source keyframe -> target frame).  Edge e IS pair e of an SpPair array (one array per pyramid level, same kld / pose /
+ * aff pointers in all of them): SpPair.kld = its block's kld, SpPair.pose = a 16-float slot and SpPair.aff = a 4-float slot
+ * {a_src, b_src, a_trg, b_trg} that sp_window_compose / sp_window_step fill.  One iteration =
+ *     sp_pairs_cost(mode 0) over all edges  ->  sp_window_step                                   (3 launches, no host sync)
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct SpWindowNode {
+    float T[16];         /* kind 0: camera-to-world pose, updated in place by the fold-in; kind 1: the constant group element X */
+    float a[6];          /* tangent [tau, phi]: zero between iterations (kind 0) / the persistent parameter (kind 1) */
+    float m[6], v[6];    /* Adam moments of the tangent */
+    float aff[2];        /* affine brightness (a, b) of this frame */
+    float aff_m[2], aff_v[2];
+    float lr_pose;       /* 0 = pose not optimised (first keyframe, odometery.py:589-592; source-only frames) */
+    float lr_aff;        /* 0 = affine not optimised */
+    int32_t kind;        /* 0: edge pose = inv(T_trg) T_src evaluated at zero tangents, T <- T inv(Exp(d)) after every step;
+                            1: edge pose = Exp(a) X (two-frame SfM; such a node is only ever a target) */
+    int32_t flags;       /* bit 0: renormalise_se3 after every iteration (odometery.py:868,879) */
+} SpWindowNode;          /* 176 bytes */
+
+typedef struct SpWindowEdge {
+    int32_t src_node;    /* pose node of the source keyframe, -1 = identity (two-frame SfM) */
+    int32_t trg_node;
+    int32_t block;       /* log-depth block of the source keyframe */
+    float weight;        /* loss = sum_e weight_e * (abs_loss ? |residual_e| : residual_e) */
+} SpWindowEdge;
+
+typedef struct SpWindowBlock {
+    float* kld;          /* [N] -- the SpPair.kld of every edge whose source is this keyframe */
+    float* m;            /* [N] Adam moments */
+    float* v;
+    int32_t N;
+    float lr;            /* 0 = frozen (oldest keyframe of a full window, odometery.py:594-603; tracking) */
+} SpWindowBlock;         /* 32 bytes */
+
+/* doubles of scratch sp_window_step needs */
+int sp_window_scratch_doubles(int n_edges, int max_N);
+
+/* Write every edge's relative pose and affine slot from the current nodes (call once before the first cost pass). */
+int sp_window_compose(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes, void* stream);
+
+/* One optimiser step from the mode-0 partials of sp_pairs_cost over `pairs`.  abs_loss: 1 = sum_e w_e |residual_e|
+ * (two_frame_sfm.py:201-202), 0 = sum_e w_e residual_e (odometery.py:394,845-850).  skip_first: no parameter update on
+ * iteration 0 (two_frame_sfm.py:203).  rel_tol > 0: once |loss - previous loss| / previous loss < rel_tol the window
+ * freezes (later calls return without touching anything), like the break at odometery.py:907-915.
+ * state: 8 floats, zeroed by the caller {Adam step count, iterations done, previous loss, converged flag, last loss, ...};
+ * losses[max_losses]: loss of iteration i (evaluated BEFORE its update) at index i. */
+int sp_window_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes,
+                   const SpWindowBlock* blocks, int n_blocks, int max_N, const float* span_partials, const float* seg_partials,
+                   double* scratch, int abs_loss, int skip_first, float rel_tol, float* state, float* losses, int max_losses,
+                   void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Helpers around the path

@@ -428,6 +428,97 @@ def golden_traj_map(ref, name, steps=30):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def reference_mapping_loop(ref, kfs, kf_poses, kf_klds, kf_affs, supp, steps, lr_pose, window_size, affine, initialised):
+    """The windowed mapping loop of odometery/odometery.py:576-648 (parameter groups), :451-479 (neighbour connectivity),
+    :756-915 (iteration) restated around the REAL ``photomeric_cost_batch`` / ``renormalise_se3`` with ``opt_supporting``
+    on; lietorch's Exp is replaced by the oracle's (parity unpinned at that boundary).
+    kfs: reference KeyFrames; kf_poses: camera-to-world (4,4); supp[k] = list of (KeyFrame, pose, affine)."""
+    K = len(kfs)
+    eye6 = lambda: torch.zeros(1, 6)
+    kf_poses = [p.clone() for p in kf_poses]
+    d_kf = [None] + [torch.nn.Parameter(eye6()) for _ in range(K - 1)]                       # first keyframe fixed (:589-592)
+    if K == window_size:                                                                      # oldest depths frozen (:594-603)
+        klds = [kf_klds[0].clone()] + [torch.nn.Parameter(k.clone()) for k in kf_klds[1:]]
+    else:
+        klds = [torch.nn.Parameter(k.clone()) for k in kf_klds]
+    affs = [kf_affs[0].clone()] + [torch.nn.Parameter(a.clone()) for a in kf_affs[1:]] if affine else [None] * K
+    s_pose = [[p.clone() for _, p, _ in supp[k]] for k in range(K)]
+    s_delta = [[torch.nn.Parameter(eye6()) for _ in supp[k]] for k in range(K)]
+    s_aff = [[torch.nn.Parameter(a.clone()) for _, _, a in supp[k]] for k in range(K)] if affine else None
+    groups = [{"params": [k for k in klds if isinstance(k, torch.nn.Parameter)], "lr": 1e-2},
+              {"params": [d for d in d_kf if d is not None], "lr": lr_pose}]
+    if affine:
+        groups.append({"params": affs[1:], "lr": 1e-5})
+    groups.append({"params": [d for row in s_delta for d in row], "lr": lr_pose})
+    if affine:
+        groups.append({"params": [a for row in s_aff for a in row], "lr": 1e-5})
+    opt = torch.optim.Adam(groups, lr=1e-3)
+    mat = lambda d: torch.eye(4) if d is None else orc.se3_exp(d)[0]
+    conn = {s: [t for t in (s - 1, s + 1) if 0 <= t < K] for s in range(K)}
+    cfg = {"mode": "colour", "collect_stats": 0}
+    losses, prev, stopped = [], float("inf"), -1
+    for it in range(steps):
+        res = []
+        for s, trgs in conn.items():
+            src_delta = mat(d_kf[s])
+            imgs, Ks, Ps, As = [], [], [], []
+            for t in trgs:
+                imgs.append(kfs[t].image); Ks.append(kfs[t].K)
+                Ps.append(mat(d_kf[t]) @ torch.linalg.inv(kf_poses[t]) @ kf_poses[s] @ torch.linalg.inv(src_delta))
+                As.append(affs[t])
+            for ss in ([s] + ([s - 1] if s > 0 else [])):
+                for j, (f, _, _) in enumerate(supp[ss]):
+                    imgs.append(f.image); Ks.append(f.K)
+                    Ps.append(mat(s_delta[ss][j]) @ torch.linalg.inv(s_pose[ss][j]) @ kf_poses[s] @ torch.linalg.inv(src_delta))
+                    As.append(s_aff[ss][j] if affine else None)
+            out = ref.dob.photomeric_cost_batch(kfs[s], torch.stack(imgs), torch.stack(Ks), klds[s], poses=torch.stack(Ps),
+                                                affine_comp=(affs[s], torch.stack(As)) if affine else None, cost_config=cfg)
+            res.append(out["residual"].mean())
+        loss = torch.sum(torch.stack(res))
+        losses.append(float(loss.detach()))
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        with torch.no_grad():
+            for i in range(K):
+                kf_poses[i] = ref.la.renormalise_se3(kf_poses[i] @ torch.linalg.inv(mat(d_kf[i])))
+                if d_kf[i] is not None:
+                    d_kf[i].data.zero_()
+            for k in range(K):
+                for j in range(len(s_pose[k])):
+                    s_pose[k][j] = ref.la.renormalise_se3(s_pose[k][j] @ torch.linalg.inv(mat(s_delta[k][j])))
+                    s_delta[k][j].data.zero_()
+        if initialised:
+            if abs(losses[-1] - prev) / prev < 1e-8:
+                stopped = it
+                break
+            prev = losses[-1]
+    det = lambda x: x.detach().clone()
+    return dict(losses=np.array(losses), stopped=np.array(stopped), kf_poses=torch.stack(kf_poses).numpy(),
+                klds=torch.stack([det(k) for k in klds]).numpy(),
+                affs=torch.stack([det(a) for a in affs]).numpy() if affine else np.zeros((K, 2), np.float32),
+                supp_poses=torch.stack([p for row in s_pose for p in row]).numpy(),
+                supp_affs=torch.stack([det(a) for row in s_aff for a in row]).numpy() if affine else np.zeros((0, 2), np.float32))
+
+
+def golden_traj_window(ref, name, steps=30):
+    """G9-d: multi-source windowed mapping.  Case 'full': 3 keyframes = window size (oldest depths frozen, first pose fixed),
+    map-mode learning rates, early stop armed.  Case 'init': 2 keyframes, window not full, mono-init pose rate 1e-2."""
+    save = {}
+    for tag, (n_kf, lr_pose, window, initialised, seed) in {"full": (3, 1e-4, 3, True, 35), "init": (2, 1e-2, 5, False, 36)}.items():
+        frames, est, klds, affs = synth.window_inputs(seed, n_kf)
+        kfs = [ref.kf.KeyFrame(T(f.image), T(f.K), T(f.logdepth_perseg), T(f.keypoints), torch.from_numpy(f.keypoint_regions.copy()))
+               for f in frames[0::2]]
+        supp = [[(ref.kf.KeyFrame(T(frames[2 * k + 1].image), T(frames[2 * k + 1].K)), T(est[2 * k + 1]), T(affs[2 * k + 1]))]
+                for k in range(n_kf)]
+        out = reference_mapping_loop(ref, kfs, [T(est[2 * k]) for k in range(n_kf)], [T(k) for k in klds],
+                                     [T(affs[2 * k]) for k in range(n_kf)], supp, steps, lr_pose, window, True, initialised)
+        save.update({f"{tag}_{k}": v for k, v in out.items()})
+        save.update({f"{tag}_cfg": np.array([n_kf, window, int(initialised), seed, steps]), f"{tag}_lr_pose": np.array(lr_pose),
+                     f"{tag}_in_poses": np.stack(est), f"{tag}_in_klds": np.stack(klds), f"{tag}_in_affs": affs})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def golden_post_process(ref, name):
     """N2: depth_discontinuity, mask_by_depth_discontinuity, connected_components_batch and
     kf_fix_disconnected_regions (torch seed 123 for the re-seeded keypoints) on keyframes with depth steps."""
@@ -518,6 +609,10 @@ def main():
     torch.set_num_threads(4)
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
+    if len(sys.argv) > 1:                      # regenerate selected fixtures only: python oracle/gen_goldens.py g9d_traj_window
+        for name in sys.argv[1:]:
+            {"g9d_traj_window": golden_traj_window}[name](ref, name)
+        return
 
     p = synth.make_pair(48, 64, 6, seed=1)
     golden_cost(ref, "g1_grid_48x64", p, p.pose_init)
@@ -556,6 +651,7 @@ def main():
     golden_kf_criteria(ref, "g11_kf_criteria")
     golden_converged(ref, "g12_converged_sfm")
     golden_helpers(ref, "g13_helpers")
+    golden_traj_window(ref, "g9d_traj_window")
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -71,7 +71,7 @@ def frames_from_synth(pair, dtype=torch.float32):
 # ----------------------------------------------------------------------------
 def to_unit_range(px, dims):
     """pixel -> [-1,1] with the align-corners convention 2x/(d-1)-1."""
-    scale = 1.0 / (torch.as_tensor(dims, dtype=torch.float32, device=px.device) - 1)
+    scale = 1.0 / (torch.as_tensor(dims, dtype=px.dtype if px.dtype == torch.float64 else torch.float32, device=px.device) - 1)
     return 2 * px * scale - 1
 
 

@@ -22,16 +22,21 @@ SIGNATURES = {
     "sp_abi_version": [],
     "sp_mask_count": [P, I, I, I, P, P, P, P],
     "sp_table_fill": [P, P, P, I, I, I, P, P, P, P, P, P],
-    "sp_table_sample_source": [P, P, P, P, P, I, I, I, I, P, I, I, P, P, P],
+    "sp_table_sample_source": [P, P, P, P, P, I, I, I, I, P, I, I, P, P, I, P],
     "sp_pack_rgb": [P, I, I, I, P, P],
     "sp_blur_decimate": [P, I, I, I, P, P],
     "sp_photo_cost_grad": [P, P, P, P, P, P, I, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P],
+    "sp_points_workspace_floats": [I, I],
+    "sp_points_cost_grad": [P, P, I, I, I, I, P, I, I, P, P, I, P, P, F, P, P, P, P, P],
     "sp_photo_stats": [P, P, P, P, I, I, I, I, P, P, P, I, I, P, P, I, P, P, F, P, P, P, P, P, P, P, P, I, P],
     "sp_pairs_cost": [P, P, P, I, I, F, P, P, P],
     "sp_pairs_adam_step": [P, I, I, P, P, F, F, F, P, P, P],
     "sp_pairs_gn_step": [P, I, I, P, P, F, F, F, P, P, P, P],
     "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, P, F, F, F, P, P, P],
     "sp_pairs_gn_iterate": [P, P, P, I, I, I, F, P, P, P, F, F, F, P, P, P, P],
+    "sp_window_scratch_doubles": [I, I],
+    "sp_window_compose": [P, P, I, P, I, P],
+    "sp_window_step": [P, P, I, P, I, P, I, I, P, P, P, I, I, F, P, P, I, P],
     "sp_depth_expand": [P, P, P, P, I, I, I, I, P, P],
     "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_segment_reinit": [P, P, P, P, I, I, I, I, P, I, P, P, P, P],
@@ -46,7 +51,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 3
+SP_ABI_VERSION = 4
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GRAD_SEG_FLOATS = 1
@@ -63,6 +68,21 @@ class SpPair(ctypes.Structure):
         ("N", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("Hl", c_int), ("Wl", c_int),
         ("tile0", c_int), ("n_tiles", c_int), ("zmin", c_float), ("rec0", c_int),
     ]
+
+
+class SpWindowNode(ctypes.Structure):
+    """Mirror of ``struct SpWindowNode`` (include/sp_hip.h); 176 bytes."""
+    _fields_ = [("T", c_float * 16), ("a", c_float * 6), ("m", c_float * 6), ("v", c_float * 6), ("aff", c_float * 2),
+                ("aff_m", c_float * 2), ("aff_v", c_float * 2), ("lr_pose", c_float), ("lr_aff", c_float),
+                ("kind", c_int), ("flags", c_int)]
+
+
+class SpWindowEdge(ctypes.Structure):
+    _fields_ = [("src_node", c_int), ("trg_node", c_int), ("block", c_int), ("weight", c_float)]
+
+
+class SpWindowBlock(ctypes.Structure):
+    _fields_ = [("kld", c_void_p), ("m", c_void_p), ("v", c_void_p), ("N", c_int), ("lr", c_float)]
 
 
 _lib = None
@@ -109,8 +129,24 @@ def stream_ptr():
 
 
 def require_device(*tensors):
-    """The hot path runs on the GPU only; refuse host tensors instead of silently computing elsewhere."""
+    """The hot path runs on the GPU only; refuse host tensors instead of silently computing elsewhere.
+
+    The raw launches go to the CURRENT device's current stream with bare pointers, so -- unlike ATen ops, which
+    switch device under the hood -- operands on different devices, or on a device that is not the current one,
+    would fault or silently rely on peer access: both are refused here."""
+    import torch
+    dev = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("super_primitive_amd: the photometric hot path is HIP-only; got a CPU tensor. "
                                "Move the keyframe to a cuda device (no CPU fallback exists).")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"super_primitive_amd: operands on different devices ({dev} and {t.device})")
+    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"super_primitive_amd: operands live on {dev} but the current device is "
+                           f"cuda:{torch.cuda.current_device()}; wrap the call in `with torch.cuda.device({dev.index}):` "
+                           "(one process per GPU is the supported layout)")

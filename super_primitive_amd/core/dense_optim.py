@@ -19,6 +19,7 @@ import os
 import torch
 
 from .. import _lib
+from .. import segment_table
 from ..segment_table import packed_target, table_of
 from ..tool import point_utils
 from .cost_utils import split_by_mode
@@ -269,32 +270,105 @@ def _keypoint_stats(src_kf, trg_kf, kld, pose):
 
 
 def unproject_kf(kf, keypoint_logdepth, jacobian=False):
-    """Source points / colours / validity of a keyframe (core/dense_optim.py:176-200); feeds the tracking loop."""
+    """Source points / colours / validity of a keyframe (core/dense_optim.py:176-200); feeds the tracking loop.
+    The returned dict is exactly the reference's: plain tensors, nothing hidden -- it may be filtered, sent through
+    ``dict_cpu`` / a queue / a checkpoint and handed back to ``photomeric_cost_precomputed``."""
     _lib.require_device(kf.image, keypoint_logdepth)
     table = table_of(kf)
     src4 = table.source_level(kf.image, kf.K, keypoint_logdepth)
     st = _run_stats(table, src4, keypoint_logdepth, _f32c(kf.K), None, None, None, None, Z_MIN_SINGLE, want_target=False)
     return {'src_pixels': st['src_rgb'], 'src_valid_mask': st['src_valid'], 'src_pts': st['src_pts'],
-            'segm_ids': st['seg_ids'], 'spatial_size': kf.geo_spatial_dim(),
-            # handle for photomeric_cost_precomputed: the table regenerates src_pts from (pix, L, kld) bit-identically
-            '_sp': (table, src4, _f32c(keypoint_logdepth).clone(), _f32c(kf.K))}
+            'segm_ids': st['seg_ids'], 'spatial_size': kf.geo_spatial_dim()}
+
+
+class _PointList:
+    """Compact 24 B/point form of a precomputed dict: xyz (n,3) and rgb (n,3) of the points whose ``src_valid_mask``
+    is set (an invalid source point contributes exact zeros in the reference, core/dense_optim.py:389-396), plus the
+    original point count -- the residual stays a mean over 3 * P_total values."""
+
+    def __init__(self, pre):
+        pts, rgb, ok = pre['src_pts'], pre['src_pixels'], pre['src_valid_mask']
+        _lib.require_device(pts, rgb, ok)
+        self.P_total = int(pts.shape[0])
+        assert rgb.shape[-1] == self.P_total and ok.shape[-1] == self.P_total
+        keep = ok.reshape(-1).bool().nonzero().reshape(-1)          # the one host sync of the conversion (sizes the list)
+        self.xyz = pts.detach().float()[keep].contiguous()
+        self.rgb = rgb.detach().float().reshape(-1, self.P_total)[:3].t()[keep].contiguous()
+        self.n = int(keep.numel())
+        self.H, self.W = (int(v) for v in pre['spatial_size'])
+        self._key = tuple(segment_table._Ident(t) for t in (pts, rgb, ok))
+
+    def matches(self, pre):
+        return segment_table._same(self._key, (pre['src_pts'], pre['src_pixels'], pre['src_valid_mask']))
+
+
+_point_lists = []          # most recent last; entries hold strong references to the dict's tensors (identity keys)
+
+
+def _point_list_of(pre):
+    for pl in reversed(_point_lists):
+        if pl.matches(pre):
+            return pl
+    pl = _PointList(pre)
+    if len(_point_lists) >= 8:
+        del _point_lists[0]
+    _point_lists.append(pl)
+    return pl
+
+
+class _FusedPointCost(torch.autograd.Function):
+    """residual (1,) = f(pose (1,4,4), aff_src (2)|None, aff_trg (1,2)|None) over an explicit point list."""
+
+    @staticmethod
+    def forward(ctx, poses, aff_src, aff_trg, pl, trg4, K_trg, zmin):
+        lib = _lib.load()
+        B, dev = poses.shape[0], poses.device
+        Hl, Wl = trg4.shape[1], trg4.shape[2]
+        has_aff = aff_src is not None
+        a_s = aff_src.detach().contiguous().float() if has_aff else None
+        a_t = aff_trg.detach().reshape(B, 2).contiguous().float() if has_aff else None
+        residual = torch.zeros(B, dtype=torch.float32, device=dev)
+        g_pose = torch.zeros(B, 4, 4, dtype=torch.float32, device=dev)
+        g_aff = torch.zeros(B, 4, dtype=torch.float32, device=dev)
+        if pl.n > 0:                     # (no valid source point at all: residual 0, like the reference's masked mean)
+            work = torch.empty(lib.sp_points_workspace_floats(pl.n, B), dtype=torch.float32, device=dev)
+            rc = lib.sp_points_cost_grad(_lib.ptr(pl.xyz), _lib.ptr(pl.rgb), pl.n, pl.P_total, pl.H, pl.W, _lib.ptr(trg4), Hl, Wl,
+                                         _lib.ptr(K_trg), _lib.ptr(poses.detach().contiguous().float()), B, _lib.ptr(a_s),
+                                         _lib.ptr(a_t), float(zmin), _lib.ptr(work), _lib.ptr(residual), _lib.ptr(g_pose),
+                                         _lib.ptr(g_aff), _lib.stream_ptr())
+            _lib.check(rc, "sp_points_cost_grad")
+        ctx.save_for_backward(g_pose, g_aff)
+        ctx.has_aff = has_aff
+        ctx.aff_trg_shape = None if not has_aff else tuple(aff_trg.shape)
+        return residual
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        g_pose, g_aff = ctx.saved_tensors
+        w = grad_out.reshape(-1)
+        d_as = d_at = None
+        if ctx.has_aff:
+            d_as = (w[:, None] * g_aff[:, :2]).sum(0)
+            d_at = (w[:, None] * g_aff[:, 2:]).reshape(ctx.aff_trg_shape)
+        return w[:, None, None] * g_pose, d_as, d_at, None, None, None, None
 
 
 def photomeric_cost_precomputed(src_precomputed, trg_keyframe, pose, cost_config, affine_comp=None):
-    """Tracking variant: source side fixed, gradient to pose and affine only (core/dense_optim.py:365-403)."""
+    """Tracking variant: source side fixed, gradient to pose and affine only (core/dense_optim.py:365-403).
+
+    ``src_precomputed`` is any reference-shaped dict ``{src_pts (P,3), src_pixels (1,3,P), src_valid_mask (1,P),
+    segm_ids, spatial_size}`` -- the one ``unproject_kf`` returns, a hand-built or filtered one, or one that went
+    through ``dict_cpu`` and back to the device.  Its points are compacted ONCE per dict (identity-cached) into a
+    24 B/point list; every call is then one fused cost + gradient launch over that list."""
     _check_mode(cost_config)
-    handle = src_precomputed.get('_sp')
-    if handle is None:
-        raise RuntimeError("photomeric_cost_precomputed needs the dict returned by this package's unproject_kf "
-                           "(it carries the segment table handle)")
-    table, src4, kld, K_src = handle
-    _lib.require_device(trg_keyframe.image, pose)
+    pl = _point_list_of(src_precomputed)
+    _lib.require_device(trg_keyframe.image, pose, pl.xyz)
     trg4 = packed_target(trg_keyframe.image)
     K_trg = _f32c(trg_keyframe.K)[None].contiguous()
     aff_s = aff_t = None
     if affine_comp is not None:
         aff_s, aff_t = affine_comp
-    residual = _FusedPhotoCost.apply(kld, pose[None], aff_s, aff_t, table, src4, trg4, K_src, K_trg, Z_MIN_SINGLE)
+    residual = _FusedPointCost.apply(pose[None], aff_s, aff_t, pl, trg4, K_trg, Z_MIN_SINGLE)
     return {'residual': residual}
 
 

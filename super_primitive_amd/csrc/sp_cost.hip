@@ -65,9 +65,13 @@ __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, uint32_t off) {
 }
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 // rgb of one packed HWC3 texel (12 bytes, dword aligned)
+template <int AUX = 0>
 __device__ __forceinline__ f32x3 buf_load3(rsrc_t r, uint32_t off) {
-    return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, 0, 0));
+    return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, 0, AUX));
 }
+
+__device__ __forceinline__ void prepare_xyz(const TileCtx& c, float x, float y, float d, bool src_ok, float sr, float sg,
+                                            float sb, Pending& p);
 
 __device__ __forceinline__ void prepare(const TileCtx& c, float shift, float ifx, float ify, uint32_t pw, const f32x4 s, Pending& p) {
     float col, row; bool src_ok;
@@ -75,6 +79,13 @@ __device__ __forceinline__ void prepare(const TileCtx& c, float shift, float ifx
     const float d = fast_exp(s.w + shift);
     float x, y;
     backproject(col, row, d, c.Ks, ifx, ify, x, y);
+    prepare_xyz(c, x, y, d, src_ok, s.x, s.y, s.z, p);
+}
+
+// from the source-camera point on: SE(3), projection, validity, tap offsets (shared with the explicit-point tiles of
+// sp_points_cost_grad, whose points come straight from a precomputed dict)
+__device__ __forceinline__ void prepare_xyz(const TileCtx& c, float x, float y, float d, bool src_ok, float sr, float sg,
+                                            float sb, Pending& p) {
     PointGeom g;
     warp_point(c.w, x, y, d, g);
     const bool ok = g.valid && src_ok && (d > 1e-7f);
@@ -83,7 +94,7 @@ __device__ __forceinline__ void prepare(const TileCtx& c, float shift, float ifx
     p.g.qx = g.qx; p.g.qy = g.qy; p.g.qz = g.qz;
     p.g.zinv = ok ? g.zinv : 0.f;
     p.g.zi = (ok && g.zguard) ? g.zinv : 0.f;
-    p.sr = s.x; p.sg = s.y; p.sb = s.z;
+    p.sr = sr; p.sg = sg; p.sb = sb;
     const float ix = ok ? g.ix : 0.f, iy = ok ? g.iy : 0.f;
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     p.wx = ix - fx0;
@@ -154,24 +165,46 @@ __device__ __forceinline__ void fold_grad(const TileCtx& c, const Geo& g, const 
 
 // One tile = one run of points of ONE segment (the single-pair path: sp_photo_cost_grad over the keyframe's own,
 // unpadded segment table).  Gradient mode only; the many-pairs path uses the span loops further down.
+// PTS = true: the run is a slice of an explicit point list (xyz 12 B + rgb 12 B per point, sp_points_cost_grad) and
+// c.pix / c.src4 carry the xyz / rgb base pointers; a lane past the end reads zeros, i.e. depth 0 = invalid.
+template <bool PTS>
 __device__ __forceinline__ void run_tile(const TileCtx& c, float* __restrict__ out, float* lds) {
     constexpr int NV = SP_GRAD_PARTIAL_FLOATS;
     float acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.f;
     const float ifx = 1.f / c.Ks.fx, ify = 1.f / c.Ks.fy;
-    const rsrc_t r_pix = make_rsrc(c.pix + c.start, (uint32_t)c.count * 4u);
-    const rsrc_t r_src = make_rsrc(c.src4 + c.start, (uint32_t)c.count * 16u);
+    const rsrc_t r_pix = PTS ? make_rsrc((gptr_f32)c.pix + 3 * (size_t)c.start, (uint32_t)c.count * 12u)
+                             : make_rsrc(c.pix + c.start, (uint32_t)c.count * 4u);
+    const rsrc_t r_src = PTS ? make_rsrc((gptr_f32)c.src4 + 3 * (size_t)c.start, (uint32_t)c.count * 12u)
+                             : make_rsrc(c.src4 + c.start, (uint32_t)c.count * 16u);
     const rsrc_t r_trg = make_rsrc(c.trg, (uint32_t)c.Wl * (uint32_t)c.Hl * (4u * SP_TEXEL_FLOATS));
     const int n_iter = (c.count + SP_BLOCK - 1) / SP_BLOCK;
     uint32_t i = threadIdx.x;
     constexpr int NT = 2;   // aux: non-temporal
+    // the stream of one point: {pix word, src4} or {xyz, rgb}
+    auto fetch = [&](uint32_t idx, uint32_t& pw, f32x4& s, f32x3& xyz) {
+        if (PTS) {
+            xyz = buf_load3<NT>(r_pix, idx * 12u);
+            const f32x3 rgb = buf_load3<NT>(r_src, idx * 12u);
+            s = f32x4{rgb.x, rgb.y, rgb.z, 0.f};
+            pw = 0u;
+        } else {
+            pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)(idx * 4u), 0, NT);
+            s = buf_load4<NT>(r_src, idx * 16u);
+            xyz = f32x3{0.f, 0.f, 0.f};
+        }
+    };
+    auto prep = [&](uint32_t pw, const f32x4& s, const f32x3& xyz, Pending& p) {
+        if (PTS) prepare_xyz(c, xyz.x, xyz.y, xyz.z, true, s.x, s.y, s.z, p);
+        else prepare(c, c.shift, ifx, ify, pw, s, p);
+    };
     // prologue: geometry of point 0
     Pending nx;
     {
-        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)(i * 4u), 0, NT);
-        const f32x4 s = buf_load4<NT>(r_src, i * 16u);
-        prepare(c, c.shift, ifx, ify, pw, s, nx);
+        uint32_t pw; f32x4 s; f32x3 xyz;
+        fetch(i, pw, s, xyz);
+        prep(pw, s, xyz, nx);
     }
     Geo cur = nx.g;
     cur.zinv = 0.f; cur.zi = 0.f;      // "point -1": contributes exact zeros
@@ -179,8 +212,8 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float* __restrict__ o
     for (int j = 0; j < n_iter; ++j) {
         // ---- top: issue everything this trip will need -------------------------------------------
         i += SP_BLOCK;
-        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)(i * 4u), 0, NT);
-        const f32x4 s = buf_load4<NT>(r_src, i * 16u);
+        uint32_t pw; f32x4 s; f32x3 xyz;
+        fetch(i, pw, s, xyz);
         f32x3 ta = buf_load3(r_trg, nx.off0);
         f32x3 tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
         f32x3 tc = buf_load3(r_trg, nx.off1);
@@ -201,8 +234,9 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float* __restrict__ o
         cur = nx.g;
         uint32_t pw_ = pw;
         f32x4 s_ = s;
-        asm volatile("" : "+v"(pw_), "+v"(s_));
-        prepare(c, c.shift, ifx, ify, pw_, s_, nx);
+        f32x3 xyz_ = xyz;
+        asm volatile("" : "+v"(pw_), "+v"(s_), "+v"(xyz_));
+        prep(pw_, s_, xyz_, nx);
     }
     fold_grad(c, cur, m0, acc);
     const float total = block_sum_to_thread<NV>(acc, lds);
@@ -644,7 +678,42 @@ __global__ __launch_bounds__(SP_BLOCK) void k_cost_single_grad(SingleArgs a, flo
         c.bias = a.aff_trg[2 * b + 1] - a.aff_src[1];
     }
     c.start = tile.z; c.count = tile.w;
-    run_tile(c, partials + ((size_t)b * a.n_tiles + t) * SP_GRAD_PARTIAL_FLOATS, lds);
+    run_tile<false>(c, partials + ((size_t)b * a.n_tiles + t) * SP_GRAD_PARTIAL_FLOATS, lds);
+}
+
+// ------------------------------------------------------------------------------------------------
+// explicit source points (a precomputed dict that did not come from this library's table), B targets:
+// grid = (ceil(n / SP_POINT_TILE), B).  24 B per point: xyz + rgb; invalid source points were dropped when the list
+// was built, P_total (the reference's denominator, core/dense_optim.py:249-253) is passed separately.
+// ------------------------------------------------------------------------------------------------
+#define SP_POINT_TILE 2048
+struct PointsArgs {
+    const float* xyz; const float* rgb; const float* trg; const float* K_trg; const float* pose;
+    const float* aff_src; const float* aff_trg;
+    int n_points, n_tiles, H, W, Hl, Wl;
+    float zmin;
+};
+
+__global__ __launch_bounds__(SP_BLOCK) void k_cost_points_grad(PointsArgs a, float* __restrict__ partials) {
+    __shared__ float lds[SP_WAVES * SP_GRAD_PARTIAL_FLOATS];
+    const int t = xcd_chunked_tile(blockIdx.x, a.n_tiles);
+    if (t >= a.n_tiles) return;
+    const int b = blockIdx.y;
+    TileCtx c;
+    c.pix = (gptr_u32)a.xyz; c.src4 = (gptr_f4)a.rgb;
+    c.trg = (gptr_f32)(a.trg + (size_t)b * a.Hl * a.Wl * SP_TEXEL_FLOATS);
+    c.Ks = Cam{1.f, 1.f, 0.f, 0.f};
+    Cam Kt; load_cam(a.K_trg + 9 * b, Kt);
+    fill_warp(c, a.pose + 16 * b, Kt, a.H, a.W, a.Hl, a.Wl, a.zmin);
+    c.shift = 0.f;
+    c.gain = 1.f; c.bias = 0.f;
+    if (a.aff_src) {
+        c.gain = expf(-(a.aff_trg[2 * b] - a.aff_src[0]));
+        c.bias = a.aff_trg[2 * b + 1] - a.aff_src[1];
+    }
+    c.start = t * SP_POINT_TILE;
+    c.count = min(SP_POINT_TILE, a.n_points - c.start);
+    run_tile<true>(c, partials + ((size_t)b * a.n_tiles + t) * SP_GRAD_PARTIAL_FLOATS, lds);
 }
 
 // Fixed-order fp64 combination of the tile partials of one target b.
@@ -673,7 +742,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_finalise_single(const float* __res
         }
     }
     if (threadIdx.x < 4) g_pose[b * 16 + 12 + threadIdx.x] = 0.f;
-    for (int n = threadIdx.x; n < N; n += SP_BLOCK) {
+    for (int n = threadIdx.x; n < N; n += SP_BLOCK) {      // (N = 0 for explicit point lists: no log-depth unknowns)
         double s = 0.0;
         for (int t = seg_tile_off[n]; t < seg_tile_off[n + 1]; ++t) s += (double)p[(size_t)t * SP_GRAD_PARTIAL_FLOATS + 13];
         g_kld[(size_t)b * N + n] = (float)(s * scale);
@@ -839,6 +908,31 @@ int sp_photo_cost_grad(const uint32_t* pix, const float* src4, const int32_t* se
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_finalise_single, dim3(B), dim3(SP_BLOCK), 0, s, workspace, seg_tile_off, n_tiles, N, P,
                        aff_src != nullptr, residual, g_kld, g_pose, g_aff);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_points_workspace_floats(int n_points, int B) {
+    if (n_points <= 0 || B <= 0) return 0;
+    return ((n_points + SP_POINT_TILE - 1) / SP_POINT_TILE) * B * SP_GRAD_PARTIAL_FLOATS;
+}
+
+int sp_points_cost_grad(const float* xyz, const float* rgb, int n_points, int P_total, int H, int W, const float* trg3,
+                        int Hl, int Wl, const float* K_trg, const float* pose, int B, const float* aff_src,
+                        const float* aff_trg, float zmin, float* workspace, float* residual, float* g_pose, float* g_aff,
+                        void* stream) {
+    if (!xyz || !rgb || !trg3 || !K_trg || !pose || !workspace || !residual || !g_pose || !g_aff) return SP_EINVAL;
+    if (n_points <= 0 || P_total < n_points || B <= 0 || H < 2 || W < 2 || Hl < 1 || Wl < 1) return SP_EINVAL;
+    if ((aff_src == nullptr) != (aff_trg == nullptr)) return SP_EINVAL;
+    if (B > 65535 || (size_t)n_points * 12u > 0xffffffffu) return SP_ELIMIT;
+    const int n_tiles = (n_points + SP_POINT_TILE - 1) / SP_POINT_TILE;
+    PointsArgs a{xyz, rgb, trg3, K_trg, pose, aff_src, aff_trg, n_points, n_tiles, H, W, Hl, Wl, zmin};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int gx = ((n_tiles + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_cost_points_grad, dim3(gx, B), dim3(SP_BLOCK), 0, s, a, workspace);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_finalise_single, dim3(B), dim3(SP_BLOCK), 0, s, workspace, (const int32_t*)nullptr, n_tiles, 0,
+                       P_total, aff_src != nullptr, residual, (float*)nullptr, g_pose, g_aff);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -18,26 +18,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
 }
 
 
-// lie/lie_algebra.py:41-119: R -> best-conditioned quaternion -> R, in place, one thread per matrix
+// lie/lie_algebra.py:41-119, one thread per matrix (body: renormalise_rotation in sp_solve_device.h)
 __global__ void k_renormalise(float* __restrict__ T, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float* M = T + 16 * (size_t)i;
-    const float m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[4], m11 = M[5], m12 = M[6], m20 = M[8], m21 = M[9], m22 = M[10];
-    float qa[4] = {1.f + m00 + m11 + m22, 1.f + m00 - m11 - m22, 1.f - m00 + m11 - m22, 1.f - m00 - m11 + m22};
-    for (int k = 0; k < 4; ++k) qa[k] = qa[k] > 0.f ? sqrtf(qa[k]) : 0.f;
-    int best = 0;
-    for (int k = 1; k < 4; ++k) if (qa[k] > qa[best]) best = k;   // argmax, first maximum like torch
-    const float cand[4][4] = {{qa[0] * qa[0], m21 - m12, m02 - m20, m10 - m01},
-                              {m21 - m12, qa[1] * qa[1], m10 + m01, m02 + m20},
-                              {m02 - m20, m10 + m01, qa[2] * qa[2], m12 + m21},
-                              {m10 - m01, m20 + m02, m21 + m12, qa[3] * qa[3]}};
-    const float den = 2.f * fmaxf(qa[best], 0.1f);
-    const float r = cand[best][0] / den, x = cand[best][1] / den, y = cand[best][2] / den, z = cand[best][3] / den;
-    const float s = 2.f / (r * r + x * x + y * y + z * z);
-    M[0] = 1.f - s * (y * y + z * z); M[1] = s * (x * y - z * r);       M[2] = s * (x * z + y * r);
-    M[4] = s * (x * y + z * r);       M[5] = 1.f - s * (x * x + z * z); M[6] = s * (y * z - x * r);
-    M[8] = s * (x * z - y * r);       M[9] = s * (y * z + x * r);       M[10] = 1.f - s * (x * x + y * y);
+    renormalise_rotation(T + 16 * (size_t)i);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -47,62 +32,6 @@ __global__ void k_renormalise(float* __restrict__ T, int n) {
 // and backward are one launch each.  The backward pass differentiates the very same code with forward-mode dual
 // numbers (6 tangents at once), so value and derivative cannot drift apart, also at a = 0.
 // ---------------------------------------------------------------------------------------------------
-template <int ND>
-struct Dual {
-    float v;
-    float d[ND];
-};
-template <int ND> __device__ __forceinline__ Dual<ND> dconst(float c) { Dual<ND> r; r.v = c; for (int i = 0; i < ND; ++i) r.d[i] = 0.f; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator+(const Dual<ND>& a, const Dual<ND>& b) { Dual<ND> r; r.v = a.v + b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND>& a, const Dual<ND>& b) { Dual<ND> r; r.v = a.v - b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator-(const Dual<ND>& a) { Dual<ND> r; r.v = -a.v; for (int i = 0; i < ND; ++i) r.d[i] = -a.d[i]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator*(const Dual<ND>& a, const Dual<ND>& b) { Dual<ND> r; r.v = a.v * b.v; for (int i = 0; i < ND; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> operator*(float a, const Dual<ND>& b) { Dual<ND> r; r.v = a * b.v; for (int i = 0; i < ND; ++i) r.d[i] = a * b.d[i]; return r; }
-template <int ND> __device__ __forceinline__ Dual<ND> chain(const Dual<ND>& a, float f, float df) { Dual<ND> r; r.v = f; for (int i = 0; i < ND; ++i) r.d[i] = df * a.d[i]; return r; }
-
-// T(3x4) = Exp(a) * X(3x4) on dual numbers; the three coefficient functions are evaluated in theta^2
-template <int ND>
-__device__ void se3_exp_times(const Dual<ND> (&a)[6], const float* __restrict__ X16, Dual<ND> (&T)[12]) {
-    const Dual<ND> th2 = a[3] * a[3] + a[4] * a[4] + a[5] * a[5];
-    const float t2 = th2.v;
-    float A, B, C, dA, dB, dC;     // values and derivatives with respect to theta^2
-    {   // evaluated in fp64: the closed forms cancel badly in fp32 for theta < ~0.5 (1 - cos, theta - sin)
-        const double t = (double)t2;
-        double a_, b_, c_, da_, db_, dc_;
-        if (t < 1e-6) {
-            a_ = 1.0 - t / 6.0 * (1.0 - t / 20.0);           da_ = -1.0 / 6.0 + t / 60.0;
-            b_ = 0.5 - t / 24.0 * (1.0 - t / 30.0);           db_ = -1.0 / 24.0 + t / 360.0;
-            c_ = 1.0 / 6.0 - t / 120.0 * (1.0 - t / 42.0);    dc_ = -1.0 / 120.0 + t / 2520.0;
-        } else {
-            const double th = sqrt(t), sn = sin(th), cs = cos(th);
-            a_ = sn / th; b_ = (1.0 - cs) / t; c_ = (th - sn) / (t * th);
-            // d/d(theta^2) = (1 / (2 theta)) d/dtheta
-            da_ = (cs * th - sn) / (2.0 * t * th);
-            db_ = (sn * th - 2.0 * (1.0 - cs)) / (2.0 * t * t);
-            dc_ = ((1.0 - cs) * th - 3.0 * (th - sn)) / (2.0 * t * t * th);
-        }
-        A = (float)a_; B = (float)b_; C = (float)c_; dA = (float)da_; dB = (float)db_; dC = (float)dc_;
-    }
-    const Dual<ND> dA_ = chain(th2, A, dA), dB_ = chain(th2, B, dB), dC_ = chain(th2, C, dC);
-    const Dual<ND> z = dconst<ND>(0.f), one = dconst<ND>(1.f);
-    const Dual<ND> W[9] = {z, -a[5], a[4], a[5], z, -a[3], -a[4], a[3], z};
-    Dual<ND> W2[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) W2[3 * i + j] = W[3 * i] * W[j] + W[3 * i + 1] * W[3 + j] + W[3 * i + 2] * W[6 + j];
-    Dual<ND> E[9], V[9];
-    for (int i = 0; i < 9; ++i) {
-        const Dual<ND> I = (i % 4 == 0) ? one : z;
-        E[i] = I + dA_ * W[i] + dB_ * W2[i];
-        V[i] = I + dB_ * W[i] + dC_ * W2[i];
-    }
-    for (int i = 0; i < 3; ++i) {
-        const Dual<ND> dt = V[3 * i] * a[0] + V[3 * i + 1] * a[1] + V[3 * i + 2] * a[2];
-        for (int j = 0; j < 3; ++j)
-            T[4 * i + j] = X16[j] * E[3 * i] + X16[4 + j] * E[3 * i + 1] + X16[8 + j] * E[3 * i + 2];
-        T[4 * i + 3] = X16[3] * E[3 * i] + X16[7] * E[3 * i + 1] + X16[11] * E[3 * i + 2] + dt;
-    }
-}
-
 // one thread per pose; G = nullptr: forward (writes T), else backward (writes ga = (dT/da)^T G)
 __global__ void k_se3_retract(const float* __restrict__ a6, const float* __restrict__ X, int n, float* __restrict__ T,
                               const float* __restrict__ G, float* __restrict__ ga) {

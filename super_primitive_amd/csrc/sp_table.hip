@@ -119,7 +119,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_sample_source(uint32_t* __restrict
                                                             const float* __restrict__ kp_L, const float* __restrict__ kld,
                                                             int N, int P, int H, int W, const float* __restrict__ img,
                                                             int Hl, int Wl, const float* __restrict__ K9,
-                                                            float4* __restrict__ src4) {
+                                                            float4* __restrict__ src4, int set_validity) {
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
     if (i >= P) return;
     const int n = segment_of(seg_off, N, i);
@@ -156,7 +156,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_sample_source(uint32_t* __restrict
         rgb[ch] = acc;
     }
     src4[i] = make_float4(rgb[0], rgb[1], rgb[2], L);
-    pix[i] = pw | (ok ? 0x80000000u : 0u);
+    // The validity bit is a property of the geometry grid (0.99 band on the point's own pixel; depth enters only
+    // through the last bit of the re-projection): it is written once, when the table is built, and is shared by all
+    // pyramid levels -- later level samplings leave pix untouched.
+    if (set_validity) pix[i] = pw | (ok ? 0x80000000u : 0u);
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_pack_rgb(const float* __restrict__ chw, int HW, float* __restrict__ out) {
@@ -226,12 +229,12 @@ int sp_table_fill(const uint8_t* masks, const float* logdepth, const float* keyp
 
 int sp_table_sample_source(uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
                            const float* kld, int N, int P, int H, int W, const float* img, int Hl, int Wl,
-                           const float* K, float* src4, void* stream) {
+                           const float* K, float* src4, int set_validity, void* stream) {
     if (!pix || !baseL || !seg_off || !kp_L || !kld || !img || !K || !src4) return SP_EINVAL;
     if (N <= 0 || P <= 0 || H < 2 || W < 2 || Hl < 1 || Wl < 1) return SP_EINVAL;
     hipLaunchKernelGGL(k_sample_source, dim3((P + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0,
                        static_cast<hipStream_t>(stream), pix, baseL, seg_off, kp_L, kld, N, P, H, W, img, Hl, Wl, K,
-                       reinterpret_cast<float4*>(src4));
+                       reinterpret_cast<float4*>(src4), set_validity);
     SP_CHECK_LAUNCH();
     return 0;
 }

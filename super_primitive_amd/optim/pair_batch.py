@@ -37,6 +37,60 @@ def _level_images(img, max_level):
     return out
 
 
+def pad_layout(counts, device):
+    """Padded layout of one segment table: segment n occupies [pseg_off[n], pseg_off[n] + counts[n]) + padding up to a
+    multiple of GRANULE.  ``dst`` maps table point i to its padded position."""
+    counts = np.asarray(counts, dtype=np.int64)
+    pc = (counts + GRANULE - 1) // GRANULE * GRANULE
+    pseg_off = np.concatenate(([0], np.cumsum(pc)))
+    seg_off = np.concatenate(([0], np.cumsum(counts)))
+    dst = torch.from_numpy(np.repeat(pseg_off[:-1] - seg_off[:-1], counts) + np.arange(int(counts.sum()))).to(device)
+    return dict(pc=pc, pseg_off=pseg_off, Ppad=int(pseg_off[-1]), dst=dst)
+
+
+def pad_points(x, pd):
+    """(P, ...) table array -> (Ppad, ...) with zeros (= invalid points) in the padding."""
+    out = torch.zeros((pd['Ppad'],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    out[pd['dst']] = x
+    return out
+
+
+def build_work_list(pads, span_points, tile_points):
+    """Chunks {pair, seg, start, count}, spans {first chunk, n chunks, points, pair} and the per-pair record offsets of
+    the many-pairs cost kernels (include/sp_hip.h, "Work list") for pairs whose padded layouts are ``pads``.
+    Returns dict(chunks (C,4) int32, spans (S,4) int32, seg_rec_offs [per pair (N+1,) int32], c_off, s_off)."""
+    chunk_max = max(GRANULE, tile_points // GRANULE * GRANULE)
+    chunks, spans, seg_rec_offs, c_off, spans_per_pair = [], [], [], [0], []
+    for m, pd in enumerate(pads):
+        first = len(chunks)
+        sto = [0]
+        for n, (pc, off) in enumerate(zip(pd['pc'], pd['pseg_off'][:-1])):
+            k = int(-(-pc // chunk_max))                       # pieces of (nearly) equal, granule-aligned length
+            if k:
+                per = int(-(-(pc // GRANULE) // k)) * GRANULE
+                done = 0
+                while done < pc:
+                    cnt = int(min(per, pc - done))
+                    chunks.append((m, n, int(off + done), cnt))
+                    done += cnt
+            sto.append(4 * (len(chunks) - first))              # records: 4 per chunk (one per wave)
+        seg_rec_offs.append(np.asarray(sto, dtype=np.int32))
+        c_off.append(len(chunks))
+        # spans: greedy runs of consecutive chunks
+        ns, q = 0, first
+        while q < len(chunks):
+            q1, pts = q, 0
+            while q1 < len(chunks) and (q1 == q or pts + chunks[q1][3] <= span_points):
+                pts += chunks[q1][3]
+                q1 += 1
+            spans.append((q, q1 - q, pts, m))
+            ns += 1
+            q = q1
+        spans_per_pair.append(ns)
+    return dict(chunks=np.asarray(chunks, dtype=np.int32).reshape(-1, 4), spans=np.asarray(spans, dtype=np.int32).reshape(-1, 4),
+                seg_rec_offs=seg_rec_offs, c_off=c_off, s_off=np.concatenate(([0], np.cumsum(spans_per_pair))))
+
+
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
                  tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None):
@@ -75,14 +129,7 @@ class PairBatch:
         self.Ps = [t.P for t in tables]
         self.max_N = max(self.Ns)
         # padded layout of every base table: segment n occupies [pseg_off[n], pseg_off[n] + counts[n]) + padding
-        pads0 = []
-        for tab in tables0:
-            counts = np.asarray(tab.counts, dtype=np.int64)
-            pc = (counts + GRANULE - 1) // GRANULE * GRANULE
-            pseg_off = np.concatenate(([0], np.cumsum(pc)))
-            seg_off = np.concatenate(([0], np.cumsum(counts)))
-            dst = torch.from_numpy(np.repeat(pseg_off[:-1] - seg_off[:-1], counts) + np.arange(int(counts.sum()))).to(dev)
-            pads0.append(dict(pc=pc, pseg_off=pseg_off, Ppad=int(pseg_off[-1]), dst=dst))
+        pads0 = [pad_layout(tab.counts, dev) for tab in tables0]
         pads = [pads0[b] for b in base]
         self.Ppads = [pd['Ppad'] for pd in pads]
         n_off = np.concatenate(([0], np.cumsum(self.Ns)))
@@ -90,10 +137,7 @@ class PairBatch:
         self.n_off, self.p_off = n_off, p_off
         cat = torch.cat
 
-        def padded(x, pd):
-            out = torch.zeros((pd['Ppad'],) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
-            out[pd['dst']] = x
-            return out
+        padded = pad_points
 
         # flat, pair-major device arrays
         self.kp_L = cat([t.kp_L for t in tables])
@@ -125,42 +169,15 @@ class PairBatch:
             span_points = min(DEFAULT_SPAN_POINTS, int(p_off[-1]) // MIN_SPANS)
         self.span_points = max(int(span_points), GRANULE)
         # work list: chunks {pair, seg, start, count} and spans {first chunk, n chunks, points, pair}
-        chunk_max = max(GRANULE, tile_points // GRANULE * GRANULE)
-        chunks, spans, seg_rec_offs, c_off, spans_per_pair = [], [], [], [0], []
-        for m, pd in enumerate(pads):
-            first = len(chunks)
-            sto = [0]
-            for n, (pc, off) in enumerate(zip(pd['pc'], pd['pseg_off'][:-1])):
-                k = int(-(-pc // chunk_max))                       # pieces of (nearly) equal, granule-aligned length
-                if k:
-                    per = int(-(-(pc // GRANULE) // k)) * GRANULE
-                    done = 0
-                    while done < pc:
-                        cnt = int(min(per, pc - done))
-                        chunks.append((m, n, int(off + done), cnt))
-                        done += cnt
-                sto.append(4 * (len(chunks) - first))              # records: 4 per chunk (one per wave)
-            seg_rec_offs.append(np.asarray(sto, dtype=np.int32))
-            c_off.append(len(chunks))
-            # spans: greedy runs of consecutive chunks
-            ns, q = 0, first
-            while q < len(chunks):
-                q1, pts = q, 0
-                while q1 < len(chunks) and (q1 == q or pts + chunks[q1][3] <= self.span_points):
-                    pts += chunks[q1][3]
-                    q1 += 1
-                spans.append((q, q1 - q, pts, m))
-                ns += 1
-                q = q1
-            spans_per_pair.append(ns)
+        wl = build_work_list(pads, self.span_points, tile_points)
+        chunks, spans, seg_rec_offs, c_off, s_off = wl['chunks'], wl['spans'], wl['seg_rec_offs'], wl['c_off'], wl['s_off']
         self.n_chunks, self.n_spans = len(chunks), len(spans)
-        s_off = np.concatenate(([0], np.cumsum(spans_per_pair)))
-        self.chunks = torch.from_numpy(np.asarray(chunks, dtype=np.int32).reshape(-1, 4)).to(dev)
-        self.spans = torch.from_numpy(np.asarray(spans, dtype=np.int32).reshape(-1, 4)).to(dev)
+        self.chunks = torch.from_numpy(chunks).to(dev)
+        self.spans = torch.from_numpy(spans).to(dev)
         # partial records: one per span (pair-level sums) and one per (chunk, wave) (segment-level sums);
         # span_pair / seg_records list the owner of every record for host-side consumers (tests, evaluate())
         self.span_pair = self.spans[:, 3].long()
-        rec = np.repeat(np.asarray(chunks, dtype=np.int32).reshape(-1, 4)[:, :2], 4, axis=0)
+        rec = np.repeat(chunks[:, :2], 4, axis=0)
         self.n_seg_records = 4 * self.n_chunks
         self.seg_records = torch.from_numpy(rec.copy()).to(dev)          # (pair, segment) of every segment record
         sto_off = np.concatenate(([0], np.cumsum([len(s) for s in seg_rec_offs])))

@@ -10,7 +10,12 @@ Masks and base log-depths never change after a keyframe is built, so the build c
 
 (20 B per point per iteration instead of >= 5 dense N*H*W*4-byte passes).  The table is attached to the
 ``keypoint_regions`` tensor object, which ``keyframe_pyramid(geo_down=False)`` shares between all levels, and is
-rebuilt whenever masks / log-depths / keypoints are replaced or modified (tensor identity + version counters).
+rebuilt whenever masks / log-depths / keypoints are replaced or modified in place.
+
+Cache keys are OBJECT identities, not addresses: every cache entry keeps strong references to the tensors it was
+built from and compares them with ``is`` (a freed address that the caching allocator hands to a new tensor can
+therefore never alias an entry), plus the tensors' version counters for in-place edits.  Writes that bypass the
+version counter (``t.data.copy_()``, ``t.data[...] = x``) are invisible to it: call ``invalidate(kf)`` after those.
 """
 from __future__ import annotations
 
@@ -22,8 +27,19 @@ from . import _lib
 DEFAULT_TILE_POINTS = 1024
 
 
-def _ident(t):
-    return (t.data_ptr(), t._version, tuple(t.shape), str(t.device))
+class _Ident:
+    """Identity of a tensor for cache keys: the object itself (held, compared with ``is``) + its version counter."""
+    __slots__ = ("t", "version")
+
+    def __init__(self, t):
+        self.t, self.version = t, t._version
+
+    def matches(self, t):
+        return t is self.t and t._version == self.version
+
+
+def _same(idents, tensors):
+    return idents is not None and len(idents) == len(tensors) and all(i.matches(t) for i, t in zip(idents, tensors))
 
 
 def make_tiles(counts, tile_points, pair=0, first_point=0, granule=256):
@@ -82,8 +98,9 @@ class SegmentTable:
                                      _lib.ptr(row_counts), _lib.ptr(self.pix), _lib.ptr(self.baseL), _lib.ptr(self.kp_L),
                                      s), "sp_table_fill")
         self.set_tile_points(tile_points)
-        self._levels = {}
+        self._levels = []          # [(idents of (image, K), src4)], most recent last
         self._key = None
+        self._validity_set = False
 
     def set_tile_points(self, tile_points):
         tiles, sto = make_tiles(self.counts, tile_points)
@@ -94,11 +111,11 @@ class SegmentTable:
 
     # -- per-level source samples ---------------------------------------------------------------
     def source_level(self, image, K, kld):
-        """{rgb at this level, baseL} per point, cached per (image, K) identity."""
-        key = (_ident(image), _ident(K))
-        hit = self._levels.get(key)
-        if hit is not None:
-            return hit
+        """{rgb at this level, baseL} per point, cached per (image, K) object identity.  The first call after the table
+        is built also sets the source-validity bit of ``pix`` (geometry only; shared by every level)."""
+        for idents, hit in self._levels:
+            if _same(idents, (image, K)):
+                return hit
         _lib.require_device(image, K, kld)
         lib = _lib.load()
         img = image[:3].detach().contiguous().float()
@@ -108,22 +125,25 @@ class SegmentTable:
         kc = kld.detach().contiguous().float()
         _lib.check(lib.sp_table_sample_source(_lib.ptr(self.pix), _lib.ptr(self.baseL), _lib.ptr(self.seg_off),
                                               _lib.ptr(self.kp_L), _lib.ptr(kc), self.N, self.P, self.H, self.W,
-                                              _lib.ptr(img), Hl, Wl, _lib.ptr(Kc), _lib.ptr(src4), _lib.stream_ptr()),
+                                              _lib.ptr(img), Hl, Wl, _lib.ptr(Kc), _lib.ptr(src4),
+                                              0 if self._validity_set else 1, _lib.stream_ptr()),
                    "sp_table_sample_source")
-        if len(self._levels) > 16:
-            self._levels.clear()
-        self._levels[key] = src4
+        self._validity_set = True
+        if len(self._levels) >= 16:
+            del self._levels[0]
+        self._levels.append(((_Ident(image), _Ident(K)), src4))
         return src4
 
 
 def table_of(kf, tile_points=None):
     """The (cached) SegmentTable of a keyframe-like object with the reference's attribute names."""
     masks, L, kp = kf.keypoint_regions, kf.get_logdepth() if hasattr(kf, "get_logdepth") else kf.logdepth_perseg, kf.keypoints
-    key = (_ident(masks), _ident(L), _ident(kp))
     tab = getattr(masks, "_sp_table", None)
-    if tab is None or tab._key != key:
+    # (the table hangs off the masks object itself, so only the masks' version needs checking -- holding the masks
+    #  in the key would make an uncollectable-by-refcount cycle that delays freeing the keyframe's device memory)
+    if tab is None or tab._key[0] != masks._version or not _same(tab._key[1], (L, kp)):
         tab = SegmentTable(masks, L, kp, tile_points or DEFAULT_TILE_POINTS)
-        tab._key = key
+        tab._key = (masks._version, (_Ident(L), _Ident(kp)))
         try:
             masks._sp_table = tab
         except Exception:  # pragma: no cover
@@ -133,10 +153,23 @@ def table_of(kf, tile_points=None):
     return tab
 
 
+def invalidate(kf_or_tensor):
+    """Drop every cache hanging off a keyframe (or a single tensor): segment table, per-level source samples, packed
+    target.  Needed only after writes that bypass torch's version counter (``.data``)."""
+    objs = [kf_or_tensor] if torch.is_tensor(kf_or_tensor) else [getattr(kf_or_tensor, a, None) for a in
+                                                               ("keypoint_regions", "logdepth_perseg", "keypoints", "image")]
+    for t in objs:
+        if torch.is_tensor(t):
+            for attr in ("_sp_table", "_sp_rgba"):
+                if hasattr(t, attr):
+                    delattr(t, attr)
+
+
 def packed_target(images):
-    """(3,H,W) or (B,3,H,W) planar f32 -> (B,H,W,3) packed (HWC3), cached on the tensor object."""
+    """(3,H,W) or (B,3,H,W) planar f32 -> (B,H,W,3) packed (HWC3), cached ON the tensor object (so the cache dies with
+    it) and keyed on its version counter."""
     _lib.require_device(images)
-    key = _ident(images)
+    key = images._version
     hit = getattr(images, "_sp_rgba", None)
     if hit is not None and hit[0] == key:
         return hit[1]

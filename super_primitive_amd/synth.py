@@ -207,3 +207,90 @@ def stepped_logdepth(pair, seed=0, n_boxes=3, factor=(0.55, 0.75)):
         r1, c1 = r0 + int(rng.uniform(0.15, 0.35) * H), c0 + int(rng.uniform(0.15, 0.35) * W)
         d[r0:r1, c0:c1] *= rng.uniform(*factor)
     return (np.log(d)[None] * pair.keypoint_regions).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------
+# several frames of one scene (windowed mapping / MonoVO-shaped inputs)
+# ----------------------------------------------------------------------------
+@dataclass
+class SynthFrame:
+    """One frame of a synthetic sequence.  ``T_wc`` is camera-to-world (the reference's ``kf_poses`` /
+    supporting-frame poses, ``odometery/odometery.py:793``: relative pose = inv(T_trg) @ T_src)."""
+    image: np.ndarray             # (3,H,W) f32
+    K: np.ndarray                 # (3,3) f32
+    T_wc: np.ndarray              # (4,4) f32 ground truth
+    depth: np.ndarray             # (H,W) f32
+    logdepth_perseg: np.ndarray | None = None   # keyframes only
+    keypoints: np.ndarray | None = None
+    keypoint_regions: np.ndarray | None = None
+    kld_gt: np.ndarray | None = None
+
+
+def make_sequence(H, W, N, twists, keyframe_ids, seed=0, overlap=0, texture_period_px=14.0):
+    """Frames of ONE textured plane seen from cameras ``T_wc[k] = Exp(twists[k])`` (world = camera of the zero twist).
+    Frames listed in ``keyframe_ids`` also get an N-segment grid tiling with per-segment log-depths (the same
+    construction as ``make_pair``); the others are supporting frames (image + K only).  Returns [SynthFrame]."""
+    rng = np.random.default_rng(seed)
+    fx = fy = 0.8 * W
+    cx, cy = W / 2.0, H / 2.0
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.0]])
+    n = np.array([0.22, -0.12, 1.0]) + 0.05 * rng.standard_normal(3)
+    n /= np.linalg.norm(n)
+    h = 3.0
+    cols, rows = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    rays = np.stack([(cols - cx) / fx, (rows - cy) / fy, np.ones_like(cols)], -1)
+    base_omega = 2.0 * math.pi / (texture_period_px * h / fx)
+    tex = np.empty((3, 6, 6))
+    d = rng.standard_normal((3, 6, 3))
+    tex[:, :, :3] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    tex[:, :, 3] = rng.uniform(0.35, 1.0, (3, 6))
+    tex[:, :, 4] = rng.uniform(0, 2 * math.pi, (3, 6))
+    tex[:, :, 5] = rng.uniform(0.04, 0.11, (3, 6))
+    gh, gw = _grid_shape(N)
+    r_edges = np.linspace(0, H, gh + 1).round().astype(int)
+    c_edges = np.linspace(0, W, gw + 1).round().astype(int)
+    f32 = np.float32
+    frames = []
+    for k, xi in enumerate(twists):
+        T = se3_exp_np(np.asarray(xi, dtype=np.float64))
+        R, t = T[:3, :3], T[:3, 3]
+        depth = (h - n @ t) / ((rays @ R.T) @ n)           # world point = R ray d + t on the plane n.X = h
+        Xw = (rays * depth[..., None]) @ R.T + t
+        fr = SynthFrame(image=_texture(Xw, tex, base_omega).astype(f32), K=K.astype(f32), T_wc=T.astype(f32),
+                        depth=depth.astype(f32))
+        if k in keyframe_ids:
+            masks = np.zeros((N, H, W), dtype=bool)
+            kp_rc = np.zeros((N, 2), dtype=np.int64)
+            q = 0
+            for i in range(gh):
+                for j in range(gw):
+                    r0, r1 = max(r_edges[i] - overlap, 0), min(r_edges[i + 1] + overlap, H)
+                    c0, c1 = max(c_edges[j] - overlap, 0), min(c_edges[j + 1] + overlap, W)
+                    masks[q, r0:r1, c0:c1] = True
+                    kp_rc[q] = ((r_edges[i] + r_edges[i + 1]) // 2, (c_edges[j] + c_edges[j + 1]) // 2)
+                    q += 1
+            logD = np.log(depth)
+            offs = rng.uniform(-0.7, 0.7, N)
+            fr.logdepth_perseg = ((logD[None] - offs[:, None, None]) * masks).astype(f32)
+            fr.keypoints = np.stack([2.0 * kp_rc[:, 0] / (H - 1) - 1.0, 2.0 * kp_rc[:, 1] / (W - 1) - 1.0], 1).astype(f32)
+            fr.keypoint_regions = masks
+            fr.kld_gt = logD[kp_rc[:, 0], kp_rc[:, 1]].astype(f32)
+        frames.append(fr)
+    return frames
+
+
+def window_inputs(seed, n_kf, H=48, W=64, N=6):
+    """A synthetic MonoVO window: keyframes at even frames, one supporting frame after each.  Returns the frames and
+    perturbed initial estimates (poses, keypoint log-depths, affines)."""
+    rng = np.random.default_rng(seed)
+    base = np.array([0.05, -0.02, 0.015, 0.01, -0.015, 0.008])
+    twists = [k * base * (1.0 + 0.15 * rng.standard_normal(6)) for k in range(2 * n_kf)]
+    frames = make_sequence(H, W, N, twists, keyframe_ids=list(range(0, 2 * n_kf, 2)), seed=seed, overlap=1)
+    est = []
+    for k, f in enumerate(frames):
+        T0 = f.T_wc.astype(np.float64) if k == 0 else f.T_wc.astype(np.float64) @ se3_exp_np(0.004 * rng.standard_normal(6))
+        est.append(T0.astype(np.float32))
+    klds = [(frames[k].kld_gt + 0.03 * rng.standard_normal(N)).astype(np.float32) for k in range(0, 2 * n_kf, 2)]
+    affs = (0.01 * rng.standard_normal((2 * n_kf, 2))).astype(np.float32)
+    affs[0] = 0
+    return frames, est, klds, affs

@@ -13,10 +13,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # the C-ABI library is a build artefact (git-ignored): make sure it exists before any test imports it
+    # the C-ABI library is a build artefact (git-ignored): (re)build it before any test imports it.  make is
+    # idempotent and tracks the headers, so an edited .hip / .h can never be tested against a stale library.
+    import shutil
+    import subprocess
     lib = os.path.join(ROOT, "super_primitive_amd", "csrc", "libsp_hip.so")
-    if not os.path.exists(lib):
-        import subprocess
+    if shutil.which("hipcc") or not os.path.exists(lib):
         subprocess.run(["make", "-C", os.path.dirname(lib), "-j8"], check=True)
 
 
