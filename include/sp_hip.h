@@ -298,6 +298,14 @@ int sp_depth_average(const uint32_t* pix, const float* baseL, const int32_t* seg
                      const float* kld, const uint8_t* visible, int N, int P, int H, int W, void* acc,
                      float* out_depth, uint8_t* out_invalid, void* stream);
 
+/* The two halves of sp_depth_average, for SEGMENT-SHARDED depth completion (BASELINE.json configs[3], SURVEY.md
+ * section 8(e)): every rank accumulates its own segments into acc = {sums[H*W] uint64 (32.32 fixed point), counts[H*W]
+ * uint32}, the ranks all_reduce(SUM) the two integer arrays (exact and order independent, so the result is bitwise the
+ * single-GPU one; a pixel is invalid iff its summed count is 0, i.e. the OR of the per-rank validity), rank-local finish. */
+int sp_depth_accumulate(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                        const float* kld, const uint8_t* visible, int N, int P, int H, int W, void* acc, void* stream);
+int sp_depth_average_finish(const void* acc, int H, int W, float* out_depth, uint8_t* out_invalid, void* stream);
+
 /* The pose parameter of the reference's drivers, T[b] = Exp(a[b]) * X[b]  (a = [tau, phi] (n,6); X, T (n,4,4)):
  * lietorch's LieGroupParameter.retr().matrix() at odometery/two_frame_sfm.py:83-84, odometery/odometery.py:224-228.
  * grad_T == NULL: forward, writes T.  grad_T != NULL: backward, writes grad_a[b] = (dT/da)^T grad_T[b] (n,6). */

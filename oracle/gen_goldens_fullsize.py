@@ -3,7 +3,7 @@ full-size configs commit only checksums/summary statistics").
 
 TEST INFRASTRUCTURE.  Runs only in the build container (needs /root/reference, minutes of CPU):
 
-    python oracle/gen_goldens_fullsize.py [g14 g15 g16]          # default: all three
+    python oracle/gen_goldens_fullsize.py [g14 g14_t1 g15 g16 g17 g18]          # default: all
 
 The inputs are NOT stored (a 640x480x64 keyframe is 100 MB): tests regenerate them with ``synth.make_pair`` from the
 seed recorded here (numpy PCG64 in float64, bit-stable) and check ``in_sha256`` before comparing anything.
@@ -19,6 +19,9 @@ seed recorded here (numpy PCG64 in float64, bit-stable) and check ``in_sha256`` 
                           them); (b) 20 Adam iterations per level (bounded run); (c) the MINIMISER of the reference
                           cost at level 0: the reference loop started from the synthetic ground truth with decaying
                           learning rates until the loss spread over 40 iterations is < 2e-9.
+  g14_config1_converged_t1  the same run on ONE thread (another fp32 reduction order): the reference against itself.
+  g17_config3_tum_shaped  BASELINE configs[2] shape, 224x288x40: tracking (300 steps) and full-window mapping (60 steps).
+  g18_config4_void_shaped BASELINE configs[3] shape, 480x640 with 1200 segments: median re-initialisation + per-pixel average.
   g16_config5_seg128      BASELINE configs[4]'s pair shape: 640x480, 128 segments: residual + gradients at the initial
                           point, level 0 (fp32 reference, fp64 oracle).
 """
@@ -184,17 +187,106 @@ def golden_config2(ref, name="g15_config2_fullsize", seed=1000, segments=64, tra
     print(f"{name}: {time.time() - t0:.0f} s", flush=True)
 
 
+def golden_config3(ref, name="g17_config3_tum_shaped", seed=300, track_steps=300, map_steps=60):
+    """BASELINE configs[2] shape (TUM fr1/desk MonoVO: 224x288 keyframes, config/tum/odom_desk.yaml): (a) frame-to-keyframe
+    tracking, steps [0, 0, 300] (odometery.py:300-312,375-407) with affine compensation; (b) windowed mapping over 3
+    keyframes = full window with one supporting frame each (odometery.py:576-648,756-915), 60 iterations.  Inputs:
+    ``synth.window_inputs(seed, 3, H=224, W=288, N=40)`` (regenerated by the tests)."""
+    from gen_goldens import reference_mapping_loop
+    H, W, N = 224, 288, 40
+    frames, est, klds, affs = synth.window_inputs(seed, 3, H=H, W=W, N=N)
+    t0 = time.time()
+    mk = lambda f: ref.kf.KeyFrame(T(f.image), T(f.K), T(f.logdepth_perseg), T(f.keypoints), torch.from_numpy(f.keypoint_regions.copy()))
+    save = dict(seed=np.array(seed), HWN=np.array([H, W, N]), track_steps=np.array(track_steps), map_steps=np.array(map_steps))
+    # (a) tracking frame 1 against keyframe 0 (depths = ground truth, as after mapping)
+    kf0 = mk(frames[0])
+    supp = ref.kf.KeyFrame(T(frames[1].image), T(frames[1].K))
+    kf_pyr = ref.kf.keyframe_pyramid(kf0, 0, 3)
+    supp_pyr = ref.kf.keyframe_pyramid(supp, 0, 3)
+    with torch.no_grad():
+        pre = [ref.do.unproject_kf(k, T(frames[0].kld_gt)) for k in kf_pyr]
+    delta = torch.nn.Parameter(torch.zeros(1, 6))
+    aff = torch.nn.Parameter(torch.zeros(2))
+    prev_aff = torch.zeros(2)
+    opt = torch.optim.Adam([{"params": [delta], "lr": 5e-3}, {"params": [aff], "lr": 5e-3}], lr=5e-3)
+    prev_pose = T(est[0])
+    supp_T = T(est[1])
+    losses = []
+    for level, n in enumerate([0, 0, track_steps]):
+        for _ in range(n):
+            pose = orc.se3_exp(delta)[0] @ ref.la.invertSE3(supp_T) @ prev_pose
+            out = ref.do.photomeric_cost_precomputed(pre[level], supp_pyr[level], pose, CFG, affine_comp=(prev_aff, aff))
+            loss = torch.mean(out["residual"])
+            losses.append(float(loss))
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+            with torch.no_grad():
+                supp_T = supp_T @ ref.la.invertSE3(orc.se3_exp(delta.detach())[0])
+                delta.data = torch.zeros_like(delta.data)
+    supp_T = ref.la.renormalise_se3(supp_T)
+    save.update(track_losses=np.array(losses), track_supp_T=supp_T.numpy(), track_aff=aff.detach().numpy(),
+                track_gt_T=frames[1].T_wc)
+    print(f"  {name} tracking done ({time.time() - t0:.0f} s): loss {losses[0]:.6f} -> {losses[-1]:.6f}", flush=True)
+    # (b) mapping
+    kfs = [mk(f) for f in frames[0::2]]
+    sup = [[(ref.kf.KeyFrame(T(frames[2 * k + 1].image), T(frames[2 * k + 1].K)), T(est[2 * k + 1]), T(affs[2 * k + 1]))] for k in range(3)]
+    out = reference_mapping_loop(ref, kfs, [T(est[2 * k]) for k in range(3)], [T(k) for k in klds], [T(affs[2 * k]) for k in range(3)],
+                                 sup, map_steps, 1e-4, 3, True, True)
+    save.update({f"map_{k}": v for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: {time.time() - t0:.0f} s; mapping loss {out['losses'][0]:.6f} -> {out['losses'][-1]:.6f}, stopped {int(out['stopped'])}", flush=True)
+
+
+def golden_config4(ref, name="g18_config4_void_shaped", seed=4, n_segments=1200):
+    """BASELINE configs[3] shape (VOID-1500 depth completion, 480x640, ~1200 sparse-depth segments): the reference's
+    per-image pipeline after the frontend (segment_based_completion.py:45-55) -- segment_based_depth_reinit (median),
+    unproject_kf_to_depths, masking, visible filter, render_depth_avg -- on a synthetic keyframe of overlapping blobs
+    with one sparse measurement per segment (at its keypoint).  Stored: kld, visible, invalid map, the completed depth on a
+    4x4-strided grid and its float64 sum."""
+    pair = synth.make_pair(480, 640, n_segments, seed=seed, shape="blobs")
+    t0 = time.time()
+    src, _ = ref_frames(ref, pair)
+    sparse = np.zeros_like(pair.depth)
+    rc = pair.meta["kp_rc"]
+    sparse[rc[:, 0], rc[:, 1]] = pair.depth[rc[:, 0], rc[:, 1]]
+    with torch.no_grad():
+        kld, vis = ref.di.segment_based_depth_reinit(T(sparse).clone(), src, mode="median", return_info=True)
+    torch.set_grad_enabled(True)
+    with torch.no_grad():
+        depths = ref.do.unproject_kf_to_depths(src, kld)
+        depths[src.keypoint_regions == 0] = -1
+        depths = depths[vis]
+        invalid = depths.max(dim=0)[0] < 1e-6
+        depths[depths < 1e-6] = 0.0
+        avg = depths.sum(dim=0) / ((depths > 1e-6).sum(dim=0) + 1e-6)
+    save = dict(seed=np.array(seed), in_sha256=input_digest(pair), make_pair_args=np.array(f"H=480,W=640,N={n_segments},shape=blobs"),
+                kld=kld.numpy(), visible=vis.numpy(), invalid=np.packbits(invalid.numpy(), axis=-1), depth_4x4=avg.numpy()[::4, ::4].copy(),
+                depth_sum=avg.double().sum().numpy(), n_points=np.array(int(pair.keypoint_regions.sum())))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: {time.time() - t0:.0f} s; {int(vis.sum())} visible of {n_segments}, coverage {1 - float(invalid.float().mean()):.3f}", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(int(os.environ.get("SP_GOLDEN_THREADS", "8")))
     ref = import_reference()
-    which = sys.argv[1:] or ["g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g14", "g14_t1", "g15", "g16", "g17", "g18"]
     if "g14" in which:
         golden_config1(ref)
+    if "g14_t1" in which:
+        # the SAME reference run with a different reduction order (1 thread instead of 8): how far the reference moves
+        # from itself under fp32 summation-order noise -- the yardstick for trajectory deviations (profiles/r02_parity.txt)
+        torch.set_num_threads(1)
+        golden_config1(ref, name="g14_config1_converged_t1")
     if "g16" in which:
         golden_config2(ref, name="g16_config5_seg128", seed=2000, segments=128, traj_steps=0, want_minimiser=False)
     if "g15" in which:
         golden_config2(ref)
+    if "g17" in which:
+        golden_config3(ref)
+    if "g18" in which:
+        golden_config4(ref)
 
 
 if __name__ == "__main__":

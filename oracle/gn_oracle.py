@@ -35,8 +35,10 @@ def residual_vector(src, trg, kld, pose, affine=None):
     return raw.reshape(-1), mask.reshape(-1), seg, out["residual"]
 
 
-def normal_equations(src, trg, kld, pose, eps=1e-3, affine=None):
-    """Returns dict(H (6+N,6+N), b (6+N), cost (mean |r| like the reference), n_valid) in float64."""
+def normal_equations(src, trg, kld, pose, eps=1e-3, affine=None, columns=None):
+    """Returns dict(H (6+N,6+N), b (6+N), cost (mean |r| like the reference), n_valid) in float64.  ``columns``: only
+    these unknowns (indices into [xi(6), kld(N)]) are differentiated -- H and b are then the corresponding sub-block
+    (full-size keyframes: 6 pose columns + a few segments instead of 2 (6+N) dense evaluations)."""
     src64 = orc.OracleFrame(src.image.double(), src.K.double(), src.logdepth_perseg.double(), src.keypoints.double(),
                             src.keypoint_regions)
     trg64 = orc.OracleFrame(trg.image.double(), trg.K.double())
@@ -52,7 +54,7 @@ def normal_equations(src, trg, kld, pose, eps=1e-3, affine=None):
     h = 1e-7
     cols = []
     with torch.no_grad():
-        for i in range(x0.numel()):
+        for i in (range(x0.numel()) if columns is None else columns):
             e = torch.zeros_like(x0)
             e[i] = h
             cols.append((f(x0 + e) - f(x0 - e)) / (2 * h))

@@ -41,6 +41,8 @@ SIGNATURES = {
     "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_segment_reinit": [P, P, P, P, I, I, I, I, P, I, P, P, P, P],
     "sp_depth_average": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],
+    "sp_depth_accumulate": [P, P, P, P, P, P, I, I, I, I, P, P],
+    "sp_depth_average_finish": [P, I, I, P, P, P],
     "sp_kf_criterion": [P, I, F, P, P, P, P],
     "sp_se3_retract": [P, P, I, P, P, P, P],
     "sp_renormalise_se3": [P, I, P],

@@ -334,10 +334,9 @@ int sp_segment_reinit(const uint32_t* pix, const float* baseL, const int32_t* se
     return 0;
 }
 
-int sp_depth_average(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
-                     const float* kld, const uint8_t* visible, int N, int P, int H, int W, void* acc,
-                     float* out_depth, uint8_t* out_invalid, void* stream) {
-    if (!pix || !baseL || !seg_off || !kp_L || !kld || !acc || !out_depth || !out_invalid) return SP_EINVAL;
+int sp_depth_accumulate(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                        const float* kld, const uint8_t* visible, int N, int P, int H, int W, void* acc, void* stream) {
+    if (!pix || !baseL || !seg_off || !kp_L || !kld || !acc) return SP_EINVAL;
     if (N <= 0 || P <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t HW = (size_t)H * W;
@@ -348,10 +347,27 @@ int sp_depth_average(const uint32_t* pix, const float* baseL, const int32_t* seg
     hipLaunchKernelGGL(k_average_scatter, dim3((P + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0, s, pix, baseL, seg_off,
                        kp_L, kld, visible, N, P, W, sums, counts);
     SP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_average_finish, dim3((unsigned)((HW + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), 0, s, sums, counts,
-                       (int)HW, out_depth, out_invalid);
+    return 0;
+}
+
+int sp_depth_average_finish(const void* acc, int H, int W, float* out_depth, uint8_t* out_invalid, void* stream) {
+    if (!acc || !out_depth || !out_invalid || H <= 0 || W <= 0) return SP_EINVAL;
+    const size_t HW = (size_t)H * W;
+    const unsigned long long* sums = static_cast<const unsigned long long*>(acc);
+    const uint32_t* counts = reinterpret_cast<const uint32_t*>(sums + HW);
+    hipLaunchKernelGGL(k_average_finish, dim3((unsigned)((HW + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), 0,
+                       static_cast<hipStream_t>(stream), sums, counts, (int)HW, out_depth, out_invalid);
     SP_CHECK_LAUNCH();
     return 0;
+}
+
+int sp_depth_average(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L,
+                     const float* kld, const uint8_t* visible, int N, int P, int H, int W, void* acc,
+                     float* out_depth, uint8_t* out_invalid, void* stream) {
+    if (!out_depth || !out_invalid) return SP_EINVAL;
+    const int rc = sp_depth_accumulate(pix, baseL, seg_off, kp_L, kld, visible, N, P, H, W, acc, stream);
+    if (rc != 0) return rc;
+    return sp_depth_average_finish(acc, H, W, out_depth, out_invalid, stream);
 }
 
 int sp_kf_criterion(const float* depth, int n, float thresh, const float* pose_src, const float* pose_trg, float* out,

@@ -82,12 +82,16 @@ __device__ void se3_retract_left(const double xi[6], float* T16) {
     T16[12] = 0.f; T16[13] = 0.f; T16[14] = 0.f; T16[15] = 1.f;
 }
 
-// torch.optim.Adam (amsgrad=False, weight_decay=0), one scalar parameter; returns the step to ADD.
-__device__ __forceinline__ float adam_delta(float g, float& m, float& v, float lr, float bc1, float bc2_sqrt) {
-    m = 0.9f * m + 0.1f * g;
-    v = 0.999f * v + 0.001f * g * g;
-    const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
-    return -(lr / bc1) * (m / denom);
+// torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay, no amsgrad) on one fp32 scalar, in torch's operation
+// order: exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2); denom = sqrt(v)/sqrt(bc2) + eps;
+// p.addcdiv_(m, denom, value=-lr/bc1).  The bias corrections are Python doubles there, cast to fp32 at the op:
+// neg_step = (float)(-lr / bc1), bc2s = (float)sqrt(bc2).  Returns the step to ADD.
+__device__ __forceinline__ float adam_torch(float g, float& m, float& v, float neg_step, float bc2s) {
+    m = m + 0.1f * (g - m);
+    v = v * 0.999f;
+    v = v + 0.001f * g * g;
+    const float denom = sqrtf(v) / bc2s + 1e-8f;
+    return neg_step * (m / denom);
 }
 
 struct AdamArgs {
@@ -119,8 +123,9 @@ __device__ __forceinline__ void solve_adam(const SpPair* __restrict__ pairs, int
     float* m_xi = v_kld + max_N; float* v_xi = m_xi + 6;
     float* m_af = v_xi + 6; float* v_af = m_af + 2;
     const float step = st[0] + 1.f;
-    const float bc1 = 1.f - powf(0.9f, step);
-    const float bc2s = sqrtf(1.f - powf(0.999f, step));
+    const double bc1 = 1.0 - pow(0.9, (double)step);
+    const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
+    const float ns_kld = (float)(-(double)lr_kld / bc1), ns_pose = (float)(-(double)lr_pose / bc1), ns_aff = (float)(-(double)lr_aff / bc1);
     __syncthreads();            // every thread has read st[0] before thread 0 stores the new step count below
     // per-segment log-depths
     for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
@@ -135,7 +140,7 @@ __device__ __forceinline__ void solve_adam(const SpPair* __restrict__ pairs, int
             for (int u = 0; u < 8; ++u) s += (t + u < t1) ? (double)v[u] : 0.0;
         }
         const float g = (float)(s * up);
-        pr.kld[n] += adam_delta(g, m_kld[n], v_kld[n], lr_kld, bc1, bc2s);
+        pr.kld[n] += adam_torch(g, m_kld[n], v_kld[n], ns_kld, bc2s);
     }
     if (threadIdx.x == 0) {
         // gradient wrt the left tangent at identity: d/dtau = g_t ; d/dphi = vee(A - A^T), A = R g_R^T + t g_t^T
@@ -152,12 +157,12 @@ __device__ __forceinline__ void solve_adam(const SpPair* __restrict__ pairs, int
         const float g6[6] = {(float)gt[0], (float)gt[1], (float)gt[2],
                              (float)(A[5] - A[7]), (float)(A[6] - A[2]), (float)(A[1] - A[3])};
         double xi[6];
-        for (int i = 0; i < 6; ++i) xi[i] = adam_delta(g6[i], m_xi[i], v_xi[i], lr_pose, bc1, bc2s);
+        for (int i = 0; i < 6; ++i) xi[i] = adam_torch(g6[i], m_xi[i], v_xi[i], ns_pose, bc2s);
         se3_retract_left(xi, pr.pose);
         if (pr.aff) {
             const float ga = (float)(sums[14] * up), gb = (float)(sums[15] * up);
-            pr.aff[2] += adam_delta(ga, m_af[0], v_af[0], lr_aff, bc1, bc2s);
-            pr.aff[3] += adam_delta(gb, m_af[1], v_af[1], lr_aff, bc1, bc2s);
+            pr.aff[2] += adam_torch(ga, m_af[0], v_af[0], ns_aff, bc2s);
+            pr.aff[3] += adam_torch(gb, m_af[1], v_af[1], ns_aff, bc2s);
         }
         st[0] = step;
         losses[pi] = fabsf(residual);

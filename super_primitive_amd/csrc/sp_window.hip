@@ -72,17 +72,6 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_reduce(const SpPair* __rest
     }
 }
 
-// torch.optim.Adam (betas 0.9/0.999, eps 1e-8, no weight decay) on one fp32 scalar, in torch's operation order:
-// exp_avg.lerp_(g, 1-b1); exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2); denom = sqrt(v)/sqrt(bc2) + eps;
-// p.addcdiv_(m, denom, value=-lr/bc1).  The bias corrections are Python doubles there, cast to fp32 at the op.
-__device__ __forceinline__ float adam_torch(float g, float& m, float& v, float neg_step, float bc2s) {
-    m = m + 0.1f * (g - m);
-    v = v * 0.999f;
-    v = v + 0.001f * g * g;
-    const float denom = sqrtf(v) / bc2s + 1e-8f;
-    return neg_step * (m / denom);
-}
-
 struct WinArgs {
     const SpPair* pairs; const SpWindowEdge* edges; int n_edges;
     SpWindowNode* nodes; int n_nodes;

@@ -87,3 +87,155 @@ def map_source_against_targets(src_kf, trg_images, trg_Ks, kld, poses, steps, lr
             break
         prev = cur
     return kld.detach(), torch.stack(poses), ([a.detach() for a in affs] if affine else None), losses
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Fused engines (optim/window.py): same loops, 3 launches per iteration, no autograd graph, no torch optimiser
+# ---------------------------------------------------------------------------------------------------------------------
+def track_frame_fused(kf, kld, supp_frame, supp_T, prev_pose, steps, levels, lr=5e-3, prev_aff=None, curr_aff=None):
+    """``track_frame`` on the fused optimiser.  kf: the latest KeyFrame (full resolution), kld: its keypoint log-depths
+    (fixed while tracking); supp_frame: the frame being tracked (image + K); steps: iterations per pyramid level, coarse ->
+    fine (config ``track.steps``); levels = (pyramid_min, pyramid_max).  Returns (supp_T, curr_aff, losses)."""
+    from ..optim.window import KIND_WINDOW, PoseWindow
+    affine = prev_aff is not None
+    nodes = [dict(T=prev_pose, kind=KIND_WINDOW, aff=prev_aff if affine else None),
+             dict(T=supp_T, kind=KIND_WINDOW, lr_pose=lr, lr_aff=5e-3 if affine else 0.0, aff=curr_aff if affine else None,
+                  image=supp_frame.image, K=supp_frame.K)]
+    win = PoseWindow([dict(kf=kf, kld=kld, lr=0.0, node=0)], nodes, [(0, 1, 1.0, dense_optim.Z_MIN_SINGLE)], levels,
+                     abs_loss=False, use_affine=affine, max_iters=max(1, sum(steps)))
+    order = list(reversed(win.level_ids))
+    for li, n in enumerate(steps):
+        if n > 0:
+            win.run(order[li], n)
+    T = renormalise_se3(win.node_poses()[1].contiguous())
+    return T, (win.node_affines()[1] if affine else None), list(win.losses().unbind(0))
+
+
+def window_connectivity(n_kfs):
+    """Neighbouring keyframes only (odometery.py:451-479, mode 'map')."""
+    return {s: [t for t in (s - 1, s + 1) if 0 <= t < n_kfs] for s in range(n_kfs)}
+
+
+def _window_targets(s, n_kfs, supp):
+    """Targets of source keyframe s, in the reference's order (odometery.py:770-823): its neighbouring keyframes, then
+    its own supporting frames, then those of the previous keyframe.  Entries: ('kf', t) or ('supp', k, j)."""
+    out = [('kf', t) for t in window_connectivity(n_kfs)[s]]
+    for ss in ([s] + ([s - 1] if s > 0 else [])):
+        out += [('supp', ss, j) for j in range(len(supp[ss]))]
+    return out
+
+
+def map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose=1e-4, window_size=5, initialised=True,
+               fused=True, rel_tol=1e-8):
+    """Windowed mapping over several source keyframes (odometery/odometery.py:576-648 parameter groups, :756-915 loop,
+    ``opt_supporting`` on).
+
+    kfs: KeyFrames, oldest first; kf_poses: their camera-to-world (4,4); kf_klds: (N_k,) log-depths; kf_affs: (2,) affine
+    pairs or None (no affine compensation); supp[k]: supporting frames attached to keyframe k as (KeyFrame, pose, affine).
+    Semantics kept: relative pose ``D_trg inv(T_trg) T_src inv(D_src)`` (:793,817); the first keyframe's pose and affine are
+    fixed (:589-592,625); the oldest keyframe's depths are frozen once the window is full (:594-603); Adam groups -- log-depths
+    1e-2, poses ``lr_pose`` (1e-4, or 1e-2 at mono-init), affines 1e-5; loss = sum_src mean_targets(residual) (:845-850);
+    every iteration every pose is folded in ``T <- T inv(Exp(D))``, renormalised and its tangent zeroed (:861-882); when
+    ``initialised`` the loop stops once the relative loss change is < ``rel_tol`` (:907-915).
+    Returns dict(kf_poses (K,4,4), klds [K], affs (K,2)|None, supp_poses [[...]], supp_affs [[...]], losses, stopped)."""
+    K = len(kfs)
+    affine = kf_affs is not None
+    frozen0 = K == window_size
+    if fused:
+        return _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol)
+    return _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol)
+
+
+def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol):
+    from ..optim.window import KIND_WINDOW, PoseWindow
+    K = len(kfs)
+    lr_aff = 1e-5 if affine else 0.0
+    nodes = [dict(T=kf_poses[k], kind=KIND_WINDOW, lr_pose=lr_pose if k > 0 else 0.0, lr_aff=lr_aff if k > 0 else 0.0,
+                  aff=kf_affs[k] if affine else None, renorm=True, image=kfs[k].image, K=kfs[k].K) for k in range(K)]
+    supp_node = {}
+    for k in range(K):
+        for j, (f, pose, aff) in enumerate(supp[k]):
+            supp_node[(k, j)] = len(nodes)
+            nodes.append(dict(T=pose, kind=KIND_WINDOW, lr_pose=lr_pose, lr_aff=lr_aff, aff=aff if affine else None, renorm=True,
+                              image=f.image, K=f.K))
+    sources = [dict(kf=kfs[k], kld=kf_klds[k], lr=0.0 if (k == 0 and frozen0) else 1e-2, node=k) for k in range(K)]
+    edges = []
+    for s in range(K):
+        trg = _window_targets(s, K, supp)
+        for t in trg:
+            node = t[1] if t[0] == 'kf' else supp_node[(t[1], t[2])]
+            edges.append((s, node, 1.0 / len(trg), dense_optim.Z_MIN_BATCH))
+    win = PoseWindow(sources, nodes, edges, (0, 1), abs_loss=False, rel_tol=rel_tol if initialised else 0.0, use_affine=affine,
+                     max_iters=max(1, num_iters))
+    win.run(0, num_iters)
+    poses, affs, losses = win.node_poses(), win.node_affines(), win.losses()
+    return dict(kf_poses=poses[:K], klds=win.klds(), affs=affs[:K] if affine else None,
+                supp_poses=[[poses[supp_node[(k, j)]] for j in range(len(supp[k]))] for k in range(K)],
+                supp_affs=[[affs[supp_node[(k, j)]] for j in range(len(supp[k]))] for k in range(K)] if affine else None,
+                losses=list(losses.unbind(0)), stopped=win.iterations() - 1 if win.converged() else -1)
+
+
+def _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol):
+    """The same loop as eager PyTorch around ``photomeric_cost_batch`` (autograd + torch.optim.Adam), statement for
+    statement the reference's; kept as the engine-independent check of the fused one."""
+    K = len(kfs)
+    dev = kf_poses[0].device
+    kf_poses = [p.detach().clone() for p in kf_poses]
+    d_kf = [None] + [LieGroupParameter(SE3.Identity(1, device=dev)) for _ in range(K - 1)]
+    klds = [k.detach().clone() if (i == 0 and frozen0) else nn.Parameter(k.detach().clone()) for i, k in enumerate(kf_klds)]
+    affs = ([kf_affs[0].detach().clone()] + [nn.Parameter(a.detach().clone()) for a in kf_affs[1:]]) if affine else [None] * K
+    s_pose = [[p.detach().clone() for _, p, _ in supp[k]] for k in range(K)]
+    s_delta = [[LieGroupParameter(SE3.Identity(1, device=dev)) for _ in supp[k]] for k in range(K)]
+    s_aff = [[nn.Parameter(a.detach().clone()) for _, _, a in supp[k]] for k in range(K)] if affine else None
+    groups = [{'params': [k for k in klds if isinstance(k, nn.Parameter)], 'lr': 1e-2},
+              {'params': [d for d in d_kf if d is not None], 'lr': lr_pose}]
+    if affine:
+        groups.append({'params': affs[1:], 'lr': 1e-5})
+    groups.append({'params': [d for row in s_delta for d in row], 'lr': lr_pose})
+    if affine:
+        groups.append({'params': [a for row in s_aff for a in row], 'lr': 1e-5})
+    optim = torch.optim.Adam(groups, lr=1e-3)
+    eye = torch.eye(4, device=dev)
+    mat = lambda d: eye if d is None else d.retr().matrix()[0]
+    exp0 = lambda d: eye if d is None else se3_exp_matrix(d.detach().as_subclass(torch.Tensor))[0]
+    losses, prev, stopped = [], float('inf'), -1
+    for it in range(num_iters):
+        res = []
+        for s in range(K):
+            src_delta = mat(d_kf[s])
+            imgs, Ks, Ps, As = [], [], [], []
+            for t in _window_targets(s, K, supp):
+                if t[0] == 'kf':
+                    f, T_t, D_t, a_t = kfs[t[1]], kf_poses[t[1]], d_kf[t[1]], affs[t[1]]
+                else:
+                    f, T_t, D_t = supp[t[1]][t[2]][0], s_pose[t[1]][t[2]], s_delta[t[1]][t[2]]
+                    a_t = s_aff[t[1]][t[2]] if affine else None
+                imgs.append(f.image); Ks.append(f.K); As.append(a_t)
+                Ps.append(mat(D_t) @ invertSE3(T_t) @ kf_poses[s] @ torch.linalg.inv(src_delta))
+            out = dense_optim_batch.photomeric_cost_batch(kfs[s], torch.stack(imgs), torch.stack(Ks), klds[s], torch.stack(Ps), CFG,
+                                                          affine_comp=(affs[s], torch.stack(As)) if affine else None)
+            res.append(out['residual'].mean())
+        loss = torch.sum(torch.stack(res))
+        losses.append(loss.detach())
+        loss.backward()
+        optim.step()
+        optim.zero_grad()
+        with torch.no_grad():
+            for i in range(K):
+                kf_poses[i] = renormalise_se3((kf_poses[i] @ invertSE3(exp0(d_kf[i]))).contiguous())
+                if d_kf[i] is not None:
+                    zero_out_lietorch_tensor(d_kf[i])
+            for k in range(K):
+                for j in range(len(s_pose[k])):
+                    s_pose[k][j] = renormalise_se3((s_pose[k][j] @ invertSE3(exp0(s_delta[k][j]))).contiguous())
+                    zero_out_lietorch_tensor(s_delta[k][j])
+        if initialised:
+            cur = float(losses[-1])
+            if abs(cur - prev) / prev < rel_tol:
+                stopped = it
+                break
+            prev = cur
+    det = lambda x: x.detach().clone()
+    return dict(kf_poses=torch.stack(kf_poses), klds=[det(k) for k in klds], affs=torch.stack([det(a) for a in affs]) if affine else None,
+                supp_poses=s_pose, supp_affs=[[det(a) for a in row] for row in s_aff] if affine else None, losses=losses,
+                stopped=stopped)

@@ -11,6 +11,12 @@ Open3D GUI; those parts are out of scope.  What is kept, with th
   frame ``photomeric_cost`` with ``collect_stats`` as configured, ``loss = sum_f mean|residual|``, **no update on
   the very first iteration** (``count > 0``, ``:203``), optional per-iteration stats callback in place of the GUI
   queue (``:175-183``).
+
+``run()`` has two engines with the same semantics.  The default (no stats consumer attached) is the FUSED one
+(``optim/window.py``: cost of every support frame in one launch + ``sp_window_step`` -- Adam with torch's arithmetic on
+the log-depths and on the persistent pose tangents, the gradient of ``Exp(a) X`` by dual numbers; 3 launches per
+iteration, no autograd graph).  ``fused=False`` -- or a ``stats_callback`` / ``collect_stats > 0`` -- runs the eager loop:
+``photomeric_cost`` + autograd + ``torch.optim.Adam``, line for line the reference's.
 """
 from __future__ import annotations
 
@@ -38,6 +44,9 @@ class SfM:
         self.collect_stats = collect_stats
         self.supp_frames = [self.init_supporting_frame(f, T) for f, T in zip(support_frames, init_poses)]
         self.losses = []
+        self._stepped = False          # the very first iteration of the first run() makes no update (two_frame_sfm.py:203)
+        self._window = None
+        self._lr_scale = 1.0
 
     def init_supporting_frame(self, frame, pose_init):
         if self.opt_pose:
@@ -61,18 +70,77 @@ class SfM:
                             {'params': [pose for _, pose, _ in self.supp_frames if isinstance(pose, LieGroupParameter)], 'lr': 1e-2}]
         self.optim = torch.optim.Adam(self.adam_params, lr=1e-3)
 
-    def run(self):
+    def run(self, fused=None, lr_scale=1.0, levels=None, num_iters=None):
+        """The reference loop.  ``fused``: None = fused unless per-iteration statistics are wanted (do not switch engines
+        between calls on one object: each keeps its own Adam moments).  ``lr_scale`` scales both learning rates -- a
+        change starts a fresh Adam -- and ``levels`` restricts the pyramid levels visited (indices into the
+        coarse-to-fine pyramid); both exist for the convergence polish of the parity tests (lr/10, lr/100 on the finest
+        level, like oracle/gen_goldens_fullsize.py) and default to the reference's behaviour."""
+        if fused is None:
+            fused = self.stats_callback is None and self.collect_stats == 0
+        if fused:
+            return self._run_fused(lr_scale, levels, num_iters)
+        return self._run_eager(lr_scale, levels, num_iters)
+
+    def _run_fused(self, lr_scale, levels, num_iters):
+        from ..optim.window import KIND_DIRECT, PoseWindow
         al = self.config['aligment']
+        n_levels = al['pyramid_max'] - al['pyramid_min']
+        iters = num_iters or self.num_iters
+        win = self._window
+        if win is None:
+            nodes = []
+            for frame, current_T, _ in self.supp_frames:
+                if isinstance(current_T, LieGroupParameter):
+                    nodes.append(dict(T=current_T.group.mat[0], kind=KIND_DIRECT, lr_pose=1e-2 * lr_scale, image=frame.image, K=frame.K))
+                else:
+                    nodes.append(dict(T=current_T, kind=KIND_DIRECT, lr_pose=0.0, image=frame.image, K=frame.K))
+            win = PoseWindow([dict(kf=self.src_keyframe, kld=self.src_depth_keypoints_opt.detach(), lr=1e-3 * lr_scale, node=-1)],
+                             nodes, [(0, f, 1.0, dense_optim.Z_MIN_SINGLE) for f in range(len(nodes))],
+                             (al['pyramid_min'], al['pyramid_max']), abs_loss=True, skip_first=not self._stepped,
+                             max_iters=max(8192, 4 * iters * n_levels))
+            tang = [T.detach().as_subclass(torch.Tensor)[0] if isinstance(T, LieGroupParameter) else torch.zeros(6, device=win.device)
+                    for _, T, _ in self.supp_frames]
+            if any(bool((t != 0).any()) for t in tang):
+                win.set_tangents(torch.stack(tang))
+            self._window, self._fused_seen = win, 0
+        elif lr_scale != self._lr_scale:
+            win.reset_optimiser(lr_scale / self._lr_scale)           # a fresh Adam at the new rates
+        self._lr_scale = lr_scale
+        order = list(reversed(win.level_ids))                       # coarse -> fine, like keyframe_pyramid's list
+        for li in (range(n_levels) if levels is None else levels):
+            win.run(order[li], iters)
+        self._stepped = True
+        hist = win.losses()
+        self.losses.extend(hist[self._fused_seen:].unbind(0))
+        self._fused_seen = int(hist.shape[0])
+        with torch.no_grad():
+            self.src_depth_keypoints_opt.data.copy_(win.klds()[0])
+            tang = win.node_tangents()
+            for f, (_, current_T, _) in enumerate(self.supp_frames):
+                if isinstance(current_T, LieGroupParameter):
+                    current_T.data.copy_(tang[f][None])
+        return self
+
+    def _run_eager(self, lr_scale=1.0, levels=None, num_iters=None):
+        al = self.config['aligment']
+        if lr_scale != self._lr_scale:                               # a fresh Adam at the new rates
+            self.adam_params = [{'params': self.src_depth_keypoints_opt, 'lr': 1e-3 * lr_scale},
+                                {'params': [pose for _, pose, _ in self.supp_frames if isinstance(pose, LieGroupParameter)],
+                                 'lr': 1e-2 * lr_scale}]
+            self.optim = torch.optim.Adam(self.adam_params, lr=1e-3)
+            self._lr_scale = lr_scale
+        num_iters = num_iters or self.num_iters
         src_pyr = keyframe.keyframe_pyramid(self.src_keyframe, al['pyramid_min'], al['pyramid_max'])
         supp_pyrs = [keyframe.keyframe_pyramid(f, al['pyramid_min'], al['pyramid_max']) for f, _, _ in self.supp_frames]
         cost_params = copy.deepcopy(al.get('cost_params', {}))
         cost_params['mode'] = 'colour'
         cost_params['collect_stats'] = self.collect_stats
-        count = 0
-        for level in range(len(src_pyr)):
+        count = 1 if self._stepped else 0
+        for level in (range(len(src_pyr)) if levels is None else levels):
             src_l = src_pyr[level]
             supp_l = [p[level] for p in supp_pyrs]
-            for _ in range(self.num_iters):
+            for _ in range(num_iters):
                 outs = []
                 for fid, frame_l in enumerate(supp_l):
                     _, current_T, pose_to_mat = self.supp_frames[fid]
@@ -87,6 +155,7 @@ class SfM:
                     self.optim.step()
                     self.optim.zero_grad()
                 count += 1
+        self._stepped = True
         return self
 
     def run_on_device(self, mode="adam", iters_per_level=None, use_graph=True, **kw):

@@ -27,6 +27,12 @@ DEFAULT_SPAN_POINTS = 16384        # most points per workgroup: consecutive chun
 MIN_SPANS = 2304                   # ... but a launch should still have about this many workgroups (256 CUs x 4 x 2.25)
 GRANULE = 256                      # SP_BLOCK: every segment is padded to a multiple of it in the batch's tables
 
+# The coarse-to-fine schedule "frame pairs per second" is quoted on (bench.py) and that tests/test_gpu_fullsize.py
+# requires to land within the north-star bar (1e-4 rad / 1e-4 t / 1e-3 relative depth) of the minimiser of the
+# reference cost at 640x480x64 (golden g15): LM iterations per pyramid level with the default IRLS epsilon, then
+# ``polish_iters`` more at the finest level with the epsilon at ``polish_eps`` (see PairBatch.run).
+FRAME_PAIR_SCHEDULE = dict(iters_per_level=20, polish_iters=10, polish_eps=1e-5)
+
 
 def _level_images(img, max_level):
     """[(3,H,W) at level 0, level 1, ...] through the HIP blur+decimate kernel."""
@@ -220,6 +226,16 @@ class PairBatch:
         self.reset_lm()
         self._graphs = {}
         self._keep = (tables0,)
+        self._initial = (self.pose.clone(), self.kld.clone())
+
+    def restore_initial(self):
+        """Poses, log-depths, affine pairs and optimiser state back to what the batch was built with."""
+        self.pose.copy_(self._initial[0])
+        self.kld.copy_(self._initial[1])
+        if self.aff is not None:
+            self.aff.zero_()
+        self.adam_state.zero_()
+        self.reset_lm()
 
     # ------------------------------------------------------------------------------------------------
     @classmethod
@@ -255,6 +271,10 @@ class PairBatch:
                        "sp_pairs_gn_iterate")
             return self._costs
         self.cost_pass(level, 1, irls_eps)
+        return self.solve_gn(level, lm_up, lm_down, lm_min)
+
+    def solve_gn(self, level=0, lm_up=8.0, lm_down=0.5, lm_min=1e-7):
+        """The second launch of a Gauss-Newton iteration: per-pair reduction of the mode-1 partials + Schur-complement LM step."""
         _lib.check(self.lib.sp_pairs_gn_step(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials), _lib.ptr(self.seg_partials),
                                              float(lm_up), float(lm_down), float(lm_min), _lib.ptr(self.lm_state),
                                              _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.stream_ptr()),
@@ -270,6 +290,10 @@ class PairBatch:
                                                       _lib.ptr(self._costs), _lib.stream_ptr()), "sp_pairs_adam_iterate")
             return self._costs
         self.cost_pass(level, 0)
+        return self.solve_adam(level, lr_kld, lr_pose, lr_aff)
+
+    def solve_adam(self, level=0, lr_kld=1e-3, lr_pose=1e-2, lr_aff=5e-3):
+        """The second launch of an Adam iteration: per-pair reduction of the mode-0 partials + Adam / SE(3) retraction."""
         _lib.check(self.lib.sp_pairs_adam_step(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials), _lib.ptr(self.seg_partials),
                                                float(lr_kld), float(lr_pose), float(lr_aff), _lib.ptr(self.adam_state),
                                                _lib.ptr(self._costs), _lib.stream_ptr()), "sp_pairs_adam_step")

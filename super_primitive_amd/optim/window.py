@@ -1,0 +1,264 @@
+"""Fused optimiser of the reference's Adam loops: poses, per-keyframe log-depths and affine
+brightness pairs of a small WINDOW of frames, optimised entirely on the GPU.
+
+The reference runs three loop shapes around its cost functions -- two-frame SfM (``odometery/two_frame_sfm.py:116-207``),
+frame-to-keyframe tracking (``odometery/odometery.py:300-312,375-407``) and windowed mapping (``:576-648,756-915``) -- each
+as eager PyTorch: autograd through ``lietorch`` + ``torch.optim.Adam`` + a dozen small pose-algebra launches per
+parameter (``torch.linalg.inv``, ``renormalise_se3``, tangent zeroing).  Behind a fused cost kernel that glue is >95 % of an
+iteration.  Here one iteration of ANY of the three is
+
+    sp_pairs_cost (mode 0)      every (source keyframe -> target frame) edge of the window in ONE launch
+    sp_window_step              per-edge reduction; chain rule onto the pose tangents; Adam with torch semantics; fold-in
+                                T <- T inv(Exp(d)); renormalise; tangent reset; relative-loss early stop; next relative
+                                poses -- two launches, no host synchronisation, capturable in a hipGraph.
+
+``PoseWindow`` is the generic object; ``odometery/two_frame_sfm.py``, ``odometery/loops.py`` build it for their loop.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..segment_table import table_of
+from .pair_batch import DEFAULT_BATCH_TILE_POINTS, DEFAULT_SPAN_POINTS, GRANULE, MIN_SPANS, _level_images, build_work_list, pad_layout, pad_points
+
+KIND_WINDOW, KIND_DIRECT = 0, 1
+
+
+def _upload_struct_array(arr, device):
+    return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
+
+
+class PoseWindow:
+    def __init__(self, sources, nodes, edges, levels, abs_loss=False, skip_first=False, rel_tol=0.0, use_affine=False,
+                 max_iters=4096, tile_points=DEFAULT_BATCH_TILE_POINTS, span_points=None):
+        """sources: list of dict(kf=KeyFrame, kld=(N,) tensor, lr=float [0 = frozen], node=int [-1 = identity pose]);
+        nodes:   list of dict(T=(4,4), kind=KIND_WINDOW|KIND_DIRECT, lr_pose=float, lr_aff=float, aff=(2,)|None,
+                              renorm=bool, image=(3,H,W)|None, K=(3,3)|None)  -- image/K needed when the node is a target;
+        edges:   list of (source index, target node, weight, zmin);
+        levels:  (pyramid_min, pyramid_max) like ``config['aligment']`` (max exclusive)."""
+        lib = _lib.load()
+        self.lib = lib
+        dev = sources[0]['kf'].image.device
+        _lib.require_device(sources[0]['kf'].image)
+        self.device = dev
+        self.level_ids = list(range(levels[0], levels[1]))
+        max_level = levels[1] - 1
+        self.abs_loss, self.skip_first, self.rel_tol = int(abs_loss), int(skip_first), float(rel_tol)
+        self.n_sources, self.n_nodes, self.n_edges = len(sources), len(nodes), len(edges)
+        S, E = self.n_sources, self.n_edges
+        # ---- source keyframes: padded segment tables, per-level source samples --------------------------------
+        tables = [table_of(s['kf']) for s in sources]
+        self.Ns = [t.N for t in tables]
+        self.max_N = max(self.Ns)
+        pads = [pad_layout(t.counts, dev) for t in tables]
+        self.src4 = {}
+        for k, (s, tab) in enumerate(zip(sources, tables)):
+            lv = _level_images(s['kf'].image[:3].float(), max_level)
+            for l in self.level_ids:
+                self.src4[(k, l)] = pad_points(tab.source_level(lv[l], s['kf'].K, s['kld'].to(dev)).reshape(-1, 4), pads[k]).reshape(-1)
+        self.pix = [pad_points(t.pix, pd) for t, pd in zip(tables, pads)]          # after source_level(): validity bits set
+        self.kp_L = [t.kp_L for t in tables]
+        # ---- log-depth blocks ----------------------------------------------------------------------------------
+        n_off = np.concatenate(([0], np.cumsum(self.Ns)))
+        self.n_off = n_off
+        self.kld = torch.cat([s['kld'].detach().float().to(dev).reshape(-1) for s in sources]).contiguous()
+        self.kld_m = torch.zeros_like(self.kld)
+        self.kld_v = torch.zeros_like(self.kld)
+        blocks = (_lib.SpWindowBlock * S)()
+        for k, s in enumerate(sources):
+            blocks[k].kld = self.kld.data_ptr() + 4 * int(n_off[k])
+            blocks[k].m = self.kld_m.data_ptr() + 4 * int(n_off[k])
+            blocks[k].v = self.kld_v.data_ptr() + 4 * int(n_off[k])
+            blocks[k].N = self.Ns[k]
+            blocks[k].lr = float(s.get('lr', 0.0))
+        self._blocks_host = blocks
+        self.blocks = _upload_struct_array(blocks, dev)
+        # ---- pose nodes ----------------------------------------------------------------------------------------
+        arr = (_lib.SpWindowNode * self.n_nodes)()
+        for i, nd in enumerate(nodes):
+            T = nd['T'].detach().float().cpu().numpy().reshape(16)
+            arr[i].T = (ctypes.c_float * 16)(*T)
+            if nd.get('aff') is not None:
+                a = nd['aff'].detach().float().cpu().numpy().reshape(2)
+                arr[i].aff = (ctypes.c_float * 2)(*a)
+            arr[i].lr_pose = float(nd.get('lr_pose', 0.0))
+            arr[i].lr_aff = float(nd.get('lr_aff', 0.0))
+            arr[i].kind = int(nd.get('kind', KIND_WINDOW))
+            arr[i].flags = 1 if nd.get('renorm', False) else 0
+        self.nodes = _upload_struct_array(arr, dev)
+        # ---- target images: packed per level -------------------------------------------------------------------
+        self.trg3, self.level_hw = {}, {}
+        targets = sorted({e[1] for e in edges})
+        for i in targets:
+            img = nodes[i]['image']
+            assert img is not None and nodes[i].get('K') is not None, f"node {i} is a target but has no image / K"
+            lv = _level_images(img[:3].float().to(dev), max_level)
+            for l in self.level_ids:
+                Hl, Wl = lv[l].shape[-2:]
+                packed = torch.empty(Hl * Wl * 3, dtype=torch.float32, device=dev)
+                _lib.check(lib.sp_pack_rgb(_lib.ptr(lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(packed), _lib.stream_ptr()), "sp_pack_rgb")
+                self.trg3[(i, l)] = packed
+                self.level_hw[(i, l)] = (Hl, Wl)
+        # ---- edges = pairs of the many-pairs cost path ---------------------------------------------------------
+        earr = (_lib.SpWindowEdge * E)()
+        for e, (k, i, wgt, _z) in enumerate(edges):
+            assert 0 <= k < S and 0 <= i < self.n_nodes
+            assert nodes[i].get('kind', KIND_WINDOW) == KIND_WINDOW or sources[k].get('node', -1) < 0
+            earr[e].src_node, earr[e].trg_node, earr[e].block, earr[e].weight = int(sources[k].get('node', -1)), i, k, float(wgt)
+        self.edges = _upload_struct_array(earr, dev)
+        self.edge_list = [(int(k), int(i), float(wgt), float(z)) for k, i, wgt, z in edges]
+        epads = [pads[k] for k, _, _, _ in edges]
+        total = sum(pd['Ppad'] for pd in epads)
+        if span_points is None:
+            span_points = min(DEFAULT_SPAN_POINTS, total // MIN_SPANS)
+        self.span_points = max(int(span_points), GRANULE)
+        wl = build_work_list(epads, self.span_points, tile_points)
+        self.n_chunks, self.n_spans = len(wl['chunks']), len(wl['spans'])
+        self.chunks = torch.from_numpy(wl['chunks']).to(dev)
+        self.spans = torch.from_numpy(wl['spans']).to(dev)
+        sto_off = np.concatenate(([0], np.cumsum([len(s) for s in wl['seg_rec_offs']])))
+        self.seg_tile_off = torch.from_numpy(np.concatenate(wl['seg_rec_offs'])).to(dev)
+        self.pose_slots = torch.zeros(E, 16, dtype=torch.float32, device=dev)
+        self.aff_slots = torch.zeros(E, 4, dtype=torch.float32, device=dev) if use_affine else None
+        self.Ps = [tables[k].P for k, _, _, _ in edges]
+        self.desc = {}
+        for l in self.level_ids:
+            parr = (_lib.SpPair * E)()
+            for e, (k, i, _w, zmin) in enumerate(edges):
+                d, kf, tab = parr[e], sources[k]['kf'], tables[k]
+                d.pix = self.pix[k].data_ptr()
+                d.src4 = self.src4[(k, l)].data_ptr()
+                d.kp_L = self.kp_L[k].data_ptr()
+                d.trg3 = self.trg3[(i, l)].data_ptr()
+                d.kld = self.kld.data_ptr() + 4 * int(n_off[k])
+                d.pose = self.pose_slots.data_ptr() + 64 * e
+                d.aff = (self.aff_slots.data_ptr() + 16 * e) if use_affine else None
+                d.seg_tile_off = self.seg_tile_off.data_ptr() + 4 * int(sto_off[e])
+                Ks = kf.K.detach().float().cpu().numpy()
+                Kt = nodes[i]['K'].detach().float().cpu().numpy()
+                d.K_src = (ctypes.c_float * 4)(Ks[0, 0], Ks[1, 1], Ks[0, 2], Ks[1, 2])
+                d.K_trg = (ctypes.c_float * 4)(Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
+                d.N, d.P, d.H, d.W = tab.N, tab.P, tab.H, tab.W
+                d.Hl, d.Wl = self.level_hw[(i, l)]
+                d.tile0, d.n_tiles = int(wl['s_off'][e]), int(wl['s_off'][e + 1] - wl['s_off'][e])
+                d.zmin = float(zmin)
+                d.rec0 = 4 * int(wl['c_off'][e])
+            self.desc[l] = _upload_struct_array(parr, dev)
+        # ---- workspaces / optimiser state ----------------------------------------------------------------------
+        self.partials = torch.empty(self.n_spans * _lib.SP_GRAD_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+        self.seg_partials = torch.empty(4 * self.n_chunks * _lib.SP_GRAD_SEG_FLOATS, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(lib.sp_window_scratch_doubles(E, self.max_N), dtype=torch.float64, device=dev)
+        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.max_iters = int(max_iters)
+        self.loss_hist = torch.zeros(self.max_iters, dtype=torch.float32, device=dev)
+        self._graphs = {}
+        self._keep = (tables, pads)
+        self.compose()
+
+    # ----------------------------------------------------------------------------------------------------------
+    def compose(self):
+        l = self.level_ids[0]
+        _lib.check(self.lib.sp_window_compose(_lib.ptr(self.desc[l]), _lib.ptr(self.edges), self.n_edges, _lib.ptr(self.nodes),
+                                              self.n_nodes, _lib.stream_ptr()), "sp_window_compose")
+
+    def step(self, level):
+        """One Adam iteration of the whole window at pyramid ``level`` (3 launches, nothing returns to the host)."""
+        d = self.desc[level]
+        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(d), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, 0, 0.0,
+                                          _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.stream_ptr()), "sp_pairs_cost")
+        _lib.check(self.lib.sp_window_step(_lib.ptr(d), _lib.ptr(self.edges), self.n_edges, _lib.ptr(self.nodes), self.n_nodes,
+                                           _lib.ptr(self.blocks), self.n_sources, self.max_N, _lib.ptr(self.partials),
+                                           _lib.ptr(self.seg_partials), _lib.ptr(self.scratch), self.abs_loss, self.skip_first,
+                                           self.rel_tol, _lib.ptr(self.state), _lib.ptr(self.loss_hist), self.max_iters,
+                                           _lib.stream_ptr()), "sp_window_step")
+
+    def run(self, level, iters, graph_chunk=25):
+        """``iters`` iterations at ``level``.  ``graph_chunk`` > 0: iterations are replayed from a hipGraph holding that
+        many (launch overhead off the critical path); with an early-stop tolerance the converged flag is polled between
+        replays -- a frozen window ignores the remaining launches, so results do not depend on the chunking."""
+        done = 0
+        if graph_chunk and iters >= 2 * graph_chunk:
+            g = self._graphs.get((level, graph_chunk))
+            if g is None:
+                self.step(level)                      # warm-up outside capture (module load); it is a real iteration
+                done += 1
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(graph_chunk):
+                        self.step(level)
+                self._graphs[(level, graph_chunk)] = g
+            while iters - done >= graph_chunk:
+                g.replay()
+                done += graph_chunk
+                if self.rel_tol > 0 and self.converged():
+                    return
+        for _ in range(iters - done):
+            self.step(level)
+
+    def set_tangents(self, a):
+        """Overwrite the (n_nodes, 6) tangents (resuming a persistent-tangent run)."""
+        arr = self._node_array()
+        a = a.detach().float().cpu().numpy()
+        for i, nd in enumerate(arr):
+            nd.a = (ctypes.c_float * 6)(*a[i])
+        self.nodes.copy_(_upload_struct_array(arr, self.device))
+        self.compose()
+
+    def reset_optimiser(self, lr_scale=None):
+        """A fresh Adam (zero moments and step count), like constructing a new torch optimiser over the same parameters."""
+        arr = self._node_array()
+        for nd in arr:
+            nd.m = (ctypes.c_float * 6)(); nd.v = (ctypes.c_float * 6)()
+            nd.aff_m = (ctypes.c_float * 2)(); nd.aff_v = (ctypes.c_float * 2)()
+            if lr_scale is not None:
+                nd.lr_pose *= lr_scale; nd.lr_aff *= lr_scale
+        self.nodes.copy_(_upload_struct_array(arr, self.device))
+        if lr_scale is not None:
+            for bk in self._blocks_host:
+                bk.lr *= lr_scale
+            self.blocks.copy_(_upload_struct_array(self._blocks_host, self.device))
+        self.kld_m.zero_(); self.kld_v.zero_()
+        self.state[0] = 0.0
+
+    # ---- results -----------------------------------------------------------------------------------------------
+    def converged(self):
+        return bool(self.state[3].item() != 0)
+
+    def iterations(self):
+        return int(self.state[1].item())
+
+    def losses(self):
+        return self.loss_hist[: min(self.iterations(), self.max_iters)].clone()
+
+    def _node_array(self):
+        raw = self.nodes.cpu().numpy().tobytes()
+        return (_lib.SpWindowNode * self.n_nodes).from_buffer_copy(raw)
+
+    def node_poses(self):
+        """(n_nodes,4,4): kind 0 -> the folded-in pose T; kind 1 -> Exp(a) X."""
+        arr = self._node_array()
+        out = []
+        for nd in arr:
+            T = torch.tensor(list(nd.T), dtype=torch.float32).reshape(4, 4)
+            if nd.kind == KIND_DIRECT:
+                from ..lie.se3 import se3_exp_matrix
+                T = (se3_exp_matrix(torch.tensor(list(nd.a), dtype=torch.float64)[None])[0] @ T.double()).float()
+            out.append(T)
+        return torch.stack(out).to(self.device)
+
+    def node_tangents(self):
+        return torch.tensor([list(nd.a) for nd in self._node_array()], dtype=torch.float32, device=self.device)
+
+    def node_affines(self):
+        return torch.tensor([list(nd.aff) for nd in self._node_array()], dtype=torch.float32, device=self.device)
+
+    def klds(self):
+        return [self.kld[self.n_off[k]: self.n_off[k + 1]].clone() for k in range(self.n_sources)]
+
+    def edge_poses(self):
+        return self.pose_slots.reshape(-1, 4, 4).clone()

@@ -97,7 +97,7 @@ def _grid_shape(N):
 
 
 def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
-              motion_scale=1.0, init_sigma=0.02, texture_period_px=14.0,
+              motion_scale=1.0, init_sigma=0.02, texture_period_px=None,
               drop_border=0):
     """Render one seeded source/target pair.
 
@@ -105,7 +105,14 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
     random overlapping ellipses (emulates SAM masks, rho > 1, ragged sizes).
     ``overlap``: grow each grid tile by this many pixels on every side.
     ``drop_border``: leave an unsegmented band of this many pixels.
+    ``texture_period_px``: shortest period of the band-limited texture (the six components per channel span 1x ... 2.9x
+    of it).  Default: 14 px up to 320 columns, scaled with the width above (28 px at 640x480) -- the random depth seeds
+    ``log(2 + 2 rand)`` (two_frame_sfm.py:103-105) put a segment up to a factor 2 off in depth, i.e. ~8 px of disparity
+    at 640x480; with a texture period that does not grow with the resolution such a segment starts outside the basin of
+    attraction even at the coarsest of 3 pyramid levels, for the reference's Adam as for Gauss-Newton.
     """
+    if texture_period_px is None:
+        texture_period_px = 14.0 * max(1.0, W / 320.0)
     rng = np.random.default_rng(seed)
     fx = fy = 0.8 * W
     cx, cy = W / 2.0, H / 2.0
@@ -226,10 +233,12 @@ class SynthFrame:
     kld_gt: np.ndarray | None = None
 
 
-def make_sequence(H, W, N, twists, keyframe_ids, seed=0, overlap=0, texture_period_px=14.0):
+def make_sequence(H, W, N, twists, keyframe_ids, seed=0, overlap=0, texture_period_px=None):
     """Frames of ONE textured plane seen from cameras ``T_wc[k] = Exp(twists[k])`` (world = camera of the zero twist).
     Frames listed in ``keyframe_ids`` also get an N-segment grid tiling with per-segment log-depths (the same
     construction as ``make_pair``); the others are supporting frames (image + K only).  Returns [SynthFrame]."""
+    if texture_period_px is None:
+        texture_period_px = 14.0 * max(1.0, W / 320.0)
     rng = np.random.default_rng(seed)
     fx = fy = 0.8 * W
     cx, cy = W / 2.0, H / 2.0

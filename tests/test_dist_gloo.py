@@ -61,3 +61,121 @@ def test_shard_range_is_a_balanced_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _void_worker(rank, world, port, out):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    from super_primitive_amd import dist as spd
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        sums = torch.randint(0, 2 ** 40, (48 * 64,), generator=g, dtype=torch.int64)
+        counts = torch.randint(0, 3, (48 * 64,), generator=g, dtype=torch.int32)
+        mine = (sums.clone(), counts.clone())
+        spd.reduce_depth_accumulators(sums, counts)
+        out.put((rank, mine[0], mine[1], sums, counts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_void_segment_sharding_collective_world2():
+    """The one collective of segment-sharded depth completion: integer SUM of the per-pixel depth
+    sums and counts.  Both ranks end up with bitwise the single-rank accumulators; validity is OR-ed (count > 0)."""
+    import torch
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_void_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    S = got[0][1] + got[1][1]
+    C = got[0][2] + got[1][2]
+    for _, _, _, s, c in got:
+        assert torch.equal(s, S) and torch.equal(c, C)
+    assert torch.equal(C > 0, (got[0][2] > 0) | (got[1][2] > 0))
+
+
+def test_segment_shards_partition_the_keyframe():
+    from super_primitive_amd import dist as spd
+    for n, world in ((1200, 8), (5, 8), (64, 3)):
+        ranges = [spd.shard_range(n, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+        sizes = [hi - lo for lo, hi in ranges]
+        assert max(sizes) - min(sizes) <= 1
+
+
+class _FakeBatch:
+    """What bench.main() touches of a PairBatch, without a GPU: the N > 1 control flow is what is rehearsed."""
+
+    def __init__(self, M):
+        self.M, self.Ps, self.max_N, self.span_points = M, [1000] * M, 4, 256
+        self.pose = torch.eye(4).reshape(1, 16).repeat(M, 1).contiguous()
+        self.kld = torch.zeros(M * 4)
+        self.calls = 0
+
+    def cost_pass(self, level, mode, irls_eps=1e-3):
+        self.calls += 1
+
+    def solve_gn(self, level=0):
+        self.pose += 1.0
+
+    solve_adam = solve_gn
+
+    def gn_step(self, level=0):
+        self.cost_pass(level, 1)
+        self.solve_gn(level)
+
+    adam_step = gn_step
+
+    def algorithmic_bytes(self, level):
+        return 20 * sum(self.Ps)
+
+
+def _bench_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import contextlib
+    import io
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    fake = _FakeBatch(6)
+    bench.build_batch = lambda args, rank, dev: (fake, [])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "2", "--settle-ms", "0", "--dry-run"])
+    out = buf.getvalue().strip()
+    q.put((rank, json.loads(out) if out else None, fake.calls))
+
+
+def test_bench_multi_rank_control_flow_dry_run_world2():
+    """bench.py's N > 1 path (process group, barriers, MAX all_reduce of the timers, final all_gather of poses and log-depths,
+    rank-0-only JSON line) executed once under gloo with the batch mocked -- so that path has run before a real 8-GPU node
+    sees it.  No measurement is made."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    line0, line1 = got[0][1], got[1][1]
+    assert line1 is None, "only rank 0 prints"
+    assert line0["n_gpus"] == 2 and line0["steps"] == 3 and line0["warmup"] == 2 and line0["scaling"] == "weak"
+    assert line0["config"]["pairs_per_gpu"] == 6 and line0["data"].startswith("DRY RUN")
+    np.testing.assert_allclose(line0["value"], 2 * 6 * 3 / (line0["ms_per_step"] * 3e-3), rtol=1e-6)     # whole-job aggregate
+    assert got[0][2] == got[1][2] == 2 + 3                                                            # warm-up + timed cost passes

@@ -1,6 +1,7 @@
 """-m gpu: the HIP cost path (through the C ABI) against (a) golden vectors produced by the real reference and
 (b) the CPU oracle on fresh seeded inputs.  Tolerances (fp32, different exp / reduction order than ATen-CPU):
-residual rtol 2e-5; per-point values atol 2e-5; gradients rtol 2e-3 of the largest entry."""
+residual rtol 2e-5; per-point values atol 2e-5; gradients within 5e-6 of the largest entry (measured: 1.1e-6 worst over
+the reference goldens, profiles/r02_parity.txt; the reference's own fp32 autograd is that far from the exact value)."""
 import numpy as np
 import pytest
 import torch
@@ -12,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 COST_CASES = ["g1_grid_48x64", "g1_blobs_affine_60x80", "g1_pyramid_72x96", "g1_behind_camera_48x64", "g1_odd_45x67"]
 CFG2 = {"mode": "colour", "collect_stats": 2}
+GRAD_TOL = 5e-6     # of the largest entry; ~5x the worst measured against the reference goldens
 
 
 def close_rel_max(got, want, rtol, what):
@@ -53,12 +55,12 @@ def test_cost_matches_reference_goldens(name):
         np.testing.assert_allclose(npy(out["src_in_trg_keypoints"]), g[p + "src_in_trg_keypoints"], rtol=1e-4, atol=1e-3)
         assert out["median_depth"] is None
         # gradients
-        close_rel_max(npy(kld.grad), g[p + "g_kld"], 2e-3, "g_kld")
-        close_rel_max(npy(pose.grad), g[p + "g_pose"], 2e-3, "g_pose")
+        close_rel_max(npy(kld.grad), g[p + "g_kld"], GRAD_TOL, "g_kld")
+        close_rel_max(npy(pose.grad), g[p + "g_pose"], GRAD_TOL, "g_pose")
         assert np.all(npy(pose.grad)[3] == 0)
         if aff is not None:
-            close_rel_max(npy(aff[0].grad), g[p + "g_aff_src"], 2e-3, "g_aff_src")
-            close_rel_max(npy(aff[1].grad), g[p + "g_aff_trg"], 2e-3, "g_aff_trg")
+            close_rel_max(npy(aff[0].grad), g[p + "g_aff_src"], GRAD_TOL, "g_aff_src")
+            close_rel_max(npy(aff[1].grad), g[p + "g_aff_trg"], GRAD_TOL, "g_aff_trg")
 
 
 def test_precomputed_matches_reference_goldens():
@@ -77,9 +79,9 @@ def test_precomputed_matches_reference_goldens():
     out = dense_optim.photomeric_cost_precomputed(pre, trg, pose, {"mode": "colour", "collect_stats": 0}, affine_comp=(a0, a1))
     out["residual"].mean().backward()
     np.testing.assert_allclose(npy(out["residual"]), g["residual"], rtol=2e-5)
-    close_rel_max(npy(pose.grad), g["g_pose"], 2e-3, "g_pose")
-    close_rel_max(npy(a0.grad), g["g_aff_src"], 2e-3, "g_aff_src")
-    close_rel_max(npy(a1.grad), g["g_aff_trg"], 2e-3, "g_aff_trg")
+    close_rel_max(npy(pose.grad), g["g_pose"], GRAD_TOL, "g_pose")
+    close_rel_max(npy(a0.grad), g["g_aff_src"], GRAD_TOL, "g_aff_src")
+    close_rel_max(npy(a1.grad), g["g_aff_trg"], GRAD_TOL, "g_aff_trg")
 
 
 def test_batch_matches_reference_goldens():
@@ -96,10 +98,10 @@ def test_batch_matches_reference_goldens():
     np.testing.assert_allclose(npy(out["residual"]), g["residual"], rtol=2e-5)
     assert_masks_close(npy(out["full_mask"]), g["full_mask"], 3, "full_mask")
     np.testing.assert_allclose(npy(out["src_in_trg_pts"]), g["src_in_trg_pts"], rtol=1e-5, atol=2e-6)
-    close_rel_max(npy(kld.grad), g["g_kld"], 2e-3, "g_kld")
-    close_rel_max(npy(P.grad), g["g_pose"], 2e-3, "g_pose")
-    close_rel_max(npy(a0.grad), g["g_aff_src"], 2e-3, "g_aff_src")
-    close_rel_max(npy(a1.grad), g["g_aff_trg"], 2e-3, "g_aff_trg")
+    close_rel_max(npy(kld.grad), g["g_kld"], GRAD_TOL, "g_kld")
+    close_rel_max(npy(P.grad), g["g_pose"], GRAD_TOL, "g_pose")
+    close_rel_max(npy(a0.grad), g["g_aff_src"], GRAD_TOL, "g_aff_src")
+    close_rel_max(npy(a1.grad), g["g_aff_trg"], GRAD_TOL, "g_aff_trg")
 
 
 @pytest.mark.parametrize("shape,hwn,seed", [("grid", (120, 160, 12), 5), ("blobs", (96, 128, 20), 6), ("grid", (37, 53, 3), 7)])
@@ -126,10 +128,10 @@ def test_cost_matches_oracle_on_fresh_inputs(shape, hwn, seed):
     out = dense_optim.photomeric_cost(src, trg, kld, pose, {"mode": "colour", "collect_stats": 0}, affine_comp=aff)
     out["residual"].abs().mean().backward()
     np.testing.assert_allclose(npy(out["residual"]), oout["residual"].detach().numpy(), rtol=2e-5)
-    close_rel_max(npy(kld.grad), okld.grad.numpy(), 2e-3, "g_kld")
-    close_rel_max(npy(pose.grad), opose.grad.numpy(), 2e-3, "g_pose")
-    close_rel_max(npy(aff[0].grad), oaff[0].grad.numpy(), 2e-3, "g_aff_src")
-    close_rel_max(npy(aff[1].grad), oaff[1].grad.numpy(), 2e-3, "g_aff_trg")
+    close_rel_max(npy(kld.grad), okld.grad.numpy(), 2e-5, "g_kld")
+    close_rel_max(npy(pose.grad), opose.grad.numpy(), 2e-5, "g_pose")
+    close_rel_max(npy(aff[0].grad), oaff[0].grad.numpy(), 2e-5, "g_aff_src")
+    close_rel_max(npy(aff[1].grad), oaff[1].grad.numpy(), 2e-5, "g_aff_trg")
 
 
 def test_bitwise_reproducible_and_tile_size_invariant():

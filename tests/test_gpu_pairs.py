@@ -14,6 +14,7 @@ from conftest import load_golden
 from gpu_util import T, frames_from_golden, npy
 
 pytestmark = pytest.mark.gpu
+ADAM_KLD_TOL, ADAM_POSE_TOL = 2.5e-5, 5e-5     # ~5x the measured 4.2e-6 / 9.3e-6 after 12 steps (profiles/r02_parity.txt)
 
 
 def make_batch(pairs, **kw):
@@ -213,9 +214,11 @@ def test_adam_step_matches_oracle_loop():
         # near zero are amplified to O(lr) parameter differences, so trajectories are compared at lr scale
         # (SURVEY.md §8(c) "Tolerances"); the first loss values, before any amplification, must agree tightly.
         np.testing.assert_allclose([l[m] for l in losses][:3], ref_losses[:3], rtol=2e-5)
+        print(f"adam-step parity pair {m}: loss rel {np.abs(np.array([l[m] for l in losses]) / np.array(ref_losses) - 1).max():.2e} "
+              f"kld {np.abs(got_kld[m] - kld.detach().numpy()).max():.2e} pose {np.abs(got_pose[m] - pose.numpy()).max():.2e}")
         np.testing.assert_allclose([l[m] for l in losses], ref_losses, rtol=3e-3)
-        np.testing.assert_allclose(got_kld[m], kld.detach().numpy(), atol=2e-3)
-        np.testing.assert_allclose(got_pose[m], pose.numpy(), atol=2e-3)
+        np.testing.assert_allclose(got_kld[m], kld.detach().numpy(), atol=ADAM_KLD_TOL)
+        np.testing.assert_allclose(got_pose[m], pose.numpy(), atol=ADAM_POSE_TOL)
 
 
 def test_evaluate_matches_single_pair_api():
