@@ -323,12 +323,7 @@ def main(argv=None):
             line["frame_pair_schedule"] = "3 levels (coarse to fine) x 500 Adam iterations (the reference's budget, two_frame_sfm.py:128)"
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
-        threads = torch.get_num_threads()
-        v = cpu_baseline(pairs[0], args.cpu_iters)
-        line["cpu_baseline"] = {"value": v, "unit": "iters/s", "cores": threads, "kind": "port",
-                                "sample": f"{args.cpu_iters} Adam iterations (dense-layout cost + autograd backward + "
-                                          f"Adam.step, the reference's algorithm restated in oracle/) of ONE 640x480x64 "
-                                          f"pair at level 0, torch CPU, {threads} threads, after 1 warm-up"}
+        line["cpu_baseline"] = cpu_baseline(pairs[0], args.cpu_iters)
     if rank == 0:
         print(json.dumps(line))
     if dist is not None:

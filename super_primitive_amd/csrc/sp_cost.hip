@@ -468,7 +468,8 @@ __device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ r
 }
 
 // ABL (developer ablation, only reachable through mode >= 10 of sp_pairs_cost): 0 = product kernel,
-// 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation)
+// 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation),
+// 3 (mode 1 only) = the four tap loads made lane-consecutive (coalesced) instead of gathered
 template <int ABL, bool WT>
 __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
                                             int n_chunks, int total, float irls_eps, float* __restrict__ span_rec,
@@ -513,7 +514,17 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
         f32x3 ta, tb, tc, td;
         if (ABL == 1) { ta = tb = tc = td = f32x3{nx.srg.x, nx.srg.y, nx.sb}; }
-        else {
+        else if (ABL == 3) {
+            // same four 12-byte loads per point, same data volume and real image values, but lane-consecutive texels
+            // (fully coalesced): what the bilinear footprint would cost if it were not a gather
+            const uint32_t lin = (op >> 2) * (4u * SP_TEXEL_FLOATS);
+            const uint32_t cap = (uint32_t)(c.Wl * (c.Hl - 2)) * (4u * SP_TEXEL_FLOATS);
+            const uint32_t o0 = lin < cap ? lin : lin - cap * (lin / cap);
+            ta = buf_load3(r_trg, o0);
+            tb = buf_load3(r_trg, o0 + 4u * SP_TEXEL_FLOATS);
+            tc = buf_load3(r_trg, o0 + c.row_bytes);
+            td = buf_load3(r_trg, o0 + c.row_bytes + 4u * SP_TEXEL_FLOATS);
+        } else {
             ta = buf_load3(r_trg, nx.off0);
             tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
             tc = buf_load3(r_trg, nx.off1);
@@ -958,7 +969,7 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
 int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                   float* partials, float* seg_partials, void* stream) {
     if (!pairs || !chunks || !spans || !partials || !seg_partials || n_spans <= 0) return SP_EINVAL;
-    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 13)) return SP_EINVAL;
+    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 14)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_spans + 7) / 8) * 8;
     const int4* c4 = reinterpret_cast<const int4*>(chunks);
@@ -972,6 +983,8 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spa
         hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 11)
         hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
+    else if (mode == 14)
+        hipLaunchKernelGGL((k_cost_pairs<1, 3>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 12)
         hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else
