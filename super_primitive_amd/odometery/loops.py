@@ -92,21 +92,28 @@ def map_source_against_targets(src_kf, trg_images, trg_Ks, kld, poses, steps, lr
 # ---------------------------------------------------------------------------------------------------------------------
 # Fused engines (optim/window.py): same loops, 3 launches per iteration, no autograd graph, no torch optimiser
 # ---------------------------------------------------------------------------------------------------------------------
-def track_frame_fused(kf, kld, supp_frame, supp_T, prev_pose, steps, levels, lr=5e-3, prev_aff=None, curr_aff=None):
+def track_frame_fused(kf, kld, supp_frame, supp_T, prev_pose, steps, levels, lr=5e-3, prev_aff=None, curr_aff=None, polish=()):
     """``track_frame`` on the fused optimiser.  kf: the latest KeyFrame (full resolution), kld: its keypoint log-depths
     (fixed while tracking); supp_frame: the frame being tracked (image + K); steps: iterations per pyramid level, coarse ->
-    fine (config ``track.steps``); levels = (pyramid_min, pyramid_max).  Returns (supp_T, curr_aff, losses)."""
+    fine (config ``track.steps``); levels = (pyramid_min, pyramid_max).  ``polish``: optional extra phases
+    ((lr scale, iterations), ...) on the finest level, each with a fresh Adam -- not part of the reference's schedule, used to
+    obtain a converged result (lr 5e-3 Adam keeps jittering ~1e-3 around the optimum).  Returns (supp_T, curr_aff, losses)."""
     from ..optim.window import KIND_WINDOW, PoseWindow
     affine = prev_aff is not None
     nodes = [dict(T=prev_pose, kind=KIND_WINDOW, aff=prev_aff if affine else None),
              dict(T=supp_T, kind=KIND_WINDOW, lr_pose=lr, lr_aff=5e-3 if affine else 0.0, aff=curr_aff if affine else None,
                   image=supp_frame.image, K=supp_frame.K)]
     win = PoseWindow([dict(kf=kf, kld=kld, lr=0.0, node=0)], nodes, [(0, 1, 1.0, dense_optim.Z_MIN_SINGLE)], levels,
-                     abs_loss=False, use_affine=affine, max_iters=max(1, sum(steps)))
+                     abs_loss=False, use_affine=affine, max_iters=max(1, sum(steps) + sum(n for _, n in polish)))
     order = list(reversed(win.level_ids))
     for li, n in enumerate(steps):
         if n > 0:
             win.run(order[li], n)
+    scale0 = 1.0
+    for scale, n in polish:
+        win.reset_optimiser(scale / scale0)
+        scale0 = scale
+        win.run(order[-1], n)
     T = renormalise_se3(win.node_poses()[1].contiguous())
     return T, (win.node_affines()[1] if affine else None), list(win.losses().unbind(0))
 

@@ -31,7 +31,7 @@ GRANULE = 256                      # SP_BLOCK: every segment is padded to a mult
 # requires to land within the north-star bar (1e-4 rad / 1e-4 t / 1e-3 relative depth) of the minimiser of the
 # reference cost at 640x480x64 (golden g15): LM iterations per pyramid level with the default IRLS epsilon, then
 # ``polish_iters`` more at the finest level with the epsilon at ``polish_eps`` (see PairBatch.run).
-FRAME_PAIR_SCHEDULE = dict(iters_per_level=20, polish_iters=10, polish_eps=1e-5)
+FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps=1e-5)
 
 
 def _level_images(img, max_level):

@@ -182,19 +182,24 @@ def test_config3_tracking_300_steps_at_size():
     frames, est, klds, affs, kfs = config3_inputs(g)
     dev = kfs[0].image.device
     supp = KeyFrame(T(frames[1].image), T(frames[1].K))
-    supp_T, aff, losses = track_frame_fused(kfs[0], T(frames[0].kld_gt), supp, T(est[1]), T(est[0]), [0, 0, int(g["track_steps"])], (0, 3),
-                                            lr=5e-3, prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
+    n = int(g["track_steps"])
+    supp_T, aff, losses = track_frame_fused(kfs[0], T(frames[0].kld_gt), supp, T(est[1]), T(est[0]), [0, 0, n], (0, 3), lr=5e-3,
+                                            prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev),
+                                            polish=((0.1, 200), (0.01, 200)))
     L = np.array([float(l) for l in losses])
-    assert L.shape == g["track_losses"].shape
-    np.testing.assert_allclose(L[0], g["track_losses"][0], rtol=2e-6)
-    np.testing.assert_allclose(L[:3], g["track_losses"][:3], rtol=2e-5)
-    # (lr 5e-3 Adam keeps jittering around the optimum: compare the level of the tail, not one sample of it)
-    np.testing.assert_allclose(L[-50:].mean(), g["track_losses"][-50:].mean(), rtol=0.1)
-    assert rot_angle(npy(supp_T), g["track_supp_T"]) <= 1e-4
-    np.testing.assert_allclose(npy(supp_T)[:3, 3], g["track_supp_T"][:3, 3], atol=1e-4)
-    np.testing.assert_allclose(npy(aff), g["track_aff"], atol=2e-4)
-    # and the tracked pose is the true one (camera-to-world of frame 1), to what lr-5e-3 Adam jitter allows
-    assert rot_angle(npy(supp_T), g["track_gt_T"]) < 2e-3
+    want = np.concatenate([g["track_losses"], g["track_polished_losses"]])
+    assert L.shape == want.shape
+    np.testing.assert_allclose(L[0], want[0], rtol=2e-6)
+    np.testing.assert_allclose(L[:3], want[:3], rtol=2e-5)
+    np.testing.assert_allclose(L[:12], want[:12], rtol=1e-3)
+    # lr 5e-3 Adam keeps jittering ~1e-3 around the optimum (the reference's 300-step end state is 8e-4 rad from a rerun of
+    # itself in another summation order): the level of the tail is compared there, the pose after the converging phases
+    np.testing.assert_allclose(L[n - 50:n].mean(), want[n - 50:n].mean(), rtol=0.1)
+    np.testing.assert_allclose(L[-1], want[-1], rtol=1e-3)
+    assert rot_angle(npy(supp_T), g["track_polished_supp_T"]) <= 1e-4
+    np.testing.assert_allclose(npy(supp_T)[:3, 3], g["track_polished_supp_T"][:3, 3], atol=1e-4)
+    np.testing.assert_allclose(npy(aff), g["track_polished_aff"], atol=2e-4)
+    assert rot_angle(npy(supp_T), g["track_gt_T"]) < 1e-3
 
 
 @pytest.mark.parametrize("fused", [True, False])

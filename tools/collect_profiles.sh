@@ -21,3 +21,9 @@ python tools/run_configs.py 2>/dev/null | grep config > $OUT/configs.txt
 for i in $(seq 1 24); do sleep 1; rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|Package Power" | sed "s/.*: //" | tr "\n" " "; echo; done > $OUT/power_clock_trace.txt
 wait
 ls $OUT
+# BASELINE configs[4]'s pair shape (128 segments per keyframe): bench line + kernel stats of the same command
+python bench.py --segments 128 --no-cpu-baseline > $OUT/bench_n1_seg128.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats128 -o bench -- python bench.py --segments 128 --no-cpu-baseline --no-extras > /dev/null 2>&1
+python tools/parity_report.py > $OUT/parity.txt 2>/dev/null
+python tools/power_by_mode.py --modes 1,14,11,13,0 --seconds 4 2>/dev/null | grep mode > $OUT/power_by_mode.txt
+ls $OUT

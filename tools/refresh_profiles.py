@@ -59,8 +59,11 @@ with open(f"{P}/{rnd}_bench_n1_pmc_cost_kernel.csv", "w") as f:
 for a, b in [("bench_n1.json", "bench_n1.json"), ("bench_n1_adam.json", "bench_n1_adam.json"),
              ("bench_under_rocprof.json", "bench_n1_under_rocprof.json"), ("bench_long.json", "bench_n1_long_run.json"),
              ("stats/bench_kernel_stats.csv", "bench_n1_kernel_stats.csv"), ("kbench_ablation.txt", "kbench_ablation.txt"),
-             ("configs.txt", "configs.txt")]:
-    shutil.copy(f"{R}/{a}", f"{P}/{rnd}_{b}")
+             ("configs.txt", "configs.txt"), ("bench_n1_seg128.json", "bench_n1_seg128.json"),
+             ("stats128/bench_kernel_stats.csv", "bench_n1_seg128_kernel_stats.csv"), ("parity.txt", "parity.txt"),
+             ("power_by_mode.txt", "power_by_mode.txt")]:
+    if os.path.exists(f"{R}/{a}"):
+        shutil.copy(f"{R}/{a}", f"{P}/{rnd}_{b}")
 with open(f"{P}/{rnd}_power_clock_trace.txt", "w") as f:
     f.write("# sclk and socket package power (W), sampled once a second with rocm-smi across `python bench.py --steps 16000`\n"
             "# (16 s of GN steps, idle before and after)\n")

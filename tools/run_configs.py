@@ -15,7 +15,7 @@ from super_primitive_amd import synth
 from super_primitive_amd.core import dense_optim
 from super_primitive_amd.image.keyframe import KeyFrame, keyframe_pyramid
 from super_primitive_amd.odometery.two_frame_sfm import SfM
-from super_primitive_amd.odometery.loops import track_frame, map_source_against_targets
+from super_primitive_amd.odometery.loops import track_frame, track_frame_fused, map_window
 from super_primitive_amd.odometery.depth_init import segment_based_depth_reinit
 from super_primitive_amd.depth_completion.segment_based_completion import average_visible_segments
 from super_primitive_amd.lie.lie_algebra import invertSE3
@@ -39,11 +39,12 @@ def rot_err(A, B):
 p = synth.make_pair(240, 320, 8, seed=1, init_sigma=0.01)
 src, trg = frames(p)
 cfg = {"aligment": {"pyramid_min": 0, "pyramid_max": 3, "cost_params": {}}}
-sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=5); sfm.init_optimisation(kld_init=t(p.kld_init)); sfm.run()
-sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=200); sfm.init_optimisation(kld_init=t(p.kld_init))
-dt = sync_time(sfm.run)
-print(f"config 1  320x240x8: HIP drop-in API loop {600/dt:.0f} Adam it/s (3 levels x 200) "
-      f"| final loss {float(sfm.losses[-1]):.4f} from {float(sfm.losses[0]):.4f}")
+for fused in (True, False):
+    sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=5); sfm.init_optimisation(kld_init=t(p.kld_init)); sfm.run(fused=fused)
+    sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=500); sfm.init_optimisation(kld_init=t(p.kld_init))
+    dt = sync_time(lambda: sfm.run(fused=fused))
+    print(f"config 1  320x240x8: drop-in SfM driver, {'fused optimiser (3 launches / iteration)' if fused else 'eager (autograd + torch Adam)'}: "
+          f"{1500/dt:.0f} Adam it/s (3 levels x 500, the reference budget) | loss {float(sfm.losses[0]):.4f} -> {float(sfm.losses[-1]):.4f}")
 
 # ---- config 3: TUM-shaped tracking + mapping ------------------------------------------------------------
 H, W, N = 224, 288, 40
@@ -60,8 +61,16 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 supp_T, _, losses = track_frame(*args, lr=5e-3, prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 est = invertSE3(supp_T).cpu().numpy()
-print(f"config 3  tracking 224x288x{N}, 300 Adam steps/frame through the API: {dt*1e3:.0f} ms/frame ({300/dt:.0f} it/s), "
-      f"loss {float(losses[0]):.4f} -> {float(losses[-1]):.4f}, rot err {rot_err(est, p.pose_gt):.2e} rad, t err {np.abs(est[:3,3]-p.pose_gt[:3,3]).max():.2e}")
+print(f"config 3  tracking 224x288x{N}, 300 Adam steps/frame, eager (precomputed dict -> 24 B/point list + autograd + torch Adam): {dt*1e3:.0f} ms/frame "
+      f"({300/dt:.0f} it/s), loss {float(losses[0]):.4f} -> {float(losses[-1]):.4f}, rot err {rot_err(est, p.pose_gt):.2e} rad, t err {np.abs(est[:3,3]-p.pose_gt[:3,3]).max():.2e}")
+fargs = (src, t(p.kld_gt), trg, supp_T0, torch.eye(4, device=dev), [0, 0, 300], levels)
+track_frame_fused(*fargs, lr=5e-3, prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+supp_T, _, losses = track_frame_fused(*fargs, lr=5e-3, prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+est = invertSE3(supp_T).cpu().numpy()
+print(f"config 3  tracking, fused optimiser incl. table / pyramid set-up per frame: {dt*1e3:.1f} ms/frame ({300/dt:.0f} it/s), "
+      f"rot err {rot_err(est, p.pose_gt):.2e} rad, t err {np.abs(est[:3,3]-p.pose_gt[:3,3]).max():.2e}")
 # the same frame-to-keyframe problem for a whole batch of frames on device (pose + affine, depths fixed)
 B = 64
 pb = PairBatch([src] * 1, [t(p.trg_image)], [t(p.K)], t(p.pose_init)[None].repeat(B, 1, 1), [t(p.kld_gt)], levels=levels, use_affine=True,
@@ -69,13 +78,17 @@ pb = PairBatch([src] * 1, [t(p.trg_image)], [t(p.K)], t(p.pose_init)[None].repea
 for _ in range(3): pb.adam_step(0, lr_kld=0.0, lr_pose=5e-3, lr_aff=5e-3)
 dt = sync_time(lambda: pb.adam_step(0, lr_kld=0.0, lr_pose=5e-3, lr_aff=5e-3), 300)
 print(f"config 3  tracking, {B} frames side by side on device: {B/ (300*dt):.0f} frames/s at 300 steps/frame ({B/dt:.0f} Adam it/s)")
-other = synth.make_pair(H, W, N, seed=3, init_sigma=0.01, overlap=3, motion_scale=1.7)
-imgs, Ks = t(np.stack([p.trg_image, other.trg_image])), t(np.stack([p.K, p.K]))
-map_source_against_targets(src, imgs, Ks, t(p.kld_init), t(np.stack([p.pose_init, other.pose_init])), 3)
-torch.cuda.synchronize(); t0 = time.perf_counter()
-kld, poses, _, losses = map_source_against_targets(src, imgs, Ks, t(p.kld_init), t(np.stack([p.pose_init, other.pose_init])), 500)
-torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"config 3  mapping 1 KF x 2 targets, {len(losses)} Adam steps through the API: {dt*1e3:.0f} ms ({len(losses)/dt:.0f} it/s), loss {float(losses[0]):.4f} -> {float(losses[-1]):.4f}")
+frames_w, est, klds, affs = synth.window_inputs(300, 3, H=H, W=W, N=N)
+kfs = [KeyFrame(t(f.image), t(f.K), t(f.logdepth_perseg), t(f.keypoints), t(f.keypoint_regions)) for f in frames_w[0::2]]
+supp = [[(KeyFrame(t(frames_w[2 * k + 1].image), t(frames_w[2 * k + 1].K)), t(est[2 * k + 1]), t(affs[2 * k + 1]))] for k in range(3)]
+margs = (kfs, [t(est[2 * k]) for k in range(3)], [t(k) for k in klds], [t(affs[2 * k]) for k in range(3)], supp)
+for fused in (True, False):
+    map_window(*margs, 5, window_size=3, initialised=False, fused=fused)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = map_window(*margs, 500, window_size=3, initialised=False, fused=fused)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"config 3  windowed mapping, 3 keyframes + 3 supporting frames (10 edges), 500 Adam steps, {'fused' if fused else 'eager'}: "
+          f"{dt*1e3:.0f} ms ({500/dt:.0f} it/s), loss {float(out['losses'][0]):.4f} -> {float(out['losses'][-1]):.4f}")
 
 # ---- config 4: VOID-shaped depth completion --------------------------------------------------------------
 p = synth.make_pair(480, 640, 1200, seed=4, shape="blobs")
