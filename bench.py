@@ -256,7 +256,8 @@ def main(argv=None):
     if os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
-            if rec.get("pairs_per_gpu") == M and rec.get("mode") == args.mode and rec.get("tile_points") == args.tile_points:
+            if (rec.get("pairs_per_gpu") == M and rec.get("mode") == args.mode and rec.get("tile_points") == args.tile_points
+                    and rec.get("algorithmic_bytes_per_launch") == alg_bytes):
                 line["roofline"]["traffic"] = rec.get("hbm_bytes_per_launch")
                 line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (rocprofv3 --pmc of this command on an earlier box; not measured in this run)"
         except Exception:
