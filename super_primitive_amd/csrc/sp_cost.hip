@@ -51,7 +51,7 @@ struct Pending {           // a point whose taps are about to be / have just bee
     Geo g;
     float wx, wy, m;
     float sr, sg, sb;      // source colour
-    uint32_t off0, off1;   // byte offsets of texels (x0,y0) and (x0,y1)
+    uint32_t off0;         // byte offset of texel (x0,y0); (x0,y1) is one row further (scalar offset of the load)
 };
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
@@ -66,8 +66,8 @@ __device__ __forceinline__ f32x4 buf_load4(rsrc_t r, uint32_t off) {
 typedef float f32x3 __attribute__((ext_vector_type(3)));
 // rgb of one packed HWC3 texel (12 bytes, dword aligned)
 template <int AUX = 0>
-__device__ __forceinline__ f32x3 buf_load3(rsrc_t r, uint32_t off) {
-    return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, 0, AUX));
+__device__ __forceinline__ f32x3 buf_load3(rsrc_t r, uint32_t off, uint32_t soff = 0) {
+    return __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, (int)off, (int)soff, AUX));
 }
 
 __device__ __forceinline__ void prepare_xyz(const TileCtx& c, float x, float y, float d, bool src_ok, float sr, float sg,
@@ -106,7 +106,6 @@ __device__ __forceinline__ void prepare_xyz(const TileCtx& c, float x, float y, 
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(texel) : "v"((uint32_t)(int)fy0), "s"((uint32_t)c.Wl), "v"((uint32_t)(int)fx0));
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(off0) : "v"(texel), "s"(4u * SP_TEXEL_FLOATS));
     p.off0 = off0;
-    p.off1 = off0 + c.row_bytes;
 }
 
 // bilinear value and both slopes of one channel from its four taps
@@ -216,8 +215,8 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float* __restrict__ o
         fetch(i, pw, s, xyz);
         f32x3 ta = buf_load3(r_trg, nx.off0);
         f32x3 tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
-        f32x3 tc = buf_load3(r_trg, nx.off1);
-        f32x3 td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
+        f32x3 tc = buf_load3(r_trg, nx.off0, c.row_bytes);          // second row: the scalar offset of the buffer instruction
+        f32x3 td = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS, c.row_bytes);
         // The machine scheduler otherwise sinks the gathers below the arithmetic to shorten their live range
         // (register pressure heuristics): pin the three sections in source order.
         __builtin_amdgcn_sched_barrier(0);
@@ -266,6 +265,21 @@ __device__ __forceinline__ void run_tile(const TileCtx& c, float* __restrict__ o
 // when the pairs are written back to the SP_GN_PARTIAL_FLOATS layout.
 // -----------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Wave-uniform values that come out of float arithmetic live in VGPRs (the scalar unit has no float ALU) and the
+// compiler never moves them back; these put them -- and pairs of them, as one 64-bit scalar -- into SGPRs, where a
+// VALU / packed-VALU instruction can read them directly.  25 loop-invariant VGPRs of the GN loop go away this way.
+__device__ __forceinline__ float sgpr(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ f32x2 sgpr2(float a, float b) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a));
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, b));
+    return __builtin_bit_cast(f32x2, ((uint64_t)hi << 32) | (uint64_t)lo);
+}
+struct PairConsts {            // the uniform operand pairs of prepare2 / fold_gn2 / finish_gn2
+    f32x2 Kc, ifxy, R03, R14, R25, t01, Kf, Ktc, invWH, sxy, gab, bias2, eps2;
+    float R6, R7, R8, t2, gain, bias, zmin, eps;
+};
 __device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pfma(float a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(f32x2{a, a}, b, c); }
 
@@ -287,30 +301,28 @@ struct Pending2 {          // Pending, with the x/y quantities as register pairs
     f32x2 qxy; float qz, zinv, zi;
     f32x2 wxy; float m;
     f32x2 srg; float sb;
-    uint32_t off0, off1;
+    uint32_t off0;
 };
 
 // prepare() on pairs: same operations in the same order per component (sp_device.h backproject / warp_point)
-__device__ __forceinline__ void prepare2(const TileCtx& c, float shift, f32x2 ifxy, uint32_t pw, const f32x4 s, Pending2& p) {
+__device__ __forceinline__ void prepare2(const TileCtx& c, const PairConsts& k, float shift, uint32_t pw, const f32x4 s, Pending2& p) {
     const f32x2 colrow{(float)(pw & 0xffffu), (float)((pw >> 16) & 0x7fffu)};
     const bool src_ok = (int32_t)pw < 0;
     const float d = fast_exp(s.w + shift);
-    const Warp& w = c.w;
-    const f32x2 xy = ((colrow - f32x2{c.Ks.cx, c.Ks.cy}) * d) * ifxy;
-    const f32x2 qxy = pfma(f32x2{w.R[0], w.R[3]}, f32x2{xy.x, xy.x},
-                           pfma(f32x2{w.R[1], w.R[4]}, f32x2{xy.y, xy.y}, f32x2{w.R[2], w.R[5]} * d)) + f32x2{w.t[0], w.t[1]};
-    const float qz = fmaf(w.R[6], xy.x, fmaf(w.R[7], xy.y, w.R[8] * d)) + w.t[2];
+    const f32x2 xy = ((colrow - k.Kc) * d) * k.ifxy;
+    const f32x2 qxy = pfma(k.R03, f32x2{xy.x, xy.x}, pfma(k.R14, f32x2{xy.y, xy.y}, k.R25 * d)) + k.t01;
+    const float qz = fmaf(k.R6, xy.x, fmaf(k.R7, xy.y, k.R8 * d)) + k.t2;
     const bool zguard = fabsf(qz) > 1e-6f;
     const float zinv = zguard ? __builtin_amdgcn_rcpf(qz) : 1e-6f;
-    const f32x2 uv = qxy * f32x2{w.Kt.fx, w.Kt.fy} * zinv + f32x2{w.Kt.cx, w.Kt.cy};
-    const f32x2 n = 2.f * uv * f32x2{w.invWm1, w.invHm1} - 1.f;
-    const bool ok = (fabsf(n.x) <= 0.99f) && (fabsf(n.y) <= 0.99f) && (qz > w.zmin) && src_ok && (d > 1e-7f);
+    const f32x2 uv = qxy * k.Kf * zinv + k.Ktc;
+    const f32x2 n = 2.f * uv * k.invWH - 1.f;
+    const bool ok = (fabsf(n.x) <= 0.99f) && (fabsf(n.y) <= 0.99f) && (qz > k.zmin) && src_ok && (d > 1e-7f);
     p.m = ok ? 1.f : 0.f;
     p.qxy = qxy; p.qz = qz;
     p.zinv = ok ? zinv : 0.f;
     p.zi = (ok && zguard) ? zinv : 0.f;
     p.srg = f32x2{s.x, s.y}; p.sb = s.z;
-    const f32x2 i0 = (n + 1.f) * f32x2{w.sx, w.sy};
+    const f32x2 i0 = (n + 1.f) * k.sxy;
     const f32x2 ixy{ok ? i0.x : 0.f, ok ? i0.y : 0.f};
     const f32x2 fl{floorf(ixy.x), floorf(ixy.y)};
     p.wxy = ixy - fl;
@@ -318,24 +330,24 @@ __device__ __forceinline__ void prepare2(const TileCtx& c, float shift, f32x2 if
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(texel) : "v"((uint32_t)(int)fl.y), "s"((uint32_t)c.Wl), "v"((uint32_t)(int)fl.x));
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(off0) : "v"(texel), "s"(4u * SP_TEXEL_FLOATS));
     p.off0 = off0;
-    p.off1 = off0 + c.row_bytes;
 }
 
 struct Mix2 { f32x2 wa, v; float w11; };      // {w00, w01}, {v0, v1}, w11
 
-__device__ __forceinline__ void finish_gn2(const TileCtx& c, const Pending2& p, const f32x3 a, const f32x3 b,
-                                           const f32x3 cc, const f32x3 d, float eps, Mix2& o, float& cost_acc, float& n_acc) {
+__device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& p, const f32x3 a, const f32x3 b,
+                                           const f32x3 cc, const f32x3 d, Mix2& o, float& cost_acc, float& n_acc) {
+    const float eps = k.eps;
     // red+green as a pair
     const f32x2 a2{a.x, a.y}, b2{b.x, b.y}, c2{cc.x, cc.y}, d2{d.x, d.y};
     const f32x2 e1 = b2 - a2, e2 = c2 - a2, e3 = (d2 - c2) - e1;
     const f32x2 Iy2 = pfma(p.wxy.x, e3, e2);
     const f32x2 Ix2 = pfma(p.wxy.y, e3, e1);
     const f32x2 it2 = pfma(p.wxy.y, Iy2, pfma(p.wxy.x, e1, a2));
-    const f32x2 r2 = p.srg - pfma(c.gain, it2, f32x2{c.bias, c.bias});
+    const f32x2 r2 = p.srg - pfma(k.gain, it2, k.bias2);
     // blue
     float itb, Ixb, Iyb;
     tap_mix(a.z, b.z, cc.z, d.z, p.wxy.x, p.wxy.y, itb, Ixb, Iyb);
-    const float rb = p.sb - fmaf(c.gain, itb, c.bias);
+    const float rb = p.sb - fmaf(k.gain, itb, k.bias);
     const float ar0 = fabsf(r2.x), ar1 = fabsf(r2.y), arb = fabsf(rb);
     const f32x2 wg2{__builtin_amdgcn_rcpf(fmaxf(ar0, eps)), __builtin_amdgcn_rcpf(fmaxf(ar1, eps))};
     const float wgb = __builtin_amdgcn_rcpf(fmaxf(arb, eps));
@@ -350,15 +362,15 @@ __device__ __forceinline__ void finish_gn2(const TileCtx& c, const Pending2& p, 
 }
 
 struct GeoGn { f32x2 qxy; float qz, zinv, zi; };
-__device__ __forceinline__ void fold_gn2(const TileCtx& c, const GeoGn g, const Mix2 w, GnAcc& A) {
-    const f32x2 g2 = f32x2{c.gain * c.ax * c.w.Kt.fx, c.gain * c.ay * c.w.Kt.fy} * g.zinv;   // {ga, gb}; zinv carries the mask
+__device__ __forceinline__ void fold_gn2(const PairConsts& k, const GeoGn g, const Mix2 w, GnAcc& A) {
+    const f32x2 g2 = k.gab * g.zinv;   // {ga, gb}; zinv carries the mask
     const f32x2 Wa = w.wa * (g2 * g2.x);                 // {W00, W01}
     const float W11 = w.w11 * (g2.y * g2.y);
     const f32x2 V = -(w.v * g2);
     const f32x2 qxy = g.qxy;
     const f32x2 u = qxy * g.zi;                          // {ux, vy}
-    const float ez = g.qz - c.w.t[2];
-    const f32x2 Q = pfma(-ez, u, qxy - f32x2{c.w.t[0], c.w.t[1]});   // column 6 of Ahat: {A0[4], A1[4]}
+    const float ez = g.qz - k.t2;
+    const f32x2 Q = pfma(-ez, u, qxy - k.t01);   // column 6 of Ahat: {A0[4], A1[4]}
     // columns 2..5 of Ahat as pairs along the column index
     const f32x2 A00{-u.x, -u.x * qxy.y}, A01{fmaf(u.x, qxy.x, g.qz), -qxy.y};
     const f32x2 A10{-u.y, -fmaf(u.y, qxy.y, g.qz)}, A11{u.y * qxy.x, qxy.x};
@@ -489,31 +501,48 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     SpanCursor k;
     cursor_init(k, pr, chunks, q0, n_chunks);
     const int start = k.chunks[q0].start;
-    const f32x2 ifxy{1.f / c.Ks.fx, 1.f / c.Ks.fy};
+    PairConsts kc;
+    {
+        const Warp& w = c.w;
+        kc.Kc = sgpr2(c.Ks.cx, c.Ks.cy);       kc.ifxy = sgpr2(1.f / c.Ks.fx, 1.f / c.Ks.fy);
+        kc.R03 = sgpr2(w.R[0], w.R[3]);        kc.R14 = sgpr2(w.R[1], w.R[4]);      kc.R25 = sgpr2(w.R[2], w.R[5]);
+        kc.t01 = sgpr2(w.t[0], w.t[1]);        kc.Kf = sgpr2(w.Kt.fx, w.Kt.fy);     kc.Ktc = sgpr2(w.Kt.cx, w.Kt.cy);
+        kc.invWH = sgpr2(w.invWm1, w.invHm1);  kc.sxy = sgpr2(w.sx, w.sy);
+        kc.gab = sgpr2(c.gain * c.ax * w.Kt.fx, c.gain * c.ay * w.Kt.fy);
+        kc.bias2 = sgpr2(c.bias, c.bias);      kc.eps2 = sgpr2(irls_eps, irls_eps);
+        kc.R6 = sgpr(w.R[6]); kc.R7 = sgpr(w.R[7]); kc.R8 = sgpr(w.R[8]); kc.t2 = sgpr(w.t[2]);
+        kc.gain = sgpr(c.gain); kc.bias = sgpr(c.bias); kc.zmin = sgpr(w.zmin); kc.eps = sgpr(irls_eps);
+    }
     const rsrc_t r_pix = make_rsrc(c.pix + start, (uint32_t)total * 4u);
     const rsrc_t r_src = make_rsrc(c.src4 + start, (uint32_t)total * 16u);
     const rsrc_t r_trg = make_rsrc(c.trg, (uint32_t)c.Wl * (uint32_t)c.Hl * (4u * SP_TEXEL_FLOATS));
     const int n_iter = total / SP_BLOCK;
-    uint32_t op = threadIdx.x * 4u;     // byte offset of this lane's word in the span's pix run (x4: its src4 record)
+    uint32_t op = threadIdx.x * 4u;
     constexpr int NT = 2;
-    Pending2 nx;
-    int nx_q, cur_q = q0;                // chunk of the trip in flight / of the trip waiting for its fold
-    bool nx_last, cur_last = false;      // ... and whether that trip is the last of its chunk
+    // Two point slots used alternately (the loop is unrolled by two with the roles swapped), so that nothing has to be
+    // copied at the back edge: point j lives in slot j % 2 from its geometry (bottom of trip j - 1) through its taps and
+    // channel mixing (trip j) to its fold (middle of trip j + 1), and the slot is overwritten by point j + 2 only after
+    // that fold.  q / last: chunk of the point and whether it closes that chunk (wave-uniform).
+    struct Slot { Pending2 p; int q; bool last; };
+    Slot S0, S1;
     {
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
-        prepare2(c, k.shift, ifxy, pw, s, nx);
-        nx_last = cursor_advance(k, nx_q);
+        prepare2(c, kc, k.shift, pw, s, S0.p);
+        S0.last = cursor_advance(k, S0.q);
     }
-    GeoGn cur{nx.qxy, nx.qz, 0.f, 0.f};
+    S1.p = S0.p;                         // "point -1": finite values, zinv = zi = 0 and a zero Mix2 -> contributes exact zeros
+    S1.p.zinv = 0.f; S1.p.zi = 0.f;
+    S1.q = q0; S1.last = false;
     Mix2 m{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, 0.f};
-    for (int j = 0; j < n_iter; ++j) {
+    // one trip: taps + channel mixing of the point in `a`, fold of the point in `b`, geometry of the next point into `b`
+    auto trip = [&](Slot& a, Slot& b) {
         op += 4u * SP_BLOCK;
         asm volatile("" : "+v"(op));        // one induction register; the src4 offset is a shift of it
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
         f32x3 ta, tb, tc, td;
-        if (ABL == 1) { ta = tb = tc = td = f32x3{nx.srg.x, nx.srg.y, nx.sb}; }
+        if (ABL == 1) { ta = tb = tc = td = f32x3{a.p.srg.x, a.p.srg.y, a.p.sb}; }
         else if (ABL == 3) {
             // same four 12-byte loads per point, same data volume and real image values, but lane-consecutive texels
             // (fully coalesced): what the bilinear footprint would cost if it were not a gather
@@ -522,34 +551,40 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
             const uint32_t o0 = lin < cap ? lin : lin - cap * (lin / cap);
             ta = buf_load3(r_trg, o0);
             tb = buf_load3(r_trg, o0 + 4u * SP_TEXEL_FLOATS);
-            tc = buf_load3(r_trg, o0 + c.row_bytes);
-            td = buf_load3(r_trg, o0 + c.row_bytes + 4u * SP_TEXEL_FLOATS);
+            tc = buf_load3(r_trg, o0, c.row_bytes);
+            td = buf_load3(r_trg, o0 + 4u * SP_TEXEL_FLOATS, c.row_bytes);
         } else {
-            ta = buf_load3(r_trg, nx.off0);
-            tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
-            tc = buf_load3(r_trg, nx.off1);
-            td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
+            ta = buf_load3(r_trg, a.p.off0);
+            tb = buf_load3(r_trg, a.p.off0 + 4u * SP_TEXEL_FLOATS);
+            tc = buf_load3(r_trg, a.p.off0, c.row_bytes);
+            td = buf_load3(r_trg, a.p.off0 + 4u * SP_TEXEL_FLOATS, c.row_bytes);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL != 2) fold_gn2(c, cur, m, A);
-        if (cur_last) flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * cur_q + wave) * NS);
+        if (ABL != 2) fold_gn2(kc, GeoGn{b.p.qxy, b.p.qz, b.p.zinv, b.p.zi}, m, A);
+        if (b.last) flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * b.q + wave) * NS);
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 1)
             asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(A.blk[0]), "+v"(A.blk[1]), "+v"(A.blk[2]),
                          "+v"(A.blk[3]), "+v"(A.blk[4]), "+v"(A.blk[5]), "+v"(A.bp[0]), "+v"(A.bp[1]), "+v"(A.hd[0]),
-                         "+v"(A.hd[1]), "+v"(A.D), "+v"(A.bd));
-        if (ABL == 2) A.cost += ta.x + tb.y + tc.z + td.x + nx.wxy.x + nx.wxy.y + nx.m;
-        else finish_gn2(c, nx, ta, tb, tc, td, irls_eps, m, A.cost, A.n);
-        cur = GeoGn{nx.qxy, nx.qz, nx.zinv, nx.zi};
-        cur_q = nx_q; cur_last = nx_last;
+                         "+v"(A.hd[1]), "+v"(A.D), "+v"(A.bd), "+v"(A.h00), "+v"(A.h0[0]), "+v"(A.h0[1]), "+v"(A.h1[0]), "+v"(A.h1[1]), "+v"(A.h11), "+v"(A.bp01), "+v"(A.hd01));
+        if (ABL == 2) A.cost += ta.x + tb.y + tc.z + td.x + a.p.wxy.x + a.p.wxy.y + a.p.m;
+        else finish_gn2(kc, a.p, ta, tb, tc, td, m, A.cost, A.n);
         uint32_t pw_ = pw;
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
-        prepare2(c, k.shift, ifxy, pw_, s_, nx);      // (the trip past the end reads zeros and is never used)
-        nx_last = cursor_advance(k, nx_q);
+        prepare2(c, kc, k.shift, pw_, s_, b.p);       // (the trip past the end reads zeros and is never used)
+        b.last = cursor_advance(k, b.q);
+    };
+    int j = 0;
+    for (; j + 1 < n_iter; j += 2) { trip(S0, S1); trip(S1, S0); }
+    if (j < n_iter) {                    // odd trip count: the last point sits in S0
+        trip(S0, S1);
+        if (ABL != 2) fold_gn2(kc, GeoGn{S0.p.qxy, S0.p.qz, S0.p.zinv, S0.p.zi}, m, A);
+        flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * S0.q + wave) * NS);
+    } else {
+        if (ABL != 2) fold_gn2(kc, GeoGn{S1.p.qxy, S1.p.qz, S1.p.zinv, S1.p.zi}, m, A);
+        flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * S1.q + wave) * NS);
     }
-    if (ABL != 2) fold_gn2(c, cur, m, A);
-    flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * cur_q + wave) * NS);      // the span ends with its last chunk
     float acc[NV];
     acc[0] = A.cost;
     acc[1] = A.h00.x; acc[2] = A.h00.y;
@@ -616,8 +651,8 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
         else {
             ta = buf_load3(r_trg, nx.off0);
             tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
-            tc = buf_load3(r_trg, nx.off1);
-            td = buf_load3(r_trg, nx.off1 + 4u * SP_TEXEL_FLOATS);
+            tc = buf_load3(r_trg, nx.off0, c.row_bytes);
+            td = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS, c.row_bytes);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 2) fold_grad(c, cur, m0, acc);
@@ -647,15 +682,16 @@ __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const C
                                           float zmin) {
     load_pose(pose, c.w.R, c.w.t);
     c.w.Kt = Kt;
-    c.w.invWm1 = 1.f / (float)(W - 1);
-    c.w.invHm1 = 1.f / (float)(H - 1);
-    c.w.sx = 0.5f * (float)(Wl - 1);
-    c.w.sy = 0.5f * (float)(Hl - 1);
+    // (results of float arithmetic on uniform values sit in VGPRs unless moved back: sgpr())
+    c.w.invWm1 = sgpr(1.f / (float)(W - 1));
+    c.w.invHm1 = sgpr(1.f / (float)(H - 1));
+    c.w.sx = sgpr(0.5f * (float)(Wl - 1));
+    c.w.sy = sgpr(0.5f * (float)(Hl - 1));
     c.w.zmin = zmin;
     c.Wl = Wl; c.Hl = Hl;
     c.row_bytes = (uint32_t)Wl * (4u * SP_TEXEL_FLOATS);
-    c.ax = 2.f * c.w.sx * c.w.invWm1;
-    c.ay = 2.f * c.w.sy * c.w.invHm1;
+    c.ax = sgpr(2.f * c.w.sx * c.w.invWm1);
+    c.ay = sgpr(2.f * c.w.sy * c.w.invHm1);
 }
 
 
@@ -796,8 +832,8 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
     c.shift = 0.f;
     c.gain = 1.f; c.bias = 0.f;
     if (pr.aff) {
-        c.gain = expf(-(pr.aff[2] - pr.aff[0]));
-        c.bias = pr.aff[3] - pr.aff[1];
+        c.gain = sgpr(expf(-(pr.aff[2] - pr.aff[0])));
+        c.bias = sgpr(pr.aff[3] - pr.aff[1]);
     }
     c.start = 0; c.count = 0;
     if (MODE == 1) run_span_gn<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials + (size_t)w * NV, seg_partials, lds);
