@@ -260,7 +260,8 @@ int sp_window_compose(const SpPair* pairs, const SpWindowEdge* edges, int n_edge
  * (two_frame_sfm.py:201-202), 0 = sum_e w_e residual_e (odometery.py:394,845-850).  skip_first: no parameter update on
  * iteration 0 (two_frame_sfm.py:203).  rel_tol > 0: once |loss - previous loss| / previous loss < rel_tol the window
  * freezes (later calls return without touching anything), like the break at odometery.py:907-915.
- * state: 8 floats, zeroed by the caller {Adam step count, iterations done, previous loss, converged flag, last loss, ...};
+ * state: 12 floats, zeroed by the caller {Adam step count, iterations done, previous loss, converged flag, last loss, -,
+ *   beta1^t and beta2^t as two doubles in [6..9]}; setting [0] = 0 restarts Adam's bias correction;
  * losses[max_losses]: loss of iteration i (evaluated BEFORE its update) at index i. */
 int sp_window_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes,
                    const SpWindowBlock* blocks, int n_blocks, int max_N, const float* span_partials, const float* seg_partials,

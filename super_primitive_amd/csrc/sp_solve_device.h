@@ -374,16 +374,22 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void renormalise_rotation(float* __restrict__ M) {
     const float m00 = M[0], m01 = M[1], m02 = M[2], m10 = M[4], m11 = M[5], m12 = M[6], m20 = M[8], m21 = M[9], m22 = M[10];
-    float qa[4] = {1.f + m00 + m11 + m22, 1.f + m00 - m11 - m22, 1.f - m00 + m11 - m22, 1.f - m00 - m11 + m22};
-    for (int k = 0; k < 4; ++k) qa[k] = qa[k] > 0.f ? sqrtf(qa[k]) : 0.f;
-    int best = 0;
-    for (int k = 1; k < 4; ++k) if (qa[k] > qa[best]) best = k;   // argmax, first maximum like torch
-    const float cand[4][4] = {{qa[0] * qa[0], m21 - m12, m02 - m20, m10 - m01},
-                              {m21 - m12, qa[1] * qa[1], m10 + m01, m02 + m20},
-                              {m02 - m20, m10 + m01, qa[2] * qa[2], m12 + m21},
-                              {m10 - m01, m20 + m02, m21 + m12, qa[3] * qa[3]}};
-    const float den = 2.f * fmaxf(qa[best], 0.1f);
-    const float r = cand[best][0] / den, x = cand[best][1] / den, y = cand[best][2] / den, z = cand[best][3] / den;
+    float q0 = 1.f + m00 + m11 + m22, q1 = 1.f + m00 - m11 - m22, q2 = 1.f - m00 + m11 - m22, q3 = 1.f - m00 - m11 + m22;
+    q0 = q0 > 0.f ? sqrtf(q0) : 0.f; q1 = q1 > 0.f ? sqrtf(q1) : 0.f;
+    q2 = q2 > 0.f ? sqrtf(q2) : 0.f; q3 = q3 > 0.f ? sqrtf(q3) : 0.f;
+    // argmax, first maximum like torch; the candidate row is picked with selects (a dynamically indexed local array would
+    // live in scratch memory, and this runs on the critical path of the one-workgroup optimiser kernel)
+    int best = 0; float qb = q0;
+    if (q1 > qb) { best = 1; qb = q1; }
+    if (q2 > qb) { best = 2; qb = q2; }
+    if (q3 > qb) { best = 3; qb = q3; }
+    const float a = m21 - m12, b = m02 - m20, c = m10 - m01, d = m10 + m01, e = m02 + m20, f = m12 + m21;
+    const float c0 = best == 0 ? q0 * q0 : (best == 1 ? a : (best == 2 ? b : c));
+    const float c1 = best == 0 ? a : (best == 1 ? q1 * q1 : (best == 2 ? d : e));
+    const float c2 = best == 0 ? b : (best == 1 ? d : (best == 2 ? q2 * q2 : f));
+    const float c3 = best == 0 ? c : (best == 1 ? e : (best == 2 ? f : q3 * q3));
+    const float den = 2.f * fmaxf(qb, 0.1f);
+    const float r = c0 / den, x = c1 / den, y = c2 / den, z = c3 / den;
     const float s = 2.f / (r * r + x * x + y * y + z * z);
     M[0] = 1.f - s * (y * y + z * z); M[1] = s * (x * y - z * r);       M[2] = s * (x * z + y * r);
     M[4] = s * (x * y + z * r);       M[5] = 1.f - s * (x * x + z * z); M[6] = s * (y * z - x * r);
@@ -416,10 +422,28 @@ __device__ void se3_exp_times(const Dual<ND> (&a)[6], const float* __restrict__ 
     {   // evaluated in fp64: the closed forms cancel badly in fp32 for theta < ~0.5 (1 - cos, theta - sin)
         const double t = (double)t2;
         double a_, b_, c_, da_, db_, dc_;
-        if (t < 1e-6) {
-            a_ = 1.0 - t / 6.0 * (1.0 - t / 20.0);           da_ = -1.0 / 6.0 + t / 60.0;
-            b_ = 0.5 - t / 24.0 * (1.0 - t / 30.0);           db_ = -1.0 / 24.0 + t / 360.0;
-            c_ = 1.0 / 6.0 - t / 120.0 * (1.0 - t / 42.0);    dc_ = -1.0 / 120.0 + t / 2520.0;
+        if (t < 0.5) {
+            // Taylor series in theta^2, Horner form, 10 terms: |error| < 1e-17 for theta^2 < 0.5, and no sqrt / sin / cos on
+            // the critical path of the one-workgroup optimiser kernels (pose tangents are small)
+            //   A = sum (-t)^k / (2k+1)!    B = sum (-t)^k / (2k+2)!    C = sum (-t)^k / (2k+3)!
+            // coefficients 1/(2k+1)!, 1/(2k+2)!, 1/(2k+3)! (folded to constants by the compiler)
+            double ia[10], ib[10], ic[10];
+            {
+                double f = 1.0;
+                for (int k = 0; k < 10; ++k) {
+                    const double n1 = 2.0 * k + 1.0;
+                    if (k > 0) f *= (2.0 * k) * n1;            // f = (2k+1)!
+                    ia[k] = 1.0 / f; ib[k] = ia[k] / (n1 + 1.0); ic[k] = ib[k] / (n1 + 2.0);
+                }
+            }
+            double va = 0.0, vb = 0.0, vc = 0.0, wa = 0.0, wb = 0.0, wc = 0.0;    // v = value, w = derivative (Horner on both)
+            for (int k = 9; k >= 0; --k) {
+                const double sg = (k & 1) ? -1.0 : 1.0;
+                wa = wa * t + va; va = va * t + sg * ia[k];
+                wb = wb * t + vb; vb = vb * t + sg * ib[k];
+                wc = wc * t + vc; vc = vc * t + sg * ic[k];
+            }
+            a_ = va; b_ = vb; c_ = vc; da_ = wa; db_ = wb; dc_ = wc;
         } else {
             const double th = sqrt(t), sn = sin(th), cs = cos(th);
             a_ = sn / th; b_ = (1.0 - cs) / t; c_ = (th - sn) / (t * th);

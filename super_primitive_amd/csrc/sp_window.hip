@@ -21,8 +21,13 @@
 
 namespace {
 
-#define SP_WIN_REC 24            // doubles per edge record, followed by max_N per-segment sums
+static_assert(sizeof(SpWindowNode) == 176 && sizeof(SpWindowEdge) == 16 && sizeof(SpWindowBlock) == 32, "window structs are part of the ABI");
+
+#define SP_WIN_REC 28            // doubles per edge record, followed by max_N per-segment sums
 #define SP_WIN_MAX_EDGES 1024
+#define SP_WIN_LDS_EDGES 96      // windows up to this many edges / 64 nodes are staged in LDS (records, edge list, slot
+#define SP_WIN_LDS_BLOCKS 64     // pointers, blocks, nodes, dExp: 52 KB)
+#define SP_WIN_LDS_NODES 64
 
 __global__ __launch_bounds__(SP_BLOCK) void k_window_reduce(const SpPair* __restrict__ pairs, const float* __restrict__ partials,
                                                             const float* __restrict__ seg_partials, double* __restrict__ scratch,
@@ -69,6 +74,16 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_reduce(const SpPair* __rest
         }
         rec[19] = sums[14] * scale;                                    // d/da_trg  (d/da_src = -this)
         rec[20] = sums[15] * scale;                                    // d/db_trg  (d/db_src = -this)
+        // gradient wrt the SOURCE node's tangent: P = M Exp(-d_src) = Exp(-Ad_M d_src) M  =>  d/dd_src = -Ad_P^T g_left,
+        // Ad^T [g_tau; g_phi] = [R^T g_tau ; R^T (g_phi - t x g_tau)]   (computed here, one workgroup per edge, so that the
+        // single-workgroup update kernel only has sums left to do)
+        const double u0 = rec[4] - (t[1] * gt[2] - t[2] * gt[1]), u1 = rec[5] - (t[2] * gt[0] - t[0] * gt[2]),
+                     u2 = rec[6] - (t[0] * gt[1] - t[1] * gt[0]);
+        for (int k = 0; k < 3; ++k) {
+            rec[21 + k] = -(R[k] * gt[0] + R[3 + k] * gt[1] + R[6 + k] * gt[2]);
+            rec[24 + k] = -(R[k] * u0 + R[3 + k] * u1 + R[6 + k] * u2);
+        }
+        rec[27] = 0.0;
     }
 }
 
@@ -112,74 +127,142 @@ __device__ void se3_exp_d(const double xi[6], double E[12]) {
     }
 }
 
-__global__ __launch_bounds__(SP_BLOCK) void k_window_update(WinArgs w) {
+#define SP_WIN_LDS_DIRECT 32     // persistent-tangent nodes whose dExp is evaluated in parallel (6 lanes each)
+
+// STAGED is a template parameter, not a run-time select: with it the compiler knows that every access below goes to LDS
+// (ds_read / ds_write) -- a pointer that may be LDS or global compiles to flat accesses, ~0.5 us each on this critical path.
+template <bool STAGED>
+__device__ __forceinline__ void window_update_body(const WinArgs& w) {
     __shared__ float coef[SP_WIN_MAX_EDGES];
     __shared__ int do_update;
     __shared__ float neg_inv_bc1, bc2s_f;
+    // One workgroup does all of this, so every global round trip and every serial stretch is on the critical path of an
+    // optimiser iteration: the edge records, the edge list, the pose-slot pointers, the log-depth blocks and the node array
+    // are staged in LDS once, coalesced; the per-edge heavy lifting (left-tangent and source-node gradients) was done by
+    // k_window_reduce with one workgroup per edge; what is left here are short sums, Adam, the fold-in and the composition.
+    __shared__ double s_rec[SP_WIN_LDS_EDGES * SP_WIN_REC];
+    __shared__ SpWindowEdge s_edge[SP_WIN_LDS_EDGES];
+    __shared__ float* s_pose_ptr[SP_WIN_LDS_EDGES];
+    __shared__ float* s_aff_ptr[SP_WIN_LDS_EDGES];
+    __shared__ SpWindowBlock s_block[SP_WIN_LDS_BLOCKS];
+    __shared__ SpWindowNode s_node[SP_WIN_LDS_NODES];
+    __shared__ float s_dP[SP_WIN_LDS_DIRECT][6][12];     // d(Exp(a) X)/da_k of the persistent-tangent nodes
     float* st = w.state;
     const int tid = threadIdx.x;
-    if (!w.compose_only) {
-        if (st[3] != 0.f) return;                       // converged earlier: the window is frozen
+    constexpr bool staged = STAGED;
+    SpWindowNode* const nodes = STAGED ? s_node : w.nodes;          // the nodes this launch works on (written back at the end)
+    // thread 0 fetches the optimiser state first so that its latency overlaps the staging
+    float st0 = 0.f, st1 = 0.f, st2 = 0.f, st3 = 0.f;
+    double b1t = 1.0, b2t = 1.0;
+    if (!w.compose_only && tid == 0) {
+        st0 = st[0]; st1 = st[1]; st2 = st[2]; st3 = st[3];
+        __builtin_memcpy(&b1t, st + 6, 8); __builtin_memcpy(&b2t, st + 8, 8);
+    }
+    if (staged) {
+        // one coalesced round trip for the node array (176-byte structs = 44 dwords each)
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(w.nodes);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_node);
+        for (int i = tid; i < w.n_nodes * 44; i += SP_BLOCK) dst[i] = src[i];
         for (int e = tid; e < w.n_edges; e += SP_BLOCK) {
-            const double r = w.scratch[(size_t)e * w.stride];
-            const float sg = w.abs_loss ? (r > 0.0 ? 1.f : (r < 0.0 ? -1.f : 0.f)) : 1.f;
-            coef[e] = w.edges[e].weight * sg;
+            s_edge[e] = w.edges[e];
+            s_pose_ptr[e] = w.pairs[e].pose;
+            s_aff_ptr[e] = w.pairs[e].aff;
         }
+        if (!w.compose_only) {
+            for (int i = tid; i < w.n_edges * SP_WIN_REC; i += SP_BLOCK) {
+                const int e = i / SP_WIN_REC, k = i - e * SP_WIN_REC;
+                s_rec[i] = w.scratch[(size_t)e * w.stride + k];
+            }
+            for (int b = tid; b < min(w.n_blocks, SP_WIN_LDS_BLOCKS); b += SP_BLOCK) s_block[b] = w.blocks[b];
+        }
+    }
+    if (!w.compose_only) {
+        __shared__ int frozen;
+        if (tid == 0) frozen = st3 != 0.f;
         __syncthreads();
+        if (frozen) return;                             // converged earlier: the window is frozen
+        auto REC = [&](int e) -> const double* { if constexpr (STAGED) return s_rec + e * SP_WIN_REC; else return w.scratch + (size_t)e * w.stride; };
+        auto EDGE = [&](int e) -> SpWindowEdge { if constexpr (STAGED) return s_edge[e]; else return w.edges[e]; };
+        for (int e = tid; e < w.n_edges; e += SP_BLOCK) {
+            const double r = REC(e)[0];
+            const float sg = w.abs_loss ? (r > 0.0 ? 1.f : (r < 0.0 ? -1.f : 0.f)) : 1.f;
+            coef[e] = EDGE(e).weight * sg;
+        }
+        // d(Exp(a) X)/da_k of the persistent-tangent nodes, one lane per (node, k): forward-mode dual numbers with a single
+        // tangent on the same code that evaluates Exp(a) X
+        for (int idx = tid; idx < min(w.n_nodes, SP_WIN_LDS_DIRECT) * 6; idx += SP_BLOCK) {
+            const int i = idx / 6, k = idx - 6 * i;
+            const SpWindowNode& nd = nodes[i];
+            if (nd.kind != 1) continue;
+            Dual<1> ad[6], out[12];
+            for (int q = 0; q < 6; ++q) { ad[q].v = nd.a[q]; ad[q].d[0] = (q == k) ? 1.f : 0.f; }
+            se3_exp_times<1>(ad, nd.T, out);
+            for (int q = 0; q < 12; ++q) s_dP[i][k][q] = out[q].d[0];
+        }
         if (tid == 0) {
             double loss = 0.0;
             for (int e = 0; e < w.n_edges; ++e) {
-                const double r = w.scratch[(size_t)e * w.stride];
-                loss += (double)w.edges[e].weight * (w.abs_loss ? fabs(r) : r);
+                const double r = REC(e)[0];
+                loss += (double)EDGE(e).weight * (w.abs_loss ? fabs(r) : r);
             }
-            const int it = (int)st[1];
+            const int it = (int)st1;
             const int upd = !(w.skip_first && it == 0);
             do_update = upd;
             if (it < w.max_losses) w.losses[it] = (float)loss;
-            float t = st[0];
-            if (upd) t += 1.f;
-            const double bc1 = 1.0 - pow(0.9, (double)t), bc2 = 1.0 - pow(0.999, (double)t);
+            float t = st0;
+            // beta^t as running products in double (state[6..9]; restarted together with the step count): the same values
+            // as pow() to 1e-13 after thousands of steps, without two double pow() calls on the critical path
+            if (t == 0.f) { b1t = 1.0; b2t = 1.0; }
+            if (upd) { t += 1.f; b1t *= 0.9; b2t *= 0.999; __builtin_memcpy(st + 6, &b1t, 8); __builtin_memcpy(st + 8, &b2t, 8); }
+            const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
             neg_inv_bc1 = upd ? (float)(-1.0 / bc1) : 0.f;
             bc2s_f = upd ? (float)sqrt(bc2) : 1.f;
             // relative-loss early stop (odometery.py:907-915): checked AFTER this iteration's update went in
-            const float prev = st[2];
             int done = 0;
             if (w.rel_tol > 0.f) {
-                if (it > 0 && fabsf((float)loss - prev) / prev < w.rel_tol) done = 1;
+                if (it > 0 && fabsf((float)loss - st2) / st2 < w.rel_tol) done = 1;
                 st[2] = (float)loss;
             }
             st[0] = t; st[1] = (float)(it + 1); st[3] = done ? 1.f : 0.f; st[4] = (float)loss;
         }
         __syncthreads();
         if (do_update) {
-            // ---- log-depth blocks ----------------------------------------------------------------
-            for (int b = 0; b < w.n_blocks; ++b) {
-                const SpWindowBlock bk = w.blocks[b];
+            // ---- log-depth blocks: one wave per block (blocks wave, wave + 4, ...), lanes over its segments -------
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int b = wave; b < w.n_blocks; b += SP_WAVES) {
+                SpWindowBlock bk;
+                if (STAGED && b < SP_WIN_LDS_BLOCKS) bk = s_block[b]; else bk = w.blocks[b];
                 if (!(bk.lr > 0.f)) continue;                       // frozen (odometery.py:594-603) or constant
                 const float ns = bk.lr * neg_inv_bc1;
-                for (int n = tid; n < bk.N; n += SP_BLOCK) {
+                for (int n = lane; n < bk.N; n += 64) {
                     double g = 0.0;
                     bool any = false;
                     for (int e = 0; e < w.n_edges; ++e)
-                        if (w.edges[e].block == b) { g += (double)coef[e] * w.scratch[(size_t)e * w.stride + SP_WIN_REC + n]; any = true; }
+                        if (EDGE(e).block == b) { g += (double)coef[e] * w.scratch[(size_t)e * w.stride + SP_WIN_REC + n]; any = true; }
                     if (any) bk.kld[n] += adam_torch((float)g, bk.m[n], bk.v[n], ns, bc2s_f);
                 }
             }
-            // ---- poses and affine pairs ----------------------------------------------------------
+            // ---- poses and affine pairs: one lane per node, sums over the edges in edge order -------------------
             for (int i = tid; i < w.n_nodes; i += SP_BLOCK) {
-                SpWindowNode& nd = w.nodes[i];
+                SpWindowNode& nd = nodes[i];
                 double g6[6] = {0, 0, 0, 0, 0, 0}, ga = 0.0, gb = 0.0;
                 bool any = false;
                 for (int e = 0; e < w.n_edges; ++e) {
-                    const SpWindowEdge ed = w.edges[e];
-                    const double* rec = w.scratch + (size_t)e * w.stride;
+                    const SpWindowEdge ed = EDGE(e);
+                    if (ed.trg_node != i && ed.src_node != i) continue;
+                    const double* rec = REC(e);
                     const double c = (double)coef[e];
+                    any = true;
                     if (ed.trg_node == i) {
-                        any = true;
                         if (nd.kind == 0) {
                             for (int k = 0; k < 6; ++k) g6[k] += c * rec[1 + k];
+                        } else if (i < SP_WIN_LDS_DIRECT) {
+                            for (int k = 0; k < 6; ++k) {
+                                double s = 0.0;
+                                for (int q = 0; q < 12; ++q) s += (double)s_dP[i][k][q] * rec[7 + q];
+                                g6[k] += c * s;
+                            }
                         } else {
-                            // persistent tangent: pose = Exp(a) X; d/da through dExp, by dual numbers on the same code
                             Dual<6> ad[6], out[12];
                             for (int q = 0; q < 6; ++q) { ad[q].v = nd.a[q]; for (int k = 0; k < 6; ++k) ad[q].d[k] = (q == k) ? 1.f : 0.f; }
                             se3_exp_times<6>(ad, nd.T, out);
@@ -192,17 +275,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_update(WinArgs w) {
                         ga += c * rec[19]; gb += c * rec[20];
                     }
                     if (ed.src_node == i) {
-                        // P = M Exp(-d_src) = Exp(-Ad_M d_src) M  =>  d/dd_src = -Ad_P^T g_left,
-                        // Ad^T [g_tau; g_phi] = [R^T g_tau ; R^T (g_phi - t x g_tau)]
-                        any = true;
-                        const float* P = w.pairs[e].pose;
-                        const double gt0 = rec[1], gt1 = rec[2], gt2 = rec[3];
-                        const double t0 = P[3], t1 = P[7], t2 = P[11];
-                        const double u0 = rec[4] - (t1 * gt2 - t2 * gt1), u1 = rec[5] - (t2 * gt0 - t0 * gt2), u2 = rec[6] - (t0 * gt1 - t1 * gt0);
-                        for (int k = 0; k < 3; ++k) {
-                            g6[k] -= c * ((double)P[k] * gt0 + (double)P[4 + k] * gt1 + (double)P[8 + k] * gt2);
-                            g6[3 + k] -= c * ((double)P[k] * u0 + (double)P[4 + k] * u1 + (double)P[8 + k] * u2);
-                        }
+                        for (int k = 0; k < 6; ++k) g6[k] += c * rec[21 + k];
                         ga -= c * rec[19]; gb -= c * rec[20];
                     }
                 }
@@ -237,13 +310,16 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_update(WinArgs w) {
                 }
             }
         }
-        __syncthreads();
     }
+    __syncthreads();
     // ---- relative pose and affine slot of every edge for the next cost pass -----------------------------
     for (int e = tid; e < w.n_edges; e += SP_BLOCK) {
-        const SpWindowEdge ed = w.edges[e];
-        const SpWindowNode& nt = w.nodes[ed.trg_node];
-        float* P = w.pairs[e].pose;
+        SpWindowEdge ed;
+        float* P;
+        float* af;
+        if constexpr (STAGED) { ed = s_edge[e]; P = s_pose_ptr[e]; af = s_aff_ptr[e]; }
+        else { ed = w.edges[e]; P = w.pairs[e].pose; af = w.pairs[e].aff; }
+        const SpWindowNode& nt = nodes[ed.trg_node];
         if (nt.kind == 1) {
             Dual<1> ad[6], out[12];
             for (int q = 0; q < 6; ++q) { ad[q].v = nt.a[q]; ad[q].d[0] = 0.f; }
@@ -253,7 +329,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_update(WinArgs w) {
             // inv(T_trg) T_src  (tangents are zero between iterations)
             double Rs[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, ts[3] = {0, 0, 0};
             if (ed.src_node >= 0) {
-                const SpWindowNode& ns = w.nodes[ed.src_node];
+                const SpWindowNode& ns = nodes[ed.src_node];
                 for (int r = 0; r < 3; ++r) { for (int cc = 0; cc < 3; ++cc) Rs[3 * r + cc] = ns.T[4 * r + cc]; ts[r] = ns.T[4 * r + 3]; }
             }
             for (int r = 0; r < 3; ++r) {
@@ -264,14 +340,23 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_update(WinArgs w) {
             }
         }
         P[12] = 0.f; P[13] = 0.f; P[14] = 0.f; P[15] = 1.f;
-        float* af = w.pairs[e].aff;
         if (af) {
-            af[0] = ed.src_node >= 0 ? w.nodes[ed.src_node].aff[0] : 0.f;
-            af[1] = ed.src_node >= 0 ? w.nodes[ed.src_node].aff[1] : 0.f;
+            af[0] = ed.src_node >= 0 ? nodes[ed.src_node].aff[0] : 0.f;
+            af[1] = ed.src_node >= 0 ? nodes[ed.src_node].aff[1] : 0.f;
             af[2] = nt.aff[0];
             af[3] = nt.aff[1];
         }
     }
+    if (staged && !w.compose_only) {                 // nodes back to global memory, coalesced
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(s_node);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(w.nodes);
+        for (int i = tid; i < w.n_nodes * 44; i += SP_BLOCK) dst[i] = src[i];
+    }
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_window_update(WinArgs w) {
+    if (w.n_edges <= SP_WIN_LDS_EDGES && w.n_nodes <= SP_WIN_LDS_NODES) window_update_body<true>(w);
+    else window_update_body<false>(w);
 }
 
 }  // namespace

@@ -152,7 +152,7 @@ class PoseWindow:
         self.partials = torch.empty(self.n_spans * _lib.SP_GRAD_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
         self.seg_partials = torch.empty(4 * self.n_chunks * _lib.SP_GRAD_SEG_FLOATS, dtype=torch.float32, device=dev)
         self.scratch = torch.zeros(lib.sp_window_scratch_doubles(E, self.max_N), dtype=torch.float64, device=dev)
-        self.state = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(12, dtype=torch.float32, device=dev)
         self.max_iters = int(max_iters)
         self.loss_hist = torch.zeros(self.max_iters, dtype=torch.float32, device=dev)
         self._graphs = {}

@@ -76,7 +76,7 @@ def _void_worker(rank, world, port, out):
         counts = torch.randint(0, 3, (48 * 64,), generator=g, dtype=torch.int32)
         mine = (sums.clone(), counts.clone())
         spd.reduce_depth_accumulators(sums, counts)
-        out.put((rank, mine[0], mine[1], sums, counts))
+        out.put((rank, mine[0].numpy(), mine[1].numpy(), sums.numpy(), counts.numpy()))       # by value: the worker exits
     finally:
         dist.destroy_process_group()
 
@@ -99,8 +99,8 @@ def test_void_segment_sharding_collective_world2():
     S = got[0][1] + got[1][1]
     C = got[0][2] + got[1][2]
     for _, _, _, s, c in got:
-        assert torch.equal(s, S) and torch.equal(c, C)
-    assert torch.equal(C > 0, (got[0][2] > 0) | (got[1][2] > 0))
+        assert np.array_equal(s, S) and np.array_equal(c, C)
+    assert np.array_equal(C > 0, (got[0][2] > 0) | (got[1][2] > 0))
 
 
 def test_segment_shards_partition_the_keyframe():
