@@ -37,6 +37,44 @@ def test_abi_constants_and_struct_layout_match_header():
         assert getattr(_lib, macro) == val, macro
     assert ctypes.sizeof(_lib.SpPair) == 136
     assert _lib.SpPair.K_src.offset == 64 and _lib.SpPair.N.offset == 96 and _lib.SpPair.zmin.offset == 128
+    # window optimiser structs (sizes are static_assert-ed on the device side, sp_window.hip)
+    assert ctypes.sizeof(_lib.SpWindowNode) == 176 and ctypes.sizeof(_lib.SpWindowEdge) == 16 and ctypes.sizeof(_lib.SpWindowBlock) == 32
+    assert _lib.SpWindowNode.a.offset == 64 and _lib.SpWindowNode.aff.offset == 136 and _lib.SpWindowNode.lr_pose.offset == 160
+    assert _lib.SpWindowNode.kind.offset == 168 and _lib.SpWindowBlock.N.offset == 24
+
+
+def test_new_entry_points_validate_arguments_and_sizes():
+    from super_primitive_amd import _lib
+    lib = _lib.load()
+    assert lib.sp_points_workspace_floats(5000, 2) == 3 * 2 * 16 and lib.sp_points_workspace_floats(0, 1) == 0
+    assert lib.sp_points_cost_grad(*([None] * 2), 10, 10, 4, 4, None, 2, 2, None, None, 1, None, None, 1e-7, *([None] * 5)) == -1
+    assert lib.sp_window_scratch_doubles(10, 40) == 10 * (28 + 40)
+    assert lib.sp_window_compose(None, None, 1, None, 1, None) == -1
+    assert lib.sp_window_step(*([None] * 2), 1, None, 1, None, 1, 1, *([None] * 3), 0, 0, 0.0, None, None, 0, None) == -1
+    assert lib.sp_depth_accumulate(*([None] * 6), 1, 1, 1, 1, None, None) == -1
+    assert lib.sp_depth_average_finish(None, 4, 4, None, None, None) == -1
+
+
+def test_work_list_helpers_cover_every_point_once():
+    """pad_layout / build_work_list (shared by PairBatch and PoseWindow): padded runs are granule multiples, chunks tile every
+    padded segment exactly once, spans tile the chunks, record offsets count 4 records per chunk."""
+    from super_primitive_amd.optim.pair_batch import GRANULE, build_work_list, pad_layout
+    rng = np.random.default_rng(3)
+    pads = [pad_layout(rng.integers(0, 3000, size=n), "cpu") for n in (7, 1, 30)]
+    wl = build_work_list(pads, span_points=2048, tile_points=1024)
+    chunks, spans = wl["chunks"], wl["spans"]
+    assert np.all(chunks[:, 3] % GRANULE == 0) and np.all(chunks[:, 3] > 0) and np.all(chunks[:, 3] <= 1024)
+    for m, pd in enumerate(pads):
+        mine = chunks[chunks[:, 0] == m]
+        covered = np.zeros(pd["Ppad"], dtype=int)
+        for _, seg, start, count in mine:
+            assert pd["pseg_off"][seg] <= start and start + count <= pd["pseg_off"][seg] + pd["pc"][seg]
+            covered[start:start + count] += 1
+        assert np.all(covered == 1)
+        assert wl["seg_rec_offs"][m][-1] == 4 * len(mine)
+    assert spans[:, 1].sum() == len(chunks) and np.array_equal(np.cumsum(spans[:, 1]) - spans[:, 1], spans[:, 0])
+    for q, n, pts, pair in spans:
+        assert pts == chunks[q:q + n, 3].sum() and np.all(chunks[q:q + n, 0] == pair)
 
 
 def test_entry_points_reject_bad_arguments_without_a_gpu():
