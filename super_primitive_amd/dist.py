@@ -93,15 +93,13 @@ def complete_depth_sharded(kf, sparse_depth, rank=None, world=None, group=None):
     sub, (lo, hi) = shard_keyframe_segments(kf, rank, world)
     H, W = kf.geo_spatial_dim()
     red = lambda s, c: reduce_depth_accumulators(s, c, group)
-    if sub is None:          # more ranks than segments: contribute zeros
-        import torch as _t
+    if sub is None:          # more ranks than segments: this rank contributes zero accumulators
         from . import _lib
-        s = _t.zeros(H * W, dtype=_t.int64, device=kf.image.device)
-        c = _t.zeros(H * W, dtype=_t.int32, device=kf.image.device)
-        red(s, c)
-        acc = _t.cat((s.view(_t.int32), c))
-        depth = _t.empty(H, W, dtype=_t.float32, device=kf.image.device)
-        invalid = _t.empty(H, W, dtype=_t.bool, device=kf.image.device)
+        dev = kf.image.device
+        acc = torch.zeros(3 * H * W, dtype=torch.int32, device=dev)
+        red(acc[: 2 * H * W].view(torch.int64), acc[2 * H * W:])
+        depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+        invalid = torch.empty(H, W, dtype=torch.bool, device=dev)
         _lib.check(_lib.load().sp_depth_average_finish(_lib.ptr(acc), H, W, _lib.ptr(depth), _lib.ptr(invalid), _lib.stream_ptr()),
                    "sp_depth_average_finish")
         return depth, invalid

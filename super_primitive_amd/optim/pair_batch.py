@@ -321,7 +321,8 @@ class PairBatch:
         return g
 
     def run(self, iters_per_level, mode="gn", use_graph=False, polish_iters=0, polish_eps=1e-5, **kw):
-        """Coarse-to-fine schedule like ``two_frame_sfm.py:150-155``: ``iters_per_level`` iterations at each level.
+        """Coarse-to-fine schedule like ``two_frame_sfm.py:150-155``: ``iters_per_level`` iterations at each level (an int, or
+        one count per level, coarse to fine).
         ``use_graph``: replay one captured iteration per level instead of issuing 2 launches per iteration from
         Python (the captured warm-up iteration counts towards ``iters_per_level``).
         ``polish_iters`` (Gauss-Newton only): that many more iterations at the finest level with the IRLS epsilon at
@@ -335,7 +336,11 @@ class PairBatch:
                 self.gn_step(finest, **{**kw, "irls_eps": polish_eps})
 
     def _run_levels(self, iters_per_level, mode, use_graph, **kw):
-        for level in reversed(self.level_ids):
+        per_level = isinstance(iters_per_level, (tuple, list))          # coarse -> fine when given per level
+        if per_level:
+            assert len(iters_per_level) == len(self.level_ids)
+        for li, level in enumerate(reversed(self.level_ids)):
+            n_iters = iters_per_level[li] if per_level else iters_per_level
             if mode == "gn":
                 self.lm_state[:, 1] = -1.0      # costs of different levels are not comparable
                 self.lm_state[:, 4] = 0.0
@@ -346,10 +351,10 @@ class PairBatch:
                 if g is None:
                     g = self._graphs[key] = self.graph(level, mode, 1, **kw)
                     done = 1                     # graph() ran one real warm-up iteration; capturing executes nothing
-                for _ in range(iters_per_level - done):
+                for _ in range(n_iters - done):
                     g.replay()
             else:
-                for _ in range(iters_per_level):
+                for _ in range(n_iters):
                     (self.gn_step if mode == "gn" else self.adam_step)(level, **kw)
 
     # ------------------------------------------------------------------------------------------------
