@@ -151,3 +151,28 @@ def test_precomputed_accepts_reference_shaped_dicts():
     want = orc.photometric_cost_precomputed(ref_half, otrg, torch.from_numpy(g["in_pose"]),
                                             affine=(torch.from_numpy(g["in_aff_src"]), torch.from_numpy(g["in_aff_trg"])))["residual"]
     np.testing.assert_allclose(run(half)[0], want.numpy(), rtol=2e-5)
+
+
+def test_large_windows_take_the_unstaged_path_and_agree_with_the_eager_engine():
+    """More than 96 edges (or 64 nodes) do not fit the LDS staging of k_window_update: the same optimiser then works out of
+    global memory.  One small keyframe against 100 supporting frames, 6 iterations, fused vs eager."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.odometery.loops import map_window
+    rng = np.random.default_rng(5)
+    n_supp = 100
+    twists = [np.zeros(6)] + [np.array([0.03, -0.01, 0.008, 0.004, -0.006, 0.003]) * rng.uniform(0.2, 1.5, 6) for _ in range(n_supp)]
+    frames = synth.make_sequence(32, 40, 4, twists, keyframe_ids=[0], seed=9, overlap=1)
+    kf = KeyFrame(T(frames[0].image), T(frames[0].K), T(frames[0].logdepth_perseg), T(frames[0].keypoints), T(frames[0].keypoint_regions))
+    dev = kf.image.device
+    supp = [[(KeyFrame(T(f.image), T(f.K)), T((f.T_wc.astype(np.float64) @ synth.se3_exp_np(0.003 * rng.standard_normal(6))).astype(np.float32)),
+              torch.zeros(2, device=dev)) for f in frames[1:]]]
+    args = ([kf], [T(frames[0].T_wc)], [T((frames[0].kld_gt + 0.02 * rng.standard_normal(4)).astype(np.float32))], [torch.zeros(2, device=dev)], supp, 6)
+    a = map_window(*args, lr_pose=1e-3, window_size=5, initialised=False, fused=True)
+    b = map_window(*args, lr_pose=1e-3, window_size=5, initialised=False, fused=False)
+    La, Lb = np.array([float(l) for l in a["losses"]]), np.array([float(l) for l in b["losses"]])
+    np.testing.assert_allclose(La, Lb, rtol=2e-5)
+    np.testing.assert_allclose(npy(a["klds"][0]), npy(b["klds"][0]), atol=2e-5)
+    pa, pb = np.stack([npy(p) for p in a["supp_poses"][0]]), np.stack([npy(p) for p in b["supp_poses"][0]])
+    np.testing.assert_allclose(pa, pb, atol=2e-5)
+    assert not np.allclose(pa, np.stack([npy(p) for _, p, _ in supp[0]]), atol=1e-4), "the supporting poses did move"
