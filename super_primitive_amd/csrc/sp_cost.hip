@@ -624,55 +624,63 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
     const int n_iter = total / SP_BLOCK;
     uint32_t op = threadIdx.x * 4u;
     constexpr int NT = 2;
-    Pending nx;
-    int nx_q, cur_q = q0;
-    bool nx_last, cur_last = false;
+    // two point slots used alternately, the loop unrolled by two (see run_span_gn): nothing is copied at the back edge
+    struct Slot { Pending p; int q; bool last; };
+    Slot S0, S1;
     {
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
-        prepare(c, k.shift, ifx, ify, pw, s, nx);
-        nx_last = cursor_advance(k, nx_q);
+        prepare(c, k.shift, ifx, ify, pw, s, S0.p);
+        S0.last = cursor_advance(k, S0.q);
     }
-    Geo cur = nx.g;
-    cur.zinv = 0.f; cur.zi = 0.f;
+    S1.p = S0.p;                         // "point -1": contributes exact zeros
+    S1.p.g.zinv = 0.f; S1.p.g.zi = 0.f;
+    S1.q = q0; S1.last = false;
     Mix0 m0{0.f, 0.f, 0.f, 0.f};
     auto flush = [&](int q) {
         const float tot = wave_sum(acc[13]);
         if (lane_id() == 0) store_partial<WT>(seg_partials + (size_t)(4 * q + wave) * SP_GRAD_SEG_FLOATS, tot);
         acc[13] = 0.f;
     };
-    for (int j = 0; j < n_iter; ++j) {
+    auto trip = [&](Slot& a, Slot& b) {
         op += 4u * SP_BLOCK;
         asm volatile("" : "+v"(op));
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
         f32x3 ta, tb, tc, td;
-        if (ABL == 1) { ta = tb = tc = td = f32x3{nx.sr, nx.sg, nx.sb}; }
+        if (ABL == 1) { ta = tb = tc = td = f32x3{a.p.sr, a.p.sg, a.p.sb}; }
         else {
-            ta = buf_load3(r_trg, nx.off0);
-            tb = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS);
-            tc = buf_load3(r_trg, nx.off0, c.row_bytes);
-            td = buf_load3(r_trg, nx.off0 + 4u * SP_TEXEL_FLOATS, c.row_bytes);
+            ta = buf_load3(r_trg, a.p.off0);
+            tb = buf_load3(r_trg, a.p.off0 + 4u * SP_TEXEL_FLOATS);
+            tc = buf_load3(r_trg, a.p.off0, c.row_bytes);
+            td = buf_load3(r_trg, a.p.off0 + 4u * SP_TEXEL_FLOATS, c.row_bytes);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL != 2) fold_grad(c, cur, m0, acc);
-        if (cur_last) flush(cur_q);
+        if (ABL != 2) fold_grad(c, b.p.g, m0, acc);
+        if (b.last) flush(b.q);
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 1)
-            asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
-                         "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]));
-        if (ABL == 2) acc[0] += ta.x + tb.y + tc.z + td.x + nx.wx + nx.wy + nx.m;
-        else finish_grad(c, nx, ta, tb, tc, td, m0, acc[0]);
-        cur = nx.g;
-        cur_q = nx_q; cur_last = nx_last;
+            asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+                         "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]),
+                         "+v"(acc[13]), "+v"(acc[14]), "+v"(acc[15]));
+        if (ABL == 2) acc[0] += ta.x + tb.y + tc.z + td.x + a.p.wx + a.p.wy + a.p.m;
+        else finish_grad(c, a.p, ta, tb, tc, td, m0, acc[0]);
         uint32_t pw_ = pw;
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
-        prepare(c, k.shift, ifx, ify, pw_, s_, nx);
-        nx_last = cursor_advance(k, nx_q);
+        prepare(c, k.shift, ifx, ify, pw_, s_, b.p);
+        b.last = cursor_advance(k, b.q);
+    };
+    int j = 0;
+    for (; j + 1 < n_iter; j += 2) { trip(S0, S1); trip(S1, S0); }
+    if (j < n_iter) {                    // odd trip count: the last point sits in S0
+        trip(S0, S1);
+        if (ABL != 2) fold_grad(c, S0.p.g, m0, acc);
+        flush(S0.q);
+    } else {
+        if (ABL != 2) fold_grad(c, S1.p.g, m0, acc);
+        flush(S1.q);
     }
-    if (ABL != 2) fold_grad(c, cur, m0, acc);
-    flush(cur_q);
     const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
     const float tot = block_sum_to_thread<NV>(acc, lds, tid);      // (column 13 is zero here: flushed per chunk)
     if (tid < NV) store_partial<WT>(span_rec + tid, tot);
