@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 4
+#define SP_ABI_VERSION 5
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -194,6 +194,18 @@ int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float*
 #define SP_LM_STATE_FLOATS 8
 int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* span_partials, const float* seg_partials,
                      float lm_up, float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream);
+
+/* Per-pair convergence on the device (the counterpart of the reference's relative-loss early stop, odometery/odometery.py:907-915,
+ * for a batch whose pairs need different numbers of iterations).  sp_pairs_gn_step_conv marks done[pair] = 1 -- and leaves the pair
+ * at its current point -- when the step that led to the evaluated point was accepted and lowered the cost by less than
+ * conv_tol * cost; it returns immediately for pairs already marked.  sp_pairs_cost_active is sp_pairs_cost whose workgroups return
+ * at once for spans of marked pairs: an iteration then costs time only for the pairs still moving.  done: n_pairs int32, zeroed
+ * by the caller (per pyramid level).  conv_tol <= 0 / done == NULL: exactly sp_pairs_gn_step / sp_pairs_cost. */
+int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
+                         float* span_partials, float* seg_partials, const int32_t* done, void* stream);
+int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const float* span_partials, const float* seg_partials,
+                          float lm_up, float lm_down, float lm_min, float* lm_state, float* backup, float* costs, float conv_tol,
+                          int32_t* done, void* stream);
 
 /* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last span of a pair
  * runs that pair's update in place (same arithmetic, same fixed reduction order as sp_pairs_cost followed by

@@ -32,6 +32,8 @@ SIGNATURES = {
     "sp_pairs_cost": [P, P, P, I, I, F, P, P, P],
     "sp_pairs_adam_step": [P, I, I, P, P, F, F, F, P, P, P],
     "sp_pairs_gn_step": [P, I, I, P, P, F, F, F, P, P, P, P],
+    "sp_pairs_cost_active": [P, P, P, I, I, F, P, P, P, P],
+    "sp_pairs_gn_step_conv": [P, I, I, P, P, F, F, F, P, P, P, F, P, P],
     "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, P, F, F, F, P, P, P],
     "sp_pairs_gn_iterate": [P, P, P, I, I, I, F, P, P, P, F, F, F, P, P, P, P],
     "sp_window_scratch_doubles": [I, I],
@@ -53,7 +55,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 4
+SP_ABI_VERSION = 5
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GRAD_SEG_FLOATS = 1

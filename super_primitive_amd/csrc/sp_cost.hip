@@ -818,6 +818,7 @@ struct FuseArgs {
     int32_t* arrivals;
     AdamArgs adam;
     GnArgs gn;
+    const int32_t* done;      // [n_pairs] or NULL: spans of pairs marked done by the solver return at once
 };
 
 template <int MODE, int ABL = 0, int FUSED = 0>
@@ -829,6 +830,7 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
     const int w = xcd_chunked_tile(blockIdx.x, n_spans);
     if (w >= n_spans) return;
     const int4 span = spans[w];             // {first chunk, number of chunks, points, pair}
+    if (f.done && f.done[span.w]) return;   // converged pair (sp_pairs_cost_active): nothing to evaluate
     const SpPair& pr = pairs[span.w];
     TileCtx c;
     c.pix = (gptr_u32)pr.pix;
@@ -1010,15 +1012,24 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
     return 0;
 }
 
+int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
+                         float* partials, float* seg_partials, const int32_t* done, void* stream);
+
 int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                   float* partials, float* seg_partials, void* stream) {
+    return sp_pairs_cost_active(pairs, chunks, spans, n_spans, mode, irls_eps, partials, seg_partials, nullptr, stream);
+}
+
+int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
+                         float* partials, float* seg_partials, const int32_t* done, void* stream) {
     if (!pairs || !chunks || !spans || !partials || !seg_partials || n_spans <= 0) return SP_EINVAL;
     if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 14)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_spans + 7) / 8) * 8;
     const int4* c4 = reinterpret_cast<const int4*>(chunks);
     const int4* s4 = reinterpret_cast<const int4*>(spans);
-    const FuseArgs nofuse{};
+    FuseArgs nofuse{};
+    nofuse.done = done;
     if (mode == 0)
         hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 1)
@@ -1061,7 +1072,7 @@ int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_
         return SP_EINVAL;
     FuseArgs f{};
     f.arrivals = arrivals;
-    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs};
+    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr};
     const int gx = ((n_spans + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cost_pairs<1, 0, 2>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
                        reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, f);

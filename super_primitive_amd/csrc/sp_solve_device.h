@@ -245,6 +245,8 @@ struct GnArgs {
     float* lm_state;
     float* backup;
     float* costs;
+    float conv_tol;          // > 0: a pair whose last accepted step lowered its cost by less than conv_tol * cost is marked done
+    int32_t* done;           // [n_pairs] or NULL; done pairs are skipped by the cost pass and by this solver
 };
 
 // One workgroup: tile-partial reduction + Schur-complement LM step of pair `pi` (include/sp_hip.h sp_pairs_gn_step).
@@ -264,6 +266,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
     __shared__ double dxi[6];
     __shared__ int decision;         // 0 = step, 1 = rejected (restore)
     const SpPair& pr = pairs[pi];
+    if (h.done && h.done[pi]) return;          // converged earlier (its spans were not evaluated either)
     const float* p = partials + (size_t)pr.tile0 * NV;
     const float* sp = seg_partials + (size_t)pr.rec0 * SP_GN_SEG_FLOATS;
     float* ls = lm_state + (size_t)pi * SP_LM_STRIDE;
@@ -274,11 +277,18 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         const float last = ls[1];
         int rej = 0;
         if (last >= 0.f && (float)cost > last * (1.f + 1e-6f) && ls[4] == 0.f) rej = 1;
+        // convergence (per pair, on the device): the step that led here was accepted and bought less than conv_tol of the
+        // cost -> keep the current point and stop working on this pair (decision 2)
+        if (!rej && h.done && h.conv_tol > 0.f && last >= 0.f && ls[4] == 0.f && (last - (float)cost) <= h.conv_tol * last) {
+            rej = 2;
+            h.done[pi] = 1;
+        }
         decision = rej;
         ls[5] = (float)cost;
         costs[pi] = (float)cost;
     }
     __syncthreads();
+    if (decision == 2) return;
     if (decision == 1) {
         // undo the previous step; the next cost pass re-evaluates at the restored point with a larger lambda
         for (int i = threadIdx.x; i < 16; i += SP_BLOCK) pr.pose[i] = bk[i];

@@ -72,13 +72,21 @@ int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float*
     return 0;
 }
 
-int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, const float* seg_partials,
-                     float lm_up, float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream) {
+int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const float* partials, const float* seg_partials,
+                          float lm_up, float lm_down, float lm_min, float* lm_state, float* backup, float* costs, float conv_tol,
+                          int32_t* done, void* stream) {
     if (!pairs || !partials || !seg_partials || !lm_state || !backup || !costs || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+    if (conv_tol > 0.f && !done) return SP_EINVAL;
     hipLaunchKernelGGL(k_pairs_gn, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs, partials,
-                       seg_partials, GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs});
+                       seg_partials, GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, conv_tol, done});
     SP_CHECK_LAUNCH();
     return 0;
+}
+
+int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, const float* seg_partials,
+                     float lm_up, float lm_down, float lm_min, float* lm_state, float* backup, float* costs, void* stream) {
+    return sp_pairs_gn_step_conv(pairs, n_pairs, max_N, partials, seg_partials, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f,
+                                 nullptr, stream);
 }
 
 int sp_renormalise_se3(float* T, int n, void* stream) {

@@ -29,9 +29,12 @@ GRANULE = 256                      # SP_BLOCK: every segment is padded to a mult
 
 # The coarse-to-fine schedule "frame pairs per second" is quoted on (bench.py) and that tests/test_gpu_fullsize.py
 # requires to land within the north-star bar (1e-4 rad / 1e-4 t / 1e-3 relative depth) of the minimiser of the
-# reference cost at 640x480x64 (golden g15): LM iterations per pyramid level with the default IRLS epsilon, then
-# ``polish_iters`` more at the finest level with the epsilon at ``polish_eps`` (see PairBatch.run).
-FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps=1e-5)
+# reference cost at 640x480x64 (golden g15): LM iterations per pyramid level with the default IRLS epsilon and PER-PAIR
+# termination on the device (PairBatch.run_converging: a pair leaves a level once an accepted step buys less than
+# ``conv_tol`` of its cost), then a polish at the finest level with the epsilon at ``polish_eps`` under ``polish_tol``.
+# FIXED_FRAME_PAIR_SCHEDULE is the same without early termination (every pair runs the maximum), kept for comparison.
+FRAME_PAIR_SCHEDULE = dict(max_iters_per_level=25, conv_tol=2e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-4, check_every=3)
+FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps=1e-5)
 
 
 def _level_images(img, max_level):
@@ -223,6 +226,7 @@ class PairBatch:
         self.lm_state = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
         self.backup = torch.zeros(M, 16 + self.max_N, dtype=torch.float32, device=dev)
         self.arrivals = torch.zeros(M, dtype=torch.int32, device=dev)     # per-pair tile-arrival counters (fused launch)
+        self.done = torch.zeros(M, dtype=torch.int32, device=dev)         # per-pair convergence flags (gn_step(conv_tol=...))
         self.reset_lm()
         self._graphs = {}
         self._keep = (tables0,)
@@ -235,6 +239,7 @@ class PairBatch:
         if self.aff is not None:
             self.aff.zero_()
         self.adam_state.zero_()
+        self.done.zero_()
         self.reset_lm()
 
     # ------------------------------------------------------------------------------------------------
@@ -257,7 +262,7 @@ class PairBatch:
         _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, mode,
                                           float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.stream_ptr()), "sp_pairs_cost")
 
-    def gn_step(self, level=0, irls_eps=1e-3, lm_up=8.0, lm_down=0.5, lm_min=1e-7, fused=False):
+    def gn_step(self, level=0, irls_eps=1e-3, lm_up=8.0, lm_down=0.5, lm_min=1e-7, fused=False, conv_tol=0.0):
         """One Gauss-Newton/LM iteration of every pair at pyramid ``level``.  Returns the (M,) device tensor of costs
         (= the reference's residual) evaluated at the parameters BEFORE this step.  Default: two launches (cost
         pass, then one workgroup per pair).  ``fused=True``: a single launch in which the workgroup finishing a
@@ -269,6 +274,16 @@ class PairBatch:
                                                     float(lm_up), float(lm_down), float(lm_min), _lib.ptr(self.lm_state),
                                                     _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.stream_ptr()),
                        "sp_pairs_gn_iterate")
+            return self._costs
+        if conv_tol > 0.0:
+            # per-pair convergence on the device: pairs in self.done are skipped by both launches (``run(conv_tol=...)``)
+            _lib.check(self.lib.sp_pairs_cost_active(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, 1,
+                                                     float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials),
+                                                     _lib.ptr(self.done), _lib.stream_ptr()), "sp_pairs_cost_active")
+            _lib.check(self.lib.sp_pairs_gn_step_conv(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials),
+                                                      _lib.ptr(self.seg_partials), float(lm_up), float(lm_down), float(lm_min),
+                                                      _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs),
+                                                      float(conv_tol), _lib.ptr(self.done), _lib.stream_ptr()), "sp_pairs_gn_step_conv")
             return self._costs
         self.cost_pass(level, 1, irls_eps)
         return self.solve_gn(level, lm_up, lm_down, lm_min)
@@ -319,6 +334,32 @@ class PairBatch:
             for _ in range(iters):
                 step(level, **kw)
         return g
+
+    def run_converging(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, check_every=3, **kw):
+        """Coarse-to-fine Gauss-Newton with PER-PAIR termination (the batch counterpart of the reference's relative-loss
+        early stop, odometery.py:907-915): at every level a pair leaves the iteration as soon as an accepted step lowers its
+        cost by less than ``conv_tol`` -- its spans and its solve are skipped from then on -- and the level ends when every
+        pair has left (polled every ``check_every`` iterations) or after ``max_iters_per_level``.  The finest level ends with
+        up to ``polish_max`` iterations at IRLS epsilon ``polish_eps`` under ``polish_tol``.  Returns the iterations launched
+        per phase.  A batch costs the SUM of the iterations its pairs need instead of pairs x the maximum."""
+        launched = []
+        phases = [(level, max_iters_per_level, kw.get("irls_eps", 1e-3), conv_tol) for level in reversed(self.level_ids)]
+        if polish_max > 0:
+            phases.append((min(self.level_ids), polish_max, polish_eps, polish_tol))
+        for level, n_max, eps, tol in phases:
+            self.lm_state[:, 1] = -1.0
+            self.lm_state[:, 4] = 0.0
+            self.done.zero_()
+            it = 0
+            while it < n_max:
+                for _ in range(min(check_every, n_max - it)):
+                    self.gn_step(level, **{**kw, "irls_eps": eps, "conv_tol": tol})
+                    it += 1
+                if bool(self.done.all()):
+                    break
+            launched.append(it)
+        self.done.zero_()
+        return launched
 
     def run(self, iters_per_level, mode="gn", use_graph=False, polish_iters=0, polish_eps=1e-5, **kw):
         """Coarse-to-fine schedule like ``two_frame_sfm.py:150-155``: ``iters_per_level`` iterations at each level (an int, or

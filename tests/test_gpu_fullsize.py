@@ -113,9 +113,9 @@ def test_bench_schedule_reaches_the_reference_minimiser_at_full_size():
     g = load_golden("g15_config2_fullsize")
     pairs = [fullsize_pair(g)] + [synth.make_pair(480, 640, 64, seed=1000 + s, overlap=4, init_sigma=0.004) for s in (1, 2, 3)]
     batch = PairBatch.from_synth(pairs, levels=(0, 3), device="cuda:0")
-    batch.run(FRAME_PAIR_SCHEDULE["iters_per_level"], mode="gn", polish_iters=FRAME_PAIR_SCHEDULE["polish_iters"],
-              polish_eps=FRAME_PAIR_SCHEDULE["polish_eps"])
+    launched = batch.run_converging(**FRAME_PAIR_SCHEDULE)
     torch.cuda.synchronize()
+    assert len(launched) == 4 and all(0 < n <= FRAME_PAIR_SCHEDULE["max_iters_per_level"] for n in launched)
     poses, klds = npy(batch.poses()), [npy(k) for k in batch.klds()]
     err = pose_depth_errors(poses[0], klds[0], g["min_pose"], g["min_kld"])
     assert within_bar(err), err
@@ -123,6 +123,12 @@ def test_bench_schedule_reaches_the_reference_minimiser_at_full_size():
     for m in (1, 2, 3):
         e = pose_depth_errors(poses[m], klds[m], pairs[m].pose_gt, pairs[m].kld_gt)
         assert e[0] <= 1e-4 and e[1] <= 1.5e-4 and e[2] <= 1.2e-3, (m, e)      # bar + the minimiser's own offset from ground truth
+    # the fixed-length form of the schedule (no early termination) lands on the same minimiser
+    from super_primitive_amd.optim.pair_batch import FIXED_FRAME_PAIR_SCHEDULE as FIX
+    batch.restore_initial()
+    batch.run(FIX["iters_per_level"], mode="gn", polish_iters=FIX["polish_iters"], polish_eps=FIX["polish_eps"])
+    err = pose_depth_errors(npy(batch.poses())[0], npy(batch.klds()[0]), g["min_pose"], g["min_kld"])
+    assert within_bar(err), err
 
 
 def test_config5_pair_shape_gn_system_and_determinism():

@@ -407,3 +407,37 @@ def test_results_do_not_depend_on_how_chunks_are_grouped_into_spans():
     np.testing.assert_allclose(outs[0][0][:, :3, :3], outs[1][0][:, :3, :3], atol=2e-5)
     unit = lambda t: t / np.linalg.norm(t, axis=-1, keepdims=True)
     np.testing.assert_allclose(unit(outs[0][0][:, :3, 3]), unit(outs[1][0][:, :3, 3]), atol=2e-4)
+
+
+def test_per_pair_convergence_skips_finished_pairs_and_keeps_their_result():
+    """gn_step(conv_tol > 0): a pair whose accepted step no longer pays is marked done on the device, its spans and its solve
+    are skipped from then on (its parameters and cost stay bit-identical), the others continue; with conv_tol = 0 the done
+    flags are never consulted."""
+    from super_primitive_amd import synth
+    easy = synth.make_pair(60, 80, 6, seed=91, init_sigma=0.0005)
+    easy.kld_init[:] = easy.kld_gt + 1e-4                      # starts at the optimum: converges at once
+    hard = synth.make_pair(60, 80, 6, seed=92, init_sigma=0.01)
+    batch = make_batch([easy, hard], levels=(0, 1), tile_points=512)
+    done_at = {}
+    snap = None
+    for it in range(40):
+        batch.gn_step(0, conv_tol=1e-3)
+        torch.cuda.synchronize()
+        d = npy(batch.done)
+        for m in (0, 1):
+            if d[m] and m not in done_at:
+                done_at[m] = it
+        if 0 in done_at and snap is None:
+            snap = (batch.poses()[0].clone(), batch.klds()[0].clone(), batch.costs()[0].clone())
+        if len(done_at) == 2:
+            break
+    assert 0 in done_at and 1 in done_at and done_at[0] < done_at[1], done_at
+    assert torch.equal(batch.poses()[0], snap[0]) and torch.equal(batch.klds()[0], snap[1]) and torch.equal(batch.costs()[0], snap[2])
+    # the converged pair sits at the optimum the plain iteration reaches
+    ref = make_batch([easy, hard], levels=(0, 1), tile_points=512)
+    for _ in range(40):
+        ref.gn_step(0)
+    np.testing.assert_allclose(npy(batch.evaluate(0)), npy(ref.evaluate(0)), rtol=2e-3)
+    p = batch.klds()[1].clone()
+    batch.gn_step(0, conv_tol=1e-3)                              # everything done: a no-op
+    assert torch.equal(batch.klds()[1], p)
