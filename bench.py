@@ -68,7 +68,7 @@ def parse(argv=None):
 
 def build_batch(args, rank, dev):
     from super_primitive_amd import synth
-    from super_primitive_amd.optim.pair_batch import PairBatch
+    from super_primitive_amd.optim.pair_batch import FRAME_PAIR_POINT_STRIDE, PairBatch
     G = max(1, min(args.distinct, args.pairs))
     R = max(1, args.pairs // G)
     pairs = [synth.make_pair(H, W, args.segments, seed=1000 * rank + s, overlap=4, init_sigma=0.004) for s in range(G)]
@@ -83,6 +83,7 @@ def build_batch(args, rank, dev):
     src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in pairs]
     batch = PairBatch(src, [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs], poses,
                       [t(p.kld_init) for p in pairs], levels=(0, 3), tile_points=args.tile_points, replicate=R,
+                      point_stride=FRAME_PAIR_POINT_STRIDE,     # extra decimated tables for the frame-pair schedule only
                       **({} if getattr(args, 'span_points', None) is None else {'span_points': args.span_points}))
     return batch, pairs
 
@@ -290,7 +291,7 @@ def main(argv=None):
             g.replay()
         torch.cuda.synchronize()
         line["single_pair_gn_iters_per_sec_hipgraph"] = 200 / (time.perf_counter() - t1)
-        from super_primitive_amd.optim.pair_batch import FIXED_FRAME_PAIR_SCHEDULE as FIX, FRAME_PAIR_SCHEDULE as SCH
+        from super_primitive_amd.optim.pair_batch import FIXED_FRAME_PAIR_SCHEDULE as FIX, FRAME_PAIR_POINT_STRIDE as STRIDE, FRAME_PAIR_SCHEDULE as SCH
         if args.mode == "gn":
             # (a) fixed schedule: every pair runs the same number of iterations
             batch.restore_initial()
@@ -303,23 +304,49 @@ def main(argv=None):
             # (b) the quoted one: per-pair termination on the device (pairs leave a level when converged); timed from the
             #     initial poses / random depth seeds, one untimed pass first (nothing is cached between passes)
             batch.restore_initial()
-            batch.run_converging(**SCH)
+            sync()
+            t1 = time.perf_counter()
+            by_level = batch.run_converging(**SCH)
+            sync()
+            line["frame_pairs_per_sec_level_synchronised"] = M / (time.perf_counter() - t1)
+            line["level_synchronised_iterations_launched"] = by_level
+            # (c) the quoted one: the schedule itself on the device, every pair walks through its own levels, the coarse
+            #     levels on their decimated point sets (FRAME_PAIR_POINT_STRIDE); (c') = the same on all points at every level
+            sched_kw = {k: v for k, v in SCH.items() if k != "check_every"}
+            coarse, batch.coarse = batch.coarse, {}
+            batch.restore_initial()
+            batch.run_scheduled(**sched_kw)
+            batch.restore_initial()
+            sync()
+            t1 = time.perf_counter()
+            n_all = batch.run_scheduled(**sched_kw)
+            sync()
+            line["frame_pairs_per_sec_all_points_at_every_level"] = M / (time.perf_counter() - t1)
+            line["all_points_iterations_launched"] = n_all
+            batch.coarse = coarse
+            batch.restore_initial()
+            batch.run_scheduled(**sched_kw)
         batch.restore_initial()
         sync()
         t1 = time.perf_counter()
         if args.mode == "gn":
-            launched = batch.run_converging(**SCH)
+            launched = batch.run_scheduled(**sched_kw)
         else:
             batch.run(500, mode="adam")
         sync()
         dt_sched = time.perf_counter() - t1
         line["frame_pairs_per_sec_per_gpu"] = M / dt_sched          # measured on rank 0 alone (the other ranks idle here)
+        if args.mode == "gn":
+            n_it = (batch.lm_state[:, 2] + batch.lm_state[:, 3]).double()       # accepted + rejected iterations of every pair
+            line["frame_pair_iterations_per_pair"] = {"mean": float(n_it.mean()), "min": float(n_it.min()), "max": float(n_it.max())}
         if world == 1:
             line["frame_pairs_per_sec"] = M / dt_sched
         if args.mode == "gn":
             line["frame_pair_schedule"] = (f"3 levels (coarse to fine), LM iterations until the pair's accepted step buys < {SCH['conv_tol']:g} of its cost "
                                            f"(at most {SCH['max_iters_per_level']} per level), then at level 0 with IRLS eps {SCH['polish_eps']:g} until < "
-                                           f"{SCH['polish_tol']:g} (at most {SCH['polish_max']}); per-pair termination on the device, iterations launched "
+                                           f"{SCH['polish_tol']:g} (at most {SCH['polish_max']}); every pair advances through these phases on its own, on the device "
+                                           f"(PairBatch.run_scheduled); levels 1 / 2 iterate on the source points of the stride-{STRIDE[1]} / stride-{STRIDE[2]} pixel "
+                                           f"lattice (1/{STRIDE[1] ** 2} and 1/{STRIDE[2] ** 2} of them), level 0 and the polish on all points; iterations launched "
                                            f"{launched} (optim.pair_batch.FRAME_PAIR_SCHEDULE; asserted within 1e-4 rad / 1e-4 t / 1e-3 depth of the "
                                            "reference's minimiser by tests/test_gpu_fullsize.py)")
             # in-run check of every resident pair against the synthetic ground truth (rotation is gauge free; translation and

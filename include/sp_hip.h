@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 5
+#define SP_ABI_VERSION 6
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -206,6 +206,36 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
 int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const float* span_partials, const float* seg_partials,
                           float lm_up, float lm_down, float lm_min, float* lm_state, float* backup, float* costs, float conv_tol,
                           int32_t* done, void* stream);
+
+/* A whole coarse-to-fine schedule PER PAIR on the device.  Phase p of the schedule runs on the descriptors `pairs` of one pyramid
+ * level (every phase describes the same n_pairs pairs) over the work list (chunks, spans) of that level's point set -- a coarse
+ * level may run on a decimated copy of the source points with its own, shorter work list -- with IRLS epsilon irls_eps; a pair
+ * moves on to phase p + 1 when an accepted step lowers its cost by less than conv_tol * cost, or after max_iters iterations, and
+ * is finished at phase n_phases.  phase[n_pairs] / iters[n_pairs] (int32, zeroed by the caller) hold every pair's position; the
+ * host only issues (sp_pairs_schedule_cost, sp_pairs_schedule_gn_step) until min(phase) == n_phases.  Pairs advance
+ * independently: one slow pair no longer keeps the others at a coarse level, and finished pairs cost nothing.
+ * sp_pairs_schedule_cost launches the Gauss-Newton cost kernel once per DISTINCT work list (phases sharing `spans` share the
+ * launch); partial buffers of different work lists must not alias.  The struct lives in host memory. */
+#define SP_MAX_PHASES 8
+typedef struct SpPhase {
+    const SpPair* pairs;
+    const int32_t* chunks;
+    const int32_t* spans;
+    float* span_partials;        /* n_spans * SP_GN_PARTIAL_FLOATS */
+    float* seg_partials;         /* 4 * n_chunks * SP_GN_SEG_FLOATS */
+    int32_t n_spans;
+    int32_t max_iters;
+    float irls_eps;
+    float conv_tol;
+} SpPhase;               /* 56 bytes */
+typedef struct SpSchedule {
+    SpPhase phase[SP_MAX_PHASES];
+    int32_t n_phases;
+    int32_t pad_;
+} SpSchedule;            /* 456 bytes */
+int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream);
+int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
+                              float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, void* stream);
 
 /* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last span of a pair
  * runs that pair's update in place (same arithmetic, same fixed reduction order as sp_pairs_cost followed by

@@ -34,6 +34,8 @@ SIGNATURES = {
     "sp_pairs_gn_step": [P, I, I, P, P, F, F, F, P, P, P, P],
     "sp_pairs_cost_active": [P, P, P, I, I, F, P, P, P, P],
     "sp_pairs_gn_step_conv": [P, I, I, P, P, F, F, F, P, P, P, F, P, P],
+    "sp_pairs_schedule_cost": [P, P, P],
+    "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P],
     "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, P, F, F, F, P, P, P],
     "sp_pairs_gn_iterate": [P, P, P, I, I, I, F, P, P, P, F, F, F, P, P, P, P],
     "sp_window_scratch_doubles": [I, I],
@@ -55,7 +57,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 5
+SP_ABI_VERSION = 6
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GRAD_SEG_FLOATS = 1
@@ -72,6 +74,20 @@ class SpPair(ctypes.Structure):
         ("N", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("Hl", c_int), ("Wl", c_int),
         ("tile0", c_int), ("n_tiles", c_int), ("zmin", c_float), ("rec0", c_int),
     ]
+
+
+SP_MAX_PHASES = 8
+
+
+class SpPhase(ctypes.Structure):
+    """Mirror of ``struct SpPhase`` (include/sp_hip.h)."""
+    _fields_ = [("pairs", c_void_p), ("chunks", c_void_p), ("spans", c_void_p), ("span_partials", c_void_p), ("seg_partials", c_void_p),
+                ("n_spans", c_int), ("max_iters", c_int), ("irls_eps", c_float), ("conv_tol", c_float)]
+
+
+class SpSchedule(ctypes.Structure):
+    """Mirror of ``struct SpSchedule``; lives in host memory, passed by address (``ctypes.addressof``)."""
+    _fields_ = [("phase", SpPhase * SP_MAX_PHASES), ("n_phases", c_int), ("pad_", c_int)]
 
 
 class SpWindowNode(ctypes.Structure):

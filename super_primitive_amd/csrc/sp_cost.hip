@@ -814,11 +814,18 @@ __global__ __launch_bounds__(SP_BLOCK) void k_finalise_single(const float* __res
 // workgroup barrier, one relaxed agent-scope fetch-add on the pair's arrival counter; the last arriver performs one
 // agent-scope acquire (invalidates its CU's L1), barrier, then reads the partials with plain loads.  The counter is
 // reset by the last arriver, so the buffer stays all-zero between launches.
+struct SchedCost {            // what the cost kernel needs of an SpSchedule, for the launch over ONE work list
+    const SpPair* pairs[SP_MAX_PHASES];
+    float irls_eps[SP_MAX_PHASES];
+    uint32_t mask;            // bit p: phase p runs on the work list of this launch
+};
 struct FuseArgs {
     int32_t* arrivals;
     AdamArgs adam;
     GnArgs gn;
     const int32_t* done;      // [n_pairs] or NULL: spans of pairs marked done by the solver return at once
+    const int32_t* phase;     // per-pair schedules (sp_pairs_schedule_cost): the phase of a pair selects its level descriptors and
+    SchedCost sched;          // IRLS epsilon; spans of pairs that are finished, or in a phase of another work list, return at once
 };
 
 template <int MODE, int ABL = 0, int FUSED = 0>
@@ -831,6 +838,12 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
     if (w >= n_spans) return;
     const int4 span = spans[w];             // {first chunk, number of chunks, points, pair}
     if (f.done && f.done[span.w]) return;   // converged pair (sp_pairs_cost_active): nothing to evaluate
+    if (f.phase) {
+        const int ph = f.phase[span.w];
+        if (ph >= SP_MAX_PHASES || !((f.sched.mask >> ph) & 1u)) return;
+        pairs = f.sched.pairs[ph];
+        irls_eps = f.sched.irls_eps[ph];
+    }
     const SpPair& pr = pairs[span.w];
     TileCtx c;
     c.pix = (gptr_u32)pr.pix;
@@ -1048,6 +1061,37 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
     return 0;
 }
 
+int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) {
+    if (!sched || !phase || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
+    for (int p = 0; p < sched->n_phases; ++p) {
+        const SpPhase& ph = sched->phase[p];
+        if (!ph.pairs || !ph.chunks || !ph.spans || !ph.span_partials || !ph.seg_partials || ph.n_spans <= 0) return SP_EINVAL;
+    }
+    uint32_t launched = 0;
+    for (int p = 0; p < sched->n_phases; ++p) {
+        if ((launched >> p) & 1u) continue;
+        const SpPhase& lead = sched->phase[p];          // first phase of a work list: one launch for all phases sharing it
+        FuseArgs f{};
+        f.phase = phase;
+        for (int q = p; q < sched->n_phases; ++q) {
+            const SpPhase& ph = sched->phase[q];
+            if (ph.spans != lead.spans) continue;
+            if (ph.chunks != lead.chunks || ph.span_partials != lead.span_partials || ph.seg_partials != lead.seg_partials ||
+                ph.n_spans != lead.n_spans) return SP_EINVAL;
+            f.sched.pairs[q] = ph.pairs;
+            f.sched.irls_eps[q] = ph.irls_eps;
+            f.sched.mask |= 1u << q;
+        }
+        launched |= f.sched.mask;
+        const int gx = ((lead.n_spans + 7) / 8) * 8;
+        hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), lead.pairs,
+                           reinterpret_cast<const int4*>(lead.chunks), reinterpret_cast<const int4*>(lead.spans), lead.n_spans, lead.irls_eps,
+                           lead.span_partials, lead.seg_partials, f);
+        SP_CHECK_LAUNCH();
+    }
+    return 0;
+}
+
 int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
                           float* partials, float* seg_partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,
                           float* losses, void* stream) {
@@ -1072,7 +1116,7 @@ int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_
         return SP_EINVAL;
     FuseArgs f{};
     f.arrivals = arrivals;
-    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr};
+    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, nullptr, nullptr, 0};
     const int gx = ((n_spans + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cost_pairs<1, 0, 2>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
                        reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, f);

@@ -247,6 +247,9 @@ struct GnArgs {
     float* costs;
     float conv_tol;          // > 0: a pair whose last accepted step lowered its cost by less than conv_tol * cost is marked done
     int32_t* done;           // [n_pairs] or NULL; done pairs are skipped by the cost pass and by this solver
+    int32_t* phase;          // per-pair schedules (sp_pairs_schedule_*): [n_pairs] current phase, advanced here instead of `done`
+    int32_t* iters;          // ... iterations spent in the current phase
+    int max_iters;           // ... of at most this many
 };
 
 // One workgroup: tile-partial reduction + Schur-complement LM step of pair `pi` (include/sp_hip.h sp_pairs_gn_step).
@@ -279,9 +282,10 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         if (last >= 0.f && (float)cost > last * (1.f + 1e-6f) && ls[4] == 0.f) rej = 1;
         // convergence (per pair, on the device): the step that led here was accepted and bought less than conv_tol of the
         // cost -> keep the current point and stop working on this pair (decision 2)
-        if (!rej && h.done && h.conv_tol > 0.f && last >= 0.f && ls[4] == 0.f && (last - (float)cost) <= h.conv_tol * last) {
+        if (!rej && (h.done || h.phase) && h.conv_tol > 0.f && last >= 0.f && ls[4] == 0.f && (last - (float)cost) <= h.conv_tol * last) {
             rej = 2;
-            h.done[pi] = 1;
+            if (h.done) h.done[pi] = 1;
+            if (h.phase) { h.phase[pi] += 1; h.iters[pi] = 0; ls[1] = -1.f; ls[4] = 0.f; }      // next phase starts afresh
         }
         decision = rej;
         ls[5] = (float)cost;
@@ -293,7 +297,14 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         // undo the previous step; the next cost pass re-evaluates at the restored point with a larger lambda
         for (int i = threadIdx.x; i < 16; i += SP_BLOCK) pr.pose[i] = bk[i];
         for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) pr.kld[n] = bk[16 + n];
-        if (threadIdx.x == 0) { ls[0] *= lm_up; ls[3] += 1.f; ls[4] = 1.f; }
+        if (threadIdx.x == 0) {
+            ls[0] *= lm_up; ls[3] += 1.f; ls[4] = 1.f;
+            if (h.phase) {                          // a rejected iteration counts towards the phase's budget like an accepted one
+                const int n = h.iters[pi] + 1;
+                if (n >= h.max_iters) { h.phase[pi] += 1; h.iters[pi] = 0; ls[1] = -1.f; ls[4] = 0.f; }
+                else h.iters[pi] = n;
+            }
+        }
         return;
     }
     float lambda = ls[0];
@@ -354,6 +365,11 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         const bool ok = ldlt6_solve(S, rhs);
         for (int i = 0; i < 6; ++i) dxi[i] = ok ? rhs[i] : 0.0;
         ls[0] = lambda; ls[1] = (float)cost; ls[2] += 1.f; ls[4] = 0.f;
+        if (h.phase) {                              // iteration budget of the phase (the step computed here is still applied)
+            const int n = h.iters[pi] + 1;
+            if (n >= h.max_iters) { h.phase[pi] += 1; h.iters[pi] = 0; ls[1] = -1.f; }
+            else h.iters[pi] = n;
+        }
     }
     __syncthreads();
     for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {

@@ -17,6 +17,19 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
     solve_gn(pairs, blockIdx.x, partials, seg_partials, h);
 }
 
+static_assert(sizeof(SpPhase) == 56 && sizeof(SpSchedule) == 456, "SpSchedule is part of the ABI");
+
+// per-pair schedules: the pair's current phase selects the level descriptors, the partial records of that level's work list,
+// the convergence threshold and the iteration budget
+__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, GnArgs h) {
+    const int ph = h.phase[blockIdx.x];
+    if (ph >= sched.n_phases) return;
+    const SpPhase& s = sched.phase[ph];
+    h.conv_tol = s.conv_tol;
+    h.max_iters = s.max_iters;
+    solve_gn(s.pairs, blockIdx.x, s.span_partials, s.seg_partials, h);
+}
+
 
 // lie/lie_algebra.py:41-119, one thread per matrix (body: renormalise_rotation in sp_solve_device.h)
 __global__ void k_renormalise(float* __restrict__ T, int n) {
@@ -78,7 +91,21 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
     if (!pairs || !partials || !seg_partials || !lm_state || !backup || !costs || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
     if (conv_tol > 0.f && !done) return SP_EINVAL;
     hipLaunchKernelGGL(k_pairs_gn, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs, partials,
-                       seg_partials, GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, conv_tol, done});
+                       seg_partials, GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, conv_tol, done, nullptr, nullptr, 0});
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
+                              float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, void* stream) {
+    if (!sched || !lm_state || !backup || !costs || !phase || !iters || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+    if (sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
+    for (int p = 0; p < sched->n_phases; ++p) {
+        const SpPhase& ph = sched->phase[p];
+        if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.max_iters <= 0) return SP_EINVAL;
+    }
+    hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), *sched,
+                       GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0});
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -33,6 +33,11 @@ GRANULE = 256                      # SP_BLOCK: every segment is padded to a mult
 # termination on the device (PairBatch.run_converging: a pair leaves a level once an accepted step buys less than
 # ``conv_tol`` of its cost), then a polish at the finest level with the epsilon at ``polish_eps`` under ``polish_tol``.
 # FIXED_FRAME_PAIR_SCHEDULE is the same without early termination (every pair runs the maximum), kept for comparison.
+# FRAME_PAIR_POINT_STRIDE: PairBatch(point_stride=...) of that schedule -- at pyramid level l (image decimated 2^l times) the
+# schedule's Gauss-Newton iterations run on the source points whose pixel coordinates are multiples of the stride (1 / stride^2
+# of them: about one source sample per TARGET pixel of that level instead of 4^l); the finest level and the polish use every
+# point, so the minimiser reached is that of the full reference cost.
+FRAME_PAIR_POINT_STRIDE = (1, 2, 4)
 FRAME_PAIR_SCHEDULE = dict(max_iters_per_level=25, conv_tol=2e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-4, check_every=3)
 FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps=1e-5)
 
@@ -100,9 +105,13 @@ def build_work_list(pads, span_points, tile_points):
                 seg_rec_offs=seg_rec_offs, c_off=c_off, s_off=np.concatenate(([0], np.cumsum(spans_per_pair))))
 
 
+class _Layout:
+    """A point set with its work list: pix / src4 tables, chunks / spans, per-level descriptors and partial buffers."""
+
+
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
-                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None):
+                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None, point_stride=None):
         """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
         device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
@@ -114,7 +123,12 @@ class PairBatch:
         run of points extended to a multiple of 256 with invalid points -- so that a workgroup can stream through a SPAN
         of several consecutive chunks (segments, or pieces of at most ``tile_points`` points of a long segment) of up
         to ``span_points`` points without any trip mixing two segments.  ``span_points=None``: 16384, reduced for small
-        batches so that a launch keeps about 2300 workgroups (a single pair then runs one chunk per workgroup)."""
+        batches so that a launch keeps about 2300 workgroups (a single pair then runs one chunk per workgroup).
+
+        ``point_stride`` (one integer per pyramid level, finest first; default all 1): levels with a stride s > 1 get, IN
+        ADDITION, a decimated copy of the point tables -- the valid points whose column and row are multiples of s -- with its
+        own work list, descriptors and partial buffers (``self.coarse[level]``).  Only ``run_scheduled`` uses them; every
+        per-level method below (cost_pass, gn_step, adam_step, evaluate, run, run_converging) works on all points."""
         lib = _lib.load()
         self.lib = lib
         M0 = len(src_frames)
@@ -193,7 +207,7 @@ class PairBatch:
         self.seg_tile_off = torch.from_numpy(np.concatenate(seg_rec_offs)).to(dev)
 
         # descriptors, one array per level
-        self.desc = {}
+        self.desc, desc_host = {}, {}
         for l in self.level_ids:
             arr = (_lib.SpPair * M)()
             for m, (f, tab) in enumerate(zip(frames, tables)):
@@ -217,6 +231,16 @@ class PairBatch:
                 d.rec0 = 4 * c_off[m]
             raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
             self.desc[l] = torch.from_numpy(raw).to(dev)
+            desc_host[l] = arr
+
+        # decimated point sets of the coarse levels (run_scheduled)
+        self.coarse = {}
+        if point_stride is not None:
+            assert len(point_stride) == len(self.level_ids), "one stride per pyramid level, finest first"
+            for l, stride in zip(self.level_ids, point_stride):
+                if int(stride) > 1:
+                    self.coarse[l] = self._decimated_layout(int(stride), pix0, [v.reshape(-1, 4) for v in src4_0[l]], pads0, base,
+                                                            desc_host[l], tile_points)
 
         # optimiser state / workspaces
         self.partials = torch.empty(self.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
@@ -227,6 +251,8 @@ class PairBatch:
         self.backup = torch.zeros(M, 16 + self.max_N, dtype=torch.float32, device=dev)
         self.arrivals = torch.zeros(M, dtype=torch.int32, device=dev)     # per-pair tile-arrival counters (fused launch)
         self.done = torch.zeros(M, dtype=torch.int32, device=dev)         # per-pair convergence flags (gn_step(conv_tol=...))
+        self.phase = torch.zeros(M, dtype=torch.int32, device=dev)        # per-pair position in a device-side schedule (run_scheduled)
+        self.phase_iters = torch.zeros(M, dtype=torch.int32, device=dev)
         self.reset_lm()
         self._graphs = {}
         self._keep = (tables0,)
@@ -240,7 +266,52 @@ class PairBatch:
             self.aff.zero_()
         self.adam_state.zero_()
         self.done.zero_()
+        self.phase.zero_()
+        self.phase_iters.zero_()
         self.reset_lm()
+
+    def _decimated_layout(self, stride, pix0, src4_l, pads0, base, desc_full, tile_points):
+        """Point tables, work list, descriptors and partial buffers of one level restricted to the valid points on the
+        ``stride`` x ``stride`` pixel lattice.  pix0 / src4_l / pads0: padded per-BASE-pair tables of the level."""
+        dev, M = self.device, self.M
+        pix_b, src_b, pads_b, real_b = [], [], [], []
+        for pix, src4, pd in zip(pix0, src4_l, pads0):
+            w = pix.view(torch.int32)
+            keep = (w < 0) & ((w & 0xffff) % stride == 0) & (((w >> 16) & 0x7fff) % stride == 0)       # bit 31 = valid source sample
+            seg = torch.repeat_interleave(torch.arange(len(pd['pc']), device=dev), torch.from_numpy(pd['pc']).to(dev))
+            counts = torch.bincount(seg[keep], minlength=len(pd['pc'])).cpu().numpy()
+            pdl = pad_layout(counts, dev)
+            pix_b.append(pad_points(pix[keep], pdl))
+            src_b.append(pad_points(src4[keep], pdl))
+            pads_b.append(pdl)
+            real_b.append(int(counts.sum()))
+        pads = [pads_b[b] for b in base]
+        p_off = np.concatenate(([0], np.cumsum([pd['Ppad'] for pd in pads])))
+        lay = _Layout()
+        lay.stride = stride
+        lay.points = [real_b[b] for b in base]
+        lay.pix = torch.cat([pix_b[b] for b in base])
+        lay.src4 = torch.cat([src_b[b] for b in base]).reshape(-1)
+        span_points = max(GRANULE, min(DEFAULT_SPAN_POINTS, int(p_off[-1]) // MIN_SPANS))
+        wl = build_work_list(pads, span_points, tile_points)
+        lay.n_chunks, lay.n_spans = len(wl['chunks']), len(wl['spans'])
+        lay.chunks = torch.from_numpy(wl['chunks']).to(dev)
+        lay.spans = torch.from_numpy(wl['spans']).to(dev)
+        sto_off = np.concatenate(([0], np.cumsum([len(v) for v in wl['seg_rec_offs']])))
+        lay.seg_tile_off = torch.from_numpy(np.concatenate(wl['seg_rec_offs'])).to(dev)
+        arr = (_lib.SpPair * M).from_buffer_copy(bytes(desc_full))
+        for m in range(M):
+            d = arr[m]
+            d.pix = lay.pix.data_ptr() + 4 * int(p_off[m])
+            d.src4 = lay.src4.data_ptr() + 16 * int(p_off[m])
+            d.seg_tile_off = lay.seg_tile_off.data_ptr() + 4 * int(sto_off[m])
+            d.P = max(lay.points[m], 1)
+            d.tile0, d.n_tiles = int(wl['s_off'][m]), int(wl['s_off'][m + 1] - wl['s_off'][m])
+            d.rec0 = 4 * int(wl['c_off'][m])
+        lay.desc = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
+        lay.partials = torch.empty(lay.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+        lay.seg_partials = torch.empty(4 * lay.n_chunks * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
+        return lay
 
     # ------------------------------------------------------------------------------------------------
     @classmethod
@@ -360,6 +431,52 @@ class PairBatch:
             launched.append(it)
         self.done.zero_()
         return launched
+
+    def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3):
+        """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
+        with a decimated point set (``point_stride``) run on it."""
+        phases = [(level, max_iters_per_level, irls_eps, conv_tol) for level in reversed(self.level_ids)]
+        if polish_max > 0:
+            phases.append((min(self.level_ids), polish_max, polish_eps, polish_tol))
+        if len(phases) > _lib.SP_MAX_PHASES:
+            raise ValueError(f"{len(phases)} phases exceed SP_MAX_PHASES = {_lib.SP_MAX_PHASES}")
+        sched = _lib.SpSchedule()
+        for p, (level, n_max, eps, tol) in enumerate(phases):
+            ph, lay = sched.phase[p], self.coarse.get(level)
+            if lay is None:
+                ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans
+                ph.span_partials, ph.seg_partials = _lib.ptr(self.partials), _lib.ptr(self.seg_partials)
+            else:
+                ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(lay.desc), _lib.ptr(lay.chunks), _lib.ptr(lay.spans), lay.n_spans
+                ph.span_partials, ph.seg_partials = _lib.ptr(lay.partials), _lib.ptr(lay.seg_partials)
+            ph.irls_eps, ph.conv_tol, ph.max_iters = float(eps), float(tol), int(n_max)
+        sched.n_phases = len(phases)
+        return sched
+
+    def run_scheduled(self, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7, **schedule_kw):
+        """``run_converging`` with the schedule itself on the device: every pair walks through ITS OWN coarse-to-fine phases
+        (sp_pairs_schedule_cost / sp_pairs_schedule_gn_step), moving to the next level the moment it converges instead of
+        waiting for the slowest pair of the batch, and the host only polls ``min(phase)`` every ``check_every`` iterations.
+        Per pair the arithmetic is that of ``run_converging`` with check_every = 1 -- except at levels built with a
+        ``point_stride`` > 1, which iterate on their decimated point set.  Returns the iterations launched."""
+        sched = self.schedule(**schedule_kw)
+        self.phase.zero_()
+        self.phase_iters.zero_()
+        self.lm_state[:, 1] = -1.0
+        self.lm_state[:, 4] = 0.0
+        bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases))
+        it = 0
+        while it < bound:
+            for _ in range(min(check_every, bound - it)):
+                _lib.check(self.lib.sp_pairs_schedule_cost(ctypes.addressof(sched), _lib.ptr(self.phase), _lib.stream_ptr()), "sp_pairs_schedule_cost")
+                _lib.check(self.lib.sp_pairs_schedule_gn_step(ctypes.addressof(sched), self.M, self.max_N, float(lm_up), float(lm_down), float(lm_min),
+                                                              _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs),
+                                                              _lib.ptr(self.phase), _lib.ptr(self.phase_iters), _lib.stream_ptr()),
+                           "sp_pairs_schedule_gn_step")
+                it += 1
+            if int(self.phase.min()) >= sched.n_phases:
+                break
+        return it
 
     def run(self, iters_per_level, mode="gn", use_graph=False, polish_iters=0, polish_eps=1e-5, **kw):
         """Coarse-to-fine schedule like ``two_frame_sfm.py:150-155``: ``iters_per_level`` iterations at each level (an int, or

@@ -109,20 +109,41 @@ def test_bench_schedule_reaches_the_reference_minimiser_at_full_size():
     pairs bench.py renders, of the synthetic ground truth, which the recorded minimiser is within 7e-6 rad / 2e-5 t / 2e-4
     of."""
     from super_primitive_amd import synth
-    from super_primitive_amd.optim.pair_batch import FRAME_PAIR_SCHEDULE, PairBatch
+    from super_primitive_amd.optim.pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
     g = load_golden("g15_config2_fullsize")
     pairs = [fullsize_pair(g)] + [synth.make_pair(480, 640, 64, seed=1000 + s, overlap=4, init_sigma=0.004) for s in (1, 2, 3)]
-    batch = PairBatch.from_synth(pairs, levels=(0, 3), device="cuda:0")
+    batch = PairBatch.from_synth(pairs, levels=(0, 3), device="cuda:0", point_stride=FRAME_PAIR_POINT_STRIDE)
+    sched_kw = {k: v for k, v in FRAME_PAIR_SCHEDULE.items() if k != "check_every"}
+
+    def check():
+        poses, klds = npy(batch.poses()), [npy(k) for k in batch.klds()]
+        err = pose_depth_errors(poses[0], klds[0], g["min_pose"], g["min_kld"])
+        assert within_bar(err), err
+        np.testing.assert_allclose(float(batch.evaluate(0)[0]), float(g["min_final_loss"]), rtol=2e-4)
+        for m in (1, 2, 3):
+            e = pose_depth_errors(poses[m], klds[m], pairs[m].pose_gt, pairs[m].kld_gt)
+            assert e[0] <= 1e-4 and e[1] <= 1.5e-4 and e[2] <= 1.2e-3, (m, e)      # bar + the minimiser's own offset from ground truth
+
+    # the quoted form: the schedule on the device, every pair advancing through its own levels, levels 1 and 2 on their
+    # decimated point sets
+    assert sorted(batch.coarse) == [1, 2]
+    launched = batch.run_scheduled(**sched_kw)
+    torch.cuda.synchronize()
+    assert 0 < launched <= 3 * FRAME_PAIR_SCHEDULE["max_iters_per_level"] + FRAME_PAIR_SCHEDULE["polish_max"]
+    check()
+    # ... and on all points at every level
+    coarse, batch.coarse = batch.coarse, {}
+    batch.restore_initial()
+    batch.run_scheduled(**sched_kw)
+    torch.cuda.synchronize()
+    check()
+    batch.coarse = coarse
+    # levels synchronised across the batch (pairs wait at each level for the slowest)
+    batch.restore_initial()
     launched = batch.run_converging(**FRAME_PAIR_SCHEDULE)
     torch.cuda.synchronize()
     assert len(launched) == 4 and all(0 < n <= FRAME_PAIR_SCHEDULE["max_iters_per_level"] for n in launched)
-    poses, klds = npy(batch.poses()), [npy(k) for k in batch.klds()]
-    err = pose_depth_errors(poses[0], klds[0], g["min_pose"], g["min_kld"])
-    assert within_bar(err), err
-    np.testing.assert_allclose(float(batch.evaluate(0)[0]), float(g["min_final_loss"]), rtol=2e-4)
-    for m in (1, 2, 3):
-        e = pose_depth_errors(poses[m], klds[m], pairs[m].pose_gt, pairs[m].kld_gt)
-        assert e[0] <= 1e-4 and e[1] <= 1.5e-4 and e[2] <= 1.2e-3, (m, e)      # bar + the minimiser's own offset from ground truth
+    check()
     # the fixed-length form of the schedule (no early termination) lands on the same minimiser
     from super_primitive_amd.optim.pair_batch import FIXED_FRAME_PAIR_SCHEDULE as FIX
     batch.restore_initial()

@@ -441,3 +441,74 @@ def test_per_pair_convergence_skips_finished_pairs_and_keeps_their_result():
     p = batch.klds()[1].clone()
     batch.gn_step(0, conv_tol=1e-3)                              # everything done: a no-op
     assert torch.equal(batch.klds()[1], p)
+
+
+def test_device_side_schedule_walks_every_pair_through_its_own_levels():
+    """run_scheduled (sp_pairs_schedule_*): every pair advances through the coarse-to-fine phases on its own -- its result is
+    bit-identical to that pair optimised ALONE by run_converging polled every iteration (where the level ends the moment the
+    single pair converges), whatever the other pairs of the batch are doing; finished pairs are no longer touched; the
+    iteration count is bounded by the slowest pair, not by levels x the slowest pair per level."""
+    from super_primitive_amd import synth
+    sch = dict(max_iters_per_level=12, conv_tol=2e-3, polish_max=6, polish_eps=1e-5, polish_tol=1e-4)
+    prs = [synth.make_pair(60, 80, 6, seed=93, init_sigma=0.002), synth.make_pair(60, 80, 6, seed=94, init_sigma=0.01),
+           synth.make_pair(60, 80, 6, seed=95, init_sigma=0.005)]
+    batch = make_batch(prs, levels=(0, 2), tile_points=512)
+    launched = batch.run_scheduled(check_every=1, **sch)
+    torch.cuda.synchronize()
+    n_phases = len(batch.level_ids) + 1
+    assert (npy(batch.phase) == n_phases).all() and launched <= n_phases * 12
+    solo_iters = []
+    for m, pr in enumerate(prs):
+        solo = make_batch([pr], levels=(0, 2), tile_points=512)
+        its = solo.run_converging(check_every=1, **sch)
+        torch.cuda.synchronize()
+        solo_iters.append(sum(its))
+        assert torch.equal(solo.poses()[0], batch.poses()[m]), m
+        assert torch.equal(solo.klds()[0], batch.klds()[m]), m
+    assert launched == max(solo_iters), (launched, solo_iters)
+    # finished: further launches are no-ops
+    import ctypes
+    from super_primitive_amd import _lib
+    before = [k.clone() for k in batch.klds()]
+    sched = batch.schedule(**sch)
+    _lib.check(batch.lib.sp_pairs_schedule_cost(ctypes.addressof(sched), _lib.ptr(batch.phase), _lib.stream_ptr()), "cost")
+    _lib.check(batch.lib.sp_pairs_schedule_gn_step(ctypes.addressof(sched), batch.M, batch.max_N, 8.0, 0.5, 1e-7, _lib.ptr(batch.lm_state),
+                                                   _lib.ptr(batch.backup), _lib.ptr(batch._costs), _lib.ptr(batch.phase),
+                                                   _lib.ptr(batch.phase_iters), _lib.stream_ptr()), "step")
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(before, batch.klds()))
+
+
+def test_decimated_coarse_levels_have_exact_point_sets_and_the_same_fine_minimiser():
+    """PairBatch(point_stride=(1, 2, 4)): the decimated table of a coarse level holds exactly the valid source points on the
+    stride lattice, segment by segment, in table order; and run_scheduled over the decimated coarse levels ends -- the finest
+    level and the polish use every point -- at the minimiser of the all-points schedule."""
+    from parity_util import pose_depth_errors
+    from super_primitive_amd import synth
+    prs = [synth.make_pair(96, 128, 6, seed=96, init_sigma=0.004), synth.make_pair(96, 128, 9, seed=97, init_sigma=0.006)]
+    batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4))
+    assert sorted(batch.coarse) == [1, 2] and batch.coarse[1].stride == 2 and batch.coarse[2].stride == 4
+    pix_full, p_off = npy(batch.pix).view(np.uint32), batch.p_off
+    for level, lay in batch.coarse.items():
+        s = lay.stride
+        pix = npy(lay.pix).view(np.uint32)
+        chunks = npy(lay.chunks)
+        assert lay.n_spans == len(npy(lay.spans)) and (chunks[:, 3] % 256 == 0).all()
+        for m in range(batch.M):
+            full = pix_full[p_off[m]: p_off[m + 1]]
+            keep = ((full >> 31) == 1) & ((full & 0xffff) % s == 0) & (((full >> 16) & 0x7fff) % s == 0)
+            base = int(chunks[chunks[:, 0] < m, 3].sum())          # chunk starts are relative to the pair's own table
+            mine = np.concatenate([pix[base + c[2]: base + c[2] + c[3]] for c in chunks if c[0] == m])
+            assert np.array_equal(mine[(mine >> 31) == 1], full[keep]) and lay.points[m] == int(keep.sum())
+    # same minimiser as the all-points schedule (both end with full-point phases run to the same tolerances)
+    sch = dict(max_iters_per_level=25, conv_tol=1e-4, polish_max=25, polish_eps=1e-5, polish_tol=1e-6)
+    launched = batch.run_scheduled(**sch)
+    torch.cuda.synchronize()
+    ref = make_batch(prs, levels=(0, 3), tile_points=1024)
+    ref.run_scheduled(**sch)
+    torch.cuda.synchronize()
+    assert 0 < launched <= 100
+    np.testing.assert_allclose(npy(batch.evaluate(0)), npy(ref.evaluate(0)), rtol=2e-5)
+    for m in range(2):
+        e = pose_depth_errors(npy(batch.poses()[m]), npy(batch.klds()[m]), npy(ref.poses()[m]), npy(ref.klds()[m]))
+        assert e[0] <= 2e-5 and e[1] <= 5e-5 and e[2] <= 5e-4, (m, e)

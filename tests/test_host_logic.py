@@ -41,6 +41,10 @@ def test_abi_constants_and_struct_layout_match_header():
     assert ctypes.sizeof(_lib.SpWindowNode) == 176 and ctypes.sizeof(_lib.SpWindowEdge) == 16 and ctypes.sizeof(_lib.SpWindowBlock) == 32
     assert _lib.SpWindowNode.a.offset == 64 and _lib.SpWindowNode.aff.offset == 136 and _lib.SpWindowNode.lr_pose.offset == 160
     assert _lib.SpWindowNode.kind.offset == 168 and _lib.SpWindowBlock.N.offset == 24
+    # per-pair schedule, passed by value
+    assert int(re.search(r"#define\s+SP_MAX_PHASES\s+(\d+)", header).group(1)) == _lib.SP_MAX_PHASES
+    assert ctypes.sizeof(_lib.SpPhase) == 56 and _lib.SpPhase.n_spans.offset == 40 and _lib.SpPhase.conv_tol.offset == 52
+    assert ctypes.sizeof(_lib.SpSchedule) == 456 and _lib.SpSchedule.n_phases.offset == 448
 
 
 def test_new_entry_points_validate_arguments_and_sizes():
@@ -51,6 +55,9 @@ def test_new_entry_points_validate_arguments_and_sizes():
     assert lib.sp_window_scratch_doubles(10, 40) == 10 * (28 + 40)
     assert lib.sp_window_compose(None, None, 1, None, 1, None) == -1
     assert lib.sp_window_step(*([None] * 2), 1, None, 1, None, 1, 1, *([None] * 3), 0, 0, 0.0, None, None, 0, None) == -1
+    sched = _lib.SpSchedule()
+    assert lib.sp_pairs_schedule_cost(ctypes.addressof(sched), None, None) == -1 and lib.sp_pairs_schedule_cost(None, None, None) == -1
+    assert lib.sp_pairs_schedule_gn_step(ctypes.addressof(sched), 1, 1, 8.0, 0.5, 1e-7, *([None] * 6)) == -1
     assert lib.sp_depth_accumulate(*([None] * 6), 1, 1, 1, 1, None, None) == -1
     assert lib.sp_depth_average_finish(None, 4, 4, None, None, None) == -1
 
