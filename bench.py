@@ -313,17 +313,15 @@ def main(argv=None):
             # (c) the quoted one: the schedule itself on the device, every pair walks through its own levels, the coarse
             #     levels on their decimated point sets (FRAME_PAIR_POINT_STRIDE); (c') = the same on all points at every level
             sched_kw = {k: v for k, v in SCH.items() if k != "check_every"}
-            coarse, batch.coarse = batch.coarse, {}
             batch.restore_initial()
-            batch.run_scheduled(**sched_kw)
+            batch.run_scheduled(use_coarse=False, **sched_kw)
             batch.restore_initial()
             sync()
             t1 = time.perf_counter()
-            n_all = batch.run_scheduled(**sched_kw)
+            n_all = batch.run_scheduled(use_coarse=False, **sched_kw)
             sync()
             line["frame_pairs_per_sec_all_points_at_every_level"] = M / (time.perf_counter() - t1)
             line["all_points_iterations_launched"] = n_all
-            batch.coarse = coarse
             batch.restore_initial()
             batch.run_scheduled(**sched_kw)
         batch.restore_initial()

@@ -111,7 +111,8 @@ class _Layout:
 
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
-                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None, point_stride=None):
+                 tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None, point_stride=None,
+                 extra_tables=()):
         """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
         device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
@@ -127,8 +128,9 @@ class PairBatch:
 
         ``point_stride`` (one integer per pyramid level, finest first; default all 1): levels with a stride s > 1 get, IN
         ADDITION, a decimated copy of the point tables -- the valid points whose column and row are multiples of s -- with its
-        own work list, descriptors and partial buffers (``self.coarse[level]``).  Only ``run_scheduled`` uses them; every
-        per-level method below (cost_pass, gn_step, adam_step, evaluate, run, run_converging) works on all points."""
+        own work list, descriptors and partial buffers (``self.coarse[(level, s)]``); ``extra_tables`` = further (level,
+        stride) combinations for explicit ``schedule(phases=...)`` lists.  Only ``run_scheduled`` uses them; every per-level
+        method below (cost_pass, gn_step, adam_step, evaluate, run, run_converging) works on all points."""
         lib = _lib.load()
         self.lib = lib
         M0 = len(src_frames)
@@ -234,13 +236,14 @@ class PairBatch:
             desc_host[l] = arr
 
         # decimated point sets of the coarse levels (run_scheduled)
-        self.coarse = {}
+        self.coarse, self.point_stride = {}, {l: 1 for l in self.level_ids}
         if point_stride is not None:
             assert len(point_stride) == len(self.level_ids), "one stride per pyramid level, finest first"
-            for l, stride in zip(self.level_ids, point_stride):
-                if int(stride) > 1:
-                    self.coarse[l] = self._decimated_layout(int(stride), pix0, [v.reshape(-1, 4) for v in src4_0[l]], pads0, base,
-                                                            desc_host[l], tile_points)
+            self.point_stride = {l: int(s) for l, s in zip(self.level_ids, point_stride)}
+        for l, stride in list(self.point_stride.items()) + [(int(l), int(s)) for l, s in extra_tables]:
+            if stride > 1 and (l, stride) not in self.coarse:
+                self.coarse[(l, stride)] = self._decimated_layout(stride, pix0, [v.reshape(-1, 4) for v in src4_0[l]], pads0, base,
+                                                                  desc_host[l], tile_points)
 
         # optimiser state / workspaces
         self.partials = torch.empty(self.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
@@ -432,24 +435,31 @@ class PairBatch:
         self.done.zero_()
         return launched
 
-    def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3):
+    def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3, phases=None,
+                 use_coarse=True):
         """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
-        with a decimated point set (``point_stride``) run on it."""
-        phases = [(level, max_iters_per_level, irls_eps, conv_tol) for level in reversed(self.level_ids)]
-        if polish_max > 0:
-            phases.append((min(self.level_ids), polish_max, polish_eps, polish_tol))
+        built with a ``point_stride`` run on their decimated point set unless ``use_coarse=False``.  ``phases``: an explicit
+        list of dict(level, stride, max_iters, irls_eps, conv_tol) instead (every (level, stride > 1) needs its table:
+        ``point_stride`` / ``extra_tables`` of the constructor)."""
+        if phases is None:
+            phases = [dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=max_iters_per_level, irls_eps=irls_eps,
+                           conv_tol=conv_tol) for level in reversed(self.level_ids)]
+            if polish_max > 0:
+                phases.append(dict(level=min(self.level_ids), stride=1, max_iters=polish_max, irls_eps=polish_eps, conv_tol=polish_tol))
         if len(phases) > _lib.SP_MAX_PHASES:
             raise ValueError(f"{len(phases)} phases exceed SP_MAX_PHASES = {_lib.SP_MAX_PHASES}")
         sched = _lib.SpSchedule()
-        for p, (level, n_max, eps, tol) in enumerate(phases):
-            ph, lay = sched.phase[p], self.coarse.get(level)
-            if lay is None:
+        for p, spec in enumerate(phases):
+            level, stride = int(spec["level"]), int(spec.get("stride", 1))
+            ph = sched.phase[p]
+            if stride == 1:
                 ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans
                 ph.span_partials, ph.seg_partials = _lib.ptr(self.partials), _lib.ptr(self.seg_partials)
             else:
+                lay = self.coarse[(level, stride)]
                 ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(lay.desc), _lib.ptr(lay.chunks), _lib.ptr(lay.spans), lay.n_spans
                 ph.span_partials, ph.seg_partials = _lib.ptr(lay.partials), _lib.ptr(lay.seg_partials)
-            ph.irls_eps, ph.conv_tol, ph.max_iters = float(eps), float(tol), int(n_max)
+            ph.irls_eps, ph.conv_tol, ph.max_iters = float(spec.get("irls_eps", irls_eps)), float(spec["conv_tol"]), int(spec["max_iters"])
         sched.n_phases = len(phases)
         return sched
 

@@ -126,18 +126,16 @@ def test_bench_schedule_reaches_the_reference_minimiser_at_full_size():
 
     # the quoted form: the schedule on the device, every pair advancing through its own levels, levels 1 and 2 on their
     # decimated point sets
-    assert sorted(batch.coarse) == [1, 2]
+    assert sorted(batch.coarse) == [(1, 2), (2, 4)]
     launched = batch.run_scheduled(**sched_kw)
     torch.cuda.synchronize()
     assert 0 < launched <= 3 * FRAME_PAIR_SCHEDULE["max_iters_per_level"] + FRAME_PAIR_SCHEDULE["polish_max"]
     check()
     # ... and on all points at every level
-    coarse, batch.coarse = batch.coarse, {}
     batch.restore_initial()
-    batch.run_scheduled(**sched_kw)
+    batch.run_scheduled(use_coarse=False, **sched_kw)
     torch.cuda.synchronize()
     check()
-    batch.coarse = coarse
     # levels synchronised across the batch (pairs wait at each level for the slowest)
     batch.restore_initial()
     launched = batch.run_converging(**FRAME_PAIR_SCHEDULE)

@@ -487,9 +487,9 @@ def test_decimated_coarse_levels_have_exact_point_sets_and_the_same_fine_minimis
     from super_primitive_amd import synth
     prs = [synth.make_pair(96, 128, 6, seed=96, init_sigma=0.004), synth.make_pair(96, 128, 9, seed=97, init_sigma=0.006)]
     batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4))
-    assert sorted(batch.coarse) == [1, 2] and batch.coarse[1].stride == 2 and batch.coarse[2].stride == 4
+    assert sorted(batch.coarse) == [(1, 2), (2, 4)] and batch.coarse[(1, 2)].stride == 2 and batch.coarse[(2, 4)].stride == 4
     pix_full, p_off = npy(batch.pix).view(np.uint32), batch.p_off
-    for level, lay in batch.coarse.items():
+    for lay in batch.coarse.values():
         s = lay.stride
         pix = npy(lay.pix).view(np.uint32)
         chunks = npy(lay.chunks)
