@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 6
+#define SP_ABI_VERSION 7
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -83,6 +83,59 @@ int sp_pack_rgb(const float* chw, int B, int H, int W, float* hwc3, void* stream
 /* One pyramid step of image/gaussian_pyramid.py:53-85: reflect-pad 1, 3x3 binomial /16, keep even rows and
  * columns.  in: planar (C,H,W); out: planar (C,ceil(H/2),ceil(W/2)). */
 int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* stream);
+
+/* ----------------------------------------------------------------------------------------------------
+ * Batched preparation: the table / pyramid / sampling passes above for MANY keyframes per launch (job records in DEVICE
+ * memory, one grid row per record).  PairBatch builds hundreds of frame pairs with ~12 launches and ONE host
+ * synchronisation (the per-segment counts, which size the tables) instead of ~15 launches and a synchronisation per pair.
+ * A "table" is the compacted point set of one keyframe on a pixel lattice: stride 1 = every mask pixel (the tables above),
+ * stride s > 1 = the mask pixels whose row and column are multiples of s (coarse levels of per-pair schedules).
+ *   sp_prepare_count : row_counts (scratch, N*H) and counts[N] of every lattice of every keyframe   [masks read once]
+ *   -- host: reads counts, lays the segments out (padded runs), allocates and ZEROES pix / baseL, uploads seg_off --
+ *   sp_prepare_fill  : pix / baseL at seg_off[n] + rank inside the segment; kp_L[N] where kp_L != NULL
+ *   sp_prepare_blur  : one pyramid step (sp_blur_decimate) of every job image
+ *   sp_prepare_pack  : planar (3,H,W) -> HWC3 of every job image
+ *   sp_prepare_sample: sp_table_sample_source of every job at all its levels; positions beyond counts[n] of a segment's run
+ *                      are padding and are left untouched (zero = invalid point)
+ * ---------------------------------------------------------------------------------------------------- */
+#define SP_PREP_MAX_STRIDES 4
+#define SP_PREP_MAX_LEVELS 4
+typedef struct SpPrepTable {     /* one keyframe: its masks are read once per pass for all its lattices */
+    const uint8_t* masks;        /* (N,H,W) bool */
+    const float* logdepth;       /* (N,H,W) */
+    const float* keypoints;      /* (N,2), used when kp_L != NULL */
+    float* kp_L;                 /* N or NULL, out of sp_prepare_fill */
+    int32_t* row_counts[SP_PREP_MAX_STRIDES];   /* N*H scratch each: written by sp_prepare_count, read by sp_prepare_fill */
+    int32_t* counts[SP_PREP_MAX_STRIDES];       /* N each, out of sp_prepare_count */
+    const int32_t* seg_off[SP_PREP_MAX_STRIDES];/* N each: first table position of every segment (host-made, padded layout) */
+    uint32_t* pix[SP_PREP_MAX_STRIDES];         /* out of sp_prepare_fill */
+    float* baseL[SP_PREP_MAX_STRIDES];
+    int32_t stride[SP_PREP_MAX_STRIDES];
+    int32_t N, H, W, n_strides;
+} SpPrepTable;                   /* 224 bytes */
+typedef struct SpPrepSample {    /* one table, sampled at up to SP_PREP_MAX_LEVELS pyramid levels in one pass; sets pix bit 31 */
+    uint32_t* pix;
+    const float* baseL;
+    const int32_t* seg_off;      /* N, relative to pix */
+    const int32_t* counts;       /* N: real points of every segment */
+    const float* kp_L;
+    const float* kld;
+    const float* K;              /* 9 floats, full-resolution intrinsics */
+    const float* image[SP_PREP_MAX_LEVELS];     /* planar (3,Hl,Wl) source image of each level */
+    float* src4[SP_PREP_MAX_LEVELS];            /* (P,4) out, one per level */
+    int32_t Hl[SP_PREP_MAX_LEVELS], Wl[SP_PREP_MAX_LEVELS];
+    int32_t N, P, H, W, n_levels, pad_;
+} SpPrepSample;                  /* 176 bytes */
+typedef struct SpPrepImage {
+    const float* in;             /* (C,H,W) planar */
+    float* out;                  /* blur: (C,ceil(H/2),ceil(W/2)); pack: (H,W,3) */
+    int32_t H, W;
+} SpPrepImage;                   /* 24 bytes */
+int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream);
+int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream);
+int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream);
+int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixels, void* stream);
+int sp_prepare_pack(const SpPrepImage* jobs, int n_jobs, int max_pixels, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * The cost: one source keyframe against B target frames (B = 1: core/dense_optim.py:265-363

@@ -34,6 +34,11 @@ SIGNATURES = {
     "sp_pairs_gn_step": [P, I, I, P, P, F, F, F, P, P, P, P],
     "sp_pairs_cost_active": [P, P, P, I, I, F, P, P, P, P],
     "sp_pairs_gn_step_conv": [P, I, I, P, P, F, F, F, P, P, P, F, P, P],
+    "sp_prepare_count": [P, I, I, I, P],
+    "sp_prepare_fill": [P, I, I, I, P],
+    "sp_prepare_sample": [P, I, I, P],
+    "sp_prepare_blur": [P, I, I, I, P],
+    "sp_prepare_pack": [P, I, I, P],
     "sp_pairs_schedule_cost": [P, P, P],
     "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P],
     "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, P, F, F, F, P, P, P],
@@ -57,7 +62,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 6
+SP_ABI_VERSION = 7
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GRAD_SEG_FLOATS = 1
@@ -77,6 +82,30 @@ class SpPair(ctypes.Structure):
 
 
 SP_MAX_PHASES = 8
+
+
+SP_PREP_MAX_STRIDES = 4
+SP_PREP_MAX_LEVELS = 4
+
+
+class SpPrepTable(ctypes.Structure):
+    """Mirror of ``struct SpPrepTable`` (include/sp_hip.h): one keyframe of the batched preparation, all its lattices."""
+    _fields_ = [("masks", c_void_p), ("logdepth", c_void_p), ("keypoints", c_void_p), ("kp_L", c_void_p),
+                ("row_counts", c_void_p * SP_PREP_MAX_STRIDES), ("counts", c_void_p * SP_PREP_MAX_STRIDES),
+                ("seg_off", c_void_p * SP_PREP_MAX_STRIDES), ("pix", c_void_p * SP_PREP_MAX_STRIDES),
+                ("baseL", c_void_p * SP_PREP_MAX_STRIDES), ("stride", c_int * SP_PREP_MAX_STRIDES),
+                ("N", c_int), ("H", c_int), ("W", c_int), ("n_strides", c_int)]
+
+
+class SpPrepSample(ctypes.Structure):
+    _fields_ = [("pix", c_void_p), ("baseL", c_void_p), ("seg_off", c_void_p), ("counts", c_void_p), ("kp_L", c_void_p), ("kld", c_void_p),
+                ("K", c_void_p), ("image", c_void_p * SP_PREP_MAX_LEVELS), ("src4", c_void_p * SP_PREP_MAX_LEVELS),
+                ("Hl", c_int * SP_PREP_MAX_LEVELS), ("Wl", c_int * SP_PREP_MAX_LEVELS),
+                ("N", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("n_levels", c_int), ("pad_", c_int)]
+
+
+class SpPrepImage(ctypes.Structure):
+    _fields_ = [("inp", c_void_p), ("out", c_void_p), ("H", c_int), ("W", c_int)]
 
 
 class SpPhase(ctypes.Structure):

@@ -4,25 +4,33 @@
 
 namespace {
 
-// one wave per (segment,row): number of set mask bytes in that row
-__global__ __launch_bounds__(SP_BLOCK) void k_row_counts(const uint8_t* __restrict__ masks, int rows_total, int W,
-                                                         int32_t* __restrict__ row_counts) {
-    const int row = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
-    if (row >= rows_total) return;
+// one wave per (segment,row): number of set mask bytes in that row.  stride > 1: only the pixels of the stride x stride
+// lattice (row and column multiples of the stride) count -- the decimated point sets of sp_prepare_*
+__device__ __forceinline__ void row_count(const uint8_t* __restrict__ masks, int row, int H, int W, int stride,
+                                          int32_t* __restrict__ row_counts) {
     const int lane = threadIdx.x & 63;
     const uint8_t* m = masks + (size_t)row * W;
     int c = 0;
-    for (int x = lane; x < W; x += 64) c += m[x] != 0;
+    if (stride == 1) {
+        for (int x = lane; x < W; x += 64) c += m[x] != 0;
+    } else if ((row % H) % stride == 0) {
+        for (int x = lane * stride; x < W; x += 64 * stride) c += m[x] != 0;
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
     if (lane == 0) row_counts[row] = c;
 }
 
+__global__ __launch_bounds__(SP_BLOCK) void k_row_counts(const uint8_t* __restrict__ masks, int rows_total, int H, int W,
+                                                         int32_t* __restrict__ row_counts) {
+    const int row = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (row >= rows_total) return;
+    row_count(masks, row, H, W, 1, row_counts);
+}
+
 // one block per segment: exclusive scan of its H row counts in place, total to counts[n]
-__global__ __launch_bounds__(SP_BLOCK) void k_segment_row_scan(int32_t* __restrict__ row_counts, int H,
-                                                               int32_t* __restrict__ counts) {
+__device__ __forceinline__ void segment_row_scan(int32_t* __restrict__ rc, int H, int32_t* __restrict__ count) {
     __shared__ int32_t part[SP_BLOCK];
-    int32_t* rc = row_counts + (size_t)blockIdx.x * H;
     const int per = (H + SP_BLOCK - 1) / SP_BLOCK;
     const int r0 = threadIdx.x * per, r1 = min(r0 + per, H);
     int s = 0;
@@ -32,11 +40,16 @@ __global__ __launch_bounds__(SP_BLOCK) void k_segment_row_scan(int32_t* __restri
     if (threadIdx.x == 0) {
         int run = 0;
         for (int i = 0; i < SP_BLOCK; ++i) { const int v = part[i]; part[i] = run; run += v; }
-        counts[blockIdx.x] = run;
+        *count = run;
     }
     __syncthreads();
     int run = part[threadIdx.x];
     for (int r = r0; r < r1; ++r) { const int v = rc[r]; rc[r] = run; run += v; }
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_segment_row_scan(int32_t* __restrict__ row_counts, int H,
+                                                               int32_t* __restrict__ counts) {
+    segment_row_scan(row_counts + (size_t)blockIdx.x * H, H, counts + blockIdx.x);
 }
 
 // single block: seg_off = exclusive scan of counts (N+1 entries)
@@ -59,21 +72,19 @@ __global__ __launch_bounds__(SP_BLOCK) void k_segment_offsets(const int32_t* __r
     for (int n = n0; n < n1; ++n) { seg_off[n] = run; run += counts[n]; }
 }
 
-// one wave per (segment,row): ordered compaction of the row (ballot + prefix popcount)
-__global__ __launch_bounds__(SP_BLOCK) void k_table_fill(const uint8_t* __restrict__ masks,
-                                                         const float* __restrict__ logdepth, int N, int H, int W,
-                                                         const int32_t* __restrict__ seg_off,
-                                                         const int32_t* __restrict__ row_off,
-                                                         uint32_t* __restrict__ pix, float* __restrict__ baseL) {
-    const int row_id = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
-    if (row_id >= N * H) return;
+// one wave per (segment,row): ordered compaction of the row (ballot + prefix popcount); stride as in row_count()
+__device__ __forceinline__ void fill_row(const uint8_t* __restrict__ masks, const float* __restrict__ logdepth, int row_id,
+                                         int H, int W, int stride, const int32_t* __restrict__ seg_off,
+                                         const int32_t* __restrict__ row_off, uint32_t* __restrict__ pix,
+                                         float* __restrict__ baseL) {
     const int lane = threadIdx.x & 63;
     const int n = row_id / H, r = row_id - n * H;
+    if (stride > 1 && r % stride != 0) return;
     const uint8_t* m = masks + (size_t)row_id * W;
     const float* L = logdepth + (size_t)row_id * W;
     int base = seg_off[n] + row_off[row_id];
-    for (int x0 = 0; x0 < W; x0 += 64) {
-        const int x = x0 + lane;
+    for (int x0 = 0; x0 < W; x0 += 64 * stride) {
+        const int x = x0 + lane * stride;
         const bool on = (x < W) && (m[x] != 0);
         const unsigned long long bal = __ballot(on);
         if (on) {
@@ -85,11 +96,19 @@ __global__ __launch_bounds__(SP_BLOCK) void k_table_fill(const uint8_t* __restri
     }
 }
 
+__global__ __launch_bounds__(SP_BLOCK) void k_table_fill(const uint8_t* __restrict__ masks,
+                                                         const float* __restrict__ logdepth, int N, int H, int W,
+                                                         const int32_t* __restrict__ seg_off,
+                                                         const int32_t* __restrict__ row_off,
+                                                         uint32_t* __restrict__ pix, float* __restrict__ baseL) {
+    const int row_id = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (row_id >= N * H) return;
+    fill_row(masks, logdepth, row_id, H, W, 1, seg_off, row_off, pix, baseL);
+}
+
 // tool/point_utils.py:37-40 + core/dense_optim.py:51-59: L at the rounded keypoint pixel
-__global__ void k_keypoint_L(const float* __restrict__ logdepth, const float* __restrict__ keypoints, int N, int H,
-                             int W, float* __restrict__ kp_L) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+__device__ __forceinline__ void keypoint_L(const float* __restrict__ logdepth, const float* __restrict__ keypoints, int n, int H,
+                                           int W, float* __restrict__ kp_L) {
     const float kr = rintf(0.5f * (float)(H - 1) * (keypoints[2 * n] + 1.f));      // rintf = half-to-even
     const float kc = rintf(0.5f * (float)(W - 1) * (keypoints[2 * n + 1] + 1.f));
     int r = (int)kr, c = (int)kc;
@@ -99,6 +118,12 @@ __global__ void k_keypoint_L(const float* __restrict__ logdepth, const float* __
     r = min(max(r, 0), H - 1);
     c = min(max(c, 0), W - 1);
     kp_L[n] = logdepth[((size_t)n * H + r) * W + c];
+}
+
+__global__ void k_keypoint_L(const float* __restrict__ logdepth, const float* __restrict__ keypoints, int N, int H,
+                             int W, float* __restrict__ kp_L) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) keypoint_L(logdepth, keypoints, n, H, W, kp_L);
 }
 
 __device__ __forceinline__ int segment_of(const int32_t* __restrict__ seg_off, int N, int i) {
@@ -114,15 +139,10 @@ __device__ __forceinline__ float planar_tap(const float* __restrict__ img, int W
 
 // Source-side sampling exactly as the reference does it (get_pixels on the source's own points,
 // core/dense_optim.py:143-162,315-317): IEEE divisions, same operation order, so the validity bit matches.
-__global__ __launch_bounds__(SP_BLOCK) void k_sample_source(uint32_t* __restrict__ pix, const float* __restrict__ baseL,
-                                                            const int32_t* __restrict__ seg_off,
-                                                            const float* __restrict__ kp_L, const float* __restrict__ kld,
-                                                            int N, int P, int H, int W, const float* __restrict__ img,
-                                                            int Hl, int Wl, const float* __restrict__ K9,
-                                                            float4* __restrict__ src4, int set_validity) {
-    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
-    if (i >= P) return;
-    const int n = segment_of(seg_off, N, i);
+__device__ __forceinline__ void sample_point(uint32_t* __restrict__ pix, const float* __restrict__ baseL, int i, int n,
+                                             const float* __restrict__ kp_L, const float* __restrict__ kld, int H, int W,
+                                             const float* __restrict__ img, int Hl, int Wl, const float* __restrict__ K9,
+                                             float4* __restrict__ src4, int set_validity) {
     const float fx = K9[0], cx = K9[2], fy = K9[4], cy = K9[5];
     const uint32_t pw = pix[i] & 0x7fffffffu;
     const float col = (float)(pw & 0xffffu), row = (float)(pw >> 16);
@@ -162,23 +182,33 @@ __global__ __launch_bounds__(SP_BLOCK) void k_sample_source(uint32_t* __restrict
     if (set_validity) pix[i] = pw | (ok ? 0x80000000u : 0u);
 }
 
+__global__ __launch_bounds__(SP_BLOCK) void k_sample_source(uint32_t* __restrict__ pix, const float* __restrict__ baseL,
+                                                            const int32_t* __restrict__ seg_off,
+                                                            const float* __restrict__ kp_L, const float* __restrict__ kld,
+                                                            int N, int P, int H, int W, const float* __restrict__ img,
+                                                            int Hl, int Wl, const float* __restrict__ K9,
+                                                            float4* __restrict__ src4, int set_validity) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    sample_point(pix, baseL, i, segment_of(seg_off, N, i), kp_L, kld, H, W, img, Hl, Wl, K9, src4, set_validity);
+}
+
+__device__ __forceinline__ void pack_texel(const float* __restrict__ p, int HW, int i, float* __restrict__ out) {
+    float* q = out + (size_t)i * SP_TEXEL_FLOATS;
+    q[0] = p[i]; q[1] = p[HW + i]; q[2] = p[2 * (size_t)HW + i];
+}
+
 __global__ __launch_bounds__(SP_BLOCK) void k_pack_rgb(const float* __restrict__ chw, int HW, float* __restrict__ out) {
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
     if (i >= HW) return;
-    const float* p = chw + (size_t)blockIdx.y * 3 * HW;
-    float* q = out + ((size_t)blockIdx.y * HW + i) * SP_TEXEL_FLOATS;
-    q[0] = p[i]; q[1] = p[HW + i]; q[2] = p[2 * (size_t)HW + i];
+    pack_texel(chw + (size_t)blockIdx.y * 3 * HW, HW, i, out + (size_t)blockIdx.y * HW * SP_TEXEL_FLOATS);
 }
 
 __device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
 // image/gaussian_pyramid.py:53-85: reflect pad 1, depthwise [1 2 1;2 4 2;1 2 1]/16, keep [::2, ::2]
-__global__ __launch_bounds__(SP_BLOCK) void k_blur_decimate(const float* __restrict__ in, int H, int W, int Ho, int Wo,
-                                                            float* __restrict__ out) {
-    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
-    if (i >= Ho * Wo) return;
+__device__ __forceinline__ float blur_decimate_at(const float* __restrict__ p, int H, int W, int Wo, int i) {
     const int yo = i / Wo, xo = i - yo * Wo;
-    const float* p = in + (size_t)blockIdx.y * H * W;
     const float wgt[3] = {1.f, 2.f, 1.f};
     float acc = 0.f;
 #pragma unroll
@@ -190,7 +220,159 @@ __global__ __launch_bounds__(SP_BLOCK) void k_blur_decimate(const float* __restr
             acc = fmaf(wgt[dy] * wgt[dx] * (1.f / 16.f), p[(size_t)y * W + x], acc);
         }
     }
-    out[(size_t)blockIdx.y * Ho * Wo + i] = acc;
+    return acc;
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_blur_decimate(const float* __restrict__ in, int H, int W, int Ho, int Wo,
+                                                            float* __restrict__ out) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    out[(size_t)blockIdx.y * Ho * Wo + i] = blur_decimate_at(in + (size_t)blockIdx.y * H * W, H, W, Wo, i);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched preparation (sp_prepare_*): the same per-row / per-point work, one launch for MANY keyframes -- blockIdx.y picks
+// the job record.  A pipeline that optimises hundreds of new frame pairs per batch is otherwise bound by the ~15 tiny
+// launches per pair above, not by the optimiser.
+// ---------------------------------------------------------------------------------------------------------------------
+// bit 7 of every byte of w that is non-zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) { return ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u); }
+
+// which of the 4 pixels x0 .. x0+3 (x0 a multiple of 4) lie on the stride lattice, as a nonzero_bytes() mask
+__device__ __forceinline__ uint32_t lattice_bytes(int x0, int stride) {
+    if (stride == 1) return 0x80808080u;
+    if (stride == 2) return 0x00800080u;
+    if (stride == 4) return 0x00000080u;
+    uint32_t sel = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sel |= ((x0 + j) % stride == 0) ? (0x80u << (8 * j)) : 0u;
+    return sel;
+}
+
+// one wave per (segment,row), every lattice of the keyframe in the same pass over the mask row (read as 32-bit words
+// when the rows are word-aligned)
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable* __restrict__ tables) {
+    const SpPrepTable& t = tables[blockIdx.y];
+    const int row = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (row >= t.N * t.H) return;
+    const int lane = threadIdx.x & 63;
+    const int r = row % t.H;
+    const uint8_t* m = t.masks + (size_t)row * t.W;
+    int c[SP_PREP_MAX_STRIDES] = {0, 0, 0, 0};
+    if ((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0) {
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(m);
+        for (int xw = lane; xw < (t.W >> 2); xw += 64) {
+            const uint32_t nz = nonzero_bytes(mw[xw]);
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                if (k < t.n_strides) c[k] += __popc(nz & lattice_bytes(4 * xw, t.stride[k]));
+        }
+    } else {
+        for (int x = lane; x < t.W; x += 64) {
+            const bool on = m[x] != 0;
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                if (k < t.n_strides) c[k] += (on && x % t.stride[k] == 0) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+        if (k >= t.n_strides) break;
+        int v = (r % t.stride[k] == 0) ? c[k] : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) t.row_counts[k][row] = v;
+    }
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* __restrict__ tables) {
+    const SpPrepTable& t = tables[blockIdx.y];
+    if ((int)blockIdx.x >= t.N) return;
+    const int k = blockIdx.z;
+    if (k >= t.n_strides) return;
+    segment_row_scan(t.row_counts[k] + (size_t)blockIdx.x * t.H, t.H, t.counts[k] + blockIdx.x);
+}
+
+// one wave per (segment,row): ordered compaction of the row into every lattice's table.  Word path: a lane owns 4
+// consecutive pixels; its rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken
+// from three ballots of the count's bits.
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __restrict__ tables) {
+    const SpPrepTable& t = tables[blockIdx.y];
+    const int row_id = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    if (row_id >= t.N * t.H) return;
+    const int lane = threadIdx.x & 63;
+    const int n = row_id / t.H, r = row_id - n * t.H;
+    const uint8_t* m = t.masks + (size_t)row_id * t.W;
+    const float* L = t.logdepth + (size_t)row_id * t.W;
+    if (!((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0)) {
+        for (int k = 0; k < t.n_strides; ++k)
+            fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
+        return;
+    }
+    int base[SP_PREP_MAX_STRIDES];
+    bool act[SP_PREP_MAX_STRIDES];
+#pragma unroll
+    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+        act[k] = k < t.n_strides && r % t.stride[k] == 0;
+        base[k] = act[k] ? t.seg_off[k][n] + t.row_counts[k][row_id] : 0;
+    }
+    const uint32_t* mw = reinterpret_cast<const uint32_t*>(m);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int w0 = 0; w0 < (t.W >> 2); w0 += 64) {
+        const int xw = w0 + lane;
+        const uint32_t nz = xw < (t.W >> 2) ? nonzero_bytes(mw[xw]) : 0u;
+        float Lv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Lv[j] = ((nz >> (8 * j + 7)) & 1u) ? L[4 * xw + j] : 0.f;
+#pragma unroll
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+            if (!act[k]) continue;
+            const uint32_t sel = nz & lattice_bytes(4 * xw, t.stride[k]);
+            const int cnt = __popc(sel);
+            const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+            int pos = base[k] + __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((sel >> (8 * j + 7)) & 1u) {
+                    t.pix[k][pos] = ((uint32_t)r << 16) | (uint32_t)(4 * xw + j);
+                    t.baseL[k][pos] = Lv[j];
+                    ++pos;
+                }
+            base[k] += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+        }
+    }
+}
+
+__global__ void k_prep_keypoint_L(const SpPrepTable* __restrict__ tables) {
+    const SpPrepTable& t = tables[blockIdx.y];
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < t.N && t.kp_L) keypoint_L(t.logdepth, t.keypoints, n, t.H, t.W, t.kp_L);
+}
+
+// every pyramid level of one table in one pass: segment search, depth and validity once per point
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs) {
+    const SpPrepSample& j = jobs[blockIdx.y];
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= j.P) return;
+    const int n = segment_of(j.seg_off, j.N, i);
+    if (i - j.seg_off[n] >= j.counts[n]) return;          // padding of the segment's run: stays {pix 0, src4 0}
+    for (int l = 0; l < j.n_levels; ++l)
+        sample_point(j.pix, j.baseL, i, n, j.kp_L, j.kld, j.H, j.W, j.image[l], j.Hl[l], j.Wl[l], j.K,
+                     reinterpret_cast<float4*>(j.src4[l]), l == 0 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_blur(const SpPrepImage* __restrict__ jobs) {
+    const SpPrepImage& j = jobs[blockIdx.z];
+    const int Ho = (j.H + 1) / 2, Wo = (j.W + 1) / 2;
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= Ho * Wo) return;
+    j.out[(size_t)blockIdx.y * Ho * Wo + i] = blur_decimate_at(j.in + (size_t)blockIdx.y * j.H * j.W, j.H, j.W, Wo, i);
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_pack(const SpPrepImage* __restrict__ jobs) {
+    const SpPrepImage& j = jobs[blockIdx.y];
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i < j.H * j.W) pack_texel(j.in, j.H * j.W, i, j.out);
 }
 
 }  // namespace
@@ -203,7 +385,7 @@ int sp_mask_count(const uint8_t* masks, int N, int H, int W, int32_t* row_counts
     if (H > 32767 || W > 65535) return SP_ELIMIT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int rows = N * H;
-    hipLaunchKernelGGL(k_row_counts, dim3((rows + SP_WAVES - 1) / SP_WAVES), dim3(SP_BLOCK), 0, s, masks, rows, W, row_counts);
+    hipLaunchKernelGGL(k_row_counts, dim3((rows + SP_WAVES - 1) / SP_WAVES), dim3(SP_BLOCK), 0, s, masks, rows, H, W, row_counts);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_segment_row_scan, dim3(N), dim3(SP_BLOCK), 0, s, row_counts, H, counts);
     SP_CHECK_LAUNCH();
@@ -252,6 +434,53 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     hipLaunchKernelGGL(k_blur_decimate, dim3((Ho * Wo + SP_BLOCK - 1) / SP_BLOCK, C), dim3(SP_BLOCK), 0,
                        static_cast<hipStream_t>(stream), in, H, W, Ho, Wo, out);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+
+static_assert(sizeof(SpPrepTable) == 224 && sizeof(SpPrepSample) == 176 && sizeof(SpPrepImage) == 24, "preparation job records are part of the ABI");
+
+// ---- batched preparation ----
+static int check_grid(long x, long y) { return (x <= 0 || y <= 0 || y > 65535) ? SP_EINVAL : 0; }
+
+int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
+    if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_prep_row_counts, dim3((max_rows + SP_WAVES - 1) / SP_WAVES, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_prep_row_scan, dim3(max_N, n_tables, SP_PREP_MAX_STRIDES), dim3(SP_BLOCK), 0, s, tables);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
+    if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_prep_fill, dim3((max_rows + SP_WAVES - 1) / SP_WAVES, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_prep_keypoint_L, dim3((max_N + 63) / 64, n_tables), dim3(64), 0, s, tables);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream) {
+    if (!jobs || check_grid(max_P, n_jobs)) return SP_EINVAL;
+    hipLaunchKernelGGL(k_prep_sample, dim3((max_P + SP_BLOCK - 1) / SP_BLOCK, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixels, void* stream) {
+    if (!jobs || check_grid(max_out_pixels, n_jobs) || C <= 0 || C > 65535) return SP_EINVAL;
+    hipLaunchKernelGGL(k_prep_blur, dim3((max_out_pixels + SP_BLOCK - 1) / SP_BLOCK, C, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_prepare_pack(const SpPrepImage* jobs, int n_jobs, int max_pixels, void* stream) {
+    if (!jobs || check_grid(max_pixels, n_jobs)) return SP_EINVAL;
+    hipLaunchKernelGGL(k_prep_pack, dim3((max_pixels + SP_BLOCK - 1) / SP_BLOCK, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
     SP_CHECK_LAUNCH();
     return 0;
 }

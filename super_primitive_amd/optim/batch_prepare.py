@@ -1,0 +1,243 @@
+"""Batched preparation of many frame pairs: point tables, image pyramids, per-level source samples and packed targets of
+a whole ``PairBatch`` with a dozen launches and ONE host synchronisation (include/sp_hip.h, "Batched preparation").
+
+The per-keyframe path (``segment_table.SegmentTable`` + ``image.gaussian_pyramid``) costs ~15 small launches, a host
+synchronisation and a few hundred microseconds of Python per pair -- fine for one keyframe, 20x the optimiser's own time
+when hundreds of new pairs are set up per batch.  Here every pass is one launch whose grid rows are job records in device
+memory, the per-segment counts of ALL tables come back in one copy, and the host-side layout (padded runs, chunks, spans,
+descriptors) is numpy-vectorised over the batch.
+
+What it replaces per pair (reference): core/dense_optim.py:38-114 ``unproject_segments`` (the torch.where compaction),
+image/gaussian_pyramid.py:53-85 (pyramids), core/dense_optim.py:315-317 (source sampling) -- same arithmetic and point
+order as the per-keyframe kernels (shared device functions, sp_table.hip)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+GRANULE = 256
+
+
+def _dev(t, dev):
+    """``t`` on ``dev`` as contiguous float32 without touching tensors that already are."""
+    t = t.detach()
+    if t.device != dev:
+        t = t.to(dev)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def flat_layout(counts, n_off):
+    """Padded layout of many tables at once.  counts: real points of every segment, all tables concatenated; n_off[t]:
+    first segment of table t.  Returns (pc, seg_pos, p_off): padded run length of every segment, its position relative to
+    its own table, and the tables' offsets into one flat array."""
+    counts = np.asarray(counts, dtype=np.int64)
+    pc = (counts + GRANULE - 1) // GRANULE * GRANULE
+    cum = np.concatenate(([0], np.cumsum(pc)))
+    p_off = cum[n_off]
+    table = np.repeat(np.arange(len(n_off) - 1), np.diff(n_off))
+    return pc, cum[:-1] - p_off[table], p_off
+
+
+def flat_work_list(pc, seg_pos, n_off, span_points, tile_points):
+    """Chunks, spans and record offsets (include/sp_hip.h, "Work list") of all pairs at once; the vectorised form of
+    ``pair_batch.build_work_list`` (same chunks, same greedy spans, same order).  pc / seg_pos: padded run length and
+    pair-relative position of every segment; n_off: first segment of every pair.  Returns dict(chunks (C,4), spans (S,4),
+    seg_tile_off (sum(N)+M,), sto_off (M+1,), c_off (M+1,), s_off (M+1,))."""
+    pc = np.asarray(pc, dtype=np.int64)
+    n_off = np.asarray(n_off, dtype=np.int64)
+    M, S = len(n_off) - 1, len(pc)
+    Ns = np.diff(n_off)
+    pair_of_seg = np.repeat(np.arange(M), Ns)
+    seg_in_pair = np.arange(S) - n_off[pair_of_seg]
+    chunk_max = max(GRANULE, tile_points // GRANULE * GRANULE)
+    k = -(-pc // chunk_max)                                                     # pieces per segment (0 for an empty one)
+    per = -(-(pc // GRANULE) // np.maximum(k, 1)) * GRANULE                    # (nearly) equal, granule-aligned lengths
+    cumk = np.concatenate(([0], np.cumsum(k)))
+    C = int(cumk[-1])
+    seg_idx = np.repeat(np.arange(S), k)
+    j = np.arange(C) - cumk[:-1][seg_idx]
+    start = seg_pos[seg_idx] + j * per[seg_idx]
+    cnt = np.minimum(per[seg_idx], pc[seg_idx] - j * per[seg_idx])
+    chunks = np.stack((pair_of_seg[seg_idx], seg_in_pair[seg_idx], start, cnt), axis=1).astype(np.int32)
+    c_off = cumk[n_off]
+    # per-pair CSR of the segment records: 4 records per chunk (one per wave)
+    ext_pair = np.repeat(np.arange(M), Ns + 1)
+    sto_off = n_off + np.arange(M + 1)
+    ext_local = np.arange(S + M) - sto_off[:-1][ext_pair]
+    seg_tile_off = (4 * (cumk[n_off[ext_pair] + ext_local] - cumk[n_off[ext_pair]])).astype(np.int32)
+    # spans: greedy runs of consecutive chunks of one pair, all pairs advanced together
+    cum = np.concatenate(([0], np.cumsum(cnt)))
+    cur, end = c_off[:-1].copy(), c_off[1:]
+    parts = []
+    act = np.nonzero(cur < end)[0]
+    while act.size:
+        q0 = cur[act]
+        q1 = np.searchsorted(cum, cum[q0] + span_points, side='right') - 1
+        q1 = np.minimum(np.maximum(q1, q0 + 1), end[act])
+        parts.append(np.stack((q0, q1 - q0, cum[q1] - cum[q0], act), axis=1))
+        cur[act] = q1
+        act = act[q1 < end[act]]
+    spans = np.concatenate(parts) if parts else np.zeros((0, 4), dtype=np.int64)
+    spans = spans[np.lexsort((spans[:, 0], spans[:, 3]))].astype(np.int32)
+    s_off = np.concatenate(([0], np.cumsum(np.bincount(spans[:, 3], minlength=M))))
+    return dict(chunks=chunks, spans=spans, seg_tile_off=seg_tile_off, sto_off=sto_off, c_off=c_off, s_off=s_off)
+
+
+class PreparedTables:
+    """Device arrays of one lattice stride for the base pairs: pix (sum Ppad,), src4 {level: (sum Ppad, 4)}, plus the host
+    layout: counts / pc / seg_pos per segment and p_off per pair."""
+
+
+_TABLE_DT, _SAMPLE_DT, _IMAGE_DT = np.dtype(_lib.SpPrepTable), np.dtype(_lib.SpPrepSample), np.dtype(_lib.SpPrepImage)
+
+
+def _ptrs(tensors):
+    return np.array([t.data_ptr() for t in tensors], dtype=np.uint64)
+
+
+def _records(arr, dev):
+    """numpy structured array of job records -> device bytes."""
+    return torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(dev)
+
+
+def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
+    """Everything PairBatch needs from the raw frames, for the M0 given pairs.
+
+    coarse: [(level, stride)] -- ADDITIONAL decimated tables (stride > 1) sampled at that level; the stride-1 tables are
+    always built and sampled at every level.  Returns dict(tabs {stride: PreparedTables}, kp_L (sum N,),
+    trg {level: (flat HWC3, trg_off, [(Hl, Wl)])}, n_off, shapes (M0, 3) = N, H, W)."""
+    lib = _lib.load()
+    M0 = len(src_frames)
+    s_ptr = _lib.stream_ptr()
+    masks = [f.keypoint_regions.contiguous() for f in src_frames]
+    for m in masks:
+        assert m.dtype == torch.bool and m.dim() == 3
+    logd = [_dev(f.logdepth_perseg, dev) for f in src_frames]
+    kps = [_dev(f.keypoints, dev) for f in src_frames]
+    simg = [_dev(f.image[:3], dev) for f in src_frames]
+    timg = [_dev(t[:3], dev) for t in trg_images]
+    Ksrc = [_dev(f.K, dev) for f in src_frames]
+    kld = [_dev(k, dev) for k in klds]
+    _lib.require_device(*masks, *logd, *simg, *timg)
+    shp = np.array([m.shape for m in masks], dtype=np.int64)                     # (M0, 3): N, H, W
+    Ns, Hs, Ws = shp[:, 0], shp[:, 1], shp[:, 2]
+    if (Hs > 32767).any() or (Ws > 65535).any():
+        raise ValueError("image too large for the packed pixel word")
+    n_off = np.concatenate(([0], np.cumsum(Ns)))
+    S = int(n_off[-1])
+    all_strides = sorted({1} | {int(s) for _, s in coarse if int(s) > 1})
+    nS = len(all_strides)
+    if nS > _lib.SP_PREP_MAX_STRIDES:
+        raise ValueError(f"{nS} lattice strides exceed SP_PREP_MAX_STRIDES = {_lib.SP_PREP_MAX_STRIDES}")
+    if len(level_ids) > _lib.SP_PREP_MAX_LEVELS:
+        raise ValueError(f"{len(level_ids)} pyramid levels exceed SP_PREP_MAX_LEVELS = {_lib.SP_PREP_MAX_LEVELS}")
+
+    # ---- pass 1: counts of every lattice of every keyframe (masks read once), one copy back ----
+    rows = Ns * Hs
+    rc_off = np.concatenate(([0], np.cumsum(rows)))
+    row_counts = torch.empty(nS * int(rc_off[-1]), dtype=torch.int32, device=dev)
+    counts_d = torch.empty(nS * S, dtype=torch.int32, device=dev)
+    recs = np.zeros(M0, dtype=_TABLE_DT)
+    recs['masks'], recs['logdepth'], recs['keypoints'] = _ptrs(masks), _ptrs(logd), _ptrs(kps)
+    recs['N'], recs['H'], recs['W'], recs['n_strides'] = Ns, Hs, Ws, nS
+    for si, s in enumerate(all_strides):
+        recs['stride'][:, si] = s
+        recs['row_counts'][:, si] = row_counts.data_ptr() + 4 * (si * int(rc_off[-1]) + rc_off[:-1])
+        recs['counts'][:, si] = counts_d.data_ptr() + 4 * (si * S + n_off[:-1])
+    max_rows, max_N = int(rows.max()), int(Ns.max())
+    recs_d = _records(recs, dev)
+    _lib.check(lib.sp_prepare_count(_lib.ptr(recs_d), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
+    counts_h = counts_d.cpu().numpy().reshape(nS, S)                            # the one host synchronisation of the set-up
+
+    # ---- host: padded layouts; device: fill straight into them ----
+    tabs = {}
+    kp_L = torch.empty(S, dtype=torch.float32, device=dev)
+    recs['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
+    pair_of_seg = np.repeat(np.arange(M0), Ns)
+    for si, s in enumerate(all_strides):
+        t = PreparedTables()
+        t.stride = s
+        t.counts = counts_h[si].astype(np.int64)
+        t.pc, t.seg_pos, t.p_off = flat_layout(t.counts, n_off)
+        if s == 1 and (np.add.reduceat(t.counts, n_off[:-1]) == 0).any():
+            raise ValueError("keyframe has no segment pixels")
+        total = max(int(t.p_off[-1]), 1)
+        t.pix = torch.zeros(total, dtype=torch.int32, device=dev)               # zero = invalid point: the padding
+        t.baseL = torch.empty(total, dtype=torch.float32, device=dev)
+        # segment positions: inside the flat array (fill) and relative to the pair's own table (sampler, cost kernels)
+        t.seg_off = torch.from_numpy(np.concatenate((t.seg_pos + t.p_off[pair_of_seg], t.seg_pos)).astype(np.int32)).to(dev)
+        t.counts_d = counts_d[si * S: (si + 1) * S]
+        recs['seg_off'][:, si] = t.seg_off.data_ptr() + 4 * n_off[:-1]
+        recs['pix'][:, si], recs['baseL'][:, si] = t.pix.data_ptr(), t.baseL.data_ptr()
+        t.src4 = {}
+        tabs[s] = t
+    recs_d = _records(recs, dev)
+    _lib.check(lib.sp_prepare_fill(_lib.ptr(recs_d), M0, max_rows, max_N, s_ptr), "sp_prepare_fill")
+
+    # ---- image pyramids of both frames, packed targets ----
+    max_level = max(level_ids)
+    pyramid = []
+    ptr_lv = {0: (_ptrs(simg), _ptrs(timg))}                                     # level -> (source, target) image pointers
+    hw = {0: np.stack((Hs, Ws), axis=1)}
+    for l in range(1, max_level + 1):
+        hw[l] = (hw[l - 1] + 1) // 2
+        sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
+        off = np.concatenate(([0], np.cumsum(np.tile(sizes, 2))))
+        buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
+        jobs = np.zeros(2 * M0, dtype=_IMAGE_DT)
+        jobs['inp'] = np.concatenate(ptr_lv[l - 1])
+        jobs['out'] = buf.data_ptr() + 4 * off[:-1]
+        jobs['H'], jobs['W'] = np.tile(hw[l - 1][:, 0], 2), np.tile(hw[l - 1][:, 1], 2)
+        jobs_d = _records(jobs, dev)
+        _lib.check(lib.sp_prepare_blur(_lib.ptr(jobs_d), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
+        ptr_lv[l] = (jobs['out'][:M0].copy(), jobs['out'][M0:].copy())
+        pyramid.append(buf)                  # read by later launches: must not return to the allocator before they are enqueued
+    trg = {}
+    jobs = np.zeros(len(level_ids) * M0, dtype=_IMAGE_DT)
+    for li, l in enumerate(level_ids):
+        sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
+        off = np.concatenate(([0], np.cumsum(sizes)))
+        buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
+        jb = jobs[li * M0: (li + 1) * M0]
+        jb['inp'], jb['out'] = ptr_lv[l][1], buf.data_ptr() + 4 * off[:-1]
+        jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
+        trg[l] = (buf, off, [(int(h), int(w)) for h, w in hw[l]])
+    jobs_d = _records(jobs, dev)
+    _lib.check(lib.sp_prepare_pack(_lib.ptr(jobs_d), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
+               "sp_prepare_pack")
+
+    # ---- source samples: the stride-1 tables at every level, a decimated table at its own level(s), all levels of a table
+    #      in one pass (which also sets the table's source-validity bits) ----
+    levels_of = {1: list(level_ids)}
+    for l, s in coarse:
+        if int(s) > 1 and int(l) not in levels_of.setdefault(int(s), []):
+            levels_of[int(s)].append(int(l))
+    jobs = np.zeros(len(levels_of) * M0, dtype=_SAMPLE_DT)
+    max_P = 1
+    for ji, (s, lv) in enumerate(levels_of.items()):
+        t = tabs[s]
+        jb = jobs[ji * M0: (ji + 1) * M0]
+        P = np.diff(t.p_off)
+        max_P = max(max_P, int(P.max()))
+        jb['pix'] = t.pix.data_ptr() + 4 * t.p_off[:-1]
+        jb['baseL'] = t.baseL.data_ptr() + 4 * t.p_off[:-1]
+        jb['seg_off'] = t.seg_off.data_ptr() + 4 * (S + n_off[:-1])              # the pair-relative half
+        jb['counts'] = t.counts_d.data_ptr() + 4 * n_off[:-1]
+        jb['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
+        jb['kld'], jb['K'] = _ptrs(kld), _ptrs(Ksrc)
+        jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'] = Ns, P, Hs, Ws, len(lv)
+        for k, l in enumerate(lv):
+            t.src4[l] = torch.zeros(max(int(t.p_off[-1]), 1), 4, dtype=torch.float32, device=dev)
+            jb['image'][:, k] = ptr_lv[l][0]
+            jb['src4'][:, k] = t.src4[l].data_ptr() + 16 * t.p_off[:-1]
+            jb['Hl'][:, k], jb['Wl'][:, k] = hw[l][:, 0], hw[l][:, 1]
+    jobs_d = _records(jobs, dev)
+    _lib.check(lib.sp_prepare_sample(_lib.ptr(jobs_d), len(jobs), max_P, s_ptr), "sp_prepare_sample")
+    del pyramid
+    # (temporaries -- job records, row counts, pyramid levels -- are released here; the caching allocator orders their reuse
+    #  after the launches above on this stream)
+    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp)

@@ -20,7 +20,9 @@ import torch
 
 from .. import _lib
 from ..image import gaussian_pyramid
-from ..segment_table import SegmentTable
+from . import batch_prepare
+
+_SP_PAIR_DTYPE = np.dtype(_lib.SpPair)
 
 DEFAULT_BATCH_TILE_POINTS = 8192   # longest chunk (run of one segment's points between two segment-level flushes)
 DEFAULT_SPAN_POINTS = 16384        # most points per workgroup: consecutive chunks of a pair are grouped up to this many
@@ -142,108 +144,111 @@ class PairBatch:
         dev = src_frames[0].image.device
         _lib.require_device(src_frames[0].image)
         self.M, self.device = M, dev
-        base = list(range(M0)) * R              # pair m of the batch is a copy of base pair base[m]
         self.level_ids = list(range(levels[0], levels[1]))
-        max_level = levels[1] - 1
         self.tile_points = tile_points
+        self.point_stride = {l: 1 for l in self.level_ids}
+        if point_stride is not None:
+            assert len(point_stride) == len(self.level_ids), "one stride per pyramid level, finest first"
+            self.point_stride = {l: int(s) for l, s in zip(self.level_ids, point_stride)}
+        coarse_keys = sorted({(l, s) for l, s in self.point_stride.items() if s > 1} | {(int(l), int(s)) for l, s in extra_tables if int(s) > 1})
 
-        tables0 = [SegmentTable(f.keypoint_regions, f.logdepth_perseg, f.keypoints, tile_points) for f in src_frames]
-        tables = [tables0[b] for b in base]
-        frames = [src_frames[b] for b in base]
-        self.Ns = [t.N for t in tables]
-        self.Ps = [t.P for t in tables]
-        self.max_N = max(self.Ns)
-        # padded layout of every base table: segment n occupies [pseg_off[n], pseg_off[n] + counts[n]) + padding
-        pads0 = [pad_layout(tab.counts, dev) for tab in tables0]
-        pads = [pads0[b] for b in base]
-        self.Ppads = [pd['Ppad'] for pd in pads]
-        n_off = np.concatenate(([0], np.cumsum(self.Ns)))
-        p_off = np.concatenate(([0], np.cumsum(self.Ppads)))
+        # tables, pyramids, source samples and packed targets of the base pairs: a dozen launches, one host synchronisation.
+        # A (level, stride) combination needs the stride's table sampled at that level
+        prep = batch_prepare.prepare_pairs(src_frames, trg_images, klds, self.level_ids, coarse_keys, dev)
+        tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
+        rep = (lambda x: x) if R == 1 else (lambda x: x.repeat(*([R] + [1] * (x.dim() - 1))))
+        tile = (lambda a: a) if R == 1 else (lambda a: np.tile(a, R))
+        Ns0 = np.diff(n_off0)
+        Ns = tile(Ns0)
+        n_off = np.concatenate(([0], np.cumsum(Ns)))
+        full = tabs[1]
+        counts, pc, seg_pos = tile(full.counts), tile(full.pc), tile(full.seg_pos)
+        Ppad = tile(np.diff(full.p_off))
+        p_off = np.concatenate(([0], np.cumsum(Ppad)))
+        self.Ns = [int(n) for n in Ns]
+        self.Ps = [int(p) for p in np.add.reduceat(counts, n_off[:-1])]
+        self.Ppads = [int(p) for p in Ppad]
+        self.max_N = int(Ns.max())
         self.n_off, self.p_off = n_off, p_off
-        cat = torch.cat
-
-        padded = pad_points
 
         # flat, pair-major device arrays
-        self.kp_L = cat([t.kp_L for t in tables])
-        self.kld = cat([klds[b].detach().float().to(dev) for b in base]).contiguous()
+        self.kp_L = rep(kp_L)
+        self.kld = rep(torch.cat([batch_prepare._dev(k, dev).reshape(-1) for k in klds])).contiguous()
         self.pose = poses.detach().float().to(dev).reshape(M, 16).contiguous()
         self.aff = torch.zeros(M, 4, dtype=torch.float32, device=dev) if use_affine else None
-        # per-level source samples + packed targets
-        self.src4, self.trg4, self.level_hw = {}, {}, {}
-        src4_0, trg4_0, hw_0 = {}, {}, {}
-        for m, (f, tab) in enumerate(zip(src_frames, tables0)):
-            s_lv = _level_images(f.image[:3].float(), max_level)
-            t_lv = _level_images(trg_images[m][:3].float().to(dev), max_level)
-            for l in self.level_ids:
-                src4_0.setdefault(l, []).append(padded(tab.source_level(s_lv[l], f.K, klds[m].to(dev)).reshape(-1, 4), pads0[m]))
-                Hl, Wl = t_lv[l].shape[-2:]
-                packed = torch.empty(1, Hl, Wl, 3, dtype=torch.float32, device=dev)
-                _lib.check(lib.sp_pack_rgb(_lib.ptr(t_lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(packed), _lib.stream_ptr()),
-                           "sp_pack_rgb")
-                trg4_0.setdefault(l, []).append(packed.reshape(-1))
-                hw_0.setdefault(l, []).append((Hl, Wl))
-        pix0 = [padded(t.pix, pd) for t, pd in zip(tables0, pads0)]        # after source_level(): validity bits are set
-        self.pix = cat([pix0[b] for b in base])
-        self.src4 = {l: cat([v[b] for b in base]).reshape(-1) for l, v in src4_0.items()}
-        trg_off = {l: np.concatenate(([0], np.cumsum([v[b].numel() for b in base]))) for l, v in trg4_0.items()}
-        self.trg4 = {l: cat([v[b] for b in base]) for l, v in trg4_0.items()}
-        self.level_hw = {l: [v[b] for b in base] for l, v in hw_0.items()}
+        self.pix = rep(full.pix)
+        self.src4 = {l: rep(full.src4[l]).reshape(-1) for l in self.level_ids}
+        self.trg4 = {l: rep(trg[l][0]) for l in self.level_ids}
+        trg_off = {l: np.concatenate(([0], np.cumsum(tile(np.diff(trg[l][1]))))) for l in self.level_ids}
+        self.level_hw = {l: list(trg[l][2]) * R for l in self.level_ids}
 
         if span_points is None:
             span_points = min(DEFAULT_SPAN_POINTS, int(p_off[-1]) // MIN_SPANS)
         self.span_points = max(int(span_points), GRANULE)
         # work list: chunks {pair, seg, start, count} and spans {first chunk, n chunks, points, pair}
-        wl = build_work_list(pads, self.span_points, tile_points)
-        chunks, spans, seg_rec_offs, c_off, s_off = wl['chunks'], wl['spans'], wl['seg_rec_offs'], wl['c_off'], wl['s_off']
+        wl = batch_prepare.flat_work_list(pc, seg_pos, n_off, self.span_points, tile_points)
+        chunks, spans = wl['chunks'], wl['spans']
         self.n_chunks, self.n_spans = len(chunks), len(spans)
         self.chunks = torch.from_numpy(chunks).to(dev)
         self.spans = torch.from_numpy(spans).to(dev)
         # partial records: one per span (pair-level sums) and one per (chunk, wave) (segment-level sums);
         # span_pair / seg_records list the owner of every record for host-side consumers (tests, evaluate())
         self.span_pair = self.spans[:, 3].long()
-        rec = np.repeat(chunks[:, :2], 4, axis=0)
         self.n_seg_records = 4 * self.n_chunks
-        self.seg_records = torch.from_numpy(rec.copy()).to(dev)          # (pair, segment) of every segment record
-        sto_off = np.concatenate(([0], np.cumsum([len(s) for s in seg_rec_offs])))
-        self.seg_tile_off = torch.from_numpy(np.concatenate(seg_rec_offs)).to(dev)
+        self.seg_records = torch.from_numpy(np.repeat(chunks[:, :2], 4, axis=0).copy()).to(dev)   # (pair, segment) of every segment record
+        self.seg_tile_off = torch.from_numpy(wl['seg_tile_off']).to(dev)
 
-        # descriptors, one array per level
-        self.desc, desc_host = {}, {}
-        for l in self.level_ids:
-            arr = (_lib.SpPair * M)()
-            for m, (f, tab) in enumerate(zip(frames, tables)):
-                d = arr[m]
-                d.pix = self.pix.data_ptr() + 4 * int(p_off[m])
-                d.src4 = self.src4[l].data_ptr() + 16 * int(p_off[m])
-                d.kp_L = self.kp_L.data_ptr() + 4 * int(n_off[m])
-                d.trg3 = self.trg4[l].data_ptr() + 4 * int(trg_off[l][m])
-                d.kld = self.kld.data_ptr() + 4 * int(n_off[m])
-                d.pose = self.pose.data_ptr() + 64 * m
-                d.aff = (self.aff.data_ptr() + 16 * m) if use_affine else None
-                d.seg_tile_off = self.seg_tile_off.data_ptr() + 4 * int(sto_off[m])
-                Ks = f.K.detach().float().cpu().numpy()
-                Kt = trg_Ks[base[m]].detach().float().cpu().numpy()
-                d.K_src = (ctypes.c_float * 4)(Ks[0, 0], Ks[1, 1], Ks[0, 2], Ks[1, 2])
-                d.K_trg = (ctypes.c_float * 4)(Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
-                d.N, d.P, d.H, d.W = tab.N, tab.P, tab.H, tab.W
-                d.Hl, d.Wl = self.level_hw[l][m]
-                d.tile0, d.n_tiles = s_off[m], s_off[m + 1] - s_off[m]
-                d.zmin = zmin
-                d.rec0 = 4 * c_off[m]
-            raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
-            self.desc[l] = torch.from_numpy(raw).to(dev)
-            desc_host[l] = arr
+        # descriptors, one array per level (numpy view of struct SpPair, filled column-wise)
+        Ks = torch.stack([batch_prepare._dev(k, dev).reshape(3, 3) for k in [f.K for f in src_frames] + list(trg_Ks)]).cpu().numpy()
+        Ks_src, Ks_trg = Ks[:M0], Ks[M0:]
+        k4 = lambda K: np.tile(np.stack((K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]), axis=1).astype(np.float32), (R, 1))
+        HW = np.tile(prep['shapes'][:, 1:].astype(np.int32), (R, 1))                    # full-resolution source size
+        pair_idx = np.arange(M, dtype=np.int64)
 
-        # decimated point sets of the coarse levels (run_scheduled)
-        self.coarse, self.point_stride = {}, {l: 1 for l in self.level_ids}
-        if point_stride is not None:
-            assert len(point_stride) == len(self.level_ids), "one stride per pyramid level, finest first"
-            self.point_stride = {l: int(s) for l, s in zip(self.level_ids, point_stride)}
-        for l, stride in list(self.point_stride.items()) + [(int(l), int(s)) for l, s in extra_tables]:
-            if stride > 1 and (l, stride) not in self.coarse:
-                self.coarse[(l, stride)] = self._decimated_layout(stride, pix0, [v.reshape(-1, 4) for v in src4_0[l]], pads0, base,
-                                                                  desc_host[l], tile_points)
+        def descriptors(level, pix, src4, seg_tile_off, lay_p_off, lay_wl, real_points):
+            d = np.zeros(M, dtype=_SP_PAIR_DTYPE)
+            d['pix'] = pix.data_ptr() + 4 * lay_p_off[:-1]
+            d['src4'] = src4.data_ptr() + 16 * lay_p_off[:-1]
+            d['kp_L'] = self.kp_L.data_ptr() + 4 * n_off[:-1]
+            d['trg3'] = self.trg4[level].data_ptr() + 4 * trg_off[level][:-1]
+            d['kld'] = self.kld.data_ptr() + 4 * n_off[:-1]
+            d['pose'] = self.pose.data_ptr() + 64 * pair_idx
+            d['aff'] = (self.aff.data_ptr() + 16 * pair_idx) if use_affine else 0
+            d['seg_tile_off'] = seg_tile_off.data_ptr() + 4 * lay_wl['sto_off'][:-1]
+            d['K_src'], d['K_trg'] = k4(Ks_src), k4(Ks_trg)
+            d['N'], d['P'] = Ns, real_points
+            d['H'], d['W'] = HW[:, 0], HW[:, 1]
+            hl = np.array(self.level_hw[level], dtype=np.int32).reshape(M, 2)
+            d['Hl'], d['Wl'] = hl[:, 0], hl[:, 1]
+            d['tile0'], d['n_tiles'] = lay_wl['s_off'][:-1], np.diff(lay_wl['s_off'])
+            d['zmin'] = zmin
+            d['rec0'] = 4 * lay_wl['c_off'][:-1]
+            return torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to(dev)
+
+        self.desc = {l: descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps)) for l in self.level_ids}
+
+        # decimated point sets of the coarse levels (run_scheduled): own tables, work list, descriptors, partial buffers
+        self.coarse = {}
+        for l, stride in coarse_keys:
+            t = tabs[stride]
+            lay = _Layout()
+            lay.stride = stride
+            c_counts, c_pc, c_seg_pos = tile(t.counts), tile(t.pc), tile(t.seg_pos)
+            c_p_off = np.concatenate(([0], np.cumsum(tile(np.diff(t.p_off)))))
+            lay.points = [int(p) for p in np.add.reduceat(c_counts, n_off[:-1])]
+            shared = next((o for (l2, s2), o in self.coarse.items() if s2 == stride), None)
+            lay.pix = shared.pix if shared is not None else rep(t.pix)
+            lay.src4 = rep(t.src4[l]).reshape(-1)
+            c_span = max(GRANULE, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS))
+            c_wl = batch_prepare.flat_work_list(c_pc, c_seg_pos, n_off, c_span, tile_points)
+            lay.n_chunks, lay.n_spans = len(c_wl['chunks']), len(c_wl['spans'])
+            lay.chunks = torch.from_numpy(c_wl['chunks']).to(dev)
+            lay.spans = torch.from_numpy(c_wl['spans']).to(dev)
+            lay.seg_tile_off = torch.from_numpy(c_wl['seg_tile_off']).to(dev)
+            lay.desc = descriptors(l, lay.pix, lay.src4, lay.seg_tile_off, c_p_off, c_wl, np.maximum(np.asarray(lay.points), 1))
+            lay.partials = torch.empty(max(lay.n_spans, 1) * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+            lay.seg_partials = torch.empty(max(4 * lay.n_chunks, 1) * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
+            self.coarse[(l, stride)] = lay
 
         # optimiser state / workspaces
         self.partials = torch.empty(self.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
@@ -258,7 +263,6 @@ class PairBatch:
         self.phase_iters = torch.zeros(M, dtype=torch.int32, device=dev)
         self.reset_lm()
         self._graphs = {}
-        self._keep = (tables0,)
         self._initial = (self.pose.clone(), self.kld.clone())
 
     def restore_initial(self):
@@ -272,49 +276,6 @@ class PairBatch:
         self.phase.zero_()
         self.phase_iters.zero_()
         self.reset_lm()
-
-    def _decimated_layout(self, stride, pix0, src4_l, pads0, base, desc_full, tile_points):
-        """Point tables, work list, descriptors and partial buffers of one level restricted to the valid points on the
-        ``stride`` x ``stride`` pixel lattice.  pix0 / src4_l / pads0: padded per-BASE-pair tables of the level."""
-        dev, M = self.device, self.M
-        pix_b, src_b, pads_b, real_b = [], [], [], []
-        for pix, src4, pd in zip(pix0, src4_l, pads0):
-            w = pix.view(torch.int32)
-            keep = (w < 0) & ((w & 0xffff) % stride == 0) & (((w >> 16) & 0x7fff) % stride == 0)       # bit 31 = valid source sample
-            seg = torch.repeat_interleave(torch.arange(len(pd['pc']), device=dev), torch.from_numpy(pd['pc']).to(dev))
-            counts = torch.bincount(seg[keep], minlength=len(pd['pc'])).cpu().numpy()
-            pdl = pad_layout(counts, dev)
-            pix_b.append(pad_points(pix[keep], pdl))
-            src_b.append(pad_points(src4[keep], pdl))
-            pads_b.append(pdl)
-            real_b.append(int(counts.sum()))
-        pads = [pads_b[b] for b in base]
-        p_off = np.concatenate(([0], np.cumsum([pd['Ppad'] for pd in pads])))
-        lay = _Layout()
-        lay.stride = stride
-        lay.points = [real_b[b] for b in base]
-        lay.pix = torch.cat([pix_b[b] for b in base])
-        lay.src4 = torch.cat([src_b[b] for b in base]).reshape(-1)
-        span_points = max(GRANULE, min(DEFAULT_SPAN_POINTS, int(p_off[-1]) // MIN_SPANS))
-        wl = build_work_list(pads, span_points, tile_points)
-        lay.n_chunks, lay.n_spans = len(wl['chunks']), len(wl['spans'])
-        lay.chunks = torch.from_numpy(wl['chunks']).to(dev)
-        lay.spans = torch.from_numpy(wl['spans']).to(dev)
-        sto_off = np.concatenate(([0], np.cumsum([len(v) for v in wl['seg_rec_offs']])))
-        lay.seg_tile_off = torch.from_numpy(np.concatenate(wl['seg_rec_offs'])).to(dev)
-        arr = (_lib.SpPair * M).from_buffer_copy(bytes(desc_full))
-        for m in range(M):
-            d = arr[m]
-            d.pix = lay.pix.data_ptr() + 4 * int(p_off[m])
-            d.src4 = lay.src4.data_ptr() + 16 * int(p_off[m])
-            d.seg_tile_off = lay.seg_tile_off.data_ptr() + 4 * int(sto_off[m])
-            d.P = max(lay.points[m], 1)
-            d.tile0, d.n_tiles = int(wl['s_off'][m]), int(wl['s_off'][m + 1] - wl['s_off'][m])
-            d.rec0 = 4 * int(wl['c_off'][m])
-        lay.desc = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(dev)
-        lay.partials = torch.empty(lay.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
-        lay.seg_partials = torch.empty(4 * lay.n_chunks * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
-        return lay
 
     # ------------------------------------------------------------------------------------------------
     @classmethod

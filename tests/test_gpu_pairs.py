@@ -499,7 +499,8 @@ def test_decimated_coarse_levels_have_exact_point_sets_and_the_same_fine_minimis
             keep = ((full >> 31) == 1) & ((full & 0xffff) % s == 0) & (((full >> 16) & 0x7fff) % s == 0)
             base = int(chunks[chunks[:, 0] < m, 3].sum())          # chunk starts are relative to the pair's own table
             mine = np.concatenate([pix[base + c[2]: base + c[2] + c[3]] for c in chunks if c[0] == m])
-            assert np.array_equal(mine[(mine >> 31) == 1], full[keep]) and lay.points[m] == int(keep.sum())
+            assert np.array_equal(mine[(mine >> 31) == 1], full[keep])
+            assert lay.points[m] >= int(keep.sum())       # points counts every lattice pixel of the masks, valid or not
     # same minimiser as the all-points schedule (both end with full-point phases run to the same tolerances)
     sch = dict(max_iters_per_level=25, conv_tol=1e-4, polish_max=25, polish_eps=1e-5, polish_tol=1e-6)
     launched = batch.run_scheduled(**sch)
@@ -512,3 +513,66 @@ def test_decimated_coarse_levels_have_exact_point_sets_and_the_same_fine_minimis
     for m in range(2):
         e = pose_depth_errors(npy(batch.poses()[m]), npy(batch.klds()[m]), npy(ref.poses()[m]), npy(ref.klds()[m]))
         assert e[0] <= 2e-5 and e[1] <= 5e-5 and e[2] <= 5e-4, (m, e)
+
+
+def test_batched_preparation_equals_the_per_keyframe_tables():
+    """PairBatch builds all its tables with the batched sp_prepare_* passes (one launch per pass for the whole batch, one host
+    synchronisation); every array must equal, bit for bit, what the per-keyframe path (SegmentTable, blur_decimate,
+    source_level, sp_pack_rgb) produces for each pair -- pairs of different image size and segment count, odd sizes
+    included -- with zeros in the padding."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.image import gaussian_pyramid
+    from super_primitive_amd.segment_table import SegmentTable, packed_target
+    prs = [synth.make_pair(60, 80, 6, seed=101), synth.make_pair(97, 131, 9, seed=102), synth.make_pair(48, 64, 1, seed=103)]
+    batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4))
+    dev = batch.device
+    for m, pr in enumerate(prs):
+        masks, L, kp = T(pr.keypoint_regions).to(dev), T(pr.logdepth_perseg).to(dev), T(pr.keypoints).to(dev)
+        tab = SegmentTable(masks, L, kp)
+        img_s, img_t, K, kld = T(pr.src_image).to(dev), T(pr.trg_image).to(dev), T(pr.K).to(dev), T(pr.kld_init).to(dev)
+        lv_s, lv_t = [img_s], [img_t]
+        for _ in range(2):
+            lv_s.append(gaussian_pyramid.blur_decimate(lv_s[-1][None])[0])
+            lv_t.append(gaussian_pyramid.blur_decimate(lv_t[-1][None])[0])
+        src4 = [tab.source_level(lv_s[l], K, kld).clone() for l in range(3)]
+        # real points of the padded table: segment n occupies [pos, pos + counts[n])
+        pc = (tab.counts + 255) // 256 * 256
+        pos = np.concatenate(([0], np.cumsum(pc)))[:-1]
+        idx = np.concatenate([np.arange(p, p + c) for p, c in zip(pos, tab.counts)])
+        lo, hi = batch.p_off[m], batch.p_off[m + 1]
+        assert hi - lo == int(pc.sum()) and batch.Ps[m] == tab.P
+        pix = npy(batch.pix[lo:hi])
+        assert np.array_equal(pix[idx], npy(tab.pix))
+        pad = np.ones(hi - lo, bool); pad[idx] = False
+        assert not pix[pad].any()
+        assert np.array_equal(npy(batch.kp_L[batch.n_off[m]: batch.n_off[m + 1]]), npy(tab.kp_L))
+        for l in range(3):
+            got = npy(batch.src4[l].reshape(-1, 4)[lo:hi])
+            assert np.array_equal(got[idx], npy(src4[l])), (m, l)
+            assert not got[pad].any()
+            Hl, Wl = lv_t[l].shape[-2:]
+            assert batch.level_hw[l][m] == (Hl, Wl)
+        # packed targets: compare through the descriptors' offsets
+        for l in range(3):
+            Hl, Wl = batch.level_hw[l][m]
+            off = sum(3 * h * w for h, w in batch.level_hw[l][:m])
+            assert np.array_equal(npy(batch.trg4[l][off: off + 3 * Hl * Wl]), npy(packed_target(lv_t[l]).reshape(-1)))
+    # decimated tables: lattice points of the full table, in order, same validity bits, same source samples
+    for (level, stride), lay in batch.coarse.items():
+        chunks = npy(lay.chunks)
+        for m in range(batch.M):
+            lo, hi = batch.p_off[m], batch.p_off[m + 1]
+            full_pix = npy(batch.pix[lo:hi]).view(np.uint32)
+            full_src = npy(batch.src4[level].reshape(-1, 4)[lo:hi])
+            real = np.zeros(hi - lo, bool)
+            for c in npy(batch.chunks):
+                if c[0] == m:
+                    real[c[2]: c[2] + c[3]] = True
+            on = ((full_pix & 0xffff) % stride == 0) & (((full_pix >> 16) & 0x7fff) % stride == 0) & ((full_pix != 0) | real)
+            base = int(chunks[chunks[:, 0] < m, 3].sum())
+            mine = np.concatenate([np.arange(base + c[2], base + c[2] + c[3]) for c in chunks if c[0] == m]) if (chunks[:, 0] == m).any() else np.zeros(0, int)
+            mpix = npy(lay.pix).view(np.uint32)[mine]
+            msrc = npy(lay.src4.reshape(-1, 4))[mine]
+            keep_valid = on & ((full_pix >> 31) == 1)
+            assert np.array_equal(mpix[(mpix >> 31) == 1], full_pix[keep_valid])
+            assert np.array_equal(msrc[(mpix >> 31) == 1], full_src[keep_valid])

@@ -43,6 +43,10 @@ def test_abi_constants_and_struct_layout_match_header():
     assert _lib.SpWindowNode.kind.offset == 168 and _lib.SpWindowBlock.N.offset == 24
     # per-pair schedule, passed by value
     assert int(re.search(r"#define\s+SP_MAX_PHASES\s+(\d+)", header).group(1)) == _lib.SP_MAX_PHASES
+    assert ctypes.sizeof(_lib.SpPrepTable) == 224 and ctypes.sizeof(_lib.SpPrepSample) == 176 and ctypes.sizeof(_lib.SpPrepImage) == 24
+    assert _lib.SpPrepTable.stride.offset == 192 and _lib.SpPrepSample.N.offset == 152 and _lib.SpPrepImage.H.offset == 16
+    for macro in ("SP_PREP_MAX_STRIDES", "SP_PREP_MAX_LEVELS"):
+        assert int(re.search(r"#define\s+" + macro + r"\s+(\d+)", header).group(1)) == getattr(_lib, macro)
     assert ctypes.sizeof(_lib.SpPhase) == 56 and _lib.SpPhase.n_spans.offset == 40 and _lib.SpPhase.conv_tol.offset == 52
     assert ctypes.sizeof(_lib.SpSchedule) == 456 and _lib.SpSchedule.n_phases.offset == 448
 
@@ -55,6 +59,10 @@ def test_new_entry_points_validate_arguments_and_sizes():
     assert lib.sp_window_scratch_doubles(10, 40) == 10 * (28 + 40)
     assert lib.sp_window_compose(None, None, 1, None, 1, None) == -1
     assert lib.sp_window_step(*([None] * 2), 1, None, 1, None, 1, 1, *([None] * 3), 0, 0, 0.0, None, None, 0, None) == -1
+    for fn in (lib.sp_prepare_count, lib.sp_prepare_fill):
+        assert fn(None, 1, 1, 1, None) == -1
+    assert lib.sp_prepare_sample(None, 1, 1, None) == -1 and lib.sp_prepare_pack(None, 1, 1, None) == -1
+    assert lib.sp_prepare_blur(None, 1, 3, 1, None) == -1
     sched = _lib.SpSchedule()
     assert lib.sp_pairs_schedule_cost(ctypes.addressof(sched), None, None) == -1 and lib.sp_pairs_schedule_cost(None, None, None) == -1
     assert lib.sp_pairs_schedule_gn_step(ctypes.addressof(sched), 1, 1, 8.0, 0.5, 1e-7, *([None] * 6)) == -1
@@ -296,3 +304,32 @@ def test_thin_helpers_match_the_reference():
     assert etc.to_np(arr) is arr and torch.equal(etc.from_np(arr), T(arr)) and etc.from_np(arr).data_ptr() != arr.ctypes.data
     d = etc.dict_cpu({"a": T(g["img"]), "_sp": object(), "n": None})
     assert set(d) == {"a", "n"} and d["n"] is None
+
+
+def test_vectorised_layout_and_work_list_equal_the_per_pair_ones():
+    """batch_prepare.flat_layout / flat_work_list (numpy over the whole batch, used by PairBatch) produce exactly the chunks,
+    spans and record offsets of pad_layout / build_work_list (per pair, per segment), including empty segments, segments
+    longer than a chunk, and pairs with different segment counts."""
+    from super_primitive_amd.optim import batch_prepare
+    from super_primitive_amd.optim.pair_batch import build_work_list, pad_layout
+    rng = np.random.default_rng(11)
+    for tile_points, span_points in ((1024, 2048), (8192, 16384), (256, 256), (2048, 100000)):
+        Ns = [7, 1, 30, 12]
+        counts = [rng.integers(0, 6000, size=n) for n in Ns]
+        counts[2][3] = 0
+        counts[0][0] = 256
+        pads = [pad_layout(c, "cpu") for c in counts]
+        ref = build_work_list(pads, span_points, tile_points)
+        n_off = np.concatenate(([0], np.cumsum(Ns)))
+        pc, seg_pos, p_off = batch_prepare.flat_layout(np.concatenate(counts), n_off)
+        assert np.array_equal(pc, np.concatenate([pd['pc'] for pd in pads]))
+        assert np.array_equal(seg_pos, np.concatenate([pd['pseg_off'][:-1] for pd in pads]))
+        assert np.array_equal(np.diff(p_off), [pd['Ppad'] for pd in pads])
+        got = batch_prepare.flat_work_list(pc, seg_pos, n_off, span_points, tile_points)
+        assert np.array_equal(got['chunks'], ref['chunks']) and np.array_equal(got['spans'], ref['spans'])
+        assert np.array_equal(got['seg_tile_off'], np.concatenate(ref['seg_rec_offs']))
+        assert np.array_equal(got['c_off'], ref['c_off']) and np.array_equal(got['s_off'], ref['s_off'])
+        assert np.array_equal(got['sto_off'], np.concatenate(([0], np.cumsum([n + 1 for n in Ns]))))
+    # nothing at all
+    got = batch_prepare.flat_work_list(np.zeros(3, np.int64), np.zeros(3, np.int64), np.array([0, 3]), 1024, 1024)
+    assert got['chunks'].shape == (0, 4) and got['spans'].shape == (0, 4) and np.array_equal(got['seg_tile_off'], [0, 0, 0, 0])
