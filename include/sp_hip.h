@@ -91,12 +91,14 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
  * A "table" is the compacted point set of one keyframe on a pixel lattice: stride 1 = every mask pixel (the tables above),
  * stride s > 1 = the mask pixels whose row and column are multiples of s (coarse levels of per-pair schedules).
  *   sp_prepare_count : row_counts (scratch, N*H) and counts[N] of every lattice of every keyframe   [masks read once]
- *   -- host: reads counts, lays the segments out (padded runs), allocates and ZEROES pix / baseL, uploads seg_off --
+ *   -- host: reads counts, lays the segments out (runs padded to multiples of 256), allocates pix / baseL, uploads seg_off --
  *   sp_prepare_fill  : pix / baseL at seg_off[n] + rank inside the segment; kp_L[N] where kp_L != NULL
  *   sp_prepare_blur  : one pyramid step (sp_blur_decimate) of every job image
  *   sp_prepare_pack  : planar (3,H,W) -> HWC3 of every job image
- *   sp_prepare_sample: sp_table_sample_source of every job at all its levels; positions beyond counts[n] of a segment's run
- *                      are padding and are left untouched (zero = invalid point)
+ *   sp_prepare_sample: sp_table_sample_source of every job at all its levels, and the source-validity bit of pix.  Every
+ *                      segment's run must start at a multiple of 256 (the padded layout of the many-pairs work list);
+ *                      positions beyond counts[n] of a run are padding and are written as {pix 0, src4 0} = invalid points,
+ *                      so pix / src4 need no prior clearing
  * ---------------------------------------------------------------------------------------------------- */
 #define SP_PREP_MAX_STRIDES 4
 #define SP_PREP_MAX_LEVELS 4

@@ -137,28 +137,32 @@ __device__ __forceinline__ float planar_tap(const float* __restrict__ img, int W
     return (x >= 0 && x < Wl && y >= 0 && y < Hl) ? img[(size_t)y * Wl + x] : 0.f;
 }
 
-// Source-side sampling exactly as the reference does it (get_pixels on the source's own points,
-// core/dense_optim.py:143-162,315-317): IEEE divisions, same operation order, so the validity bit matches.
-__device__ __forceinline__ void sample_point(uint32_t* __restrict__ pix, const float* __restrict__ baseL, int i, int n,
-                                             const float* __restrict__ kp_L, const float* __restrict__ kld, int H, int W,
-                                             const float* __restrict__ img, int Hl, int Wl, const float* __restrict__ K9,
-                                             float4* __restrict__ src4, int set_validity) {
+struct SourceGeom { float xn, yn, L; bool ok; uint32_t pw; };
+
+// geometry of a table point in its own frame: normalised image coordinates and the validity of the sample
+__device__ __forceinline__ SourceGeom source_geometry(uint32_t pix_word, float L, float shift, int H, int W, const float* __restrict__ K9) {
     const float fx = K9[0], cx = K9[2], fy = K9[4], cy = K9[5];
-    const uint32_t pw = pix[i] & 0x7fffffffu;
-    const float col = (float)(pw & 0xffffu), row = (float)(pw >> 16);
-    const float L = baseL[i];
-    const float d = expf(L + (kld[n] - kp_L[n]));
+    SourceGeom g;
+    g.pw = pix_word & 0x7fffffffu;
+    g.L = L;
+    const float col = (float)(g.pw & 0xffffu), row = (float)(g.pw >> 16);
+    const float d = expf(L + shift);
     const float x = __fdiv_rn(__fmul_rn(__fsub_rn(col, cx), d), fx);
     const float y = __fdiv_rn(__fmul_rn(__fsub_rn(row, cy), d), fy);
     const float zinv = (fabsf(d) > 1e-6f) ? __fdiv_rn(1.0f, d) : 1e-6f;
     const float u = __fadd_rn(__fmul_rn(__fmul_rn(x, fx), zinv), cx);
     const float v = __fadd_rn(__fmul_rn(__fmul_rn(y, fy), zinv), cy);
     const float invW = __fdiv_rn(1.0f, (float)(W - 1)), invH = __fdiv_rn(1.0f, (float)(H - 1));
-    const float xn = __fsub_rn(__fmul_rn(__fmul_rn(2.f, u), invW), 1.f);
-    const float yn = __fsub_rn(__fmul_rn(__fmul_rn(2.f, v), invH), 1.f);
-    const bool ok = (fabsf(xn) <= 0.99f) && (fabsf(yn) <= 0.99f) && (d > 1e-7f);
-    const float ix = __fmul_rn(__fmul_rn(__fadd_rn(xn, 1.f), 0.5f), (float)(Wl - 1));
-    const float iy = __fmul_rn(__fmul_rn(__fadd_rn(yn, 1.f), 0.5f), (float)(Hl - 1));
+    g.xn = __fsub_rn(__fmul_rn(__fmul_rn(2.f, u), invW), 1.f);
+    g.yn = __fsub_rn(__fmul_rn(__fmul_rn(2.f, v), invH), 1.f);
+    g.ok = (fabsf(g.xn) <= 0.99f) && (fabsf(g.yn) <= 0.99f) && (d > 1e-7f);
+    return g;
+}
+
+// bilinear sample of one pyramid level at that position: {r, g, b, L}
+__device__ __forceinline__ float4 source_sample(const SourceGeom& g, const float* __restrict__ img, int Hl, int Wl) {
+    const float ix = __fmul_rn(__fmul_rn(__fadd_rn(g.xn, 1.f), 0.5f), (float)(Wl - 1));
+    const float iy = __fmul_rn(__fmul_rn(__fadd_rn(g.yn, 1.f), 0.5f), (float)(Hl - 1));
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const int x0 = (int)fx0, y0 = (int)fy0;
     const float wx = ix - fx0, wy = iy - fy0;
@@ -175,11 +179,21 @@ __device__ __forceinline__ void sample_point(uint32_t* __restrict__ pix, const f
         acc += se * (wx * wy);
         rgb[ch] = acc;
     }
-    src4[i] = make_float4(rgb[0], rgb[1], rgb[2], L);
-    // The validity bit is a property of the geometry grid (0.99 band on the point's own pixel; depth enters only
-    // through the last bit of the re-projection): it is written once, when the table is built, and is shared by all
-    // pyramid levels -- later level samplings leave pix untouched.
-    if (set_validity) pix[i] = pw | (ok ? 0x80000000u : 0u);
+    return make_float4(rgb[0], rgb[1], rgb[2], g.L);
+}
+
+// Source-side sampling exactly as the reference does it (get_pixels on the source's own points,
+// core/dense_optim.py:143-162,315-317): IEEE divisions, same operation order, so the validity bit matches.
+// The validity bit is a property of the geometry grid (0.99 band on the point's own pixel; depth enters only through the
+// last bit of the re-projection): it is written once, when the table is built, and is shared by all pyramid levels --
+// later level samplings leave pix untouched.
+__device__ __forceinline__ void sample_point(uint32_t* __restrict__ pix, const float* __restrict__ baseL, int i, int n,
+                                             const float* __restrict__ kp_L, const float* __restrict__ kld, int H, int W,
+                                             const float* __restrict__ img, int Hl, int Wl, const float* __restrict__ K9,
+                                             float4* __restrict__ src4, int set_validity) {
+    const SourceGeom g = source_geometry(pix[i], baseL[i], kld[n] - kp_L[n], H, W, K9);
+    src4[i] = source_sample(g, img, Hl, Wl);
+    if (set_validity) pix[i] = g.pw | (g.ok ? 0x80000000u : 0u);
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_sample_source(uint32_t* __restrict__ pix, const float* __restrict__ baseL,
@@ -249,40 +263,59 @@ __device__ __forceinline__ uint32_t lattice_bytes(int x0, int stride) {
     return sel;
 }
 
-// one wave per (segment,row), every lattice of the keyframe in the same pass over the mask row (read as 32-bit words
-// when the rows are word-aligned)
+// Every lattice of the keyframe in the same pass over the masks.  A wave takes SP_PREP_ROWS consecutive (segment,row)
+// rows; when the rows are word-aligned and at most 1024 pixels wide all their words are requested before any is counted
+// (a row is only 160 words at W = 640: one row per wave leaves the memory system idle and the dispatcher busy).
+#define SP_PREP_ROWS 4
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable* __restrict__ tables) {
     const SpPrepTable& t = tables[blockIdx.y];
-    const int row = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
-    if (row >= t.N * t.H) return;
+    const int rows = t.N * t.H;
+    const int row0 = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * SP_PREP_ROWS;
+    if (row0 >= rows) return;
     const int lane = threadIdx.x & 63;
-    const int r = row % t.H;
-    const uint8_t* m = t.masks + (size_t)row * t.W;
-    int c[SP_PREP_MAX_STRIDES] = {0, 0, 0, 0};
-    if ((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0) {
-        const uint32_t* mw = reinterpret_cast<const uint32_t*>(m);
-        for (int xw = lane; xw < (t.W >> 2); xw += 64) {
-            const uint32_t nz = nonzero_bytes(mw[xw]);
+    const int wpr = t.W >> 2;
+    // per-lane counts of SP_PREP_ROWS rows x SP_PREP_MAX_STRIDES lattices (exact in fp32: a row has at most 65535 pixels),
+    // reduced over the wave together (recursive halving: 17 cross-lane moves for the 16 values)
+    float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
 #pragma unroll
-            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
-                if (k < t.n_strides) c[k] += __popc(nz & lattice_bytes(4 * xw, t.stride[k]));
-        }
+    for (int i = 0; i < SP_PREP_ROWS * SP_PREP_MAX_STRIDES; ++i) acc[i] = 0.f;
+    if ((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0 && wpr <= 256) {
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks) + (size_t)row0 * wpr;
+        uint32_t w[SP_PREP_ROWS][4];
+#pragma unroll
+        for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xw = q * 64 + lane;
+                w[rr][q] = (row0 + rr < rows && xw < wpr) ? mw[(size_t)rr * wpr + xw] : 0u;
+            }
+#pragma unroll
+        for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t nz = nonzero_bytes(w[rr][q]);
+#pragma unroll
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                    if (k < t.n_strides) acc[rr * SP_PREP_MAX_STRIDES + k] += (float)__popc(nz & lattice_bytes(4 * (q * 64 + lane), t.stride[k]));
+            }
     } else {
-        for (int x = lane; x < t.W; x += 64) {
-            const bool on = m[x] != 0;
 #pragma unroll
-            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
-                if (k < t.n_strides) c[k] += (on && x % t.stride[k] == 0) ? 1 : 0;
+        for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
+            if (row0 + rr >= rows) break;
+            const uint8_t* m = t.masks + (size_t)(row0 + rr) * t.W;
+            for (int x = lane; x < t.W; x += 64) {
+                const bool on = m[x] != 0;
+#pragma unroll
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                    if (k < t.n_strides) acc[rr * SP_PREP_MAX_STRIDES + k] += (on && x % t.stride[k] == 0) ? 1.f : 0.f;
+            }
         }
     }
-#pragma unroll
-    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-        if (k >= t.n_strides) break;
-        int v = (r % t.stride[k] == 0) ? c[k] : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) t.row_counts[k][row] = v;
-    }
+    int pos;
+    bool ok;
+    wave_sum_to_lanes<SP_PREP_ROWS * SP_PREP_MAX_STRIDES>(acc, lane, pos, ok);
+    const int rr = pos / SP_PREP_MAX_STRIDES, k = pos % SP_PREP_MAX_STRIDES, row = row0 + rr;
+    if (ok && k < t.n_strides && row < rows) t.row_counts[k][row] = ((row % t.H) % t.stride[k] == 0) ? (int)acc[0] : 0;
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* __restrict__ tables) {
@@ -293,52 +326,61 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* _
     segment_row_scan(t.row_counts[k] + (size_t)blockIdx.x * t.H, t.H, t.counts[k] + blockIdx.x);
 }
 
-// one wave per (segment,row): ordered compaction of the row into every lattice's table.  Word path: a lane owns 4
-// consecutive pixels; its rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken
-// from three ballots of the count's bits.
+// Ordered compaction of (segment,row) rows into every lattice's table; a wave takes SP_PREP_ROWS consecutive rows and
+// skips the empty ones on their row count alone (a segment covers a small part of the image: most rows of its mask are
+// empty and are not read again).  Word path: a lane owns 4 consecutive pixels; its rank inside the row is the prefix sum
+// over lower lanes of their set-pixel counts (0..4), taken from three ballots of the count's bits.
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __restrict__ tables) {
     const SpPrepTable& t = tables[blockIdx.y];
-    const int row_id = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
-    if (row_id >= t.N * t.H) return;
+    const int rows = t.N * t.H;
+    const int row0 = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * SP_PREP_ROWS;
     const int lane = threadIdx.x & 63;
-    const int n = row_id / t.H, r = row_id - n * t.H;
-    const uint8_t* m = t.masks + (size_t)row_id * t.W;
-    const float* L = t.logdepth + (size_t)row_id * t.W;
-    if (!((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0)) {
-        for (int k = 0; k < t.n_strides; ++k)
-            fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
-        return;
-    }
-    int base[SP_PREP_MAX_STRIDES];
-    bool act[SP_PREP_MAX_STRIDES];
-#pragma unroll
-    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-        act[k] = k < t.n_strides && r % t.stride[k] == 0;
-        base[k] = act[k] ? t.seg_off[k][n] + t.row_counts[k][row_id] : 0;
-    }
-    const uint32_t* mw = reinterpret_cast<const uint32_t*>(m);
+    const bool words = (t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0;
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int w0 = 0; w0 < (t.W >> 2); w0 += 64) {
-        const int xw = w0 + lane;
-        const uint32_t nz = xw < (t.W >> 2) ? nonzero_bytes(mw[xw]) : 0u;
-        float Lv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) Lv[j] = ((nz >> (8 * j + 7)) & 1u) ? L[4 * xw + j] : 0.f;
+    for (int row_id = row0; row_id < min(row0 + SP_PREP_ROWS, rows); ++row_id) {
+        const int n = row_id / t.H, r = row_id - n * t.H;
+        if (t.stride[0] == 1) {          // lattice 0 holds every mask pixel: its row count says whether the row is empty
+            const int32_t* rc = t.row_counts[0];
+            const int next = (r + 1 < t.H) ? rc[row_id + 1] : t.counts[0][n];
+            if (next == rc[row_id]) continue;
+        }
+        if (!words) {
+            for (int k = 0; k < t.n_strides; ++k)
+                fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
+            continue;
+        }
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks + (size_t)row_id * t.W);
+        const float* L = t.logdepth + (size_t)row_id * t.W;
+        int base[SP_PREP_MAX_STRIDES];
+        bool act[SP_PREP_MAX_STRIDES];
 #pragma unroll
         for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-            if (!act[k]) continue;
-            const uint32_t sel = nz & lattice_bytes(4 * xw, t.stride[k]);
-            const int cnt = __popc(sel);
-            const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
-            int pos = base[k] + __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+            act[k] = k < t.n_strides && r % t.stride[k] == 0;
+            base[k] = act[k] ? t.seg_off[k][n] + t.row_counts[k][row_id] : 0;
+        }
+        for (int w0 = 0; w0 < (t.W >> 2); w0 += 64) {
+            const int xw = w0 + lane;
+            const uint32_t nz = xw < (t.W >> 2) ? nonzero_bytes(mw[xw]) : 0u;
+            if (__ballot(nz != 0u) == 0ull) continue;
+            float Lv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if ((sel >> (8 * j + 7)) & 1u) {
-                    t.pix[k][pos] = ((uint32_t)r << 16) | (uint32_t)(4 * xw + j);
-                    t.baseL[k][pos] = Lv[j];
-                    ++pos;
-                }
-            base[k] += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+            for (int j = 0; j < 4; ++j) Lv[j] = ((nz >> (8 * j + 7)) & 1u) ? L[4 * xw + j] : 0.f;
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+                if (!act[k]) continue;
+                const uint32_t sel = nz & lattice_bytes(4 * xw, t.stride[k]);
+                const int cnt = __popc(sel);
+                const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
+                int pos = base[k] + __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if ((sel >> (8 * j + 7)) & 1u) {
+                        t.pix[k][pos] = ((uint32_t)r << 16) | (uint32_t)(4 * xw + j);
+                        t.baseL[k][pos] = Lv[j];
+                        ++pos;
+                    }
+                base[k] += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+            }
         }
     }
 }
@@ -349,16 +391,26 @@ __global__ void k_prep_keypoint_L(const SpPrepTable* __restrict__ tables) {
     if (n < t.N && t.kp_L) keypoint_L(t.logdepth, t.keypoints, n, t.H, t.W, t.kp_L);
 }
 
-// every pyramid level of one table in one pass: segment search, depth and validity once per point
+// every pyramid level of one table in one pass: segment search, depth and validity once per point.  Padding positions of a
+// segment's run are written as {pix 0, src4 0} = invalid points (the arrays need no prior clearing).
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs) {
     const SpPrepSample& j = jobs[blockIdx.y];
-    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    const int i0 = blockIdx.x * SP_BLOCK;
+    if (i0 >= j.P) return;
+    // segment runs are padded to multiples of SP_BLOCK: the whole block lies in one segment -> one (scalar) search
+    const int n = segment_of(j.seg_off, j.N, i0);
+    const int first = j.seg_off[n], count = j.counts[n];
+    const float shift = j.kld[n] - j.kp_L[n];
+    const int i = i0 + threadIdx.x;
     if (i >= j.P) return;
-    const int n = segment_of(j.seg_off, j.N, i);
-    if (i - j.seg_off[n] >= j.counts[n]) return;          // padding of the segment's run: stays {pix 0, src4 0}
-    for (int l = 0; l < j.n_levels; ++l)
-        sample_point(j.pix, j.baseL, i, n, j.kp_L, j.kld, j.H, j.W, j.image[l], j.Hl[l], j.Wl[l], j.K,
-                     reinterpret_cast<float4*>(j.src4[l]), l == 0 ? 1 : 0);
+    if (i - first >= count) {
+        j.pix[i] = 0u;
+        for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const SourceGeom g = source_geometry(j.pix[i], j.baseL[i], shift, j.H, j.W, j.K);
+    for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = source_sample(g, j.image[l], j.Hl[l], j.Wl[l]);
+    j.pix[i] = g.pw | (g.ok ? 0x80000000u : 0u);
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_blur(const SpPrepImage* __restrict__ jobs) {
@@ -447,7 +499,8 @@ static int check_grid(long x, long y) { return (x <= 0 || y <= 0 || y > 65535) ?
 int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_prep_row_counts, dim3((max_rows + SP_WAVES - 1) / SP_WAVES, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    const int per_block = SP_WAVES * SP_PREP_ROWS;
+    hipLaunchKernelGGL(k_prep_row_counts, dim3((max_rows + per_block - 1) / per_block, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_row_scan, dim3(max_N, n_tables, SP_PREP_MAX_STRIDES), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
@@ -457,7 +510,8 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
 int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_prep_fill, dim3((max_rows + SP_WAVES - 1) / SP_WAVES, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    const int per_block = SP_WAVES * SP_PREP_ROWS;
+    hipLaunchKernelGGL(k_prep_fill, dim3((max_rows + per_block - 1) / per_block, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_keypoint_L, dim3((max_N + 63) / 64, n_tables), dim3(64), 0, s, tables);
     SP_CHECK_LAUNCH();

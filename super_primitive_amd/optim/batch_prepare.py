@@ -99,9 +99,28 @@ def _ptrs(tensors):
     return np.array([t.data_ptr() for t in tensors], dtype=np.uint64)
 
 
-def _records(arr, dev):
-    """numpy structured array of job records -> device bytes."""
-    return torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(dev)
+_TORCH_OF = {np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}
+
+
+def stage(arrays, dev):
+    """Host arrays -> device tensors through ONE pinned staging buffer and one asynchronous copy (a copy from pageable memory
+    would make the host wait for everything already enqueued on the stream).  int32 / float32 arrays come back typed and
+    shaped, anything else (job records) as bytes; all are views of one device buffer."""
+    offs, total = [], 0
+    for a in arrays:
+        offs.append(total)
+        total += (a.nbytes + 15) // 16 * 16
+    host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
+    hv = host.numpy()
+    for a, o in zip(arrays, offs):
+        hv[o: o + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    d = host.to(dev, non_blocking=True)
+    out = []
+    for a, o in zip(arrays, offs):
+        v = d[o: o + a.nbytes]
+        tt = _TORCH_OF.get(a.dtype)
+        out.append(v.view(tt).reshape(a.shape) if tt is not None and tt != torch.uint8 else v)
+    return out
 
 
 def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
@@ -136,7 +155,7 @@ def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
     if len(level_ids) > _lib.SP_PREP_MAX_LEVELS:
         raise ValueError(f"{len(level_ids)} pyramid levels exceed SP_PREP_MAX_LEVELS = {_lib.SP_PREP_MAX_LEVELS}")
 
-    # ---- pass 1: counts of every lattice of every keyframe (masks read once), one copy back ----
+    # ---- pass 1: counts of every lattice of every keyframe (masks read once); the copy back is asynchronous ----
     rows = Ns * Hs
     rc_off = np.concatenate(([0], np.cumsum(rows)))
     row_counts = torch.empty(nS * int(rc_off[-1]), dtype=torch.int32, device=dev)
@@ -149,11 +168,48 @@ def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
         recs['row_counts'][:, si] = row_counts.data_ptr() + 4 * (si * int(rc_off[-1]) + rc_off[:-1])
         recs['counts'][:, si] = counts_d.data_ptr() + 4 * (si * S + n_off[:-1])
     max_rows, max_N = int(rows.max()), int(Ns.max())
-    recs_d = _records(recs, dev)
-    _lib.check(lib.sp_prepare_count(_lib.ptr(recs_d), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
-    counts_h = counts_d.cpu().numpy().reshape(nS, S)                            # the one host synchronisation of the set-up
+
+    # image pyramids of both frames and packed targets: independent of the counts, enqueued before the host waits for them
+    max_level = max(level_ids)
+    pyramid, blur_jobs = [], []
+    ptr_lv = {0: (_ptrs(simg), _ptrs(timg))}                                     # level -> (source, target) image pointers
+    hw = {0: np.stack((Hs, Ws), axis=1)}
+    for l in range(1, max_level + 1):
+        hw[l] = (hw[l - 1] + 1) // 2
+        sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
+        off = np.concatenate(([0], np.cumsum(np.tile(sizes, 2))))
+        buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
+        jobs = np.zeros(2 * M0, dtype=_IMAGE_DT)
+        jobs['inp'] = np.concatenate(ptr_lv[l - 1])
+        jobs['out'] = buf.data_ptr() + 4 * off[:-1]
+        jobs['H'], jobs['W'] = np.tile(hw[l - 1][:, 0], 2), np.tile(hw[l - 1][:, 1], 2)
+        ptr_lv[l] = (jobs['out'][:M0].copy(), jobs['out'][M0:].copy())
+        blur_jobs.append(jobs)
+        pyramid.append(buf)                  # read by later launches: must not return to the allocator before they are enqueued
+    trg = {}
+    pack_jobs = np.zeros(len(level_ids) * M0, dtype=_IMAGE_DT)
+    for li, l in enumerate(level_ids):
+        sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
+        off = np.concatenate(([0], np.cumsum(sizes)))
+        buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
+        jb = pack_jobs[li * M0: (li + 1) * M0]
+        jb['inp'], jb['out'] = ptr_lv[l][1], buf.data_ptr() + 4 * off[:-1]
+        jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
+        trg[l] = (buf, off, [(int(h), int(w)) for h, w in hw[l]])
+    staged = stage([recs, pack_jobs] + blur_jobs, dev)
+    _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
+    counts_pinned = torch.empty(nS * S, dtype=torch.int32, pin_memory=True)
+    counts_pinned.copy_(counts_d, non_blocking=True)
+    counts_ready = torch.cuda.Event()
+    counts_ready.record()
+    for l in range(1, max_level + 1):
+        _lib.check(lib.sp_prepare_blur(_lib.ptr(staged[1 + l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
+    _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[1]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
+               "sp_prepare_pack")
 
     # ---- host: padded layouts; device: fill straight into them ----
+    counts_ready.synchronize()                    # the one host synchronisation of the set-up (the pyramids keep the GPU busy)
+    counts_h = counts_pinned.numpy().reshape(nS, S)
     tabs = {}
     kp_L = torch.empty(S, dtype=torch.float32, device=dev)
     recs['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
@@ -166,49 +222,18 @@ def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
         if s == 1 and (np.add.reduceat(t.counts, n_off[:-1]) == 0).any():
             raise ValueError("keyframe has no segment pixels")
         total = max(int(t.p_off[-1]), 1)
-        t.pix = torch.zeros(total, dtype=torch.int32, device=dev)               # zero = invalid point: the padding
+        t.pix = torch.empty(total, dtype=torch.int32, device=dev)               # (the sampler writes the padding: zero = invalid point)
         t.baseL = torch.empty(total, dtype=torch.float32, device=dev)
         # segment positions: inside the flat array (fill) and relative to the pair's own table (sampler, cost kernels)
-        t.seg_off = torch.from_numpy(np.concatenate((t.seg_pos + t.p_off[pair_of_seg], t.seg_pos)).astype(np.int32)).to(dev)
         t.counts_d = counts_d[si * S: (si + 1) * S]
-        recs['seg_off'][:, si] = t.seg_off.data_ptr() + 4 * n_off[:-1]
         recs['pix'][:, si], recs['baseL'][:, si] = t.pix.data_ptr(), t.baseL.data_ptr()
         t.src4 = {}
         tabs[s] = t
-    recs_d = _records(recs, dev)
-    _lib.check(lib.sp_prepare_fill(_lib.ptr(recs_d), M0, max_rows, max_N, s_ptr), "sp_prepare_fill")
-
-    # ---- image pyramids of both frames, packed targets ----
-    max_level = max(level_ids)
-    pyramid = []
-    ptr_lv = {0: (_ptrs(simg), _ptrs(timg))}                                     # level -> (source, target) image pointers
-    hw = {0: np.stack((Hs, Ws), axis=1)}
-    for l in range(1, max_level + 1):
-        hw[l] = (hw[l - 1] + 1) // 2
-        sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
-        off = np.concatenate(([0], np.cumsum(np.tile(sizes, 2))))
-        buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
-        jobs = np.zeros(2 * M0, dtype=_IMAGE_DT)
-        jobs['inp'] = np.concatenate(ptr_lv[l - 1])
-        jobs['out'] = buf.data_ptr() + 4 * off[:-1]
-        jobs['H'], jobs['W'] = np.tile(hw[l - 1][:, 0], 2), np.tile(hw[l - 1][:, 1], 2)
-        jobs_d = _records(jobs, dev)
-        _lib.check(lib.sp_prepare_blur(_lib.ptr(jobs_d), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
-        ptr_lv[l] = (jobs['out'][:M0].copy(), jobs['out'][M0:].copy())
-        pyramid.append(buf)                  # read by later launches: must not return to the allocator before they are enqueued
-    trg = {}
-    jobs = np.zeros(len(level_ids) * M0, dtype=_IMAGE_DT)
-    for li, l in enumerate(level_ids):
-        sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
-        off = np.concatenate(([0], np.cumsum(sizes)))
-        buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
-        jb = jobs[li * M0: (li + 1) * M0]
-        jb['inp'], jb['out'] = ptr_lv[l][1], buf.data_ptr() + 4 * off[:-1]
-        jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
-        trg[l] = (buf, off, [(int(h), int(w)) for h, w in hw[l]])
-    jobs_d = _records(jobs, dev)
-    _lib.check(lib.sp_prepare_pack(_lib.ptr(jobs_d), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
-               "sp_prepare_pack")
+    # segment positions: inside the flat array (fill) and relative to the pair's own table (sampler)
+    seg_off = stage([np.concatenate((t.seg_pos + t.p_off[pair_of_seg], t.seg_pos)).astype(np.int32) for t in tabs.values()], dev)
+    for si, t in enumerate(tabs.values()):
+        t.seg_off = seg_off[si]
+        recs['seg_off'][:, si] = t.seg_off.data_ptr() + 4 * n_off[:-1]
 
     # ---- source samples: the stride-1 tables at every level, a decimated table at its own level(s), all levels of a table
     #      in one pass (which also sets the table's source-validity bits) ----
@@ -231,12 +256,13 @@ def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
         jb['kld'], jb['K'] = _ptrs(kld), _ptrs(Ksrc)
         jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'] = Ns, P, Hs, Ws, len(lv)
         for k, l in enumerate(lv):
-            t.src4[l] = torch.zeros(max(int(t.p_off[-1]), 1), 4, dtype=torch.float32, device=dev)
+            t.src4[l] = torch.empty(max(int(t.p_off[-1]), 1), 4, dtype=torch.float32, device=dev)
             jb['image'][:, k] = ptr_lv[l][0]
             jb['src4'][:, k] = t.src4[l].data_ptr() + 16 * t.p_off[:-1]
             jb['Hl'][:, k], jb['Wl'][:, k] = hw[l][:, 0], hw[l][:, 1]
-    jobs_d = _records(jobs, dev)
-    _lib.check(lib.sp_prepare_sample(_lib.ptr(jobs_d), len(jobs), max_P, s_ptr), "sp_prepare_sample")
+    staged = stage([recs, jobs], dev)
+    _lib.check(lib.sp_prepare_fill(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_fill")
+    _lib.check(lib.sp_prepare_sample(_lib.ptr(staged[1]), len(jobs), max_P, s_ptr), "sp_prepare_sample")
     del pyramid
     # (temporaries -- job records, row counts, pyramid levels -- are released here; the caching allocator orders their reuse
     #  after the launches above on this stream)

@@ -154,6 +154,10 @@ class PairBatch:
 
         # tables, pyramids, source samples and packed targets of the base pairs: a dozen launches, one host synchronisation.
         # A (level, stride) combination needs the stride's table sampled at that level
+        # (the intrinsics come back to the host for the descriptors: enqueued first, complete once prepare_pairs has waited
+        #  for its segment counts)
+        Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)
+        Ks_pinned.copy_(torch.stack([batch_prepare._dev(k, dev).reshape(3, 3) for k in [f.K for f in src_frames] + list(trg_Ks)]), non_blocking=True)
         prep = batch_prepare.prepare_pairs(src_frames, trg_images, klds, self.level_ids, coarse_keys, dev)
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
         rep = (lambda x: x) if R == 1 else (lambda x: x.repeat(*([R] + [1] * (x.dim() - 1))))
@@ -189,17 +193,41 @@ class PairBatch:
         wl = batch_prepare.flat_work_list(pc, seg_pos, n_off, self.span_points, tile_points)
         chunks, spans = wl['chunks'], wl['spans']
         self.n_chunks, self.n_spans = len(chunks), len(spans)
-        self.chunks = torch.from_numpy(chunks).to(dev)
-        self.spans = torch.from_numpy(spans).to(dev)
-        # partial records: one per span (pair-level sums) and one per (chunk, wave) (segment-level sums);
-        # span_pair / seg_records list the owner of every record for host-side consumers (tests, evaluate())
-        self.span_pair = self.spans[:, 3].long()
         self.n_seg_records = 4 * self.n_chunks
-        self.seg_records = torch.from_numpy(np.repeat(chunks[:, :2], 4, axis=0).copy()).to(dev)   # (pair, segment) of every segment record
-        self.seg_tile_off = torch.from_numpy(wl['seg_tile_off']).to(dev)
+        # decimated point sets of the coarse levels (run_scheduled): own tables, work list, descriptors, partial buffers
+        self.coarse = {}
+        coarse_host = {}
+        for l, stride in coarse_keys:
+            t = tabs[stride]
+            lay = _Layout()
+            lay.stride = stride
+            c_counts, c_pc, c_seg_pos = tile(t.counts), tile(t.pc), tile(t.seg_pos)
+            c_p_off = np.concatenate(([0], np.cumsum(tile(np.diff(t.p_off)))))
+            lay.points = [int(p) for p in np.add.reduceat(c_counts, n_off[:-1])]
+            shared = next((o for (l2, s2), o in self.coarse.items() if s2 == stride), None)
+            lay.pix = shared.pix if shared is not None else rep(t.pix)
+            lay.src4 = rep(t.src4[l]).reshape(-1)
+            c_span = max(GRANULE, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS))
+            c_wl = batch_prepare.flat_work_list(c_pc, c_seg_pos, n_off, c_span, tile_points)
+            lay.n_chunks, lay.n_spans = len(c_wl['chunks']), len(c_wl['spans'])
+            coarse_host[(l, stride)] = (c_wl, c_p_off)
+            self.coarse[(l, stride)] = lay
+        # every host-made array goes to the device through one staging buffer (asynchronously: the preparation kernels are
+        # still running): chunks {pair, seg, start, count}, spans {first chunk, n chunks, points, pair}, the per-pair CSR of
+        # the segment records, and -- for host-side consumers (tests, evaluate()) -- the owner (pair, segment) of every
+        # segment record
+        host = [chunks, spans, wl['seg_tile_off'], np.repeat(chunks[:, :2], 4, axis=0)]
+        for key in self.coarse:
+            c_wl = coarse_host[key][0]
+            host += [c_wl['chunks'], c_wl['spans'], c_wl['seg_tile_off']]
+        staged = batch_prepare.stage(host, dev)
+        self.chunks, self.spans, self.seg_tile_off, self.seg_records = staged[:4]
+        self.span_pair = self.spans[:, 3].long()
+        for i, lay in enumerate(self.coarse.values()):
+            lay.chunks, lay.spans, lay.seg_tile_off = staged[4 + 3 * i: 7 + 3 * i]
 
         # descriptors, one array per level (numpy view of struct SpPair, filled column-wise)
-        Ks = torch.stack([batch_prepare._dev(k, dev).reshape(3, 3) for k in [f.K for f in src_frames] + list(trg_Ks)]).cpu().numpy()
+        Ks = Ks_pinned.numpy()
         Ks_src, Ks_trg = Ks[:M0], Ks[M0:]
         k4 = lambda K: np.tile(np.stack((K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]), axis=1).astype(np.float32), (R, 1))
         HW = np.tile(prep['shapes'][:, 1:].astype(np.int32), (R, 1))                    # full-resolution source size
@@ -223,32 +251,18 @@ class PairBatch:
             d['tile0'], d['n_tiles'] = lay_wl['s_off'][:-1], np.diff(lay_wl['s_off'])
             d['zmin'] = zmin
             d['rec0'] = 4 * lay_wl['c_off'][:-1]
-            return torch.from_numpy(d.view(np.uint8).reshape(-1).copy()).to(dev)
+            return d
 
-        self.desc = {l: descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps)) for l in self.level_ids}
-
-        # decimated point sets of the coarse levels (run_scheduled): own tables, work list, descriptors, partial buffers
-        self.coarse = {}
-        for l, stride in coarse_keys:
-            t = tabs[stride]
-            lay = _Layout()
-            lay.stride = stride
-            c_counts, c_pc, c_seg_pos = tile(t.counts), tile(t.pc), tile(t.seg_pos)
-            c_p_off = np.concatenate(([0], np.cumsum(tile(np.diff(t.p_off)))))
-            lay.points = [int(p) for p in np.add.reduceat(c_counts, n_off[:-1])]
-            shared = next((o for (l2, s2), o in self.coarse.items() if s2 == stride), None)
-            lay.pix = shared.pix if shared is not None else rep(t.pix)
-            lay.src4 = rep(t.src4[l]).reshape(-1)
-            c_span = max(GRANULE, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS))
-            c_wl = batch_prepare.flat_work_list(c_pc, c_seg_pos, n_off, c_span, tile_points)
-            lay.n_chunks, lay.n_spans = len(c_wl['chunks']), len(c_wl['spans'])
-            lay.chunks = torch.from_numpy(c_wl['chunks']).to(dev)
-            lay.spans = torch.from_numpy(c_wl['spans']).to(dev)
-            lay.seg_tile_off = torch.from_numpy(c_wl['seg_tile_off']).to(dev)
-            lay.desc = descriptors(l, lay.pix, lay.src4, lay.seg_tile_off, c_p_off, c_wl, np.maximum(np.asarray(lay.points), 1))
+        host = [descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps)) for l in self.level_ids]
+        for (l, stride), lay in self.coarse.items():
+            c_wl, c_p_off = coarse_host[(l, stride)]
+            host.append(descriptors(l, lay.pix, lay.src4, lay.seg_tile_off, c_p_off, c_wl, np.maximum(np.asarray(lay.points), 1)))
+        staged = batch_prepare.stage(host, dev)
+        self.desc = dict(zip(self.level_ids, staged))
+        for i, lay in enumerate(self.coarse.values()):
+            lay.desc = staged[len(self.level_ids) + i]
             lay.partials = torch.empty(max(lay.n_spans, 1) * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
             lay.seg_partials = torch.empty(max(4 * lay.n_chunks, 1) * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
-            self.coarse[(l, stride)] = lay
 
         # optimiser state / workspaces
         self.partials = torch.empty(self.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
