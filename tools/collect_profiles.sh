@@ -26,4 +26,7 @@ python bench.py --segments 128 --no-cpu-baseline > $OUT/bench_n1_seg128.json 2>/
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats128 -o bench -- python bench.py --segments 128 --no-cpu-baseline --no-extras > /dev/null 2>&1
 python tools/parity_report.py > $OUT/parity.txt 2>/dev/null
 python tools/power_by_mode.py --modes 1,14,11,13,0 --seconds 4 2>/dev/null | grep mode > $OUT/power_by_mode.txt
+# set-up of frame pairs from raw frames (optim/batch_prepare.py): timings and the kernel stats of the same command
+python tools/setup_profile.py 128 2>/dev/null | grep "PairBatch of\|run_scheduled\|build:" > $OUT/setup.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_setup -o setup -- python tools/setup_profile.py 128 > /dev/null 2>&1
 ls $OUT

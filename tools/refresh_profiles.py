@@ -61,7 +61,8 @@ for a, b in [("bench_n1.json", "bench_n1.json"), ("bench_n1_adam.json", "bench_n
              ("stats/bench_kernel_stats.csv", "bench_n1_kernel_stats.csv"), ("kbench_ablation.txt", "kbench_ablation.txt"),
              ("configs.txt", "configs.txt"), ("bench_n1_seg128.json", "bench_n1_seg128.json"),
              ("stats128/bench_kernel_stats.csv", "bench_n1_seg128_kernel_stats.csv"), ("parity.txt", "parity.txt"),
-             ("power_by_mode.txt", "power_by_mode.txt")]:
+             ("power_by_mode.txt", "power_by_mode.txt"), ("setup.txt", "setup.txt"),
+             ("stats_setup/setup_kernel_stats.csv", "setup_kernel_stats.csv")]:
     if os.path.exists(f"{R}/{a}"):
         shutil.copy(f"{R}/{a}", f"{P}/{rnd}_{b}")
 with open(f"{P}/{rnd}_power_clock_trace.txt", "w") as f:
