@@ -38,7 +38,8 @@ GRANULE = 256                      # SP_BLOCK: every segment is padded to a mult
 # FRAME_PAIR_POINT_STRIDE: PairBatch(point_stride=...) of that schedule -- at pyramid level l (image decimated 2^l times) the
 # schedule's Gauss-Newton iterations run on the source points whose pixel coordinates are multiples of the stride (1 / stride^2
 # of them: about one source sample per TARGET pixel of that level instead of 4^l); the finest level and the polish use every
-# point, so the minimiser reached is that of the full reference cost.
+# point, so the minimiser reached is that of the full reference cost.  (The reference evaluates every full-resolution source
+# point at every level, odometery/two_frame_sfm.py:128-207; every per-level method of PairBatch does too.)
 FRAME_PAIR_POINT_STRIDE = (1, 2, 4)
 FRAME_PAIR_SCHEDULE = dict(max_iters_per_level=25, conv_tol=2e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-4, check_every=3)
 FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps=1e-5)
@@ -129,7 +130,7 @@ class PairBatch:
         batches so that a launch keeps about 2300 workgroups (a single pair then runs one chunk per workgroup).
 
         ``point_stride`` (one integer per pyramid level, finest first; default all 1): levels with a stride s > 1 get, IN
-        ADDITION, a decimated copy of the point tables -- the valid points whose column and row are multiples of s -- with its
+        ADDITION, a decimated copy of the point tables -- the mask pixels whose column and row are multiples of s -- with its
         own work list, descriptors and partial buffers (``self.coarse[(level, s)]``); ``extra_tables`` = further (level,
         stride) combinations for explicit ``schedule(phases=...)`` lists.  Only ``run_scheduled`` uses them; every per-level
         method below (cost_pass, gn_step, adam_step, evaluate, run, run_converging) works on all points."""
@@ -152,10 +153,9 @@ class PairBatch:
             self.point_stride = {l: int(s) for l, s in zip(self.level_ids, point_stride)}
         coarse_keys = sorted({(l, s) for l, s in self.point_stride.items() if s > 1} | {(int(l), int(s)) for l, s in extra_tables if int(s) > 1})
 
-        # tables, pyramids, source samples and packed targets of the base pairs: a dozen launches, one host synchronisation.
-        # A (level, stride) combination needs the stride's table sampled at that level
-        # (the intrinsics come back to the host for the descriptors: enqueued first, complete once prepare_pairs has waited
-        #  for its segment counts)
+        # tables, pyramids, source samples and packed targets of the base pairs: a dozen launches, one host synchronisation
+        # (optim/batch_prepare.py).  The intrinsics come back to the host for the descriptors: their copy is enqueued first and
+        # is complete once prepare_pairs has waited for its segment counts
         Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)
         Ks_pinned.copy_(torch.stack([batch_prepare._dev(k, dev).reshape(3, 3) for k in [f.K for f in src_frames] + list(trg_Ks)]), non_blocking=True)
         prep = batch_prepare.prepare_pairs(src_frames, trg_images, klds, self.level_ids, coarse_keys, dev)
