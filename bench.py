@@ -304,6 +304,8 @@ def main(argv=None):
             # (b) the quoted one: per-pair termination on the device (pairs leave a level when converged); timed from the
             #     initial poses / random depth seeds, one untimed pass first (nothing is cached between passes)
             batch.restore_initial()
+            batch.run_converging(**SCH)                  # untimed pass first, like the other forms
+            batch.restore_initial()
             sync()
             t1 = time.perf_counter()
             by_level = batch.run_converging(**SCH)
