@@ -553,6 +553,11 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
             tb = buf_load3(r_trg, o0 + 4u * SP_TEXEL_FLOATS);
             tc = buf_load3(r_trg, o0, c.row_bytes);
             td = buf_load3(r_trg, o0 + 4u * SP_TEXEL_FLOATS, c.row_bytes);
+        } else if (ABL == 4) {
+            // upper bound of sharing the right-hand texels with the neighbouring lane: only the left column is loaded
+            ta = buf_load3(r_trg, a.p.off0);
+            tc = buf_load3(r_trg, a.p.off0, c.row_bytes);
+            tb = ta; td = tc;
         } else {
             ta = buf_load3(r_trg, a.p.off0);
             tb = buf_load3(r_trg, a.p.off0 + 4u * SP_TEXEL_FLOATS);
@@ -1036,7 +1041,7 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spa
 int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                          float* partials, float* seg_partials, const int32_t* done, void* stream) {
     if (!pairs || !chunks || !spans || !partials || !seg_partials || n_spans <= 0) return SP_EINVAL;
-    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 14)) return SP_EINVAL;
+    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 15)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_spans + 7) / 8) * 8;
     const int4* c4 = reinterpret_cast<const int4*>(chunks);
@@ -1053,6 +1058,8 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
         hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 14)
         hipLaunchKernelGGL((k_cost_pairs<1, 3>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
+    else if (mode == 15)
+        hipLaunchKernelGGL((k_cost_pairs<1, 4>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 12)
         hipLaunchKernelGGL((k_cost_pairs<0, 2>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else

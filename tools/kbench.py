@@ -18,25 +18,47 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--levels", default="0")
     ap.add_argument("--modes", default="0,1")
+    ap.add_argument("--tile-order", default="", help="comma list of t: re-time with the points of every chunk re-ordered into t x t pixel "
+                                                     "blocks (developer experiment on the table order; 0 = restore row-major)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     batch, _ = bench.build_batch(a, 0, dev)
     for _ in range(3):
         batch.gn_step(0)
-    for level in [int(x) for x in a.levels.split(",")]:
+    orders = [None] + [int(t) for t in a.tile_order.split(",") if t]
+    original = (batch.pix.clone(), {l: v.clone() for l, v in batch.src4.items()})
+    for order in orders:
+      if order is not None:
+        batch.pix.copy_(original[0])
+        for l in batch.src4:
+            batch.src4[l].copy_(original[1][l])
+        if order > 0:
+            ch = batch.chunks.long()
+            run = torch.repeat_interleave(torch.arange(ch.shape[0], device=dev), ch[:, 3])       # chunk of every table position
+            w = batch.pix.long() & 0xffffffff
+            col, row, real = w & 0xffff, (w >> 16) & 0x7fff, (w != 0)
+            key = (((row // order) * 8192 + col // order) * order + row % order) * order + col % order
+            key = torch.where(real, key, torch.full_like(key, (1 << 38) - 1)) + (run << 38)
+            perm = torch.argsort(key)
+            batch.pix.copy_(batch.pix[perm])
+            for l in batch.src4:
+                batch.src4[l].view(-1, 4).copy_(batch.src4[l].view(-1, 4)[perm])
+            del key, perm, w, col, row, real, run
+        print(f"--- table order: {order} x {order} pixel blocks inside every chunk" if order else "--- table order: row-major")
+      for level in [int(x) for x in a.levels.split(",")]:
         for mode in [int(x) for x in a.modes.split(",")]:
-            for _ in range(3):
-                batch.cost_pass(level, mode)
-            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
-            torch.cuda.synchronize()
-            for e0, e1 in ev:
-                e0.record(); batch.cost_pass(level, mode); e1.record()
-            torch.cuda.synchronize()
-            ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
-            by = batch.algorithmic_bytes(level)
-            print(f"level {level} mode {mode} pairs {batch.M} spans {batch.n_spans}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
-                  f"alg {by/1e6:.1f} MB -> {by/np.median(ms)/1e6:.0f} GB/s ({by/np.median(ms)/1e6/8000*100:.1f}% of 8 TB/s)  "
-                  f"{sum(batch.Ps)/np.median(ms)/1e6:.2f} Gpt/s")
+              for _ in range(3):
+                  batch.cost_pass(level, mode)
+              ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+              torch.cuda.synchronize()
+              for e0, e1 in ev:
+                  e0.record(); batch.cost_pass(level, mode); e1.record()
+              torch.cuda.synchronize()
+              ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
+              by = batch.algorithmic_bytes(level)
+              print(f"level {level} mode {mode} pairs {batch.M} spans {batch.n_spans}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us  "
+                    f"alg {by/1e6:.1f} MB -> {by/np.median(ms)/1e6:.0f} GB/s ({by/np.median(ms)/1e6/8000*100:.1f}% of 8 TB/s)  "
+                    f"{sum(batch.Ps)/np.median(ms)/1e6:.2f} Gpt/s")
 
 
 if __name__ == "__main__":
