@@ -392,7 +392,18 @@ def main(argv=None):
             line["frame_pairs_per_sec_from_raw_frames"] = n_raw / (t_setup + t_opt)
             line["from_raw_frames"] = {"pairs": n_raw, "setup_ms": 1e3 * t_setup, "optimise_ms": 1e3 * t_opt,
                                        "setup_us_per_pair": 1e6 * t_setup / n_raw}
-            del raw, frames, base
+            # (e) batches back to back, the set-up of the next one overlapped with the optimisation of the current one on a
+            #     second HIP stream (optim.pair_stream.PairStream): 4 batches of the same raw frames
+            from super_primitive_amd.optim.pair_stream import PairStream
+            item = dict(src_frames=frames, trg_images=[r["trg"] for r in raw], trg_Ks=[r["K"] for r in raw], poses=poses0, klds=[r["kld"] for r in raw])
+            for _ in range(2):
+                sync()
+                t1 = time.perf_counter()
+                for _res in PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, tile_points=args.tile_points).run(iter([item] * 4)):
+                    pass
+                sync()
+                line["from_raw_frames"]["pipelined_pairs_per_sec"] = 4 * n_raw / (time.perf_counter() - t1)
+            del raw, frames, base, item
         else:
             line["frame_pair_schedule"] = "3 levels (coarse to fine) x 500 Adam iterations (the reference's budget, two_frame_sfm.py:128)"
 

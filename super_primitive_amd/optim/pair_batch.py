@@ -178,7 +178,7 @@ class PairBatch:
         # flat, pair-major device arrays
         self.kp_L = rep(kp_L)
         self.kld = rep(torch.cat([batch_prepare._dev(k, dev).reshape(-1) for k in klds])).contiguous()
-        self.pose = poses.detach().float().to(dev).reshape(M, 16).contiguous()
+        self.pose = poses.detach().to(device=dev, dtype=torch.float32).reshape(M, 16).clone()       # owned: updated in place
         self.aff = torch.zeros(M, 4, dtype=torch.float32, device=dev) if use_affine else None
         self.pix = rep(full.pix)
         self.src4 = {l: rep(full.src4[l]).reshape(-1) for l in self.level_ids}

@@ -1,0 +1,76 @@
+"""Batches of frame pairs through the GPU back to back: the set-up of batch k+1 overlaps the optimisation of batch k.
+
+One batch alone leaves the GPU idle twice: while the host lays out the tables between the count pass and the fill pass of the
+set-up (``optim/batch_prepare.py``), and in the tail of the schedule, when the last few pairs iterate alone
+(``PairBatch.run_scheduled``; ``profiles/r02_schedule_sweep.txt``).  Two host threads with one HIP stream each fill those gaps
+with the other batch's work: a producer builds ``PairBatch`` objects one batch ahead on the set-up stream, the consumer runs
+the schedule on the optimisation stream, an event orders "built" before "optimise", and a batch's arrays stay referenced until
+its results have been read.  Frame pairs are independent problems, so nothing else is shared.
+"""
+from __future__ import annotations
+
+import queue
+import threading
+
+import torch
+
+from .pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
+
+
+class PairStream:
+    def __init__(self, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, schedule=None, device="cuda:0", depth=1, **batch_kw):
+        """``schedule``: keyword arguments of ``PairBatch.run_scheduled`` (default: FRAME_PAIR_SCHEDULE); ``depth``: how many
+        built batches may wait for the optimiser (each holds its tables in device memory); ``batch_kw``: passed to PairBatch."""
+        self.levels, self.point_stride, self.batch_kw = levels, point_stride, batch_kw
+        self.schedule = {k: v for k, v in (FRAME_PAIR_SCHEDULE if schedule is None else schedule).items() if k != "check_every"}
+        self.device = torch.device(device)
+        self.depth = depth
+        self.setup_stream = torch.cuda.Stream(self.device)
+        self.optim_stream = torch.cuda.Stream(self.device)
+
+    def _producer(self, inputs, out, ready_for_inputs):
+        try:
+            torch.cuda.set_device(self.device)
+            with torch.cuda.stream(self.setup_stream):
+                self.setup_stream.wait_event(ready_for_inputs)
+                for item in inputs:
+                    batch = PairBatch(item["src_frames"], item["trg_images"], item["trg_Ks"], item["poses"], item["klds"], levels=self.levels,
+                                      point_stride=self.point_stride, **self.batch_kw)
+                    built = torch.cuda.Event()
+                    built.record(self.setup_stream)
+                    out.put((batch, built))
+            out.put(None)
+        except BaseException as e:          # surfaces in the consumer
+            out.put(e)
+
+    def run(self, inputs):
+        """inputs: iterable of dict(src_frames, trg_images, trg_Ks, poses, klds) -- the arguments of PairBatch, device resident.
+        Yields (poses (M,4,4), [klds]) of every batch, in order, as device tensors valid on the caller's current stream."""
+        caller = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(caller)                 # the inputs may still be in flight on the caller's stream
+        built_q = queue.Queue(maxsize=self.depth)
+        worker = threading.Thread(target=self._producer, args=(inputs, built_q, ready), daemon=True)
+        worker.start()
+        try:
+            while True:
+                got = built_q.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                batch, built = got
+                with torch.cuda.stream(self.optim_stream):
+                    self.optim_stream.wait_event(built)
+                    batch.run_scheduled(**self.schedule)
+                    poses, klds = batch.poses().clone(), [k.clone() for k in batch.klds()]
+                    done = torch.cuda.Event()
+                    done.record(self.optim_stream)
+                # the batch (allocated on the set-up stream, used on the optimisation stream) is released only after the
+                # optimiser has finished with it
+                done.synchronize()
+                caller.wait_event(done)
+                del batch
+                yield poses, klds
+        finally:
+            worker.join(timeout=60)

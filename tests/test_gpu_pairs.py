@@ -576,3 +576,41 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
             keep_valid = on & ((full_pix >> 31) == 1)
             assert np.array_equal(mpix[(mpix >> 31) == 1], full_pix[keep_valid])
             assert np.array_equal(msrc[(mpix >> 31) == 1], full_src[keep_valid])
+
+
+def test_pair_stream_overlaps_batches_and_returns_each_batch_s_own_result():
+    """PairStream: batch k+1 is built on the set-up stream by a producer thread while batch k runs its schedule on the
+    optimisation stream.  Every batch's result is bit-identical to the same batch built and optimised alone on the default
+    stream -- ragged batches (different pair counts, sizes and segment counts), consumed in order."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.optim.pair_batch import PairBatch
+    from super_primitive_amd.optim.pair_stream import PairStream
+    dev = torch.device("cuda:0")
+    sch = dict(max_iters_per_level=12, conv_tol=2e-3, polish_max=6, polish_eps=1e-5, polish_tol=1e-4)
+    groups = [[synth.make_pair(60, 80, 6, seed=111), synth.make_pair(60, 80, 6, seed=112)],
+              [synth.make_pair(96, 128, 9, seed=113)],
+              [synth.make_pair(60, 80, 6, seed=114), synth.make_pair(48, 64, 4, seed=115), synth.make_pair(60, 80, 6, seed=116)]]
+
+    def inputs(prs):
+        t = lambda a: T(a).to(dev)
+        return dict(src_frames=[KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in prs],
+                    trg_images=[t(p.trg_image) for p in prs], trg_Ks=[t(p.K) for p in prs],
+                    poses=torch.stack([t(p.pose_init) for p in prs]), klds=[t(p.kld_init) for p in prs])
+
+    items = [inputs(g) for g in groups]
+    stream = PairStream(levels=(0, 3), point_stride=(1, 2, 4), schedule=sch, tile_points=1024)
+    got = list(stream.run(iter(items)))
+    torch.cuda.synchronize()
+    assert len(got) == len(groups)
+    for item, (poses, klds) in zip(items, got):
+        ref = PairBatch(item["src_frames"], item["trg_images"], item["trg_Ks"], item["poses"], item["klds"], levels=(0, 3),
+                        point_stride=(1, 2, 4), tile_points=1024)
+        ref.run_scheduled(**sch)
+        torch.cuda.synchronize()
+        assert torch.equal(poses, ref.poses())
+        assert all(torch.equal(a, b) for a, b in zip(klds, ref.klds()))
+    # an error in the producer thread reaches the caller
+    bad = dict(items[0]); bad["klds"] = bad["klds"][:1]
+    with pytest.raises(AssertionError):
+        list(stream.run(iter([bad])))

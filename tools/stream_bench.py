@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Developer tool: frame pairs per second from raw device-resident frames, one batch at a time against PairStream (set-up of the
+next batch overlapped with the optimisation of the current one)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from super_primitive_amd import synth
+from super_primitive_amd.image.keyframe import KeyFrame
+from super_primitive_amd.optim.pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
+from super_primitive_amd.optim.pair_stream import PairStream
+
+dev = torch.device("cuda:0")
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+base = [synth.make_pair(480, 640, 64, seed=1000 + s, overlap=4, init_sigma=0.004) for s in range(4)]
+sk = {k: v for k, v in FRAME_PAIR_SCHEDULE.items() if k != "check_every"}
+
+
+def make_items(per_batch, n_batches, distinct_batches):
+    items = []
+    for b in range(distinct_batches):
+        prs = [base[(b * per_batch + i) % len(base)] for i in range(per_batch)]
+        items.append(dict(src_frames=[KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in prs],
+                          trg_images=[t(p.trg_image) for p in prs], trg_Ks=[t(p.K) for p in prs],
+                          poses=torch.stack([t(p.pose_init) for p in prs]), klds=[t(p.kld_init) for p in prs]))
+    return [items[i % distinct_batches] for i in range(n_batches)]
+
+
+for per_batch, n_batches, distinct in ((128, 9, 3), (384, 4, 1), (64, 12, 3)):
+    items = make_items(per_batch, n_batches, distinct)
+    for label in ("sequential", "pipelined"):
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if label == "sequential":
+                for it in items:
+                    b = PairBatch(it["src_frames"], it["trg_images"], it["trg_Ks"], it["poses"], it["klds"], levels=(0, 3),
+                                  point_stride=FRAME_PAIR_POINT_STRIDE)
+                    b.run_scheduled(**sk)
+                    res = (b.poses().clone(), [k.clone() for k in b.klds()])
+            else:
+                for res in PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE).run(iter(items)):
+                    pass
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"{n_batches} batches x {per_batch} pairs, {label}: {dt * 1e3:.1f} ms = {n_batches * per_batch / dt:.0f} pairs/s", flush=True)
+    del items
