@@ -278,7 +278,7 @@ typedef struct SpPhase {
     const int32_t* spans;
     float* span_partials;        /* n_spans * SP_GN_PARTIAL_FLOATS */
     float* seg_partials;         /* 4 * n_chunks * SP_GN_SEG_FLOATS */
-    int32_t n_spans;
+    int32_t n_spans;             /* 0 = an empty point set: nothing is launched, its pairs pass through the phase */
     int32_t max_iters;
     float irls_eps;
     float conv_tol;

@@ -1072,17 +1072,19 @@ int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* 
     if (!sched || !phase || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
     for (int p = 0; p < sched->n_phases; ++p) {
         const SpPhase& ph = sched->phase[p];
-        if (!ph.pairs || !ph.chunks || !ph.spans || !ph.span_partials || !ph.seg_partials || ph.n_spans <= 0) return SP_EINVAL;
+        if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.n_spans < 0) return SP_EINVAL;
+        if (ph.n_spans > 0 && (!ph.chunks || !ph.spans)) return SP_EINVAL;
     }
     uint32_t launched = 0;
     for (int p = 0; p < sched->n_phases; ++p) {
         if ((launched >> p) & 1u) continue;
         const SpPhase& lead = sched->phase[p];          // first phase of a work list: one launch for all phases sharing it
+        if (lead.n_spans == 0) continue;                // an empty point set (every segment smaller than the lattice stride)
         FuseArgs f{};
         f.phase = phase;
         for (int q = p; q < sched->n_phases; ++q) {
             const SpPhase& ph = sched->phase[q];
-            if (ph.spans != lead.spans) continue;
+            if (ph.spans != lead.spans || ph.n_spans != lead.n_spans) continue;
             if (ph.chunks != lead.chunks || ph.span_partials != lead.span_partials || ph.seg_partials != lead.seg_partials ||
                 ph.n_spans != lead.n_spans) return SP_EINVAL;
             f.sched.pairs[q] = ph.pairs;

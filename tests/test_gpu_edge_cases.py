@@ -123,3 +123,22 @@ def test_tiny_pyramid_level_and_argument_limits():
     lib = _lib.load()
     assert lib.sp_mask_count(_lib.ptr(src.keypoint_regions), 2, 40000, 24, _lib.ptr(src.keypoint_regions),
                              _lib.ptr(src.keypoint_regions), _lib.ptr(src.keypoint_regions), None) == -2   # SP_ELIMIT
+
+
+def test_schedule_with_an_empty_decimated_point_set():
+    """A lattice stride larger than every segment leaves the coarse table EMPTY (no mask pixel on the lattice): the scheduled
+    run must pass through that phase (no launch for it, no hang, no division by zero) and still converge on the full points."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.optim.pair_batch import PairBatch
+    pr = synth.make_pair(24, 32, 4, seed=121, init_sigma=0.002)
+    pr.keypoint_regions[:, ::2, :] = False                      # no pixel with an even row survives ...
+    pr.keypoint_regions[:, :, ::2] = False                      # ... nor with an even column: strides 2 and 4 find nothing
+    batch = PairBatch.from_synth([pr], levels=(0, 3), device="cuda:0", tile_points=512, point_stride=(1, 2, 4))
+    assert all(lay.n_spans == 0 and lay.points == [0] for lay in batch.coarse.values())
+    launched = batch.run_scheduled(max_iters_per_level=10, conv_tol=1e-3, polish_max=5, polish_eps=1e-5, polish_tol=1e-4)
+    torch.cuda.synchronize()
+    assert 0 < launched <= 35 and int(batch.phase[0]) == 4
+    assert np.isfinite(batch.poses().cpu().numpy()).all() and np.isfinite(batch.klds()[0].cpu().numpy()).all()
+    ref = PairBatch.from_synth([pr], levels=(0, 3), device="cuda:0", tile_points=512)
+    c0 = float(ref.evaluate(0)[0])
+    assert float(batch.evaluate(0)[0]) < c0
