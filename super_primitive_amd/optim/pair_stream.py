@@ -23,7 +23,9 @@ from .pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
 class PairStream:
     def __init__(self, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, schedule=None, device="cuda:0", depth=1, **batch_kw):
         """``schedule``: keyword arguments of ``PairBatch.run_scheduled`` (default: FRAME_PAIR_SCHEDULE); ``depth``: how many
-        built batches may wait for the optimiser (each holds its tables in device memory); ``batch_kw``: passed to PairBatch."""
+        built batches may wait for the optimiser (each holds its tables in device memory); ``batch_kw``: passed to PairBatch.
+        Meant to be long-lived: the caching allocator keeps one pool per stream, so a PairStream reuses its tables' memory
+        from batch to batch, while a fresh one (fresh streams) pays for device allocations again."""
         self.levels, self.point_stride, self.batch_kw = levels, point_stride, batch_kw
         self.schedule = {k: v for k, v in (FRAME_PAIR_SCHEDULE if schedule is None else schedule).items() if k != "check_every"}
         self.device = torch.device(device)

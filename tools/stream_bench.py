@@ -27,8 +27,9 @@ def make_items(per_batch, n_batches, distinct_batches):
 
 for per_batch, n_batches, distinct in ((128, 9, 3), (384, 4, 1), (64, 12, 3)):
     items = make_items(per_batch, n_batches, distinct)
+    pipe = PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE)          # long-lived: its streams' allocator pools are reused
     for label in ("sequential", "pipelined"):
-        for rep in range(2):
+        for rep in range(3):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             if label == "sequential":
                 for it in items:
@@ -37,7 +38,7 @@ for per_batch, n_batches, distinct in ((128, 9, 3), (384, 4, 1), (64, 12, 3)):
                     b.run_scheduled(**sk)
                     res = (b.poses().clone(), [k.clone() for k in b.klds()])
             else:
-                for res in PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE).run(iter(items)):
+                for res in pipe.run(iter(items)):
                     pass
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"{n_batches} batches x {per_batch} pairs, {label}: {dt * 1e3:.1f} ms = {n_batches * per_batch / dt:.0f} pairs/s", flush=True)
