@@ -338,3 +338,20 @@ def test_void_driver_reruns_and_merges_when_coverage_is_low():
     assert np.array_equal(depth[ok1], npy(d1)[ok1]), "pixels covered by the first pass keep its depth"
     newly = npy(i1) & ~invalid
     np.testing.assert_allclose(depth[newly], pair.depth[newly], rtol=5e-3)
+
+
+def test_bench_schedule_on_distinct_scenes_at_full_size():
+    """The quoted schedule (device-side, decimated coarse levels) on 10 scenes bench.py does not render, 640x480x64, against
+    each scene's ground truth (gauge removed): every pair inside bar + the minimiser's own offset from the ground truth
+    (tools/schedule_sweep.py scenes 48 -> profiles/r02_schedule_sweep.txt: worst 8e-6 rad / 2.6e-5 t / 3.3e-4 depth)."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.optim.pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
+    prs = [synth.make_pair(480, 640, 64, seed=2000 + s, overlap=4, init_sigma=0.004) for s in range(10)]
+    batch = PairBatch.from_synth(prs, levels=(0, 3), device="cuda:0", point_stride=FRAME_PAIR_POINT_STRIDE)
+    batch.run_scheduled(**{k: v for k, v in FRAME_PAIR_SCHEDULE.items() if k != "check_every"})
+    torch.cuda.synchronize()
+    assert (npy(batch.phase) == 4).all()
+    poses, klds = npy(batch.poses()), [npy(k) for k in batch.klds()]
+    for m, pr in enumerate(prs):
+        e = pose_depth_errors(poses[m], klds[m], pr.pose_gt, pr.kld_gt)
+        assert e[0] <= 1e-4 and e[1] <= 1.5e-4 and e[2] <= 1.2e-3, (m, e)

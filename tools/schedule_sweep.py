@@ -89,9 +89,41 @@ def trace():
     print(f"total {sum(r[0] for r in rounds) * 1e3:.2f} ms")
 
 
+
+
+def scenes(n=48):
+    """The quoted schedule on n DISTINCT synthetic scenes (bench.py renders 4 and copies them): worst error of each against its
+    ground truth, with the decimated coarse levels and on all points."""
+    import super_primitive_amd.optim.pair_batch as pb
+    from super_primitive_amd import synth
+    prs = [synth.make_pair(480, 640, 64, seed=2000 + s, overlap=4, init_sigma=0.004) for s in range(n)]
+    batch = pb.PairBatch.from_synth(prs, levels=(0, 3), device="cuda:0", point_stride=pb.FRAME_PAIR_POINT_STRIDE)
+    kw = {k: v for k, v in pb.FRAME_PAIR_SCHEDULE.items() if k != "check_every"}
+    for label, use_coarse in (("decimated coarse levels", True), ("all points at every level", False)):
+        batch.restore_initial()
+        n_it = batch.run_scheduled(use_coarse=use_coarse, **kw)
+        torch.cuda.synchronize()
+        P, K = batch.poses().double().cpu().numpy(), [k.double().cpu().numpy() for k in batch.klds()]
+        errs = []
+        for m, gt in enumerate(prs):
+            ls = float(np.mean(gt.kld_gt - K[m]))
+            R = P[m][:3, :3].T @ gt.pose_gt[:3, :3].astype(np.float64)
+            rot = float(np.arctan2(0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]), 0.5 * (np.trace(R) - 1)))
+            errs.append((rot, float(np.abs(P[m][:3, 3] * np.exp(ls) - gt.pose_gt[:3, 3]).max()), float(np.abs(np.expm1(K[m] + ls - gt.kld_gt)).max())))
+        e = np.array(errs)
+        bad = [m for m in range(n) if e[m, 0] > 1e-4 or e[m, 1] > 1.5e-4 or e[m, 2] > 1.2e-3]
+        its = (batch.lm_state[:, 2] + batch.lm_state[:, 3]).cpu().numpy()
+        print(f"{n} distinct scenes, {label}: launched {n_it}, iterations per pair {its.mean():.1f} (max {int(its.max())}); worst rot {e[:, 0].max():.1e} "
+              f"t {e[:, 1].max():.1e} depth {e[:, 2].max():.1e}; median depth {np.median(e[:, 2]):.1e}; outside the bar: {bad}", flush=True)
+        for m in bad:
+            print(f"   scene seed {2000 + m}: rot {e[m, 0]:.1e} t {e[m, 1]:.1e} depth {e[m, 2]:.1e}")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "trace":
         sys.argv.pop(1)
         trace()
+    elif len(sys.argv) > 1 and sys.argv[1] == "scenes":
+        scenes(int(sys.argv[2]) if len(sys.argv) > 2 else 48)
     else:
         main()
