@@ -123,25 +123,20 @@ def stage(arrays, dev):
     return out
 
 
-def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
+def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev):
     """Everything PairBatch needs from the raw frames, for the M0 given pairs.
 
     coarse: [(level, stride)] -- ADDITIONAL decimated tables (stride > 1) sampled at that level; the stride-1 tables are
     always built and sampled at every level.  Returns dict(tabs {stride: PreparedTables}, kp_L (sum N,),
-    trg {level: (flat HWC3, trg_off, [(Hl, Wl)])}, n_off, shapes (M0, 3) = N, H, W)."""
+    trg {level: (flat HWC3, trg_off, [(Hl, Wl)])}, n_off, shapes (M0, 3) = N, H, W, Ks (2 M0, 3, 3) = the source and target
+    intrinsics on the HOST, for the descriptors)."""
     lib = _lib.load()
     M0 = len(src_frames)
     s_ptr = _lib.stream_ptr()
     masks = [f.keypoint_regions.contiguous() for f in src_frames]
     for m in masks:
         assert m.dtype == torch.bool and m.dim() == 3
-    logd = [_dev(f.logdepth_perseg, dev) for f in src_frames]
-    kps = [_dev(f.keypoints, dev) for f in src_frames]
-    simg = [_dev(f.image[:3], dev) for f in src_frames]
-    timg = [_dev(t[:3], dev) for t in trg_images]
-    Ksrc = [_dev(f.K, dev) for f in src_frames]
-    kld = [_dev(k, dev) for k in klds]
-    _lib.require_device(*masks, *logd, *simg, *timg)
+    _lib.require_device(*masks)
     shp = np.array([m.shape for m in masks], dtype=np.int64)                     # (M0, 3): N, H, W
     Ns, Hs, Ws = shp[:, 0], shp[:, 1], shp[:, 2]
     if (Hs > 32767).any() or (Ws > 65535).any():
@@ -161,13 +156,33 @@ def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
     row_counts = torch.empty(nS * int(rc_off[-1]), dtype=torch.int32, device=dev)
     counts_d = torch.empty(nS * S, dtype=torch.int32, device=dev)
     recs = np.zeros(M0, dtype=_TABLE_DT)
-    recs['masks'], recs['logdepth'], recs['keypoints'] = _ptrs(masks), _ptrs(logd), _ptrs(kps)
+    recs['masks'] = _ptrs(masks)
     recs['N'], recs['H'], recs['W'], recs['n_strides'] = Ns, Hs, Ws, nS
     for si, s in enumerate(all_strides):
         recs['stride'][:, si] = s
         recs['row_counts'][:, si] = row_counts.data_ptr() + 4 * (si * int(rc_off[-1]) + rc_off[:-1])
         recs['counts'][:, si] = counts_d.data_ptr() + 4 * (si * S + n_off[:-1])
     max_rows, max_N = int(rows.max()), int(Ns.max())
+    staged = stage([recs], dev)
+    _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
+    counts_pinned = torch.empty(nS * S, dtype=torch.int32, pin_memory=True)
+    counts_pinned.copy_(counts_d, non_blocking=True)
+    counts_ready = torch.cuda.Event()
+    counts_ready.record()
+
+    # the other inputs are gathered while the masks are being counted
+    logd = [_dev(f.logdepth_perseg, dev) for f in src_frames]
+    kps = [_dev(f.keypoints, dev) for f in src_frames]
+    simg = [_dev(f.image[:3], dev) for f in src_frames]
+    timg = [_dev(t[:3], dev) for t in trg_images]
+    Ksrc = [_dev(f.K, dev) for f in src_frames]
+    kld = [_dev(k, dev) for k in klds]
+    _lib.require_device(*logd, *simg, *timg)
+    recs['logdepth'], recs['keypoints'] = _ptrs(logd), _ptrs(kps)
+    Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)      # complete once the counts have been waited for
+    Ks_pinned.copy_(torch.stack([k.reshape(3, 3) for k in Ksrc + [_dev(k, dev) for k in trg_Ks]]), non_blocking=True)
+    Ks_ready = torch.cuda.Event()
+    Ks_ready.record()
 
     # image pyramids of both frames and packed targets: independent of the counts, enqueued before the host waits for them
     max_level = max(level_ids)
@@ -196,15 +211,10 @@ def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
         jb['inp'], jb['out'] = ptr_lv[l][1], buf.data_ptr() + 4 * off[:-1]
         jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
         trg[l] = (buf, off, [(int(h), int(w)) for h, w in hw[l]])
-    staged = stage([recs, pack_jobs] + blur_jobs, dev)
-    _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
-    counts_pinned = torch.empty(nS * S, dtype=torch.int32, pin_memory=True)
-    counts_pinned.copy_(counts_d, non_blocking=True)
-    counts_ready = torch.cuda.Event()
-    counts_ready.record()
+    staged = stage([pack_jobs] + blur_jobs, dev)
     for l in range(1, max_level + 1):
-        _lib.check(lib.sp_prepare_blur(_lib.ptr(staged[1 + l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
-    _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[1]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
+        _lib.check(lib.sp_prepare_blur(_lib.ptr(staged[l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
+    _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
                "sp_prepare_pack")
 
     # ---- host: padded layouts; device: fill straight into them ----
@@ -266,4 +276,5 @@ def prepare_pairs(src_frames, trg_images, klds, level_ids, coarse, dev):
     del pyramid
     # (temporaries -- job records, row counts, pyramid levels -- are released here; the caching allocator orders their reuse
     #  after the launches above on this stream)
-    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp)
+    Ks_ready.synchronize()
+    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp, Ks=Ks_pinned.numpy())

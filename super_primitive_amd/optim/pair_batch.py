@@ -154,11 +154,8 @@ class PairBatch:
         coarse_keys = sorted({(l, s) for l, s in self.point_stride.items() if s > 1} | {(int(l), int(s)) for l, s in extra_tables if int(s) > 1})
 
         # tables, pyramids, source samples and packed targets of the base pairs: a dozen launches, one host synchronisation
-        # (optim/batch_prepare.py).  The intrinsics come back to the host for the descriptors: their copy is enqueued first and
-        # is complete once prepare_pairs has waited for its segment counts
-        Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)
-        Ks_pinned.copy_(torch.stack([batch_prepare._dev(k, dev).reshape(3, 3) for k in [f.K for f in src_frames] + list(trg_Ks)]), non_blocking=True)
-        prep = batch_prepare.prepare_pairs(src_frames, trg_images, klds, self.level_ids, coarse_keys, dev)
+        # (optim/batch_prepare.py)
+        prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev)
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
         rep = (lambda x: x) if R == 1 else (lambda x: x.repeat(*([R] + [1] * (x.dim() - 1))))
         tile = (lambda a: a) if R == 1 else (lambda a: np.tile(a, R))
@@ -227,7 +224,7 @@ class PairBatch:
             lay.chunks, lay.spans, lay.seg_tile_off = staged[4 + 3 * i: 7 + 3 * i]
 
         # descriptors, one array per level (numpy view of struct SpPair, filled column-wise)
-        Ks = Ks_pinned.numpy()
+        Ks = prep['Ks']
         Ks_src, Ks_trg = Ks[:M0], Ks[M0:]
         k4 = lambda K: np.tile(np.stack((K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]), axis=1).astype(np.float32), (R, 1))
         HW = np.tile(prep['shapes'][:, 1:].astype(np.int32), (R, 1))                    # full-resolution source size

@@ -7,8 +7,9 @@ with the other batch's work: a producer builds ``PairBatch`` objects one batch a
 the schedule on the optimisation stream, an event orders "built" before "optimise", and a batch's arrays stay referenced until
 its results have been read.  Frame pairs are independent problems, so nothing else is shared.
 
-Measured (tools/stream_bench.py, 640x480x64 pairs from raw frames): +11 % at 384 pairs per batch (11.6 k -> 12.9 k pairs/s), +4 %
-at 128, none at 64 -- both halves are mostly GPU-bound, so the overlap only recovers the idle gaps.
+Measured (tools/stream_bench.py, 640x480x64 pairs from raw frames, a long-lived PairStream): +14 ... +16 % at 64-128 pairs per
+batch, nothing at 384 (where one batch alone already keeps the GPU busy) -- both halves are mostly GPU-bound, so the overlap only
+recovers idle gaps.
 """
 from __future__ import annotations
 
