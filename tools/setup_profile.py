@@ -26,6 +26,7 @@ def build(**kw):
 
 for kw in ({}, {"point_stride": FRAME_PAIR_POINT_STRIDE}):
     build(**kw)
+    build(**kw)                    # (twice: the allocator's pools settle on the second pass)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(3):
