@@ -368,7 +368,8 @@ def main(argv=None):
             #     the rendered pairs, so nothing is shared between pairs.
             from super_primitive_amd.image.keyframe import KeyFrame
             from super_primitive_amd.optim.pair_batch import PairBatch
-            n_raw = M
+            raw_bytes = 5 * pairs[0].keypoint_regions.size + 24 * H * W            # masks + dense seeds + two images, per pair
+            n_raw = max(1, min(M, int(64e9 // raw_bytes)))                         # at most 64 GB of raw frames
             up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
             base = [dict(img=up(p.src_image), K=up(p.K), L=up(p.logdepth_perseg), kp=up(p.keypoints), m=up(p.keypoint_regions), trg=up(p.trg_image),
                          kld=up(p.kld_init)) for p in pairs]
