@@ -279,7 +279,35 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
     float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
 #pragma unroll
     for (int i = 0; i < SP_PREP_ROWS * SP_PREP_MAX_STRIDES; ++i) acc[i] = 0.f;
-    if ((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0 && wpr <= 256) {
+    // lattice masks of the strides that divide 4 do not depend on the position of the word: taken out of the loops
+    uint32_t sel[SP_PREP_MAX_STRIDES];
+    bool fixed = true;
+#pragma unroll
+    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+        const int st = k < t.n_strides ? t.stride[k] : 1;
+        sel[k] = k < t.n_strides ? lattice_bytes(0, st) : 0u;
+        fixed = fixed && (st == 1 || st == 2 || st == 4);
+    }
+    if ((t.W & 15) == 0 && ((uintptr_t)t.masks & 15) == 0 && t.W <= 1024) {
+        // 16 bytes per lane: a row of up to 1024 pixels is ONE load per lane
+        const int qpr = t.W >> 4;
+        const uint4* mq = reinterpret_cast<const uint4*>(t.masks) + (size_t)row0 * qpr;
+        uint4 w[SP_PREP_ROWS];
+#pragma unroll
+        for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
+            w[rr] = (row0 + rr < rows && lane < qpr) ? mq[(size_t)rr * qpr + lane] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
+            const uint32_t ws[4] = {w[rr].x, w[rr].y, w[rr].z, w[rr].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t nz = nonzero_bytes(ws[q]);
+#pragma unroll
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                    acc[rr * SP_PREP_MAX_STRIDES + k] += (float)__popc(nz & (fixed ? sel[k] : (k < t.n_strides ? lattice_bytes(16 * lane + 4 * q, t.stride[k]) : 0u)));
+            }
+        }
+    } else if ((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0 && wpr <= 256) {
         const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks) + (size_t)row0 * wpr;
         uint32_t w[SP_PREP_ROWS][4];
 #pragma unroll
@@ -296,7 +324,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
                 const uint32_t nz = nonzero_bytes(w[rr][q]);
 #pragma unroll
                 for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
-                    if (k < t.n_strides) acc[rr * SP_PREP_MAX_STRIDES + k] += (float)__popc(nz & lattice_bytes(4 * (q * 64 + lane), t.stride[k]));
+                    acc[rr * SP_PREP_MAX_STRIDES + k] += (float)__popc(nz & (fixed ? sel[k] : (k < t.n_strides ? lattice_bytes(4 * (q * 64 + lane), t.stride[k]) : 0u)));
             }
     } else {
 #pragma unroll
