@@ -354,24 +354,43 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* _
     segment_row_scan(t.row_counts[k] + (size_t)blockIdx.x * t.H, t.H, t.counts[k] + blockIdx.x);
 }
 
-// Ordered compaction of (segment,row) rows into every lattice's table; a wave takes SP_PREP_ROWS consecutive rows and
-// skips the empty ones on their row count alone (a segment covers a small part of the image: most rows of its mask are
-// empty and are not read again).  Word path: a lane owns 4 consecutive pixels; its rank inside the row is the prefix sum
-// over lower lanes of their set-pixel counts (0..4), taken from three ballots of the count's bits.
+// Ordered compaction of (segment,row) rows into every lattice's table.  A workgroup takes 256 consecutive rows, one thread per
+// row decides from the row counts alone which of them are non-empty (a segment covers a small part of the image: ~85 % of its mask
+// rows are empty and are not read again) and the four waves share those.  Word path: a lane owns 4 consecutive pixels; its
+// rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken from three ballots of the
+// count's bits.
+#define SP_FILL_ROWS SP_BLOCK
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __restrict__ tables) {
     const SpPrepTable& t = tables[blockIdx.y];
     const int rows = t.N * t.H;
-    const int row0 = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * SP_PREP_ROWS;
-    const int lane = threadIdx.x & 63;
-    const bool words = (t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0;
+    const int row_base = blockIdx.x * SP_FILL_ROWS;
+    if (row_base >= rows) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_rows[SP_FILL_ROWS];
+    __shared__ int s_cnt[SP_WAVES];
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (int row_id = row0; row_id < min(row0 + SP_PREP_ROWS, rows); ++row_id) {
-        const int n = row_id / t.H, r = row_id - n * t.H;
-        if (t.stride[0] == 1) {          // lattice 0 holds every mask pixel: its row count says whether the row is empty
+    {   // one thread per row: is it empty?  then a block-wide ordered compaction of the non-empty ones
+        const int row = row_base + (int)threadIdx.x;
+        bool todo = row < rows;
+        if (todo && t.stride[0] == 1) {      // lattice 0 holds every mask pixel: its row count says whether the row is empty
+            const int n = row / t.H, r = row - n * t.H;
             const int32_t* rc = t.row_counts[0];
-            const int next = (r + 1 < t.H) ? rc[row_id + 1] : t.counts[0][n];
-            if (next == rc[row_id]) continue;
+            const int next = (r + 1 < t.H) ? rc[row + 1] : t.counts[0][n];
+            todo = next != rc[row];
         }
+        const unsigned long long bal = __ballot(todo);
+        if (lane == 0) s_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = 0;
+        for (int w = 0; w < wave; ++w) off += s_cnt[w];
+        if (todo) s_rows[off + __popcll(bal & below)] = row;
+        __syncthreads();
+    }
+    const int s_n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    const bool words = (t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0;
+    for (int i = wave; i < s_n; i += SP_WAVES) {
+        const int row_id = s_rows[i];
+        const int n = row_id / t.H, r = row_id - n * t.H;
         if (!words) {
             for (int k = 0; k < t.n_strides; ++k)
                 fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
@@ -538,8 +557,7 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
 int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int per_block = SP_WAVES * SP_PREP_ROWS;
-    hipLaunchKernelGGL(k_prep_fill, dim3((max_rows + per_block - 1) / per_block, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    hipLaunchKernelGGL(k_prep_fill, dim3((max_rows + SP_FILL_ROWS - 1) / SP_FILL_ROWS, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_keypoint_L, dim3((max_N + 63) / 64, n_tables), dim3(64), 0, s, tables);
     SP_CHECK_LAUNCH();
