@@ -36,20 +36,32 @@ class PairStream:
         self.setup_stream = torch.cuda.Stream(self.device)
         self.optim_stream = torch.cuda.Stream(self.device)
 
-    def _producer(self, inputs, out, ready_for_inputs):
+    def _producer(self, inputs, out, ready_for_inputs, stop):
+        def put(item):                       # never blocks for good: the consumer may have gone away
+            while not stop.is_set():
+                try:
+                    out.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         try:
             torch.cuda.set_device(self.device)
             with torch.cuda.stream(self.setup_stream):
                 self.setup_stream.wait_event(ready_for_inputs)
                 for item in inputs:
+                    if stop.is_set():
+                        return
                     batch = PairBatch(item["src_frames"], item["trg_images"], item["trg_Ks"], item["poses"], item["klds"], levels=self.levels,
                                       point_stride=self.point_stride, **self.batch_kw)
                     built = torch.cuda.Event()
                     built.record(self.setup_stream)
-                    out.put((batch, built))
-            out.put(None)
+                    if not put((batch, built)):
+                        return
+            put(None)
         except BaseException as e:          # surfaces in the consumer
-            out.put(e)
+            put(e)
 
     def run(self, inputs):
         """inputs: iterable of dict(src_frames, trg_images, trg_Ks, poses, klds) -- the arguments of PairBatch, device resident.
@@ -58,7 +70,8 @@ class PairStream:
         ready = torch.cuda.Event()
         ready.record(caller)                 # the inputs may still be in flight on the caller's stream
         built_q = queue.Queue(maxsize=self.depth)
-        worker = threading.Thread(target=self._producer, args=(inputs, built_q, ready), daemon=True)
+        stop = threading.Event()
+        worker = threading.Thread(target=self._producer, args=(inputs, built_q, ready, stop), daemon=True)
         worker.start()
         try:
             while True:
@@ -80,5 +93,6 @@ class PairStream:
                 caller.wait_event(done)
                 del batch
                 yield poses, klds
-        finally:
+        finally:                            # also when the caller abandons the generator early
+            stop.set()
             worker.join(timeout=60)

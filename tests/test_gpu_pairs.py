@@ -524,7 +524,8 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
     from super_primitive_amd.image import gaussian_pyramid
     from super_primitive_amd.segment_table import SegmentTable, packed_target
     prs = [synth.make_pair(60, 80, 6, seed=101), synth.make_pair(97, 131, 9, seed=102), synth.make_pair(48, 64, 1, seed=103)]
-    batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4))
+    batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), extra_tables=[(1, 3)])     # 3: not a divisor of 4
+    assert sorted(batch.coarse) == [(1, 2), (1, 3), (2, 4)]
     dev = batch.device
     for m, pr in enumerate(prs):
         masks, L, kp = T(pr.keypoint_regions).to(dev), T(pr.logdepth_perseg).to(dev), T(pr.keypoints).to(dev)
@@ -614,3 +615,10 @@ def test_pair_stream_overlaps_batches_and_returns_each_batch_s_own_result():
     bad = dict(items[0]); bad["klds"] = bad["klds"][:1]
     with pytest.raises(AssertionError):
         list(stream.run(iter([bad])))
+    # a caller that stops early does not leave the producer blocked
+    import time
+    gen = stream.run(iter(items * 3))
+    next(gen)
+    t0 = time.time()
+    gen.close()
+    assert time.time() - t0 < 10.0
