@@ -266,6 +266,22 @@ def main(argv=None):
 
     if dry:
         line["data"] = "DRY RUN (no measurement)"
+    if world > 1 and args.mode == "gn" and not args.no_extras:
+        # whole-job frame pairs per second: every rank runs the quoted schedule on its own pairs at the same time (barrier, max
+        # over ranks), from the initial values; one untimed pass first.  (On one GPU this is leg (c) of the extras below.)
+        from super_primitive_amd.optim.pair_batch import FRAME_PAIR_SCHEDULE
+        kw = {k: v for k, v in FRAME_PAIR_SCHEDULE.items() if k != "check_every"}
+        batch.restore_initial()
+        batch.run_scheduled(**kw)
+        batch.restore_initial()
+        barrier()
+        t1 = time.perf_counter()
+        batch.run_scheduled(**kw)
+        barrier()
+        dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        line["frame_pairs_per_sec"] = world * M / float(dt.item())
+        batch.restore_initial()
     if rank == 0 and not args.no_extras and not dry:
         # side measurements outside the timed region: (a) one pair alone (launch/latency bound, lives in the
         # Infinity Cache), (b) full coarse-to-fine schedule -> frame pairs per second

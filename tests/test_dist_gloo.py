@@ -139,6 +139,13 @@ class _FakeBatch:
     def algorithmic_bytes(self, level):
         return 20 * sum(self.Ps)
 
+    def restore_initial(self):
+        self.restored = getattr(self, "restored", 0) + 1
+
+    def run_scheduled(self, **kw):
+        self.scheduled = getattr(self, "scheduled", 0) + 1
+        return 1
+
 
 def _bench_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
@@ -155,7 +162,7 @@ def _bench_worker(rank, world, port, q):
     with contextlib.redirect_stdout(buf):
         bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "2", "--settle-ms", "0", "--dry-run"])
     out = buf.getvalue().strip()
-    q.put((rank, json.loads(out) if out else None, fake.calls))
+    q.put((rank, json.loads(out) if out else None, fake.calls, fake.scheduled, fake.restored))
 
 
 def test_bench_multi_rank_control_flow_dry_run_world2():
@@ -179,3 +186,5 @@ def test_bench_multi_rank_control_flow_dry_run_world2():
     assert line0["config"]["pairs_per_gpu"] == 6 and line0["data"].startswith("DRY RUN")
     np.testing.assert_allclose(line0["value"], 2 * 6 * 3 / (line0["ms_per_step"] * 3e-3), rtol=1e-6)     # whole-job aggregate
     assert got[0][2] == got[1][2] == 2 + 3                                                            # warm-up + timed cost passes
+    # the whole-job frame-pair leg: every rank ran the schedule twice (one untimed pass) from restored initial values
+    assert got[0][3] == got[1][3] == 2 and got[0][4] == got[1][4] == 3 and line0["frame_pairs_per_sec"] > 0
