@@ -182,6 +182,12 @@ def test_bench_multi_rank_control_flow_dry_run_world2():
         assert p.exitcode == 0
     line0, line1 = got[0][1], got[1][1]
     assert line1 is None, "only rank 0 prints"
+    # the driver's contract: every key of the bench line, plus the roofline object (cpu_baseline is an N = 1 leg)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in line0, key
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line0["roofline"]) and line0["roofline"]["bound"] == "hbm"
+    assert "workload" in line0["config"] and line0["unit"] == "iters/s" and line0["higher_is_better"] is True and line0["vs_baseline"] is None
     assert line0["n_gpus"] == 2 and line0["steps"] == 3 and line0["warmup"] == 2 and line0["scaling"] == "weak"
     assert line0["config"]["pairs_per_gpu"] == 6 and line0["data"].startswith("DRY RUN")
     np.testing.assert_allclose(line0["value"], 2 * 6 * 3 / (line0["ms_per_step"] * 3e-3), rtol=1e-6)     # whole-job aggregate
