@@ -523,7 +523,10 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
     from super_primitive_amd import synth
     from super_primitive_amd.image import gaussian_pyramid
     from super_primitive_amd.segment_table import SegmentTable, packed_target
-    prs = [synth.make_pair(60, 80, 6, seed=101), synth.make_pair(97, 131, 9, seed=102), synth.make_pair(48, 64, 1, seed=103)]
+    # widths that take each load path of the count / fill passes: 80, 64 (16-byte words), 84 (4-byte words), 131 (bytes),
+    # 1040 (wider than the one-load-per-row fast paths)
+    prs = [synth.make_pair(60, 80, 6, seed=101), synth.make_pair(97, 131, 9, seed=102), synth.make_pair(48, 64, 1, seed=103),
+           synth.make_pair(50, 84, 4, seed=104), synth.make_pair(24, 1040, 2, seed=105)]
     batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), extra_tables=[(1, 3)])     # 3: not a divisor of 4
     assert sorted(batch.coarse) == [(1, 2), (1, 3), (2, 4)]
     dev = batch.device
