@@ -333,3 +333,28 @@ def test_vectorised_layout_and_work_list_equal_the_per_pair_ones():
     # nothing at all
     got = batch_prepare.flat_work_list(np.zeros(3, np.int64), np.zeros(3, np.int64), np.array([0, 3]), 1024, 1024)
     assert got['chunks'].shape == (0, 4) and got['spans'].shape == (0, 4) and np.array_equal(got['seg_tile_off'], [0, 0, 0, 0])
+
+
+def test_vectorised_work_list_equals_the_loop_on_random_layouts():
+    """Property test (hypothesis): for random segment counts (empty segments, segments longer than a chunk, single-segment
+    pairs), chunk and span sizes, flat_layout / flat_work_list reproduce pad_layout / build_work_list exactly."""
+    from hypothesis import given, settings, strategies as st
+    from super_primitive_amd.optim import batch_prepare
+    from super_primitive_amd.optim.pair_batch import build_work_list, pad_layout
+
+    pair = st.lists(st.one_of(st.just(0), st.integers(1, 9000)), min_size=1, max_size=12)
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.lists(pair, min_size=1, max_size=5), st.sampled_from([256, 512, 1000, 2048, 8192]), st.sampled_from([256, 700, 4096, 16384, 10 ** 6]))
+    def check(counts, tile_points, span_points):
+        pads = [pad_layout(np.asarray(c), "cpu") for c in counts]
+        ref = build_work_list(pads, span_points, tile_points)
+        n_off = np.concatenate(([0], np.cumsum([len(c) for c in counts])))
+        pc, seg_pos, p_off = batch_prepare.flat_layout(np.concatenate([np.asarray(c) for c in counts]), n_off)
+        got = batch_prepare.flat_work_list(pc, seg_pos, n_off, span_points, tile_points)
+        assert np.array_equal(got['chunks'], ref['chunks']) and np.array_equal(got['spans'], ref['spans'])
+        assert np.array_equal(got['seg_tile_off'], np.concatenate(ref['seg_rec_offs']))
+        assert np.array_equal(got['c_off'], ref['c_off']) and np.array_equal(got['s_off'], ref['s_off'])
+        assert np.array_equal(np.diff(p_off), [pd['Ppad'] for pd in pads])
+
+    check()
