@@ -186,7 +186,12 @@ def kf_fix_disconnected_regions(kf, filter_size=3, depth_threshold=0.1, area_kee
     ``mask_by_depth_discontinuity`` with its default filter/threshold (the arguments only feed the unused count)."""
     split = mask_by_depth_discontinuity(kf.logdepth_perseg, kf.keypoint_regions)
     new_mask, new_logdepth, new_keypoints = post_process_kf(kf, None, keep_ratio=area_keep_ratio, _split=split)
-    kf_new = copy.deepcopy(kf)        # post_processer.py:176 of the reference: a deep copy, nothing aliased
+    # post_processer.py:176 of the reference: a deep copy, nothing aliased.  Tensor.__deepcopy__ also copies the tensors'
+    # __dict__, i.e. the caches hanging off them (segment table with up to 8 sampled levels, packed target): drop those first --
+    # the masks / log-depths they describe are replaced right below anyway
+    from ... import segment_table
+    segment_table.invalidate(kf)
+    kf_new = copy.deepcopy(kf)
     kf_new.logdepth_perseg = new_logdepth
     kf_new.keypoint_regions = new_mask
     kf_new.keypoints = new_keypoints

@@ -65,7 +65,13 @@ class SfM:
         self.src_depth_keypoints_opt = nn.Parameter(kld_init.detach().clone().float().to(dev))
         self.instatiate_optimisation()
 
+    def _drop_window(self):
+        """The fused engine's window owns copies of the log-depths, tangents and Adam moments: anything that replaces or
+        edits the parameters outside ``_run_fused`` invalidates it (the next fused run rebuilds it from the parameters)."""
+        self._window = None
+
     def instatiate_optimisation(self):
+        self._drop_window()
         self.adam_params = [{'params': self.src_depth_keypoints_opt, 'lr': 1e-3},
                             {'params': [pose for _, pose, _ in self.supp_frames if isinstance(pose, LieGroupParameter)], 'lr': 1e-2}]
         self.optim = torch.optim.Adam(self.adam_params, lr=1e-3)
@@ -88,6 +94,8 @@ class SfM:
         n_levels = al['pyramid_max'] - al['pyramid_min']
         iters = num_iters or self.num_iters
         win = self._window
+        if win is not None and not self._window_in_sync(win):
+            win = self._window = None                                # parameters were edited behind the window's back
         if win is None:
             nodes = []
             for frame, current_T, _ in self.supp_frames:
@@ -122,8 +130,21 @@ class SfM:
                     current_T.data.copy_(tang[f][None])
         return self
 
+    def _window_in_sync(self, win):
+        """True when the window's log-depths and tangents are still the values of the parameters (they are written back at the
+        end of every fused run; an in-place edit of a parameter in between shows up here)."""
+        with torch.no_grad():
+            if not torch.equal(win.klds()[0], self.src_depth_keypoints_opt.detach().to(win.device)):
+                return False
+            tang = win.node_tangents()
+            for f, (_, current_T, _) in enumerate(self.supp_frames):
+                if isinstance(current_T, LieGroupParameter) and not torch.equal(tang[f], current_T.detach().as_subclass(torch.Tensor)[0].to(win.device)):
+                    return False
+        return True
+
     def _run_eager(self, lr_scale=1.0, levels=None, num_iters=None):
         al = self.config['aligment']
+        self._drop_window()                                          # this engine moves the parameters: the fused window's copies go stale
         if lr_scale != self._lr_scale:                               # a fresh Adam at the new rates
             self.adam_params = [{'params': self.src_depth_keypoints_opt, 'lr': 1e-3 * lr_scale},
                                 {'params': [pose for _, pose, _ in self.supp_frames if isinstance(pose, LieGroupParameter)],
@@ -171,6 +192,7 @@ class SfM:
         if len(self.supp_frames) != 1:
             raise NotImplementedError("run_on_device handles one supporting frame; use run() for several")
         al = self.config['aligment']
+        self._drop_window()
         frame, current_T, pose_to_mat = self.supp_frames[0]
         with torch.no_grad():
             pose0 = pose_to_mat(current_T).detach().clone()

@@ -24,7 +24,8 @@ from .pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
 class PairStream:
     def __init__(self, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, schedule=None, device="cuda:0", depth=1, **batch_kw):
         """``schedule``: keyword arguments of ``PairBatch.run_scheduled`` (default: FRAME_PAIR_SCHEDULE); ``depth``: how many
-        built batches may wait for the optimiser (each holds its tables in device memory); ``batch_kw``: passed to PairBatch.
+        built batches may wait for the optimiser (each holds its tables in device memory; peak residency is ``depth`` + 2
+        batches: one being built, ``depth`` queued, one being optimised); ``batch_kw``: passed to PairBatch.
         Meant to be long-lived: the caching allocator keeps one pool per stream, so a PairStream reuses its tables' memory
         from batch to batch, while a fresh one (fresh streams) pays for device allocations again."""
         self.levels, self.point_stride, self.batch_kw = levels, point_stride, batch_kw
@@ -57,7 +58,9 @@ class PairStream:
                                       point_stride=self.point_stride, **self.batch_kw)
                     built = torch.cuda.Event()
                     built.record(self.setup_stream)
-                    if not put((batch, built)):
+                    ok = put((batch, built))
+                    del batch                # the queue (then the consumer) holds the only reference: at most depth + 2 batches are
+                    if not ok:               # resident -- one being built, ``depth`` waiting, one being optimised
                         return
             put(None)
         except BaseException as e:          # surfaces in the consumer
@@ -85,6 +88,12 @@ class PairStream:
                     self.optim_stream.wait_event(built)
                     batch.run_scheduled(**self.schedule)
                     poses, klds = batch.poses().clone(), [k.clone() for k in batch.klds()]
+                    # the results were allocated in the optimisation stream's pool and are consumed on the caller's stream:
+                    # tell the allocator, so that a block the caller drops is not handed to the next batch's clone() while
+                    # caller-stream work on it is still queued
+                    poses.record_stream(caller)
+                    for k in klds:
+                        k.record_stream(caller)
                     done = torch.cuda.Event()
                     done.record(self.optim_stream)
                 # the batch (allocated on the set-up stream, used on the optimisation stream) is released only after the

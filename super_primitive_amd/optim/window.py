@@ -59,7 +59,7 @@ class PoseWindow:
         for k, (s, tab) in enumerate(zip(sources, tables)):
             lv = _level_images(s['kf'].image[:3].float(), max_level)
             for l in self.level_ids:
-                self.src4[(k, l)] = pad_points(tab.source_level(lv[l], s['kf'].K, s['kld'].to(dev)).reshape(-1, 4), pads[k]).reshape(-1)
+                self.src4[(k, l)] = pad_points(tab.source_level(lv[l], s['kf'].K, s['kld'].to(dev), cache=False).reshape(-1, 4), pads[k]).reshape(-1)
         self.pix = [pad_points(t.pix, pd) for t, pd in zip(tables, pads)]          # after source_level(): validity bits set
         self.kp_L = [t.kp_L for t in tables]
         # ---- log-depth blocks ----------------------------------------------------------------------------------

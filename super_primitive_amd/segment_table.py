@@ -110,12 +110,16 @@ class SegmentTable:
         self.seg_tile_off = torch.from_numpy(sto).to(self.device)
 
     # -- per-level source samples ---------------------------------------------------------------
-    def source_level(self, image, K, kld):
+    def source_level(self, image, K, kld, cache=True):
         """{rgb at this level, baseL} per point, cached per (image, K) object identity.  The first call after the table
-        is built also sets the source-validity bit of ``pix`` (geometry only; shared by every level)."""
-        for idents, hit in self._levels:
-            if _same(idents, (image, K)):
-                return hit
+        is built also sets the source-validity bit of ``pix`` (geometry only; shared by every level; it assumes depths
+        above the reference's 1e-7 floor, i.e. finite log-depth seeds -- DESIGN.md section 5).  ``cache=False``: callers
+        that pass freshly built pyramid tensors on every call (optim/window.py) would never hit the identity-keyed cache
+        and only pin dead level images and their samples -- nothing is looked up or kept for them."""
+        if cache:
+            for idents, hit in self._levels:
+                if _same(idents, (image, K)):
+                    return hit
         _lib.require_device(image, K, kld)
         lib = _lib.load()
         img = image[:3].detach().contiguous().float()
@@ -129,9 +133,10 @@ class SegmentTable:
                                               0 if self._validity_set else 1, _lib.stream_ptr()),
                    "sp_table_sample_source")
         self._validity_set = True
-        if len(self._levels) >= 16:
-            del self._levels[0]
-        self._levels.append(((_Ident(image), _Ident(K)), src4))
+        if cache:
+            if len(self._levels) >= 8:
+                del self._levels[0]
+            self._levels.append(((_Ident(image), _Ident(K)), src4))
         return src4
 
 

@@ -125,3 +125,50 @@ def test_sfm_run_on_device_reaches_the_same_optimum(mode):
     assert ang(pb, pair.pose_gt) < 5e-3 and ang(pa, pair.pose_gt) < 2e-2
     np.testing.assert_allclose(kb, pair.kld_gt, atol=2e-2)
     np.testing.assert_allclose(pb[:3, 3] / sb, pair.pose_gt[:3, 3], atol=1e-2)
+
+
+def test_fused_sfm_window_follows_parameter_changes_between_runs():
+    """the fused engine caches a PoseWindow with its own copies of the log-depths / tangents / Adam moments.  A new
+    ``init_optimisation``, an eager run, ``run_on_device`` or an in-place edit of a parameter between two fused runs must not
+    leave it optimising from stale values: the first loss of the next fused run is the cost AT THE CURRENT PARAMETERS."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.core import dense_optim
+    from super_primitive_amd.odometery.two_frame_sfm import SfM
+    from gpu_util import frames_from_synth
+    pair = synth.make_pair(60, 80, 6, seed=7, init_sigma=0.01, overlap=1)
+    cfg = {"aligment": {"pyramid_min": 0, "pyramid_max": 1, "cost_params": {}}}
+    src, trg = frames_from_synth(pair)
+
+    def cost_now(sfm):
+        with torch.no_grad():
+            out = dense_optim.photomeric_cost(src, trg, sfm.keypoint_logdepths(), sfm.poses()[0], {"mode": "colour", "collect_stats": 0})
+        return abs(float(out["residual"]))
+
+    sfm = SfM(cfg, src, [trg], [T(pair.pose_init)], num_iters=6)
+    sfm.init_optimisation(kld_init=T(pair.kld_init))
+    sfm.run(fused=True)
+    # (a) a new set of depth seeds
+    sfm.init_optimisation(kld_init=T(pair.kld_init + 0.05))
+    want = cost_now(sfm)
+    n0 = len(sfm.losses)
+    sfm.run(fused=True)
+    np.testing.assert_allclose(float(sfm.losses[n0]), want, rtol=2e-5)
+    # (b) an eager run in between
+    sfm.run(fused=False)
+    want = cost_now(sfm)
+    n0 = len(sfm.losses)
+    sfm.run(fused=True)
+    np.testing.assert_allclose(float(sfm.losses[n0]), want, rtol=2e-5)
+    # (c) the whole loop on the device in between (replaces the pose parameter)
+    sfm.run_on_device(mode="gn", iters_per_level=3)
+    want = cost_now(sfm)
+    n0 = len(sfm.losses)
+    sfm.run(fused=True)
+    np.testing.assert_allclose(float(sfm.losses[n0]), want, rtol=2e-5)
+    # (d) an in-place edit of the log-depth parameter
+    with torch.no_grad():
+        sfm.src_depth_keypoints_opt.add_(0.02)
+    want = cost_now(sfm)
+    n0 = len(sfm.losses)
+    sfm.run(fused=True)
+    np.testing.assert_allclose(float(sfm.losses[n0]), want, rtol=2e-5)
