@@ -284,6 +284,95 @@ def golden_config4(ref, name="g18_config4_void_shaped", seed=4, n_segments=1200)
     print(f"{name}: {time.time() - t0:.0f} s; {int(vis.sum())} visible of {n_segments}, coverage {1 - float(invalid.float().mean()):.3f}", flush=True)
 
 
+POLISH = ((0.3, 200), (0.1, 300), (0.03, 200), (0.01, 200), (0.003, 150), (0.001, 100))     # one polish round: fresh Adam per phase, lr x scale
+POLISH_SETTLED = (1e-5, 1e-5, 1e-4)      # rounds are repeated until the end state moves less than this (0.1 x the north-star bar)
+POLISH_MAX_ROUNDS = 4
+
+
+def reference_sfm_run(ref, pair, iters=500, polish=POLISH, log=None):
+    """The reference's two-frame SfM loop (two_frame_sfm.py:116-123,150-207: ONE Adam over all levels, 500 iterations per
+    level of a 3-level pyramid, no update on the very first iteration) around the real ``photomeric_cost`` from
+    (pair.kld_init, pair.pose_init), then a polish at the finest level with decaying learning rates (fresh Adam per phase,
+    like g15's minimiser) until Adam's fixed-step jitter is far below the 1e-4 bar.  Returns a dict of numpy arrays."""
+    src, trg = ref_frames(ref, pair)
+    sp = ref.kf.keyframe_pyramid(src, 0, 3)
+    tp = ref.kf.keyframe_pyramid(trg, 0, 3)
+    kld = torch.nn.Parameter(T(pair.kld_init))
+    a = torch.nn.Parameter(torch.zeros(1, 6))
+    T0 = T(pair.pose_init)
+    losses = []
+    opt = torch.optim.Adam([{"params": kld, "lr": 1e-3}, {"params": [a], "lr": 1e-2}], lr=1e-3)
+    for li, (s, t) in enumerate(zip(sp, tp)):
+        adam_run(ref, opt, s, t, kld, a, T0, iters, losses, skip_first=(li == 0), log=log and f"{log} level {li}")
+    with torch.no_grad():
+        out = dict(sched_kld=kld.detach().numpy().copy(), sched_pose=(orc.se3_exp(a)[0] @ T0).numpy())
+    n_sched = len(losses)
+    prev, moved, rounds = (out["sched_pose"], out["sched_kld"]), None, 0
+    while rounds < POLISH_MAX_ROUNDS:
+        for scale, n in polish:
+            adam_phase(ref, sp[-1], tp[-1], kld, a, T0, n, scale, losses, log=log and f"{log} polish {rounds} x{scale}")
+        rounds += 1
+        with torch.no_grad():
+            cur = ((orc.se3_exp(a)[0] @ T0).numpy(), kld.detach().numpy().copy())
+        moved = errors_vs(cur[0], cur[1], prev[0], prev[1], gauge=False)
+        prev = cur
+        if all(m <= b for m, b in zip(moved, POLISH_SETTLED)):
+            break
+    with torch.no_grad():
+        pose = orc.se3_exp(a)[0] @ T0
+        final = float(torch.mean(torch.abs(ref.do.photomeric_cost(sp[-1], tp[-1], kld, pose, CFG)["residual"])))
+    out.update(polish_rounds=np.int64(rounds), last_round_moved=np.array(moved), final_kld=kld.detach().numpy().copy(), final_pose=pose.numpy(), final_loss=np.float64(final),
+               sched_losses=np.array(losses[:n_sched], dtype=np.float64), polish_losses=np.array(losses[n_sched:], dtype=np.float64),
+               spread40=np.float64(np.ptp(losses[-40:])))
+    return out
+
+
+def errors_vs(pose, kld, pose_ref, kld_ref, gauge=True):
+    """(rot [rad], t [max abs], depth [max rel]); gauge=True: after removing the two-view scale gauge (tests/parity_util.py)."""
+    pose, pose_ref = np.asarray(pose, np.float64), np.asarray(pose_ref, np.float64)
+    kld, kld_ref = np.asarray(kld, np.float64), np.asarray(kld_ref, np.float64)
+    ls = float(np.mean(kld_ref - kld)) if gauge else 0.0
+    R = pose[:3, :3].T @ pose_ref[:3, :3]
+    rot = float(np.arctan2(0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]), 0.5 * (np.trace(R) - 1.0)))
+    return rot, float(np.abs(pose[:3, 3] * np.exp(ls) - pose_ref[:3, 3]).max()), float(np.abs(np.expm1(kld + ls - kld_ref)).max())
+
+
+SIGMA05_ARGS = dict(overlap=3, init_sigma=0.05, texture="octaves", init_mode="reference")
+CONVERGED_VS_GT = (2e-3, 2e-3, 2e-2)      # rot rad / t / relative depth against the synthetic ground truth (gauge removed)
+
+
+def golden_sigma05(ref, name="g19_sigma05_320x240x8", H=240, W=320, N=8, seeds=tuple(range(500, 512))):
+    """the reference's OWN starting distribution -- pose_init = T_gt * Exp(0.05 randn(6))
+    (two_frame_sfm.py:77-81), depth seeds log(2 + 2 rand) (:103-105) -- on a multi-octave (~1/f) texture, BASELINE configs[0]
+    shape.  For every scene the real reference loop (3 x 500 Adam + polish) is run; stored per scene: input digest, state after
+    the schedule, polished end state, final loss, errors against the ground truth and whether the run CONVERGED (inside
+    CONVERGED_VS_GT of the ground truth; a run that leaves a segment in a neighbouring basin of the texture does not)."""
+    t0 = time.time()
+    rows = []
+    for seed in seeds:
+        pair = synth.make_pair(H, W, N, seed=seed, **SIGMA05_ARGS)
+        r = reference_sfm_run(ref, pair)
+        e_gt = errors_vs(r["final_pose"], r["final_kld"], pair.pose_gt, pair.kld_gt)
+        e_sched = errors_vs(r["sched_pose"], r["sched_kld"], pair.pose_gt, pair.kld_gt)
+        e_init = errors_vs(pair.pose_init, pair.kld_init, pair.pose_gt, pair.kld_gt)
+        conv = all(e <= b for e, b in zip(e_gt, CONVERGED_VS_GT))
+        rows.append(dict(seed=seed, in_sha256=input_digest(pair), sched_kld=r["sched_kld"], sched_pose=r["sched_pose"],
+                         final_kld=r["final_kld"], final_pose=r["final_pose"], final_loss=r["final_loss"], spread40=r["spread40"],
+                         polish_rounds=r["polish_rounds"], last_round_moved=r["last_round_moved"],
+                         err_gt=np.array(e_gt), err_sched_gt=np.array(e_sched), err_init_gt=np.array(e_init), converged=conv,
+                         loss_every10=r["sched_losses"][::10].copy(), pose_gt=pair.pose_gt, kld_gt=pair.kld_gt,
+                         pose_init=pair.pose_init, kld_init=pair.kld_init))
+        print(f"  {name} seed {seed}: init err {e_init[0]:.3f} rad {e_init[1]:.3f} t {e_init[2]:.2f} d | after schedule {e_sched[0]:.1e} {e_sched[1]:.1e} "
+              f"{e_sched[2]:.1e} | polished ({int(r['polish_rounds'])} rounds, last moved {r['last_round_moved'][0]:.0e} {r['last_round_moved'][1]:.0e} {r['last_round_moved'][2]:.0e}) "
+              f"{e_gt[0]:.1e} {e_gt[1]:.1e} {e_gt[2]:.1e} loss {r['final_loss']:.6f} spread {r['spread40']:.1e} "
+              f"{'CONVERGED' if conv else 'not converged'} ({time.time() - t0:.0f} s)", flush=True)
+    save = {k: np.stack([np.asarray(r[k]) for r in rows]) for k in rows[0]}
+    save.update(HWN=np.array([H, W, N]), make_pair_args=np.array(f"H={H},W={W},N={N},overlap=3,init_sigma=0.05,texture=octaves,init_mode=reference"),
+                converged_vs_gt=np.array(CONVERGED_VS_GT), polish=np.array(POLISH))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: {time.time() - t0:.0f} s; converged {int(save['converged'].sum())} of {len(rows)}", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(int(os.environ.get("SP_GOLDEN_THREADS", "8")))
@@ -304,6 +393,11 @@ def main():
         golden_config3(ref)
     if "g18" in which:
         golden_config4(ref)
+    if "g19" in which:
+        golden_sigma05(ref)
+    if "g20" in which:
+        # the same at BASELINE configs[1] size (640x480x64), two scenes: minutes of CPU each
+        golden_sigma05(ref, name="g20_sigma05_640x480x64", H=480, W=640, N=64, seeds=(1000, 1001))
 
 
 if __name__ == "__main__":

@@ -43,6 +43,13 @@ GRANULE = 256                      # SP_BLOCK: every segment is padded to a mult
 FRAME_PAIR_POINT_STRIDE = (1, 2, 4)
 FRAME_PAIR_SCHEDULE = dict(max_iters_per_level=25, conv_tol=2e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-4, check_every=3)
 FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps=1e-5)
+# The schedule for the REFERENCE'S OWN starting distribution (odometery/two_frame_sfm.py:77-81,103-105: pose = T_gt Exp(0.05
+# randn(6)), depth seeds log(2 + 2 rand)): tests/test_gpu_sigma05.py requires it to converge wherever the real reference loop does
+# (golden g19), inside the north-star bar of the reference's end state; bench.py quotes ``frame_pairs_per_sec`` on it next to the
+# near-start figure (tools/sigma05_sweep.py holds the sweep it was chosen from, profiles/r03_sigma05_sweep.txt its results).
+REFERENCE_START_LEVELS = (0, 4)
+REFERENCE_START_POINT_STRIDE = (1, 2, 4, 8)
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE)
 
 
 def _level_images(img, max_level):
@@ -121,7 +128,8 @@ class PairBatch:
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
         ``config['aligment']`` (max exclusive).  ``replicate`` = R > 1 lays the M0 given pairs out R times in
         device memory (distinct copies of every array, poses/klds = ``poses[r*M0+m]`` when (R*M0,4,4) poses are
-        given): bench.py uses it to build a large streaming batch without uploading R*M0 dense keyframes.
+        given, log-depths = ``klds[r*M0+m]`` when R*M0 vectors are given): bench.py uses it to build a large streaming batch
+        without uploading R*M0 dense keyframes.
 
         Layout (include/sp_hip.h, "Work list"): the batch keeps its own PADDED copy of every table -- each segment's
         run of points extended to a multiple of 256 with invalid points -- so that a workgroup can stream through a SPAN
@@ -139,7 +147,7 @@ class PairBatch:
         M0 = len(src_frames)
         R = int(replicate)
         M = M0 * R
-        assert M0 == len(trg_images) == len(trg_Ks) == len(klds) and poses.shape[0] in (M0, M)
+        assert M0 == len(trg_images) == len(trg_Ks) and len(klds) in (M0, M) and poses.shape[0] in (M0, M)
         if poses.shape[0] == M0 and R > 1:
             poses = poses.repeat(R, 1, 1)
         dev = src_frames[0].image.device
@@ -155,6 +163,8 @@ class PairBatch:
 
         # tables, pyramids, source samples and packed targets of the base pairs: a dozen launches, one host synchronisation
         # (optim/batch_prepare.py)
+        klds_all = klds if len(klds) == M and R > 1 else None
+        klds = klds[:M0]
         prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev)
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
         rep = (lambda x: x) if R == 1 else (lambda x: x.repeat(*([R] + [1] * (x.dim() - 1))))
@@ -174,7 +184,11 @@ class PairBatch:
 
         # flat, pair-major device arrays
         self.kp_L = rep(kp_L)
-        self.kld = rep(torch.cat([batch_prepare._dev(k, dev).reshape(-1) for k in klds])).contiguous()
+        if klds_all is None:
+            self.kld = rep(torch.cat([batch_prepare._dev(k, dev).reshape(-1) for k in klds])).contiguous()
+        else:
+            self.kld = torch.cat([batch_prepare._dev(k, dev).reshape(-1) for k in klds_all]).contiguous()
+            assert self.kld.numel() == int(n_off[-1]), "one (N_m,) log-depth vector per replicated pair"
         self.pose = poses.detach().to(device=dev, dtype=torch.float32).reshape(M, 16).clone()       # owned: updated in place
         self.aff = torch.zeros(M, 4, dtype=torch.float32, device=dev) if use_affine else None
         self.pix = rep(full.pix)

@@ -79,7 +79,7 @@ def _texture(X, rng_tex, base_omega):
     out = []
     for ch in range(3):
         acc = np.full(X.shape[:-1], 0.5)
-        for k in range(6):
+        for k in range(rng_tex.shape[1]):
             direction = rng_tex[ch, k, :3]
             omega = base_omega * rng_tex[ch, k, 3]
             phase = rng_tex[ch, k, 4]
@@ -87,6 +87,24 @@ def _texture(X, rng_tex, base_omega):
             acc = acc + amp * np.sin(omega * (X @ direction) + phase)
         out.append(acc)
     return np.clip(np.stack(out, 0), 0.0, 1.0)
+
+
+def _octave_texture_table(rng, n_octaves, per_octave=4, slope=1.0, total_amp=0.45):
+    """Component table (3, n_octaves * per_octave, 6) of a multi-octave (~1/f) texture for ``_texture``: octave o has
+    ``per_octave`` randomly oriented sinusoids of period ``2^o x (1 ... 1.6) x`` the shortest one and amplitude proportional
+    to ``period^slope`` (slope 1 = a 1/f amplitude spectrum, what natural images roughly have), scaled so that the amplitudes of
+    a channel sum to ``total_amp``.  Coarse-to-fine alignment has structure to hold on to at every pyramid level -- unlike the
+    single-octave band texture, whose basin of attraction is half its shortest period at every level."""
+    n = n_octaves * per_octave
+    tex = np.empty((3, n, 6))
+    d = rng.standard_normal((3, n, 3))
+    tex[:, :, :3] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    period = (2.0 ** np.repeat(np.arange(n_octaves), per_octave))[None, :] * rng.uniform(1.0, 1.6, (3, n))
+    tex[:, :, 3] = 1.0 / period                    # omega multiplier relative to the shortest period
+    tex[:, :, 4] = rng.uniform(0, 2 * math.pi, (3, n))
+    amp = period ** slope * rng.uniform(0.7, 1.3, (3, n))
+    tex[:, :, 5] = total_amp * amp / amp.sum(axis=1, keepdims=True)
+    return tex
 
 
 def _grid_shape(N):
@@ -98,7 +116,7 @@ def _grid_shape(N):
 
 def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
               motion_scale=1.0, init_sigma=0.02, texture_period_px=None,
-              drop_border=0):
+              drop_border=0, texture="band", init_mode="left", octave_slope=1.0):
     """Render one seeded source/target pair.
 
     ``shape``: 'grid' = gh x gw rectangular tiling; 'blobs' =
@@ -110,9 +128,15 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
     ``log(2 + 2 rand)`` (two_frame_sfm.py:103-105) put a segment up to a factor 2 off in depth, i.e. ~8 px of disparity
     at 640x480; with a texture period that does not grow with the resolution such a segment starts outside the basin of
     attraction even at the coarsest of 3 pyramid levels, for the reference's Adam as for Gauss-Newton.
+    ``texture``: 'band' = that single-octave texture (six components per channel); 'octaves' = a multi-octave ~1/f texture
+    (``_octave_texture_table``; shortest period ``texture_period_px``, default 8 px per 320 columns, octaves up to about the
+    image width, amplitude ~ period^``octave_slope``) -- what the reference's own starting distribution needs.
+    ``init_mode``: 'left' = ``pose_init = Exp(sigma xi) T_gt`` (the default of every earlier golden); 'reference' =
+    ``T_gt Exp(sigma xi)``, the reference's ``current_T.mul(SE3.Random(sigma=0.05))`` (odometery/two_frame_sfm.py:77-81;
+    lietorch's Random is exp(sigma * randn(6)) on the tangent [tau, phi]).
     """
     if texture_period_px is None:
-        texture_period_px = 14.0 * max(1.0, W / 320.0)
+        texture_period_px = (8.0 if texture == "octaves" else 14.0) * max(1.0, W / 320.0)
     rng = np.random.default_rng(seed)
     fx = fy = 0.8 * W
     cx, cy = W / 2.0, H / 2.0
@@ -130,12 +154,18 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
     Xs = rays * depth[..., None]
 
     base_omega = 2.0 * math.pi / (texture_period_px * h / fx)
-    tex = np.empty((3, 6, 6))
-    d = rng.standard_normal((3, 6, 3))
-    tex[:, :, :3] = d / np.linalg.norm(d, axis=-1, keepdims=True)
-    tex[:, :, 3] = rng.uniform(0.35, 1.0, (3, 6))
-    tex[:, :, 4] = rng.uniform(0, 2 * math.pi, (3, 6))
-    tex[:, :, 5] = rng.uniform(0.04, 0.11, (3, 6))
+    if texture == "octaves":
+        n_oct = max(1, int(math.floor(math.log2(max(W, H) / texture_period_px))) + 1)
+        tex = _octave_texture_table(rng, n_oct, slope=octave_slope)
+    elif texture == "band":
+        tex = np.empty((3, 6, 6))
+        d = rng.standard_normal((3, 6, 3))
+        tex[:, :, :3] = d / np.linalg.norm(d, axis=-1, keepdims=True)
+        tex[:, :, 3] = rng.uniform(0.35, 1.0, (3, 6))
+        tex[:, :, 4] = rng.uniform(0, 2 * math.pi, (3, 6))
+        tex[:, :, 5] = rng.uniform(0.04, 0.11, (3, 6))
+    else:
+        raise ValueError(texture)
     src_image = _texture(Xs, tex, base_omega)
 
     # ground-truth motion target <- source
@@ -189,7 +219,13 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
     keypoints = np.stack([2.0 * kp_rc[:, 0] / (H - 1) - 1.0, 2.0 * kp_rc[:, 1] / (W - 1) - 1.0], 1)
     kld_gt = logD[kp_rc[:, 0], kp_rc[:, 1]]
     kld_init = np.log(2.0 + 2.0 * rng.uniform(size=N))      # odometery/two_frame_sfm.py:103-105
-    T_init = se3_exp_np(init_sigma * rng.standard_normal(6)) @ T_gt
+    noise = se3_exp_np(init_sigma * rng.standard_normal(6))
+    if init_mode == "left":
+        T_init = noise @ T_gt
+    elif init_mode == "reference":
+        T_init = T_gt @ noise
+    else:
+        raise ValueError(init_mode)
 
     f32 = np.float32
     return SynthPair(
@@ -199,7 +235,8 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
         keypoints=keypoints.astype(f32), keypoint_regions=masks,
         kld_gt=kld_gt.astype(f32), kld_init=kld_init.astype(f32),
         pose_gt=T_gt.astype(f32), pose_init=T_init.astype(f32),
-        meta=dict(seed=seed, shape=shape, overlap=overlap, xi_gt=xi_gt, kp_rc=kp_rc),
+        meta=dict(seed=seed, shape=shape, overlap=overlap, xi_gt=xi_gt, kp_rc=kp_rc, texture=texture,
+                  texture_period_px=float(texture_period_px), init_sigma=float(init_sigma), init_mode=init_mode),
     )
 
 

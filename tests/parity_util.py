@@ -43,8 +43,17 @@ def input_digest(pair):
 def fullsize_pair(g):
     """Regenerate the synthetic pair a full-size golden was recorded on and check it is bit-identical to the recorded one."""
     from super_primitive_amd import synth
-    kw = dict(item.split("=") for item in str(g["make_pair_args"]).split(","))
-    pair = synth.make_pair(int(kw["H"]), int(kw["W"]), int(kw["N"]), seed=int(g["seed"]), overlap=int(kw["overlap"]),
-                           init_sigma=float(kw["init_sigma"]))
-    assert np.array_equal(input_digest(pair), g["in_sha256"]), "regenerated inputs differ from the ones the golden was recorded on"
+    return pair_from_args(str(g["make_pair_args"]), int(g["seed"]), g["in_sha256"])
+
+
+def pair_from_args(make_pair_args, seed, digest=None):
+    """``synth.make_pair`` from a golden's recorded argument string ("H=..,W=..,N=..,overlap=..,init_sigma=..[,texture=..,
+    init_mode=..]"), checked against the recorded input digest."""
+    from super_primitive_amd import synth
+    kw = dict(item.split("=") for item in make_pair_args.split(","))
+    extra = {k: kw[k] for k in ("texture", "init_mode", "shape") if k in kw}
+    pair = synth.make_pair(int(kw["H"]), int(kw["W"]), int(kw["N"]), seed=int(seed), overlap=int(kw.get("overlap", 0)),
+                           init_sigma=float(kw["init_sigma"]), **extra)
+    if digest is not None:
+        assert np.array_equal(input_digest(pair), digest), "regenerated inputs differ from the ones the golden was recorded on"
     return pair

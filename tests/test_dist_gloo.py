@@ -194,3 +194,10 @@ def test_bench_multi_rank_control_flow_dry_run_world2():
     assert got[0][2] == got[1][2] == 2 + 3                                                            # warm-up + timed cost passes
     # the whole-job frame-pair leg: every rank ran the schedule twice (one untimed pass) from restored initial values
     assert got[0][3] == got[1][3] == 2 and got[0][4] == got[1][4] == 3 and line0["frame_pairs_per_sec"] > 0
+    # the self-proving part of an N > 1 line: the collective saw `world` ranks, and every rank reported its own record
+    assert line0["rccl_world"] == world
+    assert [r["rank"] for r in line0["ranks"]] == list(range(world))
+    for r in line0["ranks"]:
+        assert set(r) == {"rank", "device_index", "pci_bus_id", "kernel_ms", "elapsed_ms", "pairs"}
+        assert r["pairs"] == 6 and r["kernel_ms"] >= 0 and r["elapsed_ms"] > 0
+    assert max(r["elapsed_ms"] for r in line0["ranks"]) == pytest.approx(line0["ms_per_step"] * 3, rel=1e-6)
