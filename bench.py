@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=10, help="timed CPU-baseline iterations per leg (after 3 warm-up)")
     ap.add_argument("--no-extras", action="store_true", help="skip the single-pair and full-schedule side measurements")
+    ap.add_argument("--sigma05-scenes", type=int, default=8,
+                    help="distinct multi-octave scenes rendered for the reference-start leg (every resident pair gets its own "
+                         "T_gt Exp(0.05 xi) start and its own depth seeds); 0 skips the leg")
     ap.add_argument("--dry-run", action="store_true",
                     help="control-flow rehearsal on CPU (tests/test_dist_gloo.py): gloo instead of RCCL, host timers instead of "
                          "HIP events, build_batch() replaced by the caller; produces no valid measurement")
@@ -86,6 +89,80 @@ def build_batch(args, rank, dev):
                       point_stride=FRAME_PAIR_POINT_STRIDE,     # extra decimated tables for the frame-pair schedule only
                       **({} if getattr(args, 'span_points', None) is None else {'span_points': args.span_points}))
     return batch, pairs
+
+
+def _render_sigma05(a):
+    from super_primitive_amd import synth
+    return synth.make_pair(H, W, a[0], seed=a[1], overlap=4, init_sigma=0.05, texture="octaves", init_mode="reference")
+
+
+def reference_start_leg(args, rank, dev, M):
+    """frame pairs per second FROM THE REFERENCE'S OWN STARTING DISTRIBUTION (odometery/two_frame_sfm.py:77-81,103-105): every
+    resident pair starts at T_gt Exp(0.05 randn(6)) with depth seeds log(2 + 2 rand) on a multi-octave (~1/f) texture
+    (synth.make_pair(texture='octaves', init_mode='reference')); the schedule is optim.pair_batch.REFERENCE_START_SCHEDULE
+    (a pose-only phase at the coarsest level in front of the usual per-pair coarse-to-fine phases), the one
+    tests/test_gpu_sigma05.py requires to converge wherever the real reference loop does (golden g19).  Every pair is checked
+    against its ground truth in the run."""
+    from multiprocessing import Pool
+    from super_primitive_amd import synth
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.optim.pair_batch import (REFERENCE_START_LEVELS, REFERENCE_START_POINT_STRIDE, REFERENCE_START_SCHEDULE,
+                                                      PairBatch)
+    G = max(1, min(args.sigma05_scenes, M))
+    R = max(1, M // G)
+    jobs = [(args.segments, 5000 + 1000 * rank + s) for s in range(G)]
+    if G > 1 and (os.cpu_count() or 1) > 2:
+        with Pool(min(G, 16)) as pool:
+            scenes = pool.map(_render_sigma05, jobs)
+    else:
+        scenes = [_render_sigma05(j) for j in jobs]
+    rng = np.random.default_rng(77 + rank)
+    poses, klds = [], []
+    for r in range(R):
+        for p in scenes:
+            if r == 0:
+                poses.append(p.pose_init); klds.append(p.kld_init)
+            else:                        # the same distribution, drawn again for every replica
+                poses.append((p.pose_gt.astype(np.float64) @ synth.se3_exp_np(0.05 * rng.standard_normal(6))).astype(np.float32))
+                klds.append(np.log(2.0 + 2.0 * rng.uniform(size=p.N)).astype(np.float32))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in scenes]
+    batch = PairBatch(src, [t(p.trg_image) for p in scenes], [t(p.K) for p in scenes], torch.from_numpy(np.stack(poses)),
+                      [t(k) for k in klds], levels=REFERENCE_START_LEVELS, tile_points=args.tile_points, replicate=R,
+                      point_stride=REFERENCE_START_POINT_STRIDE)
+    kw = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
+    batch.run_scheduled(**kw)                   # untimed pass first, like the other legs
+    batch.restore_initial()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    launched = batch.run_scheduled(**kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    Mb = batch.M
+    P, K = batch.poses().double().cpu().numpy(), [k.double().cpu().numpy() for k in batch.klds()]
+    err, err0 = np.zeros((Mb, 3)), np.zeros((Mb, 3))
+    for m in range(Mb):
+        gt = scenes[m % G]
+        for out, (pose, kld) in ((err, (P[m], K[m])), (err0, (poses[m].astype(np.float64), klds[m].astype(np.float64)))):
+            ls = float(np.mean(gt.kld_gt - kld))
+            Rm = pose[:3, :3].T @ gt.pose_gt[:3, :3].astype(np.float64)
+            out[m] = (float(np.arctan2(0.5 * np.linalg.norm([Rm[2, 1] - Rm[1, 2], Rm[0, 2] - Rm[2, 0], Rm[1, 0] - Rm[0, 1]]), 0.5 * (np.trace(Rm) - 1))),
+                      float(np.abs(pose[:3, 3] * np.exp(ls) - gt.pose_gt[:3, 3]).max()), float(np.abs(np.expm1(kld + ls - gt.kld_gt)).max()))
+    conv = (err[:, 0] <= 2e-3) & (err[:, 1] <= 2e-3) & (err[:, 2] <= 2e-2)          # golden g19's convergence criterion (vs ground truth)
+    bar = (err[:, 0] <= 2e-4) & (err[:, 1] <= 2e-4) & (err[:, 2] <= 2e-3)
+    n_it = (batch.lm_state[:, 2] + batch.lm_state[:, 3]).double()
+    rec = {"pairs": Mb, "distinct_scenes": G, "frame_pairs_per_sec": Mb / dt, "converged_fraction": float(conv.mean()),
+           "within_2x_bar_of_ground_truth_fraction": float(bar.mean()),
+           "iterations_per_pair": {"mean": float(n_it.mean()), "min": float(n_it.min()), "max": float(n_it.max())},
+           "iterations_launched": int(launched),
+           "initial_error_mean": {"rot_rad": float(err0[:, 0].mean()), "t": float(err0[:, 1].mean()), "depth_rel": float(err0[:, 2].mean())},
+           "worst_error_of_converged_vs_ground_truth": ({"rot_rad": float(err[conv, 0].max()), "t": float(err[conv, 1].max()),
+                                                         "depth_rel": float(err[conv, 2].max())} if conv.any() else None),
+           "start": "pose_init = T_gt Exp(0.05 randn(6)) (SE3.Random(sigma=0.05), two_frame_sfm.py:77-81), depth seeds log(2 + 2 rand) (:103-105)",
+           "texture": f"multi-octave ~1/f, shortest period {scenes[0].meta['texture_period_px']:g} px",
+           "schedule": f"levels {REFERENCE_START_LEVELS}, point strides {REFERENCE_START_POINT_STRIDE}, {kw}"}
+    del batch
+    return rec
 
 
 def _cpu_leg(pair, levels, iters, threads):
@@ -262,6 +339,8 @@ def main(argv=None):
         "config": {"workload": f"Replica-shaped two-frame SfM, 640x480, {args.segments} segments (grid, 4 px overlap), pyramid "
                                "level 0 of a 3-level pyramid; BASELINE.json configs[1]",
                    "pairs_per_gpu": M, "segment_pixels_per_pair": int(batch.Ps[0]), "optimiser": args.mode,
+                   "texture": (f"single-octave band, shortest period {pairs[0].meta['texture_period_px']:g} px; initial pose Exp(0.004 xi) T_gt (+0.002 per copy)"
+                               if pairs else None),
                    "tile_points": args.tile_points, "span_points": batch.span_points, "sharding": f"{world} x independent pair batches, final all_gather only"},
         "roofline": {"bound": "hbm", "kernel": f"k_cost_pairs<{mode_id}>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -413,35 +492,56 @@ def main(argv=None):
             frames = [KeyFrame(r["img"], r["K"], r["L"], r["kp"], r["m"]) for r in raw]
             poses0 = batch._initial[0][:n_raw].reshape(n_raw, 4, 4).clone()
 
-            def from_raw():
+            def from_raw(timer=None):
                 sync()
                 t0 = time.perf_counter()
                 b = PairBatch(frames, [r["trg"] for r in raw], [r["K"] for r in raw], poses0, [r["kld"] for r in raw], levels=(0, 3),
-                              tile_points=args.tile_points, point_stride=STRIDE)
+                              tile_points=args.tile_points, point_stride=STRIDE, timer=timer)
                 sync()
                 t1 = time.perf_counter()
                 b.run_scheduled(**sched_kw)
                 sync()
-                return t1 - t0, time.perf_counter() - t1
+                return t1 - t0, time.perf_counter() - t1, b.setup_bytes
 
             from_raw()
-            t_setup, t_opt = from_raw()
+            t_setup, t_opt, _ = from_raw()
             line["frame_pairs_per_sec_from_raw_frames"] = n_raw / (t_setup + t_opt)
             line["from_raw_frames"] = {"pairs": n_raw, "setup_ms": 1e3 * t_setup, "optimise_ms": 1e3 * t_opt,
                                        "setup_us_per_pair": 1e6 * t_setup / n_raw}
+            # HBM roofline of the set-up passes: algorithmic bytes of every pass (optim/batch_prepare.py) over
+            # its duration between HIP events on the launch stream (a third, instrumented build)
+            from super_primitive_amd.optim.batch_prepare import _Timer
+            tm = _Timer()
+            _, _, nbytes = from_raw(tm)
+            ms = tm.milliseconds()
+            rs = {k: {"ms": ms[k], "algorithmic_bytes": int(nbytes[k]), "achieved": nbytes[k] / (ms[k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                      "unit": "GB/s", "frac": nbytes[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for k in ms if ms[k] > 0}
+            tot_b, tot_ms = sum(nbytes[k] for k in ms), sum(ms.values())
+            line["roofline_setup"] = {"bound": "hbm", "passes": rs, "kernels_ms": tot_ms, "algorithmic_bytes": int(tot_b),
+                                      "achieved": tot_b / (tot_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                      "algorithmic_bytes_per_pair": int(tot_b / n_raw), "pairs": n_raw}
             # (e) batches back to back, the set-up of the next one overlapped with the optimisation of the current one on a
             #     second HIP stream (optim.pair_stream.PairStream): 4 batches of the same raw frames
             from super_primitive_amd.optim.pair_stream import PairStream
             item = dict(src_frames=frames, trg_images=[r["trg"] for r in raw], trg_Ks=[r["K"] for r in raw], poses=poses0, klds=[r["kld"] for r in raw])
-            pipe = PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, tile_points=args.tile_points)
-            for _ in range(2):                           # (first pass: the two streams' allocator pools fill)
-                sync()
-                t1 = time.perf_counter()
-                for _res in pipe.run(iter([item] * 4)):
-                    pass
-                sync()
-                line["from_raw_frames"]["pipelined_pairs_per_sec"] = 4 * n_raw / (time.perf_counter() - t1)
+            for key, n_opt, n_b in (("pipelined_pairs_per_sec", 1, 4), ("continuous_batching_pairs_per_sec", 2, 8)):
+                # n_opt = 2: two batches run their schedules at the same time on two HIP streams -- the bulk of one fills the
+                # tail of the other (optim/pair_stream.py); sustained over n_b batches back to back, set-up included
+                pipe = PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, tile_points=args.tile_points, optimisers=n_opt)
+                for _ in range(2):                           # (first pass: the streams' allocator pools fill)
+                    sync()
+                    t1 = time.perf_counter()
+                    for _res in pipe.run(iter([item] * n_b)):
+                        pass
+                    sync()
+                    line["from_raw_frames"][key] = n_b * n_raw / (time.perf_counter() - t1)
+                del pipe
             del raw, frames, base, item
+            if args.sigma05_scenes > 0:
+                # (f) the same metric from the reference's own starting distribution
+                line["reference_start"] = reference_start_leg(args, rank, dev, M)
+                line["frame_pairs_per_sec_reference_start"] = line["reference_start"]["frame_pairs_per_sec"]
         else:
             line["frame_pair_schedule"] = "3 levels (coarse to fine) x 500 Adam iterations (the reference's budget, two_frame_sfm.py:128)"
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 7
+#define SP_ABI_VERSION 8
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -47,6 +47,7 @@ extern "C" {
  * sp_pairs_cost; mode 1 -- one span of sp_pairs_cost */
 #define SP_GRAD_PARTIAL_FLOATS 16
 #define SP_GN_PARTIAL_FLOATS   32
+#define SP_GNA_PARTIAL_FLOATS  48   /* mode 2: Gauss-Newton with the affine brightness pair among the unknowns */
 
 int sp_abi_version(void);
 
@@ -90,7 +91,8 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
  * synchronisation (the per-segment counts, which size the tables) instead of ~15 launches and a synchronisation per pair.
  * A "table" is the compacted point set of one keyframe on a pixel lattice: stride 1 = every mask pixel (the tables above),
  * stride s > 1 = the mask pixels whose row and column are multiples of s (coarse levels of per-pair schedules).
- *   sp_prepare_count : row_counts (scratch, N*H) and counts[N] of every lattice of every keyframe   [masks read once]
+ *   sp_prepare_count : row_counts (scratch, N*H) and counts[N] of every lattice of every keyframe, and the masks as packed bit
+ *                      words (SpPrepTable.bits)                                                     [masks read once]
  *   -- host: reads counts, lays the segments out (runs padded to multiples of 256), allocates pix / baseL, uploads seg_off --
  *   sp_prepare_fill  : pix / baseL at seg_off[n] + rank inside the segment; kp_L[N] where kp_L != NULL
  *   sp_prepare_blur  : one pyramid step (sp_blur_decimate) of every job image
@@ -114,7 +116,12 @@ typedef struct SpPrepTable {     /* one keyframe: its masks are read once per pa
     float* baseL[SP_PREP_MAX_STRIDES];
     int32_t stride[SP_PREP_MAX_STRIDES];
     int32_t N, H, W, n_strides;
-} SpPrepTable;                   /* 224 bytes */
+    uint32_t* bits;              /* N*H*(W/16) words or NULL: the masks as one bit word per 16 pixels, written by sp_prepare_count on
+                                    its fast path (W a multiple of 16 up to 1024, masks 16-byte aligned, strides in {1,2,4,8,16}) and
+                                    read by sp_prepare_fill INSTEAD of the masks (4 instead of 16 bytes per 16 pixels); NULL, or a
+                                    keyframe off the fast path: the fill pass reads the masks.  logdepth must be 16-byte aligned
+                                    when bits is given */
+} SpPrepTable;                   /* 232 bytes */
 typedef struct SpPrepSample {    /* one table, sampled at up to SP_PREP_MAX_LEVELS pyramid levels in one pass; sets pix bit 31 */
     uint32_t* pix;
     const float* baseL;
@@ -210,6 +217,7 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
  * ---------------------------------------------------------------------------------------------------- */
 #define SP_GRAD_SEG_FLOATS 1
 #define SP_GN_SEG_FLOATS 8
+#define SP_GNA_SEG_FLOATS 12
 typedef struct SpPair {
     const uint32_t* pix;      /* [P_padded] */
     const float*    src4;     /* [P_padded*4] for the level being optimised */
@@ -228,7 +236,10 @@ typedef struct SpPair {
     int32_t rec0;             /* first segment record of this pair (= 4 * its first chunk) */
 } SpPair;
 
-/* mode 0 / 1 as above. */
+/* mode 0 / 1 as above.  mode 2 = mode 1 plus the affine brightness pair of the TARGET frame as two more unknowns (a_t, b_t; the
+ * source frame's pair enters with the opposite sign): residual columns j_a = gain * I_trg(sample), j_b = -1.  Span record
+ * (SP_GNA_PARTIAL_FLOATS): [0..28] as mode 1, [29..31] H_aa = {aa, ab, bb}, [32,33] b_a, [34..39] H_{a,pose}, [40..45] H_{b,pose};
+ * segment record (SP_GNA_SEG_FLOATS): [0..7] as mode 1, [8] H_{a,depth}, [9] H_{b,depth}.  Consumed by sp_window_gn_step. */
 int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                   float* span_partials, float* seg_partials, void* stream);
 
@@ -272,6 +283,13 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
  * sp_pairs_schedule_cost launches the Gauss-Newton cost kernel once per DISTINCT work list (phases sharing `spans` share the
  * launch); partial buffers of different work lists must not alias.  The struct lives in host memory. */
 #define SP_MAX_PHASES 8
+/* SP_PHASE_POSE_ONLY: the phase moves the pose alone, the log-depths stay where they are (the solver skips the Schur complement
+ * and the depth update; the cost pass is unchanged).  From the reference's own starting distribution (pose off by SE3.Random(sigma =
+ * 0.05), depth seeds log(2 + 2 rand), odometery/two_frame_sfm.py:77-81,103-105) a joint Gauss-Newton step lets single segments run
+ * away in depth while the pose is still wrong -- the total cost keeps falling, so LM never objects; the reference's Adam moves the
+ * pose 10x faster than the depths (lr 1e-2 vs 1e-3, :116-123) and so aligns the pose first.  A pose-only phase at the coarsest
+ * level is the Gauss-Newton counterpart (tools/gn_model.py, profiles/r03_sigma05_sweep.txt). */
+#define SP_PHASE_POSE_ONLY 1
 typedef struct SpPhase {
     const SpPair* pairs;
     const int32_t* chunks;
@@ -282,15 +300,28 @@ typedef struct SpPhase {
     int32_t max_iters;
     float irls_eps;
     float conv_tol;
-} SpPhase;               /* 56 bytes */
+    int32_t flags;               /* SP_PHASE_* */
+    int32_t pad_;
+} SpPhase;               /* 64 bytes */
 typedef struct SpSchedule {
     SpPhase phase[SP_MAX_PHASES];
     int32_t n_phases;
     int32_t pad_;
-} SpSchedule;            /* 456 bytes */
+} SpSchedule;            /* 520 bytes */
 int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream);
 int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
                               float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, void* stream);
+
+/* The host loop of a scheduled run, natively: issues (sp_pairs_schedule_cost, sp_pairs_schedule_gn_step) up to max_rounds times and,
+ * every check_every iterations, reads min(phase) back (one tiny kernel, a 4-byte copy into flag_host -- PINNED host memory -- and a
+ * synchronisation of `stream` only) to stop once every pair has finished.  One foreign call per scheduled run instead of ~100: a
+ * Python caller issues nothing per iteration, so several batches can run their schedules from several host threads without
+ * contending for the interpreter lock (optim/pair_stream.py), and the launch-bound tail of a schedule runs at the rate of the
+ * runtime's launch path.  flag_dev: one int32 of device scratch.  Returns the number of iterations launched (>= 0), SP_EINVAL, or
+ * -(1000 + hipError_t) for a runtime error.  This is the one entry point that synchronises the host (with `stream` only). */
+int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
+                          float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, int check_every,
+                          int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream);
 
 /* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last span of a pair
  * runs that pair's update in place (same arithmetic, same fixed reduction order as sp_pairs_cost followed by

@@ -314,7 +314,7 @@ def reference_sfm_run(ref, pair, iters=500, polish=POLISH, log=None):
         rounds += 1
         with torch.no_grad():
             cur = ((orc.se3_exp(a)[0] @ T0).numpy(), kld.detach().numpy().copy())
-        moved = errors_vs(cur[0], cur[1], prev[0], prev[1], gauge=False)
+        moved = errors_vs(cur[0], cur[1], prev[0], prev[1])       # gauge removed: Adam's noise random-walks along the scale gauge, where the cost is flat
         prev = cur
         if all(m <= b for m, b in zip(moved, POLISH_SETTLED)):
             break

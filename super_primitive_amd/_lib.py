@@ -41,6 +41,7 @@ SIGNATURES = {
     "sp_prepare_pack": [P, I, I, P],
     "sp_pairs_schedule_cost": [P, P, P],
     "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P],
+    "sp_pairs_schedule_run": [P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P],
     "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, P, F, F, F, P, P, P],
     "sp_pairs_gn_iterate": [P, P, P, I, I, I, F, P, P, P, F, F, F, P, P, P, P],
     "sp_window_scratch_doubles": [I, I],
@@ -62,7 +63,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 7
+SP_ABI_VERSION = 8
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GRAD_SEG_FLOATS = 1
@@ -82,6 +83,7 @@ class SpPair(ctypes.Structure):
 
 
 SP_MAX_PHASES = 8
+SP_PHASE_POSE_ONLY = 1
 
 
 SP_PREP_MAX_STRIDES = 4
@@ -94,7 +96,7 @@ class SpPrepTable(ctypes.Structure):
                 ("row_counts", c_void_p * SP_PREP_MAX_STRIDES), ("counts", c_void_p * SP_PREP_MAX_STRIDES),
                 ("seg_off", c_void_p * SP_PREP_MAX_STRIDES), ("pix", c_void_p * SP_PREP_MAX_STRIDES),
                 ("baseL", c_void_p * SP_PREP_MAX_STRIDES), ("stride", c_int * SP_PREP_MAX_STRIDES),
-                ("N", c_int), ("H", c_int), ("W", c_int), ("n_strides", c_int)]
+                ("N", c_int), ("H", c_int), ("W", c_int), ("n_strides", c_int), ("bits", c_void_p)]
 
 
 class SpPrepSample(ctypes.Structure):
@@ -111,7 +113,7 @@ class SpPrepImage(ctypes.Structure):
 class SpPhase(ctypes.Structure):
     """Mirror of ``struct SpPhase`` (include/sp_hip.h)."""
     _fields_ = [("pairs", c_void_p), ("chunks", c_void_p), ("spans", c_void_p), ("span_partials", c_void_p), ("seg_partials", c_void_p),
-                ("n_spans", c_int), ("max_iters", c_int), ("irls_eps", c_float), ("conv_tol", c_float)]
+                ("n_spans", c_int), ("max_iters", c_int), ("irls_eps", c_float), ("conv_tol", c_float), ("flags", c_int), ("pad_", c_int)]
 
 
 class SpSchedule(ctypes.Structure):

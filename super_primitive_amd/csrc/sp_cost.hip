@@ -333,9 +333,23 @@ __device__ __forceinline__ void prepare2(const TileCtx& c, const PairConsts& k, 
 }
 
 struct Mix2 { f32x2 wa, v; float w11; };      // {w00, w01}, {v0, v1}, w11
+// mode 2 (Gauss-Newton WITH the affine brightness pair of the target as unknowns, the window optimiser's flavour): two more
+// residual columns per channel, j_a = d r / d a_t = gain * I  and  j_b = d r / d b_t = -1  (r = I_src - (gain I + bias),
+// gain = exp(-(a_t - a_s)), bias = b_t - b_s; the source frame's pair enters with the opposite sign).
+//   carried per point: ua = {sum w j_a Ix, sum w j_a Iy}, ub = {sum w Ix, sum w Iy}   (cross terms with the geometric columns)
+//   accumulated:       H_aa = [sum w j_a^2, -sum w j_a, sum w], b_a = [sum w r j_a, -sum w r]                (pair level)
+//                      pa / pb (6 each) = cross terms with the pose columns (pair level), hda / hdb with the depth column (segment)
+struct MixA { f32x2 ua, ub; };
+struct AffAcc {
+    float haa, hab, hbb, ba, bb;
+    f32x2 pa01, pa[2], pb01, pb[2];
+    float hda, hdb;
+};
 
+template <bool AFF = false>
 __device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& p, const f32x3 a, const f32x3 b,
-                                           const f32x3 cc, const f32x3 d, Mix2& o, float& cost_acc, float& n_acc) {
+                                           const f32x3 cc, const f32x3 d, Mix2& o, float& cost_acc, float& n_acc,
+                                           MixA* oa = nullptr, AffAcc* aa = nullptr) {
     const float eps = k.eps;
     // red+green as a pair
     const f32x2 a2{a.x, a.y}, b2{b.x, b.y}, c2{cc.x, cc.y}, d2{d.x, d.y};
@@ -359,10 +373,25 @@ __device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& 
     o.v = f32x2{fmaf(wxb, rb, v0p.x) + v0p.y, fmaf(wyb, rb, v1p.x) + v1p.y};
     cost_acc = fmaf(p.m, (ar0 + ar1) + arb, cost_acc);
     n_acc += p.m;
+    if constexpr (AFF) {
+        const f32x2 ja2 = k.gain * it2;
+        const float jab = k.gain * itb;
+        const f32x2 wj2 = wg2 * ja2;
+        const float wjb = wgb * jab;
+        aa->haa = fmaf(p.m, fmaf(wjb, jab, wj2.x * ja2.x) + wj2.y * ja2.y, aa->haa);
+        aa->hab = fmaf(-p.m, (wj2.x + wj2.y) + wjb, aa->hab);
+        aa->hbb = fmaf(p.m, (wg2.x + wg2.y) + wgb, aa->hbb);
+        aa->ba = fmaf(p.m, fmaf(wjb, rb, wj2.x * r2.x) + wj2.y * r2.y, aa->ba);
+        aa->bb = fmaf(-p.m, fmaf(wgb, rb, wg2.x * r2.x) + wg2.y * r2.y, aa->bb);
+        oa->ua = f32x2{fmaf(wjb, Ixb, wj2.x * Ix2.x) + wj2.y * Ix2.y, fmaf(wjb, Iyb, wj2.x * Iy2.x) + wj2.y * Iy2.y};
+        oa->ub = f32x2{(wx2.x + wx2.y) + wxb, (wy2.x + wy2.y) + wyb};
+    }
 }
 
 struct GeoGn { f32x2 qxy; float qz, zinv, zi; };
-__device__ __forceinline__ void fold_gn2(const PairConsts& k, const GeoGn g, const Mix2 w, GnAcc& A) {
+template <bool AFF = false>
+__device__ __forceinline__ void fold_gn2(const PairConsts& k, const GeoGn g, const Mix2 w, GnAcc& A, const MixA* wa = nullptr,
+                                         AffAcc* aa = nullptr) {
     const f32x2 g2 = k.gab * g.zinv;   // {ga, gb}; zinv carries the mask
     const f32x2 Wa = w.wa * (g2 * g2.x);                 // {W00, W01}
     const float W11 = w.w11 * (g2.y * g2.y);
@@ -394,6 +423,18 @@ __device__ __forceinline__ void fold_gn2(const PairConsts& k, const GeoGn g, con
     A.hd[1] = pfma(P.x, A01, pfma(P.y, A11, A.hd[1]));
     A.D = fmaf(Q.x, P.x, fmaf(Q.y, P.y, A.D));
     A.bd = fmaf(Q.x, V.x, fmaf(Q.y, V.y, A.bd));
+    if constexpr (AFF) {
+        // sum_ch w j_a J_geo = -(g2 o ua) Ahat ;  sum_ch w j_b J_geo = +(g2 o ub) Ahat      (g2 carries the mask)
+        const f32x2 Ua = -(wa->ua * g2), Ub = wa->ub * g2;
+        aa->pa01 += Ua;
+        aa->pa[0] = pfma(Ua.x, A00, pfma(Ua.y, A10, aa->pa[0]));
+        aa->pa[1] = pfma(Ua.x, A01, pfma(Ua.y, A11, aa->pa[1]));
+        aa->hda = fmaf(Q.x, Ua.x, fmaf(Q.y, Ua.y, aa->hda));
+        aa->pb01 += Ub;
+        aa->pb[0] = pfma(Ub.x, A00, pfma(Ub.y, A10, aa->pb[0]));
+        aa->pb[1] = pfma(Ub.x, A01, pfma(Ub.y, A11, aa->pb[1]));
+        aa->hdb = fmaf(Q.x, Ub.x, fmaf(Q.y, Ub.y, aa->hdb));
+    }
 }
 
 // =====================================================================================================
@@ -467,14 +508,21 @@ __device__ __forceinline__ void store_partial(float* p, float v) {
 
 __device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// mode 1: flush {h_pd(6), D, b_d} of the chunk this wave just finished into its segment record
-template <bool WT>
-__device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ rec) {
-    float v[8] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D, A.bd};
+// mode 1: flush {h_pd(6), D, b_d} of the chunk this wave just finished into its segment record (mode 2: + {h_da, h_db})
+template <bool WT, bool AFF = false>
+__device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ rec, AffAcc* aa = nullptr) {
     const int lane = lane_id();
     int pos; bool ok;
-    wave_sum_to_lanes<8>(v, lane, pos, ok);
-    if (ok) store_partial<WT>(rec + pos, v[0]);
+    if constexpr (AFF) {
+        float v[10] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D, A.bd, aa->hda, aa->hdb};
+        wave_sum_to_lanes<10>(v, lane, pos, ok);
+        if (ok) store_partial<WT>(rec + pos, v[0]);
+        aa->hda = 0.f; aa->hdb = 0.f;
+    } else {
+        float v[8] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D, A.bd};
+        wave_sum_to_lanes<8>(v, lane, pos, ok);
+        if (ok) store_partial<WT>(rec + pos, v[0]);
+    }
     const f32x2 z{0.f, 0.f};
     A.hd01 = z; A.hd[0] = z; A.hd[1] = z; A.D = 0.f; A.bd = 0.f;
 }
@@ -482,12 +530,19 @@ __device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ r
 // ABL (developer ablation, only reachable through mode >= 10 of sp_pairs_cost): 0 = product kernel,
 // 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation),
 // 3 (mode 1 only) = the four tap loads made lane-consecutive (coalesced) instead of gathered
-template <int ABL, bool WT>
+template <int ABL, bool WT, bool AFF = false>
 __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
                                             int n_chunks, int total, float irls_eps, float* __restrict__ span_rec,
                                             float* __restrict__ seg_partials, float* lds) {
-    constexpr int NV = SP_GN_PARTIAL_FLOATS, NS = SP_GN_SEG_FLOATS;
+    constexpr int NV = AFF ? SP_GNA_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS, NS = AFF ? SP_GNA_SEG_FLOATS : SP_GN_SEG_FLOATS;
     GnAcc A;
+    AffAcc AA;
+    MixA ma{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
+    {
+        const f32x2 z{0.f, 0.f};
+        AA.haa = AA.hab = AA.hbb = AA.ba = AA.bb = AA.hda = AA.hdb = 0.f;
+        AA.pa01 = z; AA.pb01 = z; AA.pa[0] = z; AA.pa[1] = z; AA.pb[0] = z; AA.pb[1] = z;
+    }
     {
         const f32x2 z{0.f, 0.f};
         A.h00 = z; A.bp01 = z; A.hd01 = z;
@@ -565,15 +620,15 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
             td = buf_load3(r_trg, a.p.off0 + 4u * SP_TEXEL_FLOATS, c.row_bytes);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL != 2) fold_gn2(kc, GeoGn{b.p.qxy, b.p.qz, b.p.zinv, b.p.zi}, m, A);
-        if (b.last) flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * b.q + wave) * NS);
+        if (ABL != 2) fold_gn2<AFF>(kc, GeoGn{b.p.qxy, b.p.qz, b.p.zinv, b.p.zi}, m, A, &ma, &AA);
+        if (b.last) flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(4 * b.q + wave) * NS, &AA);
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 1)
             asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(A.blk[0]), "+v"(A.blk[1]), "+v"(A.blk[2]),
                          "+v"(A.blk[3]), "+v"(A.blk[4]), "+v"(A.blk[5]), "+v"(A.bp[0]), "+v"(A.bp[1]), "+v"(A.hd[0]),
                          "+v"(A.hd[1]), "+v"(A.D), "+v"(A.bd), "+v"(A.h00), "+v"(A.h0[0]), "+v"(A.h0[1]), "+v"(A.h1[0]), "+v"(A.h1[1]), "+v"(A.h11), "+v"(A.bp01), "+v"(A.hd01));
         if (ABL == 2) A.cost += ta.x + tb.y + tc.z + td.x + a.p.wxy.x + a.p.wxy.y + a.p.m;
-        else finish_gn2(kc, a.p, ta, tb, tc, td, m, A.cost, A.n);
+        else finish_gn2<AFF>(kc, a.p, ta, tb, tc, td, m, A.cost, A.n, &ma, &AA);
         uint32_t pw_ = pw;
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
@@ -584,11 +639,11 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     for (; j + 1 < n_iter; j += 2) { trip(S0, S1); trip(S1, S0); }
     if (j < n_iter) {                    // odd trip count: the last point sits in S0
         trip(S0, S1);
-        if (ABL != 2) fold_gn2(kc, GeoGn{S0.p.qxy, S0.p.qz, S0.p.zinv, S0.p.zi}, m, A);
-        flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * S0.q + wave) * NS);
+        if (ABL != 2) fold_gn2<AFF>(kc, GeoGn{S0.p.qxy, S0.p.qz, S0.p.zinv, S0.p.zi}, m, A, &ma, &AA);
+        flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(4 * S0.q + wave) * NS, &AA);
     } else {
-        if (ABL != 2) fold_gn2(kc, GeoGn{S1.p.qxy, S1.p.qz, S1.p.zinv, S1.p.zi}, m, A);
-        flush_segment_gn<WT>(A, seg_partials + (size_t)(4 * S1.q + wave) * NS);
+        if (ABL != 2) fold_gn2<AFF>(kc, GeoGn{S1.p.qxy, S1.p.qz, S1.p.zinv, S1.p.zi}, m, A, &ma, &AA);
+        flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(4 * S1.q + wave) * NS, &AA);
     }
     float acc[NV];
     acc[0] = A.cost;
@@ -601,7 +656,15 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     acc[19] = A.blk[4].x; acc[20] = A.blk[4].y; acc[21] = A.blk[5].y;
     acc[22] = A.bp01.x; acc[23] = A.bp01.y;
     acc[24] = A.bp[0].x; acc[25] = A.bp[0].y; acc[26] = A.bp[1].x; acc[27] = A.bp[1].y;
-    acc[28] = A.n; acc[29] = acc[30] = acc[31] = 0.f;
+    acc[28] = A.n;
+    if constexpr (AFF) {
+        acc[29] = AA.haa; acc[30] = AA.hab; acc[31] = AA.hbb; acc[32] = AA.ba; acc[33] = AA.bb;
+        acc[34] = AA.pa01.x; acc[35] = AA.pa01.y; acc[36] = AA.pa[0].x; acc[37] = AA.pa[0].y; acc[38] = AA.pa[1].x; acc[39] = AA.pa[1].y;
+        acc[40] = AA.pb01.x; acc[41] = AA.pb01.y; acc[42] = AA.pb[0].x; acc[43] = AA.pb[0].y; acc[44] = AA.pb[1].x; acc[45] = AA.pb[1].y;
+        acc[46] = acc[47] = 0.f;
+    } else {
+        acc[29] = acc[30] = acc[31] = 0.f;
+    }
     // op still knows the thread index (op = 4 * (threadIdx.x + trips * SP_BLOCK)): nothing derived from threadIdx.x
     // has to stay live, or be spilled, across the loop for the sake of this epilogue
     const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
@@ -834,10 +897,10 @@ struct FuseArgs {
 };
 
 template <int MODE, int ABL = 0, int FUSED = 0>
-__global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
+__global__ __launch_bounds__(SP_BLOCK, FUSED != 0 ? 1 : (MODE == 2 ? 2 : 4)) void k_cost_pairs(
         const SpPair* __restrict__ pairs, const int4* __restrict__ chunks, const int4* __restrict__ spans, int n_spans,
         float irls_eps, float* __restrict__ partials, float* __restrict__ seg_partials, FuseArgs f) {
-    constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS;
+    constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : (MODE == 2 ? SP_GNA_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS);
     __shared__ float lds[SP_WAVES * NV];
     const int w = xcd_chunked_tile(blockIdx.x, n_spans);
     if (w >= n_spans) return;
@@ -864,7 +927,8 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED == 0 ? 4 : 1) void k_cost_pairs(
         c.bias = sgpr(pr.aff[3] - pr.aff[1]);
     }
     c.start = 0; c.count = 0;
-    if (MODE == 1) run_span_gn<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials + (size_t)w * NV, seg_partials, lds);
+    if (MODE == 2) run_span_gn<ABL, FUSED != 0, true>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials + (size_t)w * NV, seg_partials, lds);
+    else if (MODE == 1) run_span_gn<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials + (size_t)w * NV, seg_partials, lds);
     else run_span_grad<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, partials + (size_t)w * NV, seg_partials, lds);
     if (FUSED != 0) {
         __shared__ int is_last;
@@ -1041,7 +1105,7 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spa
 int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                          float* partials, float* seg_partials, const int32_t* done, void* stream) {
     if (!pairs || !chunks || !spans || !partials || !seg_partials || n_spans <= 0) return SP_EINVAL;
-    if (mode != 0 && mode != 1 && !(mode >= 10 && mode <= 15)) return SP_EINVAL;
+    if (mode != 0 && mode != 1 && mode != 2 && !(mode >= 10 && mode <= 15)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_spans + 7) / 8) * 8;
     const int4* c4 = reinterpret_cast<const int4*>(chunks);
@@ -1052,6 +1116,8 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
         hipLaunchKernelGGL(k_cost_pairs<0>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 1)
         hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
+    else if (mode == 2)
+        hipLaunchKernelGGL(k_cost_pairs<2>, dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 10)   /* developer ablations, see run_span_gn */
         hipLaunchKernelGGL((k_cost_pairs<0, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 11)
@@ -1125,7 +1191,7 @@ int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_
         return SP_EINVAL;
     FuseArgs f{};
     f.arrivals = arrivals;
-    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, nullptr, nullptr, 0};
+    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, nullptr, nullptr, 0, 0};
     const int gx = ((n_spans + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cost_pairs<1, 0, 2>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
                        reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, f);

@@ -209,8 +209,13 @@ __device__ bool ldlt6_solve(double S[36], double rhs[6]) {
 
 // {h_pd(6), D, b_d} of segment n summed over its (chunk, wave) records; lam -> {h, 1/(D(1+lam)) or 0, b_d}
 __device__ __forceinline__ void segment_system(const float* __restrict__ p, const int32_t* __restrict__ seg_tile_off, int n,
-                                               double lam, double (&o)[8]) {
+                                               double lam, double (&o)[8], bool pose_only = false) {
     constexpr int NV = SP_GN_SEG_FLOATS;
+    if (pose_only) {             // the segment's depth is not an unknown of this step: nothing to eliminate, nothing to update
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.0;
+        return;
+    }
     double h[6] = {0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
     const int t0 = seg_tile_off[n], t1 = seg_tile_off[n + 1];
     for (int t = t0; t < t1; t += 8) {          // eight records in flight per trip, summed in record order
@@ -250,6 +255,7 @@ struct GnArgs {
     int32_t* phase;          // per-pair schedules (sp_pairs_schedule_*): [n_pairs] current phase, advanced here instead of `done`
     int32_t* iters;          // ... iterations spent in the current phase
     int max_iters;           // ... of at most this many
+    int pose_only;           // SP_PHASE_POSE_ONLY: no Schur complement, no depth update
 };
 
 // One workgroup: tile-partial reduction + Schur-complement LM step of pair `pi` (include/sp_hip.h sp_pairs_gn_step).
@@ -317,7 +323,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
     const int n_cached = min(pr.N, SP_SEG_CACHE);
     for (int n = threadIdx.x; n < n_cached; n += SP_BLOCK) {
         double o[8];
-        segment_system(sp, pr.seg_tile_off, n, lam, o);
+        segment_system(sp, pr.seg_tile_off, n, lam, o, h.pose_only != 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) seg[n][i] = o[i];
     }
@@ -337,7 +343,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
                 if (n < SP_SEG_CACHE) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
-                } else segment_system(sp, pr.seg_tile_off, n, lam, o);
+                } else segment_system(sp, pr.seg_tile_off, n, lam, o, h.pose_only != 0);
                 acc += o[a] * (k < 21 ? o[b] : o[7]) * o[6];
             }
             schur_part[j][k] = acc;
@@ -377,7 +383,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         if (n < SP_SEG_CACHE) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
-        } else segment_system(sp, pr.seg_tile_off, n, lam, o);
+        } else segment_system(sp, pr.seg_tile_off, n, lam, o, h.pose_only != 0);
         if (o[6] > 0.0) {
             double r = -o[7];
 #pragma unroll

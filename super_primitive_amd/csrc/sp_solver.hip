@@ -17,7 +17,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
     solve_gn(pairs, blockIdx.x, partials, seg_partials, h);
 }
 
-static_assert(sizeof(SpPhase) == 56 && sizeof(SpSchedule) == 456, "SpSchedule is part of the ABI");
+static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 520, "SpSchedule is part of the ABI");
 
 // per-pair schedules: the pair's current phase selects the level descriptors, the partial records of that level's work list,
 // the convergence threshold and the iteration budget
@@ -27,9 +27,22 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
     const SpPhase& s = sched.phase[ph];
     h.conv_tol = s.conv_tol;
     h.max_iters = s.max_iters;
+    h.pose_only = s.flags & SP_PHASE_POSE_ONLY;
     solve_gn(s.pairs, blockIdx.x, s.span_partials, s.seg_partials, h);
 }
 
+
+// min over the per-pair phases (one workgroup): what the host polls to end a scheduled run
+__global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restrict__ phase, int n, int32_t* __restrict__ out) {
+    __shared__ int part[SP_WAVES];
+    int m = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += SP_BLOCK) m = min(m, phase[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = min(min(part[0], part[1]), min(part[2], part[3]));
+}
 
 // lie/lie_algebra.py:41-119, one thread per matrix (body: renormalise_rotation in sp_solve_device.h)
 __global__ void k_renormalise(float* __restrict__ T, int n) {
@@ -91,7 +104,7 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
     if (!pairs || !partials || !seg_partials || !lm_state || !backup || !costs || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
     if (conv_tol > 0.f && !done) return SP_EINVAL;
     hipLaunchKernelGGL(k_pairs_gn, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs, partials,
-                       seg_partials, GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, conv_tol, done, nullptr, nullptr, 0});
+                       seg_partials, GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, conv_tol, done, nullptr, nullptr, 0, 0});
     SP_CHECK_LAUNCH();
     return 0;
 }
@@ -105,9 +118,32 @@ int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, f
         if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.max_iters <= 0) return SP_EINVAL;
     }
     hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), *sched,
-                       GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0});
+                       GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0});
     SP_CHECK_LAUNCH();
     return 0;
+}
+
+int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
+                          float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, int check_every,
+                          int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream) {
+    if (!sched || !phase || !iters || !flag_dev || !flag_host || check_every <= 0 || max_rounds < 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int it = 0;
+    while (it < max_rounds) {
+        const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
+        for (int k = 0; k < n; ++k, ++it) {
+            int rc = sp_pairs_schedule_cost(sched, phase, stream);
+            if (rc == 0) rc = sp_pairs_schedule_gn_step(sched, n_pairs, max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, phase, iters, stream);
+            if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
+        }
+        hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_pairs, flag_dev);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        if (*static_cast<volatile int32_t*>(flag_host) >= sched->n_phases) break;
+    }
+    return it;
 }
 
 int sp_pairs_gn_step(const SpPair* pairs, int n_pairs, int max_N, const float* partials, const float* seg_partials,

@@ -167,12 +167,20 @@ __device__ __forceinline__ float4 source_sample(const SourceGeom& g, const float
     const int x0 = (int)fx0, y0 = (int)fy0;
     const float wx = ix - fx0, wy = iy - fy0;
     float rgb[3];
+    // a valid point (0.99 band) has all four taps inside the level whenever Wl, Hl >= 2: one index, no bounds tests
+    const bool inside = g.ok && Wl >= 2 && Hl >= 2;
+    const size_t i00 = (size_t)y0 * Wl + x0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const float* pl = img + (size_t)ch * Hl * Wl;
         // same weight products and summation order as ATen's grid_sampler_2d (nw, ne, sw, se)
-        const float nw = planar_tap(pl, Wl, Hl, x0, y0), ne = planar_tap(pl, Wl, Hl, x0 + 1, y0);
-        const float sw = planar_tap(pl, Wl, Hl, x0, y0 + 1), se = planar_tap(pl, Wl, Hl, x0 + 1, y0 + 1);
+        float nw, ne, sw, se;
+        if (inside) {
+            nw = pl[i00]; ne = pl[i00 + 1]; sw = pl[i00 + Wl]; se = pl[i00 + Wl + 1];
+        } else {
+            nw = planar_tap(pl, Wl, Hl, x0, y0); ne = planar_tap(pl, Wl, Hl, x0 + 1, y0);
+            sw = planar_tap(pl, Wl, Hl, x0, y0 + 1); se = planar_tap(pl, Wl, Hl, x0 + 1, y0 + 1);
+        }
         float acc = nw * ((1.f - wx) * (1.f - wy));
         acc += ne * (wx * (1.f - wy));
         acc += sw * ((1.f - wx) * wy);
@@ -263,87 +271,128 @@ __device__ __forceinline__ uint32_t lattice_bytes(int x0, int stride) {
     return sel;
 }
 
-// Every lattice of the keyframe in the same pass over the masks.  A wave takes SP_PREP_ROWS consecutive (segment,row)
-// rows; when the rows are word-aligned and at most 1024 pixels wide all their words are requested before any is counted
-// (a row is only 160 words at W = 640: one row per wave leaves the memory system idle and the dispatcher busy).
+// Mask word of 16 consecutive pixels (one 16-byte piece of a mask row) as written by the count pass and consumed by the fill
+// pass: pixel 4 q + j of the piece sits at bit 8 j + q, i.e. m = (nz0 >> 7) | (nz1 >> 6) | (nz2 >> 5) | (nz3 >> 4) with nz_q =
+// nonzero_bytes(word q) -- four shifts and two three-input ORs, and ((m >> q) & 0x01010101) << 7 gives nz_q back.  Two bits of
+// storage per pixel (the bits 4-7 of every byte stay clear); the fill pass then reads 4 bytes per 16 pixels instead of 16.
+__device__ __forceinline__ uint32_t piece_bits(uint32_t nz0, uint32_t nz1, uint32_t nz2, uint32_t nz3) {
+    return (nz0 >> 7) | (nz1 >> 6) | (nz2 >> 5) | (nz3 >> 4);
+}
+// the pixels of a 16-pixel piece that lie on the stride lattice, in piece_bits() layout (strides that divide 16 only)
+__device__ __forceinline__ uint32_t lattice_piece(int stride) {
+    return stride == 1 ? 0x0f0f0f0fu : (stride == 2 ? 0x000f000fu : (stride == 4 ? 0x0000000fu : (stride == 8 ? 0x00000005u : 0x00000001u)));
+}
+
+// Every lattice of the keyframe in the same pass over the masks.  Fast path (rows of W = 16 k <= 1024 pixels, 16-byte aligned,
+// lattice strides 1 / 2 / 4 / 8 / 16): a wave takes SP_PREP_ROWS x SP_PREP_TRIPS consecutive (segment,row) rows; a lane owns one
+// 16-byte piece of every row, the loads of the next SP_PREP_ROWS rows are in flight while the current ones are counted, and a
+// row costs ~30 vector instructions (one packed bit word per piece, one and + popcount-accumulate per lattice) -- the round-2
+// form spent 80 (a popcount, a conversion and a float add per word and lattice) and was bound by the vector ALU at 2.7 TB/s.
+// The bit words are also WRITTEN (SpPrepTable.bits): the fill pass reads them instead of the masks.
 #define SP_PREP_ROWS 4
-__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable* __restrict__ tables) {
-    const SpPrepTable& t = tables[blockIdx.y];
-    const int rows = t.N * t.H;
-    const int row0 = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * SP_PREP_ROWS;
-    if (row0 >= rows) return;
-    const int lane = threadIdx.x & 63;
-    const int wpr = t.W >> 2;
-    // per-lane counts of SP_PREP_ROWS rows x SP_PREP_MAX_STRIDES lattices (exact in fp32: a row has at most 65535 pixels),
-    // reduced over the wave together (recursive halving: 17 cross-lane moves for the 16 values)
-    float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
-#pragma unroll
-    for (int i = 0; i < SP_PREP_ROWS * SP_PREP_MAX_STRIDES; ++i) acc[i] = 0.f;
-    // lattice masks of the strides that divide 4 do not depend on the position of the word: taken out of the loops
-    uint32_t sel[SP_PREP_MAX_STRIDES];
+#define SP_PREP_TRIPS 4
+// does this keyframe take the fast path of the count pass (and, if it has a bits array, of the fill pass)?
+__device__ __forceinline__ bool prep_fast_path(const SpPrepTable& t) {
     bool fixed = true;
 #pragma unroll
     for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
         const int st = k < t.n_strides ? t.stride[k] : 1;
-        sel[k] = k < t.n_strides ? lattice_bytes(0, st) : 0u;
-        fixed = fixed && (st == 1 || st == 2 || st == 4);
+        fixed = fixed && (st == 1 || st == 2 || st == 4 || st == 8 || st == 16);
     }
-    if ((t.W & 15) == 0 && ((uintptr_t)t.masks & 15) == 0 && t.W <= 1024) {
-        // 16 bytes per lane: a row of up to 1024 pixels is ONE load per lane
+    return fixed && (t.W & 15) == 0 && ((uintptr_t)t.masks & 15) == 0 && t.W <= 1024;
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable* __restrict__ tables) {
+    const SpPrepTable& t = tables[blockIdx.y];
+    const int rows = t.N * t.H;
+    const int lane = threadIdx.x & 63;
+    if (prep_fast_path(t)) {
+        const int row_base = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * (SP_PREP_ROWS * SP_PREP_TRIPS);
+        if (row_base >= rows) return;
+        uint32_t sel[SP_PREP_MAX_STRIDES];
+#pragma unroll
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) sel[k] = k < t.n_strides ? lattice_piece(t.stride[k]) : 0u;
         const int qpr = t.W >> 4;
-        const uint4* mq = reinterpret_cast<const uint4*>(t.masks) + (size_t)row0 * qpr;
-        uint4 w[SP_PREP_ROWS];
+        const uint4* mq = reinterpret_cast<const uint4*>(t.masks) + (size_t)row_base * qpr;
+        uint32_t* bits = t.bits ? t.bits + (size_t)row_base * qpr : nullptr;
+        const bool mine = lane < qpr;
+        uint4 w[2][SP_PREP_ROWS];
 #pragma unroll
         for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
-            w[rr] = (row0 + rr < rows && lane < qpr) ? mq[(size_t)rr * qpr + lane] : make_uint4(0u, 0u, 0u, 0u);
+            w[0][rr] = (row_base + rr < rows && mine) ? mq[(size_t)rr * qpr + lane] : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
-            const uint32_t ws[4] = {w[rr].x, w[rr].y, w[rr].z, w[rr].w};
+        for (int tr = 0; tr < SP_PREP_TRIPS; ++tr) {
+            const int row0 = row_base + tr * SP_PREP_ROWS;
+            if (tr + 1 < SP_PREP_TRIPS) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t nz = nonzero_bytes(ws[q]);
-#pragma unroll
-                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
-                    acc[rr * SP_PREP_MAX_STRIDES + k] += (float)__popc(nz & (fixed ? sel[k] : (k < t.n_strides ? lattice_bytes(16 * lane + 4 * q, t.stride[k]) : 0u)));
+                for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
+                    const int r = row0 + SP_PREP_ROWS + rr;
+                    w[(tr + 1) & 1][rr] = (r < rows && mine) ? mq[(size_t)(r - row_base) * qpr + lane] : make_uint4(0u, 0u, 0u, 0u);
+                }
             }
+            float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
+#pragma unroll
+            for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
+                const uint4 v = w[tr & 1][rr];
+                const uint32_t m = piece_bits(nonzero_bytes(v.x), nonzero_bytes(v.y), nonzero_bytes(v.z), nonzero_bytes(v.w));
+                if (bits && mine && row0 + rr < rows) bits[(size_t)(row0 + rr - row_base) * qpr + lane] = m;
+#pragma unroll
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) acc[rr * SP_PREP_MAX_STRIDES + k] = (float)__popc(m & sel[k]);
+            }
+            int pos;
+            bool ok;
+            wave_sum_to_lanes<SP_PREP_ROWS * SP_PREP_MAX_STRIDES>(acc, lane, pos, ok);
+            const int rr = pos / SP_PREP_MAX_STRIDES, k = pos % SP_PREP_MAX_STRIDES, row = row0 + rr;
+            if (ok && k < t.n_strides && row < rows) t.row_counts[k][row] = ((row % t.H) % t.stride[k] == 0) ? (int)acc[0] : 0;
         }
-    } else if ((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0 && wpr <= 256) {
-        const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks) + (size_t)row0 * wpr;
-        uint32_t w[SP_PREP_ROWS][4];
-#pragma unroll
-        for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int xw = q * 64 + lane;
-                w[rr][q] = (row0 + rr < rows && xw < wpr) ? mw[(size_t)rr * wpr + xw] : 0u;
-            }
-#pragma unroll
-        for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t nz = nonzero_bytes(w[rr][q]);
-#pragma unroll
-                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
-                    acc[rr * SP_PREP_MAX_STRIDES + k] += (float)__popc(nz & (fixed ? sel[k] : (k < t.n_strides ? lattice_bytes(4 * (q * 64 + lane), t.stride[k]) : 0u)));
-            }
-    } else {
-#pragma unroll
-        for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
-            if (row0 + rr >= rows) break;
-            const uint8_t* m = t.masks + (size_t)(row0 + rr) * t.W;
-            for (int x = lane; x < t.W; x += 64) {
-                const bool on = m[x] != 0;
-#pragma unroll
-                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
-                    if (k < t.n_strides) acc[rr * SP_PREP_MAX_STRIDES + k] += (on && x % t.stride[k] == 0) ? 1.f : 0.f;
-            }
-        }
+        return;
     }
-    int pos;
-    bool ok;
-    wave_sum_to_lanes<SP_PREP_ROWS * SP_PREP_MAX_STRIDES>(acc, lane, pos, ok);
-    const int rr = pos / SP_PREP_MAX_STRIDES, k = pos % SP_PREP_MAX_STRIDES, row = row0 + rr;
-    if (ok && k < t.n_strides && row < rows) t.row_counts[k][row] = ((row % t.H) % t.stride[k] == 0) ? (int)acc[0] : 0;
+    // general path (any width, alignment and stride): the same rows, SP_PREP_ROWS at a time, word or byte loads
+    const int wpr = t.W >> 2;
+    for (int tr = 0; tr < SP_PREP_TRIPS; ++tr) {
+        const int row0 = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * (SP_PREP_ROWS * SP_PREP_TRIPS) + tr * SP_PREP_ROWS;
+        if (row0 >= rows) return;
+        float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
+#pragma unroll
+        for (int i = 0; i < SP_PREP_ROWS * SP_PREP_MAX_STRIDES; ++i) acc[i] = 0.f;
+        if ((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0 && wpr <= 256) {
+            const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks) + (size_t)row0 * wpr;
+            uint32_t w[SP_PREP_ROWS][4];
+#pragma unroll
+            for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int xw = q * 64 + lane;
+                    w[rr][q] = (row0 + rr < rows && xw < wpr) ? mw[(size_t)rr * wpr + xw] : 0u;
+                }
+#pragma unroll
+            for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t nz = nonzero_bytes(w[rr][q]);
+#pragma unroll
+                    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                        acc[rr * SP_PREP_MAX_STRIDES + k] += (float)__popc(nz & (k < t.n_strides ? lattice_bytes(4 * (q * 64 + lane), t.stride[k]) : 0u));
+                }
+        } else {
+#pragma unroll
+            for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
+                if (row0 + rr >= rows) break;
+                const uint8_t* m = t.masks + (size_t)(row0 + rr) * t.W;
+                for (int x = lane; x < t.W; x += 64) {
+                    const bool on = m[x] != 0;
+#pragma unroll
+                    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                        if (k < t.n_strides) acc[rr * SP_PREP_MAX_STRIDES + k] += (on && x % t.stride[k] == 0) ? 1.f : 0.f;
+                }
+            }
+        }
+        int pos;
+        bool ok;
+        wave_sum_to_lanes<SP_PREP_ROWS * SP_PREP_MAX_STRIDES>(acc, lane, pos, ok);
+        const int rr = pos / SP_PREP_MAX_STRIDES, k = pos % SP_PREP_MAX_STRIDES, row = row0 + rr;
+        if (ok && k < t.n_strides && row < rows) t.row_counts[k][row] = ((row % t.H) % t.stride[k] == 0) ? (int)acc[0] : 0;
+    }
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* __restrict__ tables) {
@@ -388,34 +437,32 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
     }
     const int s_n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     const bool words = (t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0;
-    for (int i = wave; i < s_n; i += SP_WAVES) {
-        const int row_id = s_rows[i];
-        const int n = row_id / t.H, r = row_id - n * t.H;
-        if (!words) {
-            for (int k = 0; k < t.n_strides; ++k)
-                fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
-            continue;
-        }
-        const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks + (size_t)row_id * t.W);
-        const float* L = t.logdepth + (size_t)row_id * t.W;
-        int base[SP_PREP_MAX_STRIDES];
-        bool act[SP_PREP_MAX_STRIDES];
+    const bool use_bits = t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0;       // (the count pass wrote them)
+    // One row's compaction into every lattice's table.  A lane owns the 4-pixel groups xw = q * 64 + lane (q < 4: rows of up to
+    // 1024 pixels); nz[q] = nonzero_bytes() form of its mask bits, Lv[q] = the 4 log-depths of the group.
+    int base[SP_PREP_MAX_STRIDES];
+    bool act[SP_PREP_MAX_STRIDES];
+    int r = 0;
+    auto row_begin = [&](int row_id) {
+        const int n = row_id / t.H;
+        r = row_id - n * t.H;
 #pragma unroll
         for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
             act[k] = k < t.n_strides && r % t.stride[k] == 0;
             base[k] = act[k] ? t.seg_off[k][n] + t.row_counts[k][row_id] : 0;
         }
-        for (int w0 = 0; w0 < (t.W >> 2); w0 += 64) {
-            const int xw = w0 + lane;
-            const uint32_t nz = xw < (t.W >> 2) ? nonzero_bytes(mw[xw]) : 0u;
-            if (__ballot(nz != 0u) == 0ull) continue;
-            float Lv[4];
+    };
+    // the groups w0 + q * 64 + lane (q < 4) of the row begun with row_begin(), left to right
+    auto emit_groups = [&](int w0, const uint32_t (&nz)[4], const float4 (&Lv)[4]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) Lv[j] = ((nz >> (8 * j + 7)) & 1u) ? L[4 * xw + j] : 0.f;
+        for (int q = 0; q < 4; ++q) {
+            if (__ballot(nz[q] != 0u) == 0ull) continue;
+            const int xw = w0 + q * 64 + lane;
+            const float Lq[4] = {Lv[q].x, Lv[q].y, Lv[q].z, Lv[q].w};
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
                 if (!act[k]) continue;
-                const uint32_t sel = nz & lattice_bytes(4 * xw, t.stride[k]);
+                const uint32_t sel = nz[q] & lattice_bytes(4 * xw, t.stride[k]);
                 const int cnt = __popc(sel);
                 const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
                 int pos = base[k] + __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
@@ -423,11 +470,71 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
                 for (int j = 0; j < 4; ++j)
                     if ((sel >> (8 * j + 7)) & 1u) {
                         t.pix[k][pos] = ((uint32_t)r << 16) | (uint32_t)(4 * xw + j);
-                        t.baseL[k][pos] = Lv[j];
+                        t.baseL[k][pos] = Lq[j];
                         ++pos;
                     }
                 base[k] += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
             }
+        }
+    };
+    if (use_bits) {
+        // Three rows in flight per wave: the bit words of row i + 2 and the log-depths of row i + 1 are requested before row i
+        // is compacted (a row is two dependent loads -- bits, then the log-depths of its set pixels -- and a chain of ballots:
+        // processed one after the other, the waves sat in memory latency and the pass ran at 0.14 of the HBM roofline).
+        const int qpr = t.W >> 4, wpr = t.W >> 2;
+        auto load_bits = [&](int row_id, uint32_t (&nz)[4]) {
+            const uint32_t* bw = t.bits + (size_t)row_id * qpr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xw = q * 64 + lane;
+                nz[q] = xw < wpr ? (((bw[xw >> 2] >> (xw & 3)) & 0x01010101u) << 7) : 0u;
+            }
+        };
+        auto load_L = [&](int row_id, const uint32_t (&nz)[4], float4 (&Lv)[4]) {
+            const float* L = t.logdepth + (size_t)row_id * t.W;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Lv[q] = nz[q] ? *reinterpret_cast<const float4*>(L + 4 * (q * 64 + lane)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        uint32_t nz0[4] = {0u, 0u, 0u, 0u}, nz1[4] = {0u, 0u, 0u, 0u}, nz2[4] = {0u, 0u, 0u, 0u};
+        float4 L0[4], L1[4];
+        int i = wave;
+        if (i < s_n) load_bits(s_rows[i], nz0);
+        if (i + SP_WAVES < s_n) load_bits(s_rows[i + SP_WAVES], nz1);
+        if (i < s_n) load_L(s_rows[i], nz0, L0);
+        for (; i < s_n; i += SP_WAVES) {
+            if (i + 2 * SP_WAVES < s_n) load_bits(s_rows[i + 2 * SP_WAVES], nz2);
+            if (i + SP_WAVES < s_n) load_L(s_rows[i + SP_WAVES], nz1, L1);
+            row_begin(s_rows[i]);
+            emit_groups(0, nz0, L0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { nz0[q] = nz1[q]; L0[q] = L1[q]; nz1[q] = nz2[q]; }
+        }
+        return;
+    }
+    for (int i = wave; i < s_n; i += SP_WAVES) {
+        const int row_id = s_rows[i];
+        if (!words) {
+            for (int k = 0; k < t.n_strides; ++k)
+                fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
+            continue;
+        }
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks + (size_t)row_id * t.W);
+        const float* L = t.logdepth + (size_t)row_id * t.W;
+        row_begin(row_id);
+        for (int w0 = 0; w0 < (t.W >> 2); w0 += 256) {       // (4 x 64 groups at a time)
+            uint32_t nz[4];
+            float4 Lv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int xw = w0 + q * 64 + lane;
+                nz[q] = xw < (t.W >> 2) ? nonzero_bytes(mw[xw]) : 0u;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ((nz[q] >> (8 * j + 7)) & 1u) ? L[4 * xw + j] : 0.f;
+                Lv[q] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            emit_groups(w0, nz, Lv);
         }
     }
 }
@@ -538,7 +645,7 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
 }
 
 
-static_assert(sizeof(SpPrepTable) == 224 && sizeof(SpPrepSample) == 176 && sizeof(SpPrepImage) == 24, "preparation job records are part of the ABI");
+static_assert(sizeof(SpPrepTable) == 232 && sizeof(SpPrepSample) == 176 && sizeof(SpPrepImage) == 24, "preparation job records are part of the ABI");
 
 // ---- batched preparation ----
 static int check_grid(long x, long y) { return (x <= 0 || y <= 0 || y > 65535) ? SP_EINVAL : 0; }
@@ -546,7 +653,7 @@ static int check_grid(long x, long y) { return (x <= 0 || y <= 0 || y > 65535) ?
 int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int per_block = SP_WAVES * SP_PREP_ROWS;
+    const int per_block = SP_WAVES * SP_PREP_ROWS * SP_PREP_TRIPS;
     hipLaunchKernelGGL(k_prep_row_counts, dim3((max_rows + per_block - 1) / per_block, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_row_scan, dim3(max_N, n_tables, SP_PREP_MAX_STRIDES), dim3(SP_BLOCK), 0, s, tables);

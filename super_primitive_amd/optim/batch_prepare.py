@@ -123,13 +123,59 @@ def stage(arrays, dev):
     return out
 
 
-def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev):
+class _Timer:
+    """Optional per-pass HIP-event timing of ``prepare_pairs`` (bench.py's ``roofline_setup``): ``with timer('count'): launch``."""
+
+    def __init__(self):
+        self.events = []
+
+    class _Span:
+        def __init__(self, owner, name):
+            self.owner, self.name = owner, name
+
+        def __enter__(self):
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+        def __exit__(self, *exc):
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.owner.events.append((self.name, self.e0, e1))
+
+    def __call__(self, name):
+        return _Timer._Span(self, name)
+
+    def milliseconds(self):
+        """{pass: ms} (call after a synchronisation)."""
+        out = {}
+        for name, e0, e1 in self.events:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
+class _NoTimer:
+    class _Null:
+        def __enter__(self):
+            pass
+
+        def __exit__(self, *exc):
+            pass
+
+    def __call__(self, name):
+        return _NoTimer._Null()
+
+
+def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, full_levels=None, timer=None):
     """Everything PairBatch needs from the raw frames, for the M0 given pairs.
 
     coarse: [(level, stride)] -- ADDITIONAL decimated tables (stride > 1) sampled at that level; the stride-1 tables are
-    always built and sampled at every level.  Returns dict(tabs {stride: PreparedTables}, kp_L (sum N,),
-    trg {level: (flat HWC3, trg_off, [(Hl, Wl)])}, n_off, shapes (M0, 3) = N, H, W, Ks (2 M0, 3, 3) = the source and target
-    intrinsics on the HOST, for the descriptors)."""
+    always built.  ``full_levels``: the pyramid levels at which the stride-1 (all points) tables are sampled NOW (default:
+    every level); the others can be sampled later with the returned ``sample_full(levels)`` -- a schedule that iterates its
+    coarse levels on decimated tables never reads them (2 x 16 B per point of writes and 24 of the 36 tap loads per point saved at
+    3 levels).  Returns dict(tabs {stride: PreparedTables}, kp_L (sum N,), trg {level: (flat HWC3, trg_off, [(Hl, Wl)])}, n_off,
+    shapes (M0, 3) = N, H, W, Ks (2 M0, 3, 3) = the source and target intrinsics on the HOST for the descriptors,
+    sample_full, bytes = algorithmic bytes of every pass)."""
+    timer = timer or _NoTimer()
     lib = _lib.load()
     M0 = len(src_frames)
     s_ptr = _lib.stream_ptr()
@@ -163,8 +209,16 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev):
         recs['row_counts'][:, si] = row_counts.data_ptr() + 4 * (si * int(rc_off[-1]) + rc_off[:-1])
         recs['counts'][:, si] = counts_d.data_ptr() + 4 * (si * S + n_off[:-1])
     max_rows, max_N = int(rows.max()), int(Ns.max())
+    # the masks as packed bit words (one per 16 pixels), written by the count pass and read by the fill pass instead of the masks;
+    # only for keyframes on the count pass's fast path (include/sp_hip.h SpPrepTable.bits)
+    fast = ((Ws % 16 == 0) & (Ws <= 1024) & (recs['masks'] % 16 == 0)) if all(s in (1, 2, 4, 8, 16) for s in all_strides) else np.zeros(M0, dtype=bool)
+    words = np.where(fast, rows * (Ws // 16), 0)
+    w_off = np.concatenate(([0], np.cumsum(words)))
+    bits = torch.empty(max(int(w_off[-1]), 1), dtype=torch.int32, device=dev)
+    recs['bits'] = np.where(fast, bits.data_ptr() + 4 * w_off[:-1], 0).astype(np.uint64)
     staged = stage([recs], dev)
-    _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
+    with timer('count'):
+        _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
     counts_pinned = torch.empty(nS * S, dtype=torch.int32, pin_memory=True)
     counts_pinned.copy_(counts_d, non_blocking=True)
     counts_ready = torch.cuda.Event()
@@ -212,10 +266,12 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev):
         jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
         trg[l] = (buf, off, [(int(h), int(w)) for h, w in hw[l]])
     staged = stage([pack_jobs] + blur_jobs, dev)
-    for l in range(1, max_level + 1):
-        _lib.check(lib.sp_prepare_blur(_lib.ptr(staged[l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
-    _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
-               "sp_prepare_pack")
+    with timer('pyramid'):
+        for l in range(1, max_level + 1):
+            _lib.check(lib.sp_prepare_blur(_lib.ptr(staged[l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
+    with timer('pack'):
+        _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
+                   "sp_prepare_pack")
 
     # ---- host: padded layouts; device: fill straight into them ----
     counts_ready.synchronize()                    # the one host synchronisation of the set-up (the pyramids keep the GPU busy)
@@ -247,34 +303,66 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev):
 
     # ---- source samples: the stride-1 tables at every level, a decimated table at its own level(s), all levels of a table
     #      in one pass (which also sets the table's source-validity bits) ----
-    levels_of = {1: list(level_ids)}
+    levels_of = {1: [int(l) for l in (level_ids if full_levels is None else full_levels)]}
     for l, s in coarse:
         if int(s) > 1 and int(l) not in levels_of.setdefault(int(s), []):
             levels_of[int(s)].append(int(l))
-    jobs = np.zeros(len(levels_of) * M0, dtype=_SAMPLE_DT)
-    max_P = 1
-    for ji, (s, lv) in enumerate(levels_of.items()):
-        t = tabs[s]
-        jb = jobs[ji * M0: (ji + 1) * M0]
-        P = np.diff(t.p_off)
-        max_P = max(max_P, int(P.max()))
-        jb['pix'] = t.pix.data_ptr() + 4 * t.p_off[:-1]
-        jb['baseL'] = t.baseL.data_ptr() + 4 * t.p_off[:-1]
-        jb['seg_off'] = t.seg_off.data_ptr() + 4 * (S + n_off[:-1])              # the pair-relative half
-        jb['counts'] = t.counts_d.data_ptr() + 4 * n_off[:-1]
-        jb['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
-        jb['kld'], jb['K'] = _ptrs(kld), _ptrs(Ksrc)
-        jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'] = Ns, P, Hs, Ws, len(lv)
-        for k, l in enumerate(lv):
-            t.src4[l] = torch.empty(max(int(t.p_off[-1]), 1), 4, dtype=torch.float32, device=dev)
-            jb['image'][:, k] = ptr_lv[l][0]
-            jb['src4'][:, k] = t.src4[l].data_ptr() + 16 * t.p_off[:-1]
-            jb['Hl'][:, k], jb['Wl'][:, k] = hw[l][:, 0], hw[l][:, 1]
+
+    def sample_jobs(levels_of):
+        """SpPrepSample records sampling table ``stride`` at the levels ``levels_of[stride]`` (allocates the src4 arrays)."""
+        jobs = np.zeros(len(levels_of) * M0, dtype=_SAMPLE_DT)
+        max_P = 1
+        for ji, (s, lv) in enumerate(levels_of.items()):
+            t = tabs[s]
+            jb = jobs[ji * M0: (ji + 1) * M0]
+            P = np.diff(t.p_off)
+            max_P = max(max_P, int(P.max()))
+            jb['pix'] = t.pix.data_ptr() + 4 * t.p_off[:-1]
+            jb['baseL'] = t.baseL.data_ptr() + 4 * t.p_off[:-1]
+            jb['seg_off'] = t.seg_off.data_ptr() + 4 * (S + n_off[:-1])              # the pair-relative half
+            jb['counts'] = t.counts_d.data_ptr() + 4 * n_off[:-1]
+            jb['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
+            jb['kld'], jb['K'] = _ptrs(kld), _ptrs(Ksrc)
+            jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'] = Ns, P, Hs, Ws, len(lv)
+            for k, l in enumerate(lv):
+                t.src4[l] = torch.empty(max(int(t.p_off[-1]), 1), 4, dtype=torch.float32, device=dev)
+                jb['image'][:, k] = ptr_lv[l][0]
+                jb['src4'][:, k] = t.src4[l].data_ptr() + 16 * t.p_off[:-1]
+                jb['Hl'][:, k], jb['Wl'][:, k] = hw[l][:, 0], hw[l][:, 1]
+        return jobs, max_P
+
+    jobs, max_P = sample_jobs(levels_of)
     staged = stage([recs, jobs], dev)
-    _lib.check(lib.sp_prepare_fill(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_fill")
-    _lib.check(lib.sp_prepare_sample(_lib.ptr(staged[1]), len(jobs), max_P, s_ptr), "sp_prepare_sample")
+    with timer('fill'):
+        _lib.check(lib.sp_prepare_fill(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_fill")
+    with timer('sample'):
+        _lib.check(lib.sp_prepare_sample(_lib.ptr(staged[1]), len(jobs), max_P, s_ptr), "sp_prepare_sample")
+
+    def sample_full(levels):
+        """Sample the stride-1 tables at further pyramid levels (those left out of ``full_levels``): {level: (sum Ppad, 4)}.
+        Holds the source pyramid and the per-pair inputs alive for as long as the caller keeps this function."""
+        levels = [int(l) for l in levels if int(l) not in tabs[1].src4]
+        if levels:
+            jb, mp = sample_jobs({1: levels})
+            st = stage([jb], dev)
+            _lib.check(lib.sp_prepare_sample(_lib.ptr(st[0]), len(jb), mp, _lib.stream_ptr()), "sp_prepare_sample")
+        return tabs[1].src4
+
+    sample_full._keep = (pyramid, simg, kld, Ksrc)
+    # algorithmic bytes of every pass (DESIGN.md section 3): what it must read and write once
+    n_pts = {s: int(t.counts.sum()) for s, t in tabs.items()}
+    img_px = {l: int((hw[l][:, 0] * hw[l][:, 1]).sum()) for l in hw}
+    sampled_levels = sorted({l for lv in levels_of.values() for l in lv})
+    nbytes = {
+        'count': int((Ns * Hs * Ws).sum()) + 4 * int(words.sum()),                       # masks in (1 B / pixel and segment), bit words out
+        'fill': 4 * n_pts[1] + 8 * sum(n_pts.values()) + n_pts[1] // 4,                  # L in (once per mask pixel), pix + baseL out per lattice point, set bits in
+        'sample': sum((12 + 16 * len(lv)) * n_pts[s] for s, lv in levels_of.items())     # pix + baseL in, pix out, one src4 per sampled level out
+                  + sum(12 * img_px[l] for l in sampled_levels),                         # ... and every sampled source level read once
+        'pyramid': sum(2 * 12 * (img_px[l - 1] + img_px[l]) for l in range(1, max_level + 1)),      # both frames: level l-1 in, level l out
+        'pack': sum(2 * 12 * img_px[l] for l in level_ids),                              # targets: planar in, HWC3 out
+    }
     del pyramid
-    # (temporaries -- job records, row counts, pyramid levels -- are released here; the caching allocator orders their reuse
-    #  after the launches above on this stream)
+    # (temporaries -- job records, row counts -- are released here; the caching allocator orders their reuse after the launches
+    #  above on this stream)
     Ks_ready.synchronize()
-    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp, Ks=Ks_pinned.numpy())
+    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp, Ks=Ks_pinned.numpy(), sample_full=sample_full, bytes=nbytes)

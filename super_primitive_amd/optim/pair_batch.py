@@ -47,9 +47,9 @@ FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps
 # randn(6)), depth seeds log(2 + 2 rand)): tests/test_gpu_sigma05.py requires it to converge wherever the real reference loop does
 # (golden g19), inside the north-star bar of the reference's end state; bench.py quotes ``frame_pairs_per_sec`` on it next to the
 # near-start figure (tools/sigma05_sweep.py holds the sweep it was chosen from, profiles/r03_sigma05_sweep.txt its results).
-REFERENCE_START_LEVELS = (0, 4)
-REFERENCE_START_POINT_STRIDE = (1, 2, 4, 8)
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE)
+REFERENCE_START_LEVELS = (0, 3)
+REFERENCE_START_POINT_STRIDE = (1, 2, 4)
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15)
 
 
 def _level_images(img, max_level):
@@ -119,10 +119,23 @@ class _Layout:
     """A point set with its work list: pix / src4 tables, chunks / spans, per-level descriptors and partial buffers."""
 
 
+class _Lazy(dict):
+    """{level: value} whose missing entries are made on first access (full-resolution source samples and descriptors of
+    pyramid levels a decimated schedule never touches)."""
+
+    def __init__(self, make, *a, **kw):
+        super().__init__(*a, **kw)
+        self._make = make
+
+    def __missing__(self, key):
+        self[key] = v = self._make(key)
+        return v
+
+
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
                  tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None, point_stride=None,
-                 extra_tables=()):
+                 extra_tables=(), lazy_levels=True, timer=None):
         """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
         device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
@@ -141,7 +154,10 @@ class PairBatch:
         ADDITION, a decimated copy of the point tables -- the mask pixels whose column and row are multiples of s -- with its
         own work list, descriptors and partial buffers (``self.coarse[(level, s)]``); ``extra_tables`` = further (level,
         stride) combinations for explicit ``schedule(phases=...)`` lists.  Only ``run_scheduled`` uses them; every per-level
-        method below (cost_pass, gn_step, adam_step, evaluate, run, run_converging) works on all points."""
+        method below (cost_pass, gn_step, adam_step, evaluate, run, run_converging) works on all points.
+        ``lazy_levels``: the all-points source samples (and descriptors) of a level that has a decimated table are made on first
+        use instead of at construction -- the scheduled run never reads them (``self.src4`` / ``self.desc`` fill in on access).
+        ``timer``: a ``batch_prepare._Timer`` that collects per-pass HIP-event times of the set-up."""
         lib = _lib.load()
         self.lib = lib
         M0 = len(src_frames)
@@ -165,7 +181,11 @@ class PairBatch:
         # (optim/batch_prepare.py)
         klds_all = klds if len(klds) == M and R > 1 else None
         klds = klds[:M0]
-        prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev)
+        decimated = {l for l, s in coarse_keys if l in self.point_stride and self.point_stride[l] == s}
+        full_levels = [l for l in self.level_ids if not (lazy_levels and l in decimated)] or [min(self.level_ids)]
+        prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev, full_levels=full_levels,
+                                           timer=timer)
+        self.setup_bytes = prep['bytes']
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
         rep = (lambda x: x) if R == 1 else (lambda x: x.repeat(*([R] + [1] * (x.dim() - 1))))
         tile = (lambda a: a) if R == 1 else (lambda a: np.tile(a, R))
@@ -192,7 +212,8 @@ class PairBatch:
         self.pose = poses.detach().to(device=dev, dtype=torch.float32).reshape(M, 16).clone()       # owned: updated in place
         self.aff = torch.zeros(M, 4, dtype=torch.float32, device=dev) if use_affine else None
         self.pix = rep(full.pix)
-        self.src4 = {l: rep(full.src4[l]).reshape(-1) for l in self.level_ids}
+        sample_full = prep['sample_full']
+        self.src4 = _Lazy(lambda l: rep(sample_full([l])[l]).reshape(-1), {l: rep(full.src4[l]).reshape(-1) for l in full_levels})
         self.trg4 = {l: rep(trg[l][0]) for l in self.level_ids}
         trg_off = {l: np.concatenate(([0], np.cumsum(tile(np.diff(trg[l][1]))))) for l in self.level_ids}
         self.level_hw = {l: list(trg[l][2]) * R for l in self.level_ids}
@@ -264,14 +285,15 @@ class PairBatch:
             d['rec0'] = 4 * lay_wl['c_off'][:-1]
             return d
 
-        host = [descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps)) for l in self.level_ids]
+        host = [descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps)) for l in full_levels]
         for (l, stride), lay in self.coarse.items():
             c_wl, c_p_off = coarse_host[(l, stride)]
             host.append(descriptors(l, lay.pix, lay.src4, lay.seg_tile_off, c_p_off, c_wl, np.maximum(np.asarray(lay.points), 1)))
         staged = batch_prepare.stage(host, dev)
-        self.desc = dict(zip(self.level_ids, staged))
+        self.desc = _Lazy(lambda l: batch_prepare.stage([descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps))], dev)[0],
+                          dict(zip(full_levels, staged)))
         for i, lay in enumerate(self.coarse.values()):
-            lay.desc = staged[len(self.level_ids) + i]
+            lay.desc = staged[len(full_levels) + i]
             lay.partials = torch.empty(max(lay.n_spans, 1) * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
             lay.seg_partials = torch.empty(max(4 * lay.n_chunks, 1) * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
 
@@ -288,6 +310,7 @@ class PairBatch:
         self.phase_iters = torch.zeros(M, dtype=torch.int32, device=dev)
         self.reset_lm()
         self._graphs = {}
+        self._flag = None
         self._initial = (self.pose.clone(), self.kld.clone())
 
     def restore_initial(self):
@@ -422,13 +445,21 @@ class PairBatch:
         return launched
 
     def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3, phases=None,
-                 use_coarse=True):
+                 use_coarse=True, pose_first_iters=0):
         """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
         built with a ``point_stride`` run on their decimated point set unless ``use_coarse=False``.  ``phases``: an explicit
         list of dict(level, stride, max_iters, irls_eps, conv_tol) instead (every (level, stride > 1) needs its table:
-        ``point_stride`` / ``extra_tables`` of the constructor)."""
+        ``point_stride`` / ``extra_tables`` of the constructor; optional ``pose_only=True``).  ``pose_first_iters`` > 0 puts a
+        POSE-ONLY phase of at most that many iterations in front, at the coarsest level (SP_PHASE_POSE_ONLY, include/sp_hip.h): the
+        depths keep their seeds while the pose is aligned -- what makes the schedule converge from the reference's own starting
+        distribution (REFERENCE_START_SCHEDULE)."""
         if phases is None:
-            phases = [dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=max_iters_per_level, irls_eps=irls_eps,
+            phases = []
+            if pose_first_iters > 0:
+                coarsest = max(self.level_ids)
+                phases.append(dict(level=coarsest, stride=self.point_stride[coarsest] if use_coarse else 1, max_iters=pose_first_iters,
+                                   irls_eps=irls_eps, conv_tol=conv_tol, pose_only=True))
+            phases += [dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=max_iters_per_level, irls_eps=irls_eps,
                            conv_tol=conv_tol) for level in reversed(self.level_ids)]
             if polish_max > 0:
                 phases.append(dict(level=min(self.level_ids), stride=1, max_iters=polish_max, irls_eps=polish_eps, conv_tol=polish_tol))
@@ -446,6 +477,7 @@ class PairBatch:
                 ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(lay.desc), _lib.ptr(lay.chunks), _lib.ptr(lay.spans), lay.n_spans
                 ph.span_partials, ph.seg_partials = _lib.ptr(lay.partials), _lib.ptr(lay.seg_partials)
             ph.irls_eps, ph.conv_tol, ph.max_iters = float(spec.get("irls_eps", irls_eps)), float(spec["conv_tol"]), int(spec["max_iters"])
+            ph.flags = _lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0
         sched.n_phases = len(phases)
         return sched
 
@@ -461,17 +493,16 @@ class PairBatch:
         self.lm_state[:, 1] = -1.0
         self.lm_state[:, 4] = 0.0
         bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases))
-        it = 0
-        while it < bound:
-            for _ in range(min(check_every, bound - it)):
-                _lib.check(self.lib.sp_pairs_schedule_cost(ctypes.addressof(sched), _lib.ptr(self.phase), _lib.stream_ptr()), "sp_pairs_schedule_cost")
-                _lib.check(self.lib.sp_pairs_schedule_gn_step(ctypes.addressof(sched), self.M, self.max_N, float(lm_up), float(lm_down), float(lm_min),
-                                                              _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs),
-                                                              _lib.ptr(self.phase), _lib.ptr(self.phase_iters), _lib.stream_ptr()),
-                           "sp_pairs_schedule_gn_step")
-                it += 1
-            if int(self.phase.min()) >= sched.n_phases:
-                break
+        if self._flag is None:
+            self._flag = (torch.zeros(1, dtype=torch.int32, device=self.device), torch.zeros(1, dtype=torch.int32).pin_memory())
+        # the whole host loop in ONE foreign call (sp_pairs_schedule_run): nothing is issued from Python per iteration, and the
+        # interpreter lock is free for the other host threads of a PairStream while this batch runs
+        it = self.lib.sp_pairs_schedule_run(ctypes.addressof(sched), self.M, self.max_N, float(lm_up), float(lm_down), float(lm_min),
+                                            _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.ptr(self.phase),
+                                            _lib.ptr(self.phase_iters), int(check_every), int(bound), _lib.ptr(self._flag[0]),
+                                            self._flag[1].data_ptr(), _lib.stream_ptr())
+        if it < 0:
+            _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run")
         return it
 
     def run(self, iters_per_level, mode="gn", use_graph=False, polish_iters=0, polish_eps=1e-5, **kw):

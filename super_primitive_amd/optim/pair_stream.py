@@ -22,10 +22,19 @@ from .pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
 
 
 class PairStream:
-    def __init__(self, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, schedule=None, device="cuda:0", depth=1, **batch_kw):
+    def __init__(self, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, schedule=None, device="cuda:0", depth=1, optimisers=1, **batch_kw):
         """``schedule``: keyword arguments of ``PairBatch.run_scheduled`` (default: FRAME_PAIR_SCHEDULE); ``depth``: how many
-        built batches may wait for the optimiser (each holds its tables in device memory; peak residency is ``depth`` + 2
-        batches: one being built, ``depth`` queued, one being optimised); ``batch_kw``: passed to PairBatch.
+        built batches may wait for an optimiser (each holds its tables in device memory; peak residency is ``depth`` + 1 +
+        ``optimisers`` batches: one being built, ``depth`` queued, one per optimiser); ``batch_kw``: passed to PairBatch.
+
+        ``optimisers`` = K > 1: CONTINUOUS BATCHING at batch granularity.  K batches run their schedules at the same time, each on
+        its own HIP stream and host thread.  A scheduled batch ends in a long tail -- the last ~10 % of its pairs iterate almost
+        alone for a third of the rounds, at the latency of a two-launch iteration, with most of the chip idle
+        (profiles/r02_schedule_sweep.txt) -- and the bulk phase of the next batch fills exactly that idle capacity: finished
+        pairs' slots are, in effect, handed to fresh pairs without touching a single table or descriptor.  Pairs never interact
+         and every batch keeps its own work lists and partial buffers, so each pair's result is bitwise
+        the one it has when optimised alone.
+
         Meant to be long-lived: the caching allocator keeps one pool per stream, so a PairStream reuses its tables' memory
         from batch to batch, while a fresh one (fresh streams) pays for device allocations again."""
         self.levels, self.point_stride, self.batch_kw = levels, point_stride, batch_kw
@@ -35,10 +44,11 @@ class PairStream:
         # (equal priorities: giving the optimiser's chain of short launches a high-priority stream measured 9 % SLOWER at 384
         #  pairs per batch and collapsed at 64 -- tools/stream_bench.py)
         self.setup_stream = torch.cuda.Stream(self.device)
-        self.optim_stream = torch.cuda.Stream(self.device)
+        self.optim_streams = [torch.cuda.Stream(self.device) for _ in range(max(1, int(optimisers)))]
+        self.optim_stream = self.optim_streams[0]
 
-    def _producer(self, inputs, out, ready_for_inputs, stop):
-        def put(item):                       # never blocks for good: the consumer may have gone away
+    def _producer(self, inputs, out, ready_for_inputs, stop, n_consumers):
+        def put(item):                       # never blocks for good: the consumers may have gone away
             while not stop.is_set():
                 try:
                     out.put(item, timeout=0.1)
@@ -51,57 +61,89 @@ class PairStream:
             torch.cuda.set_device(self.device)
             with torch.cuda.stream(self.setup_stream):
                 self.setup_stream.wait_event(ready_for_inputs)
-                for item in inputs:
+                for idx, item in enumerate(inputs):
                     if stop.is_set():
                         return
                     batch = PairBatch(item["src_frames"], item["trg_images"], item["trg_Ks"], item["poses"], item["klds"], levels=self.levels,
                                       point_stride=self.point_stride, **self.batch_kw)
                     built = torch.cuda.Event()
                     built.record(self.setup_stream)
-                    ok = put((batch, built))
-                    del batch                # the queue (then the consumer) holds the only reference: at most depth + 2 batches are
-                    if not ok:               # resident -- one being built, ``depth`` waiting, one being optimised
+                    ok = put((idx, batch, built))
+                    del batch                # the queue (then an optimiser) holds the only reference
+                    if not ok:
                         return
-            put(None)
+            for _ in range(n_consumers):
+                put(None)
         except BaseException as e:          # surfaces in the consumer
-            put(e)
+            for _ in range(n_consumers):
+                put(e)
 
-    def run(self, inputs):
-        """inputs: iterable of dict(src_frames, trg_images, trg_Ks, poses, klds) -- the arguments of PairBatch, device resident.
-        Yields (poses (M,4,4), [klds]) of every batch, in order, as device tensors valid on the caller's current stream."""
-        caller = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(caller)                 # the inputs may still be in flight on the caller's stream
-        built_q = queue.Queue(maxsize=self.depth)
-        stop = threading.Event()
-        worker = threading.Thread(target=self._producer, args=(inputs, built_q, ready, stop), daemon=True)
-        worker.start()
+    def _optimiser(self, stream, built_q, results, caller, stop):
+        """One optimiser: takes built batches, runs their schedules on its own stream, hands (index, poses, klds) over."""
         try:
-            while True:
-                got = built_q.get()
-                if got is None:
-                    break
-                if isinstance(got, BaseException):
-                    raise got
-                batch, built = got
-                with torch.cuda.stream(self.optim_stream):
-                    self.optim_stream.wait_event(built)
+            torch.cuda.set_device(self.device)
+            while not stop.is_set():
+                try:
+                    got = built_q.get(timeout=0.1)
+                except queue.Empty:
+                    continue
+                if got is None or isinstance(got, BaseException):
+                    results.put(got)
+                    return
+                idx, batch, built = got
+                with torch.cuda.stream(stream):
+                    stream.wait_event(built)
                     batch.run_scheduled(**self.schedule)
                     poses, klds = batch.poses().clone(), [k.clone() for k in batch.klds()]
-                    # the results were allocated in the optimisation stream's pool and are consumed on the caller's stream:
-                    # tell the allocator, so that a block the caller drops is not handed to the next batch's clone() while
+                    # the results were allocated in this stream's pool and are consumed on the caller's stream: tell the
+                    # allocator, so that a block the caller drops is not handed to a later batch's clone() while
                     # caller-stream work on it is still queued
                     poses.record_stream(caller)
                     for k in klds:
                         k.record_stream(caller)
                     done = torch.cuda.Event()
-                    done.record(self.optim_stream)
-                # the batch (allocated on the set-up stream, used on the optimisation stream) is released only after the
-                # optimiser has finished with it
+                    done.record(stream)
+                # the batch (allocated on the set-up stream, used on this stream) is released only after the optimiser has
+                # finished with it
                 done.synchronize()
-                caller.wait_event(done)
                 del batch
-                yield poses, klds
+                results.put((idx, poses, klds, done))
+        except BaseException as e:
+            results.put(e)
+
+    def run(self, inputs):
+        """inputs: iterable of dict(src_frames, trg_images, trg_Ks, poses, klds) -- the arguments of PairBatch, device resident.
+        Yields (poses (M,4,4), [klds]) of every batch, in input order, as device tensors valid on the caller's current stream."""
+        caller = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(caller)                 # the inputs may still be in flight on the caller's stream
+        built_q = queue.Queue(maxsize=self.depth)
+        results = queue.Queue()
+        stop = threading.Event()
+        K = len(self.optim_streams)
+        workers = [threading.Thread(target=self._producer, args=(inputs, built_q, ready, stop, K), daemon=True)]
+        workers += [threading.Thread(target=self._optimiser, args=(st, built_q, results, caller, stop), daemon=True) for st in self.optim_streams]
+        for w in workers:
+            w.start()
+        try:
+            pending, nxt, finished = {}, 0, 0
+            while finished < K or pending:
+                if nxt in pending:
+                    poses, klds, done = pending.pop(nxt)
+                    caller.wait_event(done)
+                    nxt += 1
+                    yield poses, klds
+                    continue
+                if finished == K:            # every optimiser has ended and the next index never came
+                    raise RuntimeError("PairStream lost a batch")
+                got = results.get()
+                if got is None:
+                    finished += 1
+                elif isinstance(got, BaseException):
+                    raise got
+                else:
+                    pending[got[0]] = got[1:]
         finally:                            # also when the caller abandons the generator early
             stop.set()
-            worker.join(timeout=60)
+            for w in workers:
+                w.join(timeout=60)

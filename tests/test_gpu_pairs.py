@@ -582,10 +582,13 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
             assert np.array_equal(msrc[(mpix >> 31) == 1], full_src[keep_valid])
 
 
-def test_pair_stream_overlaps_batches_and_returns_each_batch_s_own_result():
-    """PairStream: batch k+1 is built on the set-up stream by a producer thread while batch k runs its schedule on the
-    optimisation stream.  Every batch's result is bit-identical to the same batch built and optimised alone on the default
-    stream -- ragged batches (different pair counts, sizes and segment counts), consumed in order."""
+@pytest.mark.parametrize("optimisers", [1, 3])
+def test_pair_stream_overlaps_batches_and_returns_each_batch_s_own_result(optimisers):
+    """PairStream: batch k+1 is built on the set-up stream by a producer thread while batch k runs its schedule on an
+    optimisation stream; with ``optimisers`` > 1 several batches run their schedules concurrently on their own streams
+    (continuous batching: the next batch's bulk fills the tail of the current one).  Every batch's result is bit-identical to the
+    same batch built and optimised alone on the default stream -- ragged batches (different pair counts, sizes and segment
+    counts), yielded in input order."""
     from super_primitive_amd import synth
     from super_primitive_amd.image.keyframe import KeyFrame
     from super_primitive_amd.optim.pair_batch import PairBatch
@@ -603,10 +606,11 @@ def test_pair_stream_overlaps_batches_and_returns_each_batch_s_own_result():
                     poses=torch.stack([t(p.pose_init) for p in prs]), klds=[t(p.kld_init) for p in prs])
 
     items = [inputs(g) for g in groups]
-    stream = PairStream(levels=(0, 3), point_stride=(1, 2, 4), schedule=sch, tile_points=1024)
+    stream = PairStream(levels=(0, 3), point_stride=(1, 2, 4), schedule=sch, tile_points=1024, optimisers=optimisers)
+    items = items * 2 if optimisers > 1 else items
     got = list(stream.run(iter(items)))
     torch.cuda.synchronize()
-    assert len(got) == len(groups)
+    assert len(got) == len(items)
     for item, (poses, klds) in zip(items, got):
         ref = PairBatch(item["src_frames"], item["trg_images"], item["trg_Ks"], item["poses"], item["klds"], levels=(0, 3),
                         point_stride=(1, 2, 4), tile_points=1024)

@@ -43,12 +43,15 @@ def test_abi_constants_and_struct_layout_match_header():
     assert _lib.SpWindowNode.kind.offset == 168 and _lib.SpWindowBlock.N.offset == 24
     # per-pair schedule, passed by value
     assert int(re.search(r"#define\s+SP_MAX_PHASES\s+(\d+)", header).group(1)) == _lib.SP_MAX_PHASES
-    assert ctypes.sizeof(_lib.SpPrepTable) == 224 and ctypes.sizeof(_lib.SpPrepSample) == 176 and ctypes.sizeof(_lib.SpPrepImage) == 24
+    assert ctypes.sizeof(_lib.SpPrepTable) == 232 and _lib.SpPrepTable.bits.offset == 224
+    assert ctypes.sizeof(_lib.SpPrepTable) == 232 and ctypes.sizeof(_lib.SpPrepSample) == 176 and ctypes.sizeof(_lib.SpPrepImage) == 24
     assert _lib.SpPrepTable.stride.offset == 192 and _lib.SpPrepSample.N.offset == 152 and _lib.SpPrepImage.H.offset == 16
     for macro in ("SP_PREP_MAX_STRIDES", "SP_PREP_MAX_LEVELS"):
         assert int(re.search(r"#define\s+" + macro + r"\s+(\d+)", header).group(1)) == getattr(_lib, macro)
-    assert ctypes.sizeof(_lib.SpPhase) == 56 and _lib.SpPhase.n_spans.offset == 40 and _lib.SpPhase.conv_tol.offset == 52
-    assert ctypes.sizeof(_lib.SpSchedule) == 456 and _lib.SpSchedule.n_phases.offset == 448
+    assert ctypes.sizeof(_lib.SpPhase) == 64 and _lib.SpPhase.n_spans.offset == 40 and _lib.SpPhase.conv_tol.offset == 52
+    assert _lib.SpPhase.flags.offset == 56
+    assert ctypes.sizeof(_lib.SpSchedule) == 520 and _lib.SpSchedule.n_phases.offset == 512
+    assert int(re.search(r"#define\s+SP_PHASE_POSE_ONLY\s+(\d+)", header).group(1)) == _lib.SP_PHASE_POSE_ONLY
 
 
 def test_new_entry_points_validate_arguments_and_sizes():

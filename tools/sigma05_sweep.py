@@ -35,6 +35,11 @@ BASE = {k: v for k, v in FRAME_PAIR_SCHEDULE.items() if k != "check_every"}
 VARIANTS = {
     # name: (levels, point_stride, schedule kwargs, initial LM lambda)
     "r02":        ((0, 3), (1, 2, 4), dict(BASE), 1e-4),
+    "pose1st":    ((0, 3), (1, 2, 4), dict(BASE, pose_first_iters=15), 1e-4),
+    "pose1st_10": ((0, 3), (1, 2, 4), dict(BASE, pose_first_iters=10), 1e-4),
+    "pose1st_25": ((0, 3), (1, 2, 4), dict(BASE, pose_first_iters=25), 1e-4),
+    "pose1st_allpts": ((0, 3), None, dict(BASE, pose_first_iters=15), 1e-4),
+    "pose1st_L4": ((0, 4), (1, 2, 4, 8), dict(BASE, pose_first_iters=15), 1e-4),
     "r02_allpts": ((0, 3), None, dict(BASE), 1e-4),
     "L4":         ((0, 4), (1, 2, 4, 8), dict(BASE), 1e-4),
     "L4_allpts":  ((0, 4), None, dict(BASE), 1e-4),
@@ -68,7 +73,7 @@ def main(argv=None):
     ap.add_argument("--size", default="240x320x8")
     ap.add_argument("--scenes", type=int, default=12)
     ap.add_argument("--seed0", type=int, default=500)
-    ap.add_argument("--variants", default=",".join(VARIANTS))
+    ap.add_argument("--variants", default="r02,pose1st,pose1st_10,pose1st_25,pose1st_allpts,pose1st_L4")
     ap.add_argument("--json", default=None)
     args = ap.parse_args(argv)
     H, W, N = (int(v) for v in args.size.split("x"))

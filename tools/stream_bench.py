@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Developer tool: frame pairs per second from raw device-resident frames, one batch at a time against PairStream (set-up of the
-next batch overlapped with the optimisation of the current one)."""
+"""Developer tool: sustained frame pairs per second from raw device-resident frames over many batches back to back: one batch at a
+time, against PairStream (set-up of the next batch overlapped with the optimisation of the current one), against PairStream with
+several optimiser streams (continuous batching: the bulk of the next batch fills the tail of the current one)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,10 +26,11 @@ def make_items(per_batch, n_batches, distinct_batches):
     return [items[i % distinct_batches] for i in range(n_batches)]
 
 
-for per_batch, n_batches, distinct in ((128, 9, 3), (384, 4, 1), (64, 12, 3)):
+for per_batch, n_batches, distinct in ((384, 8, 2), (128, 24, 3), (64, 24, 3)):
     items = make_items(per_batch, n_batches, distinct)
-    pipe = PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE)          # long-lived: its streams' allocator pools are reused
-    for label in ("sequential", "pipelined"):
+    pipes = {f"pipelined, {k} optimiser stream{'s' if k > 1 else ''}": PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE, optimisers=k, depth=max(1, k - 1))
+             for k in (1, 2, 3)}                                            # long-lived: their streams' allocator pools are reused
+    for label in ("sequential",) + tuple(pipes):
         for rep in range(3):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             if label == "sequential":
@@ -38,7 +40,7 @@ for per_batch, n_batches, distinct in ((128, 9, 3), (384, 4, 1), (64, 12, 3)):
                     b.run_scheduled(**sk)
                     res = (b.poses().clone(), [k.clone() for k in b.klds()])
             else:
-                for res in pipe.run(iter(items)):
+                for res in pipes[label].run(iter(items)):
                     pass
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
         print(f"{n_batches} batches x {per_batch} pairs, {label}: {dt * 1e3:.1f} ms = {n_batches * per_batch / dt:.0f} pairs/s", flush=True)
