@@ -63,6 +63,10 @@ def parse(argv=None):
     ap.add_argument("--sigma05-scenes", type=int, default=8,
                     help="distinct multi-octave scenes rendered for the reference-start leg (every resident pair gets its own "
                          "T_gt Exp(0.05 xi) start and its own depth seeds); 0 skips the leg")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not measure the HBM traffic of the dominant kernel in this run (by default, on one GPU, bench.py re-runs 10 "
+                         "steps of itself under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE`, one counter per "
+                         "pass as MI355X_MICROARCH.md prescribes, when rocprofv3 is on PATH)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control-flow rehearsal on CPU (tests/test_dist_gloo.py): gloo instead of RCCL, host timers instead of "
                          "HIP events, build_batch() replaced by the caller; produces no valid measurement")
@@ -227,6 +231,49 @@ def cpu_baseline(pair2, iters):
             "config1_320x240x8_one_thread_level0": c1_one}
 
 
+def measure_traffic(args, kernel_substr):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two child runs of this script (10 steps, no extras)
+    under rocprofv3 --pmc, one counter per pass with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not
+    fit one pass).  gfx950 correction of the guide's HBM section: FETCH_SIZE counts 128-byte read requests at 64 B, so read bytes
+    = 2 x FETCH_SIZE; both counters are in KB.  Returns (bytes_per_launch, detail) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="sp_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
+               os.path.join(ROOT, "bench.py"), "--settle-ms", "0", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extras",
+               "--no-pmc", "--pairs", str(args.pairs), "--segments", str(args.segments), "--distinct", str(args.distinct),
+               "--tile-points", str(args.tile_points), "--mode", args.mode]
+        if args.span_points is not None:
+            cmd += ["--span-points", str(args.span_points)]
+        try:
+            proc = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                  timeout=240, start_new_session=True)
+            per = {}
+            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if proc.returncode != 0 or not per:
+                return None, f"rocprofv3 --pmc {counter}: rc {proc.returncode}, {len(per)} dispatches of {kernel_substr}"
+            vals[counter] = (sum(per.values()) / len(per), len(per))
+        except Exception as e:                       # noqa: BLE001  (a failed profile pass must not take the bench line down)
+            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    hbm = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return hbm, {"FETCH_SIZE_KB_mean": vals["FETCH_SIZE"][0], "WRITE_SIZE_KB_mean": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1],
+                 "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950: FETCH_SIZE tallies 128-B read requests at 64 B)"}
+
+
 class _HostEvent:
     """Stand-in for torch.cuda.Event in --dry-run."""
 
@@ -346,11 +393,21 @@ def main(argv=None):
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
     }
-    # HBM traffic per launch is a PMC measurement (rocprofv3 --pmc, separate passes, tools/collect_profiles.sh): it cannot
-    # be taken inside this run, so the figure is read from the committed summary and labelled as such
+    # HBM traffic per launch is a PMC measurement (rocprofv3 --pmc, one counter per pass): taken in this run by profiling
+    # two short child runs of this very command; if that is not possible the figure of the committed summary is carried,
+    # labelled as such
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     line["roofline"]["traffic_source"] = None
-    if os.path.exists(pmc):
+    if rank == 0 and world == 1 and not dry and not args.no_pmc:
+        hbm, detail = measure_traffic(args, f"k_cost_pairs<{mode_id}, 0, 0>")
+        if hbm is not None:
+            line["roofline"]["traffic"] = hbm
+            line["roofline"]["traffic_source"] = "this run (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one pass each, 10 steps of this command)"
+            line["roofline"]["traffic_detail"] = detail
+            line["roofline"]["traffic_over_algorithmic"] = hbm / alg_bytes
+        else:
+            line["roofline"]["traffic_note"] = detail
+    if line["roofline"]["traffic"] is None and os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
             if (rec.get("pairs_per_gpu") == M and rec.get("mode") == args.mode and rec.get("tile_points") == args.tile_points

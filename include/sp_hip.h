@@ -396,6 +396,29 @@ int sp_window_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, 
                    double* scratch, int abs_loss, int skip_first, float rel_tol, float* state, float* losses, int max_losses,
                    void* stream);
 
+/* Gauss-Newton / Levenberg-Marquardt step of the SAME window graph (BASELINE.json north_star: "Gauss-Newton/LM solve on SE(3) (+)
+ * log-depth"; the reference's loops it accelerates: odometery/odometery.py:375-407 tracking -- 6 pose + 2 affine unknowns, keyframe
+ * depths fixed -- and :756-915 windowed mapping -- K poses + sum N log-depths + affines, first keyframe fixed (:589-592), oldest
+ * depths frozen (:594-603), fold-in T <- T inv(Exp(D)) + renormalise_se3 after the step (:861-882)).  One iteration =
+ *     sp_pairs_cost(mode 2, irls_eps) over all edges  ->  sp_window_gn_step                       (3 launches, no host sync)
+ * Unknowns: the pose tangent of every node with lr_pose > 0, the affine pair of every node with lr_aff > 0 (at most 128 scalars
+ * together, the reduced camera system is solved in LDS in fp64), the log-depths of every block with lr > 0 (eliminated by a Schur
+ * complement, like the per-pair solver).  flags bit 0: pose-only step (all depth blocks treated as frozen).
+ * LM: lambda adapts on the device exactly like sp_pairs_gn_step (loss up -> previous step undone from nodes_backup / kld_backup,
+ * lambda *= lm_up, re-evaluated next call; loss down -> lambda = max(lambda lm_down, lm_min)); conv_tol > 0: an accepted step that
+ * lowered the loss by less than conv_tol * loss freezes the window (later calls return at once), like the relative-loss break at
+ * odometery.py:907-915.
+ * state: 16 floats {lambda (set by the caller, e.g. 1e-4), loss at the last accepted point (init -1), accepted, rejected,
+ *   rejected-last flag, iterations, converged flag, last loss, failed solves, too-many-unknowns flag, ...}; losses[max_losses]: loss of
+ *   call i.  scratch: sp_window_gn_scratch_doubles(n_edges, sum_N, max_N) doubles; nodes_backup: n_nodes nodes; kld_backup: sum_N floats
+ *   (blocks in order; sum_N = total log-depths of all blocks). */
+int sp_window_gn_scratch_doubles(int n_edges, int sum_N, int max_N);
+int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes,
+                      const SpWindowBlock* blocks, int n_blocks, int sum_N, int max_N, const float* span_partials,
+                      const float* seg_partials, double* scratch, SpWindowNode* nodes_backup, float* kld_backup, int flags,
+                      float lm_up, float lm_down, float lm_min, float conv_tol, float* state, float* losses, int max_losses,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Helpers around the path
  * ---------------------------------------------------------------------------------------------------- */

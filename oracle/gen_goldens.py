@@ -428,7 +428,7 @@ def golden_traj_map(ref, name, steps=30):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
-def reference_mapping_loop(ref, kfs, kf_poses, kf_klds, kf_affs, supp, steps, lr_pose, window_size, affine, initialised):
+def reference_mapping_loop(ref, kfs, kf_poses, kf_klds, kf_affs, supp, steps, lr_pose, window_size, affine, initialised, lr_kld=1e-2, lr_aff=1e-5):
     """The windowed mapping loop of odometery/odometery.py:576-648 (parameter groups), :451-479 (neighbour connectivity),
     :756-915 (iteration) restated around the REAL ``photomeric_cost_batch`` / ``renormalise_se3`` with ``opt_supporting``
     on; lietorch's Exp is replaced by the oracle's (parity unpinned at that boundary).
@@ -445,13 +445,13 @@ def reference_mapping_loop(ref, kfs, kf_poses, kf_klds, kf_affs, supp, steps, lr
     s_pose = [[p.clone() for _, p, _ in supp[k]] for k in range(K)]
     s_delta = [[torch.nn.Parameter(eye6()) for _ in supp[k]] for k in range(K)]
     s_aff = [[torch.nn.Parameter(a.clone()) for _, _, a in supp[k]] for k in range(K)] if affine else None
-    groups = [{"params": [k for k in klds if isinstance(k, torch.nn.Parameter)], "lr": 1e-2},
+    groups = [{"params": [k for k in klds if isinstance(k, torch.nn.Parameter)], "lr": lr_kld},
               {"params": [d for d in d_kf if d is not None], "lr": lr_pose}]
     if affine:
-        groups.append({"params": affs[1:], "lr": 1e-5})
+        groups.append({"params": affs[1:], "lr": lr_aff})
     groups.append({"params": [d for row in s_delta for d in row], "lr": lr_pose})
     if affine:
-        groups.append({"params": [a for row in s_aff for a in row], "lr": 1e-5})
+        groups.append({"params": [a for row in s_aff for a in row], "lr": lr_aff})
     opt = torch.optim.Adam(groups, lr=1e-3)
     mat = lambda d: torch.eye(4) if d is None else orc.se3_exp(d)[0]
     conn = {s: [t for t in (s - 1, s + 1) if 0 <= t < K] for s in range(K)}

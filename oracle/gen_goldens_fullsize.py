@@ -255,6 +255,45 @@ def golden_config3(ref, name="g17_config3_tum_shaped", seed=300, track_steps=300
     print(f"{name}: {time.time() - t0:.0f} s; mapping loss {out['losses'][0]:.6f} -> {out['losses'][-1]:.6f}, stopped {int(out['stopped'])}", flush=True)
 
 
+def golden_config3_min(ref, name="g17min_config3_mapping_minimiser", seed=300):
+    """The MINIMISER of the reference's windowed-mapping cost at BASELINE configs[2] size (224x288x40, 3 keyframes = full window with
+    one supporting frame each; g17's scene): the reference loop (odometery.py:576-648,756-915 around the real
+    ``photomeric_cost_batch``) started FROM THE SYNTHETIC GROUND TRUTH with decaying learning rates (fresh Adam per phase) until the
+    state stops moving -- like g15's minimiser of the two-frame cost.  The fixed parts of the window are exact here (first keyframe
+    pose = ground truth, frozen oldest depths = ground-truth log-depths), so the minimiser sits next to the ground truth and Adam
+    reaches it; the Gauss-Newton window optimiser (sp_window_gn_step) must reach the same point from g17's PERTURBED estimates of
+    everything else (tests/test_gpu_window_gn.py).  Pins the fixed point of that solver: same unknowns, any path."""
+    from gen_goldens import reference_mapping_loop
+    H, W, N = 224, 288, 40
+    frames, est, klds, affs = synth.window_inputs(seed, 3, H=H, W=W, N=N)
+    t0 = time.time()
+    mk = lambda f: ref.kf.KeyFrame(T(f.image), T(f.K), T(f.logdepth_perseg), T(f.keypoints), torch.from_numpy(f.keypoint_regions.copy()))
+    kfs = [mk(f) for f in frames[0::2]]
+    supf = [ref.kf.KeyFrame(T(frames[2 * k + 1].image), T(frames[2 * k + 1].K)) for k in range(3)]
+    zero2 = np.zeros(2, np.float32)
+    state = dict(kf_poses=np.stack([frames[2 * k].T_wc for k in range(3)]), klds=np.stack([frames[2 * k].kld_gt for k in range(3)]),
+                 affs=np.stack([zero2] * 3), supp_poses=np.stack([frames[2 * k + 1].T_wc for k in range(3)]), supp_affs=np.stack([zero2] * 3))
+    start = {k: v.copy() for k, v in state.items()}
+    losses, moved = [], None
+    for lr_kld, lr_pose, lr_aff, steps in ((3e-3, 3e-4, 3e-4, 150), (1e-3, 1e-4, 1e-4, 150), (3e-4, 3e-5, 3e-5, 120), (1e-4, 1e-5, 1e-5, 100),
+                                           (3e-5, 3e-6, 3e-6, 100), (1e-5, 1e-6, 1e-6, 80)):
+        sup = [[(supf[k], T(state["supp_poses"][k]), T(state["supp_affs"][k]))] for k in range(3)]
+        out = reference_mapping_loop(ref, kfs, [T(p) for p in state["kf_poses"]], [T(k) for k in state["klds"]], [T(a) for a in state["affs"]],
+                                     sup, steps, lr_pose, 3, True, False, lr_kld=lr_kld, lr_aff=lr_aff)
+        moved = (float(np.abs(out["kf_poses"] - state["kf_poses"]).max()), float(np.abs(out["klds"] - state["klds"]).max()))
+        state = {k: out[k] for k in state}
+        losses += list(out["losses"])
+        print(f"  {name} lr {lr_kld:g}/{lr_pose:g}: loss {out['losses'][0]:.8f} -> {out['losses'][-1]:.8f}, moved pose {moved[0]:.1e} kld {moved[1]:.1e} "
+              f"({time.time() - t0:.0f} s)", flush=True)
+    from_gt = (float(np.abs(state["kf_poses"] - start["kf_poses"]).max()), float(np.abs(state["klds"] - start["klds"]).max()))
+    save = dict(seed=np.array(seed), HWN=np.array([H, W, N]), losses=np.array(losses), last_phase_moved=np.array(moved),
+                distance_from_ground_truth=np.array(from_gt), spread40=np.array(np.ptp(losses[-40:])),
+                **{f"min_{k}": v for k, v in state.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: {time.time() - t0:.0f} s; final loss {losses[-1]:.8f}, spread of the last 40 losses {np.ptp(losses[-40:]):.1e}; "
+          f"minimiser is {from_gt[0]:.1e} (pose entries) / {from_gt[1]:.1e} (log-depths) from the ground truth", flush=True)
+
+
 def golden_config4(ref, name="g18_config4_void_shaped", seed=4, n_segments=1200):
     """BASELINE configs[3] shape (VOID-1500 depth completion, 480x640, ~1200 sparse-depth segments): the reference's
     per-image pipeline after the frontend (segment_based_completion.py:45-55) -- segment_based_depth_reinit (median),
@@ -391,6 +430,8 @@ def main():
         golden_config2(ref)
     if "g17" in which:
         golden_config3(ref)
+    if "g17min" in which:
+        golden_config3_min(ref)
     if "g18" in which:
         golden_config4(ref)
     if "g19" in which:

@@ -35,22 +35,28 @@ def residual_vector(src, trg, kld, pose, affine=None):
     return raw.reshape(-1), mask.reshape(-1), seg, out["residual"]
 
 
-def normal_equations(src, trg, kld, pose, eps=1e-3, affine=None, columns=None):
+def normal_equations(src, trg, kld, pose, eps=1e-3, affine=None, columns=None, with_affine=False):
     """Returns dict(H (6+N,6+N), b (6+N), cost (mean |r| like the reference), n_valid) in float64.  ``columns``: only
     these unknowns (indices into [xi(6), kld(N)]) are differentiated -- H and b are then the corresponding sub-block
-    (full-size keyframes: 6 pose columns + a few segments instead of 2 (6+N) dense evaluations)."""
+    (full-size keyframes: 6 pose columns + a few segments instead of 2 (6+N) dense evaluations).
+    ``with_affine``: the TARGET frame's brightness pair (a_t, b_t) of ``affine = ((a_s, b_s), (a_t, b_t))`` joins the unknowns as
+    the last two columns: x = [xi(6), kld(N), a_t, b_t] (the window optimiser's Gauss-Newton flavour, sp_pairs_cost mode 2)."""
     src64 = orc.OracleFrame(src.image.double(), src.K.double(), src.logdepth_perseg.double(), src.keypoints.double(),
                             src.keypoint_regions)
     trg64 = orc.OracleFrame(trg.image.double(), trg.K.double())
     kld0, pose0 = kld.double(), pose.double()
     N = kld0.numel()
+    assert not with_affine or affine is not None
+
+    aff64 = None if affine is None else (affine[0].double(), affine[1].double())
 
     def f(x):
         T = orc.se3_exp(x[:6][None])[0] @ pose0
-        r, _, _, _ = residual_vector(src64, trg64, x[6:], T, affine)
+        aff = aff64 if not with_affine else (aff64[0], x[6 + N: 8 + N])
+        r, _, _, _ = residual_vector(src64, trg64, x[6: 6 + N], T, aff)
         return r
 
-    x0 = torch.cat((torch.zeros(6, dtype=torch.float64), kld0))
+    x0 = torch.cat((torch.zeros(6, dtype=torch.float64), kld0) + ((aff64[1],) if with_affine else ()))
     h = 1e-7
     cols = []
     with torch.no_grad():
@@ -59,7 +65,7 @@ def normal_equations(src, trg, kld, pose, eps=1e-3, affine=None, columns=None):
             e[i] = h
             cols.append((f(x0 + e) - f(x0 - e)) / (2 * h))
     J = torch.stack(cols, dim=1)
-    r, mask, seg, res = residual_vector(src64, trg64, kld0, pose0, affine)
+    r, mask, seg, res = residual_vector(src64, trg64, kld0, pose0, aff64)
     m3 = mask.repeat(3)
     w = m3 / torch.clamp(r.abs(), min=eps)
     H = J.T @ (w[:, None] * J)

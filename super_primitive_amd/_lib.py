@@ -47,6 +47,8 @@ SIGNATURES = {
     "sp_window_scratch_doubles": [I, I],
     "sp_window_compose": [P, P, I, P, I, P],
     "sp_window_step": [P, P, I, P, I, P, I, I, P, P, P, I, I, F, P, P, I, P],
+    "sp_window_gn_scratch_doubles": [I, I, I],
+    "sp_window_gn_step": [P, P, I, P, I, P, I, I, I, P, P, P, P, P, I, F, F, F, F, P, P, I, P],
     "sp_depth_expand": [P, P, P, P, I, I, I, I, P, P],
     "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_segment_reinit": [P, P, P, P, I, I, I, I, P, I, P, P, P, P],
@@ -66,6 +68,8 @@ SIGNATURES = {
 SP_ABI_VERSION = 8
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
+SP_GNA_PARTIAL_FLOATS = 48
+SP_GNA_SEG_FLOATS = 12
 SP_GRAD_SEG_FLOATS = 1
 SP_GN_SEG_FLOATS = 8
 SP_LM_STATE_FLOATS = 8

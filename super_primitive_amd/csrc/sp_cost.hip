@@ -529,7 +529,15 @@ __device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ r
 
 // ABL (developer ablation, only reachable through mode >= 10 of sp_pairs_cost): 0 = product kernel,
 // 1 = no target gathers (taps replaced by the source colour), 2 = loads + geometry only (no accumulation),
-// 3 (mode 1 only) = the four tap loads made lane-consecutive (coalesced) instead of gathered
+// 3 (mode 1 only) = the four tap loads made lane-consecutive (coalesced) instead of gathered,
+// 5 (mode 16) = NO pix stream: the pixel word of a point comes out of the low mantissa bits of its own src4 colours (tools/kbench.py
+//   packs it there for the run): the cheapest conceivable way of "deriving" the pixel -- 6 integer instructions, no load, 16 B per
+//   point instead of 20 -- i.e. the upper bound of what replacing pix[P] by run descriptors + a validity mask could gain
+__device__ __forceinline__ uint32_t pix_from_colour_bits(const f32x4 s) {
+    const uint32_t a = __builtin_bit_cast(uint32_t, s.x), b = __builtin_bit_cast(uint32_t, s.y), c = __builtin_bit_cast(uint32_t, s.z);
+    const uint32_t v = (a & 0x7fu) | ((b & 0x7fu) << 7) | ((c & 0x3fu) << 14);            // col (10) | row (9) << 10 | valid << 19
+    return (v & 0x3ffu) | (((v >> 10) & 0x1ffu) << 16) | ((v >> 19) << 31);
+}
 template <int ABL, bool WT, bool AFF = false>
 __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
                                             int n_chunks, int total, float irls_eps, float* __restrict__ span_rec,
@@ -581,8 +589,8 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     struct Slot { Pending2 p; int q; bool last; };
     Slot S0, S1;
     {
-        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
+        const uint32_t pw = ABL == 5 ? pix_from_colour_bits(s) : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         prepare2(c, kc, k.shift, pw, s, S0.p);
         S0.last = cursor_advance(k, S0.q);
     }
@@ -594,7 +602,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     auto trip = [&](Slot& a, Slot& b) {
         op += 4u * SP_BLOCK;
         asm volatile("" : "+v"(op));        // one induction register; the src4 offset is a shift of it
-        const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
+        const uint32_t pw = ABL == 5 ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
         f32x3 ta, tb, tc, td;
         if (ABL == 1) { ta = tb = tc = td = f32x3{a.p.srg.x, a.p.srg.y, a.p.sb}; }
@@ -632,6 +640,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         uint32_t pw_ = pw;
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
+        if (ABL == 5) pw_ = pix_from_colour_bits(s_);
         prepare2(c, kc, k.shift, pw_, s_, b.p);       // (the trip past the end reads zeros and is never used)
         b.last = cursor_advance(k, b.q);
     };
@@ -1105,7 +1114,7 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spa
 int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                          float* partials, float* seg_partials, const int32_t* done, void* stream) {
     if (!pairs || !chunks || !spans || !partials || !seg_partials || n_spans <= 0) return SP_EINVAL;
-    if (mode != 0 && mode != 1 && mode != 2 && !(mode >= 10 && mode <= 15)) return SP_EINVAL;
+    if (mode != 0 && mode != 1 && mode != 2 && !(mode >= 10 && mode <= 16)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int gx = ((n_spans + 7) / 8) * 8;
     const int4* c4 = reinterpret_cast<const int4*>(chunks);
@@ -1124,6 +1133,8 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
         hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 14)
         hipLaunchKernelGGL((k_cost_pairs<1, 3>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
+    else if (mode == 16)
+        hipLaunchKernelGGL((k_cost_pairs<1, 5>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 15)
         hipLaunchKernelGGL((k_cost_pairs<1, 4>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 12)

@@ -118,6 +118,38 @@ def track_frame_fused(kf, kld, supp_frame, supp_T, prev_pose, steps, levels, lr=
     return T, (win.node_affines()[1] if affine else None), list(win.losses().unbind(0))
 
 
+# Gauss-Newton schedules of the window optimiser (optim/window.py run_gn; sp_window_gn_step): per pyramid level, coarse -> fine, LM
+# iterations until an accepted step buys less than ``conv_tol`` of the loss, then a polish at the finest level with the IRLS epsilon
+# at ``polish_eps`` (the default epsilon smooths |r| like a Huber kernel and leaves the fixed point ~1e-4 from the L1 minimiser).
+TRACK_GN_SCHEDULE = dict(max_iters_per_level=8, conv_tol=2e-3, irls_eps=1e-3, polish_max=8, polish_eps=1e-5, polish_tol=1e-4)
+MAP_GN_SCHEDULE = dict(max_iters=25, conv_tol=1e-3, irls_eps=1e-3, polish_max=12, polish_eps=1e-5, polish_tol=1e-5)
+
+
+def track_frame_gn(kf, kld, supp_frame, supp_T, prev_pose, levels, prev_aff=None, curr_aff=None, schedule=None):
+    """Frame-to-keyframe tracking (odometery/odometery.py:300-312,375-407) by Gauss-Newton / LM instead of 300 Adam steps: 6 pose
+    + 2 affine unknowns of the tracked frame against the latest keyframe's points (its depths fixed), coarse to fine over
+    ``levels`` = (pyramid_min, pyramid_max).  Same parameterisation as the reference's loop -- relative pose
+    Exp(d) inv(T_supp) T_prev, fold-in T_supp <- T_supp inv(Exp(d)) after every step, renormalise_se3 at the end -- so the result
+    is directly comparable with ``track_frame`` / ``track_frame_fused`` run to convergence.
+    Returns (supp_T, curr_aff, losses, iterations)."""
+    from ..optim.window import KIND_WINDOW, PoseWindow
+    sch = dict(TRACK_GN_SCHEDULE, **(schedule or {}))
+    affine = prev_aff is not None
+    nodes = [dict(T=prev_pose, kind=KIND_WINDOW, aff=prev_aff if affine else None),
+             dict(T=supp_T, kind=KIND_WINDOW, lr_pose=1.0, lr_aff=1.0 if affine else 0.0, aff=curr_aff if affine else None,
+                  image=supp_frame.image, K=supp_frame.K)]
+    n_lv = levels[1] - levels[0]
+    win = PoseWindow([dict(kf=kf, kld=kld, lr=0.0, node=0)], nodes, [(0, 1, 1.0, dense_optim.Z_MIN_SINGLE)], levels,
+                     abs_loss=False, use_affine=affine, max_iters=n_lv * sch['max_iters_per_level'] + sch['polish_max'] + 8)
+    its = 0
+    for level in reversed(win.level_ids):
+        its += win.run_gn(level, sch['max_iters_per_level'], irls_eps=sch['irls_eps'], conv_tol=sch['conv_tol'])
+    if sch['polish_max'] > 0:
+        its += win.run_gn(win.level_ids[0], sch['polish_max'], irls_eps=sch['polish_eps'], conv_tol=sch['polish_tol'])
+    T = renormalise_se3(win.node_poses()[1].contiguous())
+    return T, (win.node_affines()[1] if affine else None), list(win.gn_losses().unbind(0)), its
+
+
 def window_connectivity(n_kfs):
     """Neighbouring keyframes only (odometery.py:451-479, mode 'map')."""
     return {s: [t for t in (s - 1, s + 1) if 0 <= t < n_kfs] for s in range(n_kfs)}
@@ -133,7 +165,7 @@ def _window_targets(s, n_kfs, supp):
 
 
 def map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose=1e-4, window_size=5, initialised=True,
-               fused=True, rel_tol=1e-8):
+               fused=True, rel_tol=1e-8, optimiser="adam", gn_schedule=None):
     """Windowed mapping over several source keyframes (odometery/odometery.py:576-648 parameter groups, :756-915 loop,
     ``opt_supporting`` on).
 
@@ -144,16 +176,21 @@ def map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose=1e-4, w
     1e-2, poses ``lr_pose`` (1e-4, or 1e-2 at mono-init), affines 1e-5; loss = sum_src mean_targets(residual) (:845-850);
     every iteration every pose is folded in ``T <- T inv(Exp(D))``, renormalised and its tangent zeroed (:861-882); when
     ``initialised`` the loop stops once the relative loss change is < ``rel_tol`` (:907-915).
+    ``optimiser='gn'``: the same window -- same unknowns, same fixed / frozen parts, same fold-in -- optimised by Gauss-Newton / LM
+    (``sp_window_gn_step``; MAP_GN_SCHEDULE, ``num_iters`` caps the main phase) instead of Adam.
     Returns dict(kf_poses (K,4,4), klds [K], affs (K,2)|None, supp_poses [[...]], supp_affs [[...]], losses, stopped)."""
     K = len(kfs)
     affine = kf_affs is not None
     frozen0 = K == window_size
+    if optimiser == "gn":
+        return _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol,
+                                 gn=dict(MAP_GN_SCHEDULE, **(gn_schedule or {})))
     if fused:
         return _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol)
     return _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol)
 
 
-def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol):
+def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, gn=None):
     from ..optim.window import KIND_WINDOW, PoseWindow
     K = len(kfs)
     lr_aff = 1e-5 if affine else 0.0
@@ -173,7 +210,16 @@ def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose,
             node = t[1] if t[0] == 'kf' else supp_node[(t[1], t[2])]
             edges.append((s, node, 1.0 / len(trg), dense_optim.Z_MIN_BATCH))
     win = PoseWindow(sources, nodes, edges, (0, 1), abs_loss=False, rel_tol=rel_tol if initialised else 0.0, use_affine=affine,
-                     max_iters=max(1, num_iters))
+                     max_iters=max(1, num_iters) + (gn['polish_max'] + 8 if gn else 0))
+    if gn:
+        n = win.run_gn(0, min(num_iters, gn['max_iters']), irls_eps=gn['irls_eps'], conv_tol=gn['conv_tol'])
+        if gn['polish_max'] > 0:
+            n += win.run_gn(0, gn['polish_max'], irls_eps=gn['polish_eps'], conv_tol=gn['polish_tol'])
+        poses, affs, losses = win.node_poses(), win.node_affines(), win.gn_losses()
+        return dict(kf_poses=poses[:K], klds=win.klds(), affs=affs[:K] if affine else None,
+                    supp_poses=[[poses[supp_node[(k, j)]] for j in range(len(supp[k]))] for k in range(K)],
+                    supp_affs=[[affs[supp_node[(k, j)]] for j in range(len(supp[k]))] for k in range(K)] if affine else None,
+                    losses=list(losses.unbind(0)), stopped=n, gn=win.gn_stats())
     win.run(0, num_iters)
     poses, affs, losses = win.node_poses(), win.node_affines(), win.losses()
     return dict(kf_poses=poses[:K], klds=win.klds(), affs=affs[:K] if affine else None,

@@ -149,8 +149,10 @@ class PoseWindow:
                 d.rec0 = 4 * int(wl['c_off'][e])
             self.desc[l] = _upload_struct_array(parr, dev)
         # ---- workspaces / optimiser state ----------------------------------------------------------------------
-        self.partials = torch.empty(self.n_spans * _lib.SP_GRAD_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
-        self.seg_partials = torch.empty(4 * self.n_chunks * _lib.SP_GRAD_SEG_FLOATS, dtype=torch.float32, device=dev)
+        # (sized for the Gauss-Newton records, the larger of the two optimisers')
+        self.partials = torch.empty(self.n_spans * _lib.SP_GNA_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+        self.seg_partials = torch.empty(4 * self.n_chunks * _lib.SP_GNA_SEG_FLOATS, dtype=torch.float32, device=dev)
+        self._gn = None
         self.scratch = torch.zeros(lib.sp_window_scratch_doubles(E, self.max_N), dtype=torch.float64, device=dev)
         self.state = torch.zeros(12, dtype=torch.float32, device=dev)
         self.max_iters = int(max_iters)
@@ -175,6 +177,81 @@ class PoseWindow:
                                            _lib.ptr(self.seg_partials), _lib.ptr(self.scratch), self.abs_loss, self.skip_first,
                                            self.rel_tol, _lib.ptr(self.state), _lib.ptr(self.loss_hist), self.max_iters,
                                            _lib.stream_ptr()), "sp_window_step")
+
+    # ---- Gauss-Newton / LM (sp_window_gn_step) ---------------------------------------------------------------------
+    def _gn_state(self):
+        if self._gn is None:
+            sum_N = int(self.n_off[-1])
+            n_y = 0
+            for nd in self._node_array():
+                n_y += (6 if nd.lr_pose > 0 else 0) + (2 if nd.lr_aff > 0 else 0)
+            if n_y > 128:
+                raise ValueError(f"{n_y} camera unknowns exceed the 128 the Gauss-Newton window solver holds; use the Adam optimiser")
+            self._gn = dict(
+                scratch=torch.zeros(self.lib.sp_window_gn_scratch_doubles(self.n_edges, sum_N, self.max_N), dtype=torch.float64, device=self.device),
+                nodes_backup=torch.zeros_like(self.nodes), kld_backup=torch.zeros(sum_N, dtype=torch.float32, device=self.device),
+                state=torch.zeros(16, dtype=torch.float32, device=self.device),
+                losses=torch.zeros(self.max_iters, dtype=torch.float32, device=self.device), sum_N=sum_N, n_y=n_y)
+            self.reset_gn()
+        return self._gn
+
+    def reset_gn(self, lam=1e-4):
+        """Fresh LM state (lambda, no accepted point yet, not converged); the loss history restarts."""
+        gn = self._gn_state() if self._gn is None else self._gn
+        gn['state'].zero_()
+        gn['state'][0] = lam
+        gn['state'][1] = -1.0
+
+    def begin_gn_phase(self):
+        """A new phase of a schedule (another pyramid level / IRLS epsilon): losses of different phases are not comparable, so
+        the accept test and the convergence test start afresh; lambda and the iteration count carry over."""
+        st = self._gn_state()['state']
+        st[1] = -1.0
+        st[4] = 0.0
+        st[6] = 0.0
+
+    def gn_step(self, level, irls_eps=1e-3, pose_only=False, conv_tol=0.0, lm_up=8.0, lm_down=0.5, lm_min=1e-7):
+        """One Gauss-Newton / LM iteration of the whole window at pyramid ``level`` (3 launches, nothing returns to the host):
+        the cost pass in mode 2 (normal equations incl. the affine brightness columns) + ``sp_window_gn_step``."""
+        gn = self._gn_state()
+        d = self.desc[level]
+        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(d), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, 2, float(irls_eps),
+                                          _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.stream_ptr()), "sp_pairs_cost")
+        _lib.check(self.lib.sp_window_gn_step(_lib.ptr(d), _lib.ptr(self.edges), self.n_edges, _lib.ptr(self.nodes), self.n_nodes,
+                                              _lib.ptr(self.blocks), self.n_sources, gn['sum_N'], self.max_N, _lib.ptr(self.partials),
+                                              _lib.ptr(self.seg_partials), _lib.ptr(gn['scratch']), _lib.ptr(gn['nodes_backup']),
+                                              _lib.ptr(gn['kld_backup']), 1 if pose_only else 0, float(lm_up), float(lm_down), float(lm_min),
+                                              float(conv_tol), _lib.ptr(gn['state']), _lib.ptr(gn['losses']), self.max_iters,
+                                              _lib.stream_ptr()), "sp_window_gn_step")
+
+    def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=4, **lm):
+        """Up to ``max_iters`` LM iterations at ``level`` as ONE phase: stops once an accepted step lowers the loss by less than
+        ``conv_tol`` of it (the device freezes the window; the host polls the flag every ``check_every`` iterations).  Returns the
+        iterations issued."""
+        self.begin_gn_phase()
+        it = 0
+        while it < max_iters:
+            for _ in range(min(check_every, max_iters - it)):
+                self.gn_step(level, irls_eps, pose_only, conv_tol, **lm)
+                it += 1
+            if conv_tol > 0 and self.gn_converged():
+                break
+        return it
+
+    def gn_converged(self):
+        return bool(self._gn_state()['state'][6].item() != 0)
+
+    def gn_iterations(self):
+        return int(self._gn_state()['state'][5].item())
+
+    def gn_losses(self):
+        gn = self._gn_state()
+        return gn['losses'][: min(self.gn_iterations(), self.max_iters)].clone()
+
+    def gn_stats(self):
+        st = self._gn_state()['state'].cpu().numpy()
+        return dict(lam=float(st[0]), accepted=int(st[2]), rejected=int(st[3]), iterations=int(st[5]), converged=bool(st[6]), failed_solves=int(st[8]),
+                    too_many_unknowns=bool(st[9]))
 
     def run(self, level, iters, graph_chunk=25):
         """``iters`` iterations at ``level``.  ``graph_chunk`` > 0: iterations are replayed from a hipGraph holding that

@@ -1,0 +1,158 @@
+"""-m gpu: the Gauss-Newton / LM flavour of the window optimiser (sp_pairs_cost mode 2 + sp_window_gn_step).
+
+* mode 2 of the cost kernel -- the Gauss-Newton sums WITH the affine brightness columns -- against the oracle's float64
+  finite-difference Jacobian of the reference residual (pose, per-segment log-depths, target affine pair);
+* tracking at BASELINE configs[2] size (224x288x40): 6 pose + 2 affine unknowns reach the reference's converged tracking result
+  (golden g17 ``track_polished_*``: its 300 Adam steps + two polish phases) within 1e-4 rad / 1e-4 t in <= 15 LM iterations;
+* windowed mapping at that size (3 keyframes = full window, one supporting frame each: 5 free poses, 80 free log-depths, 5 free
+  affine pairs; first keyframe and oldest depths fixed) from g17's perturbed estimates: the minimiser of the reference's mapping
+  cost (golden g17min: the real ``photomeric_cost_batch`` loop from the ground truth with decaying learning rates until settled)
+  inside the north-star bar;
+* the loop semantics both share with the reference (fixed / frozen parts untouched, rotations orthonormal after the fold-in +
+  renormalisation, monotone accepted losses, a converged window ignores further launches)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from gpu_util import T, npy
+from parity_util import rot_angle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mode2_normal_equations_with_affine_columns_match_oracle_jacobian():
+    from oracle import gn_oracle, photometric_oracle as orc
+    from super_primitive_amd import _lib, synth
+    from super_primitive_amd.optim.pair_batch import PairBatch
+    pairs = [synth.make_pair(48, 64, 6, seed=21 + k, shape=("grid", "blobs")[k], init_sigma=0.01) for k in range(2)]
+    batch = PairBatch.from_synth(pairs, levels=(0, 1), tile_points=512, use_affine=True, device="cuda:0")
+    aff = np.array([[0.03, -0.02, -0.05, 0.04], [-0.02, 0.01, 0.06, -0.03]], dtype=np.float32)         # {a_s, b_s, a_t, b_t} per pair
+    batch.aff.copy_(T(aff))
+    NV, NS = _lib.SP_GNA_PARTIAL_FLOATS, _lib.SP_GNA_SEG_FLOATS
+    partials = torch.zeros(batch.n_spans * NV, dtype=torch.float32, device=batch.device)
+    seg_partials = torch.zeros(batch.n_seg_records * NS, dtype=torch.float32, device=batch.device)
+    _lib.check(batch.lib.sp_pairs_cost(_lib.ptr(batch.desc[0]), _lib.ptr(batch.chunks), _lib.ptr(batch.spans), batch.n_spans, 2, 1e-3,
+                                       _lib.ptr(partials), _lib.ptr(seg_partials), _lib.stream_ptr()), "sp_pairs_cost")
+    torch.cuda.synchronize()
+    span = npy(partials).reshape(-1, NV).astype(np.float64)
+    segp = npy(seg_partials).reshape(-1, NS).astype(np.float64)
+    span_pair, seg_rec = npy(batch.span_pair), npy(batch.seg_records)
+    iu = np.triu_indices(6)
+    for m, p in enumerate(pairs):
+        N = batch.Ns[m]
+        s = span[span_pair == m].sum(0)
+        H = np.zeros((8 + N, 8 + N))                       # x = [xi(6), kld(N), a_t, b_t]
+        b = np.zeros(8 + N)
+        Hpp = np.zeros((6, 6)); Hpp[iu] = s[1:22]
+        H[:6, :6] = Hpp + np.triu(Hpp, 1).T
+        b[:6] = s[22:28]
+        A, B = 6 + N, 7 + N
+        H[A, A], H[A, B], H[B, A], H[B, B] = s[29], s[30], s[30], s[31]
+        b[A], b[B] = s[32], s[33]
+        H[:6, A] = H[A, :6] = s[34:40]
+        H[:6, B] = H[B, :6] = s[40:46]
+        for r in np.nonzero(seg_rec[:, 0] == m)[0]:
+            n, q = 6 + seg_rec[r, 1], segp[r]
+            H[:6, n] += q[0:6]; H[n, :6] += q[0:6]
+            H[n, n] += q[6]; b[n] += q[7]
+            H[n, A] += q[8]; H[A, n] += q[8]; H[n, B] += q[9]; H[B, n] += q[9]
+        src, trg = orc.frames_from_synth(p)
+        want = gn_oracle.normal_equations(src, trg, torch.from_numpy(p.kld_init), torch.from_numpy(p.pose_init), eps=1e-3,
+                                          affine=(torch.from_numpy(aff[m, :2]), torch.from_numpy(aff[m, 2:])), with_affine=True)
+        Hw, bw = want["H"].numpy(), want["b"].numpy()
+        np.testing.assert_allclose(s[0] / (3.0 * batch.Ps[m]), want["cost"], rtol=2e-5)
+        blocks = {"H_pp": np.s_[:6, :6], "H_pd": np.s_[:6, 6:A], "H_dd": np.s_[6:A, 6:A], "H_aa": np.s_[A:, A:], "H_pa": np.s_[:6, A:],
+                  "H_da": np.s_[6:A, A:]}
+        for name, sl in blocks.items():
+            assert np.abs(H[sl] - Hw[sl]).max() <= 3e-3 * np.abs(Hw[sl]).max(), (name, m)
+        for name, sl in (("b_p", np.s_[:6]), ("b_d", np.s_[6:A]), ("b_a", np.s_[A:])):
+            assert np.abs(b[sl] - bw[sl]).max() <= 3e-3 * np.abs(bw[sl]).max(), (name, m)
+
+
+def _config3(g):
+    from test_gpu_fullsize import config3_inputs
+    return config3_inputs(g)
+
+
+def test_config3_tracking_by_gauss_newton_reaches_the_reference_result_in_15_iterations():
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.odometery.loops import track_frame_gn
+    g = load_golden("g17_config3_tum_shaped")
+    frames, est, klds, affs, kfs = _config3(g)
+    dev = kfs[0].image.device
+    supp = KeyFrame(T(frames[1].image), T(frames[1].K))
+    supp_T, aff, losses, its = track_frame_gn(kfs[0], T(frames[0].kld_gt), supp, T(est[1]), T(est[0]), (0, 3),
+                                              prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
+    L = np.array([float(l) for l in losses])
+    print(f"\ntracking by Gauss-Newton: {its} iterations, loss {L[0]:.6f} -> {L[-1]:.6f}; vs the reference's converged result: "
+          f"rot {rot_angle(npy(supp_T), g['track_polished_supp_T']):.2e} rad, t {np.abs(npy(supp_T)[:3, 3] - g['track_polished_supp_T'][:3, 3]).max():.2e}, "
+          f"affine {np.abs(npy(aff) - g['track_polished_aff']).max():.2e}")
+    assert its <= 15
+    assert rot_angle(npy(supp_T), g["track_polished_supp_T"]) <= 1e-4
+    np.testing.assert_allclose(npy(supp_T)[:3, 3], g["track_polished_supp_T"][:3, 3], atol=1e-4)
+    np.testing.assert_allclose(npy(aff), g["track_polished_aff"], atol=2e-4)
+    R = npy(supp_T)[:3, :3]
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+    # the reference's own loss at its converged point (finest level) is what LM ends at
+    np.testing.assert_allclose(L[-1], g["track_polished_losses"][-1], rtol=2e-3)
+
+
+def test_config3_mapping_by_gauss_newton_reaches_the_minimiser_of_the_reference_cost():
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.odometery.loops import map_window
+    g = load_golden("g17_config3_tum_shaped")
+    gm = load_golden("g17min_config3_mapping_minimiser")
+    frames, est, klds, affs, kfs = _config3(g)
+    klds = [frames[0].kld_gt.copy()] + list(klds[1:])        # the frozen oldest depths are exact in g17min (its docstring); the rest is g17's
+    supp = [[(KeyFrame(T(frames[2 * k + 1].image), T(frames[2 * k + 1].K)), T(est[2 * k + 1]), T(affs[2 * k + 1]))] for k in range(3)]
+    out = map_window(kfs, [T(est[2 * k]) for k in range(3)], [T(k) for k in klds], [T(affs[2 * k]) for k in range(3)], supp,
+                     40, window_size=3, initialised=True, optimiser="gn")
+    L = np.array([float(l) for l in out["losses"]])
+    poses = np.concatenate([npy(out["kf_poses"]), np.stack([npy(p) for row in out["supp_poses"] for p in row])])
+    want = np.concatenate([gm["min_kf_poses"], gm["min_supp_poses"]])
+    rot = max(rot_angle(a, b) for a, b in zip(poses, want))
+    tt = float(np.abs(poses[:, :3, 3] - want[:, :3, 3]).max())
+    dd = float(np.abs(np.expm1(np.stack([npy(k) for k in out["klds"]]).astype(np.float64) - gm["min_klds"])).max())
+    print(f"\nmapping by Gauss-Newton: {out['stopped']} iterations ({out['gn']}), loss {L[0]:.7f} -> {L[-1]:.7f} (reference minimiser "
+          f"{gm['losses'][-1]:.7f}); vs the minimiser: rot {rot:.2e} rad, t {tt:.2e}, depth {dd:.2e}")
+    assert rot <= 1e-4 and tt <= 1e-4 and dd <= 1e-3
+    np.testing.assert_allclose(L[-1], gm["losses"][-1], rtol=2e-3)
+    assert np.array_equal(npy(out["kf_poses"][0]), est[0])                   # first keyframe fixed (odometery.py:589-592)
+    assert np.array_equal(npy(out["klds"][0]), klds[0])                      # full window: oldest depths frozen (:594-603)
+    assert np.array_equal(npy(out["affs"][0]), affs[0])
+    for P in poses:
+        np.testing.assert_allclose(P[:3, :3] @ P[:3, :3].T, np.eye(3), atol=1e-6)
+    acc = L[np.concatenate(([True], np.diff(L) < 0))]
+    assert L[-1] < 0.5 * L[0] and np.all(np.diff(acc) < 0)
+
+
+def test_window_gn_freezes_when_converged_and_undoes_rejected_steps():
+    """LM bookkeeping on a small tracking window: (a) after convergence further launches change nothing; (b) with lm_down = 1
+    and a huge initial step (lambda tiny on a far start) a rejected step restores the previous point exactly."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.core import dense_optim
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.optim.window import KIND_WINDOW, PoseWindow
+    pair = synth.make_pair(60, 80, 6, seed=9, init_sigma=0.01, overlap=1)
+    t = lambda a: T(np.ascontiguousarray(a))
+    kf = KeyFrame(t(pair.src_image), t(pair.K), t(pair.logdepth_perseg), t(pair.keypoints), t(pair.keypoint_regions))
+    eye = torch.eye(4, device=kf.image.device)
+    supp_T0 = torch.linalg.inv(t(pair.pose_init))            # relative pose inv(T_supp) T_prev = pose_init
+    nodes = [dict(T=eye, kind=KIND_WINDOW), dict(T=supp_T0, kind=KIND_WINDOW, lr_pose=1.0, image=t(pair.trg_image), K=t(pair.K))]
+    win = PoseWindow([dict(kf=kf, kld=t(pair.kld_gt), lr=0.0, node=0)], nodes, [(0, 1, 1.0, dense_optim.Z_MIN_SINGLE)], (0, 1), max_iters=64)
+    n = win.run_gn(0, 30, conv_tol=1e-4)
+    assert win.gn_converged() and n < 30
+    before = (win.node_poses().clone(), win.gn_iterations())
+    for _ in range(3):
+        win.gn_step(0, conv_tol=1e-4)
+    assert torch.equal(win.node_poses(), before[0]) and win.gn_iterations() == before[1]
+    P = npy(torch.linalg.inv(win.node_poses()[1]))
+    assert rot_angle(P, pair.pose_gt) < 2e-3
+    # (b) the losses of accepted points never increase; a rejected evaluation is followed by the previous loss again
+    L = npy(win.gn_losses())
+    st = win.gn_stats()
+    assert st["accepted"] + st["rejected"] >= len(L) - 1
+    for i in range(1, len(L) - 1):
+        if L[i] > L[i - 1] * (1 + 1e-6):
+            np.testing.assert_allclose(L[i + 1], L[i - 1], rtol=1e-6)
