@@ -593,8 +593,30 @@ def main(argv=None):
                         pass
                     sync()
                     line["from_raw_frames"][key] = n_b * n_raw / (time.perf_counter() - t1)
-                del pipe
+                del pipe, _res
+                torch.cuda.empty_cache()         # (the dead streams' allocator pools go back to the device)
             del raw, frames, base, item
+            # (e') continuous batching of the optimisation alone: 8 scheduled runs back to back over 4 resident batches (distinct
+            #      device copies of this rank's pairs, all set up beforehand), on one stream and with 2 / 3 batches in flight on
+            #      their own streams (optim.pair_stream.PairStream.optimise): the bulk of one batch fills the tail of another
+            copies = [batch] + [build_batch(args, rank, dev)[0] for _ in range(3)]
+            cb = {}
+            for n_opt in (1, 2, 3):
+                pipe = PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, optimisers=n_opt)
+                for _ in range(2):
+                    sync()
+                    t1 = time.perf_counter()
+                    pipe.optimise(copies * 2, restore=True)
+                    sync()
+                    cb[n_opt] = 8 * M / (time.perf_counter() - t1)
+                del pipe
+            line["continuous_batching"] = {"batches": 8, "pairs_per_batch": M, "frame_pairs_per_sec_by_streams": {str(k): v for k, v in cb.items()},
+                                           "gain_over_one_stream": max(cb.values()) / cb[1],
+                                           "what": "8 scheduled runs (FRAME_PAIR_SCHEDULE, set-up excluded) over 4 resident batches, back to back on one HIP "
+                                                   "stream vs 2 / 3 batches in flight on their own streams and host threads"}
+            line["frame_pairs_per_sec_continuous_batching"] = max(cb.values())
+            del copies
+            torch.cuda.empty_cache()
             if args.sigma05_scenes > 0:
                 # (f) the same metric from the reference's own starting distribution
                 line["reference_start"] = reference_start_leg(args, rank, dev, M)

@@ -121,14 +121,14 @@ def track_frame_fused(kf, kld, supp_frame, supp_T, prev_pose, steps, levels, lr=
 # Gauss-Newton schedules of the window optimiser (optim/window.py run_gn; sp_window_gn_step): per pyramid level, coarse -> fine, LM
 # iterations until an accepted step buys less than ``conv_tol`` of the loss, then a polish at the finest level with the IRLS epsilon
 # at ``polish_eps`` (the default epsilon smooths |r| like a Huber kernel and leaves the fixed point ~1e-4 from the L1 minimiser).
-TRACK_GN_SCHEDULE = dict(max_iters_per_level=8, conv_tol=2e-3, irls_eps=1e-3, polish_max=8, polish_eps=1e-5, polish_tol=1e-4)
+TRACK_GN_SCHEDULE = dict(phases=((1, 4), (0, 6)), conv_tol=2e-3, irls_eps=1e-3, polish_max=5, polish_eps=1e-5, polish_tol=1e-4)      # phases: (pyramid level, max iterations), coarse -> fine
 MAP_GN_SCHEDULE = dict(max_iters=25, conv_tol=1e-3, irls_eps=1e-3, polish_max=12, polish_eps=1e-5, polish_tol=1e-5)
 
 
 def track_frame_gn(kf, kld, supp_frame, supp_T, prev_pose, levels, prev_aff=None, curr_aff=None, schedule=None):
     """Frame-to-keyframe tracking (odometery/odometery.py:300-312,375-407) by Gauss-Newton / LM instead of 300 Adam steps: 6 pose
-    + 2 affine unknowns of the tracked frame against the latest keyframe's points (its depths fixed), coarse to fine over
-    ``levels`` = (pyramid_min, pyramid_max).  Same parameterisation as the reference's loop -- relative pose
+    + 2 affine unknowns of the tracked frame against the latest keyframe's points (its depths fixed), coarse to fine over the
+    phases of the schedule (pyramid levels inside ``levels`` = (pyramid_min, pyramid_max); at most 15 iterations by default).  Same parameterisation as the reference's loop -- relative pose
     Exp(d) inv(T_supp) T_prev, fold-in T_supp <- T_supp inv(Exp(d)) after every step, renormalise_se3 at the end -- so the result
     is directly comparable with ``track_frame`` / ``track_frame_fused`` run to convergence.
     Returns (supp_T, curr_aff, losses, iterations)."""
@@ -138,12 +138,12 @@ def track_frame_gn(kf, kld, supp_frame, supp_T, prev_pose, levels, prev_aff=None
     nodes = [dict(T=prev_pose, kind=KIND_WINDOW, aff=prev_aff if affine else None),
              dict(T=supp_T, kind=KIND_WINDOW, lr_pose=1.0, lr_aff=1.0 if affine else 0.0, aff=curr_aff if affine else None,
                   image=supp_frame.image, K=supp_frame.K)]
-    n_lv = levels[1] - levels[0]
+    phases = [(int(l), int(n)) for l, n in sch['phases'] if levels[0] <= int(l) < levels[1]]
     win = PoseWindow([dict(kf=kf, kld=kld, lr=0.0, node=0)], nodes, [(0, 1, 1.0, dense_optim.Z_MIN_SINGLE)], levels,
-                     abs_loss=False, use_affine=affine, max_iters=n_lv * sch['max_iters_per_level'] + sch['polish_max'] + 8)
+                     abs_loss=False, use_affine=affine, max_iters=sum(n for _, n in phases) + sch['polish_max'] + 8)
     its = 0
-    for level in reversed(win.level_ids):
-        its += win.run_gn(level, sch['max_iters_per_level'], irls_eps=sch['irls_eps'], conv_tol=sch['conv_tol'])
+    for level, n in phases:
+        its += win.run_gn(level, n, irls_eps=sch['irls_eps'], conv_tol=sch['conv_tol'])
     if sch['polish_max'] > 0:
         its += win.run_gn(win.level_ids[0], sch['polish_max'], irls_eps=sch['polish_eps'], conv_tol=sch['polish_tol'])
     T = renormalise_se3(win.node_poses()[1].contiguous())

@@ -32,6 +32,7 @@ def run_sequence(frames, to_keyframe, pose0, kld0, engine="gn", **cfg):
     to_keyframe(i) -> KeyFrame of frame i (the frontend's job in the reference: segments + per-segment log-depth shapes);
     pose0: camera-to-world of frame 0; kld0: keypoint log-depths of the first keyframe.
     Returns dict(track_poses (n,4,4) camera-to-world as tracked, kf_ids, kf_poses, kf_klds, n_mappings, seconds dict)."""
+    log = cfg.pop('log', None)              # optional list: (frame, event, payload) records for diagnostics
     c = dict(DEFAULTS, **cfg)
     dev = pose0.device
     affine = c['affine_compensation']
@@ -74,13 +75,18 @@ def run_sequence(frames, to_keyframe, pose0, kld0, engine="gn", **cfg):
             supp = [[(fr, out['supp_poses'][k][j].clone(), (out['supp_affs'][k][j].clone() if affine else a)) for j, (fr, _, a) in enumerate(row)]
                     for k, row in enumerate(supp)]
             scheduled, n_map = False, n_map + 1
+            if log is not None:
+                log.append((i, 'mapping', dict(kf_ids=list(kf_ids), klds=[k.clone() for k in kf_klds], kf_poses=[p.clone() for p in kf_poses],
+                                               losses=[float(out['losses'][0]), float(out['losses'][-1])], n=len(out['losses']))))
         # ---- keyframe decision on the latest keyframe's depth rendered into the current pose (is_kf) ----
         sync(); t0 = time.perf_counter()
         est_depth = estimate_depth_kf_native(kfs[-1], kf_klds[-1], invertSE3(cur_T) @ kf_poses[-1])
         crit = keyframe_criterion(cur_T, kf_poses[-1], est_depth).tolist()        # [validity ratio, scale, translation diff, rotation deg]
         if crit[0] < c['depth_validity_ratio'] or crit[2] > c['translation_thresh']:
             kf = to_keyframe(i)
-            kld = segment_based_depth_reinit(est_depth.clone(), kf, mode='median')
+            kld, vis = segment_based_depth_reinit(est_depth.clone(), kf, mode='median', return_info=True)
+            if log is not None:
+                log.append((i, 'keyframe', dict(criterion=crit, kld=kld.clone(), visible=int(vis.sum()), valid_ratio=float((est_depth > 1e-6).float().mean()))))
             kfs.append(kf); kf_ids.append(i); kf_poses.append(cur_T.clone()); kf_klds.append(kld); kf_affs.append(cur_aff.clone()); supp.append([])
             if len(kfs) > c['window_size']:
                 for lst in (kfs, kf_ids, kf_poses, kf_klds, kf_affs, supp):

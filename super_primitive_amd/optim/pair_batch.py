@@ -265,20 +265,26 @@ class PairBatch:
         HW = np.tile(prep['shapes'][:, 1:].astype(np.int32), (R, 1))                    # full-resolution source size
         pair_idx = np.arange(M, dtype=np.int64)
 
+        # (everything the descriptor maker needs is bound to LOCALS: the lazily evaluated entries of self.src4 / self.desc keep this
+        #  closure alive, and a closure over ``self`` would make every PairBatch a reference cycle -- its ~25 MB per pair of tables
+        #  would then wait for the cyclic garbage collector instead of being freed when the last reference goes)
+        kp_L_t, trg4_t, kld_t, pose_t, aff_t, level_hw = self.kp_L, self.trg4, self.kld, self.pose, self.aff, self.level_hw
+        pix_t, seg_tile_off_t, Ps_a = self.pix, None, np.asarray(self.Ps)
+
         def descriptors(level, pix, src4, seg_tile_off, lay_p_off, lay_wl, real_points):
             d = np.zeros(M, dtype=_SP_PAIR_DTYPE)
             d['pix'] = pix.data_ptr() + 4 * lay_p_off[:-1]
             d['src4'] = src4.data_ptr() + 16 * lay_p_off[:-1]
-            d['kp_L'] = self.kp_L.data_ptr() + 4 * n_off[:-1]
-            d['trg3'] = self.trg4[level].data_ptr() + 4 * trg_off[level][:-1]
-            d['kld'] = self.kld.data_ptr() + 4 * n_off[:-1]
-            d['pose'] = self.pose.data_ptr() + 64 * pair_idx
-            d['aff'] = (self.aff.data_ptr() + 16 * pair_idx) if use_affine else 0
+            d['kp_L'] = kp_L_t.data_ptr() + 4 * n_off[:-1]
+            d['trg3'] = trg4_t[level].data_ptr() + 4 * trg_off[level][:-1]
+            d['kld'] = kld_t.data_ptr() + 4 * n_off[:-1]
+            d['pose'] = pose_t.data_ptr() + 64 * pair_idx
+            d['aff'] = (aff_t.data_ptr() + 16 * pair_idx) if use_affine else 0
             d['seg_tile_off'] = seg_tile_off.data_ptr() + 4 * lay_wl['sto_off'][:-1]
             d['K_src'], d['K_trg'] = k4(Ks_src), k4(Ks_trg)
             d['N'], d['P'] = Ns, real_points
             d['H'], d['W'] = HW[:, 0], HW[:, 1]
-            hl = np.array(self.level_hw[level], dtype=np.int32).reshape(M, 2)
+            hl = np.array(level_hw[level], dtype=np.int32).reshape(M, 2)
             d['Hl'], d['Wl'] = hl[:, 0], hl[:, 1]
             d['tile0'], d['n_tiles'] = lay_wl['s_off'][:-1], np.diff(lay_wl['s_off'])
             d['zmin'] = zmin
@@ -290,7 +296,8 @@ class PairBatch:
             c_wl, c_p_off = coarse_host[(l, stride)]
             host.append(descriptors(l, lay.pix, lay.src4, lay.seg_tile_off, c_p_off, c_wl, np.maximum(np.asarray(lay.points), 1)))
         staged = batch_prepare.stage(host, dev)
-        self.desc = _Lazy(lambda l: batch_prepare.stage([descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps))], dev)[0],
+        src4_d, seg_tile_off_t = self.src4, self.seg_tile_off
+        self.desc = _Lazy(lambda l: batch_prepare.stage([descriptors(l, pix_t, src4_d[l], seg_tile_off_t, p_off, wl, Ps_a)], dev)[0],
                           dict(zip(full_levels, staged)))
         for i, lay in enumerate(self.coarse.values()):
             lay.desc = staged[len(full_levels) + i]

@@ -13,8 +13,10 @@ recovers idle gaps.
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
+import time
 
 import torch
 
@@ -46,6 +48,7 @@ class PairStream:
         self.setup_stream = torch.cuda.Stream(self.device)
         self.optim_streams = [torch.cuda.Stream(self.device) for _ in range(max(1, int(optimisers)))]
         self.optim_stream = self.optim_streams[0]
+        self.trace = [] if os.environ.get("SP_STREAM_TRACE") else None       # developer aid: (what, batch, host t0, host t1) per step
 
     def _producer(self, inputs, out, ready_for_inputs, stop, n_consumers):
         def put(item):                       # never blocks for good: the consumers may have gone away
@@ -64,10 +67,13 @@ class PairStream:
                 for idx, item in enumerate(inputs):
                     if stop.is_set():
                         return
+                    t0 = time.perf_counter()
                     batch = PairBatch(item["src_frames"], item["trg_images"], item["trg_Ks"], item["poses"], item["klds"], levels=self.levels,
                                       point_stride=self.point_stride, **self.batch_kw)
                     built = torch.cuda.Event()
                     built.record(self.setup_stream)
+                    if self.trace is not None:
+                        self.trace.append(("build", idx, t0, time.perf_counter()))
                     ok = put((idx, batch, built))
                     del batch                # the queue (then an optimiser) holds the only reference
                     if not ok:
@@ -93,7 +99,10 @@ class PairStream:
                 idx, batch, built = got
                 with torch.cuda.stream(stream):
                     stream.wait_event(built)
+                    t0 = time.perf_counter()
                     batch.run_scheduled(**self.schedule)
+                    if self.trace is not None:
+                        self.trace.append(("optimise", idx, t0, time.perf_counter()))
                     poses, klds = batch.poses().clone(), [k.clone() for k in batch.klds()]
                     # the results were allocated in this stream's pool and are consumed on the caller's stream: tell the
                     # allocator, so that a block the caller drops is not handed to a later batch's clone() while
@@ -110,6 +119,43 @@ class PairStream:
                 results.put((idx, poses, klds, done))
         except BaseException as e:
             results.put(e)
+
+    def optimise(self, batches, restore=False):
+        """The schedules of ALREADY BUILT batches (PairBatch objects, their set-up complete), K at a time: every optimiser stream
+        takes the next batch off the list as soon as it has finished one, so the long tail of a batch -- its last few pairs
+        iterating almost alone -- overlaps the bulk of the next (continuous batching without any set-up work in the picture).
+        ``restore``: reset each batch to its initial values first (benchmarks re-running the same batches).  Returns when every
+        batch has finished (device synchronised)."""
+        batches = list(batches)
+        nxt = [0]
+        lock = threading.Lock()
+        errors = []
+        torch.cuda.synchronize(self.device)          # the batches may have been built / touched on other streams
+
+        def worker(stream):
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.cuda.stream(stream):
+                    while True:
+                        with lock:
+                            i = nxt[0]
+                            nxt[0] += 1
+                        if i >= len(batches):
+                            break
+                        if restore:
+                            batches[i].restore_initial()
+                        batches[i].run_scheduled(**self.schedule)
+                stream.synchronize()
+            except BaseException as e:               # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(st,), daemon=True) for st in self.optim_streams]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
 
     def run(self, inputs):
         """inputs: iterable of dict(src_frames, trg_images, trg_Ks, poses, klds) -- the arguments of PairBatch, device resident.

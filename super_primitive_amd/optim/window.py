@@ -224,11 +224,13 @@ class PoseWindow:
                                               float(conv_tol), _lib.ptr(gn['state']), _lib.ptr(gn['losses']), self.max_iters,
                                               _lib.stream_ptr()), "sp_window_gn_step")
 
-    def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=4, **lm):
+    def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=2, **lm):
         """Up to ``max_iters`` LM iterations at ``level`` as ONE phase: stops once an accepted step lowers the loss by less than
-        ``conv_tol`` of it (the device freezes the window; the host polls the flag every ``check_every`` iterations).  Returns the
-        iterations issued."""
+        ``conv_tol`` of it (the device freezes the window -- launches after that change nothing; the host polls the flag every
+        ``check_every`` iterations).  Returns the iterations the phase really took (evaluations of the cost, rejected ones and the
+        final converged-test evaluation included), from the device's counter."""
         self.begin_gn_phase()
+        n0 = self.gn_iterations()
         it = 0
         while it < max_iters:
             for _ in range(min(check_every, max_iters - it)):
@@ -236,7 +238,7 @@ class PoseWindow:
                 it += 1
             if conv_tol > 0 and self.gn_converged():
                 break
-        return it
+        return self.gn_iterations() - n0
 
     def gn_converged(self):
         return bool(self._gn_state()['state'][6].item() != 0)

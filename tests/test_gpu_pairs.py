@@ -629,3 +629,22 @@ def test_pair_stream_overlaps_batches_and_returns_each_batch_s_own_result(optimi
     t0 = time.time()
     gen.close()
     assert time.time() - t0 < 10.0
+
+
+def test_pair_batch_is_freed_by_reference_count_alone():
+    """A PairBatch holds ~25 MB of tables per pair: it must go away when the last reference goes (no reference cycle through the
+    lazily built level samples / descriptors), otherwise a stream of batches waits for the cyclic collector and the allocator
+    runs dry (seen as multi-second stalls of the set-up thread of a PairStream)."""
+    import gc
+    import weakref
+    from super_primitive_amd import synth
+    gc.disable()
+    try:
+        batch = make_batch([synth.make_pair(60, 80, 6, seed=3)], levels=(0, 3), point_stride=(1, 2, 4))
+        batch.run_scheduled(max_iters_per_level=3, polish_max=2)
+        batch.gn_step(1)                      # a lazily sampled level
+        ref = weakref.ref(batch)
+        del batch
+        assert ref() is None
+    finally:
+        gc.enable()

@@ -85,7 +85,8 @@ def test_config3_tracking_by_gauss_newton_reaches_the_reference_result_in_15_ite
     supp_T, aff, losses, its = track_frame_gn(kfs[0], T(frames[0].kld_gt), supp, T(est[1]), T(est[0]), (0, 3),
                                               prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
     L = np.array([float(l) for l in losses])
-    print(f"\ntracking by Gauss-Newton: {its} iterations, loss {L[0]:.6f} -> {L[-1]:.6f}; vs the reference's converged result: "
+    print("\ntracking losses: " + " ".join(f"{v:.6f}" for v in L))
+    print(f"tracking by Gauss-Newton: {its} iterations, loss {L[0]:.6f} -> {L[-1]:.6f}; vs the reference's converged result: "
           f"rot {rot_angle(npy(supp_T), g['track_polished_supp_T']):.2e} rad, t {np.abs(npy(supp_T)[:3, 3] - g['track_polished_supp_T'][:3, 3]).max():.2e}, "
           f"affine {np.abs(npy(aff) - g['track_polished_aff']).max():.2e}")
     assert its <= 15
@@ -123,8 +124,12 @@ def test_config3_mapping_by_gauss_newton_reaches_the_minimiser_of_the_reference_
     assert np.array_equal(npy(out["affs"][0]), affs[0])
     for P in poses:
         np.testing.assert_allclose(P[:3, :3] @ P[:3, :3].T, np.eye(3), atol=1e-6)
-    acc = L[np.concatenate(([True], np.diff(L) < 0))]
-    assert L[-1] < 0.5 * L[0] and np.all(np.diff(acc) < 0)
+    # LM: a loss above the last accepted one is a rejected evaluation and is followed by the accepted loss again (the step is undone)
+    best = np.minimum.accumulate(L)
+    assert L[-1] < 0.5 * L[0] and L[-1] <= best[-1] * (1 + 1e-6)
+    for i in range(1, len(L) - 1):
+        if L[i] > best[i - 1] * (1 + 1e-6):
+            np.testing.assert_allclose(L[i + 1], best[i - 1], rtol=1e-5)
 
 
 def test_window_gn_freezes_when_converged_and_undoes_rejected_steps():

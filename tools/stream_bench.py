@@ -12,36 +12,52 @@ from super_primitive_amd.optim.pair_stream import PairStream
 
 dev = torch.device("cuda:0")
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-base = [synth.make_pair(480, 640, 64, seed=1000 + s, overlap=4, init_sigma=0.004) for s in range(4)]
+scenes = [synth.make_pair(480, 640, 64, seed=1000 + s, overlap=4, init_sigma=0.004) for s in range(4)]
 sk = {k: v for k, v in FRAME_PAIR_SCHEDULE.items() if k != "check_every"}
 
 
 def make_items(per_batch, n_batches, distinct_batches):
     items = []
     for b in range(distinct_batches):
-        prs = [base[(b * per_batch + i) % len(base)] for i in range(per_batch)]
+        prs = [scenes[(b * per_batch + i) % len(scenes)] for i in range(per_batch)]
         items.append(dict(src_frames=[KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in prs],
                           trg_images=[t(p.trg_image) for p in prs], trg_Ks=[t(p.K) for p in prs],
                           poses=torch.stack([t(p.pose_init) for p in prs]), klds=[t(p.kld_init) for p in prs]))
     return [items[i % distinct_batches] for i in range(n_batches)]
 
 
-for per_batch, n_batches, distinct in ((384, 8, 2), (128, 24, 3), (64, 24, 3)):
+import gc
+
+for per_batch, n_batches, distinct in ((384, 8, 2), (128, 16, 3)):
     items = make_items(per_batch, n_batches, distinct)
-    pipes = {f"pipelined, {k} optimiser stream{'s' if k > 1 else ''}": PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE, optimisers=k, depth=max(1, k - 1))
-             for k in (1, 2, 3)}                                            # long-lived: their streams' allocator pools are reused
-    for label in ("sequential",) + tuple(pipes):
+    for k in (0, 1, 2, 3):
+        label = "sequential" if k == 0 else f"pipelined, {k} optimiser stream{'s' if k > 1 else ''}"
+        # one long-lived PairStream at a time (its streams' allocator pools are reused from batch to batch; the pools of a
+        # discarded one are returned to the device before the next configuration runs)
+        pipe = None if k == 0 else PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE, optimisers=k, depth=max(1, k - 1))
         for rep in range(3):
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            if label == "sequential":
+            if pipe is None:
                 for it in items:
                     b = PairBatch(it["src_frames"], it["trg_images"], it["trg_Ks"], it["poses"], it["klds"], levels=(0, 3),
                                   point_stride=FRAME_PAIR_POINT_STRIDE)
                     b.run_scheduled(**sk)
-                    res = (b.poses().clone(), [k.clone() for k in b.klds()])
+                    res = (b.poses().clone(), [k_.clone() for k_ in b.klds()])
+                del b
             else:
-                for res in pipes[label].run(iter(items)):
+                for res in pipe.run(iter(items)):
                     pass
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f"{n_batches} batches x {per_batch} pairs, {label}: {dt * 1e3:.1f} ms = {n_batches * per_batch / dt:.0f} pairs/s", flush=True)
+        print(f"{n_batches} batches x {per_batch} pairs, {label}: {dt * 1e3:.1f} ms = {n_batches * per_batch / dt:.0f} pairs/s "
+              f"(device memory reserved {torch.cuda.memory_reserved() / 2**30:.0f} GiB)", flush=True)
+        if pipe is not None and pipe.trace:
+            tr = pipe.trace[-2 * n_batches:]
+            base = min(t[2] for t in tr)
+            for what, idx, a, b_ in sorted(tr, key=lambda t: t[2]):
+                print(f"      {what:9s} batch {idx}: {1e3 * (a - base):8.1f} -> {1e3 * (b_ - base):8.1f} ms ({1e3 * (b_ - a):.1f})")
+        del pipe, res
+        gc.collect()
+        torch.cuda.empty_cache()
     del items
+    gc.collect()
+    torch.cuda.empty_cache()
