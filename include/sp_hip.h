@@ -435,6 +435,12 @@ int sp_depth_splat(const uint32_t* pix, const float* baseL, const int32_t* seg_o
                    const float* kld, int N, int P, int H, int W, const float* K, const float* pose,
                    unsigned long long* keys, float* out, void* stream);
 
+/* core/ops.py:84-92 estimate_depth_diff(mean=True): scatter_reduce_('mean') at the truncated pixel, WITH the reference's "initial
+ * zero counted" semantics (include_self defaults to True): a pixel hit by c points holds sum(z) / (c + 1), an untouched one 0.
+ * acc: 12*H*W bytes of scratch (32.32 fixed-point sums + counts: order independent).  No reference caller passes mean=True. */
+int sp_depth_splat_mean(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L, const float* kld, int N,
+                        int P, int H, int W, const float* K, const float* pose, void* acc, float* out, void* stream);
+
 /* odometery/depth_init.py:10-67 segment_based_depth_reinit.  mode 0 = mean, 1 = median (lower middle for
  * even counts, like torch.median).  est_depth (H,W).  scratch: P floats.  out_kld[N], out_visible[N] u8.
  * Invisible segments receive the (lower) median of the visible segments' values. */

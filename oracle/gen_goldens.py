@@ -234,9 +234,14 @@ def golden_depth_render(ref, name):
     pose_h[1, 3] = 0.5 * 2.0 / pair.K[1, 1]
     img_half = ref.dr.estimate_depth_kf_native(src, T(kldc), T(pose_h))
     save = pair_inputs(pair)
+    # mean=True (core/ops.py:84-92): scatter_reduce 'mean' incl. the initial zero; a pose that piles several points onto a pixel
+    pose_far = np.eye(4, dtype=np.float32)
+    pose_far[2, 3] = 2.5
+    img_mean = ref.dr.estimate_depth_kf_native(src2, T(pair.kld_gt), T(pose_far), mean=True)
+    img_mean_gen = ref.dr.estimate_depth_kf_native(src2, T(pair.kld_gt), T(pair.pose_gt), mean=True)
     save.update(in_L_const=L, in_kld_levels=kld, out_identity=img_id.numpy(), in_kld_gt=pair.kld_gt,
                 in_pose_gt=pair.pose_gt, out_general=img_gen.numpy(), in_kld_const=kldc, in_pose_half=pose_h,
-                out_half=img_half.numpy())
+                out_half=img_half.numpy(), in_pose_far=pose_far, out_mean_far=img_mean.numpy(), out_mean_general=img_mean_gen.numpy())
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 

@@ -122,19 +122,49 @@ def golden_config1(ref, name="g14_config1_converged", seed=101, iters=500, polis
             save[f"L{li}_end_kld"] = kld.detach().numpy().copy()
             save[f"L{li}_end_a"] = a.detach().numpy().copy()
             save[f"L{li}_end_pose"] = (orc.se3_exp(a)[0] @ T0).numpy()
-    for pi, scale in enumerate((0.1, 0.01)):
-        adam_phase(ref, sp[-1], tp[-1], kld, a, T0, polish, scale, losses, log=f"g14 polish {scale}")
+    # polish at the finest level: rounds of decaying learning rates (fresh Adam per phase) until the end state of a round is within
+    # POLISH_SETTLED (0.1 x the north-star bar, gauge removed) of the previous round's -- so that regenerating this golden on another
+    # thread count (another fp32 summation order, another chaotic 3 x 500 trajectory) lands on the same point
+    phases = []
+    with torch.no_grad():
+        prev = ((orc.se3_exp(a)[0] @ T0).numpy(), kld.detach().numpy().copy())
+    moved = None
+    for rnd in range(POLISH_MAX_ROUNDS):
+        for scale, n in POLISH:
+            adam_phase(ref, sp[-1], tp[-1], kld, a, T0, n, scale, losses, log=f"{name} polish {rnd} x{scale}")
+            phases.append((scale, n))
         with torch.no_grad():
-            save[f"P{pi}_end_kld"] = kld.detach().numpy().copy()
-            save[f"P{pi}_end_pose"] = (orc.se3_exp(a)[0] @ T0).numpy()
+            cur = ((orc.se3_exp(a)[0] @ T0).numpy(), kld.detach().numpy().copy())
+        moved = errors_vs(cur[0], cur[1], prev[0], prev[1])
+        prev = cur
+        if all(m <= b for m, b in zip(moved, POLISH_SETTLED)):
+            break
     with torch.no_grad():
         pose = orc.se3_exp(a)[0] @ T0
         final = float(torch.mean(torch.abs(ref.do.photomeric_cost(sp[-1], tp[-1], kld, pose, CFG)["residual"])))
     save.update(losses=np.array(losses, dtype=np.float64), final_loss=np.array(final), final_kld=kld.detach().numpy(),
                 final_pose=pose.numpy(), pose_gt=pair.pose_gt, kld_gt=pair.kld_gt, pose_init=pair.pose_init,
-                kld_init=pair.kld_init)
+                kld_init=pair.kld_init, polish_phases=np.array(phases, dtype=np.float64), last_round_moved=np.array(moved),
+                threads=np.array(torch.get_num_threads()))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
-    print(f"{name}: {time.time() - t0:.0f} s, final loss {final:.9f}, spread last 50 = {np.ptp(losses[-50:]):.2e}", flush=True)
+    print(f"{name}: {time.time() - t0:.0f} s, {len(phases)} polish phases, last round moved {moved}, final loss {final:.9f}, "
+          f"spread last 40 = {np.ptp(losses[-40:]):.2e}", flush=True)
+
+
+def record_regen_spread(names=("g14_config1_converged", "g14_config1_converged_t4", "g14_config1_converged_t1")):
+    """How far regenerations of g14 on 8 / 4 / 1 threads end from one another (gauge removed and raw): stored in the main golden,
+    which tests/test_gpu_fullsize.py ties its 'as close to the reference as the reference is to itself' assertion to."""
+    runs = [dict(np.load(os.path.join(OUT, n + ".npz"))) for n in names]
+    spread, raw = np.zeros(3), np.zeros(3)
+    for i in range(len(runs)):
+        for j in range(i + 1, len(runs)):
+            spread = np.maximum(spread, errors_vs(runs[i]["final_pose"], runs[i]["final_kld"], runs[j]["final_pose"], runs[j]["final_kld"]))
+            raw = np.maximum(raw, errors_vs(runs[i]["final_pose"], runs[i]["final_kld"], runs[j]["final_pose"], runs[j]["final_kld"], gauge=False))
+    main = runs[0]
+    main["regen_spread"], main["regen_spread_raw"] = spread, raw
+    main["regen_threads"] = np.array([int(r["threads"]) for r in runs])
+    np.savez_compressed(os.path.join(OUT, names[0] + ".npz"), **main)
+    print(f"g14 regeneration spread over threads {main['regen_threads']}: gauge removed {spread}, raw {raw}", flush=True)
 
 
 def golden_config2(ref, name="g15_config2_fullsize", seed=1000, segments=64, traj_steps=20, want_minimiser=True):
@@ -419,11 +449,17 @@ def main():
     which = sys.argv[1:] or ["g14", "g14_t1", "g15", "g16", "g17", "g18"]
     if "g14" in which:
         golden_config1(ref)
+    if "g14_t4" in which:
+        torch.set_num_threads(4)
+        golden_config1(ref, name="g14_config1_converged_t4")
     if "g14_t1" in which:
         # the SAME reference run with a different reduction order (1 thread instead of 8): how far the reference moves
         # from itself under fp32 summation-order noise -- the yardstick for trajectory deviations (profiles/r02_parity.txt)
         torch.set_num_threads(1)
         golden_config1(ref, name="g14_config1_converged_t1")
+    if "g14_spread" in which:
+        record_regen_spread()
+    torch.set_num_threads(int(os.environ.get("SP_GOLDEN_THREADS", "8")))
     if "g16" in which:
         golden_config2(ref, name="g16_config5_seg128", seed=2000, segments=128, traj_steps=0, want_minimiser=False)
     if "g15" in which:

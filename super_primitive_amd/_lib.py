@@ -50,6 +50,7 @@ SIGNATURES = {
     "sp_window_gn_scratch_doubles": [I, I, I],
     "sp_window_gn_step": [P, P, I, P, I, P, I, I, I, P, P, P, P, P, I, F, F, F, F, P, P, I, P],
     "sp_depth_expand": [P, P, P, P, I, I, I, I, P, P],
+    "sp_depth_splat_mean": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_segment_reinit": [P, P, P, P, I, I, I, I, P, I, P, P, P, P],
     "sp_depth_average": [P, P, P, P, P, P, I, I, I, I, P, P, P, P],

@@ -75,6 +75,41 @@ __global__ __launch_bounds__(SP_BLOCK) void k_splat_keys(const uint32_t* __restr
     atomicMax(&keys[(size_t)r * W + c], key);
 }
 
+// core/ops.py:84-92 (mean=True): scatter_reduce_(0, index, depth, reduce='mean') with its default include_self=True -- the zero
+// the image was initialised with COUNTS as one sample: a pixel hit by c points holds sum / (c + 1), an untouched pixel 0.
+// Sums in 32.32 fixed point (order independent, hence reproducible; the reference's fp32 sum depends on the scatter order).
+__global__ __launch_bounds__(SP_BLOCK) void k_splat_mean_scatter(const uint32_t* __restrict__ pix, const float* __restrict__ baseL,
+                                                                 const int32_t* __restrict__ seg_off, const float* __restrict__ kp_L,
+                                                                 const float* __restrict__ kld, int N, int P, int H, int W,
+                                                                 const float* __restrict__ K9, const float* __restrict__ T16,
+                                                                 unsigned long long* __restrict__ sums, uint32_t* __restrict__ counts) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    float x, y, d; int n;
+    table_point(pix, baseL, seg_off, kp_L, kld, N, i, K9, x, y, d, n);
+    const float qx = fmaf(T16[0], x, fmaf(T16[1], y, T16[2] * d)) + T16[3];
+    const float qy = fmaf(T16[4], x, fmaf(T16[5], y, T16[6] * d)) + T16[7];
+    const float qz = fmaf(T16[8], x, fmaf(T16[9], y, T16[10] * d)) + T16[11];
+    const float zinv = (fabsf(qz) > 1e-6f) ? __fdiv_rn(1.0f, qz) : 1e-6f;
+    const float u = qx * K9[0] * zinv + K9[2];
+    const float v = qy * K9[4] * zinv + K9[5];
+    if (!(qz > 1e-6f) || !isfinite(u) || !isfinite(v)) return;
+    if (fabsf(u) > 1e9f || fabsf(v) > 1e9f) return;
+    const long long c = (long long)u, r = (long long)v;
+    if (r < 0 || r >= H || c < 0 || c >= W) return;
+    const size_t o = (size_t)r * W + c;
+    atomicAdd(&sums[o], (unsigned long long)((double)qz * 4294967296.0));
+    atomicAdd(&counts[o], 1u);
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_splat_mean_finish(const unsigned long long* __restrict__ sums,
+                                                                const uint32_t* __restrict__ counts, int HW, float* __restrict__ out) {
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    if (i >= HW) return;
+    const uint32_t c = counts[i];
+    out[i] = c ? (float)((double)sums[i] * (1.0 / 4294967296.0)) / (float)(c + 1u) : 0.f;
+}
+
 __global__ __launch_bounds__(SP_BLOCK) void k_splat_decode(const unsigned long long* __restrict__ keys, int HW,
                                                            float* __restrict__ out) {
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
@@ -316,6 +351,24 @@ int sp_depth_splat(const uint32_t* pix, const float* baseL, const int32_t* seg_o
                        kld, N, P, H, W, K, pose, keys);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_splat_decode, dim3((H * W + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0, s, keys, H * W, out);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_depth_splat_mean(const uint32_t* pix, const float* baseL, const int32_t* seg_off, const float* kp_L, const float* kld, int N,
+                        int P, int H, int W, const float* K, const float* pose, void* acc, float* out, void* stream) {
+    if (!pix || !baseL || !seg_off || !kp_L || !kld || !K || !pose || !acc || !out) return SP_EINVAL;
+    if (N <= 0 || P <= 0 || H <= 0 || W <= 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t HW = (size_t)H * W;
+    hipError_t e = hipMemsetAsync(acc, 0, 12 * HW, s);
+    if (e != hipSuccess) return (int)e;
+    unsigned long long* sums = static_cast<unsigned long long*>(acc);
+    uint32_t* counts = reinterpret_cast<uint32_t*>(sums + HW);
+    hipLaunchKernelGGL(k_splat_mean_scatter, dim3((P + SP_BLOCK - 1) / SP_BLOCK), dim3(SP_BLOCK), 0, s, pix, baseL, seg_off, kp_L, kld, N,
+                       P, H, W, K, pose, sums, counts);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_splat_mean_finish, dim3((unsigned)((HW + SP_BLOCK - 1) / SP_BLOCK)), dim3(SP_BLOCK), 0, s, sums, counts, (int)HW, out);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -546,25 +546,37 @@ __global__ void k_prep_keypoint_L(const SpPrepTable* __restrict__ tables) {
 }
 
 // every pyramid level of one table in one pass: segment search, depth and validity once per point.  Padding positions of a
-// segment's run are written as {pix 0, src4 0} = invalid points (the arrays need no prior clearing).
+// segment's run are written as {pix 0, src4 0} = invalid points (the arrays need no prior clearing).  A workgroup takes
+// SP_SAMPLE_BLOCKS consecutive 256-point blocks: the scalar segment search (a chain of dependent loads) is repeated only when a
+// block leaves the current segment's padded run.
+#define SP_SAMPLE_BLOCKS 4
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs) {
     const SpPrepSample& j = jobs[blockIdx.y];
-    const int i0 = blockIdx.x * SP_BLOCK;
-    if (i0 >= j.P) return;
-    // segment runs are padded to multiples of SP_BLOCK: the whole block lies in one segment -> one (scalar) search
-    const int n = segment_of(j.seg_off, j.N, i0);
-    const int first = j.seg_off[n], count = j.counts[n];
-    const float shift = j.kld[n] - j.kp_L[n];
-    const int i = i0 + threadIdx.x;
-    if (i >= j.P) return;
-    if (i - first >= count) {
-        j.pix[i] = 0u;
-        for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
+    int n = 0, first = 0, count = 0, next_first = -1;
+    float shift = 0.f;
+    for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) {
+        const int i0 = (blockIdx.x * SP_SAMPLE_BLOCKS + k) * SP_BLOCK;
+        if (i0 >= j.P) return;
+        if (k == 0 || i0 >= next_first) {
+            // segment runs are padded to multiples of SP_BLOCK: the whole block lies in one segment -> one (scalar) search
+            n = segment_of(j.seg_off, j.N, i0);
+            first = j.seg_off[n];
+            count = j.counts[n];
+            shift = j.kld[n] - j.kp_L[n];
+            next_first = n + 1 < j.N ? j.seg_off[n + 1] : j.P;
+            if (next_first <= first) next_first = j.P;      // (an empty successor shares the offset: search again next block)
+        }
+        const int i = i0 + threadIdx.x;
+        if (i >= j.P) return;
+        if (i - first >= count) {
+            j.pix[i] = 0u;
+            for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            continue;
+        }
+        const SourceGeom g = source_geometry(j.pix[i], j.baseL[i], shift, j.H, j.W, j.K);
+        for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = source_sample(g, j.image[l], j.Hl[l], j.Wl[l]);
+        j.pix[i] = g.pw | (g.ok ? 0x80000000u : 0u);
     }
-    const SourceGeom g = source_geometry(j.pix[i], j.baseL[i], shift, j.H, j.W, j.K);
-    for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = source_sample(g, j.image[l], j.Hl[l], j.Wl[l]);
-    j.pix[i] = g.pw | (g.ok ? 0x80000000u : 0u);
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_blur(const SpPrepImage* __restrict__ jobs) {
@@ -673,7 +685,7 @@ int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int m
 
 int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream) {
     if (!jobs || check_grid(max_P, n_jobs)) return SP_EINVAL;
-    hipLaunchKernelGGL(k_prep_sample, dim3((max_P + SP_BLOCK - 1) / SP_BLOCK, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
+    hipLaunchKernelGGL(k_prep_sample, dim3((max_P + SP_BLOCK * SP_SAMPLE_BLOCKS - 1) / (SP_BLOCK * SP_SAMPLE_BLOCKS), n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -12,6 +12,8 @@ image/gaussian_pyramid.py:53-85 (pyramids), core/dense_optim.py:315-317 (source 
 order as the per-keyframe kernels (shared device functions, sp_table.hip)."""
 from __future__ import annotations
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -336,7 +338,12 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     with timer('fill'):
         _lib.check(lib.sp_prepare_fill(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_fill")
     with timer('sample'):
-        _lib.check(lib.sp_prepare_sample(_lib.ptr(staged[1]), len(jobs), max_P, s_ptr), "sp_prepare_sample")
+        # one launch per lattice: the grid is (blocks of the LARGEST table, jobs), and a stride-4 table has 1/16 of the points of
+        # a stride-1 table -- in one launch over all lattices two thirds of the workgroups would start only to find nothing to do
+        rec_bytes = _SAMPLE_DT.itemsize
+        for ji, s_ in enumerate(levels_of):
+            grp_P = max(int(np.diff(tabs[s_].p_off).max()), 1)
+            _lib.check(lib.sp_prepare_sample(ctypes.c_void_p(staged[1].data_ptr() + ji * M0 * rec_bytes), M0, grp_P, s_ptr), "sp_prepare_sample")
 
     def sample_full(levels):
         """Sample the stride-1 tables at further pyramid levels (those left out of ``full_levels``): {level: (sum Ppad, 4)}.

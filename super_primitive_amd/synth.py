@@ -116,7 +116,7 @@ def _grid_shape(N):
 
 def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
               motion_scale=1.0, init_sigma=0.02, texture_period_px=None,
-              drop_border=0, texture="band", init_mode="left", octave_slope=1.0):
+              drop_border=0, texture="band", init_mode="left", octave_slope=1.0, blob_coverage=None):
     """Render one seeded source/target pair.
 
     ``shape``: 'grid' = gh x gw rectangular tiling; 'blobs' =
@@ -131,6 +131,8 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
     ``texture``: 'band' = that single-octave texture (six components per channel); 'octaves' = a multi-octave ~1/f texture
     (``_octave_texture_table``; shortest period ``texture_period_px``, default 8 px per 320 columns, octaves up to about the
     image width, amplitude ~ period^``octave_slope``) -- what the reference's own starting distribution needs.
+    ``blob_coverage`` (shape='blobs'): scale the ellipses so that their areas sum to about this many image areas (rho; SAM-like
+    masks cover the image ~1.2 times) -- the default (None) keeps the unscaled ellipses, whose coverage grows with N (rho ~ 0.11 N).
     ``init_mode``: 'left' = ``pose_init = Exp(sigma xi) T_gt`` (the default of every earlier golden); 'reference' =
     ``T_gt Exp(sigma xi)``, the reference's ``current_T.mul(SE3.Random(sigma=0.05))`` (odometery/two_frame_sfm.py:77-81;
     lietorch's Random is exp(sigma * randn(6)) on the tangent [tau, phi]).
@@ -198,9 +200,10 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
                 kp_rc[k] = ((r_edges[i] + r_edges[i + 1]) // 2, (c_edges[j] + c_edges[j + 1]) // 2)
                 k += 1
     elif shape == "blobs":
+        bs = 1.0 if blob_coverage is None else math.sqrt(blob_coverage / (N * math.pi * 0.19 * 0.19))
         for k in range(N):
             cr, cc = rng.uniform(0.1 * H, 0.9 * H), rng.uniform(0.1 * W, 0.9 * W)
-            ar, ac = rng.uniform(0.08 * H, 0.3 * H), rng.uniform(0.08 * W, 0.3 * W)
+            ar, ac = bs * rng.uniform(0.08 * H, 0.3 * H), bs * rng.uniform(0.08 * W, 0.3 * W)
             ang = rng.uniform(0, math.pi)
             dr, dc = rows - cr, cols - cc
             a = (dc * math.cos(ang) + dr * math.sin(ang)) / ac

@@ -46,6 +46,17 @@ def test_depth_render_matches_reference():
     # reproducible: collisions resolved by point index, not by scheduling
     again = npy(estimate_depth_kf_native(kf2, T(g["in_kld_gt"]), T(g["in_pose_gt"])))
     assert np.array_equal(gen, again)
+    # mean=True (core/ops.py:84-92): scatter_reduce 'mean' with the zero-initialised image counted as one sample.  The far pose
+    # piles several points onto every pixel it reaches; truncation flips at pixel borders move a point between neighbours, so
+    # the bulk must agree tightly and the touched set almost exactly
+    far = npy(estimate_depth_kf_native(kf2, T(g["in_kld_gt"]), T(g["in_pose_far"]), mean=True))
+    assert ((far > 0) != (g["out_mean_far"] > 0)).mean() < 0.01
+    assert np.isclose(far, g["out_mean_far"], rtol=1e-5).mean() > 0.97
+    both = (far > 0) & (g["out_mean_far"] > 0)
+    np.testing.assert_allclose(np.median(far[both] / g["out_mean_far"][both]), 1.0, rtol=1e-5)
+    mg = npy(estimate_depth_kf_native(kf2, T(g["in_kld_gt"]), T(g["in_pose_gt"]), mean=True))
+    assert np.isclose(mg, g["out_mean_general"], rtol=1e-5).mean() > 0.98
+    assert np.array_equal(far, npy(estimate_depth_kf_native(kf2, T(g["in_kld_gt"]), T(g["in_pose_far"]), mean=True)))
 
 
 def test_segment_reinit_and_average_match_reference():

@@ -57,9 +57,10 @@ def test_residual_and_gradients_at_size(name):
 @pytest.mark.parametrize("fused", [True, False])
 def test_config1_reference_schedule_converges_to_the_reference_result(fused):
     """BASELINE configs[0] (320x240, 8 segments, 3 levels): the reference's own schedule -- 500 Adam iterations per level,
-    lr 1e-3 / 1e-2, no update on the first -- then the polish the golden used (300 @ lr/10, 300 @ lr/100 on the finest
-    level), through the drop-in SfM driver on both engines.  Early losses must match; the converged pose and depths must
-    meet the north-star bar."""
+    lr 1e-3 / 1e-2, no update on the first -- then the polish the golden used (rounds of decaying learning rates on the finest
+    level until the reference's end state stopped moving, ``polish_phases``), through the drop-in SfM driver on both engines.
+    Early losses must match; the converged pose and depths must meet the north-star bar -- and be as close to the reference as
+    the reference is to itself when regenerated on 8 / 4 / 1 threads (``regen_spread``, recorded in the golden)."""
     from super_primitive_amd.odometery.two_frame_sfm import SfM
     g = load_golden("g14_config1_converged")
     alt = load_golden("g14_config1_converged_t1")
@@ -68,8 +69,8 @@ def test_config1_reference_schedule_converges_to_the_reference_result(fused):
     sfm = SfM({"aligment": {"pyramid_min": 0, "pyramid_max": 3, "cost_params": {}}}, src, [trg], [T(pair.pose_init)], num_iters=int(g["iters"]))
     sfm.init_optimisation(kld_init=T(pair.kld_init))
     sfm.run(fused=fused)
-    for scale in (0.1, 0.01):
-        sfm.run(fused=fused, lr_scale=scale, levels=[2], num_iters=int(g["polish"]))
+    for scale, n in g["polish_phases"]:
+        sfm.run(fused=fused, lr_scale=float(scale), levels=[2], num_iters=int(n))
     L = np.array([float(l) for l in sfm.losses])
     assert L.shape == g["losses"].shape
     np.testing.assert_allclose(L[:3], g["losses"][:3], rtol=2e-6)
@@ -78,7 +79,10 @@ def test_config1_reference_schedule_converges_to_the_reference_result(fused):
     P, k = npy(sfm.poses()[0]), npy(sfm.keypoint_logdepths())
     aligned = pose_depth_errors(P, k, g["final_pose"], g["final_kld"])
     assert within_bar(aligned), aligned
-    assert within_bar(aligned, 0.25), aligned                 # measured: 9e-7 rad / 3e-6 / 1.5e-5
+    # ... and inside what separates regenerations of the reference itself (+ 0.1 x bar, the golden's own settling criterion)
+    allowed = 0.1 * np.array(BAR) + 2.0 * g["regen_spread"]
+    assert all(e <= a for e, a in zip(aligned, allowed)), (aligned, allowed)
+    assert within_bar(g["regen_spread"], 0.1), g["regen_spread"]        # the golden is reproducible to 0.1 x bar
     # raw (no gauge removal): not worse than a small multiple of what the reference does to itself on another thread count
     raw = pose_depth_errors(P, k, g["final_pose"], g["final_kld"], gauge=False)
     self_dev = pose_depth_errors(alt["final_pose"], alt["final_kld"], g["final_pose"], g["final_kld"], gauge=False)

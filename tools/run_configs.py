@@ -15,7 +15,7 @@ from super_primitive_amd import synth
 from super_primitive_amd.core import dense_optim
 from super_primitive_amd.image.keyframe import KeyFrame, keyframe_pyramid
 from super_primitive_amd.odometery.two_frame_sfm import SfM
-from super_primitive_amd.odometery.loops import track_frame, track_frame_fused, map_window
+from super_primitive_amd.odometery.loops import track_frame, track_frame_fused, track_frame_gn, map_window
 from super_primitive_amd.odometery.depth_init import segment_based_depth_reinit
 from super_primitive_amd.depth_completion.segment_based_completion import average_visible_segments
 from super_primitive_amd.lie.lie_algebra import invertSE3
@@ -71,6 +71,16 @@ torch.cuda.synchronize(); dt = time.perf_counter() - t0
 est = invertSE3(supp_T).cpu().numpy()
 print(f"config 3  tracking, fused optimiser incl. table / pyramid set-up per frame: {dt*1e3:.1f} ms/frame ({300/dt:.0f} it/s), "
       f"rot err {rot_err(est, p.pose_gt):.2e} rad, t err {np.abs(est[:3,3]-p.pose_gt[:3,3]).max():.2e}")
+# Gauss-Newton / LM tracking (sp_window_gn_step): 6 pose + 2 affine unknowns, <= 15 iterations
+gargs = (src, t(p.kld_gt), trg, supp_T0, torch.eye(4, device=dev), levels)
+track_frame_gn(*gargs, prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5):
+    supp_T, _, losses, its = track_frame_gn(*gargs, prev_aff=torch.zeros(2, device=dev), curr_aff=torch.zeros(2, device=dev))
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+est = invertSE3(supp_T).cpu().numpy()
+print(f"config 3  tracking, Gauss-Newton window optimiser incl. table / pyramid set-up per frame: {dt*1e3:.1f} ms/frame ({1/dt:.0f} frames/s), {its} LM iterations, "
+      f"loss {float(losses[0]):.4f} -> {float(losses[-1]):.4f}, rot err {rot_err(est, p.pose_gt):.2e} rad, t err {np.abs(est[:3,3]-p.pose_gt[:3,3]).max():.2e}")
 # the same frame-to-keyframe problem for a whole batch of frames on device (pose + affine, depths fixed)
 B = 64
 pb = PairBatch([src] * 1, [t(p.trg_image)], [t(p.K)], t(p.pose_init)[None].repeat(B, 1, 1), [t(p.kld_gt)], levels=levels, use_affine=True,
@@ -89,6 +99,31 @@ for fused in (True, False):
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"config 3  windowed mapping, 3 keyframes + 3 supporting frames (10 edges), 500 Adam steps, {'fused' if fused else 'eager'}: "
           f"{dt*1e3:.0f} ms ({500/dt:.0f} it/s), loss {float(out['losses'][0]):.4f} -> {float(out['losses'][-1]):.4f}")
+
+map_window(*margs, 40, window_size=3, initialised=True, optimiser="gn")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5):
+    out = map_window(*margs, 40, window_size=3, initialised=True, optimiser="gn")
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+print(f"config 3  windowed mapping, same window, Gauss-Newton (5 free poses, 80 log-depths, 5 affine pairs; Schur + Cholesky on the device): {dt*1e3:.1f} ms/window "
+      f"({1/dt:.0f} windows/s), {out['stopped']} LM iterations ({out['gn']['accepted']} accepted), loss {float(out['losses'][0]):.4f} -> {float(out['losses'][-1]):.6f}")
+# the whole chain on a 30-frame sequence (odometery/sequence.py): track -> keyframe criterion -> depth render -> re-initialisation -> mapping
+from super_primitive_amd.odometery.sequence import run_sequence
+rng = np.random.default_rng(31)
+base = 0.6 * np.array([0.05, -0.02, 0.015, 0.01, -0.015, 0.008])
+seq = synth.make_sequence(H, W, N, [k * base + 0.003 * rng.standard_normal(6) * (k > 0) for k in range(30)], keyframe_ids=list(range(30)), seed=31, overlap=1)
+sframes = [KeyFrame(t(f.image), t(f.K)) for f in seq]
+to_kf = lambda i: KeyFrame(t(seq[i].image), t(seq[i].K), t(seq[i].logdepth_perseg), t(seq[i].keypoints), t(seq[i].keypoint_regions))
+for engine in ("gn", "adam"):
+    run_sequence(sframes[:4], to_kf, t(seq[0].T_wc), t(seq[0].kld_gt), engine=engine)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = run_sequence(sframes, to_kf, t(seq[0].T_wc), t(seq[0].kld_gt), engine=engine, translation_thresh=0.1, window_size=3, map_steps=300)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    P = out["track_poses"].cpu().numpy().astype(np.float64); G = np.stack([f.T_wc for f in seq]).astype(np.float64)
+    sec = out["seconds"]
+    print(f"config 3  30-frame sequence, {engine}: {29/dt:.0f} frames/s end to end (tracking {29/sec['track']:.0f} frames/s, {out['n_mappings']} mappings at "
+          f"{1e3*sec['mapping']/max(out['n_mappings'],1):.1f} ms, keyframes {out['all_kf_ids']}); trajectory error max rot {max(rot_err(a, b) for a, b in zip(P, G)):.1e} rad, "
+          f"t {np.abs(P[:, :3, 3] - G[:, :3, 3]).max():.1e}")
 
 # ---- config 4: VOID-shaped depth completion --------------------------------------------------------------
 p = synth.make_pair(480, 640, 1200, seed=4, shape="blobs")
