@@ -236,6 +236,18 @@ typedef struct SpPair {
     int32_t rec0;             /* first segment record of this pair (= 4 * its first chunk) */
 } SpPair;
 
+/* HOST helpers (no device work): the work list above for a whole batch.  pc[s] / seg_pos[s]: padded run length and pair-relative
+ * position of every segment (all pairs concatenated), n_off[m]: first segment of pair m (n_pairs + 1 entries).  Chunks: pieces of at
+ * most tile_points points (granule-aligned, nearly equal) of every segment; spans: greedy runs of consecutive chunks of one pair up
+ * to span_points points.  sp_host_work_list_chunks returns the number of chunks (sizes the arrays: chunks and spans 4 int32 per
+ * entry, spans at most as many as chunks); sp_host_work_list fills chunks, spans, seg_tile_off (per pair N + 1 record offsets, 4
+ * records per chunk; sum N + n_pairs entries, pair m at sto_off[m]), c_off / s_off (first chunk / span of every pair) and returns
+ * the number of spans. */
+int sp_host_work_list_chunks(const long long* pc, int n_segs, int tile_points);
+int sp_host_work_list(const long long* pc, const long long* seg_pos, const long long* n_off, int n_pairs, int span_points,
+                      int tile_points, int32_t* chunks, int32_t* spans, int32_t* seg_tile_off, long long* sto_off, long long* c_off,
+                      long long* s_off);
+
 /* mode 0 / 1 as above.  mode 2 = mode 1 plus the affine brightness pair of the TARGET frame as two more unknowns (a_t, b_t; the
  * source frame's pair enters with the opposite sign): residual columns j_a = gain * I_trg(sample), j_b = -1.  Span record
  * (SP_GNA_PARTIAL_FLOATS): [0..28] as mode 1, [29..31] H_aa = {aa, ab, bb}, [32,33] b_a, [34..39] H_{a,pose}, [40..45] H_{b,pose};

@@ -39,6 +39,8 @@ SIGNATURES = {
     "sp_prepare_sample": [P, I, I, P],
     "sp_prepare_blur": [P, I, I, I, P],
     "sp_prepare_pack": [P, I, I, P],
+    "sp_host_work_list_chunks": [P, I, I],
+    "sp_host_work_list": [P, P, P, I, I, I, P, P, P, P, P, P],
     "sp_pairs_schedule_cost": [P, P, P],
     "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P],
     "sp_pairs_schedule_run": [P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P],

@@ -1,0 +1,68 @@
+// Host-side helpers of the many-pairs path (no device code): the work list of a batch -- chunks, spans and per-pair record
+// offsets (include/sp_hip.h, "Work list") -- from the padded run lengths of its segments.  The numpy form of the same
+// (optim/batch_prepare.py flat_work_list) costs ~1-2 ms per lattice for 128 pairs x 64 segments, which made the HOST the bottleneck
+// of the set-up once the preparation kernels were down to ~3 ms; these loops take tens of microseconds.
+#include <stdint.h>
+#include "../../include/sp_hip.h"
+
+namespace {
+const int64_t kGranule = 256;
+inline int64_t chunk_max_of(int tile_points) {
+    const int64_t c = (int64_t)tile_points / kGranule * kGranule;
+    return c > kGranule ? c : kGranule;
+}
+}  // namespace
+
+extern "C" {
+
+int sp_host_work_list_chunks(const long long* pc, int n_segs, int tile_points) {
+    if (!pc || n_segs < 0 || tile_points <= 0) return SP_EINVAL;
+    const int64_t cm = chunk_max_of(tile_points);
+    long long total = 0;
+    for (int s = 0; s < n_segs; ++s) total += (pc[s] + cm - 1) / cm;
+    return total > 0x7fffffffLL ? SP_ELIMIT : (int)total;
+}
+
+int sp_host_work_list(const long long* pc, const long long* seg_pos, const long long* n_off, int n_pairs, int span_points,
+                      int tile_points, int32_t* chunks, int32_t* spans, int32_t* seg_tile_off, long long* sto_off, long long* c_off,
+                      long long* s_off) {
+    if (!pc || !seg_pos || !n_off || !chunks || !spans || !seg_tile_off || !sto_off || !c_off || !s_off) return SP_EINVAL;
+    if (n_pairs < 0 || span_points <= 0 || tile_points <= 0) return SP_EINVAL;
+    const int64_t cm = chunk_max_of(tile_points);
+    int64_t nc = 0, ns = 0;
+    for (int m = 0; m < n_pairs; ++m) {
+        const int64_t first = nc;
+        c_off[m] = nc;
+        s_off[m] = ns;
+        sto_off[m] = n_off[m] + m;
+        int32_t* sto = seg_tile_off + sto_off[m];
+        for (int64_t s = n_off[m]; s < n_off[m + 1]; ++s) {
+            *sto++ = (int32_t)(4 * (nc - first));
+            const int64_t p = pc[s];
+            const int64_t k = (p + cm - 1) / cm;                 // pieces of (nearly) equal, granule-aligned length
+            if (k > 0) {
+                const int64_t per = ((p / kGranule + k - 1) / k) * kGranule;
+                for (int64_t done = 0; done < p; done += per) {
+                    int32_t* c = chunks + 4 * nc++;
+                    c[0] = m; c[1] = (int32_t)(s - n_off[m]); c[2] = (int32_t)(seg_pos[s] + done);
+                    c[3] = (int32_t)(p - done < per ? p - done : per);
+                }
+            }
+        }
+        *sto = (int32_t)(4 * (nc - first));
+        // spans: greedy runs of consecutive chunks of this pair, at most span_points points each (at least one chunk)
+        for (int64_t q = first; q < nc;) {
+            int64_t q1 = q, pts = 0;
+            while (q1 < nc && (q1 == q || pts + chunks[4 * q1 + 3] <= span_points)) pts += chunks[4 * q1++ + 3];
+            int32_t* sp = spans + 4 * ns++;
+            sp[0] = (int32_t)q; sp[1] = (int32_t)(q1 - q); sp[2] = (int32_t)pts; sp[3] = m;
+            q = q1;
+        }
+    }
+    c_off[n_pairs] = nc;
+    s_off[n_pairs] = ns;
+    sto_off[n_pairs] = n_off[n_pairs] + n_pairs;
+    return (int)ns;
+}
+
+}  // extern "C"

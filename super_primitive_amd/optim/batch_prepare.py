@@ -24,6 +24,8 @@ GRANULE = 256
 
 def _dev(t, dev):
     """``t`` on ``dev`` as contiguous float32 without touching tensors that already are."""
+    if t.dtype == torch.float32 and t.device == dev and not t.requires_grad and t.is_contiguous():
+        return t
     t = t.detach()
     if t.device != dev:
         t = t.to(dev)
@@ -45,10 +47,33 @@ def flat_layout(counts, n_off):
 
 
 def flat_work_list(pc, seg_pos, n_off, span_points, tile_points):
-    """Chunks, spans and record offsets (include/sp_hip.h, "Work list") of all pairs at once; the vectorised form of
-    ``pair_batch.build_work_list`` (same chunks, same greedy spans, same order).  pc / seg_pos: padded run length and
-    pair-relative position of every segment; n_off: first segment of every pair.  Returns dict(chunks (C,4), spans (S,4),
-    seg_tile_off (sum(N)+M,), sto_off (M+1,), c_off (M+1,), s_off (M+1,))."""
+    """Chunks, spans and record offsets (include/sp_hip.h, "Work list") of all pairs at once (same chunks, same greedy spans,
+    same order as ``pair_batch.build_work_list``), built by the library's host helper ``sp_host_work_list`` -- tens of
+    microseconds where the numpy form below takes 1-2 ms per lattice.  pc / seg_pos: padded run length and pair-relative position
+    of every segment; n_off: first segment of every pair.  Returns dict(chunks (C,4), spans (S,4), seg_tile_off (sum(N)+M,),
+    sto_off (M+1,), c_off (M+1,), s_off (M+1,))."""
+    lib = _lib.load()
+    pc = np.ascontiguousarray(pc, dtype=np.int64)
+    seg_pos = np.ascontiguousarray(seg_pos, dtype=np.int64)
+    n_off = np.ascontiguousarray(n_off, dtype=np.int64)
+    M, S = len(n_off) - 1, len(pc)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    C = lib.sp_host_work_list_chunks(vp(pc), S, int(tile_points))
+    if C < 0:
+        _lib.check(C, "sp_host_work_list_chunks")
+    chunks = np.empty((max(C, 1), 4), dtype=np.int32)
+    spans = np.empty((max(C, 1), 4), dtype=np.int32)
+    seg_tile_off = np.empty(S + M, dtype=np.int32)
+    sto_off, c_off, s_off = (np.empty(M + 1, dtype=np.int64) for _ in range(3))
+    ns = lib.sp_host_work_list(vp(pc), vp(seg_pos), vp(n_off), M, int(span_points), int(tile_points), vp(chunks), vp(spans), vp(seg_tile_off),
+                               vp(sto_off), vp(c_off), vp(s_off))
+    if ns < 0:
+        _lib.check(ns, "sp_host_work_list")
+    return dict(chunks=chunks[:C], spans=spans[:ns], seg_tile_off=seg_tile_off, sto_off=sto_off, c_off=c_off, s_off=s_off)
+
+
+def flat_work_list_numpy(pc, seg_pos, n_off, span_points, tile_points):
+    """The same work list in vectorised numpy (kept as the independent statement the host helper is tested against)."""
     pc = np.asarray(pc, dtype=np.int64)
     n_off = np.asarray(n_off, dtype=np.int64)
     M, S = len(n_off) - 1, len(pc)

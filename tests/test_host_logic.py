@@ -328,11 +328,12 @@ def test_vectorised_layout_and_work_list_equal_the_per_pair_ones():
         assert np.array_equal(pc, np.concatenate([pd['pc'] for pd in pads]))
         assert np.array_equal(seg_pos, np.concatenate([pd['pseg_off'][:-1] for pd in pads]))
         assert np.array_equal(np.diff(p_off), [pd['Ppad'] for pd in pads])
-        got = batch_prepare.flat_work_list(pc, seg_pos, n_off, span_points, tile_points)
-        assert np.array_equal(got['chunks'], ref['chunks']) and np.array_equal(got['spans'], ref['spans'])
-        assert np.array_equal(got['seg_tile_off'], np.concatenate(ref['seg_rec_offs']))
-        assert np.array_equal(got['c_off'], ref['c_off']) and np.array_equal(got['s_off'], ref['s_off'])
-        assert np.array_equal(got['sto_off'], np.concatenate(([0], np.cumsum([n + 1 for n in Ns]))))
+        for build in (batch_prepare.flat_work_list, batch_prepare.flat_work_list_numpy):      # the library's host helper and its numpy statement
+            got = build(pc, seg_pos, n_off, span_points, tile_points)
+            assert np.array_equal(got['chunks'], ref['chunks']) and np.array_equal(got['spans'], ref['spans'])
+            assert np.array_equal(got['seg_tile_off'], np.concatenate(ref['seg_rec_offs']))
+            assert np.array_equal(got['c_off'], ref['c_off']) and np.array_equal(got['s_off'], ref['s_off'])
+            assert np.array_equal(got['sto_off'], np.concatenate(([0], np.cumsum([n + 1 for n in Ns]))))
     # nothing at all
     got = batch_prepare.flat_work_list(np.zeros(3, np.int64), np.zeros(3, np.int64), np.array([0, 3]), 1024, 1024)
     assert got['chunks'].shape == (0, 4) and got['spans'].shape == (0, 4) and np.array_equal(got['seg_tile_off'], [0, 0, 0, 0])
@@ -354,10 +355,11 @@ def test_vectorised_work_list_equals_the_loop_on_random_layouts():
         ref = build_work_list(pads, span_points, tile_points)
         n_off = np.concatenate(([0], np.cumsum([len(c) for c in counts])))
         pc, seg_pos, p_off = batch_prepare.flat_layout(np.concatenate([np.asarray(c) for c in counts]), n_off)
-        got = batch_prepare.flat_work_list(pc, seg_pos, n_off, span_points, tile_points)
-        assert np.array_equal(got['chunks'], ref['chunks']) and np.array_equal(got['spans'], ref['spans'])
-        assert np.array_equal(got['seg_tile_off'], np.concatenate(ref['seg_rec_offs']))
-        assert np.array_equal(got['c_off'], ref['c_off']) and np.array_equal(got['s_off'], ref['s_off'])
+        for build in (batch_prepare.flat_work_list, batch_prepare.flat_work_list_numpy):
+            got = build(pc, seg_pos, n_off, span_points, tile_points)
+            assert np.array_equal(got['chunks'].reshape(-1, 4), ref['chunks']) and np.array_equal(got['spans'].reshape(-1, 4), ref['spans'])
+            assert np.array_equal(got['seg_tile_off'], np.concatenate(ref['seg_rec_offs']))
+            assert np.array_equal(got['c_off'], ref['c_off']) and np.array_equal(got['s_off'], ref['s_off'])
         assert np.array_equal(np.diff(p_off), [pd['Ppad'] for pd in pads])
 
     check()
