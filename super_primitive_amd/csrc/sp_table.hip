@@ -403,14 +403,26 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* _
     segment_row_scan(t.row_counts[k] + (size_t)blockIdx.x * t.H, t.H, t.counts[k] + blockIdx.x);
 }
 
-// Ordered compaction of (segment,row) rows into every lattice's table.  A workgroup takes 256 consecutive rows, one thread per
+// Ordered compaction of (segment,row) rows into every lattice's table.  A workgroup takes SP_FILL_ROWS consecutive rows, one thread per
 // row decides from the row counts alone which of them are non-empty (a segment covers a small part of the image: ~85 % of its mask
 // rows are empty and are not read again) and the four waves share those.  Word path: a lane owns 4 consecutive pixels; its
 // rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken from three ballots of the
 // count's bits.
-#define SP_FILL_ROWS SP_BLOCK
+template <int SP_FILL_ROWS, bool BYVAL>
+__device__ __forceinline__ void prep_fill_body(const SpPrepTable& t);
+
+template <int SP_FILL_ROWS, bool BYVAL>
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __restrict__ tables) {
-    const SpPrepTable& t = tables[blockIdx.y];
+    if (BYVAL) {
+        const SpPrepTable t = tables[blockIdx.y];
+        prep_fill_body<SP_FILL_ROWS, BYVAL>(t);
+    } else {
+        prep_fill_body<SP_FILL_ROWS, BYVAL>(tables[blockIdx.y]);
+    }
+}
+
+template <int SP_FILL_ROWS, bool BYVAL>
+__device__ __forceinline__ void prep_fill_body(const SpPrepTable& t) {
     const int rows = t.N * t.H;
     const int row_base = blockIdx.x * SP_FILL_ROWS;
     if (row_base >= rows) return;
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
     const unsigned long long below = (1ull << lane) - 1ull;
     {   // one thread per row: is it empty?  then a block-wide ordered compaction of the non-empty ones
         const int row = row_base + (int)threadIdx.x;
-        bool todo = row < rows;
+        bool todo = row < rows && (int)threadIdx.x < SP_FILL_ROWS;
         if (todo && t.stride[0] == 1) {      // lattice 0 holds every mask pixel: its row count says whether the row is empty
             const int n = row / t.H, r = row - n * t.H;
             const int32_t* rc = t.row_counts[0];
@@ -515,8 +527,9 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
     for (int i = wave; i < s_n; i += SP_WAVES) {
         const int row_id = s_rows[i];
         if (!words) {
-            for (int k = 0; k < t.n_strides; ++k)
-                fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                if (k < t.n_strides) fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
             continue;
         }
         const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks + (size_t)row_id * t.W);
@@ -676,7 +689,10 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
 int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_prep_fill, dim3((max_rows + SP_FILL_ROWS - 1) / SP_FILL_ROWS, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    // 256 rows per workgroup, job record by reference: measured against 64 rows and against the record by value (scalar registers)
+    // on 384 pairs -- 2.36 ms vs 2.89 / 2.69 / 3.35 ms (profiles/r03_kernel_experiments.txt): the pass likes few, fat workgroups
+    // and occupancy more than it dislikes re-loading the record's pointers
+    hipLaunchKernelGGL((k_prep_fill<256, false>), dim3((max_rows + 255) / 256, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_keypoint_L, dim3((max_N + 63) / 64, n_tables), dim3(64), 0, s, tables);
     SP_CHECK_LAUNCH();

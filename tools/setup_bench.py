@@ -1,40 +1,33 @@
 #!/usr/bin/env python
-"""Developer tool: what it costs to make one keyframe / frame pair ready for the optimiser at 640x480x64 --
-segment table, pyramid, per-level source sampling and target packing -- i.e. everything outside the iteration loop."""
+"""Developer tool: per-pass HIP-event times of the batched set-up (optim/batch_prepare.py) for 384 distinct 640x480x64 pairs, e.g.
+under different SP_FILL_VARIANT settings:  SP_FILL_VARIANT=64 python tools/setup_bench.py"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from super_primitive_amd import synth
-from super_primitive_amd.image.keyframe import KeyFrame, keyframe_pyramid
-from super_primitive_amd.segment_table import SegmentTable, packed_target, table_of
-from super_primitive_amd.optim.pair_batch import PairBatch
+from super_primitive_amd.image.keyframe import KeyFrame
+from super_primitive_amd.optim.batch_prepare import _Timer
+from super_primitive_amd.optim.pair_batch import FRAME_PAIR_POINT_STRIDE, PairBatch
 
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 384
 dev = torch.device("cuda:0")
-p = synth.make_pair(480, 640, 64, seed=1, overlap=4)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-img_s, img_t, K, L, kp, M = t(p.src_image), t(p.trg_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)
-
-
-def timed(fn, n=20):
-    for _ in range(3):
-        fn()
+base = [synth.make_pair(480, 640, 64, seed=7000 + s, overlap=4, init_sigma=0.004) for s in range(4)]
+pairs = [base[i % len(base)] for i in range(G)]
+src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in pairs]
+trg, Ks, klds = [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs], [t(p.kld_init) for p in pairs]
+poses = torch.stack([t(p.pose_init) for p in pairs])
+build = lambda tm=None: PairBatch(src, trg, Ks, poses, klds, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, timer=tm)
+build(); build()
+acc = {}
+wall = []
+for _ in range(4):
+    tm = _Timer()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
-
-
-print(f"segment table (masks {tuple(M.shape)} -> P points, tiles): {timed(lambda: SegmentTable(M, L, kp)):.3f} ms")
-print(f"3-level pyramids of both frames (keyframe_pyramid x2): {timed(lambda: (keyframe_pyramid(KeyFrame(img_s, K, L, kp, M), 0, 3), keyframe_pyramid(KeyFrame(img_t, K), 0, 3))):.3f} ms")
-tab = SegmentTable(M, L, kp)
-kld = t(p.kld_init)
-print(f"source sampling of one level (src4): {timed(lambda: tab.sample_source(img_s, K) if hasattr(tab, 'sample_source') else tab.source_level(img_s.clone(), K, kld)):.3f} ms")
-print(f"target packing of one level (HWC3): {timed(lambda: packed_target(img_t.clone())):.3f} ms")
-def whole():
-    src = KeyFrame(img_s, K, L, kp, M)
-    b = PairBatch([src], [img_t], [K], t(p.pose_init)[None], [kld], levels=(0, 3), tile_points=2048)
-    return b
-print(f"PairBatch of one pair from raw tensors (table + pyramids + 3 levels of src4/trg3 + descriptors): {timed(whole, 10):.3f} ms")
-b = whole()
-print(f"30 GN iterations (3 levels x 10) as hipGraphs: {timed(lambda: b.run(10, mode='gn', use_graph=True), 10):.3f} ms")
+    b = build(tm)
+    torch.cuda.synchronize(); wall.append(time.perf_counter() - t0)
+    for k, v in tm.milliseconds().items():
+        acc.setdefault(k, []).append(v)
+nb = b.setup_bytes
+print(f"SP_FILL_VARIANT={os.environ.get('SP_FILL_VARIANT', 'default')}: {G} pairs, set-up {1e3 * np.median(wall):.2f} ms = {1e6 * np.median(wall) / G:.1f} us/pair; "
+      + "  ".join(f"{k} {np.median(v):.2f} ms ({nb[k] / np.median(v) / 1e6 / 8000:.3f})" for k, v in acc.items()))
