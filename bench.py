@@ -56,6 +56,9 @@ def parse(argv=None):
     ap.add_argument("--shape", choices=["grid", "blobs"], default="grid",
                     help="segment masks: the grid tiling of the headline workload, or ragged overlapping ellipses (SAM-like; --coverage)")
     ap.add_argument("--coverage", type=float, default=1.2, help="--shape blobs: total mask area in image areas (rho)")
+    ap.add_argument("--granule", type=int, choices=[256, 64], default=256,
+                    help="padding granule of the point tables: 256 (a span per workgroup), or 64 = wave spans (SP_COST_WAVE_SPANS), for "
+                         "batches of many small ragged segments")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
     ap.add_argument("--tile-points", type=int, default=8192, help="longest chunk (piece of one segment)")
     ap.add_argument("--span-points", type=int, default=None, help="points per workgroup (run of consecutive chunks); default: PairBatch's")
@@ -95,6 +98,7 @@ def build_batch(args, rank, dev):
     batch = PairBatch(src, [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs], poses,
                       [t(p.kld_init) for p in pairs], levels=(0, 3), tile_points=args.tile_points, replicate=R,
                       point_stride=FRAME_PAIR_POINT_STRIDE,     # extra decimated tables for the frame-pair schedule only
+                      granule=getattr(args, 'granule', 256),
                       **({} if getattr(args, 'span_points', None) is None else {'span_points': args.span_points}))
     return batch, pairs
 
@@ -254,7 +258,8 @@ def measure_traffic(args, kernel_substr):
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
                os.path.join(ROOT, "bench.py"), "--settle-ms", "0", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extras",
                "--no-pmc", "--pairs", str(args.pairs), "--segments", str(args.segments), "--distinct", str(args.distinct),
-               "--tile-points", str(args.tile_points), "--mode", args.mode, "--shape", args.shape, "--coverage", str(args.coverage)]
+               "--tile-points", str(args.tile_points), "--mode", args.mode, "--shape", args.shape, "--coverage", str(args.coverage),
+               "--granule", str(args.granule)]
         if args.span_points is not None:
             cmd += ["--span-points", str(args.span_points)]
         try:
@@ -392,7 +397,8 @@ def main(argv=None):
                    "pairs_per_gpu": M, "segment_pixels_per_pair": int(batch.Ps[0]), "optimiser": args.mode,
                    "texture": (f"single-octave band, shortest period {pairs[0].meta['texture_period_px']:g} px; initial pose Exp(0.004 xi) T_gt (+0.002 per copy)"
                                if pairs else None),
-                   "tile_points": args.tile_points, "span_points": batch.span_points, "sharding": f"{world} x independent pair batches, final all_gather only"},
+                   "tile_points": args.tile_points, "span_points": batch.span_points, "granule": args.granule,
+                   "padded_points_per_real_point": float(sum(batch.Ppads)) / float(sum(batch.Ps)), "sharding": f"{world} x independent pair batches, final all_gather only"},
         "roofline": {"bound": "hbm", "kernel": f"k_cost_pairs<{mode_id}>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
@@ -403,7 +409,7 @@ def main(argv=None):
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     line["roofline"]["traffic_source"] = None
     if rank == 0 and world == 1 and not dry and not args.no_pmc:
-        hbm, detail = measure_traffic(args, f"k_cost_pairs<{mode_id}, 0, 0>")
+        hbm, detail = measure_traffic(args, f"k_cost_pairs<{mode_id}, 0, 0, {'true' if args.granule == 64 else 'false'}>")
         if hbm is not None:
             line["roofline"]["traffic"] = hbm
             line["roofline"]["traffic_source"] = "this run (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one pass each, 10 steps of this command)"
@@ -557,7 +563,7 @@ def main(argv=None):
                 sync()
                 t0 = time.perf_counter()
                 b = PairBatch(frames, [r["trg"] for r in raw], [r["K"] for r in raw], poses0, [r["kld"] for r in raw], levels=(0, 3),
-                              tile_points=args.tile_points, point_stride=STRIDE, timer=timer)
+                              tile_points=args.tile_points, point_stride=STRIDE, timer=timer, granule=args.granule)
                 sync()
                 t1 = time.perf_counter()
                 b.run_scheduled(**sched_kw)
@@ -589,7 +595,7 @@ def main(argv=None):
             for key, n_opt, n_b in (("pipelined_pairs_per_sec", 1, 4), ("continuous_batching_pairs_per_sec", 2, 8)):
                 # n_opt = 2: two batches run their schedules at the same time on two HIP streams -- the bulk of one fills the
                 # tail of the other (optim/pair_stream.py); sustained over n_b batches back to back, set-up included
-                pipe = PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, tile_points=args.tile_points, optimisers=n_opt)
+                pipe = PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, tile_points=args.tile_points, optimisers=n_opt, granule=args.granule)
                 for _ in range(2):                           # (first pass: the streams' allocator pools fill)
                     sync()
                     t1 = time.perf_counter()

@@ -98,7 +98,8 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
  *   sp_prepare_blur  : one pyramid step (sp_blur_decimate) of every job image
  *   sp_prepare_pack  : planar (3,H,W) -> HWC3 of every job image
  *   sp_prepare_sample: sp_table_sample_source of every job at all its levels, and the source-validity bit of pix.  Every
- *                      segment's run must start at a multiple of 256 (the padded layout of the many-pairs work list);
+ *                      segment's run must start at a multiple of 256 (the padded layout of the many-pairs work list; of 64 when
+ *                      SpPrepSample.granule is 64);
  *                      positions beyond counts[n] of a run are padding and are written as {pix 0, src4 0} = invalid points,
  *                      so pix / src4 need no prior clearing
  * ---------------------------------------------------------------------------------------------------- */
@@ -133,7 +134,8 @@ typedef struct SpPrepSample {    /* one table, sampled at up to SP_PREP_MAX_LEVE
     const float* image[SP_PREP_MAX_LEVELS];     /* planar (3,Hl,Wl) source image of each level */
     float* src4[SP_PREP_MAX_LEVELS];            /* (P,4) out, one per level */
     int32_t Hl[SP_PREP_MAX_LEVELS], Wl[SP_PREP_MAX_LEVELS];
-    int32_t N, P, H, W, n_levels, pad_;
+    int32_t N, P, H, W, n_levels;
+    int32_t granule;             /* padding granule of the runs: 0 / 256, or 64 for wave-span tables (SP_COST_WAVE_SPANS) */
 } SpPrepSample;                  /* 176 bytes */
 typedef struct SpPrepImage {
     const float* in;             /* (C,H,W) planar */
@@ -243,10 +245,16 @@ typedef struct SpPair {
  * entry, spans at most as many as chunks); sp_host_work_list fills chunks, spans, seg_tile_off (per pair N + 1 record offsets, 4
  * records per chunk; sum N + n_pairs entries, pair m at sto_off[m]), c_off / s_off (first chunk / span of every pair) and returns
  * the number of spans. */
-int sp_host_work_list_chunks(const long long* pc, int n_segs, int tile_points);
+int sp_host_work_list_chunks(const long long* pc, int n_segs, int tile_points, int granule);
 int sp_host_work_list(const long long* pc, const long long* seg_pos, const long long* n_off, int n_pairs, int span_points,
-                      int tile_points, int32_t* chunks, int32_t* spans, int32_t* seg_tile_off, long long* sto_off, long long* c_off,
-                      long long* s_off);
+                      int tile_points, int granule /* 256, or 64 for wave spans */, int records_per_chunk /* 4, or 1 for wave spans */,
+                      int32_t* chunks, int32_t* spans, int32_t* seg_tile_off, long long* sto_off, long long* c_off, long long* s_off);
+
+/* WAVE SPANS (mode | SP_COST_WAVE_SPANS, modes 0 and 1): a work list whose spans belong to single WAVES instead of workgroups -- the
+ * tables are padded to multiples of 64 points instead of 256, chunk counts are multiples of 64, and there is ONE segment record per
+ * chunk (record index = chunk index) instead of four.  For batches of many small ragged segments (SAM-like masks): at 1200
+ * segments of ~280 pixels the 256-point granule pads 40 %, the 64-point granule 11 %.  Four consecutive spans share a workgroup. */
+#define SP_COST_WAVE_SPANS 0x100
 
 /* mode 0 / 1 as above.  mode 2 = mode 1 plus the affine brightness pair of the TARGET frame as two more unknowns (a_t, b_t; the
  * source frame's pair enters with the opposite sign): residual columns j_a = gain * I_trg(sample), j_b = -1.  Span record
@@ -302,6 +310,8 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
  * pose 10x faster than the depths (lr 1e-2 vs 1e-3, :116-123) and so aligns the pose first.  A pose-only phase at the coarsest
  * level is the Gauss-Newton counterpart (tools/gn_model.py, profiles/r03_sigma05_sweep.txt). */
 #define SP_PHASE_POSE_ONLY 1
+/* SP_PHASE_WAVE_SPANS: the phase's work list is wave-granular (see SP_COST_WAVE_SPANS). */
+#define SP_PHASE_WAVE_SPANS 2
 typedef struct SpPhase {
     const SpPair* pairs;
     const int32_t* chunks;

@@ -39,8 +39,8 @@ SIGNATURES = {
     "sp_prepare_sample": [P, I, I, P],
     "sp_prepare_blur": [P, I, I, I, P],
     "sp_prepare_pack": [P, I, I, P],
-    "sp_host_work_list_chunks": [P, I, I],
-    "sp_host_work_list": [P, P, P, I, I, I, P, P, P, P, P, P],
+    "sp_host_work_list_chunks": [P, I, I, I],
+    "sp_host_work_list": [P, P, P, I, I, I, I, I, P, P, P, P, P, P],
     "sp_pairs_schedule_cost": [P, P, P],
     "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P],
     "sp_pairs_schedule_run": [P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P],
@@ -91,6 +91,8 @@ class SpPair(ctypes.Structure):
 
 SP_MAX_PHASES = 8
 SP_PHASE_POSE_ONLY = 1
+SP_PHASE_WAVE_SPANS = 2
+SP_COST_WAVE_SPANS = 0x100
 
 
 SP_PREP_MAX_STRIDES = 4
@@ -110,7 +112,7 @@ class SpPrepSample(ctypes.Structure):
     _fields_ = [("pix", c_void_p), ("baseL", c_void_p), ("seg_off", c_void_p), ("counts", c_void_p), ("kp_L", c_void_p), ("kld", c_void_p),
                 ("K", c_void_p), ("image", c_void_p * SP_PREP_MAX_LEVELS), ("src4", c_void_p * SP_PREP_MAX_LEVELS),
                 ("Hl", c_int * SP_PREP_MAX_LEVELS), ("Wl", c_int * SP_PREP_MAX_LEVELS),
-                ("N", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("n_levels", c_int), ("pad_", c_int)]
+                ("N", c_int), ("P", c_int), ("H", c_int), ("W", c_int), ("n_levels", c_int), ("granule", c_int)]
 
 
 class SpPrepImage(ctypes.Structure):

@@ -467,35 +467,38 @@ struct SpanCursor {            // all wave-uniform
     float nq_kld, nq_kpl;
 };
 
+template <int TRIP = SP_BLOCK>
 __device__ __forceinline__ void cursor_fetch_next(SpanCursor& k) {
     if (k.q + 1 < k.q_end) {
         const int seg = k.chunks[k.q + 1].seg;
-        k.nq_left = k.chunks[k.q + 1].count / SP_BLOCK;
+        k.nq_left = k.chunks[k.q + 1].count / TRIP;
         k.nq_kld = k.kld[seg];
         k.nq_kpl = k.kp_L[seg];
     }
 }
 
+template <int TRIP = SP_BLOCK>
 __device__ __forceinline__ void cursor_init(SpanCursor& k, const SpPair& pr, const int4* chunks, int q0, int n) {
     k.chunks = (cptr_i4)chunks;
     k.kld = (cptr_f32)pr.kld;
     k.kp_L = (cptr_f32)pr.kp_L;
     k.q = q0; k.q_end = q0 + n;
     const int seg0 = k.chunks[q0].seg;
-    k.left = k.chunks[q0].count / SP_BLOCK;
+    k.left = k.chunks[q0].count / TRIP;
     k.shift = k.kld[seg0] - k.kp_L[seg0];
     k.nq_left = 0; k.nq_kld = 0.f; k.nq_kpl = 0.f;
-    cursor_fetch_next(k);
+    cursor_fetch_next<TRIP>(k);
 }
 
 // Account one prepared trip.  Returns true if that trip was the last of its chunk (whose index is written to `done_q`).
+template <int TRIP = SP_BLOCK>
 __device__ __forceinline__ bool cursor_advance(SpanCursor& k, int& done_q) {
     done_q = k.q;
     if (--k.left > 0) return false;
     ++k.q;
     k.left = k.nq_left;
     k.shift = k.nq_kld - k.nq_kpl;
-    cursor_fetch_next(k);
+    cursor_fetch_next<TRIP>(k);
     return true;
 }
 
@@ -538,10 +541,14 @@ __device__ __forceinline__ uint32_t pix_from_colour_bits(const f32x4 s) {
     const uint32_t v = (a & 0x7fu) | ((b & 0x7fu) << 7) | ((c & 0x3fu) << 14);            // col (10) | row (9) << 10 | valid << 19
     return (v & 0x3ffu) | (((v >> 10) & 0x1ffu) << 16) | ((v >> 19) << 31);
 }
-template <int ABL, bool WT, bool AFF = false>
+// W64 ("wave spans"): the span belongs to ONE WAVE -- trips of 64 points, segment records one per chunk, pair-level sums reduced
+// over the wave only -- so that the padding granule of the tables is 64 points instead of 256 (small ragged segments: 1200
+// SAM-like masks of ~280 pixels pad 40 % at 256 and 11 % at 64); the four waves of a workgroup work on four consecutive spans.
+template <int ABL, bool WT, bool AFF = false, bool W64 = false>
 __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
                                             int n_chunks, int total, float irls_eps, float* __restrict__ span_rec,
                                             float* __restrict__ seg_partials, float* lds) {
+    constexpr int TRIP = W64 ? 64 : SP_BLOCK;
     constexpr int NV = AFF ? SP_GNA_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS, NS = AFF ? SP_GNA_SEG_FLOATS : SP_GN_SEG_FLOATS;
     GnAcc A;
     AffAcc AA;
@@ -562,7 +569,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     SpanCursor k;
-    cursor_init(k, pr, chunks, q0, n_chunks);
+    cursor_init<TRIP>(k, pr, chunks, q0, n_chunks);
     const int start = k.chunks[q0].start;
     PairConsts kc;
     {
@@ -579,8 +586,8 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     const rsrc_t r_pix = make_rsrc(c.pix + start, (uint32_t)total * 4u);
     const rsrc_t r_src = make_rsrc(c.src4 + start, (uint32_t)total * 16u);
     const rsrc_t r_trg = make_rsrc(c.trg, (uint32_t)c.Wl * (uint32_t)c.Hl * (4u * SP_TEXEL_FLOATS));
-    const int n_iter = total / SP_BLOCK;
-    uint32_t op = threadIdx.x * 4u;
+    const int n_iter = total / TRIP;
+    uint32_t op = (W64 ? (threadIdx.x & 63u) : threadIdx.x) * 4u;
     constexpr int NT = 2;
     // Two point slots used alternately (the loop is unrolled by two with the roles swapped), so that nothing has to be
     // copied at the back edge: point j lives in slot j % 2 from its geometry (bottom of trip j - 1) through its taps and
@@ -592,7 +599,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
         const uint32_t pw = ABL == 5 ? pix_from_colour_bits(s) : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         prepare2(c, kc, k.shift, pw, s, S0.p);
-        S0.last = cursor_advance(k, S0.q);
+        S0.last = cursor_advance<TRIP>(k, S0.q);
     }
     S1.p = S0.p;                         // "point -1": finite values, zinv = zi = 0 and a zero Mix2 -> contributes exact zeros
     S1.p.zinv = 0.f; S1.p.zi = 0.f;
@@ -600,7 +607,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     Mix2 m{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, 0.f};
     // one trip: taps + channel mixing of the point in `a`, fold of the point in `b`, geometry of the next point into `b`
     auto trip = [&](Slot& a, Slot& b) {
-        op += 4u * SP_BLOCK;
+        op += 4u * TRIP;
         asm volatile("" : "+v"(op));        // one induction register; the src4 offset is a shift of it
         const uint32_t pw = ABL == 5 ? 0u : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
@@ -629,7 +636,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 2) fold_gn2<AFF>(kc, GeoGn{b.p.qxy, b.p.qz, b.p.zinv, b.p.zi}, m, A, &ma, &AA);
-        if (b.last) flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(4 * b.q + wave) * NS, &AA);
+        if (b.last) flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(W64 ? b.q : 4 * b.q + wave) * NS, &AA);
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 1)
             asm volatile("" : "+v"(ta), "+v"(tb), "+v"(tc), "+v"(td), "+v"(A.blk[0]), "+v"(A.blk[1]), "+v"(A.blk[2]),
@@ -642,17 +649,17 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         asm volatile("" : "+v"(pw_), "+v"(s_));
         if (ABL == 5) pw_ = pix_from_colour_bits(s_);
         prepare2(c, kc, k.shift, pw_, s_, b.p);       // (the trip past the end reads zeros and is never used)
-        b.last = cursor_advance(k, b.q);
+        b.last = cursor_advance<TRIP>(k, b.q);
     };
     int j = 0;
     for (; j + 1 < n_iter; j += 2) { trip(S0, S1); trip(S1, S0); }
     if (j < n_iter) {                    // odd trip count: the last point sits in S0
         trip(S0, S1);
         if (ABL != 2) fold_gn2<AFF>(kc, GeoGn{S0.p.qxy, S0.p.qz, S0.p.zinv, S0.p.zi}, m, A, &ma, &AA);
-        flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(4 * S0.q + wave) * NS, &AA);
+        flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(W64 ? S0.q : 4 * S0.q + wave) * NS, &AA);
     } else {
         if (ABL != 2) fold_gn2<AFF>(kc, GeoGn{S1.p.qxy, S1.p.qz, S1.p.zinv, S1.p.zi}, m, A, &ma, &AA);
-        flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(4 * S1.q + wave) * NS, &AA);
+        flush_segment_gn<WT, AFF>(A, seg_partials + (size_t)(W64 ? S1.q : 4 * S1.q + wave) * NS, &AA);
     }
     float acc[NV];
     acc[0] = A.cost;
@@ -676,30 +683,37 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     }
     // op still knows the thread index (op = 4 * (threadIdx.x + trips * SP_BLOCK)): nothing derived from threadIdx.x
     // has to stay live, or be spilled, across the loop for the sake of this epilogue
-    const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
-    const float tot = block_sum_to_thread<NV>(acc, lds, tid);
-    if (tid < NV) store_partial<WT>(span_rec + tid, tot);
+    if (W64) {
+        int pos; bool ok;
+        wave_sum_to_lanes<NV>(acc, (int)((op >> 2) & 63u), pos, ok);
+        if (ok) store_partial<WT>(span_rec + pos, acc[0]);
+    } else {
+        const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
+        const float tot = block_sum_to_thread<NV>(acc, lds, tid);
+        if (tid < NV) store_partial<WT>(span_rec + tid, tot);
+    }
 }
 
 // mode 0: the segment column is 13 (d/dkld)
-template <int ABL, bool WT>
+template <int ABL, bool WT, bool W64 = false>
 __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr, const int4* __restrict__ chunks, int q0,
                                               int n_chunks, int total, float* __restrict__ span_rec,
                                               float* __restrict__ seg_partials, float* lds) {
+    constexpr int TRIP = W64 ? 64 : SP_BLOCK;
     constexpr int NV = SP_GRAD_PARTIAL_FLOATS;
     float acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     SpanCursor k;
-    cursor_init(k, pr, chunks, q0, n_chunks);
+    cursor_init<TRIP>(k, pr, chunks, q0, n_chunks);
     const int start = k.chunks[q0].start;
     const float ifx = 1.f / c.Ks.fx, ify = 1.f / c.Ks.fy;
     const rsrc_t r_pix = make_rsrc(c.pix + start, (uint32_t)total * 4u);
     const rsrc_t r_src = make_rsrc(c.src4 + start, (uint32_t)total * 16u);
     const rsrc_t r_trg = make_rsrc(c.trg, (uint32_t)c.Wl * (uint32_t)c.Hl * (4u * SP_TEXEL_FLOATS));
-    const int n_iter = total / SP_BLOCK;
-    uint32_t op = threadIdx.x * 4u;
+    const int n_iter = total / TRIP;
+    uint32_t op = (W64 ? (threadIdx.x & 63u) : threadIdx.x) * 4u;
     constexpr int NT = 2;
     // two point slots used alternately, the loop unrolled by two (see run_span_gn): nothing is copied at the back edge
     struct Slot { Pending p; int q; bool last; };
@@ -708,7 +722,7 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
         prepare(c, k.shift, ifx, ify, pw, s, S0.p);
-        S0.last = cursor_advance(k, S0.q);
+        S0.last = cursor_advance<TRIP>(k, S0.q);
     }
     S1.p = S0.p;                         // "point -1": contributes exact zeros
     S1.p.g.zinv = 0.f; S1.p.g.zi = 0.f;
@@ -716,11 +730,11 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
     Mix0 m0{0.f, 0.f, 0.f, 0.f};
     auto flush = [&](int q) {
         const float tot = wave_sum(acc[13]);
-        if (lane_id() == 0) store_partial<WT>(seg_partials + (size_t)(4 * q + wave) * SP_GRAD_SEG_FLOATS, tot);
+        if (lane_id() == 0) store_partial<WT>(seg_partials + (size_t)(W64 ? q : 4 * q + wave) * SP_GRAD_SEG_FLOATS, tot);
         acc[13] = 0.f;
     };
     auto trip = [&](Slot& a, Slot& b) {
-        op += 4u * SP_BLOCK;
+        op += 4u * TRIP;
         asm volatile("" : "+v"(op));
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
@@ -746,7 +760,7 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
         prepare(c, k.shift, ifx, ify, pw_, s_, b.p);
-        b.last = cursor_advance(k, b.q);
+        b.last = cursor_advance<TRIP>(k, b.q);
     };
     int j = 0;
     for (; j + 1 < n_iter; j += 2) { trip(S0, S1); trip(S1, S0); }
@@ -758,9 +772,15 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
         if (ABL != 2) fold_grad(c, S1.p.g, m0, acc);
         flush(S1.q);
     }
-    const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
-    const float tot = block_sum_to_thread<NV>(acc, lds, tid);      // (column 13 is zero here: flushed per chunk)
-    if (tid < NV) store_partial<WT>(span_rec + tid, tot);
+    if (W64) {
+        int pos; bool ok;
+        wave_sum_to_lanes<NV>(acc, (int)((op >> 2) & 63u), pos, ok);
+        if (ok) store_partial<WT>(span_rec + pos, acc[0]);
+    } else {
+        const int tid = (int)((op >> 2) & (uint32_t)(SP_BLOCK - 1));
+        const float tot = block_sum_to_thread<NV>(acc, lds, tid);      // (column 13 is zero here: flushed per chunk)
+        if (tid < NV) store_partial<WT>(span_rec + tid, tot);
+    }
 }
 
 __device__ __forceinline__ void fill_warp(TileCtx& c, const float* pose, const Cam& Kt, int H, int W, int Hl, int Wl,
@@ -905,13 +925,15 @@ struct FuseArgs {
     SchedCost sched;          // IRLS epsilon; spans of pairs that are finished, or in a phase of another work list, return at once
 };
 
-template <int MODE, int ABL = 0, int FUSED = 0>
+template <int MODE, int ABL = 0, int FUSED = 0, bool W64 = false>
 __global__ __launch_bounds__(SP_BLOCK, FUSED != 0 ? 1 : (MODE == 2 ? 2 : 4)) void k_cost_pairs(
         const SpPair* __restrict__ pairs, const int4* __restrict__ chunks, const int4* __restrict__ spans, int n_spans,
         float irls_eps, float* __restrict__ partials, float* __restrict__ seg_partials, FuseArgs f) {
     constexpr int NV = MODE == 0 ? SP_GRAD_PARTIAL_FLOATS : (MODE == 2 ? SP_GNA_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS);
     __shared__ float lds[SP_WAVES * NV];
-    const int w = xcd_chunked_tile(blockIdx.x, n_spans);
+    // (wave spans: the four waves of the workgroup take four consecutive spans)
+    const int w = W64 ? 4 * xcd_chunked_tile(blockIdx.x, (n_spans + 3) >> 2) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+                      : xcd_chunked_tile(blockIdx.x, n_spans);
     if (w >= n_spans) return;
     const int4 span = spans[w];             // {first chunk, number of chunks, points, pair}
     if (f.done && f.done[span.w]) return;   // converged pair (sp_pairs_cost_active): nothing to evaluate
@@ -937,8 +959,8 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED != 0 ? 1 : (MODE == 2 ? 2 : 4)) voi
     }
     c.start = 0; c.count = 0;
     if (MODE == 2) run_span_gn<ABL, FUSED != 0, true>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials + (size_t)w * NV, seg_partials, lds);
-    else if (MODE == 1) run_span_gn<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials + (size_t)w * NV, seg_partials, lds);
-    else run_span_grad<ABL, FUSED != 0>(c, pr, chunks, span.x, span.y, span.z, partials + (size_t)w * NV, seg_partials, lds);
+    else if (MODE == 1) run_span_gn<ABL, FUSED != 0, false, W64>(c, pr, chunks, span.x, span.y, span.z, irls_eps, partials + (size_t)w * NV, seg_partials, lds);
+    else run_span_grad<ABL, FUSED != 0, W64>(c, pr, chunks, span.x, span.y, span.z, partials + (size_t)w * NV, seg_partials, lds);
     if (FUSED != 0) {
         __shared__ int is_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1114,8 +1136,23 @@ int sp_pairs_cost(const SpPair* pairs, const int32_t* chunks, const int32_t* spa
 int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int mode, float irls_eps,
                          float* partials, float* seg_partials, const int32_t* done, void* stream) {
     if (!pairs || !chunks || !spans || !partials || !seg_partials || n_spans <= 0) return SP_EINVAL;
-    if (mode != 0 && mode != 1 && mode != 2 && !(mode >= 10 && mode <= 16)) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (mode & SP_COST_WAVE_SPANS) {        // wave-granular work list (granule 64): modes 0 and 1
+        const int base = mode & ~SP_COST_WAVE_SPANS;
+        if (base != 0 && base != 1) return SP_EINVAL;
+        const int gw = ((((n_spans + 3) / 4) + 7) / 8) * 8;
+        FuseArgs nf{};
+        nf.done = done;
+        if (base == 0)
+            hipLaunchKernelGGL((k_cost_pairs<0, 0, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, s, pairs, reinterpret_cast<const int4*>(chunks),
+                               reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, nf);
+        else
+            hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, s, pairs, reinterpret_cast<const int4*>(chunks),
+                               reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, nf);
+        SP_CHECK_LAUNCH();
+        return 0;
+    }
+    if (mode != 0 && mode != 1 && mode != 2 && !(mode >= 10 && mode <= 16)) return SP_EINVAL;
     const int gx = ((n_spans + 7) / 8) * 8;
     const int4* c4 = reinterpret_cast<const int4*>(chunks);
     const int4* s4 = reinterpret_cast<const int4*>(spans);
@@ -1163,12 +1200,20 @@ int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* 
             const SpPhase& ph = sched->phase[q];
             if (ph.spans != lead.spans || ph.n_spans != lead.n_spans) continue;
             if (ph.chunks != lead.chunks || ph.span_partials != lead.span_partials || ph.seg_partials != lead.seg_partials ||
-                ph.n_spans != lead.n_spans) return SP_EINVAL;
+                ph.n_spans != lead.n_spans || ((ph.flags ^ lead.flags) & SP_PHASE_WAVE_SPANS)) return SP_EINVAL;
             f.sched.pairs[q] = ph.pairs;
             f.sched.irls_eps[q] = ph.irls_eps;
             f.sched.mask |= 1u << q;
         }
         launched |= f.sched.mask;
+        if (lead.flags & SP_PHASE_WAVE_SPANS) {
+            const int gw = ((((lead.n_spans + 3) / 4) + 7) / 8) * 8;
+            hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), lead.pairs,
+                               reinterpret_cast<const int4*>(lead.chunks), reinterpret_cast<const int4*>(lead.spans), lead.n_spans, lead.irls_eps,
+                               lead.span_partials, lead.seg_partials, f);
+            SP_CHECK_LAUNCH();
+            continue;
+        }
         const int gx = ((lead.n_spans + 7) / 8) * 8;
         hipLaunchKernelGGL(k_cost_pairs<1>, dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), lead.pairs,
                            reinterpret_cast<const int4*>(lead.chunks), reinterpret_cast<const int4*>(lead.spans), lead.n_spans, lead.irls_eps,

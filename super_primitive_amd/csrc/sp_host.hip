@@ -6,29 +6,29 @@
 #include "../../include/sp_hip.h"
 
 namespace {
-const int64_t kGranule = 256;
-inline int64_t chunk_max_of(int tile_points) {
-    const int64_t c = (int64_t)tile_points / kGranule * kGranule;
-    return c > kGranule ? c : kGranule;
+inline int64_t chunk_max_of(int tile_points, int64_t granule) {
+    const int64_t c = (int64_t)tile_points / granule * granule;
+    return c > granule ? c : granule;
 }
 }  // namespace
 
 extern "C" {
 
-int sp_host_work_list_chunks(const long long* pc, int n_segs, int tile_points) {
-    if (!pc || n_segs < 0 || tile_points <= 0) return SP_EINVAL;
-    const int64_t cm = chunk_max_of(tile_points);
+int sp_host_work_list_chunks(const long long* pc, int n_segs, int tile_points, int granule) {
+    if (!pc || n_segs < 0 || tile_points <= 0 || (granule != 64 && granule != 256)) return SP_EINVAL;
+    const int64_t cm = chunk_max_of(tile_points, granule);
     long long total = 0;
     for (int s = 0; s < n_segs; ++s) total += (pc[s] + cm - 1) / cm;
     return total > 0x7fffffffLL ? SP_ELIMIT : (int)total;
 }
 
 int sp_host_work_list(const long long* pc, const long long* seg_pos, const long long* n_off, int n_pairs, int span_points,
-                      int tile_points, int32_t* chunks, int32_t* spans, int32_t* seg_tile_off, long long* sto_off, long long* c_off,
-                      long long* s_off) {
+                      int tile_points, int granule, int records_per_chunk, int32_t* chunks, int32_t* spans, int32_t* seg_tile_off,
+                      long long* sto_off, long long* c_off, long long* s_off) {
     if (!pc || !seg_pos || !n_off || !chunks || !spans || !seg_tile_off || !sto_off || !c_off || !s_off) return SP_EINVAL;
-    if (n_pairs < 0 || span_points <= 0 || tile_points <= 0) return SP_EINVAL;
-    const int64_t cm = chunk_max_of(tile_points);
+    if (n_pairs < 0 || span_points <= 0 || tile_points <= 0 || (granule != 64 && granule != 256) || records_per_chunk <= 0) return SP_EINVAL;
+    const int64_t kGranule = granule, R = records_per_chunk;
+    const int64_t cm = chunk_max_of(tile_points, granule);
     int64_t nc = 0, ns = 0;
     for (int m = 0; m < n_pairs; ++m) {
         const int64_t first = nc;
@@ -37,7 +37,7 @@ int sp_host_work_list(const long long* pc, const long long* seg_pos, const long 
         sto_off[m] = n_off[m] + m;
         int32_t* sto = seg_tile_off + sto_off[m];
         for (int64_t s = n_off[m]; s < n_off[m + 1]; ++s) {
-            *sto++ = (int32_t)(4 * (nc - first));
+            *sto++ = (int32_t)(R * (nc - first));
             const int64_t p = pc[s];
             const int64_t k = (p + cm - 1) / cm;                 // pieces of (nearly) equal, granule-aligned length
             if (k > 0) {
@@ -49,7 +49,7 @@ int sp_host_work_list(const long long* pc, const long long* seg_pos, const long 
                 }
             }
         }
-        *sto = (int32_t)(4 * (nc - first));
+        *sto = (int32_t)(R * (nc - first));
         // spans: greedy runs of consecutive chunks of this pair, at most span_points points each (at least one chunk)
         for (int64_t q = first; q < nc;) {
             int64_t q1 = q, pts = 0;

@@ -565,22 +565,26 @@ __global__ void k_prep_keypoint_L(const SpPrepTable* __restrict__ tables) {
 #define SP_SAMPLE_BLOCKS 4
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs) {
     const SpPrepSample& j = jobs[blockIdx.y];
+    // padding granule of the table: 256 (a whole 256-point block lies in one segment) or 64 (wave spans: every WAVE's 64 points
+    // do; the search then runs per wave)
+    const int unit = j.granule == 64 ? 64 : SP_BLOCK;
+    const int lane_off = j.granule == 64 ? (int)(threadIdx.x & ~63u) : 0;
     int n = 0, first = 0, count = 0, next_first = -1;
     float shift = 0.f;
     for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) {
-        const int i0 = (blockIdx.x * SP_SAMPLE_BLOCKS + k) * SP_BLOCK;
-        if (i0 >= j.P) return;
-        if (k == 0 || i0 >= next_first) {
-            // segment runs are padded to multiples of SP_BLOCK: the whole block lies in one segment -> one (scalar) search
+        const int b0 = (blockIdx.x * SP_SAMPLE_BLOCKS + k) * SP_BLOCK;
+        if (b0 >= j.P) return;
+        const int i0 = __builtin_amdgcn_readfirstlane(b0 + lane_off);        // first point of this wave's / block's unit
+        const int i = b0 + (int)threadIdx.x;
+        if (i0 < j.P && (k == 0 || i0 >= next_first || unit == 64)) {
             n = segment_of(j.seg_off, j.N, i0);
             first = j.seg_off[n];
             count = j.counts[n];
             shift = j.kld[n] - j.kp_L[n];
             next_first = n + 1 < j.N ? j.seg_off[n + 1] : j.P;
-            if (next_first <= first) next_first = j.P;      // (an empty successor shares the offset: search again next block)
+            if (next_first <= first) next_first = j.P;
         }
-        const int i = i0 + threadIdx.x;
-        if (i >= j.P) return;
+        if (i >= j.P) continue;
         if (i - first >= count) {
             j.pix[i] = 0u;
             for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = make_float4(0.f, 0.f, 0.f, 0.f);

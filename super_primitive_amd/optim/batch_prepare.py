@@ -34,19 +34,19 @@ def _dev(t, dev):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def flat_layout(counts, n_off):
+def flat_layout(counts, n_off, granule=GRANULE):
     """Padded layout of many tables at once.  counts: real points of every segment, all tables concatenated; n_off[t]:
     first segment of table t.  Returns (pc, seg_pos, p_off): padded run length of every segment, its position relative to
-    its own table, and the tables' offsets into one flat array."""
+    its own table, and the tables' offsets into one flat array.  ``granule``: 256, or 64 for wave-span work lists."""
     counts = np.asarray(counts, dtype=np.int64)
-    pc = (counts + GRANULE - 1) // GRANULE * GRANULE
+    pc = (counts + granule - 1) // granule * granule
     cum = np.concatenate(([0], np.cumsum(pc)))
     p_off = cum[n_off]
     table = np.repeat(np.arange(len(n_off) - 1), np.diff(n_off))
     return pc, cum[:-1] - p_off[table], p_off
 
 
-def flat_work_list(pc, seg_pos, n_off, span_points, tile_points):
+def flat_work_list(pc, seg_pos, n_off, span_points, tile_points, granule=GRANULE):
     """Chunks, spans and record offsets (include/sp_hip.h, "Work list") of all pairs at once (same chunks, same greedy spans,
     same order as ``pair_batch.build_work_list``), built by the library's host helper ``sp_host_work_list`` -- tens of
     microseconds where the numpy form below takes 1-2 ms per lattice.  pc / seg_pos: padded run length and pair-relative position
@@ -58,15 +58,16 @@ def flat_work_list(pc, seg_pos, n_off, span_points, tile_points):
     n_off = np.ascontiguousarray(n_off, dtype=np.int64)
     M, S = len(n_off) - 1, len(pc)
     vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
-    C = lib.sp_host_work_list_chunks(vp(pc), S, int(tile_points))
+    rec = 4 if granule == GRANULE else 1                  # segment records per chunk: one per wave, or one (wave spans)
+    C = lib.sp_host_work_list_chunks(vp(pc), S, int(tile_points), int(granule))
     if C < 0:
         _lib.check(C, "sp_host_work_list_chunks")
     chunks = np.empty((max(C, 1), 4), dtype=np.int32)
     spans = np.empty((max(C, 1), 4), dtype=np.int32)
     seg_tile_off = np.empty(S + M, dtype=np.int32)
     sto_off, c_off, s_off = (np.empty(M + 1, dtype=np.int64) for _ in range(3))
-    ns = lib.sp_host_work_list(vp(pc), vp(seg_pos), vp(n_off), M, int(span_points), int(tile_points), vp(chunks), vp(spans), vp(seg_tile_off),
-                               vp(sto_off), vp(c_off), vp(s_off))
+    ns = lib.sp_host_work_list(vp(pc), vp(seg_pos), vp(n_off), M, int(span_points), int(tile_points), int(granule), rec, vp(chunks), vp(spans),
+                               vp(seg_tile_off), vp(sto_off), vp(c_off), vp(s_off))
     if ns < 0:
         _lib.check(ns, "sp_host_work_list")
     return dict(chunks=chunks[:C], spans=spans[:ns], seg_tile_off=seg_tile_off, sto_off=sto_off, c_off=c_off, s_off=s_off)
@@ -192,7 +193,7 @@ class _NoTimer:
         return _NoTimer._Null()
 
 
-def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, full_levels=None, timer=None):
+def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, full_levels=None, timer=None, granule=GRANULE):
     """Everything PairBatch needs from the raw frames, for the M0 given pairs.
 
     coarse: [(level, stride)] -- ADDITIONAL decimated tables (stride > 1) sampled at that level; the stride-1 tables are
@@ -311,7 +312,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         t = PreparedTables()
         t.stride = s
         t.counts = counts_h[si].astype(np.int64)
-        t.pc, t.seg_pos, t.p_off = flat_layout(t.counts, n_off)
+        t.pc, t.seg_pos, t.p_off = flat_layout(t.counts, n_off, granule)
         if s == 1 and (np.add.reduceat(t.counts, n_off[:-1]) == 0).any():
             raise ValueError("keyframe has no segment pixels")
         total = max(int(t.p_off[-1]), 1)
@@ -350,7 +351,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
             jb['counts'] = t.counts_d.data_ptr() + 4 * n_off[:-1]
             jb['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
             jb['kld'], jb['K'] = _ptrs(kld), _ptrs(Ksrc)
-            jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'] = Ns, P, Hs, Ws, len(lv)
+            jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'], jb['granule'] = Ns, P, Hs, Ws, len(lv), granule
             for k, l in enumerate(lv):
                 t.src4[l] = torch.empty(max(int(t.p_off[-1]), 1), 4, dtype=torch.float32, device=dev)
                 jb['image'][:, k] = ptr_lv[l][0]

@@ -135,7 +135,7 @@ class _Lazy(dict):
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
                  tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None, point_stride=None,
-                 extra_tables=(), lazy_levels=True, timer=None):
+                 extra_tables=(), lazy_levels=True, timer=None, granule=GRANULE):
         """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
         device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
@@ -157,7 +157,14 @@ class PairBatch:
         method below (cost_pass, gn_step, adam_step, evaluate, run, run_converging) works on all points.
         ``lazy_levels``: the all-points source samples (and descriptors) of a level that has a decimated table are made on first
         use instead of at construction -- the scheduled run never reads them (``self.src4`` / ``self.desc`` fill in on access).
-        ``timer``: a ``batch_prepare._Timer`` that collects per-pass HIP-event times of the set-up."""
+        ``timer``: a ``batch_prepare._Timer`` that collects per-pass HIP-event times of the set-up.
+        ``granule`` = 64: WAVE SPANS (include/sp_hip.h SP_COST_WAVE_SPANS) -- segments are padded to multiples of 64 instead of
+        256 points, a span belongs to one wave, one segment record per chunk.  For batches of many small ragged segments: 1200
+        SAM-like masks of ~280 pixels pad 40 % at 256 and 11 % at 64.  The single-launch forms (``fused=True``) are not available."""
+        assert granule in (GRANULE, 64)
+        self.granule = int(granule)
+        self.rec_per_chunk = 4 if granule == GRANULE else 1
+        self.wave_flag = 0 if granule == GRANULE else _lib.SP_COST_WAVE_SPANS
         lib = _lib.load()
         self.lib = lib
         M0 = len(src_frames)
@@ -184,7 +191,7 @@ class PairBatch:
         decimated = {l for l, s in coarse_keys if l in self.point_stride and self.point_stride[l] == s}
         full_levels = [l for l in self.level_ids if not (lazy_levels and l in decimated)] or [min(self.level_ids)]
         prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev, full_levels=full_levels,
-                                           timer=timer)
+                                           timer=timer, granule=self.granule)
         self.setup_bytes = prep['bytes']
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
         rep = (lambda x: x) if R == 1 else (lambda x: x.repeat(*([R] + [1] * (x.dim() - 1))))
@@ -218,14 +225,16 @@ class PairBatch:
         trg_off = {l: np.concatenate(([0], np.cumsum(tile(np.diff(trg[l][1]))))) for l in self.level_ids}
         self.level_hw = {l: list(trg[l][2]) * R for l in self.level_ids}
 
+        # (wave spans: a span is a quarter of a workgroup's worth of work, so four times as many of them)
+        span_div = 1 if self.granule == GRANULE else 4
         if span_points is None:
-            span_points = min(DEFAULT_SPAN_POINTS, int(p_off[-1]) // MIN_SPANS)
-        self.span_points = max(int(span_points), GRANULE)
+            span_points = min(DEFAULT_SPAN_POINTS, int(p_off[-1]) // MIN_SPANS) // span_div
+        self.span_points = max(int(span_points), self.granule)
         # work list: chunks {pair, seg, start, count} and spans {first chunk, n chunks, points, pair}
-        wl = batch_prepare.flat_work_list(pc, seg_pos, n_off, self.span_points, tile_points)
+        wl = batch_prepare.flat_work_list(pc, seg_pos, n_off, self.span_points, tile_points, self.granule)
         chunks, spans = wl['chunks'], wl['spans']
         self.n_chunks, self.n_spans = len(chunks), len(spans)
-        self.n_seg_records = 4 * self.n_chunks
+        self.n_seg_records = self.rec_per_chunk * self.n_chunks
         # decimated point sets of the coarse levels (run_scheduled): own tables, work list, descriptors, partial buffers
         self.coarse = {}
         coarse_host = {}
@@ -239,8 +248,8 @@ class PairBatch:
             shared = next((o for (l2, s2), o in self.coarse.items() if s2 == stride), None)
             lay.pix = shared.pix if shared is not None else rep(t.pix)
             lay.src4 = rep(t.src4[l]).reshape(-1)
-            c_span = max(GRANULE, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS))
-            c_wl = batch_prepare.flat_work_list(c_pc, c_seg_pos, n_off, c_span, tile_points)
+            c_span = max(self.granule, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS) // span_div)
+            c_wl = batch_prepare.flat_work_list(c_pc, c_seg_pos, n_off, c_span, tile_points, self.granule)
             lay.n_chunks, lay.n_spans = len(c_wl['chunks']), len(c_wl['spans'])
             coarse_host[(l, stride)] = (c_wl, c_p_off)
             self.coarse[(l, stride)] = lay
@@ -248,7 +257,7 @@ class PairBatch:
         # still running): chunks {pair, seg, start, count}, spans {first chunk, n chunks, points, pair}, the per-pair CSR of
         # the segment records, and -- for host-side consumers (tests, evaluate()) -- the owner (pair, segment) of every
         # segment record
-        host = [chunks, spans, wl['seg_tile_off'], np.repeat(chunks[:, :2], 4, axis=0)]
+        host = [chunks, spans, wl['seg_tile_off'], np.repeat(chunks[:, :2], self.rec_per_chunk, axis=0)]
         for key in self.coarse:
             c_wl = coarse_host[key][0]
             host += [c_wl['chunks'], c_wl['spans'], c_wl['seg_tile_off']]
@@ -269,7 +278,7 @@ class PairBatch:
         #  closure alive, and a closure over ``self`` would make every PairBatch a reference cycle -- its ~25 MB per pair of tables
         #  would then wait for the cyclic garbage collector instead of being freed when the last reference goes)
         kp_L_t, trg4_t, kld_t, pose_t, aff_t, level_hw = self.kp_L, self.trg4, self.kld, self.pose, self.aff, self.level_hw
-        pix_t, seg_tile_off_t, Ps_a = self.pix, None, np.asarray(self.Ps)
+        pix_t, seg_tile_off_t, Ps_a, rec_per_chunk = self.pix, None, np.asarray(self.Ps), self.rec_per_chunk
 
         def descriptors(level, pix, src4, seg_tile_off, lay_p_off, lay_wl, real_points):
             d = np.zeros(M, dtype=_SP_PAIR_DTYPE)
@@ -288,7 +297,7 @@ class PairBatch:
             d['Hl'], d['Wl'] = hl[:, 0], hl[:, 1]
             d['tile0'], d['n_tiles'] = lay_wl['s_off'][:-1], np.diff(lay_wl['s_off'])
             d['zmin'] = zmin
-            d['rec0'] = 4 * lay_wl['c_off'][:-1]
+            d['rec0'] = rec_per_chunk * lay_wl['c_off'][:-1]
             return d
 
         host = [descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps)) for l in full_levels]
@@ -302,7 +311,7 @@ class PairBatch:
         for i, lay in enumerate(self.coarse.values()):
             lay.desc = staged[len(full_levels) + i]
             lay.partials = torch.empty(max(lay.n_spans, 1) * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
-            lay.seg_partials = torch.empty(max(4 * lay.n_chunks, 1) * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
+            lay.seg_partials = torch.empty(max(self.rec_per_chunk * lay.n_chunks, 1) * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
 
         # optimiser state / workspaces
         self.partials = torch.empty(self.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
@@ -349,7 +358,7 @@ class PairBatch:
 
     # ------------------------------------------------------------------------------------------------
     def cost_pass(self, level, mode, irls_eps=1e-3):
-        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, mode,
+        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, mode | self.wave_flag,
                                           float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.stream_ptr()), "sp_pairs_cost")
 
     def gn_step(self, level=0, irls_eps=1e-3, lm_up=8.0, lm_down=0.5, lm_min=1e-7, fused=False, conv_tol=0.0):
@@ -359,6 +368,7 @@ class PairBatch:
         pair's last tile also solves that pair -- bitwise the same results; measured 0-4 % slower on MI355X (the
         solver's register/LDS footprint costs the cost kernel one wave per SIMD), kept for launch-bound hosts."""
         if fused:
+            assert not self.wave_flag, "the single-launch form has no wave-span variant"
             _lib.check(self.lib.sp_pairs_gn_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, self.M,
                                                     self.max_N, float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(self.arrivals),
                                                     float(lm_up), float(lm_down), float(lm_min), _lib.ptr(self.lm_state),
@@ -367,7 +377,7 @@ class PairBatch:
             return self._costs
         if conv_tol > 0.0:
             # per-pair convergence on the device: pairs in self.done are skipped by both launches (``run(conv_tol=...)``)
-            _lib.check(self.lib.sp_pairs_cost_active(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, 1,
+            _lib.check(self.lib.sp_pairs_cost_active(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, 1 | self.wave_flag,
                                                      float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials),
                                                      _lib.ptr(self.done), _lib.stream_ptr()), "sp_pairs_cost_active")
             _lib.check(self.lib.sp_pairs_gn_step_conv(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials),
@@ -389,6 +399,7 @@ class PairBatch:
     def adam_step(self, level=0, lr_kld=1e-3, lr_pose=1e-2, lr_aff=5e-3, fused=False):
         """One Adam iteration (reset-tangent flavour of the reference's tracking/mapping loops) of every pair."""
         if fused:
+            assert not self.wave_flag, "the single-launch form has no wave-span variant"
             _lib.check(self.lib.sp_pairs_adam_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, self.M,
                                                       self.max_N, _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(self.arrivals),
                                                       float(lr_kld), float(lr_pose), float(lr_aff), _lib.ptr(self.adam_state),
@@ -484,7 +495,7 @@ class PairBatch:
                 ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(lay.desc), _lib.ptr(lay.chunks), _lib.ptr(lay.spans), lay.n_spans
                 ph.span_partials, ph.seg_partials = _lib.ptr(lay.partials), _lib.ptr(lay.seg_partials)
             ph.irls_eps, ph.conv_tol, ph.max_iters = float(spec.get("irls_eps", irls_eps)), float(spec["conv_tol"]), int(spec["max_iters"])
-            ph.flags = _lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0
+            ph.flags = (_lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0) | (_lib.SP_PHASE_WAVE_SPANS if self.wave_flag else 0)
         sched.n_phases = len(phases)
         return sched
 

@@ -648,3 +648,53 @@ def test_pair_batch_is_freed_by_reference_count_alone():
         assert ref() is None
     finally:
         gc.enable()
+
+
+@pytest.mark.parametrize("shape,seed", [("grid", 3), ("blobs", 4)])
+def test_wave_span_work_list_gives_the_same_sums_and_steps(shape, seed):
+    """granule = 64 (SP_COST_WAVE_SPANS: spans belong to single waves, tables padded to multiples of 64, one segment record per
+    chunk) against the oracle's Gauss-Newton system and against the 256-granule batch: same cost, same normal equations and
+    gradients up to fp32 summation order, same scheduled end state inside half the north-star bar; less padding."""
+    from oracle import gn_oracle, photometric_oracle as orc
+    from super_primitive_amd import synth
+    kw = dict(blob_coverage=1.2) if shape == "blobs" else dict(overlap=1)
+    pairs = [synth.make_pair(60, 80, 24, seed=seed + k, shape=shape, init_sigma=0.006, **kw) for k in range(3)]
+    a = make_batch(pairs, levels=(0, 2), tile_points=512, point_stride=(1, 2))
+    b = make_batch(pairs, levels=(0, 2), tile_points=512, point_stride=(1, 2), granule=64)
+    assert b.granule == 64 and b.n_seg_records == b.n_chunks and sum(b.Ppads) < sum(a.Ppads)
+    assert all(int(c) % 64 == 0 for c in npy(b.chunks)[:, 3])
+    got = assemble_gn(b)
+    ref = assemble_gn(a)
+    for m, p in enumerate(pairs):
+        src, trg = orc.frames_from_synth(p)
+        want = gn_oracle.normal_equations(src, trg, torch.from_numpy(p.kld_init), torch.from_numpy(p.pose_init), eps=1e-3)
+        H, bb = want["H"].numpy(), want["b"].numpy()
+        np.testing.assert_allclose(got[m]["cost"], want["cost"], rtol=2e-5)
+        for sl, name in ((np.s_[:6, :6], "H_pp"), (np.s_[:6, 6:], "H_pd"), (np.s_[6:, 6:], "H_dd")):
+            assert np.abs(got[m]["H"][sl] - H[sl]).max() <= 3e-3 * np.abs(H[sl]).max(), name
+            assert np.abs(got[m]["H"][sl] - ref[m]["H"][sl]).max() <= 2e-5 * np.abs(H[sl]).max(), name      # vs the 256-granule sums
+        assert np.abs(got[m]["b"] - bb).max() <= 3e-3 * np.abs(bb).max()
+        assert got[m]["n_valid"] == ref[m]["n_valid"]
+    # gradient mode: one Adam step moves both batches alike
+    np.testing.assert_allclose(npy(b.evaluate(0)), npy(a.evaluate(0)), rtol=2e-6)
+    for x in (a, b):
+        x.adam_step(0)
+    np.testing.assert_allclose(npy(b.pose), npy(a.pose), atol=2e-6)
+    np.testing.assert_allclose(npy(b.kld), npy(a.kld), atol=2e-6)
+    # the scheduled run (device-side phases on the wave-span work lists of both lattices)
+    sch = dict(max_iters_per_level=12, conv_tol=2e-3, polish_max=8, polish_eps=1e-5, polish_tol=1e-4)
+    for x in (a, b):
+        x.restore_initial()
+        x.run_scheduled(**sch)
+    # (the two work lists sum in different orders, so a pair may take one LM iteration more or fewer: the end states agree to the
+    #  schedule's own convergence tolerance, compared with the two-view scale gauge removed)
+    from parity_util import pose_depth_errors
+    for m in range(len(pairs)):
+        e = pose_depth_errors(npy(b.poses()[m]), npy(b.klds()[m]), npy(a.poses()[m]), npy(a.klds()[m]))
+        assert e[0] <= 5e-5 and e[1] <= 5e-5 and e[2] <= 5e-4, (m, e)
+    b.restore_initial()
+    b.run_scheduled(**sch)
+    again = (b.pose.clone(), b.kld.clone())
+    b.restore_initial()
+    b.run_scheduled(**sch)
+    assert torch.equal(again[0], b.pose) and torch.equal(again[1], b.kld)            # deterministic
