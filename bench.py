@@ -56,9 +56,10 @@ def parse(argv=None):
     ap.add_argument("--shape", choices=["grid", "blobs"], default="grid",
                     help="segment masks: the grid tiling of the headline workload, or ragged overlapping ellipses (SAM-like; --coverage)")
     ap.add_argument("--coverage", type=float, default=1.2, help="--shape blobs: total mask area in image areas (rho)")
-    ap.add_argument("--granule", type=int, choices=[256, 64], default=256,
-                    help="padding granule of the point tables: 256 (a span per workgroup), or 64 = wave spans (SP_COST_WAVE_SPANS), for "
-                         "batches of many small ragged segments")
+    ap.add_argument("--granule", type=int, choices=[256, 64], default=64,
+                    help="padding granule of the point tables: 64 = wave spans (SP_COST_WAVE_SPANS: a span per wave; the default since "
+                         "round 3 -- 2.7 %% faster than 256 on the headline workload in an interleaved A/B, 1.4x on 1200 small ragged "
+                         "segments, profiles/r03_kernel_experiments.txt), or 256 (a span per workgroup, rounds 1-2)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
     ap.add_argument("--tile-points", type=int, default=8192, help="longest chunk (piece of one segment)")
     ap.add_argument("--span-points", type=int, default=None, help="points per workgroup (run of consecutive chunks); default: PairBatch's")

@@ -567,7 +567,6 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
     const SpPrepSample& j = jobs[blockIdx.y];
     // padding granule of the table: 256 (a whole 256-point block lies in one segment) or 64 (wave spans: every WAVE's 64 points
     // do; the search then runs per wave)
-    const int unit = j.granule == 64 ? 64 : SP_BLOCK;
     const int lane_off = j.granule == 64 ? (int)(threadIdx.x & ~63u) : 0;
     int n = 0, first = 0, count = 0, next_first = -1;
     float shift = 0.f;
@@ -576,7 +575,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
         if (b0 >= j.P) return;
         const int i0 = __builtin_amdgcn_readfirstlane(b0 + lane_off);        // first point of this wave's / block's unit
         const int i = b0 + (int)threadIdx.x;
-        if (i0 < j.P && (k == 0 || i0 >= next_first || unit == 64)) {
+        if (i0 < j.P && (k == 0 || i0 >= next_first)) {          // (per wave when the granule is 64: every wave tracks its own run)
             n = segment_of(j.seg_off, j.N, i0);
             first = j.seg_off[n];
             count = j.counts[n];

@@ -106,7 +106,8 @@ def test_config2_adam_loop_follows_the_reference_at_size():
     assert e[0] <= 1e-4 and e[1] <= 1e-4 and e[2] <= 1e-3, e
 
 
-def test_bench_schedule_reaches_the_reference_minimiser_at_full_size():
+@pytest.mark.parametrize("granule", [256, 64])
+def test_bench_schedule_reaches_the_reference_minimiser_at_full_size(granule):
     """The schedule frame_pairs_per_sec is quoted on (pair_batch.FRAME_PAIR_SCHEDULE, used verbatim by bench.py), run on
     bench.py's pairs from bench.py's initial values, lands within the bar of the minimiser of the REFERENCE cost at
     640x480x64 (golden g15: the reference's Adam loop converged with decaying learning rates) -- and, for the other
@@ -116,7 +117,8 @@ def test_bench_schedule_reaches_the_reference_minimiser_at_full_size():
     from super_primitive_amd.optim.pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
     g = load_golden("g15_config2_fullsize")
     pairs = [fullsize_pair(g)] + [synth.make_pair(480, 640, 64, seed=1000 + s, overlap=4, init_sigma=0.004) for s in (1, 2, 3)]
-    batch = PairBatch.from_synth(pairs, levels=(0, 3), device="cuda:0", point_stride=FRAME_PAIR_POINT_STRIDE)
+    # (granule 64 = wave spans, bench.py's default work list since round 3; 256 = a span per workgroup)
+    batch = PairBatch.from_synth(pairs, levels=(0, 3), device="cuda:0", point_stride=FRAME_PAIR_POINT_STRIDE, granule=granule)
     sched_kw = {k: v for k, v in FRAME_PAIR_SCHEDULE.items() if k != "check_every"}
 
     def check():

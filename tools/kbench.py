@@ -16,6 +16,10 @@ def main():
     ap.add_argument("--tile-points", type=int, default=2048)
     ap.add_argument("--segments", type=int, default=64)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--granule", type=int, default=256)
+    ap.add_argument("--shape", default="grid")
+    ap.add_argument("--coverage", type=float, default=1.2)
+    ap.add_argument("--ab-granule", action="store_true", help="time mode 1 / mode 0 on a 256-granule and a 64-granule (wave spans) batch, interleaved")
     ap.add_argument("--levels", default="0")
     ap.add_argument("--modes", default="0,1")
     ap.add_argument("--tile-order", default="", help="comma list of t: re-time with the points of every chunk re-ordered into t x t pixel "
@@ -25,6 +29,25 @@ def main():
     batch, _ = bench.build_batch(a, 0, dev)
     for _ in range(3):
         batch.gn_step(0)
+    if a.ab_granule:
+        import copy
+        a2 = copy.copy(a); a2.granule = 64 if a.granule == 256 else 256
+        other, _ = bench.build_batch(a2, 0, dev)
+        for rnd in range(4):
+            for bt in (batch, other):
+                for mode in (1, 0):
+                    for _ in range(3):
+                        bt.cost_pass(0, mode)
+                    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+                    torch.cuda.synchronize()
+                    for e0, e1 in ev:
+                        e0.record(); bt.cost_pass(0, mode); e1.record()
+                    torch.cuda.synchronize()
+                    ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
+                    by = bt.algorithmic_bytes(0)
+                    print(f"level 0 granule {bt.granule:3d} mode {mode} pairs {bt.M} spans {bt.n_spans}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us -> "
+                          f"{by/np.median(ms)/1e6/8000*100:.1f}% of 8 TB/s  (padding {sum(bt.Ppads)/sum(bt.Ps):.4f})", flush=True)
+        return
     orders = [None] + [int(t) for t in a.tile_order.split(",") if t]
     original = (batch.pix.clone(), {l: v.clone() for l, v in batch.src4.items()})
     for order in orders:

@@ -17,7 +17,8 @@ pairs = [base[i % len(base)] for i in range(G)]
 src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in pairs]
 trg, Ks, klds = [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs], [t(p.kld_init) for p in pairs]
 poses = torch.stack([t(p.pose_init) for p in pairs])
-build = lambda tm=None: PairBatch(src, trg, Ks, poses, klds, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, timer=tm)
+GRAN = int(os.environ.get('SP_GRANULE', '256'))
+build = lambda tm=None: PairBatch(src, trg, Ks, poses, klds, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, timer=tm, granule=GRAN)
 build(); build()
 acc = {}
 wall = []
@@ -29,5 +30,5 @@ for _ in range(4):
     for k, v in tm.milliseconds().items():
         acc.setdefault(k, []).append(v)
 nb = b.setup_bytes
-print(f"SP_FILL_VARIANT={os.environ.get('SP_FILL_VARIANT', 'default')}: {G} pairs, set-up {1e3 * np.median(wall):.2f} ms = {1e6 * np.median(wall) / G:.1f} us/pair; "
+print(f"granule {GRAN}: {G} pairs, set-up {1e3 * np.median(wall):.2f} ms = {1e6 * np.median(wall) / G:.1f} us/pair; "
       + "  ".join(f"{k} {np.median(v):.2f} ms ({nb[k] / np.median(v) / 1e6 / 8000:.3f})" for k, v in acc.items()))
