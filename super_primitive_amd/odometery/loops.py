@@ -150,6 +150,51 @@ def track_frame_gn(kf, kld, supp_frame, supp_T, prev_pose, levels, prev_aff=None
     return T, (win.node_affines()[1] if affine else None), list(win.gn_losses().unbind(0)), its
 
 
+class GnTracker:
+    """Frame-to-keyframe tracking by Gauss-Newton with ONE window per keyframe: the keyframe's padded tables, per-level source
+    samples, work list and descriptors are built once (they are a property of the keyframe and its depths -- the reference also
+    prepares ``kf_precomputed`` per level before the loop, ``odometery/odometery.py:365-369``); every tracked frame only replaces
+    the target image's pyramid in place, the two poses and the LM state.  ``track`` = ``track_frame_gn`` (same schedule, same
+    result), at a fraction of the per-frame cost (tools/run_configs.py)."""
+
+    def __init__(self, kf, kld, kf_pose, frame, levels, kf_aff=None, schedule=None):
+        from ..optim.window import KIND_WINDOW, PoseWindow
+        self.sch = dict(TRACK_GN_SCHEDULE, **(schedule or {}))
+        self.affine = kf_aff is not None
+        dev = kf.image.device
+        z2 = torch.zeros(2, device=dev)
+        nodes = [dict(T=kf_pose, kind=KIND_WINDOW, aff=kf_aff if self.affine else None),
+                 dict(T=kf_pose, kind=KIND_WINDOW, lr_pose=1.0, lr_aff=1.0 if self.affine else 0.0, aff=z2 if self.affine else None,
+                      image=frame.image, K=frame.K)]
+        self.phases = [(int(l), int(n)) for l, n in self.sch['phases'] if levels[0] <= int(l) < levels[1]]
+        self.win = PoseWindow([dict(kf=kf, kld=kld, lr=0.0, node=0)], nodes, [(0, 1, 1.0, dense_optim.Z_MIN_SINGLE)], levels, abs_loss=False,
+                              use_affine=self.affine, max_iters=sum(n for _, n in self.phases) + self.sch['polish_max'] + 8)
+        self._first_image = frame.image
+
+    def update_keyframe(self, kld=None, kf_pose=None, kf_aff=None):
+        """After a mapping pass moved the keyframe: new depths / pose / affine pair (the tables do not depend on them)."""
+        if kld is not None:
+            self.win.set_klds([kld])
+        if kf_pose is not None:
+            self.win.set_nodes({0: dict(T=kf_pose, aff=kf_aff)})
+
+    def track(self, frame, supp_T, curr_aff=None):
+        """Returns (supp_T, curr_aff, losses, iterations) like ``track_frame_gn``."""
+        win, sch = self.win, self.sch
+        if frame.image is not self._first_image:
+            win.set_target_image(1, frame.image)
+        self._first_image = None
+        win.set_nodes({1: dict(T=supp_T, aff=curr_aff if self.affine else None)})
+        win.reset_gn()
+        its = 0
+        for level, n in self.phases:
+            its += win.run_gn(level, n, irls_eps=sch['irls_eps'], conv_tol=sch['conv_tol'])
+        if sch['polish_max'] > 0:
+            its += win.run_gn(win.level_ids[0], sch['polish_max'], irls_eps=sch['polish_eps'], conv_tol=sch['polish_tol'])
+        T = renormalise_se3(win.node_poses()[1].contiguous())
+        return T, (win.node_affines()[1] if self.affine else None), list(win.gn_losses().unbind(0)), its
+
+
 def window_connectivity(n_kfs):
     """Neighbouring keyframes only (odometery.py:451-479, mode 'map')."""
     return {s: [t for t in (s - 1, s + 1) if 0 <= t < n_kfs] for s in range(n_kfs)}

@@ -21,7 +21,7 @@ from ..core.depth_render import estimate_depth_kf_native
 from ..lie.lie_algebra import invertSE3
 from .depth_init import segment_based_depth_reinit
 from .kf_criteria import keyframe_criterion
-from .loops import map_window, track_frame_fused, track_frame_gn
+from .loops import GnTracker, map_window, track_frame_fused, track_frame_gn  # noqa: F401
 
 DEFAULTS = dict(track_steps=(0, 0, 300), track_levels=(0, 3), track_lr=5e-3, map_steps=500, map_lr_pose=1e-4, window_size=5,
                 supp_every_n=3, depth_validity_ratio=0.60, translation_thresh=0.2, affine_compensation=True)
@@ -42,6 +42,7 @@ def run_sequence(frames, to_keyframe, pose0, kld0, engine="gn", **cfg):
     all_kf_ids = [0]
     cur_T, cur_aff = pose0.clone(), zero2()
     since_kf, scheduled, n_map = 0, False, 0
+    tracker = None                       # (Gauss-Newton engine: one window per keyframe, re-used for every frame tracked against it)
     secs = dict(track=0.0, keyframe=0.0, mapping=0.0)
     sync = torch.cuda.synchronize
     for i in range(1, len(frames)):
@@ -50,8 +51,9 @@ def run_sequence(frames, to_keyframe, pose0, kld0, engine="gn", **cfg):
         init_T = cur_T if len(track) < 2 else (cur_T @ invertSE3(track[-2])) @ cur_T
         sync(); t0 = time.perf_counter()
         if engine == "gn":
-            cur_T, aff, _, _ = track_frame_gn(kfs[-1], kf_klds[-1], f, init_T, kf_poses[-1], c['track_levels'],
-                                              prev_aff=kf_affs[-1] if affine else None, curr_aff=cur_aff if affine else None)
+            if tracker is None:
+                tracker = GnTracker(kfs[-1], kf_klds[-1], kf_poses[-1], f, c['track_levels'], kf_aff=kf_affs[-1] if affine else None)
+            cur_T, aff, _, _ = tracker.track(f, init_T, cur_aff if affine else None)
         else:
             cur_T, aff, _ = track_frame_fused(kfs[-1], kf_klds[-1], f, init_T, kf_poses[-1], list(c['track_steps']), c['track_levels'],
                                               lr=c['track_lr'], prev_aff=kf_affs[-1] if affine else None, curr_aff=cur_aff if affine else None)
@@ -75,6 +77,8 @@ def run_sequence(frames, to_keyframe, pose0, kld0, engine="gn", **cfg):
             supp = [[(fr, out['supp_poses'][k][j].clone(), (out['supp_affs'][k][j].clone() if affine else a)) for j, (fr, _, a) in enumerate(row)]
                     for k, row in enumerate(supp)]
             scheduled, n_map = False, n_map + 1
+            if tracker is not None:          # the latest keyframe moved
+                tracker.update_keyframe(kf_klds[-1], kf_poses[-1], kf_affs[-1] if affine else None)
             if log is not None:
                 log.append((i, 'mapping', dict(kf_ids=list(kf_ids), klds=[k.clone() for k in kf_klds], kf_poses=[p.clone() for p in kf_poses],
                                                losses=[float(out['losses'][0]), float(out['losses'][-1])], n=len(out['losses']))))
@@ -92,6 +96,6 @@ def run_sequence(frames, to_keyframe, pose0, kld0, engine="gn", **cfg):
                 for lst in (kfs, kf_ids, kf_poses, kf_klds, kf_affs, supp):
                     lst.pop(0)
             all_kf_ids.append(i)
-            since_kf, scheduled = 0, True
+            since_kf, scheduled, tracker = 0, True, None
         sync(); secs['keyframe'] += time.perf_counter() - t0
     return dict(track_poses=torch.stack(track), kf_ids=kf_ids, all_kf_ids=all_kf_ids, kf_poses=torch.stack(kf_poses), kf_klds=kf_klds, n_mappings=n_map, seconds=secs)

@@ -178,6 +178,36 @@ class PoseWindow:
                                            self.rel_tol, _lib.ptr(self.state), _lib.ptr(self.loss_hist), self.max_iters,
                                            _lib.stream_ptr()), "sp_window_step")
 
+    # ---- re-use of a built window for new data (same graph, same source keyframes) --------------------------------------
+    def set_target_image(self, node, image):
+        """Replace the image of target node ``node`` IN PLACE (same size, same intrinsics): its pyramid levels are rebuilt and
+        packed into the buffers the edge descriptors already point to -- a tracker keeps ONE window per keyframe and feeds it the
+        frames (the source tables, samples, work list and descriptors are a per-keyframe cost, not a per-frame one)."""
+        lv = _level_images(image[:3].float().to(self.device), max(self.level_ids))
+        for l in self.level_ids:
+            Hl, Wl = lv[l].shape[-2:]
+            assert (Hl, Wl) == self.level_hw[(node, l)], "set_target_image: the frame size changed; build a new window"
+            _lib.check(self.lib.sp_pack_rgb(_lib.ptr(lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(self.trg3[(node, l)]), _lib.stream_ptr()), "sp_pack_rgb")
+
+    def set_nodes(self, updates):
+        """updates: {node index: dict(T=(4,4) [, aff=(2,)])}: overwrite poses / affine pairs (tangents and Adam moments cleared), then
+        re-compose every edge's relative pose.  One small upload."""
+        arr = self._node_array()
+        for i, u in updates.items():
+            nd = arr[i]
+            nd.T = (ctypes.c_float * 16)(*u['T'].detach().float().cpu().numpy().reshape(16))
+            if u.get('aff') is not None:
+                nd.aff = (ctypes.c_float * 2)(*u['aff'].detach().float().cpu().numpy().reshape(2))
+            nd.a = (ctypes.c_float * 6)(); nd.m = (ctypes.c_float * 6)(); nd.v = (ctypes.c_float * 6)()
+            nd.aff_m = (ctypes.c_float * 2)(); nd.aff_v = (ctypes.c_float * 2)()
+        self.nodes.copy_(_upload_struct_array(arr, self.device))
+        self.compose()
+
+    def set_klds(self, klds):
+        """Overwrite the log-depth blocks (one (N_k,) tensor per source keyframe); Adam moments cleared."""
+        self.kld.copy_(torch.cat([k.detach().float().to(self.device).reshape(-1) for k in klds]))
+        self.kld_m.zero_(); self.kld_v.zero_()
+
     # ---- Gauss-Newton / LM (sp_window_gn_step) ---------------------------------------------------------------------
     def _gn_state(self):
         if self._gn is None:
@@ -191,7 +221,9 @@ class PoseWindow:
                 scratch=torch.zeros(self.lib.sp_window_gn_scratch_doubles(self.n_edges, sum_N, self.max_N), dtype=torch.float64, device=self.device),
                 nodes_backup=torch.zeros_like(self.nodes), kld_backup=torch.zeros(sum_N, dtype=torch.float32, device=self.device),
                 state=torch.zeros(16, dtype=torch.float32, device=self.device),
-                losses=torch.zeros(self.max_iters, dtype=torch.float32, device=self.device), sum_N=sum_N, n_y=n_y)
+                losses=torch.zeros(self.max_iters, dtype=torch.float32, device=self.device), sum_N=sum_N, n_y=n_y,
+                phase_keep=torch.tensor([1, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1], dtype=torch.float32, device=self.device),
+                phase_set=torch.tensor([0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], dtype=torch.float32, device=self.device))
             self.reset_gn()
         return self._gn
 
@@ -205,10 +237,8 @@ class PoseWindow:
     def begin_gn_phase(self):
         """A new phase of a schedule (another pyramid level / IRLS epsilon): losses of different phases are not comparable, so
         the accept test and the convergence test start afresh; lambda and the iteration count carry over."""
-        st = self._gn_state()['state']
-        st[1] = -1.0
-        st[4] = 0.0
-        st[6] = 0.0
+        gn = self._gn_state()
+        gn['state'].mul_(gn['phase_keep']).add_(gn['phase_set'])          # [1] = -1, [4] = [6] = 0 in two launches, no host value involved
 
     def gn_step(self, level, irls_eps=1e-3, pose_only=False, conv_tol=0.0, lm_up=8.0, lm_down=0.5, lm_min=1e-7):
         """One Gauss-Newton / LM iteration of the whole window at pyramid ``level`` (3 launches, nothing returns to the host):

@@ -15,7 +15,7 @@ from super_primitive_amd import synth
 from super_primitive_amd.core import dense_optim
 from super_primitive_amd.image.keyframe import KeyFrame, keyframe_pyramid
 from super_primitive_amd.odometery.two_frame_sfm import SfM
-from super_primitive_amd.odometery.loops import track_frame, track_frame_fused, track_frame_gn, map_window
+from super_primitive_amd.odometery.loops import GnTracker, track_frame, track_frame_fused, track_frame_gn, map_window
 from super_primitive_amd.odometery.depth_init import segment_based_depth_reinit
 from super_primitive_amd.depth_completion.segment_based_completion import average_visible_segments
 from super_primitive_amd.lie.lie_algebra import invertSE3
@@ -81,6 +81,15 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
 est = invertSE3(supp_T).cpu().numpy()
 print(f"config 3  tracking, Gauss-Newton window optimiser incl. table / pyramid set-up per frame: {dt*1e3:.1f} ms/frame ({1/dt:.0f} frames/s), {its} LM iterations, "
       f"loss {float(losses[0]):.4f} -> {float(losses[-1]):.4f}, rot err {rot_err(est, p.pose_gt):.2e} rad, t err {np.abs(est[:3,3]-p.pose_gt[:3,3]).max():.2e}")
+trk = GnTracker(src, t(p.kld_gt), torch.eye(4, device=dev), trg, levels, kf_aff=torch.zeros(2, device=dev))
+trk.track(trg, supp_T0, torch.zeros(2, device=dev))
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(20):
+    supp_T, _, losses, its = trk.track(trg, supp_T0, torch.zeros(2, device=dev))
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+est = invertSE3(supp_T).cpu().numpy()
+print(f"config 3  tracking, Gauss-Newton with ONE window per keyframe (GnTracker: per frame only the target pyramid, the poses and the LM state): {dt*1e3:.2f} ms/frame "
+      f"({1/dt:.0f} frames/s), {its} LM iterations, rot err {rot_err(est, p.pose_gt):.2e} rad, t err {np.abs(est[:3,3]-p.pose_gt[:3,3]).max():.2e}")
 # the same frame-to-keyframe problem for a whole batch of frames on device (pose + affine, depths fixed)
 B = 64
 pb = PairBatch([src] * 1, [t(p.trg_image)], [t(p.K)], t(p.pose_init)[None].repeat(B, 1, 1), [t(p.kld_gt)], levels=levels, use_affine=True,
