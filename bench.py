@@ -399,7 +399,7 @@ def main(argv=None):
                    "texture": (f"single-octave band, shortest period {pairs[0].meta['texture_period_px']:g} px; initial pose Exp(0.004 xi) T_gt (+0.002 per copy)"
                                if pairs else None),
                    "tile_points": args.tile_points, "span_points": batch.span_points, "granule": args.granule,
-                   "padded_points_per_real_point": float(sum(batch.Ppads)) / float(sum(batch.Ps)), "sharding": f"{world} x independent pair batches, final all_gather only"},
+                   "padded_points_per_real_point": (float(sum(batch.Ppads)) / float(sum(batch.Ps)) if hasattr(batch, "Ppads") else None), "sharding": f"{world} x independent pair batches, final all_gather only"},
         "roofline": {"bound": "hbm", "kernel": f"k_cost_pairs<{mode_id}>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
