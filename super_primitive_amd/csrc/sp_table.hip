@@ -257,6 +257,56 @@ __global__ __launch_bounds__(SP_BLOCK) void k_blur_decimate(const float* __restr
 // the job record.  A pipeline that optimises hundreds of new frame pairs per batch is otherwise bound by the ~15 tiny
 // launches per pair above, not by the optimiser.
 // ---------------------------------------------------------------------------------------------------------------------
+// Device views of the job records (include/sp_hip.h): the same bytes, the pointers typed as global memory.  A pointer read out
+// of a record is otherwise a generic pointer to the compiler -- flat_load / flat_store, 64-bit address arithmetic in vector
+// registers for every access, vmcnt and lgkmcnt both held -- and every access of these passes goes through one.
+#define SP_GLOBAL __attribute__((address_space(1)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ T* generic(SP_GLOBAL T* p) { return (T*)p; }      // for the helpers shared with the per-keyframe kernels
+__device__ __forceinline__ uint4 load4(const SP_GLOBAL u32x4* p) { const u32x4 v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 load4(const SP_GLOBAL f32x4* p) { const f32x4 v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void store4(SP_GLOBAL f32x4* p, const float4& v) { const f32x4 w = {v.x, v.y, v.z, v.w}; *p = w; }
+
+struct PrepTable {
+    const SP_GLOBAL uint8_t* masks;
+    const SP_GLOBAL float* logdepth;
+    const SP_GLOBAL float* keypoints;
+    SP_GLOBAL float* kp_L;
+    SP_GLOBAL int32_t* row_counts[SP_PREP_MAX_STRIDES];
+    SP_GLOBAL int32_t* counts[SP_PREP_MAX_STRIDES];
+    const SP_GLOBAL int32_t* seg_off[SP_PREP_MAX_STRIDES];
+    SP_GLOBAL uint32_t* pix[SP_PREP_MAX_STRIDES];
+    SP_GLOBAL float* baseL[SP_PREP_MAX_STRIDES];
+    int32_t stride[SP_PREP_MAX_STRIDES];
+    int32_t N, H, W, n_strides;
+    SP_GLOBAL uint32_t* bits;
+};
+struct PrepSample {
+    SP_GLOBAL uint32_t* pix;
+    const SP_GLOBAL float* baseL;
+    const SP_GLOBAL int32_t* seg_off;
+    const SP_GLOBAL int32_t* counts;
+    const SP_GLOBAL float* kp_L;
+    const SP_GLOBAL float* kld;
+    const SP_GLOBAL float* K;
+    const SP_GLOBAL float* image[SP_PREP_MAX_LEVELS];
+    SP_GLOBAL float* src4[SP_PREP_MAX_LEVELS];
+    int32_t Hl[SP_PREP_MAX_LEVELS], Wl[SP_PREP_MAX_LEVELS];
+    int32_t N, P, H, W, n_levels;
+    int32_t granule;
+};
+struct PrepImage {
+    const SP_GLOBAL float* in;
+    SP_GLOBAL float* out;
+    int32_t H, W;
+};
+static_assert(sizeof(PrepTable) == sizeof(SpPrepTable) && sizeof(PrepSample) == sizeof(SpPrepSample) && sizeof(PrepImage) == sizeof(SpPrepImage),
+              "device views of the job records");
+static_assert(offsetof(PrepTable, bits) == offsetof(SpPrepTable, bits) && offsetof(PrepTable, stride) == offsetof(SpPrepTable, stride)
+              && offsetof(PrepSample, granule) == offsetof(SpPrepSample, granule) && offsetof(PrepSample, src4) == offsetof(SpPrepSample, src4), "device views of the job records");
+__device__ __forceinline__ const PrepTable& table_of(const SpPrepTable* tables, int i) { return reinterpret_cast<const PrepTable*>(tables)[i]; }
+
 // bit 7 of every byte of w that is non-zero
 __device__ __forceinline__ uint32_t nonzero_bytes(uint32_t w) { return ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u); }
 
@@ -292,7 +342,7 @@ __device__ __forceinline__ uint32_t lattice_piece(int stride) {
 #define SP_PREP_ROWS 4
 #define SP_PREP_TRIPS 4
 // does this keyframe take the fast path of the count pass (and, if it has a bits array, of the fill pass)?
-__device__ __forceinline__ bool prep_fast_path(const SpPrepTable& t) {
+__device__ __forceinline__ bool prep_fast_path(const PrepTable& t) {
     bool fixed = true;
 #pragma unroll
     for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
@@ -303,60 +353,66 @@ __device__ __forceinline__ bool prep_fast_path(const SpPrepTable& t) {
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable* __restrict__ tables) {
-    const SpPrepTable& t = tables[blockIdx.y];
+    const PrepTable& t = table_of(tables, blockIdx.y);
+    if (!prep_fast_path(t)) return;          // (k_prep_row_counts_general takes those keyframes)
     const int rows = t.N * t.H;
     const int lane = threadIdx.x & 63;
-    if (prep_fast_path(t)) {
-        const int row_base = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * (SP_PREP_ROWS * SP_PREP_TRIPS);
-        if (row_base >= rows) return;
-        uint32_t sel[SP_PREP_MAX_STRIDES];
+    const int row_base = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * (SP_PREP_ROWS * SP_PREP_TRIPS);
+    if (row_base >= rows) return;
+    uint32_t sel[SP_PREP_MAX_STRIDES];
 #pragma unroll
-        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) sel[k] = k < t.n_strides ? lattice_piece(t.stride[k]) : 0u;
-        const int qpr = t.W >> 4;
-        const uint4* mq = reinterpret_cast<const uint4*>(t.masks) + (size_t)row_base * qpr;
-        uint32_t* bits = t.bits ? t.bits + (size_t)row_base * qpr : nullptr;
-        const bool mine = lane < qpr;
-        uint4 w[2][SP_PREP_ROWS];
+    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) sel[k] = k < t.n_strides ? lattice_piece(t.stride[k]) : 0u;
+    const int qpr = t.W >> 4;
+    const SP_GLOBAL u32x4* mq = (const SP_GLOBAL u32x4*)t.masks + (size_t)row_base * qpr;
+    SP_GLOBAL uint32_t* bits = t.bits ? t.bits + (size_t)row_base * qpr : nullptr;
+    const bool mine = lane < qpr;
+    uint4 w[2][SP_PREP_ROWS];
 #pragma unroll
-        for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
-            w[0][rr] = (row_base + rr < rows && mine) ? mq[(size_t)rr * qpr + lane] : make_uint4(0u, 0u, 0u, 0u);
+    for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
+        w[0][rr] = (row_base + rr < rows && mine) ? load4(mq + (size_t)rr * qpr + lane) : make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-        for (int tr = 0; tr < SP_PREP_TRIPS; ++tr) {
-            const int row0 = row_base + tr * SP_PREP_ROWS;
-            if (tr + 1 < SP_PREP_TRIPS) {
-#pragma unroll
-                for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
-                    const int r = row0 + SP_PREP_ROWS + rr;
-                    w[(tr + 1) & 1][rr] = (r < rows && mine) ? mq[(size_t)(r - row_base) * qpr + lane] : make_uint4(0u, 0u, 0u, 0u);
-                }
-            }
-            float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
+    for (int tr = 0; tr < SP_PREP_TRIPS; ++tr) {
+        const int row0 = row_base + tr * SP_PREP_ROWS;
+        if (tr + 1 < SP_PREP_TRIPS) {
 #pragma unroll
             for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
-                const uint4 v = w[tr & 1][rr];
-                const uint32_t m = piece_bits(nonzero_bytes(v.x), nonzero_bytes(v.y), nonzero_bytes(v.z), nonzero_bytes(v.w));
-                if (bits && mine && row0 + rr < rows) bits[(size_t)(row0 + rr - row_base) * qpr + lane] = m;
-#pragma unroll
-                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) acc[rr * SP_PREP_MAX_STRIDES + k] = (float)__popc(m & sel[k]);
+                const int r = row0 + SP_PREP_ROWS + rr;
+                w[(tr + 1) & 1][rr] = (r < rows && mine) ? load4(mq + (size_t)(r - row_base) * qpr + lane) : make_uint4(0u, 0u, 0u, 0u);
             }
-            int pos;
-            bool ok;
-            wave_sum_to_lanes<SP_PREP_ROWS * SP_PREP_MAX_STRIDES>(acc, lane, pos, ok);
-            const int rr = pos / SP_PREP_MAX_STRIDES, k = pos % SP_PREP_MAX_STRIDES, row = row0 + rr;
-            if (ok && k < t.n_strides && row < rows) t.row_counts[k][row] = ((row % t.H) % t.stride[k] == 0) ? (int)acc[0] : 0;
         }
-        return;
+        float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
+#pragma unroll
+        for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
+            const uint4 v = w[tr & 1][rr];
+            const uint32_t m = piece_bits(nonzero_bytes(v.x), nonzero_bytes(v.y), nonzero_bytes(v.z), nonzero_bytes(v.w));
+            if (bits && mine && row0 + rr < rows) bits[(size_t)(row0 + rr - row_base) * qpr + lane] = m;
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) acc[rr * SP_PREP_MAX_STRIDES + k] = (float)__popc(m & sel[k]);
+        }
+        int pos;
+        bool ok;
+        wave_sum_to_lanes<SP_PREP_ROWS * SP_PREP_MAX_STRIDES>(acc, lane, pos, ok);
+        const int rr = pos / SP_PREP_MAX_STRIDES, k = pos % SP_PREP_MAX_STRIDES, row = row0 + rr;
+        if (ok && k < t.n_strides && row < rows) t.row_counts[k][row] = ((row % t.H) % t.stride[k] == 0) ? (int)acc[0] : 0;
     }
-    // general path (any width, alignment and stride): the same rows, SP_PREP_ROWS at a time, word or byte loads
+}
+
+// General path (any width, alignment and stride): SP_PREP_ROWS rows at a time, word or byte loads.  Its own kernel -- the two
+// paths in one cost the fast one its occupancy (138 vector registers against 56) -- on a bounded grid per keyframe whose waves
+// walk the rows, so that the launch costs nothing when every keyframe is on the fast path.
+#define SP_PREP_GENERAL_BLOCKS 64
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts_general(const SpPrepTable* __restrict__ tables) {
+    const PrepTable& t = table_of(tables, blockIdx.y);
+    if (prep_fast_path(t)) return;
+    const int rows = t.N * t.H;
+    const int lane = threadIdx.x & 63;
     const int wpr = t.W >> 2;
-    for (int tr = 0; tr < SP_PREP_TRIPS; ++tr) {
-        const int row0 = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * (SP_PREP_ROWS * SP_PREP_TRIPS) + tr * SP_PREP_ROWS;
-        if (row0 >= rows) return;
+    for (int row0 = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * SP_PREP_ROWS; row0 < rows; row0 += gridDim.x * SP_WAVES * SP_PREP_ROWS) {
         float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
 #pragma unroll
         for (int i = 0; i < SP_PREP_ROWS * SP_PREP_MAX_STRIDES; ++i) acc[i] = 0.f;
         if ((t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0 && wpr <= 256) {
-            const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks) + (size_t)row0 * wpr;
+            const SP_GLOBAL uint32_t* mw = (const SP_GLOBAL uint32_t*)t.masks + (size_t)row0 * wpr;
             uint32_t w[SP_PREP_ROWS][4];
 #pragma unroll
             for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
@@ -378,7 +434,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
 #pragma unroll
             for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
                 if (row0 + rr >= rows) break;
-                const uint8_t* m = t.masks + (size_t)(row0 + rr) * t.W;
+                const SP_GLOBAL uint8_t* m = t.masks + (size_t)(row0 + rr) * t.W;
                 for (int x = lane; x < t.W; x += 64) {
                     const bool on = m[x] != 0;
 #pragma unroll
@@ -396,55 +452,58 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* __restrict__ tables) {
-    const SpPrepTable& t = tables[blockIdx.y];
+    const PrepTable& t = table_of(tables, blockIdx.y);
     if ((int)blockIdx.x >= t.N) return;
     const int k = blockIdx.z;
     if (k >= t.n_strides) return;
-    segment_row_scan(t.row_counts[k] + (size_t)blockIdx.x * t.H, t.H, t.counts[k] + blockIdx.x);
+    segment_row_scan(generic(t.row_counts[k] + (size_t)blockIdx.x * t.H), t.H, generic(t.counts[k] + blockIdx.x));
 }
 
-// Ordered compaction of (segment,row) rows into every lattice's table.  A workgroup takes SP_FILL_ROWS consecutive rows, one thread per
-// row decides from the row counts alone which of them are non-empty (a segment covers a small part of the image: ~85 % of its mask
-// rows are empty and are not read again) and the four waves share those.  Word path: a lane owns 4 consecutive pixels; its
-// rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken from three ballots of the
-// count's bits.
-template <int SP_FILL_ROWS, bool BYVAL>
-__device__ __forceinline__ void prep_fill_body(const SpPrepTable& t);
-
-template <int SP_FILL_ROWS, bool BYVAL>
+// Ordered compaction of (segment,row) rows into every lattice's table.  A workgroup takes SP_FILL_ROWS consecutive rows; one thread
+// per row decides from the row counts alone whether its row is empty (a segment covers a small part of the image: ~85 % of its
+// mask rows are empty and are not read again) and, if not, fetches where the row's points start in every lattice's table: those
+// loads are in flight together, once per workgroup, and the row loop takes row and starts from LDS (fetched inside the loop they
+// were a dependent global load per row and wave).  The four waves share the non-empty rows.  Word path: a lane owns 4
+// consecutive pixels; its rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken from
+// three ballots of the count's bits.  (Gathering a row's points in LDS and storing them by consecutive lanes -- full
+// lines per store instead of 4-byte stores 4 to 16 bytes apart -- was slower: 1.86 ms against 1.36 ms for 384 keyframes.)
+#define SP_FILL_ROWS 256
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __restrict__ tables) {
-    if (BYVAL) {
-        const SpPrepTable t = tables[blockIdx.y];
-        prep_fill_body<SP_FILL_ROWS, BYVAL>(t);
-    } else {
-        prep_fill_body<SP_FILL_ROWS, BYVAL>(tables[blockIdx.y]);
-    }
-}
-
-template <int SP_FILL_ROWS, bool BYVAL>
-__device__ __forceinline__ void prep_fill_body(const SpPrepTable& t) {
+    const PrepTable& t = table_of(tables, blockIdx.y);
     const int rows = t.N * t.H;
     const int row_base = blockIdx.x * SP_FILL_ROWS;
     if (row_base >= rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ int s_rows[SP_FILL_ROWS];
+    __shared__ int s_rows[SP_FILL_ROWS];                             // row id << 16 | row of the image
+    __shared__ int s_r[SP_FILL_ROWS];
+    __shared__ int s_base[SP_PREP_MAX_STRIDES][SP_FILL_ROWS];       // first table position of the row per lattice, -1: not on the lattice
     __shared__ int s_cnt[SP_WAVES];
     const unsigned long long below = (1ull << lane) - 1ull;
     {   // one thread per row: is it empty?  then a block-wide ordered compaction of the non-empty ones
         const int row = row_base + (int)threadIdx.x;
         bool todo = row < rows && (int)threadIdx.x < SP_FILL_ROWS;
+        const int n = todo ? row / t.H : 0, r = row - n * t.H;
         if (todo && t.stride[0] == 1) {      // lattice 0 holds every mask pixel: its row count says whether the row is empty
-            const int n = row / t.H, r = row - n * t.H;
-            const int32_t* rc = t.row_counts[0];
+            const SP_GLOBAL int32_t* rc = t.row_counts[0];
             const int next = (r + 1 < t.H) ? rc[row + 1] : t.counts[0][n];
             todo = next != rc[row];
         }
+        int b[SP_PREP_MAX_STRIDES];
+#pragma unroll
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+            b[k] = (todo && k < t.n_strides && r % t.stride[k] == 0) ? t.seg_off[k][n] + t.row_counts[k][row] : -1;
         const unsigned long long bal = __ballot(todo);
         if (lane == 0) s_cnt[wave] = __popcll(bal);
         __syncthreads();
         int off = 0;
         for (int w = 0; w < wave; ++w) off += s_cnt[w];
-        if (todo) s_rows[off + __popcll(bal & below)] = row;
+        if (todo) {
+            const int slot = off + __popcll(bal & below);
+            s_rows[slot] = row;
+            s_r[slot] = r;
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_base[k][slot] = b[k];
+        }
         __syncthreads();
     }
     const int s_n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
@@ -453,16 +512,11 @@ __device__ __forceinline__ void prep_fill_body(const SpPrepTable& t) {
     // One row's compaction into every lattice's table.  A lane owns the 4-pixel groups xw = q * 64 + lane (q < 4: rows of up to
     // 1024 pixels); nz[q] = nonzero_bytes() form of its mask bits, Lv[q] = the 4 log-depths of the group.
     int base[SP_PREP_MAX_STRIDES];
-    bool act[SP_PREP_MAX_STRIDES];
     int r = 0;
-    auto row_begin = [&](int row_id) {
-        const int n = row_id / t.H;
-        r = row_id - n * t.H;
+    auto row_begin = [&](int slot) {
+        r = __builtin_amdgcn_readfirstlane(s_r[slot]);
 #pragma unroll
-        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-            act[k] = k < t.n_strides && r % t.stride[k] == 0;
-            base[k] = act[k] ? t.seg_off[k][n] + t.row_counts[k][row_id] : 0;
-        }
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) base[k] = __builtin_amdgcn_readfirstlane(s_base[k][slot]);
     };
     // the groups w0 + q * 64 + lane (q < 4) of the row begun with row_begin(), left to right
     auto emit_groups = [&](int w0, const uint32_t (&nz)[4], const float4 (&Lv)[4]) {
@@ -473,7 +527,7 @@ __device__ __forceinline__ void prep_fill_body(const SpPrepTable& t) {
             const float Lq[4] = {Lv[q].x, Lv[q].y, Lv[q].z, Lv[q].w};
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-                if (!act[k]) continue;
+                if (base[k] < 0) continue;
                 const uint32_t sel = nz[q] & lattice_bytes(4 * xw, t.stride[k]);
                 const int cnt = __popc(sel);
                 const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
@@ -494,30 +548,30 @@ __device__ __forceinline__ void prep_fill_body(const SpPrepTable& t) {
         // is compacted (a row is two dependent loads -- bits, then the log-depths of its set pixels -- and a chain of ballots:
         // processed one after the other, the waves sat in memory latency and the pass ran at 0.14 of the HBM roofline).
         const int qpr = t.W >> 4, wpr = t.W >> 2;
-        auto load_bits = [&](int row_id, uint32_t (&nz)[4]) {
-            const uint32_t* bw = t.bits + (size_t)row_id * qpr;
+        auto load_bits = [&](int slot, uint32_t (&nz)[4]) {
+            const SP_GLOBAL uint32_t* bw = t.bits + (size_t)__builtin_amdgcn_readfirstlane(s_rows[slot]) * qpr;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int xw = q * 64 + lane;
                 nz[q] = xw < wpr ? (((bw[xw >> 2] >> (xw & 3)) & 0x01010101u) << 7) : 0u;
             }
         };
-        auto load_L = [&](int row_id, const uint32_t (&nz)[4], float4 (&Lv)[4]) {
-            const float* L = t.logdepth + (size_t)row_id * t.W;
+        auto load_L = [&](int slot, const uint32_t (&nz)[4], float4 (&Lv)[4]) {
+            const SP_GLOBAL float* L = t.logdepth + (size_t)__builtin_amdgcn_readfirstlane(s_rows[slot]) * t.W;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                Lv[q] = nz[q] ? *reinterpret_cast<const float4*>(L + 4 * (q * 64 + lane)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                Lv[q] = nz[q] ? load4((const SP_GLOBAL f32x4*)(L + 4 * (q * 64 + lane))) : make_float4(0.f, 0.f, 0.f, 0.f);
         };
         uint32_t nz0[4] = {0u, 0u, 0u, 0u}, nz1[4] = {0u, 0u, 0u, 0u}, nz2[4] = {0u, 0u, 0u, 0u};
         float4 L0[4], L1[4];
         int i = wave;
-        if (i < s_n) load_bits(s_rows[i], nz0);
-        if (i + SP_WAVES < s_n) load_bits(s_rows[i + SP_WAVES], nz1);
-        if (i < s_n) load_L(s_rows[i], nz0, L0);
+        if (i < s_n) load_bits(i, nz0);
+        if (i + SP_WAVES < s_n) load_bits(i + SP_WAVES, nz1);
+        if (i < s_n) load_L(i, nz0, L0);
         for (; i < s_n; i += SP_WAVES) {
-            if (i + 2 * SP_WAVES < s_n) load_bits(s_rows[i + 2 * SP_WAVES], nz2);
-            if (i + SP_WAVES < s_n) load_L(s_rows[i + SP_WAVES], nz1, L1);
-            row_begin(s_rows[i]);
+            if (i + 2 * SP_WAVES < s_n) load_bits(i + 2 * SP_WAVES, nz2);
+            if (i + SP_WAVES < s_n) load_L(i + SP_WAVES, nz1, L1);
+            row_begin(i);
             emit_groups(0, nz0, L0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { nz0[q] = nz1[q]; L0[q] = L1[q]; nz1[q] = nz2[q]; }
@@ -529,12 +583,14 @@ __device__ __forceinline__ void prep_fill_body(const SpPrepTable& t) {
         if (!words) {
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
-                if (k < t.n_strides) fill_row(t.masks, t.logdepth, row_id, t.H, t.W, t.stride[k], t.seg_off[k], t.row_counts[k], t.pix[k], t.baseL[k]);
+                if (k < t.n_strides)
+                    fill_row(generic(t.masks), generic(t.logdepth), row_id, t.H, t.W, t.stride[k], generic(t.seg_off[k]), generic(t.row_counts[k]),
+                             generic(t.pix[k]), generic(t.baseL[k]));
             continue;
         }
-        const uint32_t* mw = reinterpret_cast<const uint32_t*>(t.masks + (size_t)row_id * t.W);
-        const float* L = t.logdepth + (size_t)row_id * t.W;
-        row_begin(row_id);
+        const SP_GLOBAL uint32_t* mw = (const SP_GLOBAL uint32_t*)(t.masks + (size_t)row_id * t.W);
+        const SP_GLOBAL float* L = t.logdepth + (size_t)row_id * t.W;
+        row_begin(i);
         for (int w0 = 0; w0 < (t.W >> 2); w0 += 256) {       // (4 x 64 groups at a time)
             uint32_t nz[4];
             float4 Lv[4];
@@ -553,9 +609,9 @@ __device__ __forceinline__ void prep_fill_body(const SpPrepTable& t) {
 }
 
 __global__ void k_prep_keypoint_L(const SpPrepTable* __restrict__ tables) {
-    const SpPrepTable& t = tables[blockIdx.y];
+    const PrepTable& t = table_of(tables, blockIdx.y);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < t.N && t.kp_L) keypoint_L(t.logdepth, t.keypoints, n, t.H, t.W, t.kp_L);
+    if (n < t.N && t.kp_L) keypoint_L(generic(t.logdepth), generic(t.keypoints), n, t.H, t.W, generic(t.kp_L));
 }
 
 // every pyramid level of one table in one pass: segment search, depth and validity once per point.  Padding positions of a
@@ -564,7 +620,7 @@ __global__ void k_prep_keypoint_L(const SpPrepTable* __restrict__ tables) {
 // block leaves the current segment's padded run.
 #define SP_SAMPLE_BLOCKS 4
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs) {
-    const SpPrepSample& j = jobs[blockIdx.y];
+    const PrepSample& j = reinterpret_cast<const PrepSample*>(jobs)[blockIdx.y];
     // padding granule of the table: 256 (a whole 256-point block lies in one segment) or 64 (wave spans: every WAVE's 64 points
     // do; the search then runs per wave)
     const int lane_off = j.granule == 64 ? (int)(threadIdx.x & ~63u) : 0;
@@ -576,7 +632,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
         const int i0 = __builtin_amdgcn_readfirstlane(b0 + lane_off);        // first point of this wave's / block's unit
         const int i = b0 + (int)threadIdx.x;
         if (i0 < j.P && (k == 0 || i0 >= next_first)) {          // (per wave when the granule is 64: every wave tracks its own run)
-            n = segment_of(j.seg_off, j.N, i0);
+            n = segment_of(generic(j.seg_off), j.N, i0);
             first = j.seg_off[n];
             count = j.counts[n];
             shift = j.kld[n] - j.kp_L[n];
@@ -586,27 +642,27 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
         if (i >= j.P) continue;
         if (i - first >= count) {
             j.pix[i] = 0u;
-            for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int l = 0; l < j.n_levels; ++l) store4((SP_GLOBAL f32x4*)j.src4[l] + i, make_float4(0.f, 0.f, 0.f, 0.f));
             continue;
         }
-        const SourceGeom g = source_geometry(j.pix[i], j.baseL[i], shift, j.H, j.W, j.K);
-        for (int l = 0; l < j.n_levels; ++l) reinterpret_cast<float4*>(j.src4[l])[i] = source_sample(g, j.image[l], j.Hl[l], j.Wl[l]);
+        const SourceGeom g = source_geometry(j.pix[i], j.baseL[i], shift, j.H, j.W, generic(j.K));
+        for (int l = 0; l < j.n_levels; ++l) store4((SP_GLOBAL f32x4*)j.src4[l] + i, source_sample(g, generic(j.image[l]), j.Hl[l], j.Wl[l]));
         j.pix[i] = g.pw | (g.ok ? 0x80000000u : 0u);
     }
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_blur(const SpPrepImage* __restrict__ jobs) {
-    const SpPrepImage& j = jobs[blockIdx.z];
+    const PrepImage& j = reinterpret_cast<const PrepImage*>(jobs)[blockIdx.z];
     const int Ho = (j.H + 1) / 2, Wo = (j.W + 1) / 2;
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
     if (i >= Ho * Wo) return;
-    j.out[(size_t)blockIdx.y * Ho * Wo + i] = blur_decimate_at(j.in + (size_t)blockIdx.y * j.H * j.W, j.H, j.W, Wo, i);
+    j.out[(size_t)blockIdx.y * Ho * Wo + i] = blur_decimate_at(generic(j.in + (size_t)blockIdx.y * j.H * j.W), j.H, j.W, Wo, i);
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_pack(const SpPrepImage* __restrict__ jobs) {
-    const SpPrepImage& j = jobs[blockIdx.y];
+    const PrepImage& j = reinterpret_cast<const PrepImage*>(jobs)[blockIdx.y];
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
-    if (i < j.H * j.W) pack_texel(j.in, j.H * j.W, i, j.out);
+    if (i < j.H * j.W) pack_texel(generic(j.in), j.H * j.W, i, generic(j.out));
 }
 
 }  // namespace
@@ -684,6 +740,9 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
     const int per_block = SP_WAVES * SP_PREP_ROWS * SP_PREP_TRIPS;
     hipLaunchKernelGGL(k_prep_row_counts, dim3((max_rows + per_block - 1) / per_block, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
+    const int general_rows = SP_WAVES * SP_PREP_ROWS;
+    hipLaunchKernelGGL(k_prep_row_counts_general, dim3(std::min((max_rows + general_rows - 1) / general_rows, SP_PREP_GENERAL_BLOCKS), n_tables), dim3(SP_BLOCK), 0, s, tables);
+    SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_row_scan, dim3(max_N, n_tables, SP_PREP_MAX_STRIDES), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     return 0;
@@ -692,10 +751,7 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
 int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // 256 rows per workgroup, job record by reference: measured against 64 rows and against the record by value (scalar registers)
-    // on 384 pairs -- 2.36 ms vs 2.89 / 2.69 / 3.35 ms (profiles/r03_kernel_experiments.txt): the pass likes few, fat workgroups
-    // and occupancy more than it dislikes re-loading the record's pointers
-    hipLaunchKernelGGL((k_prep_fill<256, false>), dim3((max_rows + 255) / 256, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    hipLaunchKernelGGL(k_prep_fill, dim3((max_rows + SP_FILL_ROWS - 1) / SP_FILL_ROWS, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_keypoint_L, dim3((max_N + 63) / 64, n_tables), dim3(64), 0, s, tables);
     SP_CHECK_LAUNCH();
