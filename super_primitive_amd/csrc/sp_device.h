@@ -52,23 +52,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 // of every lane pair split the surviving values between them, swap the halves they give up and add -- NV/2 +
 // NV/4 + ... cross-lane moves in total (41 for NV = 40) instead of 6 per value (240) for a butterfly per value.
 // The order of additions is fixed by the lane numbering, so results stay bitwise reproducible.
-template <int N, int OFF>
-__device__ __forceinline__ void halve_step(float* v, bool upper) {
+template <int N, int OFF, class T>
+__device__ __forceinline__ void halve_step(T* v, bool upper) {
     constexpr int H = (N + 1) / 2;
 #pragma unroll
     for (int k = 0; k < H; ++k) {
-        const float lo = v[k];
-        const float hi = (k + H < N) ? v[k + H] : 0.f;
-        const float keep = upper ? hi : lo;
-        const float give = upper ? lo : hi;
+        const T lo = v[k];
+        const T hi = (k + H < N) ? v[k + H] : T(0);
+        const T keep = upper ? hi : lo;
+        const T give = upper ? lo : hi;
         v[k] = keep + __shfl_xor(give, OFF, 64);
     }
 }
 
 // Wave stage: reduce NV per-lane values over the 64 lanes.  Afterwards lane `lane` holds the total of value `pos` in
 // acc[0] if `ok` (each of the NV totals lives in exactly one lane).
-template <int NV>
-__device__ __forceinline__ void wave_sum_to_lanes(float (&acc)[NV], int lane, int& pos, bool& ok) {
+template <int NV, class T>
+__device__ __forceinline__ void wave_sum_to_lanes(T (&acc)[NV], int lane, int& pos, bool& ok) {
     static_assert(NV <= 64, "one value per lane at most");
     constexpr int N0 = NV, N1 = (N0 + 1) / 2, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2, N5 = (N4 + 1) / 2;
     halve_step<N0, 32>(acc, lane & 32);

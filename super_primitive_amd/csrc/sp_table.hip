@@ -133,10 +133,6 @@ __device__ __forceinline__ int segment_of(const int32_t* __restrict__ seg_off, i
     return lo;
 }
 
-__device__ __forceinline__ float planar_tap(const float* __restrict__ img, int Wl, int Hl, int x, int y) {
-    return (x >= 0 && x < Wl && y >= 0 && y < Hl) ? img[(size_t)y * Wl + x] : 0.f;
-}
-
 struct SourceGeom { float xn, yn, L; bool ok; uint32_t pw; };
 
 // geometry of a table point in its own frame: normalised image coordinates and the validity of the sample
@@ -159,28 +155,25 @@ __device__ __forceinline__ SourceGeom source_geometry(uint32_t pix_word, float L
     return g;
 }
 
-// bilinear sample of one pyramid level at that position: {r, g, b, L}
+// bilinear sample of one pyramid level at that position: {r, g, b, L}.  Taps outside the level read as zero (grid_sample's zeros
+// padding); the addresses are clamped into the level and the value selected afterwards, so the twelve loads of a point have no
+// control flow between them and those of several points can be in flight together.
 __device__ __forceinline__ float4 source_sample(const SourceGeom& g, const float* __restrict__ img, int Hl, int Wl) {
     const float ix = __fmul_rn(__fmul_rn(__fadd_rn(g.xn, 1.f), 0.5f), (float)(Wl - 1));
     const float iy = __fmul_rn(__fmul_rn(__fadd_rn(g.yn, 1.f), 0.5f), (float)(Hl - 1));
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const int x0 = (int)fx0, y0 = (int)fy0;
     const float wx = ix - fx0, wy = iy - fy0;
+    const bool xa = x0 >= 0 && x0 < Wl, xb = x0 + 1 >= 0 && x0 + 1 < Wl, ya = y0 >= 0 && y0 < Hl, yb = y0 + 1 >= 0 && y0 + 1 < Hl;
+    const int xc0 = min(max(x0, 0), Wl - 1), xc1 = min(max(x0 + 1, 0), Wl - 1), yc0 = min(max(y0, 0), Hl - 1), yc1 = min(max(y0 + 1, 0), Hl - 1);
+    const int i00 = yc0 * Wl + xc0, i01 = yc0 * Wl + xc1, i10 = yc1 * Wl + xc0, i11 = yc1 * Wl + xc1;
     float rgb[3];
-    // a valid point (0.99 band) has all four taps inside the level whenever Wl, Hl >= 2: one index, no bounds tests
-    const bool inside = g.ok && Wl >= 2 && Hl >= 2;
-    const size_t i00 = (size_t)y0 * Wl + x0;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const float* pl = img + (size_t)ch * Hl * Wl;
         // same weight products and summation order as ATen's grid_sampler_2d (nw, ne, sw, se)
-        float nw, ne, sw, se;
-        if (inside) {
-            nw = pl[i00]; ne = pl[i00 + 1]; sw = pl[i00 + Wl]; se = pl[i00 + Wl + 1];
-        } else {
-            nw = planar_tap(pl, Wl, Hl, x0, y0); ne = planar_tap(pl, Wl, Hl, x0 + 1, y0);
-            sw = planar_tap(pl, Wl, Hl, x0, y0 + 1); se = planar_tap(pl, Wl, Hl, x0 + 1, y0 + 1);
-        }
+        const float t00 = pl[i00], t01 = pl[i01], t10 = pl[i10], t11 = pl[i11];
+        const float nw = (xa && ya) ? t00 : 0.f, ne = (xb && ya) ? t01 : 0.f, sw = (xa && yb) ? t10 : 0.f, se = (xb && yb) ? t11 : 0.f;
         float acc = nw * ((1.f - wx) * (1.f - wy));
         acc += ne * (wx * (1.f - wy));
         acc += sw * ((1.f - wx) * wy);
@@ -370,6 +363,9 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
 #pragma unroll
     for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
         w[0][rr] = (row_base + rr < rows && mine) ? load4(mq + (size_t)rr * qpr + lane) : make_uint4(0u, 0u, 0u, 0u);
+    // a row's counts of lattices {0, 1} and {2, 3} as two words of 16-bit fields (a count is at most 1024): 2 values per row go
+    // through the wave reduction instead of 4, as integers, once per 2 trips
+    uint32_t acc[2 * SP_PREP_ROWS * 2];
 #pragma unroll
     for (int tr = 0; tr < SP_PREP_TRIPS; ++tr) {
         const int row0 = row_base + tr * SP_PREP_ROWS;
@@ -380,20 +376,26 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
                 w[(tr + 1) & 1][rr] = (r < rows && mine) ? load4(mq + (size_t)(r - row_base) * qpr + lane) : make_uint4(0u, 0u, 0u, 0u);
             }
         }
-        float acc[SP_PREP_ROWS * SP_PREP_MAX_STRIDES];
 #pragma unroll
         for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
             const uint4 v = w[tr & 1][rr];
             const uint32_t m = piece_bits(nonzero_bytes(v.x), nonzero_bytes(v.y), nonzero_bytes(v.z), nonzero_bytes(v.w));
             if (bits && mine && row0 + rr < rows) bits[(size_t)(row0 + rr - row_base) * qpr + lane] = m;
-#pragma unroll
-            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) acc[rr * SP_PREP_MAX_STRIDES + k] = (float)__popc(m & sel[k]);
+            const int a = ((tr & 1) * SP_PREP_ROWS + rr) * 2;
+            acc[a] = (uint32_t)__popc(m & sel[0]) | ((uint32_t)__popc(m & sel[1]) << 16);
+            acc[a + 1] = (uint32_t)__popc(m & sel[2]) | ((uint32_t)__popc(m & sel[3]) << 16);
         }
-        int pos;
-        bool ok;
-        wave_sum_to_lanes<SP_PREP_ROWS * SP_PREP_MAX_STRIDES>(acc, lane, pos, ok);
-        const int rr = pos / SP_PREP_MAX_STRIDES, k = pos % SP_PREP_MAX_STRIDES, row = row0 + rr;
-        if (ok && k < t.n_strides && row < rows) t.row_counts[k][row] = ((row % t.H) % t.stride[k] == 0) ? (int)acc[0] : 0;
+        if (tr & 1) {
+            int pos;
+            bool ok;
+            wave_sum_to_lanes<2 * SP_PREP_ROWS * 2>(acc, lane, pos, ok);
+            const int row = row0 - SP_PREP_ROWS + (pos >> 1), k = 2 * (pos & 1);
+            if (ok && row < rows) {
+                const int r = row % t.H;
+                if (k < t.n_strides) t.row_counts[k][row] = (r % t.stride[k] == 0) ? (int)(acc[0] & 0xffffu) : 0;
+                if (k + 1 < t.n_strides) t.row_counts[k + 1][row] = (r % t.stride[k + 1] == 0) ? (int)(acc[0] >> 16) : 0;
+            }
+        }
     }
 }
 
@@ -507,8 +509,21 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
         __syncthreads();
     }
     const int s_n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (s_n == 0) return;
     const bool words = (t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0;
     const bool use_bits = t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0;       // (the count pass wrote them)
+    // The fields of the record the row loop uses, read ONCE into registers: the compiler cannot know that the stores through
+    // pix / baseL leave the record alone and read a field again after every one of them -- 200 scalar loads in the kernel, each
+    // a wait inside the row loop, which is where the waves were parked.
+    SP_GLOBAL uint32_t* pix_k[SP_PREP_MAX_STRIDES];
+    SP_GLOBAL float* baseL_k[SP_PREP_MAX_STRIDES];
+    int stride_k[SP_PREP_MAX_STRIDES];
+#pragma unroll
+    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) { pix_k[k] = t.pix[k]; baseL_k[k] = t.baseL[k]; stride_k[k] = t.stride[k]; }
+    const SP_GLOBAL uint32_t* const bits_p = t.bits;
+    const SP_GLOBAL float* const logdepth_p = t.logdepth;
+    const SP_GLOBAL uint8_t* const masks_p = t.masks;
+    const int W = t.W;
     // One row's compaction into every lattice's table.  A lane owns the 4-pixel groups xw = q * 64 + lane (q < 4: rows of up to
     // 1024 pixels); nz[q] = nonzero_bytes() form of its mask bits, Lv[q] = the 4 log-depths of the group.
     int base[SP_PREP_MAX_STRIDES];
@@ -528,15 +543,15 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
                 if (base[k] < 0) continue;
-                const uint32_t sel = nz[q] & lattice_bytes(4 * xw, t.stride[k]);
+                const uint32_t sel = nz[q] & lattice_bytes(4 * xw, stride_k[k]);
                 const int cnt = __popc(sel);
                 const unsigned long long b0 = __ballot(cnt & 1), b1 = __ballot(cnt & 2), b2 = __ballot(cnt & 4);
                 int pos = base[k] + __popcll(b0 & below) + 2 * __popcll(b1 & below) + 4 * __popcll(b2 & below);
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if ((sel >> (8 * j + 7)) & 1u) {
-                        t.pix[k][pos] = ((uint32_t)r << 16) | (uint32_t)(4 * xw + j);
-                        t.baseL[k][pos] = Lq[j];
+                        pix_k[k][pos] = ((uint32_t)r << 16) | (uint32_t)(4 * xw + j);
+                        baseL_k[k][pos] = Lq[j];
                         ++pos;
                     }
                 base[k] += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
@@ -546,10 +561,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
     if (use_bits) {
         // Three rows in flight per wave: the bit words of row i + 2 and the log-depths of row i + 1 are requested before row i
         // is compacted (a row is two dependent loads -- bits, then the log-depths of its set pixels -- and a chain of ballots:
-        // processed one after the other, the waves sat in memory latency and the pass ran at 0.14 of the HBM roofline).
-        const int qpr = t.W >> 4, wpr = t.W >> 2;
+        // processed one after the other, the waves sat in memory latency and the pass ran at 0.14 of the HBM roofline).  (Four
+        // rows in flight cost 20 vector registers = a third of the occupancy and were slower, 1.59 against 1.38 ms.)
+        const int qpr = W >> 4, wpr = W >> 2;
         auto load_bits = [&](int slot, uint32_t (&nz)[4]) {
-            const SP_GLOBAL uint32_t* bw = t.bits + (size_t)__builtin_amdgcn_readfirstlane(s_rows[slot]) * qpr;
+            const SP_GLOBAL uint32_t* bw = bits_p + (size_t)__builtin_amdgcn_readfirstlane(s_rows[slot]) * qpr;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int xw = q * 64 + lane;
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
             }
         };
         auto load_L = [&](int slot, const uint32_t (&nz)[4], float4 (&Lv)[4]) {
-            const SP_GLOBAL float* L = t.logdepth + (size_t)__builtin_amdgcn_readfirstlane(s_rows[slot]) * t.W;
+            const SP_GLOBAL float* L = logdepth_p + (size_t)__builtin_amdgcn_readfirstlane(s_rows[slot]) * W;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 Lv[q] = nz[q] ? load4((const SP_GLOBAL f32x4*)(L + 4 * (q * 64 + lane))) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -584,20 +600,20 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
                 if (k < t.n_strides)
-                    fill_row(generic(t.masks), generic(t.logdepth), row_id, t.H, t.W, t.stride[k], generic(t.seg_off[k]), generic(t.row_counts[k]),
-                             generic(t.pix[k]), generic(t.baseL[k]));
+                    fill_row(generic(t.masks), generic(t.logdepth), row_id, t.H, W, stride_k[k], generic(t.seg_off[k]), generic(t.row_counts[k]),
+                             generic(pix_k[k]), generic(baseL_k[k]));
             continue;
         }
-        const SP_GLOBAL uint32_t* mw = (const SP_GLOBAL uint32_t*)(t.masks + (size_t)row_id * t.W);
-        const SP_GLOBAL float* L = t.logdepth + (size_t)row_id * t.W;
+        const SP_GLOBAL uint32_t* mw = (const SP_GLOBAL uint32_t*)(masks_p + (size_t)row_id * W);
+        const SP_GLOBAL float* L = logdepth_p + (size_t)row_id * W;
         row_begin(i);
-        for (int w0 = 0; w0 < (t.W >> 2); w0 += 256) {       // (4 x 64 groups at a time)
+        for (int w0 = 0; w0 < (W >> 2); w0 += 256) {       // (4 x 64 groups at a time)
             uint32_t nz[4];
             float4 Lv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int xw = w0 + q * 64 + lane;
-                nz[q] = xw < (t.W >> 2) ? nonzero_bytes(mw[xw]) : 0u;
+                nz[q] = xw < (W >> 2) ? nonzero_bytes(mw[xw]) : 0u;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = ((nz[q] >> (8 * j + 7)) & 1u) ? L[4 * xw + j] : 0.f;
@@ -618,45 +634,107 @@ __global__ void k_prep_keypoint_L(const SpPrepTable* __restrict__ tables) {
 // segment's run are written as {pix 0, src4 0} = invalid points (the arrays need no prior clearing).  A workgroup takes
 // SP_SAMPLE_BLOCKS consecutive 256-point blocks: the scalar segment search (a chain of dependent loads) is repeated only when a
 // block leaves the current segment's padded run.
-#define SP_SAMPLE_BLOCKS 4
-__global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs) {
-    const PrepSample& j = reinterpret_cast<const PrepSample*>(jobs)[blockIdx.y];
+template <int SP_SAMPLE_BLOCKS>
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs, int blocks_per_job, int total_blocks) {
+    // One-dimensional grid over (table, block) pairs, rounded up to a multiple of 8.  Workgroups are dealt to the 8 XCDs round robin
+    // in dispatch order: taken as they come, the blocks of one table -- which gather from the same source image -- run on all
+    // eight and every XCD's L2 fetches that image.  Chunked order: every XCD gets a contiguous range of the pairs.
+    const int v = xcd_chunked_tile(blockIdx.x, total_blocks);
+    if (v >= total_blocks) return;
+    const int job = v / blocks_per_job, bx = v - job * blocks_per_job;
+    const PrepSample& j = reinterpret_cast<const PrepSample*>(jobs)[job];
     // padding granule of the table: 256 (a whole 256-point block lies in one segment) or 64 (wave spans: every WAVE's 64 points
     // do; the search then runs per wave)
     const int lane_off = j.granule == 64 ? (int)(threadIdx.x & ~63u) : 0;
-    int n = 0, first = 0, count = 0, next_first = -1;
-    float shift = 0.f;
-    for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) {
-        const int b0 = (blockIdx.x * SP_SAMPLE_BLOCKS + k) * SP_BLOCK;
-        if (b0 >= j.P) return;
-        const int i0 = __builtin_amdgcn_readfirstlane(b0 + lane_off);        // first point of this wave's / block's unit
-        const int i = b0 + (int)threadIdx.x;
-        if (i0 < j.P && (k == 0 || i0 >= next_first)) {          // (per wave when the granule is 64: every wave tracks its own run)
-            n = segment_of(generic(j.seg_off), j.N, i0);
-            first = j.seg_off[n];
-            count = j.counts[n];
-            shift = j.kld[n] - j.kp_L[n];
-            next_first = n + 1 < j.N ? j.seg_off[n + 1] : j.P;
-            if (next_first <= first) next_first = j.P;
+    // The pass is bound by memory latency, not bytes or arithmetic (waves parked on s_waitcnt 87 % of their cycles when every
+    // point went load -> geometry -> 12 taps -> store on its own): the SP_SAMPLE_BLOCKS points of a thread go through each stage
+    // together -- all table words requested, then all taps of a level, then the stores.
+    int idx[SP_SAMPLE_BLOCKS];
+    bool in_table[SP_SAMPLE_BLOCKS], live[SP_SAMPLE_BLOCKS];
+    float shift[SP_SAMPLE_BLOCKS];
+    {
+        int n = 0, first = 0, count = 0, next_first = -1;
+        float sh = 0.f;
+#pragma unroll
+        for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) {
+            const int b0 = (bx * SP_SAMPLE_BLOCKS + k) * SP_BLOCK;
+            const int i0 = __builtin_amdgcn_readfirstlane(b0 + lane_off);        // first point of this wave's / block's unit
+            idx[k] = b0 + (int)threadIdx.x;
+            if (i0 < j.P && (k == 0 || i0 >= next_first)) {          // (per wave when the granule is 64: every wave tracks its own run)
+                n = segment_of(generic(j.seg_off), j.N, i0);
+                first = j.seg_off[n];
+                count = j.counts[n];
+                sh = j.kld[n] - j.kp_L[n];
+                next_first = n + 1 < j.N ? j.seg_off[n + 1] : j.P;
+                if (next_first <= first) next_first = j.P;
+            }
+            in_table[k] = idx[k] < j.P;
+            live[k] = in_table[k] && idx[k] - first < count;       // (else padding of the segment's run: an invalid point)
+            shift[k] = sh;
         }
-        if (i >= j.P) continue;
-        if (i - first >= count) {
-            j.pix[i] = 0u;
-            for (int l = 0; l < j.n_levels; ++l) store4((SP_GLOBAL f32x4*)j.src4[l] + i, make_float4(0.f, 0.f, 0.f, 0.f));
-            continue;
-        }
-        const SourceGeom g = source_geometry(j.pix[i], j.baseL[i], shift, j.H, j.W, generic(j.K));
-        for (int l = 0; l < j.n_levels; ++l) store4((SP_GLOBAL f32x4*)j.src4[l] + i, source_sample(g, generic(j.image[l]), j.Hl[l], j.Wl[l]));
-        j.pix[i] = g.pw | (g.ok ? 0x80000000u : 0u);
     }
+    SP_GLOBAL uint32_t* const pix = j.pix;             // (record fields in registers before the first store: see k_prep_fill)
+    const int n_levels = j.n_levels;
+    uint32_t pw[SP_SAMPLE_BLOCKS];
+    float L[SP_SAMPLE_BLOCKS];
+#pragma unroll
+    for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) {
+        pw[k] = live[k] ? pix[idx[k]] : 0u;
+        L[k] = live[k] ? j.baseL[idx[k]] : 0.f;
+    }
+    SourceGeom g[SP_SAMPLE_BLOCKS];
+#pragma unroll
+    for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) g[k] = source_geometry(pw[k], L[k], shift[k], j.H, j.W, generic(j.K));
+    for (int l = 0; l < n_levels; ++l) {
+        const SP_GLOBAL float* const image = j.image[l];
+        SP_GLOBAL f32x4* const out = (SP_GLOBAL f32x4*)j.src4[l];
+        const int Hl = j.Hl[l], Wl = j.Wl[l];
+        float4 v[SP_SAMPLE_BLOCKS];
+#pragma unroll
+        for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) v[k] = source_sample(g[k], generic(image), Hl, Wl);
+#pragma unroll
+        for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k)
+            if (in_table[k]) store4(out + idx[k], live[k] ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f));
+    }
+#pragma unroll
+    for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k)
+        if (in_table[k]) pix[idx[k]] = live[k] ? (g[k].pw | (g[k].ok ? 0x80000000u : 0u)) : 0u;
 }
 
+// One pyramid step of a batch of planar images.  Rows of W = 4 k pixels (16-byte aligned): a thread makes TWO neighbouring outputs
+// from one 16-byte load and one 4-byte load (the column left of it) of each of the three input rows -- 6 loads per 2 outputs, the
+// wide ones contiguous over the wave; one output per thread is 9 four-byte loads 8 bytes apart, and the pass sat in the load
+// issue (issue stalls 43 % of the wave cycles, 0.43 of the HBM roofline).  Same products and summation order as
+// blur_decimate_at().  The grid covers max_out_pixels / 2 threads per plane: other shapes take two outputs per thread, one at a time.
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_blur(const SpPrepImage* __restrict__ jobs) {
     const PrepImage& j = reinterpret_cast<const PrepImage*>(jobs)[blockIdx.z];
     const int Ho = (j.H + 1) / 2, Wo = (j.W + 1) / 2;
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
-    if (i >= Ho * Wo) return;
-    j.out[(size_t)blockIdx.y * Ho * Wo + i] = blur_decimate_at(generic(j.in + (size_t)blockIdx.y * j.H * j.W), j.H, j.W, Wo, i);
+    const SP_GLOBAL float* in = j.in + (size_t)blockIdx.y * j.H * j.W;
+    SP_GLOBAL float* out = j.out + (size_t)blockIdx.y * Ho * Wo;
+    if ((j.W & 3) == 0 && ((uintptr_t)j.in & 15) == 0 && ((uintptr_t)j.out & 7) == 0) {
+        const int half = Wo >> 1;
+        if (i >= Ho * half) return;
+        const int yo = i / half, t = i - yo * half;
+        const float wgt[3] = {1.f, 2.f, 1.f};
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const SP_GLOBAL float* row = in + (size_t)reflect1(2 * yo + dy - 1, j.H) * j.W;
+            const float4 v = load4((const SP_GLOBAL f32x4*)(row + 4 * t));
+            const float left = row[max(4 * t - 1, 0)];
+            const float c0 = t > 0 ? left : v.y;            // column -1 reflects onto column 1
+            const float w0 = wgt[dy] * wgt[0] * (1.f / 16.f), w1 = wgt[dy] * wgt[1] * (1.f / 16.f), w2 = wgt[dy] * wgt[2] * (1.f / 16.f);
+            a0 = fmaf(w0, c0, a0);  a0 = fmaf(w1, v.x, a0);  a0 = fmaf(w2, v.y, a0);
+            a1 = fmaf(w0, v.y, a1); a1 = fmaf(w1, v.z, a1);  a1 = fmaf(w2, v.w, a1);
+        }
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 o = {a0, a1};
+        *(SP_GLOBAL f32x2*)(out + (size_t)yo * Wo + 2 * t) = o;
+        return;
+    }
+    const int n_threads = gridDim.x * SP_BLOCK;
+    for (int o = i; o < Ho * Wo; o += n_threads) out[o] = blur_decimate_at(generic(in), j.H, j.W, Wo, o);
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_pack(const SpPrepImage* __restrict__ jobs) {
@@ -760,14 +838,18 @@ int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int m
 
 int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream) {
     if (!jobs || check_grid(max_P, n_jobs)) return SP_EINVAL;
-    hipLaunchKernelGGL(k_prep_sample, dim3((max_P + SP_BLOCK * SP_SAMPLE_BLOCKS - 1) / (SP_BLOCK * SP_SAMPLE_BLOCKS), n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
+    constexpr int K = 2;               // points per thread (1: 2.17 ms, 2: 1.98 ms, 4: 2.18 ms for 384 pairs of 640x480x64)
+    const long per_job = (max_P + SP_BLOCK * K - 1) / (SP_BLOCK * K), total = per_job * n_jobs;
+    if (total + 7 > 0x7fffffffL) return SP_ELIMIT;
+    hipLaunchKernelGGL((k_prep_sample<K>), dim3((unsigned)((total + 7) / 8 * 8)), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs, (int)per_job, (int)total);
     SP_CHECK_LAUNCH();
     return 0;
 }
 
 int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixels, void* stream) {
     if (!jobs || check_grid(max_out_pixels, n_jobs) || C <= 0 || C > 65535) return SP_EINVAL;
-    hipLaunchKernelGGL(k_prep_blur, dim3((max_out_pixels + SP_BLOCK - 1) / SP_BLOCK, C, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
+    const int threads = (max_out_pixels + 1) / 2;          // (k_prep_blur: two outputs per thread)
+    hipLaunchKernelGGL(k_prep_blur, dim3((threads + SP_BLOCK - 1) / SP_BLOCK, C, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import ctypes
 
+import time
+
 import numpy as np
 import torch
 
@@ -156,6 +158,17 @@ class _Timer:
 
     def __init__(self):
         self.events = []
+        self.marks = []                     # (name, host seconds since the timer was made): where the HOST is, for tools/setup_bench.py
+        self.t0 = time.perf_counter()
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def mark(self, name):
+        self.marks.append((name, time.perf_counter() - self.t0))
+
+    def timeline(self):
+        """[(pass, GPU start ms, GPU end ms)] since the timer was made, and the host marks in ms (call after a synchronisation)."""
+        return [(n, self.e0.elapsed_time(a), self.e0.elapsed_time(b)) for n, a, b in self.events], [(n, 1e3 * t) for n, t in self.marks]
 
     class _Span:
         def __init__(self, owner, name):
@@ -191,6 +204,9 @@ class _NoTimer:
 
     def __call__(self, name):
         return _NoTimer._Null()
+
+    def mark(self, name):
+        pass
 
 
 def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, full_levels=None, timer=None, granule=GRANULE):
@@ -245,6 +261,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     bits = torch.empty(max(int(w_off[-1]), 1), dtype=torch.int32, device=dev)
     recs['bits'] = np.where(fast, bits.data_ptr() + 4 * w_off[:-1], 0).astype(np.uint64)
     staged = stage([recs], dev)
+    timer.mark('count launch')
     with timer('count'):
         _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
     counts_pinned = torch.empty(nS * S, dtype=torch.int32, pin_memory=True)
@@ -252,21 +269,11 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     counts_ready = torch.cuda.Event()
     counts_ready.record()
 
-    # the other inputs are gathered while the masks are being counted
-    logd = [_dev(f.logdepth_perseg, dev) for f in src_frames]
-    kps = [_dev(f.keypoints, dev) for f in src_frames]
-    simg = [_dev(f.image[:3], dev) for f in src_frames]
-    timg = [_dev(t[:3], dev) for t in trg_images]
-    Ksrc = [_dev(f.K, dev) for f in src_frames]
-    kld = [_dev(k, dev) for k in klds]
-    _lib.require_device(*logd, *simg, *timg)
-    recs['logdepth'], recs['keypoints'] = _ptrs(logd), _ptrs(kps)
-    Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)      # complete once the counts have been waited for
-    Ks_pinned.copy_(torch.stack([k.reshape(3, 3) for k in Ksrc + [_dev(k, dev) for k in trg_Ks]]), non_blocking=True)
-    Ks_ready = torch.cuda.Event()
-    Ks_ready.record()
-
-    # image pyramids of both frames and packed targets: independent of the counts, enqueued before the host waits for them
+    # image pyramids of both frames and packed targets: independent of the counts, enqueued right behind the count pass
+    rgb = lambda im: im if im.shape[0] == 3 else im[:3]
+    simg = [_dev(rgb(f.image), dev) for f in src_frames]
+    timg = [_dev(rgb(t), dev) for t in trg_images]
+    _lib.require_device(*simg, *timg)
     max_level = max(level_ids)
     pyramid, blur_jobs = [], []
     ptr_lv = {0: (_ptrs(simg), _ptrs(timg))}                                     # level -> (source, target) image pointers
@@ -301,8 +308,23 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
                    "sp_prepare_pack")
 
+    # the other inputs are gathered while the masks are being counted and the pyramids built (~2 us of interpreter time per
+    # tensor: with hundreds of pairs this is milliseconds, and the GPU must not wait for it with an empty queue)
+    logd = [_dev(f.logdepth_perseg, dev) for f in src_frames]
+    kps = [_dev(f.keypoints, dev) for f in src_frames]
+    Ksrc = [_dev(f.K, dev) for f in src_frames]
+    kld = [_dev(k, dev) for k in klds]
+    _lib.require_device(*logd)
+    recs['logdepth'], recs['keypoints'] = _ptrs(logd), _ptrs(kps)
+    Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)      # complete once the counts have been waited for
+    Ks_pinned.copy_(torch.stack([k if k.dim() == 2 else k.reshape(3, 3) for k in Ksrc + [_dev(k, dev) for k in trg_Ks]]), non_blocking=True)
+    Ks_ready = torch.cuda.Event()
+    Ks_ready.record()
+
     # ---- host: padded layouts; device: fill straight into them ----
+    timer.mark('wait for counts')
     counts_ready.synchronize()                    # the one host synchronisation of the set-up (the pyramids keep the GPU busy)
+    timer.mark('counts here')
     counts_h = counts_pinned.numpy().reshape(nS, S)
     tabs = {}
     kp_L = torch.empty(S, dtype=torch.float32, device=dev)
@@ -361,6 +383,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
 
     jobs, max_P = sample_jobs(levels_of)
     staged = stage([recs, jobs], dev)
+    timer.mark('fill launch')
     with timer('fill'):
         _lib.check(lib.sp_prepare_fill(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_fill")
     with timer('sample'):
@@ -398,4 +421,5 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     # (temporaries -- job records, row counts -- are released here; the caching allocator orders their reuse after the launches
     #  above on this stream)
     Ks_ready.synchronize()
+    timer.mark('prepare_pairs returns')
     return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp, Ks=Ks_pinned.numpy(), sample_full=sample_full, bytes=nbytes)

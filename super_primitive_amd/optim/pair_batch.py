@@ -193,6 +193,7 @@ class PairBatch:
         prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev, full_levels=full_levels,
                                            timer=timer, granule=self.granule)
         self.setup_bytes = prep['bytes']
+        mark = timer.mark if timer is not None else (lambda name: None)
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
         rep = (lambda x: x) if R == 1 else (lambda x: x.repeat(*([R] + [1] * (x.dim() - 1))))
         tile = (lambda a: a) if R == 1 else (lambda a: np.tile(a, R))
@@ -300,6 +301,7 @@ class PairBatch:
             d['rec0'] = rec_per_chunk * lay_wl['c_off'][:-1]
             return d
 
+        mark('work lists staged')
         host = [descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps)) for l in full_levels]
         for (l, stride), lay in self.coarse.items():
             c_wl, c_p_off = coarse_host[(l, stride)]
@@ -323,6 +325,7 @@ class PairBatch:
         self.arrivals = torch.zeros(M, dtype=torch.int32, device=dev)     # per-pair tile-arrival counters (fused launch)
         self.done = torch.zeros(M, dtype=torch.int32, device=dev)         # per-pair convergence flags (gn_step(conv_tol=...))
         self.phase = torch.zeros(M, dtype=torch.int32, device=dev)        # per-pair position in a device-side schedule (run_scheduled)
+        mark('workspaces')
         self.phase_iters = torch.zeros(M, dtype=torch.int32, device=dev)
         self.reset_lm()
         self._graphs = {}

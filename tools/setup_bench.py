@@ -32,3 +32,6 @@ for _ in range(4):
 nb = b.setup_bytes
 print(f"granule {GRAN}: {G} pairs, set-up {1e3 * np.median(wall):.2f} ms = {1e6 * np.median(wall) / G:.1f} us/pair; "
       + "  ".join(f"{k} {np.median(v):.2f} ms ({nb[k] / np.median(v) / 1e6 / 8000:.3f})" for k, v in acc.items()))
+ev, marks = tm.timeline()
+print("timeline of the last build (ms): GPU " + "  ".join(f"{n} {a:.2f}-{b:.2f}" for n, a, b in ev) + " | host " + "  ".join(f"{n} {t:.2f}" for n, t in marks)
+      + f" | wall {1e3 * wall[-1]:.2f}")
