@@ -470,6 +470,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* _
 // three ballots of the count's bits.  (Gathering a row's points in LDS and storing them by consecutive lanes -- full
 // lines per store instead of 4-byte stores 4 to 16 bytes apart -- was slower: 1.86 ms against 1.36 ms for 384 keyframes.)
 #define SP_FILL_ROWS 256
+#define SP_FILL_BATCH 32            /* rows of a workgroup's non-empty rows per batch of the bits path (k_prep_fill) */
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __restrict__ tables) {
     const PrepTable& t = table_of(tables, blockIdx.y);
     const int rows = t.N * t.H;
@@ -559,38 +560,121 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
         }
     };
     if (use_bits) {
-        // Three rows in flight per wave: the bit words of row i + 2 and the log-depths of row i + 1 are requested before row i
-        // is compacted (a row is two dependent loads -- bits, then the log-depths of its set pixels -- and a chain of ballots:
-        // processed one after the other, the waves sat in memory latency and the pass ran at 0.14 of the HBM roofline).  (Four
-        // rows in flight cost 20 vector registers = a third of the occupancy and were slower, 1.59 against 1.38 ms.)
-        const int qpr = W >> 4, wpr = W >> 2;
-        auto load_bits = [&](int slot, uint32_t (&nz)[4]) {
-            const SP_GLOBAL uint32_t* bw = bits_p + (size_t)__builtin_amdgcn_readfirstlane(s_rows[slot]) * qpr;
+        // Bits path, by OCTETS (8 pixels = half a bit word) instead of by rows.  A row at a time -- a lane per 4 pixels, ballots
+        // for the ranks -- is ~330 instructions per row of which a segment fills a fifth of the lanes, and the pass was bound by
+        // instruction issue (SIMDs ~80 % busy issuing at 0.19 of the HBM roofline; deeper prefetch and rows in batches changed
+        // nothing or lost).  Here a batch of SP_FILL_BATCH rows goes through three block-wide stages: (a) its bit words into LDS
+        // (all loads in flight together), (b) the ordered list of its NON-EMPTY octets, (c) 256 listed octets at a time, one per
+        // thread: the log-depths of the octet (two 16-byte loads), its point counts per lattice, a block-wide exclusive scan
+        // of those = the rank of its first point in table order, minus the scan value at the row's first octet = the rank inside
+        // the row, plus the row's start = where its points go.
+        const int qpr = W >> 4;
+        const int n_strides = t.n_strides;
+        uint32_t lmask[SP_PREP_MAX_STRIDES];            // pixels of an octet on lattice k, bit i = pixel i (strides 8, 16: pixel 0, and only
+#pragma unroll                                         //  of even octets for 16)
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+            const int st = stride_k[k];
+            lmask[k] = k < n_strides ? (st == 1 ? 0xffu : (st == 2 ? 0x55u : (st == 4 ? 0x11u : 0x01u))) : 0u;
+        }
+        __shared__ uint32_t s_bits[SP_FILL_BATCH][64];
+        __shared__ uint16_t s_list[SP_WAVES][SP_FILL_BATCH * 128 / SP_WAVES];      // octet = row of the batch << 7 | octet of the row
+        __shared__ int s_nlist[SP_WAVES];
+        __shared__ uint32_t s_wsum[2][SP_WAVES];
+        __shared__ int s_delta[SP_PREP_MAX_STRIDES][SP_FILL_BATCH];
+        constexpr int ROWS_PER_WAVE = SP_FILL_BATCH / SP_WAVES;
+        for (int s0 = 0; s0 < s_n; s0 += SP_FILL_BATCH) {
+            const int nb = min(SP_FILL_BATCH, s_n - s0);
+            __syncthreads();                         // (the previous batch is done with s_bits / s_list)
+            // (a) + (b): every wave for its own ROWS_PER_WAVE rows of the batch
+            uint32_t bw[ROWS_PER_WAVE];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int xw = q * 64 + lane;
-                nz[q] = xw < wpr ? (((bw[xw >> 2] >> (xw & 3)) & 0x01010101u) << 7) : 0u;
+            for (int i = 0; i < ROWS_PER_WAVE; ++i) {
+                const int sl = wave * ROWS_PER_WAVE + i;
+                bw[i] = (sl < nb && lane < qpr) ? bits_p[(size_t)s_rows[s0 + sl] * qpr + lane] : 0u;
             }
-        };
-        auto load_L = [&](int slot, const uint32_t (&nz)[4], float4 (&Lv)[4]) {
-            const SP_GLOBAL float* L = logdepth_p + (size_t)__builtin_amdgcn_readfirstlane(s_rows[slot]) * W;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                Lv[q] = nz[q] ? load4((const SP_GLOBAL f32x4*)(L + 4 * (q * 64 + lane))) : make_float4(0.f, 0.f, 0.f, 0.f);
-        };
-        uint32_t nz0[4] = {0u, 0u, 0u, 0u}, nz1[4] = {0u, 0u, 0u, 0u}, nz2[4] = {0u, 0u, 0u, 0u};
-        float4 L0[4], L1[4];
-        int i = wave;
-        if (i < s_n) load_bits(i, nz0);
-        if (i + SP_WAVES < s_n) load_bits(i + SP_WAVES, nz1);
-        if (i < s_n) load_L(i, nz0, L0);
-        for (; i < s_n; i += SP_WAVES) {
-            if (i + 2 * SP_WAVES < s_n) load_bits(i + 2 * SP_WAVES, nz2);
-            if (i + SP_WAVES < s_n) load_L(i + SP_WAVES, nz1, L1);
-            row_begin(i);
-            emit_groups(0, nz0, L0);
+            for (int i = 0; i < ROWS_PER_WAVE; ++i) s_bits[wave * ROWS_PER_WAVE + i][lane] = bw[i];
+            __syncthreads();
+            int n_w = 0;
+#pragma unroll 4
+            for (int it = 0; it < ROWS_PER_WAVE * 2; ++it) {
+                const int c = (wave * ROWS_PER_WAVE * 2 + it) * 64 + lane;
+                const uint32_t m = s_bits[c >> 7][(c & 127) >> 1];
+                const bool on = ((m >> (2 * (c & 1))) & 0x03030303u) != 0u;
+                const unsigned long long bal = __ballot(on);
+                if (on) s_list[wave][n_w + __popcll(bal & below)] = (uint16_t)c;
+                n_w += __popcll(bal);
+            }
+            if (lane == 0) s_nlist[wave] = n_w;
+            __syncthreads();
+            const int n0 = s_nlist[0], n1 = n0 + s_nlist[1], n2 = n1 + s_nlist[2], n_total = n2 + s_nlist[3];
+            auto listed = [&](int g) -> int {     // g-th non-empty octet of the batch
+                const int w = (g >= n0) + (g >= n1) + (g >= n2);
+                return s_list[w][g - (w == 0 ? 0 : (w == 1 ? n0 : (w == 2 ? n1 : n2)))];
+            };
+            int run[SP_PREP_MAX_STRIDES] = {0, 0, 0, 0};        // points of the batch before this chunk, per lattice
+            for (int g0 = 0; g0 < n_total; g0 += SP_BLOCK) {
+                const int g = g0 + (int)threadIdx.x;
+                const bool valid = g < n_total;
+                const int c = valid ? listed(g) : 0;
+                const int sl = c >> 7, oct = c & 127;
+                const bool first = valid && (g == 0 || (listed(g - 1) >> 7) != sl);            // first octet of its row
+                const int slot = s0 + sl;
+                const uint32_t e = valid ? ((s_bits[sl][oct >> 1] >> (2 * (oct & 1))) & 0x03030303u) : 0u;
+                // pixel i of the octet sits at bit 8 i of e (i < 4) or 8 (i - 4) + 1: bring it to bit i
+                const uint32_t m8 = (((e & 0x01010101u) * 0x10204080u) >> 28) | ((((e >> 1) & 0x01010101u) * 0x10204080u) >> 24 & 0xf0u);
+                const int row = s_rows[slot], r = s_r[slot];
+                const SP_GLOBAL float* Lp = logdepth_p + (size_t)row * W + 8 * oct;
+                const float4 La = (m8 & 0x0fu) ? load4((const SP_GLOBAL f32x4*)Lp) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 Lb = (m8 & 0xf0u) ? load4((const SP_GLOBAL f32x4*)(Lp + 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                int bk[SP_PREP_MAX_STRIDES];
+                uint32_t sel[SP_PREP_MAX_STRIDES];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { nz0[q] = nz1[q]; L0[q] = L1[q]; nz1[q] = nz2[q]; }
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+                    bk[k] = valid ? s_base[k][slot] : -1;
+                    sel[k] = (bk[k] >= 0 && !(stride_k[k] == 16 && (oct & 1))) ? (m8 & lmask[k]) : 0u;
+                }
+                // block-wide exclusive scan of the four counts (two words of 16-bit fields: a chunk holds at most 2048 points)
+                const uint32_t p0 = (uint32_t)__popc(sel[0]) | ((uint32_t)__popc(sel[1]) << 16), p1 = (uint32_t)__popc(sel[2]) | ((uint32_t)__popc(sel[3]) << 16);
+                uint32_t i0 = p0, i1 = p1;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t u0 = __shfl_up(i0, d, 64), u1 = __shfl_up(i1, d, 64);
+                    if (lane >= d) { i0 += u0; i1 += u1; }
+                }
+                if (lane == 63) { s_wsum[0][wave] = i0; s_wsum[1][wave] = i1; }
+                __syncthreads();
+                uint32_t o0 = 0u, o1 = 0u, t0 = 0u, t1 = 0u;
+#pragma unroll
+                for (int w = 0; w < SP_WAVES; ++w) {
+                    const uint32_t a0 = s_wsum[0][w], a1 = s_wsum[1][w];
+                    if (w < wave) { o0 += a0; o1 += a1; }
+                    t0 += a0; t1 += a1;
+                }
+                const uint32_t e0 = i0 - p0 + o0, e1 = i1 - p1 + o1;
+                const int G[SP_PREP_MAX_STRIDES] = {run[0] + (int)(e0 & 0xffffu), run[1] + (int)(e0 >> 16), run[2] + (int)(e1 & 0xffffu), run[3] + (int)(e1 >> 16)};
+                if (first) {
+#pragma unroll
+                    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_delta[k][sl] = bk[k] - G[k];
+                }
+                __syncthreads();
+                const float Lq[8] = {La.x, La.y, La.z, La.w, Lb.x, Lb.y, Lb.z, Lb.w};
+                const uint32_t pw0 = ((uint32_t)r << 16) | (uint32_t)(8 * oct);
+#pragma unroll
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+                    if (k >= n_strides) break;
+                    if (__ballot(sel[k] != 0u) == 0ull) continue;
+                    int pos = sel[k] ? s_delta[k][sl] + G[k] : 0;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if ((sel[k] >> i) & 1u) {
+                            pix_k[k][pos] = pw0 + (uint32_t)i;
+                            baseL_k[k][pos] = Lq[i];
+                            ++pos;
+                        }
+                }
+                run[0] += (int)(t0 & 0xffffu); run[1] += (int)(t0 >> 16); run[2] += (int)(t1 & 0xffffu); run[3] += (int)(t1 >> 16);
+            }
         }
         return;
     }
