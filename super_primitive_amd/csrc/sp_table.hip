@@ -327,13 +327,13 @@ __device__ __forceinline__ uint32_t lattice_piece(int stride) {
 }
 
 // Every lattice of the keyframe in the same pass over the masks.  Fast path (rows of W = 16 k <= 1024 pixels, 16-byte aligned,
-// lattice strides 1 / 2 / 4 / 8 / 16): a wave takes SP_PREP_ROWS x SP_PREP_TRIPS consecutive (segment,row) rows; a lane owns one
-// 16-byte piece of every row, the loads of the next SP_PREP_ROWS rows are in flight while the current ones are counted, and a
-// row costs ~30 vector instructions (one packed bit word per piece, one and + popcount-accumulate per lattice) -- the round-2
-// form spent 80 (a popcount, a conversion and a float add per word and lattice) and was bound by the vector ALU at 2.7 TB/s.
-// The bit words are also WRITTEN (SpPrepTable.bits): the fill pass reads them instead of the masks.
-#define SP_PREP_ROWS 4
-#define SP_PREP_TRIPS 4
+// lattice strides 1 / 2 / 4 / 8 / 16): a wave takes SP_PREP_WAVE_ROWS consecutive (segment,row) rows -- ONE contiguous run of
+// 16-byte pieces in memory -- and its lanes walk that run densely, a piece per lane and trip, whatever the row length (a lane per
+// piece of ONE row left 24 of 64 lanes idle at W = 640, and the pass was bound by the vector ALU: 97 % busy at 0.60 of the HBM
+// roofline).  Per piece: one packed bit word (written to SpPrepTable.bits: the fill pass reads those instead of the masks) and
+// its four lattice counts as the bytes of one word in LDS; then four lanes per row add up the row's words.
+#define SP_PREP_WAVE_ROWS 16
+#define SP_PREP_LOADS 8             /* 16-byte loads a lane has in flight */
 // does this keyframe take the fast path of the count pass (and, if it has a bits array, of the fill pass)?
 __device__ __forceinline__ bool prep_fast_path(const PrepTable& t) {
     bool fixed = true;
@@ -349,53 +349,54 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
     const PrepTable& t = table_of(tables, blockIdx.y);
     if (!prep_fast_path(t)) return;          // (k_prep_row_counts_general takes those keyframes)
     const int rows = t.N * t.H;
-    const int lane = threadIdx.x & 63;
-    const int row_base = (blockIdx.x * SP_WAVES + (threadIdx.x >> 6)) * (SP_PREP_ROWS * SP_PREP_TRIPS);
-    if (row_base >= rows) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row_base = (blockIdx.x * SP_WAVES + wave) * SP_PREP_WAVE_ROWS;
+    const int qpr = t.W >> 4;
+    const int n_rows = min(SP_PREP_WAVE_ROWS, rows - row_base);          // (<= 0: a wave past the end, which still meets the barrier)
+    const int n_pieces = n_rows * qpr;
+    __shared__ uint32_t s_c[SP_WAVES][SP_PREP_WAVE_ROWS * 64];
     uint32_t sel[SP_PREP_MAX_STRIDES];
 #pragma unroll
     for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) sel[k] = k < t.n_strides ? lattice_piece(t.stride[k]) : 0u;
-    const int qpr = t.W >> 4;
-    const SP_GLOBAL u32x4* mq = (const SP_GLOBAL u32x4*)t.masks + (size_t)row_base * qpr;
+    const SP_GLOBAL u32x4* mq = (const SP_GLOBAL u32x4*)t.masks + (size_t)max(row_base, 0) * qpr;
     SP_GLOBAL uint32_t* bits = t.bits ? t.bits + (size_t)row_base * qpr : nullptr;
-    const bool mine = lane < qpr;
-    uint4 w[2][SP_PREP_ROWS];
+    for (int p0 = 0; p0 < n_pieces; p0 += SP_PREP_LOADS * 64) {
+        uint4 w[SP_PREP_LOADS];
 #pragma unroll
-    for (int rr = 0; rr < SP_PREP_ROWS; ++rr)
-        w[0][rr] = (row_base + rr < rows && mine) ? load4(mq + (size_t)rr * qpr + lane) : make_uint4(0u, 0u, 0u, 0u);
-    // a row's counts of lattices {0, 1} and {2, 3} as two words of 16-bit fields (a count is at most 1024): 2 values per row go
-    // through the wave reduction instead of 4, as integers, once per 2 trips
-    uint32_t acc[2 * SP_PREP_ROWS * 2];
+        for (int u = 0; u < SP_PREP_LOADS; ++u) {
+            const int p = p0 + u * 64 + lane;
+            w[u] = p < n_pieces ? load4(mq + p) : make_uint4(0u, 0u, 0u, 0u);
+        }
 #pragma unroll
-    for (int tr = 0; tr < SP_PREP_TRIPS; ++tr) {
-        const int row0 = row_base + tr * SP_PREP_ROWS;
-        if (tr + 1 < SP_PREP_TRIPS) {
-#pragma unroll
-            for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
-                const int r = row0 + SP_PREP_ROWS + rr;
-                w[(tr + 1) & 1][rr] = (r < rows && mine) ? load4(mq + (size_t)(r - row_base) * qpr + lane) : make_uint4(0u, 0u, 0u, 0u);
+        for (int u = 0; u < SP_PREP_LOADS; ++u) {
+            const int p = p0 + u * 64 + lane;
+            if (p0 + u * 64 >= n_pieces) break;
+            const uint32_t m = piece_bits(nonzero_bytes(w[u].x), nonzero_bytes(w[u].y), nonzero_bytes(w[u].z), nonzero_bytes(w[u].w));
+            if (p < n_pieces) {
+                if (bits) bits[p] = m;
+                s_c[wave][p] = (uint32_t)__popc(m & sel[0]) | ((uint32_t)__popc(m & sel[1]) << 8) | ((uint32_t)__popc(m & sel[2]) << 16)
+                               | ((uint32_t)__popc(m & sel[3]) << 24);
             }
         }
+    }
+    __syncthreads();
+    // four lanes per row: bytes -> two words of 16-bit fields (a row's count is at most 1024), summed over the row's pieces
+    const int row_l = lane >> 2, sub = lane & 3;
+    uint32_t a0 = 0u, a1 = 0u;
+    if (row_l < n_rows)
+        for (int i = sub; i < qpr; i += 4) {
+            const uint32_t c = s_c[wave][row_l * qpr + i];
+            a0 += (c & 0xffu) | ((c & 0xff00u) << 8);
+            a1 += ((c >> 16) & 0xffu) | ((c >> 8) & 0xff0000u);
+        }
+    a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64);
+    a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64);
+    if (sub == 0 && row_l < n_rows) {
+        const int row = row_base + row_l, r = row % t.H;
+        const int cnt[SP_PREP_MAX_STRIDES] = {(int)(a0 & 0xffffu), (int)(a0 >> 16), (int)(a1 & 0xffffu), (int)(a1 >> 16)};
 #pragma unroll
-        for (int rr = 0; rr < SP_PREP_ROWS; ++rr) {
-            const uint4 v = w[tr & 1][rr];
-            const uint32_t m = piece_bits(nonzero_bytes(v.x), nonzero_bytes(v.y), nonzero_bytes(v.z), nonzero_bytes(v.w));
-            if (bits && mine && row0 + rr < rows) bits[(size_t)(row0 + rr - row_base) * qpr + lane] = m;
-            const int a = ((tr & 1) * SP_PREP_ROWS + rr) * 2;
-            acc[a] = (uint32_t)__popc(m & sel[0]) | ((uint32_t)__popc(m & sel[1]) << 16);
-            acc[a + 1] = (uint32_t)__popc(m & sel[2]) | ((uint32_t)__popc(m & sel[3]) << 16);
-        }
-        if (tr & 1) {
-            int pos;
-            bool ok;
-            wave_sum_to_lanes<2 * SP_PREP_ROWS * 2>(acc, lane, pos, ok);
-            const int row = row0 - SP_PREP_ROWS + (pos >> 1), k = 2 * (pos & 1);
-            if (ok && row < rows) {
-                const int r = row % t.H;
-                if (k < t.n_strides) t.row_counts[k][row] = (r % t.stride[k] == 0) ? (int)(acc[0] & 0xffffu) : 0;
-                if (k + 1 < t.n_strides) t.row_counts[k + 1][row] = (r % t.stride[k + 1] == 0) ? (int)(acc[0] >> 16) : 0;
-            }
-        }
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+            if (k < t.n_strides) t.row_counts[k][row] = (r % t.stride[k] == 0) ? cnt[k] : 0;
     }
 }
 
@@ -403,6 +404,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
 // paths in one cost the fast one its occupancy (138 vector registers against 56) -- on a bounded grid per keyframe whose waves
 // walk the rows, so that the launch costs nothing when every keyframe is on the fast path.
 #define SP_PREP_GENERAL_BLOCKS 64
+#define SP_PREP_ROWS 4
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts_general(const SpPrepTable* __restrict__ tables) {
     const PrepTable& t = table_of(tables, blockIdx.y);
     if (prep_fast_path(t)) return;
@@ -482,19 +484,22 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
     __shared__ int s_base[SP_PREP_MAX_STRIDES][SP_FILL_ROWS];       // first table position of the row per lattice, -1: not on the lattice
     __shared__ int s_cnt[SP_WAVES];
     const unsigned long long below = (1ull << lane) - 1ull;
-    {   // one thread per row: is it empty?  then a block-wide ordered compaction of the non-empty ones
+    {   // one thread per row: is it empty?  then a block-wide ordered compaction of the non-empty ones.  The row's start in every
+        // lattice's table is requested together with the counts that say whether it is empty (not after: one round trip to
+        // memory per workgroup less, for 24 bytes per row more)
         const int row = row_base + (int)threadIdx.x;
-        bool todo = row < rows && (int)threadIdx.x < SP_FILL_ROWS;
-        const int n = todo ? row / t.H : 0, r = row - n * t.H;
+        const bool in_range = row < rows && (int)threadIdx.x < SP_FILL_ROWS;
+        const int n = in_range ? row / t.H : 0, r = row - n * t.H;
+        int b[SP_PREP_MAX_STRIDES];
+#pragma unroll
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+            b[k] = (in_range && k < t.n_strides && r % t.stride[k] == 0) ? t.seg_off[k][n] + t.row_counts[k][row] : -1;
+        bool todo = in_range;
         if (todo && t.stride[0] == 1) {      // lattice 0 holds every mask pixel: its row count says whether the row is empty
             const SP_GLOBAL int32_t* rc = t.row_counts[0];
             const int next = (r + 1 < t.H) ? rc[row + 1] : t.counts[0][n];
             todo = next != rc[row];
         }
-        int b[SP_PREP_MAX_STRIDES];
-#pragma unroll
-        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
-            b[k] = (todo && k < t.n_strides && r % t.stride[k] == 0) ? t.seg_off[k][n] + t.row_counts[k][row] : -1;
         const unsigned long long bal = __ballot(todo);
         if (lane == 0) s_cnt[wave] = __popcll(bal);
         __syncthreads();
@@ -582,19 +587,23 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
         __shared__ uint32_t s_wsum[2][SP_WAVES];
         __shared__ int s_delta[SP_PREP_MAX_STRIDES][SP_FILL_BATCH];
         constexpr int ROWS_PER_WAVE = SP_FILL_BATCH / SP_WAVES;
-        for (int s0 = 0; s0 < s_n; s0 += SP_FILL_BATCH) {
-            const int nb = min(SP_FILL_BATCH, s_n - s0);
-            __syncthreads();                         // (the previous batch is done with s_bits / s_list)
-            // (a) + (b): every wave for its own ROWS_PER_WAVE rows of the batch
-            uint32_t bw[ROWS_PER_WAVE];
+        // (a) + (b): every wave for its own ROWS_PER_WAVE rows of the batch; the words of the NEXT batch are requested as soon as
+        // this one's are in LDS
+        uint32_t bw[ROWS_PER_WAVE];
+        auto request_bits = [&](int s0) {
 #pragma unroll
             for (int i = 0; i < ROWS_PER_WAVE; ++i) {
-                const int sl = wave * ROWS_PER_WAVE + i;
-                bw[i] = (sl < nb && lane < qpr) ? bits_p[(size_t)s_rows[s0 + sl] * qpr + lane] : 0u;
+                const int sl = s0 + wave * ROWS_PER_WAVE + i;
+                bw[i] = (sl < min(s0 + SP_FILL_BATCH, s_n) && lane < qpr) ? bits_p[(size_t)s_rows[sl] * qpr + lane] : 0u;
             }
+        };
+        request_bits(0);
+        for (int s0 = 0; s0 < s_n; s0 += SP_FILL_BATCH) {
+            __syncthreads();                         // (the previous batch is done with s_bits / s_list)
 #pragma unroll
             for (int i = 0; i < ROWS_PER_WAVE; ++i) s_bits[wave * ROWS_PER_WAVE + i][lane] = bw[i];
             __syncthreads();
+            if (s0 + SP_FILL_BATCH < s_n) request_bits(s0 + SP_FILL_BATCH);
             int n_w = 0;
 #pragma unroll 4
             for (int it = 0; it < ROWS_PER_WAVE * 2; ++it) {
@@ -899,7 +908,7 @@ static int check_grid(long x, long y) { return (x <= 0 || y <= 0 || y > 65535) ?
 int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int per_block = SP_WAVES * SP_PREP_ROWS * SP_PREP_TRIPS;
+    const int per_block = SP_WAVES * SP_PREP_WAVE_ROWS;
     hipLaunchKernelGGL(k_prep_row_counts, dim3((max_rows + per_block - 1) / per_block, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     const int general_rows = SP_WAVES * SP_PREP_ROWS;
