@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import os
 import queue
+import sys
 import threading
 import time
 
@@ -103,13 +104,14 @@ class PairStream:
                     batch.run_scheduled(**self.schedule)
                     if self.trace is not None:
                         self.trace.append(("optimise", idx, t0, time.perf_counter()))
-                    poses, klds = batch.poses().clone(), [k.clone() for k in batch.klds()]
+                    # (one copy of the flat log-depth array, handed out as per-pair views: a clone per pair is M launches)
+                    poses, kld_flat = batch.poses().clone(), batch.kld.clone()
+                    klds = [kld_flat[batch.n_off[m]: batch.n_off[m + 1]] for m in range(batch.M)]
                     # the results were allocated in this stream's pool and are consumed on the caller's stream: tell the
                     # allocator, so that a block the caller drops is not handed to a later batch's clone() while
                     # caller-stream work on it is still queued
                     poses.record_stream(caller)
-                    for k in klds:
-                        k.record_stream(caller)
+                    kld_flat.record_stream(caller)
                     done = torch.cuda.Event()
                     done.record(stream)
                 # the batch (allocated on the set-up stream, used on this stream) is released only after the optimiser has
@@ -150,10 +152,15 @@ class PairStream:
                 errors.append(e)
 
         threads = [threading.Thread(target=worker, args=(st,), daemon=True) for st in self.optim_streams]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+        switch_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(switch_interval, 2e-4))           # (see run())
+        try:
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        finally:
+            sys.setswitchinterval(switch_interval)
         if errors:
             raise errors[0]
 
@@ -169,6 +176,11 @@ class PairStream:
         K = len(self.optim_streams)
         workers = [threading.Thread(target=self._producer, args=(inputs, built_q, ready, stop, K), daemon=True)]
         workers += [threading.Thread(target=self._optimiser, args=(st, built_q, results, caller, stop), daemon=True) for st in self.optim_streams]
+        # The producer is interpreter-bound for milliseconds at a time (a few thousand tensor handles per batch) and CPython hands
+        # the GIL over only every sys.getswitchinterval() = 5 ms: an optimiser thread that has just come back from the native
+        # schedule loop would wait that long before it can even take the next batch (measured: a 7 ms hole after every batch).
+        switch_interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(switch_interval, 2e-4))
         for w in workers:
             w.start()
         try:
@@ -190,6 +202,7 @@ class PairStream:
                 else:
                     pending[got[0]] = got[1:]
         finally:                            # also when the caller abandons the generator early
+            sys.setswitchinterval(switch_interval)
             stop.set()
             for w in workers:
                 w.join(timeout=60)

@@ -28,19 +28,23 @@ def make_items(per_batch, n_batches, distinct_batches):
 
 import gc
 
-for per_batch, n_batches, distinct in ((384, 8, 2), (128, 16, 3)):
+CONFIGS = ((384, 8, 2), (128, 16, 3))
+if len(sys.argv) > 1:                  # e.g.  stream_bench.py 384   (only the batch size given)
+    CONFIGS = tuple(c for c in CONFIGS if c[0] == int(sys.argv[1]))
+GRAN = int(os.environ.get('SP_GRANULE', '64'))
+for per_batch, n_batches, distinct in CONFIGS:
     items = make_items(per_batch, n_batches, distinct)
     for k in (0, 1, 2, 3):
         label = "sequential" if k == 0 else f"pipelined, {k} optimiser stream{'s' if k > 1 else ''}"
         # one long-lived PairStream at a time (its streams' allocator pools are reused from batch to batch; the pools of a
         # discarded one are returned to the device before the next configuration runs)
-        pipe = None if k == 0 else PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE, optimisers=k, depth=max(1, k - 1))
+        pipe = None if k == 0 else PairStream(levels=(0, 3), schedule=FRAME_PAIR_SCHEDULE, optimisers=k, depth=max(1, k - 1), granule=GRAN)
         for rep in range(3):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             if pipe is None:
                 for it in items:
                     b = PairBatch(it["src_frames"], it["trg_images"], it["trg_Ks"], it["poses"], it["klds"], levels=(0, 3),
-                                  point_stride=FRAME_PAIR_POINT_STRIDE)
+                                  point_stride=FRAME_PAIR_POINT_STRIDE, granule=GRAN)
                     b.run_scheduled(**sk)
                     res = (b.poses().clone(), [k_.clone() for k_ in b.klds()])
                 del b
