@@ -593,10 +593,11 @@ def main(argv=None):
             #     second HIP stream (optim.pair_stream.PairStream): 4 batches of the same raw frames
             from super_primitive_amd.optim.pair_stream import PairStream
             item = dict(src_frames=frames, trg_images=[r["trg"] for r in raw], trg_Ks=[r["K"] for r in raw], poses=poses0, klds=[r["kld"] for r in raw])
-            for key, n_opt, n_b in (("pipelined_pairs_per_sec", 1, 4), ("continuous_batching_pairs_per_sec", 2, 8)):
-                # n_opt = 2: two batches run their schedules at the same time on two HIP streams -- the bulk of one fills the
-                # tail of the other (optim/pair_stream.py); sustained over n_b batches back to back, set-up included
-                pipe = PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, tile_points=args.tile_points, optimisers=n_opt, granule=args.granule)
+            for key, n_opt, n_b in (("pipelined_pairs_per_sec", 1, 8), ("continuous_batching_pairs_per_sec", 3, 8)):
+                # n_opt = 3: three batches run their schedules at the same time on their own HIP streams -- the bulk of one fills
+                # the tail of the others (optim/pair_stream.py); sustained over n_b batches back to back, set-up included
+                pipe = PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, tile_points=args.tile_points, optimisers=n_opt, depth=max(1, n_opt - 1),
+                                  granule=args.granule)
                 for _ in range(2):                           # (first pass: the streams' allocator pools fill)
                     sync()
                     t1 = time.perf_counter()
@@ -606,6 +607,8 @@ def main(argv=None):
                     line["from_raw_frames"][key] = n_b * n_raw / (time.perf_counter() - t1)
                 del pipe, _res
                 torch.cuda.empty_cache()         # (the dead streams' allocator pools go back to the device)
+            # sustained over 8 batches back to back through PairStream (set-up of the next batches overlapped with three schedules in flight)
+            line["frame_pairs_per_sec_from_raw_frames_sustained"] = line["from_raw_frames"]["continuous_batching_pairs_per_sec"]
             del raw, frames, base, item
             # (e') continuous batching of the optimisation alone: 8 scheduled runs back to back over 4 resident batches (distinct
             #      device copies of this rank's pairs, all set up beforehand), on one stream and with 2 / 3 batches in flight on

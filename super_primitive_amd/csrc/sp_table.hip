@@ -156,8 +156,15 @@ __device__ __forceinline__ SourceGeom source_geometry(uint32_t pix_word, float L
 }
 
 // bilinear sample of one pyramid level at that position: {r, g, b, L}.  Taps outside the level read as zero (grid_sample's zeros
-// padding); the addresses are clamped into the level and the value selected afterwards, so the twelve loads of a point have no
-// control flow between them and those of several points can be in flight together.
+// padding); the addresses are clamped into the level and the value selected afterwards, so the loads of a point have no control
+// flow between them and those of several points can be in flight together.  The two taps of an image row come from ONE 8-byte
+// load (levels at least 2 pixels wide): 6 load instructions per point and level instead of 12.
+struct Tap2 { float a, b; };
+__device__ __forceinline__ Tap2 load_tap2(const float* p) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2), aligned(4)));
+    const f32x2_t v = *reinterpret_cast<const f32x2_t*>(p);
+    return Tap2{v.x, v.y};
+}
 __device__ __forceinline__ float4 source_sample(const SourceGeom& g, const float* __restrict__ img, int Hl, int Wl) {
     const float ix = __fmul_rn(__fmul_rn(__fadd_rn(g.xn, 1.f), 0.5f), (float)(Wl - 1));
     const float iy = __fmul_rn(__fmul_rn(__fadd_rn(g.yn, 1.f), 0.5f), (float)(Hl - 1));
@@ -165,13 +172,34 @@ __device__ __forceinline__ float4 source_sample(const SourceGeom& g, const float
     const int x0 = (int)fx0, y0 = (int)fy0;
     const float wx = ix - fx0, wy = iy - fy0;
     const bool xa = x0 >= 0 && x0 < Wl, xb = x0 + 1 >= 0 && x0 + 1 < Wl, ya = y0 >= 0 && y0 < Hl, yb = y0 + 1 >= 0 && y0 + 1 < Hl;
-    const int xc0 = min(max(x0, 0), Wl - 1), xc1 = min(max(x0 + 1, 0), Wl - 1), yc0 = min(max(y0, 0), Hl - 1), yc1 = min(max(y0 + 1, 0), Hl - 1);
-    const int i00 = yc0 * Wl + xc0, i01 = yc0 * Wl + xc1, i10 = yc1 * Wl + xc0, i11 = yc1 * Wl + xc1;
+    const int yc0 = min(max(y0, 0), Hl - 1), yc1 = min(max(y0 + 1, 0), Hl - 1);
     float rgb[3];
+    if (Wl >= 2) {
+        // the pair of columns (xs, xs + 1) inside the row that holds whichever of x0, x0 + 1 exist: x0 itself unless x0 is the last
+        // column (then x0 is the pair's second entry) or the column left of the first (then x0 + 1 is its first)
+        const int xs = min(max(x0, 0), Wl - 2);
+        const bool at = x0 == xs;
+        const int i0 = yc0 * Wl + xs, i1 = yc1 * Wl + xs;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float* pl = img + (size_t)ch * Hl * Wl;
+            const Tap2 t0 = load_tap2(pl + i0), t1 = load_tap2(pl + i1);
+            const float nw = (xa && ya) ? (at ? t0.a : t0.b) : 0.f, ne = (xb && ya) ? (at ? t0.b : t0.a) : 0.f;
+            const float sw = (xa && yb) ? (at ? t1.a : t1.b) : 0.f, se = (xb && yb) ? (at ? t1.b : t1.a) : 0.f;
+            // same weight products and summation order as ATen's grid_sampler_2d (nw, ne, sw, se)
+            float acc = nw * ((1.f - wx) * (1.f - wy));
+            acc += ne * (wx * (1.f - wy));
+            acc += sw * ((1.f - wx) * wy);
+            acc += se * (wx * wy);
+            rgb[ch] = acc;
+        }
+        return make_float4(rgb[0], rgb[1], rgb[2], g.L);
+    }
+    const int xc0 = min(max(x0, 0), Wl - 1), xc1 = min(max(x0 + 1, 0), Wl - 1);
+    const int i00 = yc0 * Wl + xc0, i01 = yc0 * Wl + xc1, i10 = yc1 * Wl + xc0, i11 = yc1 * Wl + xc1;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const float* pl = img + (size_t)ch * Hl * Wl;
-        // same weight products and summation order as ATen's grid_sampler_2d (nw, ne, sw, se)
         const float t00 = pl[i00], t01 = pl[i01], t10 = pl[i10], t11 = pl[i11];
         const float nw = (xa && ya) ? t00 : 0.f, ne = (xb && ya) ? t01 : 0.f, sw = (xa && yb) ? t10 : 0.f, se = (xb && yb) ? t11 : 0.f;
         float acc = nw * ((1.f - wx) * (1.f - wy));
