@@ -959,7 +959,7 @@ int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int m
 
 int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream) {
     if (!jobs || check_grid(max_P, n_jobs)) return SP_EINVAL;
-    constexpr int K = 2;               // points per thread (1: 2.17 ms, 2: 1.98 ms, 4: 2.18 ms for 384 pairs of 640x480x64)
+    constexpr int K = 4;               // points per thread (384 pairs of 640x480x64: 1 -> 1.86 ms, 2 -> 1.46-1.51, 3 -> 1.40, 4 -> 1.40-1.42)
     const long per_job = (max_P + SP_BLOCK * K - 1) / (SP_BLOCK * K), total = per_job * n_jobs;
     if (total + 7 > 0x7fffffffL) return SP_ELIMIT;
     hipLaunchKernelGGL((k_prep_sample<K>), dim3((unsigned)((total + 7) / 8 * 8)), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs, (int)per_job, (int)total);
