@@ -23,9 +23,13 @@ timeout 300 python tools/sigma05_sweep.py --size 240x320x8 --scenes 12 --variant
 timeout 400 python tools/sigma05_sweep.py --size 480x640x64 --scenes 64 --seed0 1000 --variants r02,pose1st,pose1st_10,pose1st_25,pose1st_allpts,pose1st_L4,L4,it40,tol5e-4,lam1e-2,eps1e-2 > $OUT/sigma05_sweep_full.txt 2>/dev/null
 timeout 400 python tools/run_configs.py 2>/dev/null | grep config > $OUT/configs.txt
 timeout 300 python tools/stream_bench.py 2>&1 | grep batches > $OUT/stream_bench.txt
-timeout 200 python tools/setup_bench.py 2>/dev/null | grep SP_FILL > $OUT/setup.txt
+SP_GRANULE=64 timeout 200 python tools/setup_bench.py 2>/dev/null | grep "set-up\|timeline" > $OUT/setup.txt
 timeout 200 python tools/setup_profile.py 128 2>/dev/null | grep "PairBatch of\|run_scheduled\|build:" >> $OUT/setup.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_setup -o setup -- python tools/setup_profile.py 128 > /dev/null 2>&1
+# where the set-up kernels' wave cycles go (SQ counters, their own passes, --kernel-trace only)
+(cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d /tmp/pmcA -o x -- python $GRAFT_REPO_ROOT/tools/setup_profile.py 128 > /dev/null 2>&1)
+(cd /tmp && timeout 200 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d /tmp/pmcB -o x -- python $GRAFT_REPO_ROOT/tools/setup_profile.py 128 > /dev/null 2>&1)
+(python tools/pmc_summary.py /tmp/pmcA k_prep; python tools/pmc_summary.py /tmp/pmcB k_prep) > $OUT/setup_pmc.txt 2>&1
 timeout 200 python tools/kbench.py --pairs 384 --tile-points 8192 --modes 1,16,1,16,1,16,0 --reps 40 2>/dev/null | grep level > $OUT/kbench_pixless.txt
 # package power and shader clock across a 12 s run of the bench step
 (python bench.py --steps 12000 --warmup 10 --no-cpu-baseline --no-extras --no-pmc > $OUT/bench_long.json 2>/dev/null &)

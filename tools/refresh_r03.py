@@ -11,7 +11,7 @@ pairs = [("bench_n1.json", "bench_n1.json"), ("bench_n1_g256.json", "bench_n1_gr
          ("stats_blobs_1200_g256/bench_kernel_stats.csv", "bench_blobs_1200_g256_kernel_stats.csv"),
          ("stats_setup/setup_kernel_stats.csv", "setup_kernel_stats.csv"), ("configs.txt", "configs.txt"), ("parity.txt", "parity.txt"),
          ("sigma05_sweep_small.txt", "sigma05_sweep_320x240x8.txt"), ("sigma05_sweep_full.txt", "sigma05_sweep_640x480x64.txt"),
-         ("stream_bench.txt", "stream_bench.txt"), ("setup.txt", "setup.txt"), ("kbench_pixless.txt", "kbench_pixless.txt"),
+         ("stream_bench.txt", "stream_bench.txt"), ("setup.txt", "setup.txt"), ("setup_pmc.txt", "setup_pmc.txt"), ("kbench_pixless.txt", "kbench_pixless.txt"),
          ("kbench_granule_ab.txt", "kbench_granule_ab.txt"), ("power_clock_trace.txt", "power_clock_trace.txt")]
 for N in (64, 300, 1200):
     for G in (256, 64):
