@@ -336,7 +336,8 @@ int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, f
 
 /* The host loop of a scheduled run, natively: issues (sp_pairs_schedule_cost, sp_pairs_schedule_gn_step) up to max_rounds times and,
  * every check_every iterations, reads min(phase) back (one tiny kernel, a 4-byte copy into flag_host -- PINNED host memory -- and a
- * synchronisation of `stream` only) to stop once every pair has finished.  One foreign call per scheduled run instead of ~100: a
+ * synchronisation of `stream` only) to stop once every pair has finished; work lists whose phases all lie behind that minimum are
+ * no longer launched (pairs only move forward).  One foreign call per scheduled run instead of ~100: a
  * Python caller issues nothing per iteration, so several batches can run their schedules from several host threads without
  * contending for the interpreter lock (optim/pair_stream.py), and the launch-bound tail of a schedule runs at the rate of the
  * runtime's launch path.  flag_dev: one int32 of device scratch.  Returns the number of iterations launched (>= 0), SP_EINVAL, or

@@ -1182,7 +1182,14 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
     return 0;
 }
 
-int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) {
+int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) { return schedule_cost_from(sched, phase, stream, 0); }
+
+}  // extern "C"
+
+// first_phase: a phase every pair is known to have reached (pairs only move forward): work lists none of whose phases is at or
+// beyond it have no pair left and are not launched -- two of the three launches of a frame-pair schedule's iteration through
+// its long tail (sp_pairs_schedule_run).
+int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase) {
     if (!sched || !phase || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
     for (int p = 0; p < sched->n_phases; ++p) {
         const SpPhase& ph = sched->phase[p];
@@ -1206,6 +1213,7 @@ int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* 
             f.sched.mask |= 1u << q;
         }
         launched |= f.sched.mask;
+        if ((f.sched.mask >> first_phase) == 0u) continue;          // (every phase of this work list lies behind all pairs)
         if (lead.flags & SP_PHASE_WAVE_SPANS) {
             const int gw = ((((lead.n_spans + 3) / 4) + 7) / 8) * 8;
             hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), lead.pairs,
@@ -1222,6 +1230,8 @@ int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* 
     }
     return 0;
 }
+
+extern "C" {
 
 int sp_pairs_adam_iterate(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, int n_pairs, int max_N,
                           float* partials, float* seg_partials, int32_t* arrivals, float lr_kld, float lr_pose, float lr_aff, float* state,

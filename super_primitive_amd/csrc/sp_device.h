@@ -37,6 +37,10 @@ __device__ __forceinline__ float fast_exp(float x) {
         if (e__ != hipSuccess) return (int)e__;    \
     } while (0)
 
+// sp_pairs_schedule_cost() from a phase every pair is known to have reached (sp_cost.hip; used by sp_pairs_schedule_run in sp_solver.hip)
+struct SpSchedule;
+__attribute__((visibility("hidden"))) int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase);
+
 // ---------------------------------------------------------------------------------------------------
 // wave64 / block reductions (fixed order -> bitwise reproducible run to run)
 // ---------------------------------------------------------------------------------------------------
