@@ -300,8 +300,9 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
  * is finished at phase n_phases.  phase[n_pairs] / iters[n_pairs] (int32, zeroed by the caller) hold every pair's position; the
  * host only issues (sp_pairs_schedule_cost, sp_pairs_schedule_gn_step) until min(phase) == n_phases.  Pairs advance
  * independently: one slow pair no longer keeps the others at a coarse level, and finished pairs cost nothing.
- * sp_pairs_schedule_cost launches the Gauss-Newton cost kernel once per DISTINCT work list (phases sharing `spans` share the
- * launch); partial buffers of different work lists must not alias.  The struct lives in host memory. */
+ * sp_pairs_schedule_cost runs the Gauss-Newton cost pass over every DISTINCT work list (phases sharing `spans` share the list) in
+ * ONE launch -- up to four lists of the same kind (wave spans or workgroup spans), one after the other in block order; otherwise a
+ * launch per list; partial buffers of different work lists must not alias.  The struct lives in host memory. */
 #define SP_MAX_PHASES 8
 /* SP_PHASE_POSE_ONLY: the phase moves the pose alone, the log-depths stay where they are (the solver skips the Schur complement
  * and the depth update; the cost pass is unchanged).  From the reference's own starting distribution (pose off by SE3.Random(sigma =
