@@ -1238,6 +1238,7 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
     for (int p = 0; p < sched->n_phases; ++p) {
         if ((seen >> p) & 1u) continue;
         const SpPhase& lead = sched->phase[p];          // first phase of a work list
+        if (lead.n_spans == 0) continue;                // an empty point set (every segment smaller than the lattice stride)
         uint32_t mask = 0;
         for (int q = p; q < sched->n_phases; ++q) {
             const SpPhase& ph = sched->phase[q];
@@ -1247,7 +1248,6 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
             mask |= 1u << q;
         }
         seen |= mask;
-        if (lead.n_spans == 0) continue;                // an empty point set (every segment smaller than the lattice stride)
         if ((mask >> first_phase) == 0u) continue;      // (every phase of this work list lies behind all pairs)
         leads[n_leads++] = Lead{p, mask};
     }
