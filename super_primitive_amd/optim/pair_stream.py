@@ -7,9 +7,9 @@ with the other batch's work: a producer builds ``PairBatch`` objects one batch a
 the schedule on the optimisation stream, an event orders "built" before "optimise", and a batch's arrays stay referenced until
 its results have been read.  Frame pairs are independent problems, so nothing else is shared.
 
-Measured (tools/stream_bench.py, 640x480x64 pairs from raw frames, a long-lived PairStream): +14 ... +16 % at 64-128 pairs per
-batch, nothing at 384 (where one batch alone already keeps the GPU busy) -- both halves are mostly GPU-bound, so the overlap only
-recovers idle gaps.
+Measured (round 3, profiles/r03_stream_bench.txt: 640x480x64 pairs from raw frames, distinct frames per batch, a long-lived
+PairStream): 384 pairs per batch 17.1 k pairs/s one batch at a time, 18.2 / 20.9 / 21.2 k with 1 / 2 / 3 schedules in flight
+(``optimisers``); 128 pairs per batch 13.8 k -> 19.9 k.  In bench.py (the same frames every batch) 21.9 k -> 24-26 k.
 """
 from __future__ import annotations
 
