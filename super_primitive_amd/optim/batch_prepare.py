@@ -227,7 +227,9 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     for m in masks:
         assert m.dtype == torch.bool and m.dim() == 3
     _lib.require_device(*masks)
-    shp = np.array([m.shape for m in masks], dtype=np.int64)                     # (M0, 3): N, H, W
+    shape0 = masks[0].shape                                                      # (M0, 3): N, H, W
+    shp = (np.tile(np.array(shape0, dtype=np.int64), (M0, 1)) if all(m.shape == shape0 for m in masks)
+           else np.array([m.shape for m in masks], dtype=np.int64))
     Ns, Hs, Ws = shp[:, 0], shp[:, 1], shp[:, 2]
     if (Hs > 32767).any() or (Ws > 65535).any():
         raise ValueError("image too large for the packed pixel word")
