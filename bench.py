@@ -210,6 +210,24 @@ def _cpu_leg(pair, levels, iters, threads):
         torch.set_num_threads(prev)
 
 
+def _host_identity():
+    """What the CPU baseline ran on: logical CPUs visible to this process (nproc), the CPU model string, torch's default thread count."""
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        nproc = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nproc = os.cpu_count() or 1
+    return {"nproc": nproc, "os_cpu_count": os.cpu_count(), "cpu_model": model, "torch_default_threads": torch.get_num_threads()}
+
+
 def _stats(times):
     r = 1.0 / np.asarray(times)
     return {"median": float(np.median(r)), "p10": float(np.percentile(r, 10)), "p90": float(np.percentile(r, 90))}
@@ -228,9 +246,11 @@ def cpu_baseline(pair2, iters):
     c2 = legs[threads]
     c1 = _cpu_leg(pair1, [2, 1, 0], iters, threads)
     c1_one = _stats(_cpu_leg(pair1, [0], iters, 1)[0])
+    c2_one = _stats(_cpu_leg(pair2, [0], max(3, iters // 3), 1)[0])           # config 2 on ONE thread as well
     c1_levels = {f"level{l}": _stats(v) for l, v in c1.items()}
     sched = 500 * sum(float(np.median(v)) for v in c1.values())              # the reference's 500 Adam iterations per level
     return {"value": c2["median"], "p10": c2["p10"], "p90": c2["p90"], "unit": "iters/s", "cores": threads, "kind": "port",
+            "host": _host_identity(), "threads_used": threads, "config2_640x480x64_one_thread_level0": c2_one,
             "sample": f"3 warm-up + {iters} timed Adam iterations (dense-layout cost + autograd backward + Adam.step, the reference's "
                       f"algorithm restated in oracle/) of ONE 640x480x64 pair at level 0, torch CPU, {threads} threads; median (p10, p90)",
             "config2_by_threads": {str(t): v for t, v in legs.items()},

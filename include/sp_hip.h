@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 8
+#define SP_ABI_VERSION 9
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -424,24 +424,43 @@ int sp_window_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, 
  * log-depth"; the reference's loops it accelerates: odometery/odometery.py:375-407 tracking -- 6 pose + 2 affine unknowns, keyframe
  * depths fixed -- and :756-915 windowed mapping -- K poses + sum N log-depths + affines, first keyframe fixed (:589-592), oldest
  * depths frozen (:594-603), fold-in T <- T inv(Exp(D)) + renormalise_se3 after the step (:861-882)).  One iteration =
- *     sp_pairs_cost(mode 2, irls_eps) over all edges  ->  sp_window_gn_step                       (3 launches, no host sync)
- * Unknowns: the pose tangent of every node with lr_pose > 0, the affine pair of every node with lr_aff > 0 (at most 128 scalars
- * together, the reduced camera system is solved in LDS in fp64), the log-depths of every block with lr > 0 (eliminated by a Schur
- * complement, like the per-pair solver).  flags bit 0: pose-only step (all depth blocks treated as frozen).
+ *     sp_pairs_cost(mode 2, irls_eps) over all edges  ->  sp_window_gn_step                       (4 launches, no host sync)
+ * Unknowns: the pose tangent of every node with lr_pose > 0, the affine pair of every node with lr_aff > 0 (the reduced camera system,
+ * fp64: in LDS as a packed triangle up to 192 scalars -- the reference's own window, config/tum/odom_desk.yaml window_size 5 with two
+ * supporting frames per keyframe and two running ones, all poses and affine pairs free (odometery.py:523-575,611-616), is 14 free
+ * nodes = 112 -- and through global scratch up to 512 = 64 nodes), the log-depths of every block with lr > 0 (eliminated by a Schur
+ * complement, like the per-pair solver; a depth unknown of keyframe k only couples with the frames k is matched against, and only
+ * those columns are stored and summed).  No camera unknown at all is allowed (the 'supp' mapping of odometery.py:576-648: only the
+ * latest keyframe's depths are free).  flags bit 0: pose-only step (all depth blocks treated as frozen).
  * LM: lambda adapts on the device exactly like sp_pairs_gn_step (loss up -> previous step undone from nodes_backup / kld_backup,
- * lambda *= lm_up, re-evaluated next call; loss down -> lambda = max(lambda lm_down, lm_min)); conv_tol > 0: an accepted step that
+ * lambda *= lm_up, re-evaluated next call; loss down -> lambda = max(lambda lm_down, lm_min); a failed factorisation counts as a
+ * rejected step: lambda *= lm_up, the same point is evaluated and solved again); conv_tol > 0: an accepted step that
  * lowered the loss by less than conv_tol * loss freezes the window (later calls return at once), like the relative-loss break at
  * odometery.py:907-915.
+ * n_unknowns: the camera unknowns of the window (6 per node with lr_pose > 0 + 2 per node with lr_aff > 0), which sizes the scratch
+ *   and selects the kernel; a window that turns out to have more freezes with state[9] = 1.
  * state: 16 floats {lambda (set by the caller, e.g. 1e-4), loss at the last accepted point (init -1), accepted, rejected,
  *   rejected-last flag, iterations, converged flag, last loss, failed solves, too-many-unknowns flag, ...}; losses[max_losses]: loss of
- *   call i.  scratch: sp_window_gn_scratch_doubles(n_edges, sum_N, max_N) doubles; nodes_backup: n_nodes nodes; kld_backup: sum_N floats
- *   (blocks in order; sum_N = total log-depths of all blocks). */
-int sp_window_gn_scratch_doubles(int n_edges, int sum_N, int max_N);
+ *   call i.  scratch: sp_window_gn_scratch_doubles(n_edges, n_blocks, sum_N, max_N, n_unknowns) doubles; nodes_backup: n_nodes nodes;
+ *   kld_backup: sum_N floats (blocks in order; sum_N = total log-depths of all blocks). */
+int sp_window_gn_scratch_doubles(int n_edges, int n_blocks, int sum_N, int max_N, int n_unknowns);
+/* where in the scratch the update kernel leaves 16 time stamps of its phases (100 MHz ticks; diagnostics, tools/window_bench.py) */
+int sp_window_gn_profile_offset(int n_edges, int n_blocks, int sum_N, int max_N, int n_unknowns);
 int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes,
-                      const SpWindowBlock* blocks, int n_blocks, int sum_N, int max_N, const float* span_partials,
+                      const SpWindowBlock* blocks, int n_blocks, int sum_N, int max_N, int n_unknowns, const float* span_partials,
                       const float* seg_partials, double* scratch, SpWindowNode* nodes_backup, float* kld_backup, int flags,
                       float lm_up, float lm_down, float lm_min, float conv_tol, float* state, float* losses, int max_losses,
                       void* stream);
+
+/* Up to max_iters iterations -- sp_pairs_cost(mode 2, irls_eps) over the window's work list + sp_window_gn_step -- as ONE foreign call
+ * (the Python loop of optim/window.py run_gn): every check_every iterations the 16-float state is copied to state_host (pinned) and this
+ * stream synchronised; with conv_tol > 0 the loop ends once the window froze.  Returns the iterations launched (>= 0), SP_EINVAL, or
+ * -(1000 + hipError_t). */
+int sp_window_gn_run(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, float irls_eps,
+                     const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes, const SpWindowBlock* blocks, int n_blocks,
+                     int sum_N, int max_N, int n_unknowns, float* span_partials, float* seg_partials, double* scratch,
+                     SpWindowNode* nodes_backup, float* kld_backup, int flags, float lm_up, float lm_down, float lm_min, float conv_tol,
+                     float* state, float* losses, int max_losses, int max_iters, int check_every, float* state_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Helpers around the path

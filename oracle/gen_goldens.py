@@ -433,33 +433,41 @@ def golden_traj_map(ref, name, steps=30):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
-def reference_mapping_loop(ref, kfs, kf_poses, kf_klds, kf_affs, supp, steps, lr_pose, window_size, affine, initialised, lr_kld=1e-2, lr_aff=1e-5):
+def reference_mapping_loop(ref, kfs, kf_poses, kf_klds, kf_affs, supp, steps, lr_pose, window_size, affine, initialised, lr_kld=1e-2, lr_aff=1e-5, mode="map"):
     """The windowed mapping loop of odometery/odometery.py:576-648 (parameter groups), :451-479 (neighbour connectivity),
     :756-915 (iteration) restated around the REAL ``photomeric_cost_batch`` / ``renormalise_se3`` with ``opt_supporting``
     on; lietorch's Exp is replaced by the oracle's (parity unpinned at that boundary).
-    kfs: reference KeyFrames; kf_poses: camera-to-world (4,4); supp[k] = list of (KeyFrame, pose, affine)."""
+    kfs: reference KeyFrames; kf_poses: camera-to-world (4,4); supp[k] = list of (KeyFrame, pose, affine).
+    mode 'supp' (the supplementary mapping after every tracked frame, :1038-1042): only the latest keyframe is a source (:467-469), the
+    optimiser holds only ITS log-depths (:616-619; no pose group :586-588, no affine groups :628-629,634-635, supporting deltas are
+    plain identities :544-560)."""
     K = len(kfs)
     eye6 = lambda: torch.zeros(1, 6)
     kf_poses = [p.clone() for p in kf_poses]
-    d_kf = [None] + [torch.nn.Parameter(eye6()) for _ in range(K - 1)]                       # first keyframe fixed (:589-592)
-    if K == window_size:                                                                      # oldest depths frozen (:594-603)
+    supp_mode = mode == "supp"
+    d_kf = [None] + [None if supp_mode else torch.nn.Parameter(eye6()) for _ in range(K - 1)]       # first keyframe fixed (:589-592)
+    if supp_mode:
+        klds = [k.clone() for k in kf_klds[:-1]] + [torch.nn.Parameter(kf_klds[-1].clone())]
+    elif K == window_size:                                                                    # oldest depths frozen (:594-603)
         klds = [kf_klds[0].clone()] + [torch.nn.Parameter(k.clone()) for k in kf_klds[1:]]
     else:
         klds = [torch.nn.Parameter(k.clone()) for k in kf_klds]
-    affs = [kf_affs[0].clone()] + [torch.nn.Parameter(a.clone()) for a in kf_affs[1:]] if affine else [None] * K
+    par = (lambda x: x.clone()) if supp_mode else (lambda x: torch.nn.Parameter(x.clone()))
+    affs = [kf_affs[0].clone()] + [par(a) for a in kf_affs[1:]] if affine else [None] * K
     s_pose = [[p.clone() for _, p, _ in supp[k]] for k in range(K)]
-    s_delta = [[torch.nn.Parameter(eye6()) for _ in supp[k]] for k in range(K)]
-    s_aff = [[torch.nn.Parameter(a.clone()) for _, _, a in supp[k]] for k in range(K)] if affine else None
+    s_delta = [[None if supp_mode else torch.nn.Parameter(eye6()) for _ in supp[k]] for k in range(K)]
+    s_aff = [[par(a) for _, _, a in supp[k]] for k in range(K)] if affine else None
     groups = [{"params": [k for k in klds if isinstance(k, torch.nn.Parameter)], "lr": lr_kld},
               {"params": [d for d in d_kf if d is not None], "lr": lr_pose}]
-    if affine:
-        groups.append({"params": affs[1:], "lr": lr_aff})
-    groups.append({"params": [d for row in s_delta for d in row], "lr": lr_pose})
-    if affine:
-        groups.append({"params": [a for row in s_aff for a in row], "lr": lr_aff})
+    if not supp_mode:
+        if affine:
+            groups.append({"params": affs[1:], "lr": lr_aff})
+        groups.append({"params": [d for row in s_delta for d in row], "lr": lr_pose})
+        if affine:
+            groups.append({"params": [a for row in s_aff for a in row], "lr": lr_aff})
     opt = torch.optim.Adam(groups, lr=1e-3)
     mat = lambda d: torch.eye(4) if d is None else orc.se3_exp(d)[0]
-    conn = {s: [t for t in (s - 1, s + 1) if 0 <= t < K] for s in range(K)}
+    conn = {s: [t for t in (s - 1, s + 1) if 0 <= t < K] for s in range(K) if not (supp_mode and s != K - 1)}
     cfg = {"mode": "colour", "collect_stats": 0}
     losses, prev, stopped = [], float("inf"), -1
     for it in range(steps):
@@ -492,18 +500,23 @@ def reference_mapping_loop(ref, kfs, kf_poses, kf_klds, kf_affs, supp, steps, lr
             for k in range(K):
                 for j in range(len(s_pose[k])):
                     s_pose[k][j] = ref.la.renormalise_se3(s_pose[k][j] @ torch.linalg.inv(mat(s_delta[k][j])))
-                    s_delta[k][j].data.zero_()
+                    if s_delta[k][j] is not None:
+                        s_delta[k][j].data.zero_()
         if initialised:
             if abs(losses[-1] - prev) / prev < 1e-8:
                 stopped = it
                 break
             prev = losses[-1]
     det = lambda x: x.detach().clone()
+    if len({int(k.shape[0]) for k in klds}) > 1:            # (keyframes of a sequence differ in their segment count)
+        klds_out = np.array([det(k).numpy() for k in klds], dtype=object)
+    else:
+        klds_out = torch.stack([det(k) for k in klds]).numpy()
     return dict(losses=np.array(losses), stopped=np.array(stopped), kf_poses=torch.stack(kf_poses).numpy(),
-                klds=torch.stack([det(k) for k in klds]).numpy(),
+                klds=klds_out,
                 affs=torch.stack([det(a) for a in affs]).numpy() if affine else np.zeros((K, 2), np.float32),
-                supp_poses=torch.stack([p for row in s_pose for p in row]).numpy(),
-                supp_affs=torch.stack([det(a) for row in s_aff for a in row]).numpy() if affine else np.zeros((0, 2), np.float32))
+                supp_poses=torch.stack([p for row in s_pose for p in row]).numpy() if any(s_pose) else np.zeros((0, 4, 4), np.float32),
+                supp_affs=torch.stack([det(a) for row in s_aff for a in row]).numpy() if affine and any(s_aff) else np.zeros((0, 2), np.float32))
 
 
 def golden_traj_window(ref, name, steps=30):
@@ -521,6 +534,20 @@ def golden_traj_window(ref, name, steps=30):
         save.update({f"{tag}_{k}": v for k, v in out.items()})
         save.update({f"{tag}_cfg": np.array([n_kf, window, int(initialised), seed, steps]), f"{tag}_lr_pose": np.array(lr_pose),
                      f"{tag}_in_poses": np.stack(est), f"{tag}_in_klds": np.stack(klds), f"{tag}_in_affs": affs})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
+def golden_traj_supp(ref, name, steps=12):
+    """G9-e: the SUPPLEMENTARY mapping (odometery.py:1038-1042, mode 'supp'): 3 keyframes with one supporting frame each + two running
+    ones for the latest; only the latest keyframe is a source, only its log-depths are optimised, every pose and affine pair stays."""
+    frames, kfi, si, est, klds, affs = synth.reference_window_inputs(37, 3, 1, 2, H=48, W=64, N=6)
+    kfs = [ref.kf.KeyFrame(T(frames[i].image), T(frames[i].K), T(frames[i].logdepth_perseg), T(frames[i].keypoints),
+                           torch.from_numpy(frames[i].keypoint_regions.copy())) for i in kfi]
+    supp = [[(ref.kf.KeyFrame(T(frames[j].image), T(frames[j].K)), T(est[j]), T(affs[j])) for j in row] for row in si]
+    out = reference_mapping_loop(ref, kfs, [T(est[i]) for i in kfi], [T(k) for k in klds], [T(affs[i]) for i in kfi], supp, steps, 1e-4, 5,
+                                 True, True, mode="supp")
+    save = {f"supp_{k}": v for k, v in out.items()}
+    save.update(cfg=np.array([37, 3, 1, 2, 48, 64, 6, steps]), in_poses=np.stack(est), in_klds=np.stack(klds), in_affs=affs)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
@@ -616,7 +643,7 @@ def main():
     ref = import_reference()
     if len(sys.argv) > 1:                      # regenerate selected fixtures only: python oracle/gen_goldens.py g9d_traj_window
         for name in sys.argv[1:]:
-            {"g9d_traj_window": golden_traj_window}[name](ref, name)
+            {"g9d_traj_window": golden_traj_window, "g9e_traj_supp": golden_traj_supp}[name](ref, name)
         return
 
     p = synth.make_pair(48, 64, 6, seed=1)
@@ -657,6 +684,7 @@ def main():
     golden_converged(ref, "g12_converged_sfm")
     golden_helpers(ref, "g13_helpers")
     golden_traj_window(ref, "g9d_traj_window")
+    golden_traj_supp(ref, "g9e_traj_supp")
     print("wrote", sorted(os.listdir(OUT)))
 
 

@@ -324,6 +324,52 @@ def golden_config3_min(ref, name="g17min_config3_mapping_minimiser", seed=300):
           f"minimiser is {from_gt[0]:.1e} (pose entries) / {from_gt[1]:.1e} (log-depths) from the ground truth", flush=True)
 
 
+def golden_config3_window5_min(ref, name="g22min_config3_window5_minimiser", seed=300, n_supp=2, n_running=2):
+    """The MINIMISER of the reference's windowed-mapping cost on a window AT THE REFERENCE'S EXTENT (config/tum/odom_desk.yaml:
+    ``window_size: 5``, ``supp_every_n: 3`` -> two supporting frames per keyframe, odometery.py:1327-1360, plus the latest keyframe's
+    two running ones, ``opt_supporting`` and affine compensation on: 4 free keyframe poses + 10 free supporting poses, 14 affine pairs,
+    4 x 40 free log-depths; 28 photometric terms) at BASELINE configs[2] size, 224x288x40:
+    ``synth.reference_window_inputs(seed, 5, n_supp, n_running)``.  Like g17min: the reference loop (odometery.py:576-648,756-915 around
+    the real ``photomeric_cost_batch``) from the synthetic ground truth with decaying learning rates (fresh Adam per phase) until the
+    state stops moving; the fixed parts are exact (first keyframe pose, frozen oldest depths).  The Gauss-Newton window optimiser must
+    reach this point from the perturbed estimates of everything else (tests/test_gpu_window_gn.py)."""
+    from gen_goldens import reference_mapping_loop
+    H, W, N = 224, 288, 40
+    frames, kfi, si, est, klds, affs = synth.reference_window_inputs(seed, 5, n_supp, n_running, H=H, W=W, N=N)
+    t0 = time.time()
+    mk = lambda f: ref.kf.KeyFrame(T(f.image), T(f.K), T(f.logdepth_perseg), T(f.keypoints), torch.from_numpy(f.keypoint_regions.copy()))
+    kfs = [mk(frames[i]) for i in kfi]
+    supf = [[ref.kf.KeyFrame(T(frames[j].image), T(frames[j].K)) for j in row] for row in si]
+    flat = [j for row in si for j in row]
+    zero2 = np.zeros(2, np.float32)
+    state = dict(kf_poses=np.stack([frames[i].T_wc for i in kfi]), klds=np.stack([frames[i].kld_gt for i in kfi]), affs=np.stack([zero2] * 5),
+                 supp_poses=np.stack([frames[j].T_wc for j in flat]), supp_affs=np.stack([zero2] * len(flat)))
+    start = {k: v.copy() for k, v in state.items()}
+    losses, moved = [], None
+    # (twice g17min's phase lengths: the far end of a 5-keyframe chain is weakly constrained and Adam crawls along it -- with g17min's lengths
+    #  the end state was still 1e-4 in translation from where Gauss-Newton settles, at a HIGHER loss)
+    for lr_kld, lr_pose, lr_aff, steps in ((3e-3, 3e-4, 3e-4, 300), (1e-3, 1e-4, 1e-4, 300), (3e-4, 3e-5, 3e-5, 250), (1e-4, 1e-5, 1e-5, 200),
+                                           (3e-5, 3e-6, 3e-6, 150), (1e-5, 1e-6, 1e-6, 100)):
+        sup, q = [], 0
+        for k, row in enumerate(si):
+            sup.append([(supf[k][j], T(state["supp_poses"][q + j]), T(state["supp_affs"][q + j])) for j in range(len(row))])
+            q += len(row)
+        out = reference_mapping_loop(ref, kfs, [T(p) for p in state["kf_poses"]], [T(k) for k in state["klds"]], [T(a) for a in state["affs"]],
+                                     sup, steps, lr_pose, 5, True, False, lr_kld=lr_kld, lr_aff=lr_aff)
+        moved = (float(np.abs(out["kf_poses"] - state["kf_poses"]).max()), float(np.abs(out["klds"] - state["klds"]).max()))
+        state = {k: out[k] for k in state}
+        losses += list(out["losses"])
+        print(f"  {name} lr {lr_kld:g}/{lr_pose:g}: loss {out['losses'][0]:.8f} -> {out['losses'][-1]:.8f}, moved pose {moved[0]:.1e} kld {moved[1]:.1e} "
+              f"({time.time() - t0:.0f} s)", flush=True)
+    from_gt = (float(np.abs(state["kf_poses"] - start["kf_poses"]).max()), float(np.abs(state["klds"] - start["klds"]).max()))
+    save = dict(seed=np.array(seed), HWN=np.array([H, W, N]), window=np.array([5, n_supp, n_running]), losses=np.array(losses), last_phase_moved=np.array(moved),
+                distance_from_ground_truth=np.array(from_gt), spread40=np.array(np.ptp(losses[-40:])),
+                **{f"min_{k}": v for k, v in state.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: {time.time() - t0:.0f} s; final loss {losses[-1]:.8f}, spread of the last 40 losses {np.ptp(losses[-40:]):.1e}; "
+          f"minimiser is {from_gt[0]:.1e} (pose entries) / {from_gt[1]:.1e} (log-depths) from the ground truth", flush=True)
+
+
 def golden_config4(ref, name="g18_config4_void_shaped", seed=4, n_segments=1200):
     """BASELINE configs[3] shape (VOID-1500 depth completion, 480x640, ~1200 sparse-depth segments): the reference's
     per-image pipeline after the frontend (segment_based_completion.py:45-55) -- segment_based_depth_reinit (median),
@@ -410,7 +456,7 @@ SIGMA05_ARGS = dict(overlap=3, init_sigma=0.05, texture="octaves", init_mode="re
 CONVERGED_VS_GT = (2e-3, 2e-3, 2e-2)      # rot rad / t / relative depth against the synthetic ground truth (gauge removed)
 
 
-def golden_sigma05(ref, name="g19_sigma05_320x240x8", H=240, W=320, N=8, seeds=tuple(range(500, 512))):
+def golden_sigma05(ref, name="g19_sigma05_320x240x8", H=240, W=320, N=8, seeds=tuple(range(500, 512)), overlap=3):
     """the reference's OWN starting distribution -- pose_init = T_gt * Exp(0.05 randn(6))
     (two_frame_sfm.py:77-81), depth seeds log(2 + 2 rand) (:103-105) -- on a multi-octave (~1/f) texture, BASELINE configs[0]
     shape.  For every scene the real reference loop (3 x 500 Adam + polish) is run; stored per scene: input digest, state after
@@ -419,8 +465,8 @@ def golden_sigma05(ref, name="g19_sigma05_320x240x8", H=240, W=320, N=8, seeds=t
     t0 = time.time()
     rows = []
     for seed in seeds:
-        pair = synth.make_pair(H, W, N, seed=seed, **SIGMA05_ARGS)
-        r = reference_sfm_run(ref, pair)
+        pair = synth.make_pair(H, W, N, seed=seed, **dict(SIGMA05_ARGS, overlap=overlap))
+        r = reference_sfm_run(ref, pair, log=(f"{name} seed {seed}" if H * W > 100000 else None))
         e_gt = errors_vs(r["final_pose"], r["final_kld"], pair.pose_gt, pair.kld_gt)
         e_sched = errors_vs(r["sched_pose"], r["sched_kld"], pair.pose_gt, pair.kld_gt)
         e_init = errors_vs(pair.pose_init, pair.kld_init, pair.pose_gt, pair.kld_gt)
@@ -435,10 +481,11 @@ def golden_sigma05(ref, name="g19_sigma05_320x240x8", H=240, W=320, N=8, seeds=t
               f"{e_sched[2]:.1e} | polished ({int(r['polish_rounds'])} rounds, last moved {r['last_round_moved'][0]:.0e} {r['last_round_moved'][1]:.0e} {r['last_round_moved'][2]:.0e}) "
               f"{e_gt[0]:.1e} {e_gt[1]:.1e} {e_gt[2]:.1e} loss {r['final_loss']:.6f} spread {r['spread40']:.1e} "
               f"{'CONVERGED' if conv else 'not converged'} ({time.time() - t0:.0f} s)", flush=True)
-    save = {k: np.stack([np.asarray(r[k]) for r in rows]) for k in rows[0]}
-    save.update(HWN=np.array([H, W, N]), make_pair_args=np.array(f"H={H},W={W},N={N},overlap=3,init_sigma=0.05,texture=octaves,init_mode=reference"),
-                converged_vs_gt=np.array(CONVERGED_VS_GT), polish=np.array(POLISH))
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+        # (written after every scene: a full-size scene is the better part of an hour of CPU)
+        save = {k: np.stack([np.asarray(r[k]) for r in rows]) for k in rows[0]}
+        save.update(HWN=np.array([H, W, N]), make_pair_args=np.array(f"H={H},W={W},N={N},overlap={overlap},init_sigma=0.05,texture=octaves,init_mode=reference"),
+                    converged_vs_gt=np.array(CONVERGED_VS_GT), polish=np.array(POLISH))
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
     print(f"{name}: {time.time() - t0:.0f} s; converged {int(save['converged'].sum())} of {len(rows)}", flush=True)
 
 
@@ -468,13 +515,16 @@ def main():
         golden_config3(ref)
     if "g17min" in which:
         golden_config3_min(ref)
+    if "g22min" in which:
+        golden_config3_window5_min(ref)
     if "g18" in which:
         golden_config4(ref)
     if "g19" in which:
         golden_sigma05(ref)
     if "g20" in which:
-        # the same at BASELINE configs[1] size (640x480x64), two scenes: minutes of CPU each
-        golden_sigma05(ref, name="g20_sigma05_640x480x64", H=480, W=640, N=64, seeds=(1000, 1001))
+        # the same at BASELINE configs[1] size (640x480x64) on the first three scenes of bench.py's reference-start leg
+        # (bench.py:_render_sigma05: seeds 5000 + s, overlap 4; replica 0 of a scene starts from the pair's own pose_init / kld_init)
+        golden_sigma05(ref, name="g20_sigma05_640x480x64", H=480, W=640, N=64, seeds=(5000, 5001, 5002), overlap=4)
 
 
 if __name__ == "__main__":

@@ -13,10 +13,16 @@ import sys
 __version__ = "0.1.0"
 
 _REFERENCE_PACKAGES = ("core", "image", "lie", "tool", "odometery", "depth_completion")
+# single modules of packages whose other modules stay the reference's own (SAM / normals frontend: out of scope)
+_REFERENCE_LEAF_MODULES = ("frontend.segment.post_processer",)
 
 
 def install_as_reference_modules():
-    """Alias ``super_primitive_amd.<pkg>[.<module>]`` as ``<pkg>[.<module>]`` in ``sys.modules``."""
+    """Alias ``super_primitive_amd.<pkg>[.<module>]`` as ``<pkg>[.<module>]`` in ``sys.modules``.  ``frontend.segment.post_processer``
+    (the keyframe post-processing) is aliased as a LEAF: when the reference's ``frontend`` package is importable
+    it keeps its other modules (``sam_tools``, ``mask_generation``, the normals code) and only ``post_processer`` is replaced; otherwise
+    the (otherwise empty) parent packages of this tree stand in."""
+    import importlib.util
     import pkgutil
     for pkg in _REFERENCE_PACKAGES:
         mod = importlib.import_module(f"{__name__}.{pkg}")
@@ -24,3 +30,19 @@ def install_as_reference_modules():
         for info in pkgutil.iter_modules(mod.__path__):
             sub = importlib.import_module(f"{__name__}.{pkg}.{info.name}")
             sys.modules[f"{pkg}.{info.name}"] = sub
+    for leaf in _REFERENCE_LEAF_MODULES:
+        ours = importlib.import_module(f"{__name__}.{leaf}")
+        parent_name, _, name = leaf.rpartition(".")
+        try:
+            found = importlib.util.find_spec(parent_name) is not None
+        except (ImportError, ValueError):
+            found = False
+        if found and not sys.modules.get(parent_name, None) is importlib.import_module(f"{__name__}.{parent_name}"):
+            parent = importlib.import_module(parent_name)                     # the reference's own package
+        else:
+            parts = parent_name.split(".")
+            for i in range(1, len(parts) + 1):
+                sys.modules[".".join(parts[:i])] = importlib.import_module(f"{__name__}." + ".".join(parts[:i]))
+            parent = sys.modules[parent_name]
+        sys.modules[leaf] = ours
+        setattr(parent, name, ours)

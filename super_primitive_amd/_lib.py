@@ -49,8 +49,10 @@ SIGNATURES = {
     "sp_window_scratch_doubles": [I, I],
     "sp_window_compose": [P, P, I, P, I, P],
     "sp_window_step": [P, P, I, P, I, P, I, I, P, P, P, I, I, F, P, P, I, P],
-    "sp_window_gn_scratch_doubles": [I, I, I],
-    "sp_window_gn_step": [P, P, I, P, I, P, I, I, I, P, P, P, P, P, I, F, F, F, F, P, P, I, P],
+    "sp_window_gn_scratch_doubles": [I, I, I, I, I],
+    "sp_window_gn_profile_offset": [I, I, I, I, I],
+    "sp_window_gn_run": [P, P, P, I, F, P, I, P, I, P, I, I, I, I, P, P, P, P, P, I, F, F, F, F, P, P, I, I, I, P, P],
+    "sp_window_gn_step": [P, P, I, P, I, P, I, I, I, I, P, P, P, P, P, I, F, F, F, F, P, P, I, P],
     "sp_depth_expand": [P, P, P, P, I, I, I, I, P, P],
     "sp_depth_splat_mean": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
     "sp_depth_splat": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
@@ -68,7 +70,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 8
+SP_ABI_VERSION = 9
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GNA_PARTIAL_FLOATS = 48

@@ -25,18 +25,32 @@ namespace {
 
 #define SP_WGN_REC 46            // doubles per edge record: cost, valid points, H_z upper triangle (36), b_z (8); then 10 per segment
 #define SP_WGN_SEG 10            // c (8) = [h_pd (6), h_ad, h_bd], D, b_d
-#define SP_WGN_MAX_Y 128         // unknowns of the reduced camera system (6 per free pose + 2 per free affine pair)
 #define SP_WGN_MAX_NODES 64
+#define SP_WGN_MAX_Y (8 * SP_WGN_MAX_NODES)      // unknowns of the reduced camera system (6 per free pose + 2 per free affine pair)
+#define SP_WGN_LDS_Y 192         // ... of which LDS holds this many (packed lower triangle, fp64); larger systems go through global scratch
 #define SP_WGN_STATE 16
 
 __device__ __forceinline__ int tri8(int i, int j) { return i * 8 - i * (i - 1) / 2 + (j - i); }      // (i <= j) in the upper triangle of an 8x8
 
+// column `col` (0..15) of the 8 x 16 map z_e = G [y_t ; y_s]: y_t = columns 0..7 (identity), y_s = columns 8..15 (-Ad, -I_2)
+__device__ __forceinline__ void wgn_gcol(const double* __restrict__ Ad, int col, double (&g)[8]) {
+#pragma unroll
+    for (int p = 0; p < 8; ++p) g[p] = 0.0;
+    if (col < 8) g[col] = 1.0;
+    else if (col < 14) { for (int p = 0; p < 6; ++p) g[p] = -Ad[6 * p + (col - 8)]; }
+    else g[col - 8] = -1.0;
+}
+
+#define SP_WGN_LOC 272           // doubles per edge of its system in NODE coordinates: 16 x 16 block G^T H_z G over [y_trg (8) ; y_src (8)], then G^T b_z (16)
+
 __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_reduce(const SpPair* __restrict__ pairs, const SpWindowEdge* __restrict__ edges,
                                                                const float* __restrict__ partials, const float* __restrict__ seg_partials,
-                                                               double* __restrict__ scratch, int stride) {
+                                                               double* __restrict__ scratch, int stride, double* __restrict__ Ad_all,
+                                                               double* __restrict__ loc_all) {
     constexpr int NV = SP_GNA_PARTIAL_FLOATS, NS = SP_GNA_SEG_FLOATS;
     __shared__ double sums[NV];
     __shared__ double red[(SP_BLOCK / NV) * NV];
+    __shared__ double Hz[36], bz[8], Ads[36];
     const int e = blockIdx.x;
     const SpPair& pr = pairs[e];
     reduce_columns<NV>(partials + (size_t)pr.tile0 * NV, pr.n_tiles, sums, red);
@@ -57,11 +71,51 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_reduce(const SpPair* __r
             v = sums[1 + (i * 6 - i * (i - 1) / 2 + (j - i))];
         } else if (i < 6) v = sums[(j == 6 ? 34 : 40) + i];
         else v = sums[29 + (i - 6) + (j - 6)];       // (6,6) -> 29, (6,7) -> 30, (7,7) -> 31
+        Hz[threadIdx.x] = v * scale;
         rec[2 + threadIdx.x] = v * scale;
     }
     if (threadIdx.x >= 64 && threadIdx.x < 72) {
         const int i = threadIdx.x - 64;
-        rec[38 + i] = (i < 6 ? sums[22 + i] : sums[32 + (i - 6)]) * scale;
+        bz[i] = (i < 6 ? sums[22 + i] : sums[32 + (i - 6)]) * scale;
+        rec[38 + i] = bz[i];
+    }
+    if (threadIdx.x >= 128 && threadIdx.x < 137) {
+        // Ad of the edge's relative pose P = [R t]: tau' = R tau + [t]x R phi, phi' = R phi  (the pose slot is what the cost pass just used)
+        const int r = (threadIdx.x - 128) / 3, c = (threadIdx.x - 128) % 3;
+        const float* P = pr.pose;
+        const double t0 = P[3], t1 = P[7], t2 = P[11];
+        const double tx[9] = {0, -t2, t1, t2, 0, -t0, -t1, t0, 0};
+        const double Rrc = P[4 * r + c];
+        Ads[6 * r + c] = Rrc;
+        Ads[6 * r + 3 + c] = tx[3 * r] * (double)P[c] + tx[3 * r + 1] * (double)P[4 + c] + tx[3 * r + 2] * (double)P[8 + c];
+        Ads[6 * (r + 3) + c] = 0.0;
+        Ads[6 * (r + 3) + 3 + c] = Rrc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 36) Ad_all[(size_t)e * 36 + threadIdx.x] = Ads[threadIdx.x];
+    {
+        // the edge's system in node coordinates: z_e = G [y_trg ; y_src], thread (li, lj) of the 16 x 16 block G^T H_z G (row-major), and
+        // G^T b_z from the threads of column 0 -- the update kernel only scatters these into the camera system
+        const int li = threadIdx.x >> 4, lj = threadIdx.x & 15;
+        double a[8], b[8];
+        wgn_gcol(Ads, li, a);
+        wgn_gcol(Ads, lj, b);
+        double v = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            double row = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) row += Hz[p <= q ? tri8(p, q) : tri8(q, p)] * b[q];
+            v += a[p] * row;
+        }
+        double* loc = loc_all + (size_t)e * SP_WGN_LOC;
+        loc[threadIdx.x] = v;
+        if (lj == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int p = 0; p < 8; ++p) t += a[p] * bz[p];
+            loc[256 + li] = t;
+        }
     }
     const float* sp = seg_partials + (size_t)pr.rec0 * NS;
     for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
@@ -88,13 +142,209 @@ struct WGnArgs {
     const SpWindowBlock* blocks; int n_blocks; int max_N;
     double* scratch; int stride;          // edge records
     double* Ad;                           // n_edges x 36: Ad of every edge's relative pose
-    double* C;                            // sum N x SP_WGN_MAX_Y: coupling of every depth unknown with the camera unknowns
+    double* loc;                          // n_edges x SP_WGN_LOC: every edge's system in node coordinates
+    double* C; int ldc;                   // sum N x ldc: row r = coupling of depth unknown r with the nc_b camera unknowns ITS keyframe meets (compact: cols[b][0 .. nc_b))
     double* Dinv;                         // sum N: 1 / (D (1 + lambda)) or 0
     double* Bd;                           // sum N
+    double* S; int lds;                   // n_blocks x lds: block b's Schur term C_b^T D_b^-1 C_b over its coupled unknowns (packed lower triangle, nc_b (nc_b + 1) / 2)
+    double* Rhs;                          // n_blocks x ldc: C_b^T D_b^-1 b_d
+    int* cols;                            // n_blocks x ldc: the coupled camera unknowns of block b, ascending
+    int* nc;                              // n_blocks
+    double* prof;                         // 16 doubles: time stamps of the update kernel's phases (last call)
+    double* Hg; int cap_y;                // the reduced camera system when it does not fit LDS (packed lower triangle); unknowns the caller sized for
     SpWindowNode* nodes_backup; float* kld_backup;
     int flags; float lm_up, lm_down, lm_min, conv_tol;
     float* state; float* losses; int max_losses;
 };
+
+// ---- what every kernel of a step must agree on: the numbering of the camera unknowns and the LM decision ---------------------------------
+// offsets of node i's pose (6) / affine (2) unknowns in y, -1 = fixed; returns n_y
+__device__ int wgn_number_unknowns(const WGnArgs& w, int* pose_off, int* aff_off) {
+    int ny = 0;
+    for (int i = 0; i < w.n_nodes; ++i) {
+        const SpWindowNode& nd = w.nodes[i];
+        pose_off[i] = nd.lr_pose > 0.f ? ny : -1;
+        if (nd.lr_pose > 0.f) ny += 6;
+        aff_off[i] = nd.lr_aff > 0.f ? ny : -1;
+        if (nd.lr_aff > 0.f) ny += 2;
+    }
+    return ny;
+}
+
+struct WGnDecision { int dec; int too_many; int converged; float lam; double loss; };      // dec: 0 = step, 1 = reject (restore), 2 = frozen
+
+// PURE (reads the state, writes nothing): k_window_gn_schur of every block and k_window_gn_update evaluate it on the same state
+__device__ WGnDecision wgn_decide(const WGnArgs& w, int ny, int cap) {
+    WGnDecision d;
+    d.dec = 0; d.too_many = 0; d.converged = 0; d.lam = 0.f;
+    double loss = 0.0;
+    for (int e = 0; e < w.n_edges; ++e) loss += (double)w.edges[e].weight * w.scratch[(size_t)e * w.stride];
+    d.loss = loss;
+    const float* st = w.state;
+    int free_depths = 0;
+    if (!(w.flags & 1))
+        for (int b = 0; b < w.n_blocks; ++b) free_depths += w.blocks[b].lr > 0.f ? w.blocks[b].N : 0;
+    if (ny > cap || ny > w.cap_y) { d.too_many = 1; d.dec = 2; return d; }        // more camera unknowns than the caller sized the scratch for: refuse
+    if ((ny == 0 && free_depths == 0) || st[6] != 0.f) { d.dec = 2; return d; }    // nothing to optimise / frozen earlier
+    const float last = st[1];
+    if (last >= 0.f && (float)loss > last * (1.f + 1e-6f) && st[4] == 0.f) d.dec = 1;
+    else if (last >= 0.f && st[4] == 0.f && w.conv_tol > 0.f && (last - (float)loss) <= w.conv_tol * last) { d.dec = 2; d.converged = 1; }
+    if (d.dec == 0) {
+        float lam = st[0];
+        if (st[4] == 0.f) lam = fmaxf(lam * w.lm_down, w.lm_min);
+        d.lam = lam;
+    }
+    return d;
+}
+
+// packed lower triangle: (i, j), j <= i
+__device__ __forceinline__ int ltri(int i, int j) { return ((i * (i + 1)) >> 1) + j; }
+// row of packed index t (largest a with a (a + 1) / 2 <= t)
+__device__ __forceinline__ int ltri_row(int t) {
+    int a = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+    while (((a + 1) * (a + 2) >> 1) <= t) ++a;
+    while (((a * (a + 1)) >> 1) > t) --a;
+    return a;
+}
+
+// ---- the depth side of the arrow system, one source keyframe (block) per blockIdx.x ---------------------------------------------------------
+// A depth unknown of keyframe k only meets the frames keyframe k is matched against (its neighbouring keyframes and the supporting frames
+// of k and k - 1, odometery.py:770-823): at most 7 of a reference-sized window's 15 free frames.  Per block: the list of those camera
+// unknowns (cols), the coupling rows C (N x nc, staged in LDS a chunk of rows at a time), D^-1 with the LM damping, and the block's
+// Schur term S_b = C^T D^-1 C + its right-hand side -- pairs (i, j) spread over blockIdx.y tiles of 2 x 256 pairs.  Tile 0 also leaves C,
+// D^-1, b_d in global memory for the back-substitution.
+#define SP_WGN_SCHUR_LDS 8192      // doubles of a staged chunk of C
+#define SP_WGN_SCHUR_ROWS 512
+#define SP_WGN_PPT 2               // pairs per thread
+
+__global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w) {
+    __shared__ double Cs[SP_WGN_SCHUR_LDS];
+    __shared__ double Dv[SP_WGN_SCHUR_ROWS], Bv[SP_WGN_SCHUR_ROWS];
+    __shared__ int pose_off[SP_WGN_MAX_NODES], aff_off[SP_WGN_MAX_NODES], lpose[SP_WGN_MAX_NODES], laff[SP_WGN_MAX_NODES];
+    __shared__ int cols[SP_WGN_MAX_Y];
+    __shared__ int nc_s, dec_s, row0_s;
+    __shared__ double lam_s;
+    const int tid = threadIdx.x, b = blockIdx.x, tile = blockIdx.y;
+    const SpWindowBlock bk = w.blocks[b];
+    const bool frozen = (w.flags & 1) || !(bk.lr > 0.f);
+    if (tid == 0) {
+        const int ny = wgn_number_unknowns(w, pose_off, aff_off);
+        const WGnDecision d = wgn_decide(w, ny, SP_WGN_MAX_Y);
+        dec_s = d.dec;
+        lam_s = (double)d.lam;
+        int off = 0;
+        for (int q = 0; q < b; ++q) off += w.blocks[q].N;
+        row0_s = off;
+        // nodes this block's edges touch, in node order => cols ascending
+        for (int i = 0; i < w.n_nodes; ++i) { lpose[i] = -1; laff[i] = -1; }
+        if (!frozen)
+            for (int e = 0; e < w.n_edges; ++e) {
+                const SpWindowEdge ed = w.edges[e];
+                if (ed.block != b) continue;
+                lpose[ed.trg_node] = 0;
+                if (ed.src_node >= 0) lpose[ed.src_node] = 0;
+            }
+        int nc = 0;
+        for (int i = 0; i < w.n_nodes; ++i) {
+            const bool touched = lpose[i] == 0;
+            lpose[i] = -1;
+            if (!touched) continue;
+            if (pose_off[i] >= 0) { lpose[i] = nc; for (int k = 0; k < 6; ++k) cols[nc++] = pose_off[i] + k; }
+            if (aff_off[i] >= 0) { laff[i] = nc; cols[nc++] = aff_off[i]; cols[nc++] = aff_off[i] + 1; }
+        }
+        nc_s = nc;
+    }
+    __syncthreads();
+    if (dec_s != 0) return;
+    const int nc = nc_s, row0 = row0_s;
+    const double lam = lam_s;
+    const int n_pairs = (nc * (nc + 1)) >> 1;
+    const int p_base = tile * (SP_BLOCK * SP_WGN_PPT);
+    if (tile > 0 && p_base >= n_pairs) return;
+    int pi[SP_WGN_PPT], pj[SP_WGN_PPT];
+    double acc[SP_WGN_PPT];
+#pragma unroll
+    for (int q = 0; q < SP_WGN_PPT; ++q) {
+        const int p = p_base + q * SP_BLOCK + tid;
+        acc[q] = 0.0;
+        if (p < n_pairs) { pi[q] = ltri_row(p); pj[q] = p - ((pi[q] * (pi[q] + 1)) >> 1); } else { pi[q] = -1; pj[q] = 0; }
+    }
+    double racc[SP_WGN_MAX_Y / SP_BLOCK];
+#pragma unroll
+    for (int q = 0; q < SP_WGN_MAX_Y / SP_BLOCK; ++q) racc[q] = 0.0;
+    const int chunk = nc > 0 ? min(SP_WGN_SCHUR_ROWS, SP_WGN_SCHUR_LDS / nc) : SP_WGN_SCHUR_ROWS;
+    for (int r0 = 0; r0 < bk.N; r0 += chunk) {
+        const int rows = min(chunk, bk.N - r0);
+        for (int n = tid; n < rows; n += SP_BLOCK) {
+            double* Crow = Cs + n * nc;
+            double D = 0.0, bd = 0.0;
+            if (!frozen) {
+                for (int i = 0; i < nc; ++i) Crow[i] = 0.0;
+                for (int e = 0; e < w.n_edges; ++e) {
+                    const SpWindowEdge ed = w.edges[e];
+                    if (ed.block != b) continue;
+                    const double* o = w.scratch + (size_t)e * w.stride + SP_WGN_REC + (size_t)(r0 + n) * SP_WGN_SEG;
+                    D += o[8]; bd += o[9];
+                    const int pt = lpose[ed.trg_node], at = laff[ed.trg_node];
+                    if (pt >= 0) for (int k = 0; k < 6; ++k) Crow[pt + k] += o[k];
+                    if (at >= 0) { Crow[at] += o[6]; Crow[at + 1] += o[7]; }
+                    if (ed.src_node >= 0) {
+                        const int ps = lpose[ed.src_node], as = laff[ed.src_node];
+                        if (ps >= 0) {
+                            const double* Ad = w.Ad + (size_t)e * 36;
+                            for (int k = 0; k < 6; ++k) {
+                                double s = 0.0;
+                                for (int p = 0; p < 6; ++p) s += Ad[6 * p + k] * o[p];
+                                Crow[ps + k] -= s;
+                            }
+                        }
+                        if (as >= 0) { Crow[as] -= o[6]; Crow[as + 1] -= o[7]; }
+                    }
+                }
+            }
+            const double Dd = D * (1.0 + lam);
+            const double dinv = (!frozen && Dd > 1e-12) ? 1.0 / Dd : 0.0;
+            Dv[n] = dinv; Bv[n] = bd;
+            if (tile == 0) {
+                const int r = row0 + r0 + n;
+                w.Dinv[r] = dinv; w.Bd[r] = bd;
+                double* Cg = w.C + (size_t)r * w.ldc;
+                for (int i = 0; i < nc; ++i) Cg[i] = Crow[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SP_WGN_PPT; ++q) {
+            if (pi[q] < 0) continue;
+            double s = acc[q];
+            for (int r = 0; r < rows; ++r) s += Cs[r * nc + pi[q]] * Cs[r * nc + pj[q]] * Dv[r];       // rows in order: a fixed summation order
+            acc[q] = s;
+        }
+        if (tile == 0) {
+#pragma unroll
+            for (int q = 0; q < SP_WGN_MAX_Y / SP_BLOCK; ++q) {
+                const int i = q * SP_BLOCK + tid;
+                if (i >= nc) continue;
+                double s = racc[q];
+                for (int r = 0; r < rows; ++r) s += Cs[r * nc + i] * Bv[r] * Dv[r];
+                racc[q] = s;
+            }
+        }
+        __syncthreads();
+    }
+    double* Sb = w.S + (size_t)b * w.lds;
+#pragma unroll
+    for (int q = 0; q < SP_WGN_PPT; ++q)
+        if (pi[q] >= 0) Sb[p_base + q * SP_BLOCK + tid] = acc[q];
+    if (tile == 0) {
+#pragma unroll
+        for (int q = 0; q < SP_WGN_MAX_Y / SP_BLOCK; ++q) {
+            const int i = q * SP_BLOCK + tid;
+            if (i < nc) { w.Rhs[(size_t)b * w.ldc + i] = racc[q]; w.cols[(size_t)b * w.ldc + i] = cols[i]; }
+        }
+        if (tid == 0) w.nc[b] = nc;
+    }
+}
 
 // Exp(xi) as a 3x4 double matrix (same closed form as sp_window.hip)
 __device__ void wgn_se3_exp(const double xi[6], double E[12]) {
@@ -158,269 +408,305 @@ __device__ void wgn_compose_edge(const WGnArgs& w, int e) {
     }
 }
 
-// column `col` (0..15) of the 8 x 16 map z_e = G [y_t ; y_s]: y_t = columns 0..7 (identity), y_s = columns 8..15 (-Ad, -I_2)
-__device__ __forceinline__ void wgn_gcol(const double* __restrict__ Ad, int col, double (&g)[8]) {
-#pragma unroll
-    for (int p = 0; p < 8; ++p) g[p] = 0.0;
-    if (col < 8) g[col] = 1.0;
-    else if (col < 14) { for (int p = 0; p < 6; ++p) g[p] = -Ad[6 * p + (col - 8)]; }
-    else g[col - 8] = -1.0;
-}
-
-__global__ __launch_bounds__(SP_BLOCK) void k_window_gn_update(WGnArgs w) {
-    __shared__ double H[SP_WGN_MAX_Y * SP_WGN_MAX_Y];
-    __shared__ double g[SP_WGN_MAX_Y], dy[SP_WGN_MAX_Y];
+// The reduced camera system S (n_y x n_y, fp64, packed lower triangle) lives in LDS when n_y <= LDS_Y (instantiations 64 / 128 / 192:
+// 17 / 66 / 148 KB of the CU's 160 KB) and in global scratch (w.Hg) in the LDS_Y = 0 instantiation: a reference-sized mapping window
+// (config/tum/odom_desk.yaml: window_size 5, two supporting frames per keyframe + the two running ones, poses and affine pairs all
+// free -- odometery.py:523-575, 611-616) is 14 free nodes = 112 unknowns, a window with three supporting frames per keyframe 168.
+#define SP_WGN_THREADS 1024     // threads of the update kernel: 4 waves per SIMD -- its phases are chains of LDS / global latencies, not throughput
+#define SP_WGN_GRID 32          // ... as a SP_WGN_GRID x SP_WGN_GRID grid over the trailing block of the factorisation
+#define WGN_STAMP(i) do { if (tid == 0) w.prof[i] = (double)wall_clock64(); } while (0)      // 100 MHz constant clock; phase boundaries of the last step
+template <int LDS_Y>
+__global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) {
+    constexpr int CAP = LDS_Y > 0 ? LDS_Y : SP_WGN_MAX_Y;
+    __shared__ double Hs[LDS_Y > 0 ? LDS_Y * (LDS_Y + 1) / 2 : 1];
+    __shared__ double g[CAP], dy[CAP], dinvs[CAP];
     __shared__ int pose_off[SP_WGN_MAX_NODES], aff_off[SP_WGN_MAX_NODES];
     __shared__ int blk_off[SP_WGN_MAX_NODES + 1];
-    __shared__ int n_y_s, decision, chol_fail;
+    __shared__ int n_y_s, decision;
     __shared__ double lam_s;
+    double* H;
+    if constexpr (LDS_Y > 0) H = Hs; else H = w.Hg;
     const int tid = threadIdx.x;
     float* st = w.state;
-    const bool pose_only = (w.flags & 1) != 0;
+    WGN_STAMP(0);
     if (tid == 0) {
-        int ny = 0;
-        for (int i = 0; i < w.n_nodes; ++i) {
-            const SpWindowNode& nd = w.nodes[i];
-            pose_off[i] = nd.lr_pose > 0.f ? ny : -1;
-            if (nd.lr_pose > 0.f) ny += 6;
-            aff_off[i] = nd.lr_aff > 0.f ? ny : -1;
-            if (nd.lr_aff > 0.f) ny += 2;
-        }
+        const int ny = wgn_number_unknowns(w, pose_off, aff_off);
         n_y_s = ny;
         int off = 0;
         for (int b = 0; b < w.n_blocks; ++b) { blk_off[b] = off; off += w.blocks[b].N; }
         blk_off[w.n_blocks] = off;
-        // ---- loss, LM decision ----------------------------------------------------------------------------------
-        double loss = 0.0;
-        for (int e = 0; e < w.n_edges; ++e) loss += (double)w.edges[e].weight * w.scratch[(size_t)e * w.stride];
-        int dec = 0;                      // 0 = step, 1 = reject (restore), 2 = converged / frozen
-        if (ny > SP_WGN_MAX_Y || ny == 0) { st[9] = 1.f; st[6] = 1.f; }      // more camera unknowns than the LDS system holds: refuse (freeze)
-        if (st[6] != 0.f) dec = 2;
-        else {
+        // ---- loss, LM decision (the one k_window_gn_schur took), committed to the state ---------------------------------
+        const WGnDecision d = wgn_decide(w, ny, CAP);
+        if (d.too_many) { st[9] = 1.f; st[6] = 1.f; }
+        if (d.dec != 2 || d.converged) {
             const int it = (int)st[5];
-            if (it < w.max_losses) w.losses[it] = (float)loss;
+            if (it < w.max_losses) w.losses[it] = (float)d.loss;
             st[5] = (float)(it + 1);
-            st[7] = (float)loss;
-            const float last = st[1];
-            if (last >= 0.f && (float)loss > last * (1.f + 1e-6f) && st[4] == 0.f) dec = 1;
-            else if (last >= 0.f && st[4] == 0.f && w.conv_tol > 0.f && (last - (float)loss) <= w.conv_tol * last) { dec = 2; st[6] = 1.f; }
-            if (dec == 1) { st[0] *= w.lm_up; st[3] += 1.f; st[4] = 1.f; }
-            if (dec == 0) {
-                float lam = st[0];
-                if (st[4] == 0.f) lam = fmaxf(lam * w.lm_down, w.lm_min);
-                st[0] = lam; st[1] = (float)loss; st[2] += 1.f; st[4] = 0.f;
-                lam_s = (double)lam;
-            }
+            st[7] = (float)d.loss;
         }
-        decision = dec;
-        chol_fail = 0;
+        if (d.converged) st[6] = 1.f;
+        if (d.dec == 1) { st[0] *= w.lm_up; st[3] += 1.f; st[4] = 1.f; }
+        if (d.dec == 0) { st[0] = d.lam; st[1] = (float)d.loss; st[2] += 1.f; st[4] = 0.f; }
+        lam_s = (double)d.lam;
+        decision = d.dec;
     }
     __syncthreads();
     const int n_y = n_y_s;
-    const int sumN = blk_off[w.n_blocks];
+    const int ldc = w.ldc;
+    WGN_STAMP(1);
     if (decision == 2) return;
     if (decision == 1) {
         // undo the previous step: nodes (pose, tangent, affine) and log-depths back to the stored point
-        for (int i = tid; i < w.n_nodes * 44; i += SP_BLOCK) reinterpret_cast<uint32_t*>(w.nodes)[i] = reinterpret_cast<const uint32_t*>(w.nodes_backup)[i];
+        for (int i = tid; i < w.n_nodes * 44; i += SP_WGN_THREADS) reinterpret_cast<uint32_t*>(w.nodes)[i] = reinterpret_cast<const uint32_t*>(w.nodes_backup)[i];
         for (int b = 0; b < w.n_blocks; ++b)
-            for (int n = tid; n < w.blocks[b].N; n += SP_BLOCK) w.blocks[b].kld[n] = w.kld_backup[blk_off[b] + n];
+            for (int n = tid; n < w.blocks[b].N; n += SP_WGN_THREADS) w.blocks[b].kld[n] = w.kld_backup[blk_off[b] + n];
         __threadfence_block();
         __syncthreads();
-        for (int e = tid; e < w.n_edges; e += SP_BLOCK) wgn_compose_edge(w, e);
+        for (int e = tid; e < w.n_edges; e += SP_WGN_THREADS) wgn_compose_edge(w, e);
         return;
     }
     const double lam = lam_s;
-    // ---- back up the point we are about to leave ----------------------------------------------------------------
-    for (int i = tid; i < w.n_nodes * 44; i += SP_BLOCK) reinterpret_cast<uint32_t*>(w.nodes_backup)[i] = reinterpret_cast<const uint32_t*>(w.nodes)[i];
+    // ---- back up the point we are about to leave; clear the system ------------------------------------------------
+    for (int i = tid; i < w.n_nodes * 44; i += SP_WGN_THREADS) reinterpret_cast<uint32_t*>(w.nodes_backup)[i] = reinterpret_cast<const uint32_t*>(w.nodes)[i];
     for (int b = 0; b < w.n_blocks; ++b)
-        for (int n = tid; n < w.blocks[b].N; n += SP_BLOCK) w.kld_backup[blk_off[b] + n] = w.blocks[b].kld[n];
-    // ---- Ad of every edge's relative pose; clear the system -----------------------------------------------------
-    for (int e = tid; e < w.n_edges; e += SP_BLOCK) {
-        const float* P = w.pairs[e].pose;
-        double R[9], t[3];
-        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) R[3 * r + c] = P[4 * r + c]; t[r] = P[4 * r + 3]; }
-        const double tx[9] = {0, -t[2], t[1], t[2], 0, -t[0], -t[1], t[0], 0};
-        double* A = w.Ad + (size_t)e * 36;
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) {
-                A[6 * r + c] = R[3 * r + c];                                                           // tau' = R tau + [t]x R phi
-                A[6 * r + 3 + c] = tx[3 * r] * R[c] + tx[3 * r + 1] * R[3 + c] + tx[3 * r + 2] * R[6 + c];
-                A[6 * (r + 3) + c] = 0.0;                                                              // phi' = R phi
-                A[6 * (r + 3) + 3 + c] = R[3 * r + c];
-            }
-    }
-    for (int i = tid; i < n_y * n_y; i += SP_BLOCK) H[i] = 0.0;
-    for (int i = tid; i < n_y; i += SP_BLOCK) g[i] = 0.0;
+        for (int n = tid; n < w.blocks[b].N; n += SP_WGN_THREADS) w.kld_backup[blk_off[b] + n] = w.blocks[b].kld[n];
+    const int n_tri = (n_y * (n_y + 1)) >> 1;
+    for (int i = tid; i < n_tri; i += SP_WGN_THREADS) H[i] = 0.0;
+    for (int i = tid; i < n_y; i += SP_WGN_THREADS) g[i] = 0.0;
     __syncthreads();
-    // ---- assembly: thread (i, j) of the 16 x 16 local block of one edge at a time ---------------------------------
-    {
+    WGN_STAMP(2);
+    // ---- assembly: scatter every edge's 16 x 16 node-coordinate block (k_window_gn_reduce), thread (i, j), one edge at a time (edges
+    //      share entries: a fixed order keeps the sums reproducible); the loads of a group of edges are issued before its barriers
+    if (n_y > 0 && tid < 256) {
         const int li = tid >> 4, lj = tid & 15;
-        for (int e = 0; e < w.n_edges; ++e) {
-            const SpWindowEdge ed = w.edges[e];
-            const double* rec = w.scratch + (size_t)e * w.stride;
-            const double* Ad = w.Ad + (size_t)e * 36;
-            auto global_index = [&](int l) -> int {
-                const int node = l < 8 ? ed.trg_node : ed.src_node;
-                if (node < 0) return -1;
-                const int k = l & 7;
-                const int base = k < 6 ? pose_off[node] : aff_off[node];
-                return base < 0 ? -1 : base + (k < 6 ? k : k - 6);
-            };
-            const int gi = global_index(li), gj = global_index(lj);
-            if (gi >= 0 && gj >= 0) {
-                double a[8], b[8];
-                wgn_gcol(Ad, li, a);
-                wgn_gcol(Ad, lj, b);
-                double v = 0.0;
+        for (int e0 = 0; e0 < w.n_edges; e0 += 8) {
+            double v[8], t[8];
+            int gi[8], gj[8];
 #pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    if (a[p] == 0.0) continue;
-                    double row = 0.0;
+            for (int q = 0; q < 8; ++q) {
+                const int e = e0 + q;
+                gi[q] = gj[q] = -1; v[q] = t[q] = 0.0;
+                if (e >= w.n_edges) continue;
+                const SpWindowEdge ed = w.edges[e];
+                auto global_index = [&](int l) -> int {
+                    const int node = l < 8 ? ed.trg_node : ed.src_node;
+                    if (node < 0) return -1;
+                    const int k = l & 7;
+                    const int base = k < 6 ? pose_off[node] : aff_off[node];
+                    return base < 0 ? -1 : base + (k < 6 ? k : k - 6);
+                };
+                gi[q] = global_index(li); gj[q] = global_index(lj);
+                const double* loc = w.loc + (size_t)e * SP_WGN_LOC;
+                if (gi[q] >= 0 && gj[q] >= 0 && gi[q] >= gj[q]) v[q] = loc[tid];
+                if (gi[q] >= 0 && lj == 0) t[q] = loc[256 + li];
+            }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) row += rec[2 + (p <= q ? tri8(p, q) : tri8(q, p))] * b[q];
-                    v += a[p] * row;
+            for (int q = 0; q < 8; ++q) {
+                if (e0 + q < w.n_edges) {
+                    if (gi[q] >= 0 && gj[q] >= 0 && gi[q] >= gj[q]) H[ltri(gi[q], gj[q])] += v[q];
+                    if (gi[q] >= 0 && lj == 0) g[gi[q]] += t[q];
                 }
-                H[gi * n_y + gj] += v;
-                if (lj == 0) {
-                    double s = 0.0;
+                __syncthreads();
+            }
+        }
+    } else if (n_y > 0) {
+        for (int e0 = 0; e0 < w.n_edges; e0 += 8)
+            for (int q = 0; q < 8; ++q) __syncthreads();
+    }
+    WGN_STAMP(3);
+    // ---- LM damping of the camera block, then minus the blocks' Schur terms (k_window_gn_schur), block after block ----
+    for (int i = tid; i < n_y; i += SP_WGN_THREADS) { H[ltri(i, i)] = H[ltri(i, i)] * (1.0 + lam) + 1e-12; g[i] = -g[i]; }
+    __syncthreads();
+    for (int b = 0; b < w.n_blocks; ++b) {
+        const int nc = w.nc[b];
+        const int* cb = w.cols + (size_t)b * ldc;
+        const double* Sb = w.S + (size_t)b * w.lds;
+        const int np = (nc * (nc + 1)) >> 1;
+        for (int p = tid; p < np; p += SP_WGN_THREADS) {
+            const int i = ltri_row(p), j = p - ((i * (i + 1)) >> 1);
+            H[ltri(cb[i], cb[j])] -= Sb[p];                            // cols ascending: cb[i] >= cb[j]
+        }
+        for (int i = tid; i < nc; i += SP_WGN_THREADS) g[cb[i]] += w.Rhs[(size_t)b * ldc + i];
+        __syncthreads();
+    }
+    for (int i = tid; i < n_y; i += SP_WGN_THREADS) dy[i] = g[i];      // right-hand side of S dy = -(g - C^T D^-1 b_d)
+    __syncthreads();
+    WGN_STAMP(4);
+    // ---- S = L D L^T in place, right-looking by blocks of 4 columns.  Column j keeps the UNSCALED entries c_ij = l_ij d_j.  Per block:
+    //      (1) every thread factors the 4 x 4 diagonal block in registers (10 broadcast LDS reads) -- so the positive-definiteness test
+    //      is uniform without a barrier -- and eliminates inside ITS row of the panel (rows are independent given the diagonal block);
+    //      (2) rank-4 update of the trailing triangle, thread (ti, tj) of a 32 x 32 grid over rows = ti, columns = tj (mod 32): 4 + 1 LDS
+    //      accesses per 4 multiply-adds.  Two barriers per 4 columns.
+    bool fail = false;
+    {
+        const int ti = tid / SP_WGN_GRID, tj = tid % SP_WGN_GRID;
+        for (int k = 0; k < n_y && !fail; k += 4) {
+            const int B = min(4, n_y - k);
+            double c[4][4], dinv[4];
 #pragma unroll
-                    for (int p = 0; p < 8; ++p) s += a[p] * rec[38 + p];
-                    g[gi] += s;
-                }
-            } else if (gi >= 0 && lj == 0) {
-                // (column 0 of the local block is fixed -- the target pose is not optimised -- but row li still owns a rhs entry)
-                double a[8];
-                wgn_gcol(Ad, li, a);
-                double s = 0.0;
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int p = 0; p < 8; ++p) s += a[p] * rec[38 + p];
-                g[gi] += s;
+                for (int q = 0; q <= a; ++q) c[a][q] = a < B ? H[ltri(k + a, k + q)] : (a == q ? 1.0 : 0.0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                // row a of the diagonal block: eliminate with the columns q < a (rows q are final by now)
+#pragma unroll
+                for (int q = 0; q < a; ++q)
+#pragma unroll
+                    for (int q2 = q + 1; q2 <= a; ++q2) c[a][q2] -= c[a][q] * c[q2][q] * dinv[q];
+                if (!(c[a][a] > 0.0)) fail = true;
+                dinv[a] = 1.0 / c[a][a];
+            }
+            if (fail) break;
+            if (tid < B) dinvs[k + tid] = tid == 0 ? dinv[0] : tid == 1 ? dinv[1] : tid == 2 ? dinv[2] : dinv[3];
+            for (int i = k + B + tid; i < n_y; i += SP_WGN_THREADS) {
+                double r[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[q] = q < B ? H[ltri(i, k + q)] : 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int q2 = q + 1; q2 < 4; ++q2) r[q2] -= r[q] * c[q2][q] * dinv[q];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) if (q < B) H[ltri(i, k + q)] = r[q];
             }
             __syncthreads();
-        }
-    }
-    // ---- depth unknowns: D, b_d and the coupling rows C of every segment (one thread per row) ---------------------
-    for (int b = 0; b < w.n_blocks; ++b) {
-        const SpWindowBlock bk = w.blocks[b];
-        const bool frozen = pose_only || !(bk.lr > 0.f);
-        for (int n = tid; n < bk.N; n += SP_BLOCK) {
-            const int r = blk_off[b] + n;
-            double* Crow = w.C + (size_t)r * SP_WGN_MAX_Y;
-            double D = 0.0, bd = 0.0;
-            if (!frozen) {
-                for (int i = 0; i < n_y; ++i) Crow[i] = 0.0;
-                for (int e = 0; e < w.n_edges; ++e) {
-                    const SpWindowEdge ed = w.edges[e];
-                    if (ed.block != b) continue;
-                    const double* o = w.scratch + (size_t)e * w.stride + SP_WGN_REC + (size_t)n * SP_WGN_SEG;
-                    D += o[8]; bd += o[9];
-                    const int pt = pose_off[ed.trg_node], at = aff_off[ed.trg_node];
-                    if (pt >= 0) for (int k = 0; k < 6; ++k) Crow[pt + k] += o[k];
-                    if (at >= 0) { Crow[at] += o[6]; Crow[at + 1] += o[7]; }
-                    if (ed.src_node >= 0) {
-                        const int ps = pose_off[ed.src_node], as = aff_off[ed.src_node];
-                        if (ps >= 0) {
-                            const double* Ad = w.Ad + (size_t)e * 36;
-                            for (int k = 0; k < 6; ++k) {
-                                double s = 0.0;
-                                for (int p = 0; p < 6; ++p) s += Ad[6 * p + k] * o[p];
-                                Crow[ps + k] -= s;
-                            }
-                        }
-                        if (as >= 0) { Crow[as] -= o[6]; Crow[as + 1] -= o[7]; }
+            if (tid < 10) {               // the diagonal block's final entries (thread t writes one of the 10; after the barrier: every thread has read the block)
+                int a = 0, q = tid;
+                while (q > a) { q -= a + 1; ++a; }
+                double v = 0.0;
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa)
+#pragma unroll
+                    for (int qq = 0; qq <= aa; ++qq) if (aa == a && qq == q) v = c[aa][qq];
+                if (a < B) H[ltri(k + a, k + q)] = v;
+            }
+            for (int i = k + B + ti; i < n_y; i += SP_WGN_GRID) {
+                double cis[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cis[q] = q < B ? H[ltri(i, k + q)] * dinv[q] : 0.0;
+                const int rowi = (i * (i + 1)) >> 1;
+                // four columns j at a time: all their loads first (a load-modify-store per element would serialise on LDS latency:
+                // the compiler cannot move the next element's loads above a store that may alias them)
+                for (int j0 = k + B + tj; j0 <= i; j0 += 4 * SP_WGN_GRID) {
+                    double hj[4][4], old[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + SP_WGN_GRID * u;
+                        const bool ok = j <= i;
+                        const int rowj = ok ? ((j * (j + 1)) >> 1) + k : 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) hj[u][q] = (ok && q < B) ? H[rowj + q] : 0.0;
+                        old[u] = ok ? H[rowi + j] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = j0 + SP_WGN_GRID * u;
+                        if (j <= i) H[rowi + j] = old[u] - (cis[0] * hj[u][0] + cis[1] * hj[u][1] + cis[2] * hj[u][2] + cis[3] * hj[u][3]);
                     }
                 }
             }
-            const double Dd = D * (1.0 + lam);
-            w.Dinv[r] = (!frozen && Dd > 1e-12) ? 1.0 / Dd : 0.0;
-            w.Bd[r] = bd;
+            __syncthreads();
         }
     }
-    __threadfence_block();
-    __syncthreads();
-    // ---- LM damping of the camera block, then the Schur complement of the depth block ------------------------------
-    for (int i = tid; i < n_y; i += SP_BLOCK) H[i * n_y + i] = H[i * n_y + i] * (1.0 + lam) + 1e-12;
-    __syncthreads();
-    for (int idx = tid; idx < n_y * n_y; idx += SP_BLOCK) {
-        const int i = idx / n_y, j = idx - i * n_y;
-        if (j > i) continue;
-        double s = 0.0;
-        for (int r = 0; r < sumN; ++r) {
-            const double dinv = w.Dinv[r];
-            if (dinv == 0.0) continue;
-            const double* Crow = w.C + (size_t)r * SP_WGN_MAX_Y;
-            s += Crow[i] * Crow[j] * dinv;
-        }
-        H[i * n_y + j] -= s;
-    }
-    for (int i = tid; i < n_y; i += SP_BLOCK) {
-        double s = 0.0;
-        for (int r = 0; r < sumN; ++r) {
-            const double dinv = w.Dinv[r];
-            if (dinv != 0.0) s += w.C[(size_t)r * SP_WGN_MAX_Y + i] * w.Bd[r] * dinv;
-        }
-        dy[i] = -(g[i] - s);                  // right-hand side of S dy = -(g - C^T D^-1 b_d)
-    }
-    __syncthreads();
-    // ---- Cholesky S = L L^T in place (lower triangle), forward / backward substitution -----------------------------
-    for (int k = 0; k < n_y; ++k) {
-        if (tid == 0) {
-            const double d = H[k * n_y + k];
-            if (!(d > 0.0)) chol_fail = 1;
-            else H[k * n_y + k] = sqrt(d);
+    WGN_STAMP(5);
+    if (!fail) {
+        // L y = rhs, z = D^-1 y, L^T x = z by ONE wave, wave-synchronously: lane l holds entries l, l + 64, ... of the vector in registers,
+        // the pivot entry of a column travels through a scalar register (v_readlane) -- no block barrier per column
+        if (tid < 64) {
+            constexpr int PER = (CAP + 63) / 64;
+            double x[PER];
+            auto bcast = [&](int k) -> double {
+                double xk = 0.0;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) if ((k >> 6) == q) xk = x[q];
+                const int lo = __builtin_amdgcn_readlane(__double2loint(xk), k & 63), hi = __builtin_amdgcn_readlane(__double2hiint(xk), k & 63);
+                return __hiloint2double(hi, lo);
+            };
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; x[q] = i < n_y ? dy[i] : 0.0; }
+            // (the matrix entries and 1 / d_k of step k + 1 are loaded while step k's pivot travels: the loop-carried chain is
+            //  readlane -> multiply -> fma only)
+            double hn[PER], dn = n_y > 0 ? dinvs[0] : 0.0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = (i > 0 && i < n_y) ? H[ltri(i, 0)] : 0.0; }
+            for (int k = 0; k < n_y; ++k) {                  // forward: y_i -= (c_ik / d_k) y_k for i > k
+                double hc[PER];
+                const double dc = dn;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) hc[q] = hn[q];
+                if (k + 1 < n_y) {
+                    dn = dinvs[k + 1];
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = (i > k + 1 && i < n_y) ? H[ltri(i, k + 1)] : 0.0; }
+                }
+                const double f = bcast(k) * dc;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) x[q] -= hc[q] * f;
+            }
+            double rd[PER];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; rd[q] = i < n_y ? dinvs[i] : 0.0; x[q] *= rd[q]; }
+            if (n_y > 0) {
+                const int rl = ((n_y - 1) * n_y) >> 1;
+#pragma unroll
+                for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = i < n_y - 1 ? H[rl + i] * rd[q] : 0.0; }
+            }
+            for (int k = n_y - 1; k >= 0; --k) {             // backward: x_i -= (c_ki / d_i) x_k for i < k
+                double hc[PER];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) hc[q] = hn[q];
+                if (k > 0) {
+                    const int rowk = ((k - 1) * k) >> 1;
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = i < k - 1 ? H[rowk + i] * rd[q] : 0.0; }
+                }
+                const double xk = bcast(k);
+#pragma unroll
+                for (int q = 0; q < PER; ++q) x[q] -= hc[q] * xk;
+            }
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; if (i < n_y) dy[i] = x[q]; }
         }
         __syncthreads();
-        if (chol_fail) break;
-        const double piv = H[k * n_y + k];
-        for (int i = k + 1 + tid; i < n_y; i += SP_BLOCK) H[i * n_y + k] /= piv;
-        __syncthreads();
-        const int m = n_y - k - 1;
-        for (int idx = tid; idx < m * m; idx += SP_BLOCK) {
-            const int i = k + 1 + idx / m, j = k + 1 + idx % m;
-            if (j <= i) H[i * n_y + j] -= H[i * n_y + k] * H[j * n_y + k];
-        }
-        __syncthreads();
-    }
-    if (!chol_fail) {
-        for (int k = 0; k < n_y; ++k) {                  // L y = rhs (column oriented)
-            if (tid == 0) dy[k] /= H[k * n_y + k];
-            __syncthreads();
-            const double yk = dy[k];
-            for (int i = k + 1 + tid; i < n_y; i += SP_BLOCK) dy[i] -= H[i * n_y + k] * yk;
-            __syncthreads();
-        }
-        for (int k = n_y - 1; k >= 0; --k) {             // L^T x = y
-            if (tid == 0) dy[k] /= H[k * n_y + k];
-            __syncthreads();
-            const double xk = dy[k];
-            for (int i = tid; i < k; i += SP_BLOCK) dy[i] -= H[k * n_y + i] * xk;
-            __syncthreads();
-        }
     } else {
-        // not positive definite at this damping: no step; raise lambda like after a rejected step (the point is unchanged, so
-        // the next evaluation repeats the cost and the solve happens again with the larger lambda)
-        if (tid == 0) { st[0] *= w.lm_up; st[8] += 1.f; }
-        for (int i = tid; i < n_y; i += SP_BLOCK) dy[i] = 0.0;
+        // not positive definite at this damping: no step.  Raise lambda and mark the point as "rejected last" (st[4]): the next call
+        // evaluates the same point, must neither test it for convergence (its loss equals the stored one) nor lower lambda, and solves
+        // again with the larger damping.
+        if (tid == 0) { st[0] *= w.lm_up; st[8] += 1.f; st[4] = 1.f; st[2] -= 1.f; }
+        for (int i = tid; i < n_y; i += SP_WGN_THREADS) dy[i] = 0.0;
         __syncthreads();
     }
+    WGN_STAMP(6);
     // ---- depth steps (back-substitution), clamped like the pair solver's ------------------------------------------
-    if (!chol_fail) {
+    if (!fail) {
         for (int b = 0; b < w.n_blocks; ++b) {
             const SpWindowBlock bk = w.blocks[b];
-            for (int n = tid; n < bk.N; n += SP_BLOCK) {
-                const int r = blk_off[b] + n;
-                const double dinv = w.Dinv[r];
-                if (dinv == 0.0) continue;
-                const double* Crow = w.C + (size_t)r * SP_WGN_MAX_Y;
-                double s = -w.Bd[r];
-                for (int i = 0; i < n_y; ++i) s -= Crow[i] * dy[i];
-                double dd = s * dinv;
-                dd = fmin(fmax(dd, -0.5), 0.5);
-                bk.kld[n] += (float)dd;
+            const int nc = w.nc[b];
+            const int* cb = w.cols + (size_t)b * ldc;
+            for (int n0 = 0; n0 < bk.N; n0 += SP_WGN_THREADS / 4) {        // four lanes per row, their partial sums added in a fixed order
+                const int n = n0 + (tid >> 2), part = tid & 3;
+                const bool row_ok = n < bk.N;
+                const int r = blk_off[b] + (row_ok ? n : 0);
+                const double dinv = row_ok ? w.Dinv[r] : 0.0;
+                const double* Crow = w.C + (size_t)r * ldc;
+                double s = 0.0;
+                if (dinv != 0.0)
+                    for (int i = part; i < nc; i += 4) s -= Crow[i] * dy[cb[i]];
+                const double s1 = __shfl_xor(s, 1);
+                s += s1;
+                const double s2 = __shfl_xor(s, 2);
+                s += s2;
+                if (part == 0 && dinv != 0.0) {
+                    double dd = (s - w.Bd[r]) * dinv;
+                    dd = fmin(fmax(dd, -0.5), 0.5);
+                    bk.kld[n] += (float)dd;
+                }
             }
         }
+        WGN_STAMP(7);
         // ---- poses and affine pairs ---------------------------------------------------------------------------------
-        for (int i = tid; i < w.n_nodes; i += SP_BLOCK) {
+        for (int i = tid; i < w.n_nodes; i += SP_WGN_THREADS) {
             SpWindowNode& nd = w.nodes[i];
             if (aff_off[i] >= 0) { nd.aff[0] += (float)dy[aff_off[i]]; nd.aff[1] += (float)dy[aff_off[i] + 1]; }
             if (pose_off[i] < 0) continue;
@@ -460,45 +746,108 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_update(WGnArgs w) {
     }
     __threadfence_block();
     __syncthreads();
-    for (int e = tid; e < w.n_edges; e += SP_BLOCK) wgn_compose_edge(w, e);
+    WGN_STAMP(8);
+    for (int e = tid; e < w.n_edges; e += SP_WGN_THREADS) wgn_compose_edge(w, e);
+    WGN_STAMP(9);
 }
 
 }  // namespace
 
 extern "C" {
 
-int sp_window_gn_scratch_doubles(int n_edges, int sum_N, int max_N) {
-    if (n_edges <= 0 || sum_N <= 0 || max_N <= 0) return 0;
-    return n_edges * (SP_WGN_REC + SP_WGN_SEG * max_N) + n_edges * 36 + sum_N * (SP_WGN_MAX_Y + 2);
+// n_unknowns: camera unknowns the window can have (6 per node with lr_pose > 0 + 2 per node with lr_aff > 0)
+int sp_window_gn_scratch_doubles(int n_edges, int n_blocks, int sum_N, int max_N, int n_unknowns) {
+    if (n_edges <= 0 || n_blocks <= 0 || sum_N <= 0 || max_N <= 0 || n_unknowns < 0 || n_unknowns > SP_WGN_MAX_Y) return 0;
+    const long long ldc = (n_unknowns + 1) & ~1;
+    const long long tri = (long long)n_unknowns * (n_unknowns + 1) / 2;
+    const long long hg = n_unknowns > SP_WGN_LDS_Y ? tri : 0;
+    const long long n = (long long)n_edges * (SP_WGN_REC + SP_WGN_SEG * max_N) + (long long)n_edges * (36 + SP_WGN_LOC) + (long long)sum_N * (ldc + 2) + (long long)n_blocks * (tri + 2 * ldc + 2) + hg + 8 + 16;
+    return n > 0x7fffffffLL ? 0 : (int)n;
+}
+
+// offset (in doubles) inside the scratch of the 16 time stamps the update kernel leaves (wall_clock64 ticks, 100 MHz): [0] entry,
+// [1] decision taken, [2] backup + clear, [3] assembly, [4] Schur terms subtracted, [5] factorisation, [6] substitutions, [7] depth
+// steps, [8] poses, [9] edges recomposed
+int sp_window_gn_profile_offset(int n_edges, int n_blocks, int sum_N, int max_N, int n_unknowns) {
+    if (n_edges <= 0 || n_blocks <= 0 || sum_N <= 0 || max_N <= 0 || n_unknowns < 0 || n_unknowns > SP_WGN_MAX_Y) return -1;
+    const long long ldc = (n_unknowns + 1) & ~1;
+    const long long tri = (long long)n_unknowns * (n_unknowns + 1) / 2;
+    return (int)((long long)n_edges * (SP_WGN_REC + SP_WGN_SEG * max_N) + (long long)n_edges * (36 + SP_WGN_LOC) + (long long)sum_N * (ldc + 2) +
+                 (long long)n_blocks * (tri + 2 * ldc) + n_blocks + 2);
 }
 
 int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes,
-                      const SpWindowBlock* blocks, int n_blocks, int sum_N, int max_N, const float* span_partials,
+                      const SpWindowBlock* blocks, int n_blocks, int sum_N, int max_N, int n_unknowns, const float* span_partials,
                       const float* seg_partials, double* scratch, SpWindowNode* nodes_backup, float* kld_backup, int flags,
                       float lm_up, float lm_down, float lm_min, float conv_tol, float* state, float* losses, int max_losses,
                       void* stream) {
     if (!pairs || !edges || !nodes || !blocks || !span_partials || !seg_partials || !scratch || !nodes_backup || !kld_backup || !state ||
         !losses)
         return SP_EINVAL;
-    if (n_edges <= 0 || n_nodes <= 0 || n_blocks <= 0 || sum_N <= 0 || max_N <= 0 || max_losses < 0) return SP_EINVAL;
-    if (n_nodes > SP_WGN_MAX_NODES || n_blocks > SP_WGN_MAX_NODES) return SP_ELIMIT;
+    if (n_edges <= 0 || n_nodes <= 0 || n_blocks <= 0 || sum_N <= 0 || max_N <= 0 || max_losses < 0 || n_unknowns < 0) return SP_EINVAL;
+    if (n_nodes > SP_WGN_MAX_NODES || n_blocks > SP_WGN_MAX_NODES || n_unknowns > SP_WGN_MAX_Y) return SP_ELIMIT;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int stride = SP_WGN_REC + SP_WGN_SEG * max_N;
-    hipLaunchKernelGGL(k_window_gn_reduce, dim3(n_edges), dim3(SP_BLOCK), 0, s, pairs, edges, span_partials, seg_partials, scratch, stride);
-    SP_CHECK_LAUNCH();
     WGnArgs w;
     w.pairs = pairs; w.edges = edges; w.n_edges = n_edges; w.nodes = nodes; w.n_nodes = n_nodes; w.blocks = blocks; w.n_blocks = n_blocks;
     w.max_N = max_N; w.scratch = scratch; w.stride = stride;
+    w.ldc = (n_unknowns + 1) & ~1;
+    w.lds = n_unknowns * (n_unknowns + 1) / 2;
+    w.cap_y = n_unknowns;
     w.Ad = scratch + (size_t)n_edges * stride;
-    w.C = w.Ad + (size_t)n_edges * 36;
-    w.Dinv = w.C + (size_t)sum_N * SP_WGN_MAX_Y;
+    w.loc = w.Ad + (size_t)n_edges * 36;
+    w.C = w.loc + (size_t)n_edges * SP_WGN_LOC;
+    w.Dinv = w.C + (size_t)sum_N * w.ldc;
     w.Bd = w.Dinv + sum_N;
+    w.S = w.Bd + sum_N;
+    w.Rhs = w.S + (size_t)n_blocks * w.lds;
+    w.cols = reinterpret_cast<int*>(w.Rhs + (size_t)n_blocks * w.ldc);           // n_blocks x ldc ints in n_blocks x ldc / 2 doubles' room ...
+    w.nc = reinterpret_cast<int*>(w.Rhs + (size_t)n_blocks * w.ldc * 2);         // ... (a full n_blocks x ldc doubles are reserved)
+    w.prof = w.Rhs + (size_t)n_blocks * w.ldc * 2 + n_blocks + 2;
+    w.Hg = w.prof + 16;
     w.nodes_backup = nodes_backup; w.kld_backup = kld_backup; w.flags = flags;
     w.lm_up = lm_up; w.lm_down = lm_down; w.lm_min = lm_min; w.conv_tol = conv_tol;
     w.state = state; w.losses = losses; w.max_losses = max_losses;
-    hipLaunchKernelGGL(k_window_gn_update, dim3(1), dim3(SP_BLOCK), 0, s, w);
+    hipLaunchKernelGGL(k_window_gn_reduce, dim3(n_edges), dim3(SP_BLOCK), 0, s, pairs, edges, span_partials, seg_partials, scratch, stride, w.Ad, w.loc);
+    SP_CHECK_LAUNCH();
+    const int tiles = max(1, (w.lds + SP_BLOCK * SP_WGN_PPT - 1) / (SP_BLOCK * SP_WGN_PPT));
+    hipLaunchKernelGGL(k_window_gn_schur, dim3(n_blocks, tiles), dim3(SP_BLOCK), 0, s, w);
+    SP_CHECK_LAUNCH();
+    if (n_unknowns <= 64) hipLaunchKernelGGL(k_window_gn_update<64>, dim3(1), dim3(SP_WGN_THREADS), 0, s, w);
+    else if (n_unknowns <= 128) hipLaunchKernelGGL(k_window_gn_update<128>, dim3(1), dim3(SP_WGN_THREADS), 0, s, w);
+    else if (n_unknowns <= SP_WGN_LDS_Y) hipLaunchKernelGGL(k_window_gn_update<SP_WGN_LDS_Y>, dim3(1), dim3(SP_WGN_THREADS), 0, s, w);
+    else hipLaunchKernelGGL(k_window_gn_update<0>, dim3(1), dim3(SP_WGN_THREADS), 0, s, w);
     SP_CHECK_LAUNCH();
     return 0;
+}
+
+/* Up to max_iters iterations (cost pass in mode 2 over the window's work list + sp_window_gn_step) as ONE foreign call: the state is
+ * copied to pinned host memory every check_every iterations (synchronising this stream only) and the loop ends once the window froze
+ * (converged, odometery.py:907-915's break).  Returns the iterations launched or a negative error. */
+int sp_window_gn_run(const SpPair* pairs, const int32_t* chunks, const int32_t* spans, int n_spans, float irls_eps,
+                     const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes, const SpWindowBlock* blocks, int n_blocks,
+                     int sum_N, int max_N, int n_unknowns, float* span_partials, float* seg_partials, double* scratch,
+                     SpWindowNode* nodes_backup, float* kld_backup, int flags, float lm_up, float lm_down, float lm_min, float conv_tol,
+                     float* state, float* losses, int max_losses, int max_iters, int check_every, float* state_host, void* stream) {
+    if (!state_host || max_iters < 0 || check_every <= 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int it = 0;
+    while (it < max_iters) {
+        const int n = (max_iters - it) < check_every ? (max_iters - it) : check_every;
+        for (int k = 0; k < n; ++k, ++it) {
+            int rc = sp_pairs_cost(pairs, chunks, spans, n_spans, 2, irls_eps, span_partials, seg_partials, stream);
+            if (rc == 0)
+                rc = sp_window_gn_step(pairs, edges, n_edges, nodes, n_nodes, blocks, n_blocks, sum_N, max_N, n_unknowns, span_partials,
+                                       seg_partials, scratch, nodes_backup, kld_backup, flags, lm_up, lm_down, lm_min, conv_tol, state, losses,
+                                       max_losses, stream);
+            if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
+        }
+        hipError_t e = hipMemcpyAsync(state_host, state, SP_WGN_STATE * sizeof(float), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        if (conv_tol > 0.f && static_cast<volatile float*>(state_host)[6] != 0.f) break;
+    }
+    return it;
 }
 
 }  // extern "C"

@@ -33,8 +33,8 @@ def gather_results(poses, klds, n_total=None):
     poses: (m_local,4,4) ; klds: (m_local, N) padded to a common N (rows may differ per rank by at most one, as
     produced by shard_range).  Returns (poses (M,4,4), klds (M,N)).  Ragged shard sizes are handled by padding to
     the largest shard and trimming -- a single all_gather per tensor, no point-to-point traffic."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return poses, klds
+    if not dist.is_initialized():
+        return poses, klds                  # (a one-rank group still goes through the backend: tests/test_gpu_rccl.py)
     world = dist.get_world_size()
     m_local = torch.tensor([poses.shape[0]], device=poses.device, dtype=torch.int64)
     sizes = [torch.zeros_like(m_local) for _ in range(world)]
@@ -64,7 +64,7 @@ def reduce_depth_accumulators(sums, counts, group=None):
     ``sp_depth_accumulate``, in place.  Integer addition is exact and commutative: every rank ends up with bitwise the
     accumulators a single GPU would have built over all segments; ``count == 0`` (invalid pixel) is the AND over ranks of
     the local invalidity, i.e. validity is OR-ed."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
     return sums, counts

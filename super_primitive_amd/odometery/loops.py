@@ -195,22 +195,31 @@ class GnTracker:
         return T, (win.node_affines()[1] if self.affine else None), list(win.gn_losses().unbind(0)), its
 
 
-def window_connectivity(n_kfs):
-    """Neighbouring keyframes only (odometery.py:451-479, mode 'map')."""
-    return {s: [t for t in (s - 1, s + 1) if 0 <= t < n_kfs] for s in range(n_kfs)}
+def window_connectivity(n_kfs, mode='map'):
+    """Neighbouring keyframes only (odometery.py:451-479); in 'supp' mode only the latest keyframe is a source (:467-469)."""
+    return {s: [t for t in (s - 1, s + 1) if 0 <= t < n_kfs] for s in range(n_kfs) if not (mode == 'supp' and s != n_kfs - 1)}
 
 
 def _window_targets(s, n_kfs, supp):
     """Targets of source keyframe s, in the reference's order (odometery.py:770-823): its neighbouring keyframes, then
     its own supporting frames, then those of the previous keyframe.  Entries: ('kf', t) or ('supp', k, j)."""
-    out = [('kf', t) for t in window_connectivity(n_kfs)[s]]
+    out = [('kf', t) for t in (s - 1, s + 1) if 0 <= t < n_kfs]
     for ss in ([s] + ([s - 1] if s > 0 else [])):
         out += [('supp', ss, j) for j in range(len(supp[ss]))]
     return out
 
 
+def _free_parts(K, mode, frozen0):
+    """Which parameters the reference's optimiser holds (odometery.py:576-648): (pose of keyframe k free, depths of keyframe k free,
+    supporting frames free).  'supp': only the latest keyframe's depths (:616-619,634-635 and no pose / affine groups, :586-588,
+    :628-629,:544)."""
+    if mode == 'supp':
+        return [False] * K, [k == K - 1 for k in range(K)], False
+    return [k > 0 for k in range(K)], [not (k == 0 and frozen0) for k in range(K)], True
+
+
 def map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose=1e-4, window_size=5, initialised=True,
-               fused=True, rel_tol=1e-8, optimiser="adam", gn_schedule=None):
+               fused=True, rel_tol=1e-8, optimiser="adam", gn_schedule=None, mode='map'):
     """Windowed mapping over several source keyframes (odometery/odometery.py:576-648 parameter groups, :756-915 loop,
     ``opt_supporting`` on).
 
@@ -221,77 +230,92 @@ def map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose=1e-4, w
     1e-2, poses ``lr_pose`` (1e-4, or 1e-2 at mono-init), affines 1e-5; loss = sum_src mean_targets(residual) (:845-850);
     every iteration every pose is folded in ``T <- T inv(Exp(D))``, renormalised and its tangent zeroed (:861-882); when
     ``initialised`` the loop stops once the relative loss change is < ``rel_tol`` (:907-915).
+    ``mode``: 'map' / 'init' as above; 'supp' = the supplementary mapping after every tracked frame (:1038-1042): only the latest
+    keyframe is a source (:467-469) and only ITS log-depths are optimised (:616-619) -- no pose, no affine pair moves.
     ``optimiser='gn'``: the same window -- same unknowns, same fixed / frozen parts, same fold-in -- optimised by Gauss-Newton / LM
     (``sp_window_gn_step``; MAP_GN_SCHEDULE, ``num_iters`` caps the main phase) instead of Adam.
     Returns dict(kf_poses (K,4,4), klds [K], affs (K,2)|None, supp_poses [[...]], supp_affs [[...]], losses, stopped)."""
+    assert mode in ('map', 'init', 'supp')
     K = len(kfs)
     affine = kf_affs is not None
     frozen0 = K == window_size
     if optimiser == "gn":
-        return _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol,
+        return _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode,
                                  gn=dict(MAP_GN_SCHEDULE, **(gn_schedule or {})))
     if fused:
-        return _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol)
-    return _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol)
+        return _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode)
+    return _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode)
 
 
-def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, gn=None):
+def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode='map', gn=None):
     from ..optim.window import KIND_WINDOW, PoseWindow
     K = len(kfs)
+    free_pose, free_kld, free_supp = _free_parts(K, mode, frozen0)
     lr_aff = 1e-5 if affine else 0.0
-    nodes = [dict(T=kf_poses[k], kind=KIND_WINDOW, lr_pose=lr_pose if k > 0 else 0.0, lr_aff=lr_aff if k > 0 else 0.0,
+    nodes = [dict(T=kf_poses[k], kind=KIND_WINDOW, lr_pose=lr_pose if free_pose[k] else 0.0, lr_aff=lr_aff if free_pose[k] else 0.0,
                   aff=kf_affs[k] if affine else None, renorm=True, image=kfs[k].image, K=kfs[k].K) for k in range(K)]
     supp_node = {}
     for k in range(K):
         for j, (f, pose, aff) in enumerate(supp[k]):
             supp_node[(k, j)] = len(nodes)
-            nodes.append(dict(T=pose, kind=KIND_WINDOW, lr_pose=lr_pose, lr_aff=lr_aff, aff=aff if affine else None, renorm=True,
-                              image=f.image, K=f.K))
-    sources = [dict(kf=kfs[k], kld=kf_klds[k], lr=0.0 if (k == 0 and frozen0) else 1e-2, node=k) for k in range(K)]
+            nodes.append(dict(T=pose, kind=KIND_WINDOW, lr_pose=lr_pose if free_supp else 0.0, lr_aff=lr_aff if free_supp else 0.0,
+                              aff=aff if affine else None, renorm=True, image=f.image, K=f.K))
+    src_ids = sorted(window_connectivity(K, mode))                 # keyframes that are sources; block index = position in this list
+    sources = [dict(kf=kfs[k], kld=kf_klds[k], lr=1e-2 if free_kld[k] else 0.0, node=k) for k in src_ids]
     edges = []
-    for s in range(K):
+    for b, s in enumerate(src_ids):
         trg = _window_targets(s, K, supp)
         for t in trg:
             node = t[1] if t[0] == 'kf' else supp_node[(t[1], t[2])]
-            edges.append((s, node, 1.0 / len(trg), dense_optim.Z_MIN_BATCH))
+            edges.append((b, node, 1.0 / len(trg), dense_optim.Z_MIN_BATCH))
+    det = lambda x: x.detach().clone()
+    if not edges:                                                  # a single keyframe without supporting frames: nothing to match
+        return dict(kf_poses=torch.stack([det(p) for p in kf_poses]), klds=[det(k) for k in kf_klds],
+                    affs=torch.stack([det(a) for a in kf_affs]) if affine else None, supp_poses=[[] for _ in range(K)],
+                    supp_affs=[[] for _ in range(K)] if affine else None, losses=[torch.zeros((), device=kf_poses[0].device)], stopped=-1)
     win = PoseWindow(sources, nodes, edges, (0, 1), abs_loss=False, rel_tol=rel_tol if initialised else 0.0, use_affine=affine,
                      max_iters=max(1, num_iters) + (gn['polish_max'] + 8 if gn else 0))
     if gn:
         n = win.run_gn(0, min(num_iters, gn['max_iters']), irls_eps=gn['irls_eps'], conv_tol=gn['conv_tol'])
-        if gn['polish_max'] > 0:
+        if gn['polish_max'] > 0 and num_iters > gn['max_iters'] // 2:      # (a short budget -- the supplementary mapping -- gets no polish)
             n += win.run_gn(0, gn['polish_max'], irls_eps=gn['polish_eps'], conv_tol=gn['polish_tol'])
         poses, affs, losses = win.node_poses(), win.node_affines(), win.gn_losses()
-        return dict(kf_poses=poses[:K], klds=win.klds(), affs=affs[:K] if affine else None,
-                    supp_poses=[[poses[supp_node[(k, j)]] for j in range(len(supp[k]))] for k in range(K)],
-                    supp_affs=[[affs[supp_node[(k, j)]] for j in range(len(supp[k]))] for k in range(K)] if affine else None,
-                    losses=list(losses.unbind(0)), stopped=n, gn=win.gn_stats())
-    win.run(0, num_iters)
-    poses, affs, losses = win.node_poses(), win.node_affines(), win.losses()
-    return dict(kf_poses=poses[:K], klds=win.klds(), affs=affs[:K] if affine else None,
+        stopped, extra = n, dict(gn=win.gn_stats(), gn_profile=win.gn_profile())
+    else:
+        win.run(0, num_iters)
+        poses, affs, losses = win.node_poses(), win.node_affines(), win.losses()
+        stopped, extra = (win.iterations() - 1 if win.converged() else -1), {}
+    wk = win.klds()
+    klds = [det(k) for k in kf_klds]
+    for b, s in enumerate(src_ids):
+        klds[s] = wk[b]
+    return dict(kf_poses=poses[:K], klds=klds, affs=affs[:K] if affine else None,
                 supp_poses=[[poses[supp_node[(k, j)]] for j in range(len(supp[k]))] for k in range(K)],
                 supp_affs=[[affs[supp_node[(k, j)]] for j in range(len(supp[k]))] for k in range(K)] if affine else None,
-                losses=list(losses.unbind(0)), stopped=win.iterations() - 1 if win.converged() else -1)
+                losses=list(losses.unbind(0)), stopped=stopped, **extra)
 
 
-def _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol):
+def _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode='map'):
     """The same loop as eager PyTorch around ``photomeric_cost_batch`` (autograd + torch.optim.Adam), statement for
     statement the reference's; kept as the engine-independent check of the fused one."""
     K = len(kfs)
     dev = kf_poses[0].device
+    free_pose, free_kld, free_supp = _free_parts(K, mode, frozen0)
     kf_poses = [p.detach().clone() for p in kf_poses]
-    d_kf = [None] + [LieGroupParameter(SE3.Identity(1, device=dev)) for _ in range(K - 1)]
-    klds = [k.detach().clone() if (i == 0 and frozen0) else nn.Parameter(k.detach().clone()) for i, k in enumerate(kf_klds)]
-    affs = ([kf_affs[0].detach().clone()] + [nn.Parameter(a.detach().clone()) for a in kf_affs[1:]]) if affine else [None] * K
+    d_kf = [LieGroupParameter(SE3.Identity(1, device=dev)) if free_pose[k] else None for k in range(K)]
+    klds = [nn.Parameter(k.detach().clone()) if free_kld[i] else k.detach().clone() for i, k in enumerate(kf_klds)]
+    affs = [nn.Parameter(a.detach().clone()) if free_pose[i] else a.detach().clone() for i, a in enumerate(kf_affs)] if affine else [None] * K
     s_pose = [[p.detach().clone() for _, p, _ in supp[k]] for k in range(K)]
-    s_delta = [[LieGroupParameter(SE3.Identity(1, device=dev)) for _ in supp[k]] for k in range(K)]
-    s_aff = [[nn.Parameter(a.detach().clone()) for _, _, a in supp[k]] for k in range(K)] if affine else None
+    s_delta = [[LieGroupParameter(SE3.Identity(1, device=dev)) if free_supp else None for _ in supp[k]] for k in range(K)]
+    s_aff = [[nn.Parameter(a.detach().clone()) if free_supp else a.detach().clone() for _, _, a in supp[k]] for k in range(K)] if affine else None
     groups = [{'params': [k for k in klds if isinstance(k, nn.Parameter)], 'lr': 1e-2},
               {'params': [d for d in d_kf if d is not None], 'lr': lr_pose}]
-    if affine:
-        groups.append({'params': affs[1:], 'lr': 1e-5})
-    groups.append({'params': [d for row in s_delta for d in row], 'lr': lr_pose})
-    if affine:
-        groups.append({'params': [a for row in s_aff for a in row], 'lr': 1e-5})
+    if affine and mode != 'supp':
+        groups.append({'params': [a for a in affs if isinstance(a, nn.Parameter)], 'lr': 1e-5})
+    if free_supp:
+        groups.append({'params': [d for row in s_delta for d in row], 'lr': lr_pose})
+        if affine:
+            groups.append({'params': [a for row in s_aff for a in row], 'lr': 1e-5})
     optim = torch.optim.Adam(groups, lr=1e-3)
     eye = torch.eye(4, device=dev)
     mat = lambda d: eye if d is None else d.retr().matrix()[0]
@@ -299,7 +323,7 @@ def _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose,
     losses, prev, stopped = [], float('inf'), -1
     for it in range(num_iters):
         res = []
-        for s in range(K):
+        for s in window_connectivity(K, mode):
             src_delta = mat(d_kf[s])
             imgs, Ks, Ps, As = [], [], [], []
             for t in _window_targets(s, K, supp):
@@ -310,9 +334,13 @@ def _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose,
                     a_t = s_aff[t[1]][t[2]] if affine else None
                 imgs.append(f.image); Ks.append(f.K); As.append(a_t)
                 Ps.append(mat(D_t) @ invertSE3(T_t) @ kf_poses[s] @ torch.linalg.inv(src_delta))
+            if not imgs:
+                continue
             out = dense_optim_batch.photomeric_cost_batch(kfs[s], torch.stack(imgs), torch.stack(Ks), klds[s], torch.stack(Ps), CFG,
                                                           affine_comp=(affs[s], torch.stack(As)) if affine else None)
             res.append(out['residual'].mean())
+        if not res:
+            break
         loss = torch.sum(torch.stack(res))
         losses.append(loss.detach())
         loss.backward()
@@ -326,7 +354,8 @@ def _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose,
             for k in range(K):
                 for j in range(len(s_pose[k])):
                     s_pose[k][j] = renormalise_se3((s_pose[k][j] @ invertSE3(exp0(s_delta[k][j]))).contiguous())
-                    zero_out_lietorch_tensor(s_delta[k][j])
+                    if s_delta[k][j] is not None:
+                        zero_out_lietorch_tensor(s_delta[k][j])
         if initialised:
             cur = float(losses[-1])
             if abs(cur - prev) / prev < rel_tol:

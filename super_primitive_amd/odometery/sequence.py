@@ -1,16 +1,27 @@
 """BASELINE configs[2] as a SEQUENCE: the chain of the reference's MonoVO driver loop (``odometery/odometery.py:1018-1075``) that
-sits on the hot path -- track every frame against the latest keyframe (``:323-428``), keyframe decision from the rendered depth
-of the latest keyframe (``is_kf``, ``:986-1016``; ``odometery/kf_criteria.py``), a new keyframe's depths from that render by the
-per-segment median (``init_keyframe``, ``:124-196``: ``estimate_depth_latest_kf`` -> ``segment_based_depth_reinit``), windowed
-mapping once the new keyframe has supporting frames (``mapping``, ``:687-937``) -- on the HIP kernels, with nothing of the
-reference's frontend, GUI queues, checkpoints or dataset loaders (out of scope).
+sits on the hot path, with the reference's own bookkeeping of keyframes, supporting frames and the tracked pool:
 
-Every step is one of the drop-in functions the reference's driver calls (``core.depth_render.estimate_depth_kf_native``,
-``odometery.kf_criteria``, ``odometery.depth_init.segment_based_depth_reinit``) or one of the two inner loops of
-``odometery/loops.py``; ``engine`` picks the optimiser of those loops: ``'adam'`` = the reference's schedule on the fused engine
-(tracking ``[0, 0, 300]`` steps, mapping ``steps`` iterations), ``'gn'`` = Gauss-Newton / LM (``track_frame_gn``,
-``map_window(optimiser='gn')``).  The first keyframe is initialised from given depths (the reference's ``mono_init: False``
-branch, ``:140-163``), which fixes the scale of the trajectory."""
+    track_frame             every frame against the latest keyframe (``:323-449``; no motion prior: ``:324`` switches it off)
+    mapping(mode='supp')    ``continual_steps`` iterations after every tracked frame: only the latest keyframe's depths move
+                            (``:1038-1042``, parameter groups ``:616-619,634-635``, connectivity ``:467-469``)
+    mapping(mode='map')     the scheduled mapping once the new keyframe has two running supporting frames (``:1046-1055``); all
+                            keyframe poses but the first, all supporting-frame poses, all affine pairs, all depths but the oldest
+                            keyframe's in a full window
+    mapping(mode='init')    mono initialisation: two keyframes, unit depths, pose rate 1e-2, no early stop (``:1066-1071,578-581``)
+    is_kf                   rendered depth of the latest keyframe -> validity ratio / scaled translation (``:986-1016``)
+    init_keyframe           new keyframe's depths from that render by the per-segment median (``:124-196``)
+    supporting frames       at most ``supp_every_n - 1`` evenly spaced frames of the tracked pool become the supporting frames of a
+                            keyframe when its successor is created (``collect_tracking_frames(last=False)``, ``:1327-1360``); the
+                            latest keyframe is supported by the last two tracked frames (``last=True``); ``update_track_pose``
+                            (``:969-983``) hands the mapped pose of the newest frame back to the tracker
+
+on the HIP kernels, with nothing of the reference's frontend, GUI queues, checkpoints or dataset loaders (out of scope, SURVEY.md
+section 2).  Every step is one of the drop-in functions the reference's driver calls (``core.depth_render.estimate_depth_kf_native``,
+``odometery.kf_criteria``, ``odometery.depth_init.segment_based_depth_reinit``) or one of the inner loops of ``odometery/loops.py``;
+``engine`` picks the optimiser of those loops: ``'adam'`` = the reference's schedules on the fused engine (tracking ``[0, 0, 300]``
+steps, mapping ``steps`` / ``continual_steps`` / ``init_steps`` iterations), ``'gn'`` = Gauss-Newton / LM (``GnTracker``,
+``map_window(optimiser='gn')``).  Without ``mono_init`` the first two keyframes take their depths from given values (the
+reference's ground-truth-depth branch, ``:140-163``), which fixes the scale of the trajectory."""
 from __future__ import annotations
 
 import time
@@ -23,79 +34,229 @@ from .depth_init import segment_based_depth_reinit
 from .kf_criteria import keyframe_criterion
 from .loops import GnTracker, map_window, track_frame_fused, track_frame_gn  # noqa: F401
 
-DEFAULTS = dict(track_steps=(0, 0, 300), track_levels=(0, 3), track_lr=5e-3, map_steps=500, map_lr_pose=1e-4, window_size=5,
-                supp_every_n=3, depth_validity_ratio=0.60, translation_thresh=0.2, affine_compensation=True)
+# config/tum/odom_desk.yaml (aligment.track / aligment.mapping / kf / window_size)
+DEFAULTS = dict(track_steps=(0, 0, 300), track_levels=(0, 3), track_lr=5e-3, map_steps=500, continual_steps=10, init_steps=1000,
+                map_lr_pose=1e-4, window_size=5, supp_every_n=3, depth_validity_ratio=0.60, translation_thresh=0.2,
+                affine_compensation=True, mono_init=False, init_frames=7, motion_prior=False)
+
+
+class _Supp:
+    """A supporting frame with its parameters (``SupportingKF`` + ``ParamsSupportingKF``, odometery.py:56-86)."""
+    __slots__ = ("frame", "pose", "aff", "ts")
+
+    def __init__(self, frame, pose, aff, ts):
+        self.frame, self.pose, self.aff, self.ts = frame, pose, aff, ts
+
+
+class MonoVO:
+    """State and steps of ``Odometery`` (odometery/odometery.py) that belong to the hot path; method names follow the reference."""
+
+    def __init__(self, frames, to_keyframe, pose0, kld0, engine="gn", log=None, depth_of=None, **cfg):
+        self.c = dict(DEFAULTS, **cfg)
+        self.frames, self.to_keyframe, self.engine, self.log = frames, to_keyframe, engine, log
+        self.depth_of = depth_of              # frame index -> keypoint log-depths (the ground-truth-depth branch for the second keyframe)
+        self.dev = pose0.device
+        self.affine = bool(self.c['affine_compensation'])
+        self.kfs, self.kf_ids, self.kf_poses, self.kf_klds, self.kf_affs, self.supp_opt = [], [], [], [], [], []
+        self.all_kf_ids = []
+        self.reset_tracked_poses()
+        self.reset_running_supp_kfs()
+        self.initialised = not self.c['mono_init']
+        self.mapping_scheduled = False
+        self.n_map = dict(supp=0, map=0, init=0)
+        self.secs = dict(track=0.0, keyframe=0.0, mapping=0.0, supp_mapping=0.0)
+        self.tracker = None                   # (Gauss-Newton engine: one window per keyframe, re-used for every frame tracked against it)
+        self.current_aff = torch.zeros(2, device=self.dev)
+        self.add_kf(to_keyframe(0), pose0.clone(), kld0.clone(), 0, self.current_aff.clone())
+        self.update_track_pose('init')
+        self.track = [pose0.clone()]
+
+    # ---- bookkeeping (odometery.py:1223-1390) ---------------------------------------------------------------------
+    def add_kf(self, kf, pose, kld, ts, aff):
+        self.kfs.append(kf); self.kf_ids.append(ts); self.kf_poses.append(pose); self.kf_klds.append(kld); self.kf_affs.append(aff)
+        self.supp_opt.append([])
+        self.all_kf_ids.append(ts)
+        self.tracker = None
+
+    def pop_kf(self, i):
+        for lst in (self.kfs, self.kf_ids, self.kf_poses, self.kf_klds, self.kf_affs, self.supp_opt):
+            lst.pop(i)
+
+    def reset_tracked_poses(self):
+        self.tracked = []
+
+    def reset_running_supp_kfs(self):
+        self.curr_supp = []
+
+    def collect_tracking_frames(self, last=False):
+        """odometery.py:1327-1360: ``last``: the two newest tracked frames; else ``supp_every_n - 1`` evenly spaced ones."""
+        n = len(self.tracked)
+        if last:
+            ids = [n - 1, n - 2]
+        else:
+            each_n = int(self.c['supp_every_n'])
+            ids = [i * (n - 1) // each_n + 1 for i in range(1, each_n)]
+        return [_Supp(self.tracked[i].frame, self.tracked[i].pose, self.tracked[i].aff, self.tracked[i].ts) for i in sorted(set(ids)) if 0 <= i < n]
+
+    def tracked_poses_to_supp(self):
+        """odometery.py:1271-1289."""
+        if not self.initialised:
+            self.reset_tracked_poses()
+            self.reset_running_supp_kfs()
+            return
+        self.curr_supp = self.collect_tracking_frames(last=True)
+
+    def flush_tracked_poses_to_supp(self):
+        """odometery.py:1314-1325 (called before the new keyframe is added: the pool supports the keyframe it was tracked against)."""
+        assert len(self.supp_opt[-1]) == 0
+        self.supp_opt[-1] = self.collect_tracking_frames(last=False)
+
+    def update_track_pose(self, mode):
+        """odometery.py:969-983."""
+        if len(self.curr_supp) == 0 or self.kf_ids[-1] > self.curr_supp[-1].ts:
+            assert mode != 'supp'
+            self.current_track = self.kf_poses[-1].detach().clone()
+            if self.affine:
+                self.current_aff = self.kf_affs[-1].detach().clone()
+            self.current_ts = self.kf_ids[-1]
+        else:
+            self.current_track = self.curr_supp[-1].pose.detach().clone()
+            if self.affine:
+                self.current_aff = self.curr_supp[-1].aff.detach().clone()
+            self.current_ts = self.curr_supp[-1].ts
+
+    # ---- tracking (odometery.py:323-449) --------------------------------------------------------------------------
+    def track_frame(self, i):
+        f, c = self.frames[i], self.c
+        supp_T = self.current_track
+        if c['motion_prior'] and len(self.tracked) >= 2:            # apply_motion_prior, :314-321 (the reference switches it off, :324)
+            supp_T = (self.current_track @ invertSE3(self.tracked[-2].pose)) @ supp_T
+        aff_kf = self.kf_affs[-1] if self.affine else None
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if self.engine == "gn":
+            if self.tracker is None:
+                self.tracker = GnTracker(self.kfs[-1], self.kf_klds[-1], self.kf_poses[-1], f, c['track_levels'], kf_aff=aff_kf)
+            T, aff, _, _ = self.tracker.track(f, supp_T, self.current_aff if self.affine else None)
+        else:
+            T, aff, _ = track_frame_fused(self.kfs[-1], self.kf_klds[-1], f, supp_T, self.kf_poses[-1], list(c['track_steps']), c['track_levels'],
+                                          lr=c['track_lr'], prev_aff=aff_kf, curr_aff=self.current_aff if self.affine else None)
+        torch.cuda.synchronize(); self.secs['track'] += time.perf_counter() - t0
+        self.current_track = T.detach().clone()
+        if self.affine:
+            self.current_aff = aff.detach().clone()
+        self.current_ts = i
+        self.tracked.append(_Supp(f, self.current_track.clone(), self.current_aff.clone(), i))
+        self.track.append(self.current_track.clone())
+
+    # ---- mapping (odometery.py:687-967) ---------------------------------------------------------------------------
+    def mapping(self, num_iters, mode='map'):
+        assert mode in ('init', 'map', 'supp')
+        c = self.c
+        if mode == 'init':
+            self.reset_running_supp_kfs()
+            self.reset_tracked_poses()
+        else:
+            self.tracked_poses_to_supp()
+        K = len(self.kfs)
+        # get_supp_kf_poses_pairs (:481-521): no supporting frames at all before the system is initialised
+        rows = [(self.curr_supp if k == K - 1 else self.supp_opt[k]) if self.initialised else [] for k in range(K)]
+        supp = [[(s.frame, s.pose, s.aff) for s in row] for row in rows]
+        lr_pose = 1e-2 if (mode == 'init' and c['mono_init']) else c['map_lr_pose']
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = map_window(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, supp, num_iters, lr_pose=lr_pose,
+                         window_size=c['window_size'], initialised=self.initialised, optimiser="gn" if self.engine == "gn" else "adam", mode=mode)
+        torch.cuda.synchronize(); self.secs['supp_mapping' if mode == 'supp' else 'mapping'] += time.perf_counter() - t0
+        self.kf_poses = [p.clone() for p in out['kf_poses']]
+        self.kf_klds = [k.clone() for k in out['klds']]
+        if self.affine:
+            self.kf_affs = [a.clone() for a in out['affs']]
+        for k, row in enumerate(rows):                            # (:949-960; rows are empty when the system was not initialised)
+            for j, s in enumerate(row):
+                s.pose = out['supp_poses'][k][j].clone()
+                if self.affine:
+                    s.aff = out['supp_affs'][k][j].clone()
+        self.n_map[mode] += 1
+        if self.tracker is not None:                              # the latest keyframe moved
+            self.tracker.update_keyframe(self.kf_klds[-1], self.kf_poses[-1], self.kf_affs[-1] if self.affine else None)
+        if self.log is not None and mode != 'supp':
+            self.log.append((self.current_ts, 'mapping', dict(mode=mode, kf_ids=list(self.kf_ids), klds=[k.clone() for k in self.kf_klds],
+                                                               kf_poses=[p.clone() for p in self.kf_poses], n_supp=[len(r) for r in rows],
+                                                               losses=[float(out['losses'][0]), float(out['losses'][-1])], n=len(out['losses']),
+                                                               gn=out.get('gn'))))
+        self.update_track_pose(mode)
+        self.initialised = True
+
+    # ---- keyframe decision and creation (odometery.py:986-1016, 124-196) ---------------------------------------------
+    def estimate_depth_latest_kf(self, pose):
+        return estimate_depth_kf_native(self.kfs[-1], self.kf_klds[-1], invertSE3(pose) @ self.kf_poses[-1])
+
+    def is_kf(self, i):
+        c = self.c
+        if not self.initialised:
+            return i == c['init_frames'], None
+        est = self.estimate_depth_latest_kf(self.current_track)
+        crit = keyframe_criterion(self.current_track, self.kf_poses[-1], est).tolist()      # [validity ratio, scale, translation diff, rotation deg]
+        return (crit[0] < c['depth_validity_ratio'] or crit[2] > c['translation_thresh']), (est, crit)
+
+    def init_keyframe(self, i, info):
+        kf = self.to_keyframe(i)
+        if len(self.kfs) < 2 and self.c['mono_init']:
+            kld = torch.zeros(kf.keypoints.shape[0], device=self.dev)                        # log(1), :136-139
+            vis, crit, valid = None, None, None
+        elif len(self.kfs) < 2 and self.depth_of is not None:
+            kld = self.depth_of(i).to(self.dev)                                              # ground-truth depth at the keypoints, :141-163
+            vis, crit, valid = None, info[1] if info else None, None
+        else:
+            est, crit = info if info is not None else (self.estimate_depth_latest_kf(self.current_track), None)
+            kld, vis = segment_based_depth_reinit(est.clone(), kf, mode='median', return_info=True)
+            valid = float((est > 1e-6).float().mean())
+        if self.log is not None:
+            self.log.append((i, 'keyframe', dict(criterion=crit, kld=kld.clone(), visible=None if vis is None else int(vis.sum()), valid_ratio=valid)))
+        self.add_kf(kf, self.current_track.detach().clone(), kld, i, self.current_aff.detach().clone())
+        if self.c['window_size'] is not None and len(self.kfs) > self.c['window_size']:
+            self.pop_kf(0)
+
+    # ---- the driver loop (odometery.py:1018-1075) -----------------------------------------------------------------------
+    def step(self, i):
+        c = self.c
+        self.track_frame(i)
+        if self.initialised and c['continual_steps'] > 0:
+            self.mapping(c['continual_steps'], mode='supp')
+        if self.mapping_scheduled and len(self.curr_supp) >= 2:
+            self.mapping(c['map_steps'], mode='map')
+            self.mapping_scheduled = False
+            self.reset_tracked_poses()
+            self.reset_running_supp_kfs()
+        assert self.current_ts == i
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        new_kf, info = self.is_kf(i)
+        if new_kf:
+            self.flush_tracked_poses_to_supp()
+            self.init_keyframe(i, info)
+            self.reset_tracked_poses()
+            self.reset_running_supp_kfs()
+        torch.cuda.synchronize(); self.secs['keyframe'] += time.perf_counter() - t0
+        if new_kf:
+            if not self.initialised:
+                self.mapping(c['init_steps'], mode='init')
+            else:
+                self.mapping_scheduled = True
+
+    def run(self):
+        for i in range(1, len(self.frames)):
+            self.step(i)
+        return self.result()
+
+    def result(self):
+        return dict(track_poses=torch.stack(self.track), kf_ids=list(self.kf_ids), all_kf_ids=list(self.all_kf_ids), kf_poses=torch.stack(self.kf_poses),
+                    kf_klds=self.kf_klds, kf_affs=self.kf_affs, supp_ids=[[s.ts for s in row] for row in self.supp_opt],
+                    n_mappings=self.n_map['map'], n_supp_mappings=self.n_map['supp'], n_init_mappings=self.n_map['init'], seconds=self.secs)
 
 
 def run_sequence(frames, to_keyframe, pose0, kld0, engine="gn", **cfg):
     """frames: list of supporting-frame-like objects (``image`` (3,H,W), ``K``), frame 0 is the first keyframe;
     to_keyframe(i) -> KeyFrame of frame i (the frontend's job in the reference: segments + per-segment log-depth shapes);
-    pose0: camera-to-world of frame 0; kld0: keypoint log-depths of the first keyframe.
-    Returns dict(track_poses (n,4,4) camera-to-world as tracked, kf_ids, kf_poses, kf_klds, n_mappings, seconds dict)."""
-    log = cfg.pop('log', None)              # optional list: (frame, event, payload) records for diagnostics
-    c = dict(DEFAULTS, **cfg)
-    dev = pose0.device
-    affine = c['affine_compensation']
-    zero2 = lambda: torch.zeros(2, device=dev)
-    kfs, kf_ids, kf_poses, kf_klds, kf_affs, supp = [to_keyframe(0)], [0], [pose0.clone()], [kld0.clone()], [zero2()], [[]]
-    track = [pose0.clone()]
-    all_kf_ids = [0]
-    cur_T, cur_aff = pose0.clone(), zero2()
-    since_kf, scheduled, n_map = 0, False, 0
-    tracker = None                       # (Gauss-Newton engine: one window per keyframe, re-used for every frame tracked against it)
-    secs = dict(track=0.0, keyframe=0.0, mapping=0.0)
-    sync = torch.cuda.synchronize
-    for i in range(1, len(frames)):
-        f = frames[i]
-        # ---- tracking against the latest keyframe; constant-velocity prior (apply_motion_prior, odometery.py:314-321) ----
-        init_T = cur_T if len(track) < 2 else (cur_T @ invertSE3(track[-2])) @ cur_T
-        sync(); t0 = time.perf_counter()
-        if engine == "gn":
-            if tracker is None:
-                tracker = GnTracker(kfs[-1], kf_klds[-1], kf_poses[-1], f, c['track_levels'], kf_aff=kf_affs[-1] if affine else None)
-            cur_T, aff, _, _ = tracker.track(f, init_T, cur_aff if affine else None)
-        else:
-            cur_T, aff, _ = track_frame_fused(kfs[-1], kf_klds[-1], f, init_T, kf_poses[-1], list(c['track_steps']), c['track_levels'],
-                                              lr=c['track_lr'], prev_aff=kf_affs[-1] if affine else None, curr_aff=cur_aff if affine else None)
-        sync(); secs['track'] += time.perf_counter() - t0
-        if affine:
-            cur_aff = aff
-        track.append(cur_T.clone())
-        since_kf += 1
-        if since_kf % c['supp_every_n'] == 0:                 # every n-th tracked frame supports the latest keyframe
-            supp[-1].append((f, cur_T.clone(), cur_aff.clone()))
-        # ---- scheduled mapping once the new keyframe has two supporting frames (odometery.py:1046-1055) ----
-        if scheduled and len(supp[-1]) >= 2:
-            sync(); t0 = time.perf_counter()
-            out = map_window(kfs, kf_poses, kf_klds, kf_affs if affine else None, supp, c['map_steps'], lr_pose=c['map_lr_pose'],
-                             window_size=c['window_size'], initialised=True, optimiser="gn" if engine == "gn" else "adam")
-            sync(); secs['mapping'] += time.perf_counter() - t0
-            kf_poses = [p.clone() for p in out['kf_poses']]
-            kf_klds = [k.clone() for k in out['klds']]
-            if affine:
-                kf_affs = [a.clone() for a in out['affs']]
-            supp = [[(fr, out['supp_poses'][k][j].clone(), (out['supp_affs'][k][j].clone() if affine else a)) for j, (fr, _, a) in enumerate(row)]
-                    for k, row in enumerate(supp)]
-            scheduled, n_map = False, n_map + 1
-            if tracker is not None:          # the latest keyframe moved
-                tracker.update_keyframe(kf_klds[-1], kf_poses[-1], kf_affs[-1] if affine else None)
-            if log is not None:
-                log.append((i, 'mapping', dict(kf_ids=list(kf_ids), klds=[k.clone() for k in kf_klds], kf_poses=[p.clone() for p in kf_poses],
-                                               losses=[float(out['losses'][0]), float(out['losses'][-1])], n=len(out['losses']))))
-        # ---- keyframe decision on the latest keyframe's depth rendered into the current pose (is_kf) ----
-        sync(); t0 = time.perf_counter()
-        est_depth = estimate_depth_kf_native(kfs[-1], kf_klds[-1], invertSE3(cur_T) @ kf_poses[-1])
-        crit = keyframe_criterion(cur_T, kf_poses[-1], est_depth).tolist()        # [validity ratio, scale, translation diff, rotation deg]
-        if crit[0] < c['depth_validity_ratio'] or crit[2] > c['translation_thresh']:
-            kf = to_keyframe(i)
-            kld, vis = segment_based_depth_reinit(est_depth.clone(), kf, mode='median', return_info=True)
-            if log is not None:
-                log.append((i, 'keyframe', dict(criterion=crit, kld=kld.clone(), visible=int(vis.sum()), valid_ratio=float((est_depth > 1e-6).float().mean()))))
-            kfs.append(kf); kf_ids.append(i); kf_poses.append(cur_T.clone()); kf_klds.append(kld); kf_affs.append(cur_aff.clone()); supp.append([])
-            if len(kfs) > c['window_size']:
-                for lst in (kfs, kf_ids, kf_poses, kf_klds, kf_affs, supp):
-                    lst.pop(0)
-            all_kf_ids.append(i)
-            since_kf, scheduled, tracker = 0, True, None
-        sync(); secs['keyframe'] += time.perf_counter() - t0
-    return dict(track_poses=torch.stack(track), kf_ids=kf_ids, all_kf_ids=all_kf_ids, kf_poses=torch.stack(kf_poses), kf_klds=kf_klds, n_mappings=n_map, seconds=secs)
+    pose0: camera-to-world of frame 0; kld0: keypoint log-depths of the first keyframe; ``depth_of(i)``: optional keypoint log-depths
+    for the second keyframe (the reference's ground-truth-depth initialisation); other keywords override ``DEFAULTS``.
+    Returns dict(track_poses (n,4,4) camera-to-world as tracked, kf_ids, kf_poses, kf_klds, n_mappings, seconds dict, ...)."""
+    return MonoVO(frames, to_keyframe, pose0, kld0, engine=engine, **cfg).run()

@@ -215,12 +215,13 @@ class PoseWindow:
             n_y = 0
             for nd in self._node_array():
                 n_y += (6 if nd.lr_pose > 0 else 0) + (2 if nd.lr_aff > 0 else 0)
-            if n_y > 128:
-                raise ValueError(f"{n_y} camera unknowns exceed the 128 the Gauss-Newton window solver holds; use the Adam optimiser")
+            if n_y > 512 or self.n_nodes > 64 or self.n_sources > 64:
+                raise ValueError(f"{n_y} camera unknowns / {self.n_nodes} nodes / {self.n_sources} source keyframes exceed the 512 / 64 / 64 "
+                                 "the Gauss-Newton window solver holds; use the Adam optimiser")
             self._gn = dict(
-                scratch=torch.zeros(self.lib.sp_window_gn_scratch_doubles(self.n_edges, sum_N, self.max_N), dtype=torch.float64, device=self.device),
+                scratch=torch.zeros(self.lib.sp_window_gn_scratch_doubles(self.n_edges, self.n_sources, sum_N, self.max_N, n_y), dtype=torch.float64, device=self.device),
                 nodes_backup=torch.zeros_like(self.nodes), kld_backup=torch.zeros(sum_N, dtype=torch.float32, device=self.device),
-                state=torch.zeros(16, dtype=torch.float32, device=self.device),
+                state=torch.zeros(16, dtype=torch.float32, device=self.device), state_host=torch.zeros(16, dtype=torch.float32).pin_memory(),
                 losses=torch.zeros(self.max_iters, dtype=torch.float32, device=self.device), sum_N=sum_N, n_y=n_y,
                 phase_keep=torch.tensor([1, 0, 1, 1, 0, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1], dtype=torch.float32, device=self.device),
                 phase_set=torch.tensor([0, -1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0], dtype=torch.float32, device=self.device))
@@ -233,6 +234,7 @@ class PoseWindow:
         gn['state'].zero_()
         gn['state'][0] = lam
         gn['state'][1] = -1.0
+        gn['state_host'].zero_()
 
     def begin_gn_phase(self):
         """A new phase of a schedule (another pyramid level / IRLS epsilon): losses of different phases are not comparable, so
@@ -248,27 +250,30 @@ class PoseWindow:
         _lib.check(self.lib.sp_pairs_cost(_lib.ptr(d), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, 2, float(irls_eps),
                                           _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.stream_ptr()), "sp_pairs_cost")
         _lib.check(self.lib.sp_window_gn_step(_lib.ptr(d), _lib.ptr(self.edges), self.n_edges, _lib.ptr(self.nodes), self.n_nodes,
-                                              _lib.ptr(self.blocks), self.n_sources, gn['sum_N'], self.max_N, _lib.ptr(self.partials),
+                                              _lib.ptr(self.blocks), self.n_sources, gn['sum_N'], self.max_N, gn['n_y'], _lib.ptr(self.partials),
                                               _lib.ptr(self.seg_partials), _lib.ptr(gn['scratch']), _lib.ptr(gn['nodes_backup']),
                                               _lib.ptr(gn['kld_backup']), 1 if pose_only else 0, float(lm_up), float(lm_down), float(lm_min),
                                               float(conv_tol), _lib.ptr(gn['state']), _lib.ptr(gn['losses']), self.max_iters,
                                               _lib.stream_ptr()), "sp_window_gn_step")
 
-    def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=2, **lm):
+    def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7):
         """Up to ``max_iters`` LM iterations at ``level`` as ONE phase: stops once an accepted step lowers the loss by less than
-        ``conv_tol`` of it (the device freezes the window -- launches after that change nothing; the host polls the flag every
-        ``check_every`` iterations).  Returns the iterations the phase really took (evaluations of the cost, rejected ones and the
-        final converged-test evaluation included), from the device's counter."""
+        ``conv_tol`` of it (the device freezes the window -- launches after that change nothing; the host loop, ONE foreign call
+        ``sp_window_gn_run``, looks at the state every ``check_every`` iterations).  Returns the iterations the phase really took
+        (evaluations of the cost, rejected ones and the final converged-test evaluation included), from the device's counter."""
+        gn = self._gn_state()
         self.begin_gn_phase()
-        n0 = self.gn_iterations()
-        it = 0
-        while it < max_iters:
-            for _ in range(min(check_every, max_iters - it)):
-                self.gn_step(level, irls_eps, pose_only, conv_tol, **lm)
-                it += 1
-            if conv_tol > 0 and self.gn_converged():
-                break
-        return self.gn_iterations() - n0
+        n0 = int(gn['state_host'][5])
+        d = self.desc[level]
+        rc = self.lib.sp_window_gn_run(_lib.ptr(d), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, float(irls_eps), _lib.ptr(self.edges),
+                                       self.n_edges, _lib.ptr(self.nodes), self.n_nodes, _lib.ptr(self.blocks), self.n_sources, gn['sum_N'],
+                                       self.max_N, gn['n_y'], _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(gn['scratch']),
+                                       _lib.ptr(gn['nodes_backup']), _lib.ptr(gn['kld_backup']), 1 if pose_only else 0, float(lm_up),
+                                       float(lm_down), float(lm_min), float(conv_tol), _lib.ptr(gn['state']), _lib.ptr(gn['losses']),
+                                       self.max_iters, int(max_iters), int(check_every), gn['state_host'].data_ptr(), _lib.stream_ptr())
+        if rc < 0:
+            _lib.check(rc, "sp_window_gn_run")
+        return int(gn['state_host'][5]) - n0
 
     def gn_converged(self):
         return bool(self._gn_state()['state'][6].item() != 0)
@@ -279,6 +284,14 @@ class PoseWindow:
     def gn_losses(self):
         gn = self._gn_state()
         return gn['losses'][: min(self.gn_iterations(), self.max_iters)].clone()
+
+    def gn_profile(self):
+        """Microseconds the LAST update kernel spent in its phases (diagnostics): dict of phase -> us."""
+        gn = self._gn_state()
+        off = self.lib.sp_window_gn_profile_offset(self.n_edges, self.n_sources, gn['sum_N'], self.max_N, gn['n_y'])
+        t = gn['scratch'][off: off + 10].cpu().numpy()
+        names = ("decision", "backup+clear", "assembly", "schur terms", "factorisation", "substitutions", "depth steps", "poses", "compose")
+        return {n: float(t[i + 1] - t[i]) / 100.0 for i, n in enumerate(names)}
 
     def gn_stats(self):
         st = self._gn_state()['state'].cpu().numpy()

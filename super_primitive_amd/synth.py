@@ -343,3 +343,28 @@ def window_inputs(seed, n_kf, H=48, W=64, N=6):
     affs = (0.01 * rng.standard_normal((2 * n_kf, 2))).astype(np.float32)
     affs[0] = 0
     return frames, est, klds, affs
+
+
+def reference_window_inputs(seed, n_kf=5, n_supp=2, n_running=2, H=224, W=288, N=40, pose_sigma=0.004, kld_sigma=0.03, step_scale=0.6):
+    """A mapping window at the reference's extent (config/tum/odom_desk.yaml: ``window_size: 5``, ``supp_every_n: 3`` -> two
+    supporting frames per keyframe, plus the two running ones of the latest keyframe, odometery.py:1327-1360): keyframe k is
+    followed by its ``n_supp`` supporting frames (the last keyframe by ``n_running``), all on one smooth trajectory.
+    Returns (frames, kf_index [n_kf], supp_index [n_kf][...], est poses per frame, klds per keyframe, affs per frame)."""
+    rng = np.random.default_rng(seed)
+    base = step_scale * np.array([0.05, -0.02, 0.015, 0.01, -0.015, 0.008])
+    kf_index, supp_index, n = [], [], 0
+    for k in range(n_kf):
+        kf_index.append(n)
+        m = n_running if k == n_kf - 1 else n_supp
+        supp_index.append(list(range(n + 1, n + 1 + m)))
+        n += 1 + m
+    twists = [k * base * (1.0 + 0.05 * rng.standard_normal(6)) for k in range(n)]
+    frames = make_sequence(H, W, N, twists, keyframe_ids=kf_index, seed=seed, overlap=1)
+    est = []
+    for k, f in enumerate(frames):
+        T0 = f.T_wc.astype(np.float64) if k == 0 else f.T_wc.astype(np.float64) @ se3_exp_np(pose_sigma * rng.standard_normal(6))
+        est.append(T0.astype(np.float32))
+    klds = [(frames[k].kld_gt + kld_sigma * rng.standard_normal(N)).astype(np.float32) for k in kf_index]
+    affs = (0.01 * rng.standard_normal((n, 2))).astype(np.float32)
+    affs[0] = 0
+    return frames, kf_index, supp_index, est, klds, affs

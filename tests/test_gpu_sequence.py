@@ -1,7 +1,8 @@
-"""-m gpu: BASELINE configs[2] as a SEQUENCE: 30 frames of 224x288 with 40 segments, the MonoVO chain
-track -> keyframe criterion -> depth render -> per-segment re-initialisation -> windowed mapping run end to end
-(``odometery/sequence.py``; reference ``odometery/odometery.py:986-1075``) on both optimisers, against the synthetic ground-truth
-trajectory."""
+"""-m gpu: BASELINE configs[2] as a SEQUENCE: 224x288 frames with 40 segments through the MonoVO chain of ``odometery/sequence.py`` (the
+reference's ``Odometery.run``, ``odometery/odometery.py:1018-1075``: track -> supplementary mapping -> scheduled mapping -> keyframe
+criterion -> depth render -> per-segment re-initialisation, with the reference's supporting-frame selection) on both optimisers:
+against the synthetic ground truth, against golden g21 (the same chain through the imported reference functions), and over 64 frames
+with the reference's window size so that the window slides."""
 import numpy as np
 import pytest
 import torch
@@ -12,11 +13,11 @@ from parity_util import rot_angle
 pytestmark = pytest.mark.gpu
 
 
-def make_sequence_inputs(n=30, H=224, W=288, N=40, seed=31):
+def make_sequence_inputs(n=30, H=224, W=288, N=40, seed=31, rot_scale=1.0):
     from super_primitive_amd import synth
     from super_primitive_amd.image.keyframe import KeyFrame
     rng = np.random.default_rng(seed)
-    base = 0.6 * np.array([0.05, -0.02, 0.015, 0.01, -0.015, 0.008])
+    base = 0.6 * np.array([0.05, -0.02, 0.015, 0.01 * rot_scale, -0.015 * rot_scale, 0.008 * rot_scale])
     # a smooth trajectory with a little jitter per frame (a multiplicative jitter on k * base would grow with k and end far outside
     # what a constant-velocity prior can bridge on this 14-px-period texture)
     twists = [k * base + 0.003 * rng.standard_normal(6) * (k > 0) for k in range(n)]
@@ -58,12 +59,89 @@ def test_config3_sequence_trajectory_against_ground_truth(engine):
     print("   per-frame (rot, t) error: " + " ".join(f"{i}:{r:.1e}/{t:.1e}" for i, r, t in per))
     print("   keyframe log-depth errors: " + " ".join(f"{i}:{float(np.abs(npy(k) - seq[i].kld_gt).max()):.1e}" for i, k in zip(out["kf_ids"], out["kf_klds"])))
     assert len(out["all_kf_ids"]) >= 3 and out["n_mappings"] >= 1
-    assert abs(s - 1.0) < 5e-3
-    # Gauss-Newton converges every frame: 1e-3 with a wide margin.  The reference's own tracking schedule ([0, 0, 300] Adam steps at lr
-    # 5e-3, no decay) keeps jittering ~1e-3 around the optimum (test_config3_tracking_300_steps_at_size; golden g17's end state is
-    # 8e-4 rad from a rerun of itself): its per-frame errors are that jitter, not drift
-    bar = 1e-3 if engine == "gn" else 3e-3
-    assert rot <= bar and tt <= bar
-    # the keyframes' depths (re-initialised from a render, then mapped) against the ground truth
+    # Gauss-Newton converges every step: 1e-3 with a wide margin, scale kept.  The reference's own schedules ([0, 0, 300] Adam tracking steps
+    # at lr 5e-3 without decay, 10 supplementary mapping steps on the latest keyframe's depths after every frame) keep jittering ~1e-3 per
+    # frame (test_config3_tracking_300_steps_at_size; golden g17's end state is 8e-4 rad from a rerun of itself) and the supplementary
+    # mapping turns that jitter into a slow drift of the monocular scale -- which golden g21 shows for the reference chain itself
+    # (test_config3_sequence_follows_the_reference_chain); the similarity alignment removes it
+    bar = (1e-3, 1e-3, 5e-3, 5e-3) if engine == "gn" else (6e-3, 2.5e-2, 0.15, 3e-2)
+    assert rot <= bar[0] and tt <= bar[1] and abs(s - 1.0) <= bar[2], (rot, tt, s)
+    # the keyframes' depths (re-initialised from a render, then mapped) against the ground truth, in the trajectory's scale
     for i, kld in zip(out["kf_ids"], out["kf_klds"]):
-        np.testing.assert_allclose(npy(kld), seq[i].kld_gt, atol=5e-3)
+        np.testing.assert_allclose(npy(kld) + np.log(s), seq[i].kld_gt, atol=bar[3])
+
+def _aligned_errors(P, G):
+    s = float((P[:, :3, 3] * G[:, :3, 3]).sum() / max((P[:, :3, 3] ** 2).sum(), 1e-30))
+    return s, max(rot_angle(a, b) for a, b in zip(P, G)), float(np.abs(s * P[:, :3, 3] - G[:, :3, 3]).max())
+
+
+@pytest.mark.parametrize("engine", ["gn", "adam"])
+def test_config3_sequence_with_the_reference_window_size_slides_the_window(engine):
+    """config/tum/odom_desk.yaml's own extent -- window_size 5, supp_every_n 3 (at most two supporting frames per
+    keyframe, odometery.py:1327-1360, + the two running ones), continual_steps 10, affine compensation, all supporting poses free -- over 64
+    frames: 7-8 keyframes, so the window fills (oldest depths frozen, 14 free nodes = 112 camera unknowns in the Gauss-Newton solver) and
+    slides.  Round 3 raised ValueError around frame 40 here (more than 128 unknowns: it appended every third frame as a supporting frame)."""
+    from super_primitive_amd.odometery.sequence import run_sequence
+    n = 64
+    seq, frames, to_kf = make_sequence_inputs(n, rot_scale=0.3)
+    log = []
+    out = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine=engine, translation_thresh=0.095, window_size=5, log=log,
+                       depth_of=lambda i: T(seq[i].kld_gt))
+    P = npy(out["track_poses"]).astype(np.float64)
+    G = np.stack([f.T_wc for f in seq]).astype(np.float64)
+    s, rot, tt = _aligned_errors(P, G)
+    sec = out["seconds"]
+    maps = [d for _, ev, d in log if ev == 'mapping']
+    print(f"\nconfig 3, {n} frames, window_size 5, {engine}: keyframes {out['all_kf_ids']}, window {out['kf_ids']}, supporting frames per keyframe {out['supp_ids']}, "
+          f"{out['n_mappings']} scheduled + {out['n_supp_mappings']} supplementary mappings; nodes per scheduled mapping {[len(d['kf_ids']) + sum(d['n_supp']) for d in maps]}; "
+          f"trajectory vs ground truth rot {rot:.2e} rad, t {tt:.2e} (scale {s:.5f}); {(n - 1) / sum(sec.values()):.0f} frames/s end to end "
+          f"(tracking {1e3 * sec['track'] / (n - 1):.2f}, supplementary mapping {1e3 * sec['supp_mapping'] / (n - 1):.2f}, keyframe work {1e3 * sec['keyframe'] / (n - 1):.2f} ms/frame; "
+          f"scheduled mapping {1e3 * sec['mapping'] / max(out['n_mappings'], 1):.1f} ms/window)")
+    for d in maps[-2:]:
+        print(f"   mapping over keyframes {d['kf_ids']} + supporting {d['n_supp']}: {d['n']} iterations, loss {d['losses'][0]:.6f} -> {d['losses'][1]:.6f} {d.get('gn') or ''}")
+    assert len(out["all_kf_ids"]) >= 7 and len(out["kf_ids"]) == 5 and out["kf_ids"] == out["all_kf_ids"][-5:]          # the window slid
+    assert all(len(r) <= 2 for r in out["supp_ids"]) and sum(len(r) == 2 for r in out["supp_ids"][:-1]) >= 3          # the reference's selection
+    assert out["n_mappings"] >= 6 and out["n_supp_mappings"] == n - 1
+    full = [d for d in maps if len(d['kf_ids']) == 5]
+    assert full and max(len(d['kf_ids']) + sum(d['n_supp']) for d in full) >= 14                                       # 5 keyframes + 8 supporting + 2 running - ...
+    if engine == "gn":
+        assert all(not d['gn']['too_many_unknowns'] for d in maps)
+    # Gauss-Newton converges every step of the chain; the reference's Adam schedules jitter ~1e-3 per frame (lr 5e-3, no decay) and the
+    # supplementary mapping lets that jitter leak into the latest keyframe's depths: a slow scale drift, removed by the alignment
+    bar = (1.5e-3, 2e-3, 0.01) if engine == "gn" else (6e-3, 2.5e-2, 0.15)
+    assert rot <= bar[0] and tt <= bar[1] and abs(s - 1) <= bar[2], (rot, tt, s)
+
+
+def test_config3_sequence_follows_the_reference_chain():
+    """Golden g21 (oracle/gen_goldens_sequence.py): the same chain, 24 frames, every numerical step by the imported reference functions
+    (300 Adam tracking steps per frame, 10 supplementary + 500 scheduled mapping steps) on the CPU.  The fused Adam engine must take the
+    same decisions -- keyframes at the same frames, the same supporting frames -- and stay within the reference's own tracking jitter of its
+    poses; the Gauss-Newton engine the same decisions."""
+    from conftest import load_golden
+    from super_primitive_amd.odometery.sequence import run_sequence
+    g = load_golden("g21_config3_sequence_chain")
+    n = int(g["n_frames"])
+    H, W, N = (int(v) for v in g["HWN"])
+    seq, frames, to_kf = make_sequence_inputs(n, H, W, N, seed=int(g["seed"]))
+    np.testing.assert_array_equal(np.stack([f.T_wc for f in seq]), g["gt_poses"])
+    ref_kf_frames = [i for i in range(1, n) if bool(g[f"f{i}_new_kf"])]
+    ref_track = np.stack([g[f"f{i}_tracked_pose"] for i in range(1, n)]).astype(np.float64)
+    for engine in ("adam", "gn"):
+        log = []
+        out = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine=engine, translation_thresh=0.095, window_size=5, log=log,
+                           depth_of=lambda i: T(seq[i].kld_gt))
+        assert out["all_kf_ids"] == [0] + ref_kf_frames, (engine, out["all_kf_ids"], ref_kf_frames)
+        assert [",".join(str(t) for t in row) for row in out["supp_ids"]] == [str(v) for v in g["final_supp_ids"]], (engine, out["supp_ids"])
+        P = npy(out["track_poses"]).astype(np.float64)[1:]
+        rot = max(rot_angle(a, b) for a, b in zip(P, ref_track))
+        tt = float(np.abs(P[:, :3, 3] - ref_track[:, :3, 3]).max())
+        kld_err = max(float(np.abs(npy(k) - w).max()) for k, w in zip(out["kf_klds"], g["final_kf_klds"]))
+        kf_t = float(np.abs(npy(out["kf_poses"])[:, :3, 3] - g["final_kf_poses"][:, :3, 3]).max())
+        gt = np.stack([f.T_wc for f in seq]).astype(np.float64)[1:]
+        ref_vs_gt = (max(rot_angle(a, b) for a, b in zip(ref_track, gt)), float(np.abs(ref_track[:, :3, 3] - gt[:, :3, 3]).max()))
+        print(f"\nchain of {n} frames, {engine}: keyframes {out['all_kf_ids']} (reference: {[0] + ref_kf_frames}), supporting frames {out['supp_ids']}; tracked poses vs the "
+              f"reference chain's: rot {rot:.2e} rad, t {tt:.2e}; final keyframe log-depths {kld_err:.2e}, keyframe translations {kf_t:.2e} "
+              f"(the reference chain itself vs ground truth: rot {ref_vs_gt[0]:.2e}, t {ref_vs_gt[1]:.2e})")
+        # the reference's tracking schedule does not converge (lr 5e-3 Adam, 300 steps: ~1e-3 of jitter per frame, golden g17's rerun spread),
+        # so two faithful runs of the chain differ by that jitter; Gauss-Newton converges and sits at the centre of it
+        assert rot <= 4e-3 and tt <= 1e-2 and kld_err <= 3e-2 and kf_t <= 1e-2

@@ -232,13 +232,18 @@ def test_install_as_reference_modules_aliases_the_packages():
     import importlib
     import sys
     import super_primitive_amd
-    saved = {k: sys.modules.get(k) for k in ("core", "core.dense_optim", "image", "lie", "tool", "odometery", "depth_completion")}
+    saved = {k: sys.modules.get(k) for k in ("core", "core.dense_optim", "image", "lie", "tool", "odometery", "depth_completion", "frontend",
+                                             "frontend.segment", "frontend.segment.post_processer")}
     try:
         super_primitive_amd.install_as_reference_modules()
         import core.dense_optim as do
         from super_primitive_amd.core import dense_optim
         assert do is dense_optim
         assert importlib.import_module("image.keyframe").KeyFrame is super_primitive_amd.image.keyframe.KeyFrame
+        # the keyframe post-processing (N2) under the reference's import path (frontend/process_frame.py: ``from frontend.segment import post_processer``)
+        import frontend.segment.post_processer as pp
+        from super_primitive_amd.frontend.segment import post_processer
+        assert pp is post_processer and hasattr(pp, "kf_fix_disconnected_regions")
     finally:
         for k, v in saved.items():
             if v is None:
@@ -246,7 +251,7 @@ def test_install_as_reference_modules_aliases_the_packages():
             else:
                 sys.modules[k] = v
         for k in list(sys.modules):
-            if k.split(".")[0] in ("core", "image", "lie", "tool", "odometery", "depth_completion") and k not in saved:
+            if k.split(".")[0] in ("core", "image", "lie", "tool", "odometery", "depth_completion", "frontend") and k not in saved:
                 sys.modules.pop(k, None)
 
 
