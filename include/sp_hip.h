@@ -347,6 +347,33 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
                           float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, int check_every,
                           int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream);
 
+/* SLOT-LEVEL CONTINUOUS BATCHING of a scheduled run.  n_queue pairs are resident (tables, unknowns, descriptors of every phase's
+ * level / lattice: qpairs[p][n_queue]); n_slots <= n_queue of them are worked on at a time -- the schedule's phase[p].pairs are the
+ * SLOT descriptors (slot_pairs[p] = phase[p].pairs, writable, n_slots records, initially the first n_slots pairs'), its work lists
+ * cover n_slots pairs, and lm_state / backup / costs / phase / iters are per slot.  The solver launch that finishes a pair files its
+ * result under the pair's index (q_costs[pair], q_lm[pair * SP_LM_STATE_FLOATS]; pose and log-depths live in the pair's own storage),
+ * takes the next waiting pair from `head` (device int32, initialised to n_slots; one atomic per finished pair), re-points the slot's
+ * descriptors at it (seg_tile_off / tile0 / n_tiles / rec0 stay: the slot's work list fits every pair, which requires the SAME padded
+ * layout for all pairs) and restarts the slot at phase 0 with lambda = lam0.  The resident set stays full until the queue is empty:
+ * no launch works on a thinning batch except the very last ones.  Which pair lands in which slot depends on timing; every pair's
+ * result does not (pairs never interact; bitwise what the pair gives alone).  slot_pair: device [n_slots], initialised 0..n_slots-1.
+ * flag_dev / flag_host: TWO int32 each (min phase, queue head).  Otherwise as sp_pairs_schedule_run. */
+typedef struct SpQueue {
+    const SpPair* qpairs[SP_MAX_PHASES];
+    SpPair* slot_pairs[SP_MAX_PHASES];
+    int32_t n_queue;
+    int32_t pad_;
+    int32_t* head;
+    int32_t* slot_pair;
+    float* q_costs;
+    float* q_lm;
+    float lam0;
+    int32_t pad2_;
+} SpQueue;               /* 176 bytes */
+int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, int n_slots, int max_N, float lm_up, float lm_down,
+                                float lm_min, float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters,
+                                int check_every, int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream);
+
 /* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last span of a pair
  * runs that pair's update in place (same arithmetic, same fixed reduction order as sp_pairs_cost followed by
  * sp_pairs_adam_step / sp_pairs_gn_step -- results are bitwise identical).  arrivals: n_pairs int32, zeroed once by

@@ -44,6 +44,7 @@ SIGNATURES = {
     "sp_pairs_schedule_cost": [P, P, P],
     "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P],
     "sp_pairs_schedule_run": [P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P],
+    "sp_pairs_schedule_run_queue": [P, P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P],
     "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, P, F, F, F, P, P, P],
     "sp_pairs_gn_iterate": [P, P, P, I, I, I, F, P, P, P, F, F, F, P, P, P, P],
     "sp_window_scratch_doubles": [I, I],
@@ -130,6 +131,12 @@ class SpPhase(ctypes.Structure):
 class SpSchedule(ctypes.Structure):
     """Mirror of ``struct SpSchedule``; lives in host memory, passed by address (``ctypes.addressof``)."""
     _fields_ = [("phase", SpPhase * SP_MAX_PHASES), ("n_phases", c_int), ("pad_", c_int)]
+
+
+class SpQueue(ctypes.Structure):
+    """Mirror of ``struct SpQueue`` (include/sp_hip.h): slot-level continuous batching of a scheduled run; host memory."""
+    _fields_ = [("qpairs", c_void_p * SP_MAX_PHASES), ("slot_pairs", c_void_p * SP_MAX_PHASES), ("n_queue", c_int), ("pad_", c_int),
+                ("head", c_void_p), ("slot_pair", c_void_p), ("q_costs", c_void_p), ("q_lm", c_void_p), ("lam0", c_float), ("pad2_", c_int)]
 
 
 class SpWindowNode(ctypes.Structure):

@@ -20,20 +20,59 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
 static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 520, "SpSchedule is part of the ABI");
 
 // per-pair schedules: the pair's current phase selects the level descriptors, the partial records of that level's work list,
-// the convergence threshold and the iteration budget
-__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, GnArgs h) {
-    const int ph = h.phase[blockIdx.x];
-    if (ph >= sched.n_phases) return;
-    const SpPhase& s = sched.phase[ph];
-    h.conv_tol = s.conv_tol;
-    h.max_iters = s.max_iters;
-    h.pose_only = s.flags & SP_PHASE_POSE_ONLY;
-    solve_gn(s.pairs, blockIdx.x, s.span_partials, s.seg_partials, h);
+// the convergence threshold and the iteration budget.
+// SLOT-LEVEL CONTINUOUS BATCHING (SpQueue, q.n_queue > 0): the launch's "pairs" are SLOTS of a resident set; the slot whose pair just
+// finished its last phase files the pair's result under the pair's own index, takes the next waiting pair off the queue (one atomic
+// per finished pair), re-points its descriptor of every phase at that pair's tables / unknowns and starts it at phase 0 -- in this very
+// launch, so the next cost pass already works on the new pair and the resident set stays full until the queue is empty.  Pairs never
+// interact and a slot's work list fits every pair (same padded layout): each pair's result is bitwise what it is alone.
+__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, GnArgs h, SpQueue q) {
+    const int slot = blockIdx.x;
+    const int ph = h.phase[slot];
+    if (ph >= sched.n_phases) return;           // finished, and the queue was empty when it did
+    {
+        const SpPhase& s = sched.phase[ph];
+        h.conv_tol = s.conv_tol;
+        h.max_iters = s.max_iters;
+        h.pose_only = s.flags & SP_PHASE_POSE_ONLY;
+        solve_gn(s.pairs, slot, s.span_partials, s.seg_partials, h);
+    }
+    if (q.n_queue <= 0) return;
+    __shared__ int next_s;
+    __syncthreads();                            // every write of solve_gn (thread 0's phase update included) is visible
+    if (h.phase[slot] < sched.n_phases) return;
+    const int pid = q.slot_pair[slot];
+    float* ls = h.lm_state + (size_t)slot * SP_LM_STRIDE;
+    if (threadIdx.x < SP_LM_STRIDE) q.q_lm[(size_t)pid * SP_LM_STRIDE + threadIdx.x] = ls[threadIdx.x];
+    if (threadIdx.x == 0) {
+        q.q_costs[pid] = h.costs[slot];
+        next_s = atomicAdd(q.head, 1);
+    }
+    __syncthreads();
+    const int next = next_s;
+    if (next >= q.n_queue) return;              // nothing is waiting: the slot stays finished
+    if (threadIdx.x < sched.n_phases) {
+        // (phases of one level / lattice share a descriptor array: they write the same values)
+        const SpPair& src = q.qpairs[threadIdx.x][next];
+        SpPair& dst = q.slot_pairs[threadIdx.x][slot];
+        dst.pix = src.pix; dst.src4 = src.src4; dst.kp_L = src.kp_L; dst.trg3 = src.trg3;
+        dst.kld = src.kld; dst.pose = src.pose; dst.aff = src.aff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { dst.K_src[i] = src.K_src[i]; dst.K_trg[i] = src.K_trg[i]; }
+        dst.N = src.N; dst.P = src.P; dst.H = src.H; dst.W = src.W; dst.Hl = src.Hl; dst.Wl = src.Wl; dst.zmin = src.zmin;
+        // (seg_tile_off, tile0, n_tiles, rec0 belong to the slot's work list and stay)
+    }
+    if (threadIdx.x == 0) {
+        h.phase[slot] = 0; h.iters[slot] = 0;
+        ls[0] = q.lam0; ls[1] = -1.f; ls[2] = 0.f; ls[3] = 0.f; ls[4] = 0.f;
+        q.slot_pair[slot] = next;
+    }
 }
 
 
 // min over the per-pair phases (one workgroup): what the host polls to end a scheduled run
-__global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restrict__ phase, int n, int32_t* __restrict__ out) {
+__global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restrict__ phase, int n, int32_t* __restrict__ out,
+                                                        const int32_t* __restrict__ head = nullptr) {
     __shared__ int part[SP_WAVES];
     int m = 0x7fffffff;
     for (int i = threadIdx.x; i < n; i += SP_BLOCK) m = min(m, phase[i]);
@@ -41,7 +80,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restric
     for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) *out = min(min(part[0], part[1]), min(part[2], part[3]));
+    if (threadIdx.x == 0) {
+        out[0] = min(min(part[0], part[1]), min(part[2], part[3]));
+        if (head) out[1] = *head;
+    }
 }
 
 // lie/lie_algebra.py:41-119, one thread per matrix (body: renormalise_rotation in sp_solve_device.h)
@@ -118,9 +160,46 @@ int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, f
         if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.max_iters <= 0) return SP_EINVAL;
     }
     hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), *sched,
-                       GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0});
+                       GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0}, SpQueue{});
     SP_CHECK_LAUNCH();
     return 0;
+}
+
+int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, int n_slots, int max_N, float lm_up, float lm_down,
+                                float lm_min, float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters,
+                                int check_every, int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream) {
+    if (!sched || !queue || !phase || !iters || !flag_dev || !flag_host || !lm_state || !backup || !costs) return SP_EINVAL;
+    if (check_every <= 0 || max_rounds < 0 || n_slots <= 0 || max_N <= 0 || queue->n_queue < n_slots) return SP_EINVAL;
+    if (sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
+    if (!queue->head || !queue->slot_pair || !queue->q_costs || !queue->q_lm) return SP_EINVAL;
+    for (int p = 0; p < sched->n_phases; ++p) {
+        const SpPhase& ph = sched->phase[p];
+        if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.max_iters <= 0) return SP_EINVAL;
+        if (!queue->qpairs[p] || queue->slot_pairs[p] != ph.pairs) return SP_EINVAL;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int it = 0;
+    int reached = 0;                  // a phase every slot has passed -- only meaningful once the queue is empty (refilled slots restart at 0)
+    while (it < max_rounds) {
+        const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
+        for (int k = 0; k < n; ++k, ++it) {
+            int rc = schedule_cost_from(sched, phase, stream, reached);
+            if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
+            hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_slots), dim3(SP_BLOCK), 0, s, *sched,
+                               GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0}, *queue);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return -(1000 + (int)e);
+        }
+        hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_slots, flag_dev, queue->head);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        const int min_phase = static_cast<volatile int32_t*>(flag_host)[0], head = static_cast<volatile int32_t*>(flag_host)[1];
+        if (min_phase >= sched->n_phases) break;          // (a slot only stays finished when the queue was empty)
+        reached = head >= queue->n_queue ? (min_phase < 0 ? 0 : min_phase) : 0;
+    }
+    return it;
 }
 
 int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,

@@ -235,6 +235,10 @@ class PairBatch:
         wl = batch_prepare.flat_work_list(pc, seg_pos, n_off, self.span_points, tile_points, self.granule)
         chunks, spans = wl['chunks'], wl['spans']
         self.n_chunks, self.n_spans = len(chunks), len(spans)
+        self._s_off = wl['s_off']
+        # every pair with the same padded layout (in every lattice): a work list prefix then fits ANY of the pairs (run_scheduled(slots=...))
+        same = lambda a: len(set(Ns.tolist())) == 1 and bool((np.asarray(a).reshape(M, -1) == np.asarray(a).reshape(M, -1)[0]).all())
+        self._uniform_layout = same(pc)
         self.n_seg_records = self.rec_per_chunk * self.n_chunks
         # decimated point sets of the coarse levels (run_scheduled): own tables, work list, descriptors, partial buffers
         self.coarse = {}
@@ -252,6 +256,8 @@ class PairBatch:
             c_span = max(self.granule, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS) // span_div)
             c_wl = batch_prepare.flat_work_list(c_pc, c_seg_pos, n_off, c_span, tile_points, self.granule)
             lay.n_chunks, lay.n_spans = len(c_wl['chunks']), len(c_wl['spans'])
+            lay.s_off = c_wl['s_off']
+            self._uniform_layout = self._uniform_layout and same(c_pc)
             coarse_host[(l, stride)] = (c_wl, c_p_off)
             self.coarse[(l, stride)] = lay
         # every host-made array goes to the device through one staging buffer (asynchronously: the preparation kernels are
@@ -502,20 +508,28 @@ class PairBatch:
         sched.n_phases = len(phases)
         return sched
 
-    def run_scheduled(self, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7, **schedule_kw):
+    def run_scheduled(self, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7, slots=None, **schedule_kw):
         """``run_converging`` with the schedule itself on the device: every pair walks through ITS OWN coarse-to-fine phases
         (sp_pairs_schedule_cost / sp_pairs_schedule_gn_step), moving to the next level the moment it converges instead of
         waiting for the slowest pair of the batch, and the host only polls ``min(phase)`` every ``check_every`` iterations.
         Per pair the arithmetic is that of ``run_converging`` with check_every = 1 -- except at levels built with a
-        ``point_stride`` > 1, which iterate on their decimated point set.  Returns the iterations launched."""
+        ``point_stride`` > 1, which iterate on their decimated point set.  Returns the iterations launched.
+
+        ``slots`` < M: SLOT-LEVEL CONTINUOUS BATCHING (include/sp_hip.h SpQueue, sp_pairs_schedule_run_queue).  Only ``slots`` pairs are
+        worked on at a time; the solver launch that finishes a pair hands its slot to the next waiting pair of the batch, so every launch
+        but the very last ones works on a FULL resident set instead of a thinning one (a scheduled batch otherwise ends in a tail: its
+        last 10 % of pairs iterate almost alone for a third of the launches).  All pairs must share one padded layout (same segment sizes:
+        the slot's work list is a prefix of the batch's).  Every pair's result is bitwise the one it gets with all pairs resident."""
         sched = self.schedule(**schedule_kw)
+        bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases))
+        if self._flag is None:
+            self._flag = (torch.zeros(2, dtype=torch.int32, device=self.device), torch.zeros(2, dtype=torch.int32).pin_memory())
+        if slots is not None and int(slots) < self.M:
+            return self._run_queue(sched, int(slots), bound, check_every, lm_up, lm_down, lm_min)
         self.phase.zero_()
         self.phase_iters.zero_()
         self.lm_state[:, 1] = -1.0
         self.lm_state[:, 4] = 0.0
-        bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases))
-        if self._flag is None:
-            self._flag = (torch.zeros(1, dtype=torch.int32, device=self.device), torch.zeros(1, dtype=torch.int32).pin_memory())
         # the whole host loop in ONE foreign call (sp_pairs_schedule_run): nothing is issued from Python per iteration, and the
         # interpreter lock is free for the other host threads of a PairStream while this batch runs
         it = self.lib.sp_pairs_schedule_run(ctypes.addressof(sched), self.M, self.max_N, float(lm_up), float(lm_down), float(lm_min),
@@ -524,6 +538,55 @@ class PairBatch:
                                             self._flag[1].data_ptr(), _lib.stream_ptr())
         if it < 0:
             _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run")
+        return it
+
+    def _run_queue(self, sched, slots, bound, check_every, lm_up, lm_down, lm_min, lam0=1e-4):
+        if not self._uniform_layout:
+            raise ValueError("run_scheduled(slots=...) needs every pair of the batch to have the same padded layout (same segment sizes)")
+        assert slots >= 1
+        M, dev = self.M, self.device
+        rec = ctypes.sizeof(_lib.SpPair)
+        # slot descriptors: a private copy of the first `slots` records of every descriptor array the phases use; the work lists are
+        # the batch's, cut after the spans of pair `slots - 1` (chunks / spans are ordered by pair)
+        s_off_of = {_lib.ptr(self.spans).value: self._s_off}
+        for lay in self.coarse.values():
+            s_off_of[_lib.ptr(lay.spans).value] = lay.s_off
+        q = _lib.SpQueue()
+        slot_desc = {}
+        keep = []
+        for p in range(sched.n_phases):
+            ph = sched.phase[p]
+            full_ptr = ph.pairs
+            if full_ptr not in slot_desc:
+                full = next(t for t in list(self.desc.values()) + [lay.desc for lay in self.coarse.values()] if t.data_ptr() == full_ptr)
+                slot_desc[full_ptr] = full[: slots * rec].clone()
+                keep.append(full)
+            q.qpairs[p] = full_ptr
+            q.slot_pairs[p] = slot_desc[full_ptr].data_ptr()
+            ph.pairs = slot_desc[full_ptr].data_ptr()
+            ph.n_spans = int(s_off_of[ph.spans][slots]) if ph.n_spans > 0 else 0
+        head = torch.tensor([slots], dtype=torch.int32, device=dev)
+        slot_pair = torch.arange(slots, dtype=torch.int32, device=dev)
+        q_costs = torch.zeros(M, dtype=torch.float32, device=dev)
+        q_lm = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
+        q.n_queue, q.head, q.slot_pair, q.q_costs, q.q_lm, q.lam0 = M, head.data_ptr(), slot_pair.data_ptr(), q_costs.data_ptr(), q_lm.data_ptr(), float(lam0)
+        self.phase.zero_()
+        self.phase_iters.zero_()
+        self.lm_state.zero_()
+        self.lm_state[:, 0] = lam0
+        self.lm_state[:, 1] = -1.0
+        rounds = bound * (-(-M // slots) + 1)
+        it = self.lib.sp_pairs_schedule_run_queue(ctypes.addressof(sched), ctypes.addressof(q), slots, self.max_N, float(lm_up), float(lm_down),
+                                                  float(lm_min), _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs),
+                                                  _lib.ptr(self.phase), _lib.ptr(self.phase_iters), int(check_every), int(rounds),
+                                                  _lib.ptr(self._flag[0]), self._flag[1].data_ptr(), _lib.stream_ptr())
+        if it < 0:
+            _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run_queue")
+        # results per PAIR (what the per-slot arrays hold is whichever pairs came last)
+        self._costs.copy_(q_costs)
+        self.lm_state.copy_(q_lm)
+        self.phase.fill_(sched.n_phases)
+        self._queue_stats = dict(slots=slots, head=int(self._flag[1][1]), slot_pair=slot_pair)
         return it
 
     def run(self, iters_per_level, mode="gn", use_graph=False, polish_iters=0, polish_eps=1e-5, **kw):

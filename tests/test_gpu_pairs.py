@@ -698,3 +698,34 @@ def test_wave_span_work_list_gives_the_same_sums_and_steps(shape, seed):
     b.restore_initial()
     b.run_scheduled(**sch)
     assert torch.equal(again[0], b.pose) and torch.equal(again[1], b.kld)            # deterministic
+
+
+@pytest.mark.parametrize("granule", [256, 64])
+def test_slot_level_continuous_batching_gives_every_pair_its_own_result(granule):
+    """run_scheduled(slots=S) (SpQueue, sp_pairs_schedule_run_queue): 14 resident pairs of one layout, 4 slots -- a
+    finished pair's slot goes to the next waiting pair inside the solver launch.  Every pair's pose, log-depths, final cost and
+    iteration counts are BITWISE those of the run with all 14 resident (pairs never interact; a slot's work list fits every pair),
+    whichever slot it happened to get; the queue is handed out completely; far fewer pair-slots are launched than slots x rounds."""
+    from super_primitive_amd import synth
+    sch = dict(max_iters_per_level=12, conv_tol=2e-3, polish_max=6, polish_eps=1e-5, polish_tol=1e-4)
+    sig = [0.002, 0.012, 0.004, 0.008, 0.001, 0.015, 0.003, 0.006, 0.010, 0.002, 0.007, 0.013, 0.005, 0.009]
+    prs = [synth.make_pair(96, 128, 6, seed=120 + i, init_sigma=s, overlap=2) for i, s in enumerate(sig)]
+    kw = dict(levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), granule=granule)
+    ref = make_batch(prs, **kw)
+    n_ref = ref.run_scheduled(check_every=1, **sch)
+    torch.cuda.synchronize()
+    its_ref = npy(ref.lm_state[:, 2] + ref.lm_state[:, 3])
+    assert its_ref.max() > 1.3 * its_ref.min()                 # (the pairs really finish at different times)
+    for slots in (4, 5):
+        q = make_batch(prs, **kw)
+        n_q = q.run_scheduled(check_every=1, slots=slots, **sch)
+        torch.cuda.synchronize()
+        assert q._queue_stats["head"] >= q.M and sorted(set(npy(q._queue_stats["slot_pair"]).tolist())) != list(range(slots))
+        for m in range(q.M):
+            assert torch.equal(q.poses()[m], ref.poses()[m]) and torch.equal(q.klds()[m], ref.klds()[m]), (slots, m)
+        assert torch.equal(q.costs(), ref.costs()) and torch.equal(q.lm_state[:, :4], ref.lm_state[:, :4])
+        # rounds: about (sum of the pairs' iterations) / slots, not (pairs / slots) x the slowest pair
+        print(f"\n{q.M} pairs, {slots} slots (granule {granule}): {n_q} rounds launched (all resident: {n_ref}; sum of iterations {int(its_ref.sum())}, / slots = {its_ref.sum() / slots:.1f}, slowest pair {int(its_ref.max())})")
+        assert n_q <= its_ref.sum() / slots + its_ref.max() + 2
+    with pytest.raises(ValueError):
+        make_batch([synth.make_pair(96, 128, 6, seed=1), synth.make_pair(96, 128, 9, seed=2)], **kw).run_scheduled(slots=1, **sch)
