@@ -50,6 +50,18 @@ class PairStream:
         self.optim_streams = [torch.cuda.Stream(self.device) for _ in range(max(1, int(optimisers)))]
         self.optim_stream = self.optim_streams[0]
         self.trace = [] if os.environ.get("SP_STREAM_TRACE") else None       # developer aid: (what, batch, host t0, host t1) per step
+        self._reap = queue.Queue()
+        self._reaper = None
+
+    def _reaper_loop(self):
+        """Frees finished batches off the optimiser threads: waits until the schedule's last launch is done, then drops the batch."""
+        while True:
+            item = self._reap.get()
+            if item is None:
+                return
+            batch, done = item
+            done.synchronize()
+            del batch, item
 
     def _producer(self, inputs, out, ready_for_inputs, stop, n_consumers):
         def put(item):                       # never blocks for good: the consumers may have gone away
@@ -114,11 +126,12 @@ class PairStream:
                     kld_flat.record_stream(caller)
                     done = torch.cuda.Event()
                     done.record(stream)
-                # the batch (allocated on the set-up stream, used on this stream) is released only after the optimiser has
-                # finished with it
-                done.synchronize()
-                del batch
+                # the batch (allocated on the set-up stream, used on this stream) is released only after the optimiser has finished with
+                # it -- by the REAPER thread: waiting for `done` and tearing down a PairBatch (a few thousand tensor handles, ~3 ms of
+                # interpreter time) here would keep this stream idle for that long after every batch
                 results.put((idx, poses, klds, done))
+                self._reap.put((batch, done))
+                del batch
         except BaseException as e:
             results.put(e)
 
@@ -129,6 +142,10 @@ class PairStream:
         ``restore``: reset each batch to its initial values first (benchmarks re-running the same batches).  Returns when every
         batch has finished (device synchronised)."""
         batches = list(batches)
+        if len({id(b) for b in batches}) != len(batches):
+            # the same PairBatch on two streams at once = restore_initial() / run_scheduled() racing on one set of poses, log-depths,
+            # phases and partial records (ADVICE r03): run a repeated batch in a second call
+            raise ValueError("PairStream.optimise: the same PairBatch appears twice in one call")
         nxt = [0]
         lock = threading.Lock()
         errors = []
@@ -181,6 +198,8 @@ class PairStream:
         # schedule loop would wait that long before it can even take the next batch (measured: a 7 ms hole after every batch).
         switch_interval = sys.getswitchinterval()
         sys.setswitchinterval(min(switch_interval, 2e-4))
+        reaper = threading.Thread(target=self._reaper_loop, daemon=True)
+        reaper.start()
         for w in workers:
             w.start()
         try:
@@ -206,3 +225,5 @@ class PairStream:
             stop.set()
             for w in workers:
                 w.join(timeout=60)
+            self._reap.put(None)
+            reaper.join(timeout=60)

@@ -192,6 +192,41 @@ def test_config5_pair_shape_gn_system_and_determinism():
     assert torch.equal(batch.poses()[0], batch.poses()[1]) and torch.equal(batch.klds()[0], batch.klds()[1])
 
 
+def _render_config5(seed):
+    from super_primitive_amd import synth
+    return synth.make_pair(480, 640, 128, seed=seed, overlap=4, init_sigma=0.004)
+
+
+def test_config5_as_a_batch_of_64_distinct_pairs_through_the_schedule():
+    """BASELINE configs[4] as a BATCH on one GPU (VERDICT r03 item 9): 64 DISTINCT 640x480x128 pairs (64 rendered scenes, no replicas;
+    pair 0 is golden g16's scene) through FRAME_PAIR_SCHEDULE -- all resident, and with slot-level continuous batching (16 slots).
+    Pair 0's cost at its initial point is the reference's (g16 ``L2_residual``: the real ``photomeric_cost`` at 407 k points); every
+    pair ends inside the north-star bar of its ground truth (gauge removed); the slot run is bitwise the all-resident run."""
+    from multiprocessing import Pool
+    from parity_util import pose_depth_errors
+    from super_primitive_amd.optim.pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
+    g = load_golden("g16_config5_seg128")
+    pair0 = fullsize_pair(g)
+    with Pool(8) as pool:
+        others = pool.map(_render_config5, range(7001, 7064))
+    pairs = [pair0] + others
+    batch = PairBatch.from_synth(pairs, levels=(0, 3), device="cuda:0", point_stride=FRAME_PAIR_POINT_STRIDE, granule=64)
+    c0 = npy(batch.evaluate(0))
+    np.testing.assert_allclose(c0[0], float(np.asarray(g["L2_residual"]).reshape(-1)[0]), rtol=3e-6)
+    kw = {k: v for k, v in FRAME_PAIR_SCHEDULE.items() if k != "check_every"}
+    batch.run_scheduled(**kw)
+    torch.cuda.synchronize()
+    P, K = npy(batch.poses()), [npy(k) for k in batch.klds()]
+    worst = np.max([pose_depth_errors(P[m], K[m], pairs[m].pose_gt, pairs[m].kld_gt) for m in range(len(pairs))], axis=0)
+    print(f"\nconfig 5 as a batch: 64 distinct 640x480x128 pairs, worst error vs ground truth rot {worst[0]:.2e} rad, t {worst[1]:.2e}, depth {worst[2]:.2e}")
+    assert worst[0] <= 1e-4 and worst[1] <= 1e-4 and worst[2] <= 1e-3
+    ref = (batch.poses().clone(), batch.kld.clone())
+    batch.restore_initial()
+    batch.run_scheduled(slots=16, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(batch.poses(), ref[0]) and torch.equal(batch.kld, ref[1])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[2] (TUM-shaped MonoVO, 224x288, 40 segments) and configs[3] (VOID-shaped, 480x640, 1200 segments)
 # ---------------------------------------------------------------------------------------------------------------------

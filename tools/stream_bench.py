@@ -29,8 +29,10 @@ def make_items(per_batch, n_batches, distinct_batches):
 import gc
 
 CONFIGS = ((384, 8, 2), (128, 16, 3))
-if len(sys.argv) > 1:                  # e.g.  stream_bench.py 384   (only the batch size given)
+if len(sys.argv) > 1:                  # e.g.  stream_bench.py 384 [distinct input sets]   (only the batch size given)
     CONFIGS = tuple(c for c in CONFIGS if c[0] == int(sys.argv[1]))
+if len(sys.argv) > 2:
+    CONFIGS = tuple((c[0], c[1], int(sys.argv[2])) for c in CONFIGS)
 GRAN = int(os.environ.get('SP_GRANULE', '64'))
 for per_batch, n_batches, distinct in CONFIGS:
     items = make_items(per_batch, n_batches, distinct)
