@@ -76,7 +76,7 @@ class SfM:
                             {'params': [pose for _, pose, _ in self.supp_frames if isinstance(pose, LieGroupParameter)], 'lr': 1e-2}]
         self.optim = torch.optim.Adam(self.adam_params, lr=1e-3)
 
-    def run(self, fused=None, lr_scale=1.0, levels=None, num_iters=None):
+    def run(self, fused=None, lr_scale=1.0, levels=None, num_iters=None, graphed=False):
         """The reference loop.  ``fused``: None = fused unless per-iteration statistics are wanted (do not switch engines
         between calls on one object: each keeps its own Adam moments).  ``lr_scale`` scales both learning rates -- a
         change starts a fresh Adam -- and ``levels`` restricts the pyramid levels visited (indices into the
@@ -86,7 +86,7 @@ class SfM:
             fused = self.stats_callback is None and self.collect_stats == 0
         if fused:
             return self._run_fused(lr_scale, levels, num_iters)
-        return self._run_eager(lr_scale, levels, num_iters)
+        return self._run_eager(lr_scale, levels, num_iters, graphed=graphed)
 
     def _run_fused(self, lr_scale, levels, num_iters):
         from ..optim.window import KIND_DIRECT, PoseWindow
@@ -142,7 +142,11 @@ class SfM:
                     return False
         return True
 
-    def _run_eager(self, lr_scale=1.0, levels=None, num_iters=None):
+    def _run_eager(self, lr_scale=1.0, levels=None, num_iters=None, graphed=False):
+        """``graphed``: the SAME statements -- ``photomeric_cost`` per support frame, ``loss.backward()``, ``torch.optim.Adam.step()``,
+        ``zero_grad()`` -- recorded once per pyramid level into a hipGraph (``tool/graph_loop.GraphedStep``) and replayed: the
+        interpreter, the autograd engine and the optimiser's Python run at capture time only (470-640 us -> well under 150 us per
+        iteration; same arithmetic, Adam's step counter on the device).  Not with a ``stats_callback`` (a per-iteration host copy)."""
         al = self.config['aligment']
         self._drop_window()                                          # this engine moves the parameters: the fused window's copies go stale
         if lr_scale != self._lr_scale:                               # a fresh Adam at the new rates
@@ -161,7 +165,7 @@ class SfM:
         for level in (range(len(src_pyr)) if levels is None else levels):
             src_l = src_pyr[level]
             supp_l = [p[level] for p in supp_pyrs]
-            for _ in range(num_iters):
+            def iteration(update=True):
                 outs = []
                 for fid, frame_l in enumerate(supp_l):
                     _, current_T, pose_to_mat = self.supp_frames[fid]
@@ -170,11 +174,26 @@ class SfM:
                 if self.stats_callback is not None:
                     self.stats_callback([dict_cpu(o) for o in outs], level)
                 loss = torch.sum(torch.stack([torch.mean(torch.abs(o['residual'])) for o in outs]))
-                self.losses.append(loss.detach())
-                if count > 0:
+                if update:
                     loss.backward()
                     self.optim.step()
                     self.optim.zero_grad()
+                return loss.detach()
+
+            left = num_iters
+            if count == 0 and left > 0:                      # the very first iteration makes no update (two_frame_sfm.py:203)
+                self.losses.append(iteration(update=False))
+                count, left = 1, left - 1
+            if graphed and self.stats_callback is None and left > 3:
+                from ..tool.graph_loop import GraphedStep
+                step = GraphedStep(iteration, [self.optim], warmup=2)
+                self.losses.extend(step.warmup_outputs)
+                for _ in range(left - 2):
+                    self.losses.append(step.replay().clone())
+                count += left
+                continue
+            for _ in range(left):
+                self.losses.append(iteration())
                 count += 1
         self._stepped = True
         return self

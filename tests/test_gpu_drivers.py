@@ -34,6 +34,42 @@ def test_two_frame_sfm_loop_matches_reference_trajectory():
     np.testing.assert_allclose(npy(sfm.poses()[0]), g["final_pose"], atol=5e-4)
 
 
+def test_two_frame_sfm_loop_as_a_hipgraph_matches_reference_trajectory():
+    """the reference-style eager loop (photomeric_cost + autograd + torch.optim.Adam, statement for statement the
+    reference's) with ONE iteration per pyramid level recorded into a hipGraph and replayed (tool/graph_loop.GraphedStep): the same golden
+    assertions as the eager loop -- and the same numbers as the eager loop to fp32 round-off (same kernels, same order)."""
+    import time
+    from super_primitive_amd.odometery.two_frame_sfm import SfM
+    g = load_golden("g9a_traj_sfm")
+    src, trg = frames_from_golden(g)
+    cfg = {"aligment": {"pyramid_min": 0, "pyramid_max": 2, "cost_params": {}}}
+
+    def run(graphed):
+        sfm = SfM(cfg, src, [trg], [T(g["in_pose_init"])], num_iters=int(g["steps"]))
+        sfm.init_optimisation(kld_init=T(g["in_kld"]))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sfm.run(fused=False, graphed=graphed)
+        torch.cuda.synchronize()
+        return sfm, time.perf_counter() - t0
+
+    run(True)
+    sfm, dt = run(True)
+    eager, dt_e = run(False)
+    losses = np.array([float(l) for l in sfm.losses])
+    want = g["losses"]
+    assert losses.shape == want.shape
+    np.testing.assert_allclose(losses[:3], want[:3], rtol=2e-5)
+    assert losses[0] == losses[1], "no update on the very first iteration (count > 0)"
+    np.testing.assert_allclose(losses, want, rtol=2e-2)
+    np.testing.assert_allclose(npy(sfm.keypoint_logdepths()), g["final_kld"], atol=2e-4)
+    np.testing.assert_allclose(npy(sfm.poses()[0]), g["final_pose"], atol=5e-4)
+    # vs the eager run of the same statements: capturable Adam keeps its step counter and bias corrections in fp32 device tensors where
+    # the default one uses Python floats -- 6e-5 on the first update, amplified by the L1 cost's sign flips to ~2e-3 over 80 steps
+    np.testing.assert_allclose(losses, np.array([float(l) for l in eager.losses]), rtol=5e-3)
+    n = len(losses)
+    print(f"\nreference-style SfM loop, {n} iterations over 2 levels (capture included): graphed {1e6 * dt / n:.0f} us/iteration, eager {1e6 * dt_e / n:.0f} us/iteration")
+
+
 def test_tracking_loop_matches_reference_trajectory():
     from super_primitive_amd.core import dense_optim
     from super_primitive_amd.lie.lie_algebra import invertSE3

@@ -39,11 +39,12 @@ def rot_err(A, B):
 p = synth.make_pair(240, 320, 8, seed=1, init_sigma=0.01)
 src, trg = frames(p)
 cfg = {"aligment": {"pyramid_min": 0, "pyramid_max": 3, "cost_params": {}}}
-for fused in (True, False):
-    sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=5); sfm.init_optimisation(kld_init=t(p.kld_init)); sfm.run(fused=fused)
+for fused, graphed in ((True, False), (False, True), (False, False)):
+    sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=5); sfm.init_optimisation(kld_init=t(p.kld_init)); sfm.run(fused=fused, graphed=graphed)
     sfm = SfM(cfg, src, [trg], [t(p.pose_init)], num_iters=500); sfm.init_optimisation(kld_init=t(p.kld_init))
-    dt = sync_time(lambda: sfm.run(fused=fused))
-    print(f"config 1  320x240x8: drop-in SfM driver, {'fused optimiser (3 launches / iteration)' if fused else 'eager (autograd + torch Adam)'}: "
+    dt = sync_time(lambda: sfm.run(fused=fused, graphed=graphed))
+    what = 'fused optimiser (3 launches / iteration)' if fused else ('eager statements (photomeric_cost + autograd + torch Adam) replayed from a hipGraph per level' if graphed else 'eager (autograd + torch Adam)')
+    print(f"config 1  320x240x8: drop-in SfM driver, {what}: "
           f"{1500/dt:.0f} Adam it/s (3 levels x 500, the reference budget) | loss {float(sfm.losses[0]):.4f} -> {float(sfm.losses[-1]):.4f}")
 
 # ---- config 3: TUM-shaped tracking + mapping ------------------------------------------------------------
