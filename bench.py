@@ -61,6 +61,7 @@ def parse(argv=None):
                          "round 3 -- 2.7 %% faster than 256 on the headline workload in an interleaved A/B, 1.4x on 1200 small ragged "
                          "segments, profiles/r03_kernel_experiments.txt), or 256 (a span per workgroup, rounds 1-2)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic pairs rendered (rest are device copies)")
+    ap.add_argument("--no-depth-table", action="store_true", help="log-depth tables (rounds 1-3) instead of depth tables (SP_COST_DEPTH_TABLE)")
     ap.add_argument("--tile-points", type=int, default=8192, help="longest chunk (piece of one segment)")
     ap.add_argument("--span-points", type=int, default=None, help="points per workgroup (run of consecutive chunks); default: PairBatch's")
     ap.add_argument("--mode", choices=["gn", "adam"], default="gn")
@@ -99,7 +100,7 @@ def build_batch(args, rank, dev):
     batch = PairBatch(src, [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs], poses,
                       [t(p.kld_init) for p in pairs], levels=(0, 3), tile_points=args.tile_points, replicate=R,
                       point_stride=FRAME_PAIR_POINT_STRIDE,     # extra decimated tables for the frame-pair schedule only
-                      granule=getattr(args, 'granule', 256),
+                      granule=getattr(args, 'granule', 256), depth_table=not getattr(args, 'no_depth_table', False),
                       **({} if getattr(args, 'span_points', None) is None else {'span_points': args.span_points}))
     return batch, pairs
 

@@ -135,8 +135,10 @@ typedef struct SpPrepSample {    /* one table, sampled at up to SP_PREP_MAX_LEVE
     float* src4[SP_PREP_MAX_LEVELS];            /* (P,4) out, one per level */
     int32_t Hl[SP_PREP_MAX_LEVELS], Wl[SP_PREP_MAX_LEVELS];
     int32_t N, P, H, W, n_levels;
-    int32_t granule;             /* padding granule of the runs: 0 / 256, or 64 for wave-span tables (SP_COST_WAVE_SPANS) */
+    int32_t granule;             /* low 16 bits: padding granule of the runs: 0 / 256, or 64 for wave-span tables (SP_COST_WAVE_SPANS);
+                                    | SP_PREP_DEPTH_TABLE: write exp(L) instead of L into src4.w (SP_COST_DEPTH_TABLE) */
 } SpPrepSample;                  /* 176 bytes */
+#define SP_PREP_DEPTH_TABLE 0x10000
 typedef struct SpPrepImage {
     const float* in;             /* (C,H,W) planar */
     float* out;                  /* blur: (C,ceil(H/2),ceil(W/2)); pack: (H,W,3) */
@@ -255,6 +257,12 @@ int sp_host_work_list(const long long* pc, const long long* seg_pos, const long 
  * chunk (record index = chunk index) instead of four.  For batches of many small ragged segments (SAM-like masks): at 1200
  * segments of ~280 pixels the 256-point granule pads 40 %, the 64-point granule 11 %.  Four consecutive spans share a workgroup. */
 #define SP_COST_WAVE_SPANS 0x100
+/* DEPTH TABLES (mode | SP_COST_DEPTH_TABLE, modes 0 and 1, with or without wave spans): src4.w of the tables holds exp(L) -- the
+ * source depth at the segment's seed -- instead of L, and a point's depth is src4.w * exp(kld - kp_L): the exponential is taken once
+ * per chunk (a scalar) instead of once per point (v_exp_f32 is a quarter-rate transcendental; -1.8 % kernel time on the headline
+ * workload, profiles/r04_kernel_experiments.txt).  Same value up to 2 ulp of the product.  sp_prepare_sample writes such tables with
+ * SP_PREP_DEPTH_TABLE. */
+#define SP_COST_DEPTH_TABLE 0x200
 
 /* mode 0 / 1 as above.  mode 2 = mode 1 plus the affine brightness pair of the TARGET frame as two more unknowns (a_t, b_t; the
  * source frame's pair enters with the opposite sign): residual columns j_a = gain * I_trg(sample), j_b = -1.  Span record
@@ -313,6 +321,8 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
 #define SP_PHASE_POSE_ONLY 1
 /* SP_PHASE_WAVE_SPANS: the phase's work list is wave-granular (see SP_COST_WAVE_SPANS). */
 #define SP_PHASE_WAVE_SPANS 2
+/* SP_PHASE_DEPTH_TABLE: the phase's tables are depth tables (see SP_COST_DEPTH_TABLE); all phases of one schedule alike. */
+#define SP_PHASE_DEPTH_TABLE 4
 typedef struct SpPhase {
     const SpPair* pairs;
     const int32_t* chunks;

@@ -96,6 +96,9 @@ SP_MAX_PHASES = 8
 SP_PHASE_POSE_ONLY = 1
 SP_PHASE_WAVE_SPANS = 2
 SP_COST_WAVE_SPANS = 0x100
+SP_COST_DEPTH_TABLE = 0x200
+SP_PHASE_DEPTH_TABLE = 4
+SP_PREP_DEPTH_TABLE = 0x10000
 
 
 SP_PREP_MAX_STRIDES = 4

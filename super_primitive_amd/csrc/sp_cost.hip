@@ -73,10 +73,11 @@ __device__ __forceinline__ f32x3 buf_load3(rsrc_t r, uint32_t off, uint32_t soff
 __device__ __forceinline__ void prepare_xyz(const TileCtx& c, float x, float y, float d, bool src_ok, float sr, float sg,
                                             float sb, Pending& p);
 
+template <bool DT = false>
 __device__ __forceinline__ void prepare(const TileCtx& c, float shift, float ifx, float ify, uint32_t pw, const f32x4 s, Pending& p) {
     float col, row; bool src_ok;
     decode_pix(pw, col, row, src_ok);
-    const float d = fast_exp(s.w + shift);
+    const float d = DT ? s.w * shift : fast_exp(s.w + shift);
     float x, y;
     backproject(col, row, d, c.Ks, ifx, ify, x, y);
     prepare_xyz(c, x, y, d, src_ok, s.x, s.y, s.z, p);
@@ -277,7 +278,7 @@ __device__ __forceinline__ f32x2 sgpr2(float a, float b) {
     return __builtin_bit_cast(f32x2, ((uint64_t)hi << 32) | (uint64_t)lo);
 }
 struct PairConsts {            // the uniform operand pairs of prepare2 / fold_gn2 / finish_gn2
-    f32x2 Kc, ifxy, R03, R14, R25, t01, Kf, Ktc, invWH, sxy, gab, bias2, eps2;
+    f32x2 nKc, ifxy, R03, R14, R25, t01, Kf, Ktc, invWH, sxy, gab, bias2, eps2;
     float R6, R7, R8, t2, gain, bias, zmin, eps;
 };
 __device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -305,24 +306,25 @@ struct Pending2 {          // Pending, with the x/y quantities as register pairs
 };
 
 // prepare() on pairs: same operations in the same order per component (sp_device.h backproject / warp_point)
+template <bool DT = false>
 __device__ __forceinline__ void prepare2(const TileCtx& c, const PairConsts& k, float shift, uint32_t pw, const f32x4 s, Pending2& p) {
     const f32x2 colrow{(float)(pw & 0xffffu), (float)((pw >> 16) & 0x7fffu)};
     const bool src_ok = (int32_t)pw < 0;
-    const float d = fast_exp(s.w + shift);
-    const f32x2 xy = ((colrow - k.Kc) * d) * k.ifxy;
+    const float d = DT ? s.w * shift : fast_exp(s.w + shift);
+    const f32x2 xy = pfma(colrow, k.ifxy, k.nKc) * d;          // ((col, row) - (cx, cy)) / (fx, fy) * d, the subtraction folded into the multiply
     const f32x2 qxy = pfma(k.R03, f32x2{xy.x, xy.x}, pfma(k.R14, f32x2{xy.y, xy.y}, k.R25 * d)) + k.t01;
     const float qz = fmaf(k.R6, xy.x, fmaf(k.R7, xy.y, k.R8 * d)) + k.t2;
     const bool zguard = fabsf(qz) > 1e-6f;
     const float zinv = zguard ? __builtin_amdgcn_rcpf(qz) : 1e-6f;
     const f32x2 uv = qxy * k.Kf * zinv + k.Ktc;
-    const f32x2 n = 2.f * uv * k.invWH - 1.f;
+    const f32x2 n = pfma(uv, k.invWH, f32x2{-1.f, -1.f});        // k.invWH = 2 / (W - 1, H - 1): the doubling is exact, folded into the constant
     const bool ok = (fabsf(n.x) <= 0.99f) && (fabsf(n.y) <= 0.99f) && (qz > k.zmin) && src_ok && (d > 1e-7f);
     p.m = ok ? 1.f : 0.f;
     p.qxy = qxy; p.qz = qz;
     p.zinv = ok ? zinv : 0.f;
     p.zi = (ok && zguard) ? zinv : 0.f;
     p.srg = f32x2{s.x, s.y}; p.sb = s.z;
-    const f32x2 i0 = (n + 1.f) * k.sxy;
+    const f32x2 i0 = pfma(n, k.sxy, k.sxy);
     const f32x2 ixy{ok ? i0.x : 0.f, ok ? i0.y : 0.f};
     const f32x2 fl{floorf(ixy.x), floorf(ixy.y)};
     p.wxy = ixy - fl;
@@ -477,7 +479,13 @@ __device__ __forceinline__ void cursor_fetch_next(SpanCursor& k) {
     }
 }
 
-template <int TRIP = SP_BLOCK>
+// DT ("depth table"): the tables hold exp(L) in src4.w instead of L, and the cursor's shift is exp(kld - kp_L): a point's depth is then
+// one multiply (d = src4.w * shift) instead of add + multiply + v_exp_f32 (a quarter-rate transcendental) -- the exponential is taken
+// once per CHUNK here, not once per point
+template <bool DT>
+__device__ __forceinline__ float cursor_shift(float kld, float kpl) { return DT ? fast_exp(kld - kpl) : kld - kpl; }
+
+template <int TRIP = SP_BLOCK, bool DT = false>
 __device__ __forceinline__ void cursor_init(SpanCursor& k, const SpPair& pr, const int4* chunks, int q0, int n) {
     k.chunks = (cptr_i4)chunks;
     k.kld = (cptr_f32)pr.kld;
@@ -485,19 +493,19 @@ __device__ __forceinline__ void cursor_init(SpanCursor& k, const SpPair& pr, con
     k.q = q0; k.q_end = q0 + n;
     const int seg0 = k.chunks[q0].seg;
     k.left = k.chunks[q0].count / TRIP;
-    k.shift = k.kld[seg0] - k.kp_L[seg0];
+    k.shift = cursor_shift<DT>(k.kld[seg0], k.kp_L[seg0]);
     k.nq_left = 0; k.nq_kld = 0.f; k.nq_kpl = 0.f;
     cursor_fetch_next<TRIP>(k);
 }
 
 // Account one prepared trip.  Returns true if that trip was the last of its chunk (whose index is written to `done_q`).
-template <int TRIP = SP_BLOCK>
+template <int TRIP = SP_BLOCK, bool DT = false>
 __device__ __forceinline__ bool cursor_advance(SpanCursor& k, int& done_q) {
     done_q = k.q;
     if (--k.left > 0) return false;
     ++k.q;
     k.left = k.nq_left;
-    k.shift = k.nq_kld - k.nq_kpl;
+    k.shift = cursor_shift<DT>(k.nq_kld, k.nq_kpl);
     cursor_fetch_next<TRIP>(k);
     return true;
 }
@@ -541,6 +549,7 @@ __device__ __forceinline__ uint32_t pix_from_colour_bits(const f32x4 s) {
     const uint32_t v = (a & 0x7fu) | ((b & 0x7fu) << 7) | ((c & 0x3fu) << 14);            // col (10) | row (9) << 10 | valid << 19
     return (v & 0x3ffu) | (((v >> 10) & 0x1ffu) << 16) | ((v >> 19) << 31);
 }
+// 6 = DEPTH TABLES (a product form, not an ablation: SP_COST_DEPTH_TABLE / SP_PHASE_DEPTH_TABLE) -- src4.w holds exp(L), see cursor_shift
 // W64 ("wave spans"): the span belongs to ONE WAVE -- trips of 64 points, segment records one per chunk, pair-level sums reduced
 // over the wave only -- so that the padding granule of the tables is 64 points instead of 256 (small ragged segments: 1200
 // SAM-like masks of ~280 pixels pad 40 % at 256 and 11 % at 64); the four waves of a workgroup work on four consecutive spans.
@@ -549,6 +558,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
                                             int n_chunks, int total, float irls_eps, float* __restrict__ span_rec,
                                             float* __restrict__ seg_partials, float* lds) {
     constexpr int TRIP = W64 ? 64 : SP_BLOCK;
+    constexpr bool DT = ABL == 6;            // depth tables (cursor_shift)
     constexpr int NV = AFF ? SP_GNA_PARTIAL_FLOATS : SP_GN_PARTIAL_FLOATS, NS = AFF ? SP_GNA_SEG_FLOATS : SP_GN_SEG_FLOATS;
     GnAcc A;
     AffAcc AA;
@@ -569,15 +579,16 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     SpanCursor k;
-    cursor_init<TRIP>(k, pr, chunks, q0, n_chunks);
+    cursor_init<TRIP, DT>(k, pr, chunks, q0, n_chunks);
     const int start = k.chunks[q0].start;
     PairConsts kc;
     {
         const Warp& w = c.w;
-        kc.Kc = sgpr2(c.Ks.cx, c.Ks.cy);       kc.ifxy = sgpr2(1.f / c.Ks.fx, 1.f / c.Ks.fy);
+        kc.ifxy = sgpr2(1.f / c.Ks.fx, 1.f / c.Ks.fy);
+        kc.nKc = sgpr2(-c.Ks.cx * (1.f / c.Ks.fx), -c.Ks.cy * (1.f / c.Ks.fy));
         kc.R03 = sgpr2(w.R[0], w.R[3]);        kc.R14 = sgpr2(w.R[1], w.R[4]);      kc.R25 = sgpr2(w.R[2], w.R[5]);
         kc.t01 = sgpr2(w.t[0], w.t[1]);        kc.Kf = sgpr2(w.Kt.fx, w.Kt.fy);     kc.Ktc = sgpr2(w.Kt.cx, w.Kt.cy);
-        kc.invWH = sgpr2(w.invWm1, w.invHm1);  kc.sxy = sgpr2(w.sx, w.sy);
+        kc.invWH = sgpr2(2.f * w.invWm1, 2.f * w.invHm1);  kc.sxy = sgpr2(w.sx, w.sy);
         kc.gab = sgpr2(c.gain * c.ax * w.Kt.fx, c.gain * c.ay * w.Kt.fy);
         kc.bias2 = sgpr2(c.bias, c.bias);      kc.eps2 = sgpr2(irls_eps, irls_eps);
         kc.R6 = sgpr(w.R[6]); kc.R7 = sgpr(w.R[7]); kc.R8 = sgpr(w.R[8]); kc.t2 = sgpr(w.t[2]);
@@ -598,8 +609,8 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     {
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
         const uint32_t pw = ABL == 5 ? pix_from_colour_bits(s) : (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
-        prepare2(c, kc, k.shift, pw, s, S0.p);
-        S0.last = cursor_advance<TRIP>(k, S0.q);
+        prepare2<DT>(c, kc, k.shift, pw, s, S0.p);
+        S0.last = cursor_advance<TRIP, DT>(k, S0.q);
     }
     S1.p = S0.p;                         // "point -1": finite values, zinv = zi = 0 and a zero Mix2 -> contributes exact zeros
     S1.p.zinv = 0.f; S1.p.zi = 0.f;
@@ -648,8 +659,8 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
         if (ABL == 5) pw_ = pix_from_colour_bits(s_);
-        prepare2(c, kc, k.shift, pw_, s_, b.p);       // (the trip past the end reads zeros and is never used)
-        b.last = cursor_advance<TRIP>(k, b.q);
+        prepare2<DT>(c, kc, k.shift, pw_, s_, b.p);       // (the trip past the end reads zeros and is never used)
+        b.last = cursor_advance<TRIP, DT>(k, b.q);
     };
     int j = 0;
     for (; j + 1 < n_iter; j += 2) { trip(S0, S1); trip(S1, S0); }
@@ -700,13 +711,14 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
                                               int n_chunks, int total, float* __restrict__ span_rec,
                                               float* __restrict__ seg_partials, float* lds) {
     constexpr int TRIP = W64 ? 64 : SP_BLOCK;
+    constexpr bool DT = ABL == 6;            // depth tables (cursor_shift)
     constexpr int NV = SP_GRAD_PARTIAL_FLOATS;
     float acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     SpanCursor k;
-    cursor_init<TRIP>(k, pr, chunks, q0, n_chunks);
+    cursor_init<TRIP, DT>(k, pr, chunks, q0, n_chunks);
     const int start = k.chunks[q0].start;
     const float ifx = 1.f / c.Ks.fx, ify = 1.f / c.Ks.fy;
     const rsrc_t r_pix = make_rsrc(c.pix + start, (uint32_t)total * 4u);
@@ -721,8 +733,8 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
     {
         const uint32_t pw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_pix, (int)op, 0, NT);
         const f32x4 s = buf_load4<NT>(r_src, op * 4u);
-        prepare(c, k.shift, ifx, ify, pw, s, S0.p);
-        S0.last = cursor_advance<TRIP>(k, S0.q);
+        prepare<DT>(c, k.shift, ifx, ify, pw, s, S0.p);
+        S0.last = cursor_advance<TRIP, DT>(k, S0.q);
     }
     S1.p = S0.p;                         // "point -1": contributes exact zeros
     S1.p.g.zinv = 0.f; S1.p.g.zi = 0.f;
@@ -759,8 +771,8 @@ __device__ __forceinline__ void run_span_grad(const TileCtx& c, const SpPair& pr
         uint32_t pw_ = pw;
         f32x4 s_ = s;
         asm volatile("" : "+v"(pw_), "+v"(s_));
-        prepare(c, k.shift, ifx, ify, pw_, s_, b.p);
-        b.last = cursor_advance<TRIP>(k, b.q);
+        prepare<DT>(c, k.shift, ifx, ify, pw_, s_, b.p);
+        b.last = cursor_advance<TRIP, DT>(k, b.q);
     };
     int j = 0;
     for (; j + 1 < n_iter; j += 2) { trip(S0, S1); trip(S1, S0); }
@@ -1166,21 +1178,31 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
     if (!pairs || !chunks || !spans || !partials || !seg_partials || n_spans <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (mode & SP_COST_WAVE_SPANS) {        // wave-granular work list (granule 64): modes 0 and 1
-        const int base = mode & ~SP_COST_WAVE_SPANS;
-        if (base != 0 && base != 1) return SP_EINVAL;
+        const int base = mode & ~(SP_COST_WAVE_SPANS | SP_COST_DEPTH_TABLE);
+        const bool dt = (mode & SP_COST_DEPTH_TABLE) != 0 || base == 17;
+        if (base != 0 && base != 1 && base != 17) return SP_EINVAL;
         const int gw = ((((n_spans + 3) / 4) + 7) / 8) * 8;
         FuseArgs nf{};
         nf.done = done;
-        if (base == 0)
-            hipLaunchKernelGGL((k_cost_pairs<0, 0, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, s, pairs, reinterpret_cast<const int4*>(chunks),
-                               reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, nf);
+        const int4* c4 = reinterpret_cast<const int4*>(chunks);
+        const int4* s4 = reinterpret_cast<const int4*>(spans);
+        if (base == 0 && dt)
+            hipLaunchKernelGGL((k_cost_pairs<0, 6, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nf);
+        else if (base == 0)
+            hipLaunchKernelGGL((k_cost_pairs<0, 0, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nf);
+        else if (dt)
+            hipLaunchKernelGGL((k_cost_pairs<1, 6, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nf);
         else
-            hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, s, pairs, reinterpret_cast<const int4*>(chunks),
-                               reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, nf);
+            hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(gw), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nf);
         SP_CHECK_LAUNCH();
         return 0;
     }
-    if (mode != 0 && mode != 1 && mode != 2 && !(mode >= 10 && mode <= 16)) return SP_EINVAL;
+    if (mode & SP_COST_DEPTH_TABLE) {
+        const int base = mode & ~SP_COST_DEPTH_TABLE;
+        if (base != 0 && base != 1) return SP_EINVAL;
+        mode = base == 0 ? 18 : 17;
+    }
+    if (mode != 0 && mode != 1 && mode != 2 && !(mode >= 10 && mode <= 18)) return SP_EINVAL;
     const int gx = ((n_spans + 7) / 8) * 8;
     const int4* c4 = reinterpret_cast<const int4*>(chunks);
     const int4* s4 = reinterpret_cast<const int4*>(spans);
@@ -1198,6 +1220,10 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
         hipLaunchKernelGGL((k_cost_pairs<1, 1>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 14)
         hipLaunchKernelGGL((k_cost_pairs<1, 3>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
+    else if (mode == 17)
+        hipLaunchKernelGGL((k_cost_pairs<1, 6>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
+    else if (mode == 18)
+        hipLaunchKernelGGL((k_cost_pairs<0, 6>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 16)
         hipLaunchKernelGGL((k_cost_pairs<1, 5>), dim3(gx), dim3(SP_BLOCK), 0, s, pairs, c4, s4, n_spans, irls_eps, partials, seg_partials, nofuse);
     else if (mode == 15)
@@ -1244,7 +1270,7 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
             const SpPhase& ph = sched->phase[q];
             if (ph.spans != lead.spans || ph.n_spans != lead.n_spans) continue;
             if (ph.chunks != lead.chunks || ph.span_partials != lead.span_partials || ph.seg_partials != lead.seg_partials ||
-                ((ph.flags ^ lead.flags) & SP_PHASE_WAVE_SPANS)) return SP_EINVAL;
+                ((ph.flags ^ lead.flags) & (SP_PHASE_WAVE_SPANS | SP_PHASE_DEPTH_TABLE))) return SP_EINVAL;
             mask |= 1u << q;
         }
         seen |= mask;
@@ -1254,8 +1280,18 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
     if (n_leads == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const auto blocks_of = [&](const SpPhase& ph) { return (ph.flags & SP_PHASE_WAVE_SPANS) ? ((((ph.n_spans + 3) / 4) + 7) / 8) * 8 : ((ph.n_spans + 7) / 8) * 8; };
+    // the four kinds of a scheduled Gauss-Newton pass: wave spans or workgroup spans, depth tables or log-depth tables
+    const auto launch_sched = [&](const SpPhase& lead, int blocks) {
+        const int4* c4 = reinterpret_cast<const int4*>(lead.chunks);
+        const int4* s4 = reinterpret_cast<const int4*>(lead.spans);
+        const bool w64 = (lead.flags & SP_PHASE_WAVE_SPANS) != 0, dt = (lead.flags & SP_PHASE_DEPTH_TABLE) != 0;
+        if (w64 && dt) hipLaunchKernelGGL((k_cost_pairs<1, 6, 0, true>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        else if (w64) hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        else if (dt) hipLaunchKernelGGL((k_cost_pairs<1, 6>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        else hipLaunchKernelGGL(k_cost_pairs<1>, dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+    };
     bool same_kind = n_leads <= SP_SCHED_LISTS;
-    for (int i = 1; i < n_leads; ++i) same_kind = same_kind && !((sched->phase[leads[i].p].flags ^ sched->phase[leads[0].p].flags) & SP_PHASE_WAVE_SPANS);
+    for (int i = 1; i < n_leads; ++i) same_kind = same_kind && !((sched->phase[leads[i].p].flags ^ sched->phase[leads[0].p].flags) & (SP_PHASE_WAVE_SPANS | SP_PHASE_DEPTH_TABLE));
     if (n_leads > 1 && same_kind) {
         // ONE launch over all of them: 30.5 k -> 35.3 k frame pairs/s on 384 pairs (a launch per list: each drains the chip before the next starts)
         int total = 0;
@@ -1267,24 +1303,14 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
         }
         f.sched.n_lists = n_leads;
         const SpPhase& lead = sched->phase[leads[0].p];
-        if (lead.flags & SP_PHASE_WAVE_SPANS)
-            hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(total), dim3(SP_BLOCK), 0, s, lead.pairs, reinterpret_cast<const int4*>(lead.chunks),
-                               reinterpret_cast<const int4*>(lead.spans), lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
-        else
-            hipLaunchKernelGGL(k_cost_pairs<1>, dim3(total), dim3(SP_BLOCK), 0, s, lead.pairs, reinterpret_cast<const int4*>(lead.chunks),
-                               reinterpret_cast<const int4*>(lead.spans), lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        launch_sched(lead, total);
         SP_CHECK_LAUNCH();
         return 0;
     }
     for (int i = 0; i < n_leads; ++i) {
         const SpPhase& lead = sched->phase[leads[i].p];
         f.sched.mask = leads[i].mask;
-        if (lead.flags & SP_PHASE_WAVE_SPANS)
-            hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(blocks_of(lead)), dim3(SP_BLOCK), 0, s, lead.pairs, reinterpret_cast<const int4*>(lead.chunks),
-                               reinterpret_cast<const int4*>(lead.spans), lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
-        else
-            hipLaunchKernelGGL(k_cost_pairs<1>, dim3(blocks_of(lead)), dim3(SP_BLOCK), 0, s, lead.pairs, reinterpret_cast<const int4*>(lead.chunks),
-                               reinterpret_cast<const int4*>(lead.spans), lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        launch_sched(lead, blocks_of(lead));
         SP_CHECK_LAUNCH();
     }
     return 0;

@@ -766,7 +766,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
     const PrepSample& j = reinterpret_cast<const PrepSample*>(jobs)[job];
     // padding granule of the table: 256 (a whole 256-point block lies in one segment) or 64 (wave spans: every WAVE's 64 points
     // do; the search then runs per wave)
-    const int lane_off = j.granule == 64 ? (int)(threadIdx.x & ~63u) : 0;
+    const int lane_off = (j.granule & 0xffff) == 64 ? (int)(threadIdx.x & ~63u) : 0;
+    const bool depth_table = (j.granule & SP_PREP_DEPTH_TABLE) != 0;      // src4.w = exp(L) for the cost kernels' depth-table form
     // The pass is bound by memory latency, not bytes or arithmetic (waves parked on s_waitcnt 87 % of their cycles when every
     // point went load -> geometry -> 12 taps -> store on its own): the SP_SAMPLE_BLOCKS points of a thread go through each stage
     // together -- all table words requested, then all taps of a level, then the stores.
@@ -812,7 +813,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
         const int Hl = j.Hl[l], Wl = j.Wl[l];
         float4 v[SP_SAMPLE_BLOCKS];
 #pragma unroll
-        for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) v[k] = source_sample(g[k], generic(image), Hl, Wl);
+        for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) {
+            v[k] = source_sample(g[k], generic(image), Hl, Wl);
+            if (depth_table) v[k].w = fast_exp(v[k].w);
+        }
 #pragma unroll
         for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k)
             if (in_table[k]) store4(out + idx[k], live[k] ? v[k] : make_float4(0.f, 0.f, 0.f, 0.f));

@@ -209,7 +209,7 @@ class _NoTimer:
         pass
 
 
-def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, full_levels=None, timer=None, granule=GRANULE):
+def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, full_levels=None, timer=None, granule=GRANULE, depth_table=False):
     """Everything PairBatch needs from the raw frames, for the M0 given pairs.
 
     coarse: [(level, stride)] -- ADDITIONAL decimated tables (stride > 1) sampled at that level; the stride-1 tables are
@@ -375,7 +375,8 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
             jb['counts'] = t.counts_d.data_ptr() + 4 * n_off[:-1]
             jb['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
             jb['kld'], jb['K'] = _ptrs(kld), _ptrs(Ksrc)
-            jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'], jb['granule'] = Ns, P, Hs, Ws, len(lv), granule
+            jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'] = Ns, P, Hs, Ws, len(lv)
+            jb['granule'] = granule | (_lib.SP_PREP_DEPTH_TABLE if depth_table else 0)      # (depth tables: src4.w = exp(L), include/sp_hip.h)
             for k, l in enumerate(lv):
                 t.src4[l] = torch.empty(max(int(t.p_off[-1]), 1), 4, dtype=torch.float32, device=dev)
                 jb['image'][:, k] = ptr_lv[l][0]

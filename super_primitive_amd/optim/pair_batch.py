@@ -135,7 +135,7 @@ class _Lazy(dict):
 class PairBatch:
     def __init__(self, src_frames, trg_images, trg_Ks, poses, klds, levels=(0, 3), use_affine=False,
                  tile_points=DEFAULT_BATCH_TILE_POINTS, zmin=1e-7, replicate=1, span_points=None, point_stride=None,
-                 extra_tables=(), lazy_levels=True, timer=None, granule=GRANULE):
+                 extra_tables=(), lazy_levels=True, timer=None, granule=GRANULE, depth_table=True):
         """src_frames: keyframe-like objects (image, K, logdepth_perseg, keypoints, keypoint_regions) on one cuda
         device; trg_images: list of (3,H,W); trg_Ks: list of (3,3); poses: (M,4,4) initial target<-source;
         klds: list of (N_m,) initial keypoint log-depths; levels = (pyramid_min, pyramid_max) like
@@ -160,11 +160,17 @@ class PairBatch:
         ``timer``: a ``batch_prepare._Timer`` that collects per-pass HIP-event times of the set-up.
         ``granule`` = 64: WAVE SPANS (include/sp_hip.h SP_COST_WAVE_SPANS) -- segments are padded to multiples of 64 instead of
         256 points, a span belongs to one wave, one segment record per chunk.  For batches of many small ragged segments: 1200
-        SAM-like masks of ~280 pixels pad 40 % at 256 and 11 % at 64.  The single-launch forms (``fused=True``) are not available."""
+        SAM-like masks of ~280 pixels pad 40 % at 256 and 11 % at 64.  The single-launch forms (``fused=True``) are not available.
+        ``depth_table`` (default): the batch's tables hold exp(L) in ``src4[..., 3]`` instead of L and the cost passes run in their
+        depth-table form (include/sp_hip.h SP_COST_DEPTH_TABLE: one multiply per point instead of add + multiply + v_exp_f32, the
+        exponential of the segment's shift taken once per chunk; -1.8 % kernel time).  ``False``: log-depth tables, as the per-keyframe
+        path (``segment_table``) keeps them; the single-launch forms (``fused=True``) need that."""
         assert granule in (GRANULE, 64)
         self.granule = int(granule)
         self.rec_per_chunk = 4 if granule == GRANULE else 1
         self.wave_flag = 0 if granule == GRANULE else _lib.SP_COST_WAVE_SPANS
+        self.depth_table = bool(depth_table)
+        self.table_flag = _lib.SP_COST_DEPTH_TABLE if self.depth_table else 0
         lib = _lib.load()
         self.lib = lib
         M0 = len(src_frames)
@@ -191,7 +197,7 @@ class PairBatch:
         decimated = {l for l, s in coarse_keys if l in self.point_stride and self.point_stride[l] == s}
         full_levels = [l for l in self.level_ids if not (lazy_levels and l in decimated)] or [min(self.level_ids)]
         prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev, full_levels=full_levels,
-                                           timer=timer, granule=self.granule)
+                                           timer=timer, granule=self.granule, depth_table=self.depth_table)
         self.setup_bytes = prep['bytes']
         mark = timer.mark if timer is not None else (lambda name: None)
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
@@ -367,7 +373,9 @@ class PairBatch:
 
     # ------------------------------------------------------------------------------------------------
     def cost_pass(self, level, mode, irls_eps=1e-3):
-        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, mode | self.wave_flag,
+        if mode not in (0, 1) and self.table_flag:
+            raise ValueError("cost mode 2 and the developer modes read log-depth tables: build the batch with depth_table=False")
+        _lib.check(self.lib.sp_pairs_cost(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, mode | self.wave_flag | (self.table_flag if mode in (0, 1) else 0),
                                           float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.stream_ptr()), "sp_pairs_cost")
 
     def gn_step(self, level=0, irls_eps=1e-3, lm_up=8.0, lm_down=0.5, lm_min=1e-7, fused=False, conv_tol=0.0):
@@ -377,7 +385,7 @@ class PairBatch:
         pair's last tile also solves that pair -- bitwise the same results; measured 0-4 % slower on MI355X (the
         solver's register/LDS footprint costs the cost kernel one wave per SIMD), kept for launch-bound hosts."""
         if fused:
-            assert not self.wave_flag, "the single-launch form has no wave-span variant"
+            assert not self.wave_flag and not self.table_flag, "the single-launch form has no wave-span / depth-table variant (PairBatch(depth_table=False))"
             _lib.check(self.lib.sp_pairs_gn_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, self.M,
                                                     self.max_N, float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(self.arrivals),
                                                     float(lm_up), float(lm_down), float(lm_min), _lib.ptr(self.lm_state),
@@ -386,7 +394,7 @@ class PairBatch:
             return self._costs
         if conv_tol > 0.0:
             # per-pair convergence on the device: pairs in self.done are skipped by both launches (``run(conv_tol=...)``)
-            _lib.check(self.lib.sp_pairs_cost_active(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, 1 | self.wave_flag,
+            _lib.check(self.lib.sp_pairs_cost_active(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, 1 | self.wave_flag | self.table_flag,
                                                      float(irls_eps), _lib.ptr(self.partials), _lib.ptr(self.seg_partials),
                                                      _lib.ptr(self.done), _lib.stream_ptr()), "sp_pairs_cost_active")
             _lib.check(self.lib.sp_pairs_gn_step_conv(_lib.ptr(self.desc[level]), self.M, self.max_N, _lib.ptr(self.partials),
@@ -408,7 +416,7 @@ class PairBatch:
     def adam_step(self, level=0, lr_kld=1e-3, lr_pose=1e-2, lr_aff=5e-3, fused=False):
         """One Adam iteration (reset-tangent flavour of the reference's tracking/mapping loops) of every pair."""
         if fused:
-            assert not self.wave_flag, "the single-launch form has no wave-span variant"
+            assert not self.wave_flag and not self.table_flag, "the single-launch form has no wave-span / depth-table variant (PairBatch(depth_table=False))"
             _lib.check(self.lib.sp_pairs_adam_iterate(_lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, self.M,
                                                       self.max_N, _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(self.arrivals),
                                                       float(lr_kld), float(lr_pose), float(lr_aff), _lib.ptr(self.adam_state),
@@ -504,7 +512,7 @@ class PairBatch:
                 ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(lay.desc), _lib.ptr(lay.chunks), _lib.ptr(lay.spans), lay.n_spans
                 ph.span_partials, ph.seg_partials = _lib.ptr(lay.partials), _lib.ptr(lay.seg_partials)
             ph.irls_eps, ph.conv_tol, ph.max_iters = float(spec.get("irls_eps", irls_eps)), float(spec["conv_tol"]), int(spec["max_iters"])
-            ph.flags = (_lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0) | (_lib.SP_PHASE_WAVE_SPANS if self.wave_flag else 0)
+            ph.flags = (_lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0) | (_lib.SP_PHASE_WAVE_SPANS if self.wave_flag else 0) | (_lib.SP_PHASE_DEPTH_TABLE if self.table_flag else 0)
         sched.n_phases = len(phases)
         return sched
 

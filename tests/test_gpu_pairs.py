@@ -358,8 +358,8 @@ def test_fused_single_launch_iteration_is_bitwise_the_two_launch_one(mode):
     from super_primitive_amd import synth
     pairs = [synth.make_pair(60 + 12 * (k % 3), 80 + 8 * (k % 4), 4 + k % 5, seed=100 + k, init_sigma=0.02,
                              shape="blobs" if k % 2 else "grid") for k in range(24)]
-    a = make_batch(pairs, levels=(0, 1), tile_points=512)
-    b = make_batch(pairs, levels=(0, 1), tile_points=512)
+    a = make_batch(pairs, levels=(0, 1), tile_points=512, depth_table=False)        # (the single-launch forms read log-depth tables)
+    b = make_batch(pairs, levels=(0, 1), tile_points=512, depth_table=False)
     for it in range(15):
         if mode == "gn":
             ca, cb = a.gn_step(0, fused=True), b.gn_step(0, fused=False)
@@ -527,8 +527,23 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
     # 1040 (wider than the one-load-per-row fast paths)
     prs = [synth.make_pair(60, 80, 6, seed=101), synth.make_pair(97, 131, 9, seed=102), synth.make_pair(48, 64, 1, seed=103),
            synth.make_pair(50, 84, 4, seed=104), synth.make_pair(24, 1040, 2, seed=105)]
-    batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), extra_tables=[(1, 3)])     # 3: not a divisor of 4
+    batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), extra_tables=[(1, 3)], depth_table=False)     # 3: not a divisor of 4
     assert sorted(batch.coarse) == [(1, 2), (1, 3), (2, 4)]
+    # the default DEPTH-TABLE form (SP_COST_DEPTH_TABLE): the same tables with exp(L) in src4.w -- colours bitwise, depths to 2 ulp -- and
+    # the same cost / normal equations to the round-off of d = exp(L) exp(shift) against exp(L + shift)
+    dt = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), extra_tables=[(1, 3)])
+    assert dt.depth_table and not batch.depth_table
+    for l in range(3):
+        a4, b4 = npy(dt.src4[l].reshape(-1, 4)), npy(batch.src4[l].reshape(-1, 4))
+        real = npy(batch.pix).view(np.uint32) != 0
+        assert np.array_equal(a4[:, :3], b4[:, :3])
+        np.testing.assert_allclose(a4[real, 3], np.exp(b4[real, 3].astype(np.float64)), rtol=3e-7)
+    for mode in (0, 1):
+        for bt in (dt, batch):
+            bt.cost_pass(0, mode)
+        torch.cuda.synchronize()
+        # (IRLS weights 1 / max(|r|, eps) amplify a 2-ulp depth difference where |r| ~ eps: a few sums move by some 1e-4)
+        np.testing.assert_allclose(npy(dt.partials), npy(batch.partials), rtol=2e-3, atol=1e-5 * float(np.abs(npy(batch.partials)).max()))
     dev = batch.device
     for m, pr in enumerate(prs):
         masks, L, kp = T(pr.keypoint_regions).to(dev), T(pr.logdepth_perseg).to(dev), T(pr.keypoints).to(dev)

@@ -26,7 +26,7 @@ def test_mode2_normal_equations_with_affine_columns_match_oracle_jacobian():
     from super_primitive_amd import _lib, synth
     from super_primitive_amd.optim.pair_batch import PairBatch
     pairs = [synth.make_pair(48, 64, 6, seed=21 + k, shape=("grid", "blobs")[k], init_sigma=0.01) for k in range(2)]
-    batch = PairBatch.from_synth(pairs, levels=(0, 1), tile_points=512, use_affine=True, device="cuda:0")
+    batch = PairBatch.from_synth(pairs, levels=(0, 1), tile_points=512, use_affine=True, device="cuda:0", depth_table=False)    # (mode 2 reads log-depth tables)
     aff = np.array([[0.03, -0.02, -0.05, 0.04], [-0.02, 0.01, 0.06, -0.03]], dtype=np.float32)         # {a_s, b_s, a_t, b_t} per pair
     batch.aff.copy_(T(aff))
     NV, NS = _lib.SP_GNA_PARTIAL_FLOATS, _lib.SP_GNA_SEG_FLOATS

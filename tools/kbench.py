@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--segments", type=int, default=64)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--granule", type=int, default=256)
+    ap.add_argument("--no-depth-table", action="store_true", help="log-depth tables (exp per point) instead of depth tables")
+    ap.add_argument("--ab-depth-table", action="store_true", help="time mode 1 / mode 0 on a depth-table and a log-depth-table batch, interleaved")
     ap.add_argument("--shape", default="grid")
     ap.add_argument("--coverage", type=float, default=1.2)
     ap.add_argument("--ab-granule", action="store_true", help="time mode 1 / mode 0 on a 256-granule and a 64-granule (wave spans) batch, interleaved")
@@ -29,9 +31,13 @@ def main():
     batch, _ = bench.build_batch(a, 0, dev)
     for _ in range(3):
         batch.gn_step(0)
-    if a.ab_granule:
+    if a.ab_granule or a.ab_depth_table:
         import copy
-        a2 = copy.copy(a); a2.granule = 64 if a.granule == 256 else 256
+        a2 = copy.copy(a)
+        if a.ab_granule:
+            a2.granule = 64 if a.granule == 256 else 256
+        else:
+            a2.no_depth_table = not a.no_depth_table
         other, _ = bench.build_batch(a2, 0, dev)
         for rnd in range(4):
             for bt in (batch, other):
@@ -45,7 +51,7 @@ def main():
                     torch.cuda.synchronize()
                     ms = np.array([e0.elapsed_time(e1) for e0, e1 in ev])
                     by = bt.algorithmic_bytes(0)
-                    print(f"level 0 granule {bt.granule:3d} mode {mode} pairs {bt.M} spans {bt.n_spans}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us -> "
+                    print(f"level 0 granule {bt.granule:3d} {'depth tables' if bt.depth_table else 'log-depth tables'} mode {mode} pairs {bt.M} spans {bt.n_spans}: median {np.median(ms)*1e3:.1f} us  min {ms.min()*1e3:.1f} us -> "
                           f"{by/np.median(ms)/1e6/8000*100:.1f}% of 8 TB/s  (padding {sum(bt.Ppads)/sum(bt.Ps):.4f})", flush=True)
         return
     orders = [None] + [int(t) for t in a.tile_order.split(",") if t]

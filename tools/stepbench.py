@@ -9,6 +9,7 @@ from super_primitive_amd import _lib
 ap = argparse.ArgumentParser(); ap.add_argument("--pairs", type=int, default=96); ap.add_argument("--distinct", type=int, default=4)
 ap.add_argument("--tile-points", type=int, default=8192); ap.add_argument("--segments", type=int, default=64); a = ap.parse_args()
 dev = torch.device("cuda:0")
+a.no_depth_table = True          # (the single-launch forms timed below read log-depth tables)
 batch, _ = bench.build_batch(a, 0, dev)
 for _ in range(5): batch.gn_step(0)
 E = lambda: torch.cuda.Event(enable_timing=True)
