@@ -489,6 +489,43 @@ def golden_sigma05(ref, name="g19_sigma05_320x240x8", H=240, W=320, N=8, seeds=t
     print(f"{name}: {time.time() - t0:.0f} s; converged {int(save['converged'].sum())} of {len(rows)}", flush=True)
 
 
+def bench_reference_start(scene, replica, G=8, N=64, rank=0, H=480, W=640):
+    """The start bench.py's reference-start leg gives pair ``replica * G + scene`` (bench.py:reference_start_leg: scenes
+    ``5000 + 1000 rank + s``, overlap 4; replica 0 = the pair's own pose_init / kld_init, replica r > 0 drawn from
+    ``default_rng(77 + rank)`` in (replica, scene) order: 6 normals for the pose, N uniforms for the depth seeds)."""
+    pair = synth.make_pair(H, W, N, seed=5000 + 1000 * rank + scene, **dict(SIGMA05_ARGS, overlap=4))
+    if replica > 0:
+        rng = np.random.default_rng(77 + rank)
+        for r in range(1, replica + 1):
+            for s_ in range(G):
+                xi, u = rng.standard_normal(6), rng.uniform(size=N)
+                if r == replica and s_ == scene:
+                    pair.pose_init = (pair.pose_gt.astype(np.float64) @ synth.se3_exp_np(0.05 * xi)).astype(np.float32)
+                    pair.kld_init = np.log(2.0 + 2.0 * u).astype(np.float32)
+    return pair
+
+
+def golden_bench_pair(ref, pair_index=105, name="g20x_sigma05_bench_pair105"):
+    """the ONE pair of bench.py's 384 reference-start pairs the Gauss-Newton schedule does not bring home (pair 105 =
+    scene 5001, replica 13: a 1.8-sigma start, 0.091 rad / 0.061 t / depth seeds 50 % off) through the REAL reference loop (3 x 500 Adam
+    + settled polish): does the reference converge from it?"""
+    t0 = time.time()
+    scene, replica = pair_index % 8, pair_index // 8
+    pair = bench_reference_start(scene, replica)
+    r = reference_sfm_run(ref, pair, log=name)
+    e_gt = errors_vs(r["final_pose"], r["final_kld"], pair.pose_gt, pair.kld_gt)
+    e_sched = errors_vs(r["sched_pose"], r["sched_kld"], pair.pose_gt, pair.kld_gt)
+    e_init = errors_vs(pair.pose_init, pair.kld_init, pair.pose_gt, pair.kld_gt)
+    conv = all(e <= b for e, b in zip(e_gt, CONVERGED_VS_GT))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), pair_index=np.array(pair_index), scene_seed=np.array(5000 + scene), replica=np.array(replica),
+                        in_sha256=input_digest(pair), pose_init=pair.pose_init, kld_init=pair.kld_init, pose_gt=pair.pose_gt, kld_gt=pair.kld_gt,
+                        sched_pose=r["sched_pose"], sched_kld=r["sched_kld"], final_pose=r["final_pose"], final_kld=r["final_kld"], final_loss=r["final_loss"],
+                        err_gt=np.array(e_gt), err_sched_gt=np.array(e_sched), err_init_gt=np.array(e_init), converged=np.array(conv),
+                        loss_every10=r["sched_losses"][::10].copy(), polish_rounds=r["polish_rounds"], last_round_moved=r["last_round_moved"])
+    print(f"{name}: init err {e_init[0]:.3f} rad {e_init[1]:.3f} t {e_init[2]:.2f} d | after schedule {e_sched[0]:.1e} {e_sched[1]:.1e} {e_sched[2]:.1e} | "
+          f"polished {e_gt[0]:.1e} {e_gt[1]:.1e} {e_gt[2]:.1e} loss {r['final_loss']:.6f} {'CONVERGED' if conv else 'NOT CONVERGED'} ({time.time() - t0:.0f} s)", flush=True)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(int(os.environ.get("SP_GOLDEN_THREADS", "8")))
@@ -521,6 +558,8 @@ def main():
         golden_config4(ref)
     if "g19" in which:
         golden_sigma05(ref)
+    if "g20x" in which:
+        golden_bench_pair(ref)
     if "g20" in which:
         # the same at BASELINE configs[1] size (640x480x64) on the first three scenes of bench.py's reference-start leg
         # (bench.py:_render_sigma05: seeds 5000 + s, overlap 4; replica 0 of a scene starts from the pair's own pose_init / kld_init)

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--tile-order", default="", help="comma list of t: re-time with the points of every chunk re-ordered into t x t pixel "
                                                      "blocks (developer experiment on the table order; 0 = restore row-major)")
     a = ap.parse_args()
+    if any(int(x) >= 2 for x in a.modes.split(",")):
+        a.no_depth_table = True          # (mode 2 and the developer modes read log-depth tables)
     dev = torch.device("cuda:0")
     batch, _ = bench.build_batch(a, 0, dev)
     for _ in range(3):
