@@ -317,6 +317,8 @@ def measure_traffic(args, kernel_substr):
                "--granule", str(args.granule)]
         if args.span_points is not None:
             cmd += ["--span-points", str(args.span_points)]
+        if args.no_depth_table:
+            cmd += ["--no-depth-table"]
         try:
             proc = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                   timeout=240, start_new_session=True)
@@ -454,7 +456,7 @@ def main(argv=None):
                                if pairs else None),
                    "tile_points": args.tile_points, "span_points": batch.span_points, "granule": args.granule,
                    "padded_points_per_real_point": (float(sum(batch.Ppads)) / float(sum(batch.Ps)) if hasattr(batch, "Ppads") else None), "sharding": f"{world} x independent pair batches, final all_gather only"},
-        "roofline": {"bound": "hbm", "kernel": f"k_cost_pairs<{mode_id}>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": f"k_cost_pairs<{mode_id}, {0 if args.no_depth_table else 6}, 0, {'true' if args.granule == 64 else 'false'}>", "achieved": alg_bytes / (kern_ms * 1e-3) / 1e9,
                      "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kern_ms},
     }
@@ -464,7 +466,7 @@ def main(argv=None):
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     line["roofline"]["traffic_source"] = None
     if rank == 0 and world == 1 and not dry and not args.no_pmc:
-        hbm, detail = measure_traffic(args, f"k_cost_pairs<{mode_id}, 0, 0, {'true' if args.granule == 64 else 'false'}>")
+        hbm, detail = measure_traffic(args, f"k_cost_pairs<{mode_id}, {0 if args.no_depth_table else 6}, 0, {'true' if args.granule == 64 else 'false'}>")
         if hbm is not None:
             line["roofline"]["traffic"] = hbm
             line["roofline"]["traffic_source"] = "this run (rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one pass each, 10 steps of this command)"
@@ -673,7 +675,7 @@ def main(argv=None):
                 # the tail of the others (optim/pair_stream.py); sustained over n_b batches back to back, set-up included
                 pipe = PairStream(levels=(0, 3), point_stride=STRIDE, schedule=SCH, tile_points=args.tile_points, optimisers=n_opt, depth=max(1, n_opt - 1),
                                   granule=args.granule)
-                for rep in range(5):                         # (first passes: the streams' allocator pools fill; quoted: the first pass
+                for rep in range(10):                        # (first passes: the streams' allocator pools fill; quoted: the first pass
                     sync()                                   #  after the warm-up that needed no new device allocation, else the last)
                     n_alloc = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
                     t1 = time.perf_counter()

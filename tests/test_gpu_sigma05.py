@@ -69,3 +69,36 @@ def test_reference_start_schedule_is_deterministic_and_per_pair():
                                span_points=batch.span_points)
     one.run_scheduled(**sched)
     assert torch.equal(one.pose[0], a[0][2]) and torch.equal(one.kld, batch.klds()[2])
+
+
+def test_reference_start_at_the_headline_size_lands_on_the_references_end_state():
+    """the same at BASELINE configs[1] size.  Golden g20 = the first scenes of bench.py's reference-start leg
+    (seeds 5000 + s, 640x480x64, replica 0) through the REAL reference loop to its settled end state (40 minutes of CPU each).  The
+    schedule bench.py quotes ``frame_pairs_per_sec`` on (REFERENCE_START_SCHEDULE, levels and point strides as in the bench, granule 64)
+    must land inside the bar of that end state; golden g20x (when present): the one bench pair Gauss-Newton loses, through the
+    reference -- which side fails is printed."""
+    import os
+    from conftest import GOLDEN
+    from super_primitive_amd.optim.pair_batch import (REFERENCE_START_LEVELS, REFERENCE_START_POINT_STRIDE, REFERENCE_START_SCHEDULE,
+                                                      PairBatch)
+    g = load_golden("g20_sigma05_640x480x64")
+    pairs = _scenes(g)
+    batch = PairBatch.from_synth(pairs, levels=REFERENCE_START_LEVELS, point_stride=REFERENCE_START_POINT_STRIDE, granule=64)
+    sched = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
+    batch.run_scheduled(**sched)
+    P = batch.poses().double().cpu().numpy()
+    K = [k.double().cpu().numpy() for k in batch.klds()]
+    ref_ok = g["converged"].astype(bool)
+    vs_ref = np.array([pose_depth_errors(P[m], K[m], g["final_pose"][m], g["final_kld"][m]) for m in range(len(pairs))])
+    n_it = (batch.lm_state[:, 2] + batch.lm_state[:, 3]).cpu().numpy()
+    print(f"\n640x480x64 from the reference's start, {len(pairs)} scenes (reference converged on {int(ref_ok.sum())}): Gauss-Newton vs the reference's settled end "
+          f"state, worst {vs_ref[ref_ok].max(axis=0) if ref_ok.any() else None}; iterations per pair {n_it}; the reference's own distance from the ground truth "
+          f"{g['err_gt'].max(axis=0)}")
+    assert ref_ok.all() and len(pairs) >= 2
+    for m in range(len(pairs)):
+        assert all(e <= b for e, b in zip(vs_ref[m], BAR)), (int(g["seed"][m]), vs_ref[m])
+    path = os.path.join(GOLDEN, "g20x_sigma05_bench_pair105.npz")
+    if os.path.exists(path):
+        gx = np.load(path)
+        print(f"bench pair {int(gx['pair_index'])} (scene {int(gx['scene_seed'])}, replica {int(gx['replica'])}; start {gx['err_init_gt']}): the reference "
+              f"{'CONVERGES' if bool(gx['converged']) else 'does NOT converge'}, end state vs ground truth {gx['err_gt']}")
