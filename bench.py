@@ -597,8 +597,8 @@ def main(argv=None):
             line["frame_pair_schedule"] = (f"3 levels (coarse to fine), LM iterations until the pair's accepted step buys < {SCH['conv_tol']:g} of its cost "
                                            f"(at most {SCH['max_iters_per_level']} per level), then at level 0 with IRLS eps {SCH['polish_eps']:g} until < "
                                            f"{SCH['polish_tol']:g} (at most {SCH['polish_max']}); every pair advances through these phases on its own, on the device "
-                                           f"(PairBatch.run_scheduled); levels 1 / 2 iterate on the source points of the stride-{STRIDE[1]} / stride-{STRIDE[2]} pixel "
-                                           f"lattice (1/{STRIDE[1] ** 2} and 1/{STRIDE[2] ** 2} of them), level 0 and the polish on all points; iterations launched "
+                                           f"(PairBatch.run_scheduled); levels 0 / 1 / 2 iterate on the source points of the stride-{STRIDE[0]} / stride-{STRIDE[1]} / stride-{STRIDE[2]} pixel "
+                                           f"lattice (1/{STRIDE[0] ** 2}, 1/{STRIDE[1] ** 2} and 1/{STRIDE[2] ** 2} of them), the polish -- which fixes the end state -- on all points; iterations launched "
                                            f"{launched} (optim.pair_batch.FRAME_PAIR_SCHEDULE; asserted within 1e-4 rad / 1e-4 t / 1e-3 depth of the "
                                            "reference's minimiser by tests/test_gpu_fullsize.py)")
             # in-run check of every resident pair against the synthetic ground truth (rotation is gauge free; translation and

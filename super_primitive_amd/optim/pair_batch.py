@@ -40,7 +40,12 @@ GRANULE = 256                      # SP_BLOCK: every segment is padded to a mult
 # of them: about one source sample per TARGET pixel of that level instead of 4^l); the finest level and the polish use every
 # point, so the minimiser reached is that of the full reference cost.  (The reference evaluates every full-resolution source
 # point at every level, odometery/two_frame_sfm.py:128-207; every per-level method of PairBatch does too.)
-FRAME_PAIR_POINT_STRIDE = (1, 2, 4)
+# Round 4: level 0 ALSO iterates on its stride-2 lattice (a quarter of the points); only the polish -- the phase that fixes the end state,
+# with its own convergence test -- runs on all points.  Once the resident set is kept full (run_scheduled(slots=...)) the frame-pair rate
+# is bound by the cost kernel's throughput, i.e. by the WORK per pair, and the all-points level-0 phase was half of it: 29.6 k -> 38.1 k
+# pairs/s near start, 25.1 k -> 30.6 k from the reference's start, same converged fraction, same end states (tools/phase_sweep.py,
+# profiles/r04_phase_sweep.txt).
+FRAME_PAIR_POINT_STRIDE = (2, 2, 4)
 FRAME_PAIR_SCHEDULE = dict(max_iters_per_level=25, conv_tol=2e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-4, check_every=3)
 FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps=1e-5)
 # The schedule for the REFERENCE'S OWN starting distribution (odometery/two_frame_sfm.py:77-81,103-105: pose = T_gt Exp(0.05
@@ -48,7 +53,7 @@ FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps
 # (golden g19), inside the north-star bar of the reference's end state; bench.py quotes ``frame_pairs_per_sec`` on it next to the
 # near-start figure (tools/sigma05_sweep.py holds the sweep it was chosen from, profiles/r03_sigma05_sweep.txt its results).
 REFERENCE_START_LEVELS = (0, 3)
-REFERENCE_START_POINT_STRIDE = (1, 2, 4)
+REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15)
 
 

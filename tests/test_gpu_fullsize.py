@@ -130,9 +130,9 @@ def test_bench_schedule_reaches_the_reference_minimiser_at_full_size(granule):
             e = pose_depth_errors(poses[m], klds[m], pairs[m].pose_gt, pairs[m].kld_gt)
             assert e[0] <= 1e-4 and e[1] <= 1.5e-4 and e[2] <= 1.2e-3, (m, e)      # bar + the minimiser's own offset from ground truth
 
-    # the quoted form: the schedule on the device, every pair advancing through its own levels, levels 1 and 2 on their
-    # decimated point sets
-    assert sorted(batch.coarse) == [(1, 2), (2, 4)]
+    # the quoted form: the schedule on the device, every pair advancing through its own levels, every level on its decimated point
+    # set (round 4: level 0 on the stride-2 lattice too) and only the polish -- which fixes the end state -- on all points
+    assert sorted(batch.coarse) == [(0, 2), (1, 2), (2, 4)]
     launched = batch.run_scheduled(**sched_kw)
     torch.cuda.synchronize()
     assert 0 < launched <= 3 * FRAME_PAIR_SCHEDULE["max_iters_per_level"] + FRAME_PAIR_SCHEDULE["polish_max"]
