@@ -36,7 +36,11 @@ def test_cost_matches_reference_goldens(name):
         out = dense_optim.photomeric_cost(src, trg, kld, pose, CFG2, affine_comp=aff)
         out["residual"].abs().mean().backward()
         assert tuple(out["residual"].shape) == (1,)
-        np.testing.assert_allclose(npy(out["residual"]), g[p + "residual"], rtol=2e-5, atol=1e-9)
+        rel = float(np.abs(npy(out["residual"]) - g[p + "residual"]).max() / np.abs(g[p + "residual"]).max())
+        print(f"   {name} level {li}: residual vs the reference, relative error {rel:.2e}")
+        # 1e-6.  Measured on MI355X over the 5 goldens x their levels (round 4, printed above with -s): 0 ... 9.5e-8,
+        # i.e. at most one or two units in the last place of the fp32 mean; asserted at about twice the worst
+        np.testing.assert_allclose(npy(out["residual"]), g[p + "residual"], rtol=2e-7, atol=1e-9)
         # per-point diagnostics: same keys, shapes, dtypes and (up to fp32 noise) values as the reference
         assert np.array_equal(npy(out["segm_ids"]), g[p + "segm_ids"])
         ok_s = assert_masks_close(npy(out["src_valid_mask"]), g[p + "src_valid_mask"], 0, "src_valid_mask")
