@@ -153,3 +153,30 @@ def test_config3_sequence_follows_the_reference_chain():
         # the reference's tracking schedule does not converge (lr 5e-3 Adam, 300 steps: ~1e-3 of jitter per frame, golden g17's rerun spread),
         # so two faithful runs of the chain differ by that jitter; Gauss-Newton converges and sits at the centre of it
         assert abs(s_ref - 1) <= 0.15 and rot <= 4e-3 and tt <= 1e-2 and kld_err <= 3e-2 and kf_t <= 1e-2
+
+
+@pytest.mark.parametrize("engine", ["gn", "adam"])
+def test_config3_sequence_with_mono_initialisation(engine):
+    """The reference's ``mono_init: True`` start (config/tum/odom_desk.yaml; odometery.py:136-139,1003-1007,1066-1071,578-581): the first
+    keyframe gets UNIT depths at its keypoints, ``init_frames`` frames are tracked against it, the frame after becomes the second keyframe
+    (unit depths again) and mapping(mode='init') -- two keyframes, no supporting frames, pose rate 1e-2, ``init_steps`` = 1000 iterations, no
+    early stop -- recovers both depth maps and the relative pose up to the one monocular scale.  From there the chain runs as usual."""
+    from super_primitive_amd.odometery.sequence import run_sequence
+    n = 24
+    seq, frames, to_kf = make_sequence_inputs(n, rot_scale=0.5)
+    log = []
+    out = run_sequence(frames, to_kf, T(seq[0].T_wc), torch.zeros(seq[0].kld_gt.shape[0], device="cuda"), engine=engine, translation_thresh=0.095,
+                       window_size=5, mono_init=True, init_frames=7, log=log)
+    P = npy(out["track_poses"]).astype(np.float64)
+    G = np.stack([f.T_wc for f in seq]).astype(np.float64)
+    s, _, _ = _aligned_errors(P[8:], G[8:])
+    rot = max(rot_angle(a, b) for a, b in zip(P[8:], G[8:]))
+    tt = float(np.abs(s * P[8:, :3, 3] - G[8:, :3, 3]).max())
+    init = [d for _, ev, d in log if ev == 'mapping' and d['mode'] == 'init']
+    kld_err = max(float(np.abs(npy(k) + np.log(s) - seq[i].kld_gt).max()) for i, k in zip(out["kf_ids"], out["kf_klds"]))
+    print(f"\nmono initialisation, {engine}: keyframes {out['all_kf_ids']}, init mapping {init[0]['n']} iterations, loss {init[0]['losses'][0]:.5f} -> {init[0]['losses'][1]:.5f}; "
+          f"monocular scale {s:.3f} (unit depths for a plane ~3 away); after the initialisation, scale aligned: rot {rot:.2e} rad, t {tt:.2e}, keyframe log-depths {kld_err:.2e}")
+    assert out["all_kf_ids"][:2] == [0, 7] and out["n_init_mappings"] == 1 and len(init) == 1 and init[0]['kf_ids'] == [0, 7]
+    assert 2.0 < s < 4.0
+    bar = (5e-4, 5e-3, 1e-2) if engine == "gn" else (6e-3, 1.5e-2, 3e-2)
+    assert rot <= bar[0] and tt <= bar[1] and kld_err <= bar[2], (rot, tt, kld_err)
