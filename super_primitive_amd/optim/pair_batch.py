@@ -54,7 +54,12 @@ FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps
 # near-start figure (tools/sigma05_sweep.py holds the sweep it was chosen from, profiles/r03_sigma05_sweep.txt its results).
 REFERENCE_START_LEVELS = (0, 3)
 REFERENCE_START_POINT_STRIDE = (2, 2, 4)
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15)
+# pose_first_iters is a CAP (the phase ends by its convergence test): 15 cut the 2-4 sigma tail of the start distribution short (rotation
+# errors of 0.09-0.22 rad need ~20 pose-only iterations; 7 of bench.py's 1536 starts, among them the one of its first 384, diverged in the
+# joint phase -- while the real reference converges from that start, golden g20x); 30 loses 1 of 1536 (tools/hard_starts.py,
+# profiles/r04_reference_start.txt).  Longer is not better without the convergence test: a pose fitted for 25 iterations to depth seeds
+# that are 50 % off (IRLS epsilon 1e-2, where the test triggers late) loses 12 %.
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=30)
 
 
 def _level_images(img, max_level):
@@ -485,7 +490,7 @@ class PairBatch:
         return launched
 
     def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3, phases=None,
-                 use_coarse=True, pose_first_iters=0):
+                 use_coarse=True, pose_first_iters=0, pose_first_eps=None):
         """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
         built with a ``point_stride`` run on their decimated point set unless ``use_coarse=False``.  ``phases``: an explicit
         list of dict(level, stride, max_iters, irls_eps, conv_tol) instead (every (level, stride > 1) needs its table:
@@ -498,7 +503,7 @@ class PairBatch:
             if pose_first_iters > 0:
                 coarsest = max(self.level_ids)
                 phases.append(dict(level=coarsest, stride=self.point_stride[coarsest] if use_coarse else 1, max_iters=pose_first_iters,
-                                   irls_eps=irls_eps, conv_tol=conv_tol, pose_only=True))
+                                   irls_eps=irls_eps if pose_first_eps is None else pose_first_eps, conv_tol=conv_tol, pose_only=True))
             phases += [dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=max_iters_per_level, irls_eps=irls_eps,
                            conv_tol=conv_tol) for level in reversed(self.level_ids)]
             if polish_max > 0:
