@@ -23,6 +23,8 @@ for tab in "" "--no-depth-table"; do
   (echo "== $tag"; python tools/pmc_summary.py /tmp/pmc_${tag}_A k_cost_pairs; python tools/pmc_summary.py /tmp/pmc_${tag}_B k_cost_pairs) >> $OUT/cost_kernel_pmc.txt 2>&1
 done
 timeout 200 python tools/kbench.py --pairs 384 --tile-points 8192 --granule 64 --ab-depth-table --reps 60 2>/dev/null | grep level > $OUT/kbench_depth_table_ab.txt
+(timeout 300 python tools/phase_sweep.py 2>&1 | grep "pairs/s"; echo "--- from the reference start"; timeout 300 python tools/phase_sweep.py --reference-start 2>&1 | grep "pairs/s") > $OUT/phase_sweep.txt
+(timeout 300 python tools/reference_start_sweep.py 2>&1 | grep "pose-only"; timeout 200 python tools/hard_starts.py 2>&1 | grep hard) > $OUT/reference_start.txt
 timeout 300 python tools/window_bench.py 1 2 3 4 2>&1 | grep -v "^make\|amdgpu.ids" > $OUT/window_bench.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_window -o wb -- python tools/window_bench.py 2 > /dev/null 2>&1
 timeout 400 python tools/run_configs.py 2>/dev/null | grep config > $OUT/configs.txt
