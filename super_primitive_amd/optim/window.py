@@ -23,7 +23,8 @@ import torch
 
 from .. import _lib
 from ..segment_table import table_of
-from .pair_batch import DEFAULT_BATCH_TILE_POINTS, DEFAULT_SPAN_POINTS, GRANULE, MIN_SPANS, _level_images, build_work_list, pad_layout, pad_points
+from .batch_prepare import flat_work_list
+from .pair_batch import DEFAULT_BATCH_TILE_POINTS, DEFAULT_SPAN_POINTS, GRANULE, MIN_SPANS, _level_images, pad_layout, pad_points
 
 KIND_WINDOW, KIND_DIRECT = 0, 1
 
@@ -79,16 +80,18 @@ class PoseWindow:
         self.blocks = _upload_struct_array(blocks, dev)
         # ---- pose nodes ----------------------------------------------------------------------------------------
         arr = (_lib.SpWindowNode * self.n_nodes)()
+        # (ONE read-back for all poses and one for all affine pairs: a .cpu() per node was a host synchronisation each)
+        Ts = torch.stack([nd['T'].detach().float().reshape(4, 4).to(dev) for nd in nodes]).cpu().numpy().reshape(-1, 16)
+        with_aff = [i for i, nd in enumerate(nodes) if nd.get('aff') is not None]
+        affs = torch.stack([nodes[i]['aff'].detach().float().reshape(2).to(dev) for i in with_aff]).cpu().numpy() if with_aff else None
         for i, nd in enumerate(nodes):
-            T = nd['T'].detach().float().cpu().numpy().reshape(16)
-            arr[i].T = (ctypes.c_float * 16)(*T)
-            if nd.get('aff') is not None:
-                a = nd['aff'].detach().float().cpu().numpy().reshape(2)
-                arr[i].aff = (ctypes.c_float * 2)(*a)
+            arr[i].T = (ctypes.c_float * 16)(*Ts[i])
             arr[i].lr_pose = float(nd.get('lr_pose', 0.0))
             arr[i].lr_aff = float(nd.get('lr_aff', 0.0))
             arr[i].kind = int(nd.get('kind', KIND_WINDOW))
             arr[i].flags = 1 if nd.get('renorm', False) else 0
+        for j, i in enumerate(with_aff):
+            arr[i].aff = (ctypes.c_float * 2)(*affs[j])
         self.nodes = _upload_struct_array(arr, dev)
         # ---- target images: packed per level -------------------------------------------------------------------
         self.trg3, self.level_hw = {}, {}
@@ -116,16 +119,21 @@ class PoseWindow:
         if span_points is None:
             span_points = min(DEFAULT_SPAN_POINTS, total // MIN_SPANS)
         self.span_points = max(int(span_points), GRANULE)
-        wl = build_work_list(epads, self.span_points, tile_points)
+        # the work list of all edges at once by the library's host helper (the Python form took 1.8 ms for a reference-sized window)
+        e_N = np.array([len(pd['pc']) for pd in epads], dtype=np.int64)
+        wl = flat_work_list(np.concatenate([pd['pc'] for pd in epads]), np.concatenate([pd['pseg_off'][:-1] for pd in epads]),
+                            np.concatenate(([0], np.cumsum(e_N))), self.span_points, tile_points, GRANULE)
         self.n_chunks, self.n_spans = len(wl['chunks']), len(wl['spans'])
         self.chunks = torch.from_numpy(wl['chunks']).to(dev)
         self.spans = torch.from_numpy(wl['spans']).to(dev)
-        sto_off = np.concatenate(([0], np.cumsum([len(s) for s in wl['seg_rec_offs']])))
-        self.seg_tile_off = torch.from_numpy(np.concatenate(wl['seg_rec_offs'])).to(dev)
+        sto_off = wl['sto_off']
+        self.seg_tile_off = torch.from_numpy(wl['seg_tile_off']).to(dev)
         self.pose_slots = torch.zeros(E, 16, dtype=torch.float32, device=dev)
         self.aff_slots = torch.zeros(E, 4, dtype=torch.float32, device=dev) if use_affine else None
         self.Ps = [tables[k].P for k, _, _, _ in edges]
         self.desc = {}
+        Ks_src = torch.stack([s_['kf'].K.detach().float().to(dev) for s_ in sources]).cpu().numpy()
+        Ks_trg = dict(zip(targets, torch.stack([nodes[i]['K'].detach().float().to(dev) for i in targets]).cpu().numpy()))
         for l in self.level_ids:
             parr = (_lib.SpPair * E)()
             for e, (k, i, _w, zmin) in enumerate(edges):
@@ -138,8 +146,7 @@ class PoseWindow:
                 d.pose = self.pose_slots.data_ptr() + 64 * e
                 d.aff = (self.aff_slots.data_ptr() + 16 * e) if use_affine else None
                 d.seg_tile_off = self.seg_tile_off.data_ptr() + 4 * int(sto_off[e])
-                Ks = kf.K.detach().float().cpu().numpy()
-                Kt = nodes[i]['K'].detach().float().cpu().numpy()
+                Ks, Kt = Ks_src[k], Ks_trg[i]
                 d.K_src = (ctypes.c_float * 4)(Ks[0, 0], Ks[1, 1], Ks[0, 2], Ks[1, 2])
                 d.K_trg = (ctypes.c_float * 4)(Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
                 d.N, d.P, d.H, d.W = tab.N, tab.P, tab.H, tab.W
