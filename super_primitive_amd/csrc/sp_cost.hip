@@ -282,6 +282,41 @@ struct PairConsts {            // the uniform operand pairs of prepare2 / fold_g
     float R6, R7, R8, t2, gain, bias, zmin, eps;
 };
 __device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+// a.y * b (+ c): the HIGH half of an aligned pair broadcast to both lanes through op_sel.  hipcc broadcasts a pair's low half this way by
+// itself but copies a high half into a fresh even register first (v_mov_b32; 22 such copies per point in the Gauss-Newton pass, 13 % of its
+// vector instructions) -- here the modifier is spelled out.
+__device__ __forceinline__ f32x2 pfma_hi(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pmul_hi(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a.x * b + c with the low half spelled out as well (keeps a and its high-half uses in ONE register pair)
+__device__ __forceinline__ f32x2 pfma_lo(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// ... and with the product negated (-a.x * b + c, -a.y * b + c): a sign carried as an operand modifier instead of a v_xor_b32
+__device__ __forceinline__ f32x2 pfnma_lo(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pfnma_hi(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pmul_lo(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 __device__ __forceinline__ f32x2 pfma(float a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(f32x2{a, a}, b, c); }
 
 struct GnAcc {
@@ -294,7 +329,7 @@ struct GnAcc {
     f32x2 hd01;       // acc[28], acc[29]
     f32x2 hd[2];      // acc[30..33]
     float h11;        // acc[7]
-    float D, bd;      // acc[34], acc[35]
+    f32x2 D, bd;      // acc[34], acc[35]: x + y (the two rows' products accumulate side by side: one v_pk_fma_f32 each; added at the flush)
     float cost, n;    // acc[0], acc[36]
 };
 
@@ -334,7 +369,7 @@ __device__ __forceinline__ void prepare2(const TileCtx& c, const PairConsts& k, 
     p.off0 = off0;
 }
 
-struct Mix2 { f32x2 wa, v; float w11; };      // {w00, w01}, {v0, v1}, w11
+struct Mix2 { f32x2 wa, wb, v; };      // {w00, w01}, {w01, w11}, {v0, v1}
 // mode 2 (Gauss-Newton WITH the affine brightness pair of the target as unknowns, the window optimiser's flavour): two more
 // residual columns per channel, j_a = d r / d a_t = gain * I  and  j_b = d r / d b_t = -1  (r = I_src - (gain I + bias),
 // gain = exp(-(a_t - a_s)), bias = b_t - b_s; the source frame's pair enters with the opposite sign).
@@ -370,8 +405,9 @@ __device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& 
     const f32x2 wx2 = wg2 * Ix2, wy2 = wg2 * Iy2;
     const float wxb = wgb * Ixb, wyb = wgb * Iyb;
     const f32x2 w00p = wx2 * Ix2, w01p = wx2 * Iy2, w11p = wy2 * Iy2, v0p = wx2 * r2, v1p = wy2 * r2;
-    o.wa = f32x2{fmaf(wxb, Ixb, w00p.x) + w00p.y, fmaf(wxb, Iyb, w01p.x) + w01p.y};
-    o.w11 = fmaf(wyb, Iyb, w11p.x) + w11p.y;
+    const float w01 = fmaf(wxb, Iyb, w01p.x) + w01p.y;
+    o.wa = f32x2{fmaf(wxb, Ixb, w00p.x) + w00p.y, w01};
+    o.wb = f32x2{w01, fmaf(wyb, Iyb, w11p.x) + w11p.y};
     o.v = f32x2{fmaf(wxb, rb, v0p.x) + v0p.y, fmaf(wyb, rb, v1p.x) + v1p.y};
     cost_acc = fmaf(p.m, (ar0 + ar1) + arb, cost_acc);
     n_acc += p.m;
@@ -395,46 +431,50 @@ template <bool AFF = false>
 __device__ __forceinline__ void fold_gn2(const PairConsts& k, const GeoGn g, const Mix2 w, GnAcc& A, const MixA* wa = nullptr,
                                          AffAcc* aa = nullptr) {
     const f32x2 g2 = k.gab * g.zinv;   // {ga, gb}; zinv carries the mask
-    const f32x2 Wa = w.wa * (g2 * g2.x);                 // {W00, W01}
-    const float W11 = w.w11 * (g2.y * g2.y);
+    // (every product with ONE half of a pair as the multiplier goes through pfma_lo / pfma_hi / pmul_lo / pmul_hi: the broadcast is an
+    //  operand modifier, no copy)
+    const f32x2 Wa = w.wa * pmul_lo(g2, g2);             // {W00, W01} = {w00, w01} * ga * {ga, gb}
+    const f32x2 Wb = w.wb * pmul_hi(g2, g2);             // {W01, W11} = {w01, w11} * gb * {ga, gb}
     const f32x2 V = -(w.v * g2);
     const f32x2 qxy = g.qxy;
     const f32x2 u = qxy * g.zi;                          // {ux, vy}
     const float ez = g.qz - k.t2;
     const f32x2 Q = pfma(-ez, u, qxy - k.t01);   // column 6 of Ahat: {A0[4], A1[4]}
-    // columns 2..5 of Ahat as pairs along the column index
-    const f32x2 A00{-u.x, -u.x * qxy.y}, A01{fmaf(u.x, qxy.x, g.qz), -qxy.y};
-    const f32x2 A10{-u.y, -fmaf(u.y, qxy.y, g.qz)}, A11{u.y * qxy.x, qxy.x};
-    const f32x2 B00 = pfma(Wa.x, A00, Wa.y * A10), B01 = pfma(Wa.x, A01, Wa.y * A11);
-    const f32x2 B10 = pfma(Wa.y, A00, W11 * A10), B11 = pfma(Wa.y, A01, W11 * A11);
-    const f32x2 P = pfma(Q.x, Wa, Q.y * f32x2{Wa.y, W11});          // {B0[4], B1[4]}
-    A.h00 += Wa; A.h11 += W11;
-    A.h0[0] += B00; A.h0[1] += B01;
-    A.h1[0] += B10; A.h1[1] += B11;
-    A.blk[0] = pfma(A00.x, B00, pfma(A10.x, B10, A.blk[0]));
-    A.blk[1] = pfma(A00.x, B01, pfma(A10.x, B11, A.blk[1]));
-    A.blk[2] = pfma(A00.y, B00, pfma(A10.y, B10, A.blk[2]));
-    A.blk[3] = pfma(A00.y, B01, pfma(A10.y, B11, A.blk[3]));
-    A.blk[4] = pfma(A01.x, B01, pfma(A11.x, B11, A.blk[4]));
-    A.blk[5] = pfma(A01.y, B01, pfma(A11.y, B11, A.blk[5]));
+    // columns 2..5 of Ahat as pairs along the column index.  Columns 2 and 3 of row 0 and of row 1 are negative throughout: they are
+    // kept with the sign flipped (nA00 = -Ahat0[2..3], nA10 = -Ahat1[2..3], hence nB00 = -B00, nB10 = -B10) and the sign goes into the
+    // operand modifiers of the products below -- four v_xor_b32 per point otherwise
+    const f32x2 nA00{u.x, u.x * qxy.y}, A01{fmaf(u.x, qxy.x, g.qz), -qxy.y};
+    const f32x2 nA10{u.y, fmaf(u.y, qxy.y, g.qz)}, A11{u.y * qxy.x, qxy.x};
+    const f32x2 nB00 = pfma_lo(Wa, nA00, pmul_hi(Wa, nA10)), B01 = pfma_lo(Wa, A01, pmul_hi(Wa, A11));
+    const f32x2 nB10 = pfma_lo(Wb, nA00, pmul_hi(Wb, nA10)), B11 = pfma_lo(Wb, A01, pmul_hi(Wb, A11));
+    const f32x2 P = pfma_lo(Q, Wa, pmul_hi(Q, Wb));          // {B0[4], B1[4]}
+    A.h00 += Wa; A.h11 += Wb.y;
+    A.h0[0] -= nB00; A.h0[1] += B01;
+    A.h1[0] -= nB10; A.h1[1] += B11;
+    A.blk[0] = pfma_lo(nA00, nB00, pfma_lo(nA10, nB10, A.blk[0]));
+    A.blk[1] = pfnma_lo(nA00, B01, pfnma_lo(nA10, B11, A.blk[1]));
+    A.blk[2] = pfma_hi(nA00, nB00, pfma_hi(nA10, nB10, A.blk[2]));
+    A.blk[3] = pfnma_hi(nA00, B01, pfnma_hi(nA10, B11, A.blk[3]));
+    A.blk[4] = pfma_lo(A01, B01, pfma_lo(A11, B11, A.blk[4]));
+    A.blk[5] = pfma_hi(A01, B01, pfma_hi(A11, B11, A.blk[5]));
     A.bp01 += V;
     A.hd01 += P;
-    A.bp[0] = pfma(V.x, A00, pfma(V.y, A10, A.bp[0]));
-    A.bp[1] = pfma(V.x, A01, pfma(V.y, A11, A.bp[1]));
-    A.hd[0] = pfma(P.x, A00, pfma(P.y, A10, A.hd[0]));
-    A.hd[1] = pfma(P.x, A01, pfma(P.y, A11, A.hd[1]));
-    A.D = fmaf(Q.x, P.x, fmaf(Q.y, P.y, A.D));
-    A.bd = fmaf(Q.x, V.x, fmaf(Q.y, V.y, A.bd));
+    A.bp[0] = pfnma_lo(V, nA00, pfnma_hi(V, nA10, A.bp[0]));
+    A.bp[1] = pfma_lo(V, A01, pfma_hi(V, A11, A.bp[1]));
+    A.hd[0] = pfnma_lo(P, nA00, pfnma_hi(P, nA10, A.hd[0]));
+    A.hd[1] = pfma_lo(P, A01, pfma_hi(P, A11, A.hd[1]));
+    A.D = pfma(Q, P, A.D);
+    A.bd = pfma(Q, V, A.bd);
     if constexpr (AFF) {
         // sum_ch w j_a J_geo = -(g2 o ua) Ahat ;  sum_ch w j_b J_geo = +(g2 o ub) Ahat      (g2 carries the mask)
         const f32x2 Ua = -(wa->ua * g2), Ub = wa->ub * g2;
         aa->pa01 += Ua;
-        aa->pa[0] = pfma(Ua.x, A00, pfma(Ua.y, A10, aa->pa[0]));
-        aa->pa[1] = pfma(Ua.x, A01, pfma(Ua.y, A11, aa->pa[1]));
+        aa->pa[0] = pfnma_lo(Ua, nA00, pfnma_hi(Ua, nA10, aa->pa[0]));
+        aa->pa[1] = pfma_lo(Ua, A01, pfma_hi(Ua, A11, aa->pa[1]));
         aa->hda = fmaf(Q.x, Ua.x, fmaf(Q.y, Ua.y, aa->hda));
         aa->pb01 += Ub;
-        aa->pb[0] = pfma(Ub.x, A00, pfma(Ub.y, A10, aa->pb[0]));
-        aa->pb[1] = pfma(Ub.x, A01, pfma(Ub.y, A11, aa->pb[1]));
+        aa->pb[0] = pfnma_lo(Ub, nA00, pfnma_hi(Ub, nA10, aa->pb[0]));
+        aa->pb[1] = pfma_lo(Ub, A01, pfma_hi(Ub, A11, aa->pb[1]));
         aa->hdb = fmaf(Q.x, Ub.x, fmaf(Q.y, Ub.y, aa->hdb));
     }
 }
@@ -525,17 +565,17 @@ __device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ r
     const int lane = lane_id();
     int pos; bool ok;
     if constexpr (AFF) {
-        float v[10] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D, A.bd, aa->hda, aa->hdb};
+        float v[10] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D.x + A.D.y, A.bd.x + A.bd.y, aa->hda, aa->hdb};
         wave_sum_to_lanes<10>(v, lane, pos, ok);
         if (ok) store_partial<WT>(rec + pos, v[0]);
         aa->hda = 0.f; aa->hdb = 0.f;
     } else {
-        float v[8] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D, A.bd};
+        float v[8] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D.x + A.D.y, A.bd.x + A.bd.y};
         wave_sum_to_lanes<8>(v, lane, pos, ok);
         if (ok) store_partial<WT>(rec + pos, v[0]);
     }
     const f32x2 z{0.f, 0.f};
-    A.hd01 = z; A.hd[0] = z; A.hd[1] = z; A.D = 0.f; A.bd = 0.f;
+    A.hd01 = z; A.hd[0] = z; A.hd[1] = z; A.D = z; A.bd = z;
 }
 
 // ABL (developer ablation, only reachable through mode >= 10 of sp_pairs_cost): 0 = product kernel,
@@ -575,7 +615,8 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         for (int k = 0; k < 2; ++k) { A.h0[k] = z; A.h1[k] = z; A.bp[k] = z; A.hd[k] = z; }
 #pragma unroll
         for (int k = 0; k < 6; ++k) A.blk[k] = z;
-        A.h11 = A.D = A.bd = A.cost = A.n = 0.f;
+        A.D = z; A.bd = z;
+        A.h11 = A.cost = A.n = 0.f;
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     SpanCursor k;
@@ -615,7 +656,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     S1.p = S0.p;                         // "point -1": finite values, zinv = zi = 0 and a zero Mix2 -> contributes exact zeros
     S1.p.zinv = 0.f; S1.p.zi = 0.f;
     S1.q = q0; S1.last = false;
-    Mix2 m{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, 0.f};
+    Mix2 m{f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};
     // one trip: taps + channel mixing of the point in `a`, fold of the point in `b`, geometry of the next point into `b`
     auto trip = [&](Slot& a, Slot& b) {
         op += 4u * TRIP;
