@@ -312,6 +312,17 @@ __device__ __forceinline__ f32x2 pfnma_hi(f32x2 a, f32x2 b, f32x2 c) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
 }
+// {a.y * b.x + c.x, a.x * b.x + c.y} and {a.y * b.y + c.x, a.x * b.y + c.y}: the halves of a swapped, one half of b for both
+__device__ __forceinline__ f32x2 pfma_swz_lo(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pfma_swz_hi(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
 __device__ __forceinline__ f32x2 pmul_lo(f32x2 a, f32x2 b) {
     f32x2 d;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
@@ -388,27 +399,26 @@ __device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& 
                                            const f32x3 cc, const f32x3 d, Mix2& o, float& cost_acc, float& n_acc,
                                            MixA* oa = nullptr, AffAcc* aa = nullptr) {
     const float eps = k.eps;
-    // red+green as a pair
+    // Per channel the pair G = {Ix, Iy} = {e1 + wy e3, e2 + wx e3} (e1 = b - a, e2 = c - a, e3 = (d - c) - e1): the sums over the
+    // channels of w G G^T and of w r G are then pair operations whose results ARE the pairs fold_gn2 consumes (a pairing across the
+    // channels needs horizontal sums and copies to build them).  e3 of red and green is one pair, used half by half.
     const f32x2 a2{a.x, a.y}, b2{b.x, b.y}, c2{cc.x, cc.y}, d2{d.x, d.y};
-    const f32x2 e1 = b2 - a2, e2 = c2 - a2, e3 = (d2 - c2) - e1;
-    const f32x2 Iy2 = pfma(p.wxy.x, e3, e2);
-    const f32x2 Ix2 = pfma(p.wxy.y, e3, e1);
-    const f32x2 it2 = pfma(p.wxy.y, Iy2, pfma(p.wxy.x, e1, a2));
+    const f32x2 e3 = ((d2 - c2) - b2) + a2;
+    const f32x2 Er{b.x - a.x, cc.x - a.x}, Eg{b.y - a.y, cc.y - a.y}, Eb{b.z - a.z, cc.z - a.z};
+    f32x2 e3b;                                   // only the low half is read
+    e3b.x = (d.z - cc.z) - Eb.x;
+    const f32x2 Gr = pfma_swz_lo(p.wxy, e3, Er), Gg = pfma_swz_hi(p.wxy, e3, Eg), Gb = pfma_swz_lo(p.wxy, e3b, Eb);
+    const f32x2 it2{fmaf(p.wxy.y, Gr.y, fmaf(p.wxy.x, Er.x, a.x)), fmaf(p.wxy.y, Gg.y, fmaf(p.wxy.x, Eg.x, a.y))};
+    const float itb = fmaf(p.wxy.y, Gb.y, fmaf(p.wxy.x, Eb.x, a.z));
     const f32x2 r2 = p.srg - pfma(k.gain, it2, k.bias2);
-    // blue
-    float itb, Ixb, Iyb;
-    tap_mix(a.z, b.z, cc.z, d.z, p.wxy.x, p.wxy.y, itb, Ixb, Iyb);
     const float rb = p.sb - fmaf(k.gain, itb, k.bias);
     const float ar0 = fabsf(r2.x), ar1 = fabsf(r2.y), arb = fabsf(rb);
     const f32x2 wg2{__builtin_amdgcn_rcpf(fmaxf(ar0, eps)), __builtin_amdgcn_rcpf(fmaxf(ar1, eps))};
     const float wgb = __builtin_amdgcn_rcpf(fmaxf(arb, eps));
-    const f32x2 wx2 = wg2 * Ix2, wy2 = wg2 * Iy2;
-    const float wxb = wgb * Ixb, wyb = wgb * Iyb;
-    const f32x2 w00p = wx2 * Ix2, w01p = wx2 * Iy2, w11p = wy2 * Iy2, v0p = wx2 * r2, v1p = wy2 * r2;
-    const float w01 = fmaf(wxb, Iyb, w01p.x) + w01p.y;
-    o.wa = f32x2{fmaf(wxb, Ixb, w00p.x) + w00p.y, w01};
-    o.wb = f32x2{w01, fmaf(wyb, Iyb, w11p.x) + w11p.y};
-    o.v = f32x2{fmaf(wxb, rb, v0p.x) + v0p.y, fmaf(wyb, rb, v1p.x) + v1p.y};
+    const f32x2 wGr = pmul_lo(wg2, Gr), wGg = pmul_hi(wg2, Gg), wGb = Gb * wgb;
+    o.wa = pfma_lo(wGb, Gb, pfma_lo(wGg, Gg, pmul_lo(wGr, Gr)));       // sum w Ix {Ix, Iy}
+    o.wb = pfma_hi(wGb, Gb, pfma_hi(wGg, Gg, pmul_hi(wGr, Gr)));       // sum w Iy {Ix, Iy}
+    o.v = pfma(wGb, rb, pfma_hi(r2, wGg, pmul_lo(r2, wGr)));           // sum w r {Ix, Iy}
     cost_acc = fmaf(p.m, (ar0 + ar1) + arb, cost_acc);
     n_acc += p.m;
     if constexpr (AFF) {
@@ -421,8 +431,8 @@ __device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& 
         aa->hbb = fmaf(p.m, (wg2.x + wg2.y) + wgb, aa->hbb);
         aa->ba = fmaf(p.m, fmaf(wjb, rb, wj2.x * r2.x) + wj2.y * r2.y, aa->ba);
         aa->bb = fmaf(-p.m, fmaf(wgb, rb, wg2.x * r2.x) + wg2.y * r2.y, aa->bb);
-        oa->ua = f32x2{fmaf(wjb, Ixb, wj2.x * Ix2.x) + wj2.y * Ix2.y, fmaf(wjb, Iyb, wj2.x * Iy2.x) + wj2.y * Iy2.y};
-        oa->ub = f32x2{(wx2.x + wx2.y) + wxb, (wy2.x + wy2.y) + wyb};
+        oa->ua = pfma(Gb, wjb, pfma_hi(wj2, Gg, pmul_lo(wj2, Gr)));    // sum w j_a {Ix, Iy}
+        oa->ub = (wGr + wGg) + wGb;                                    // sum w {Ix, Iy}
     }
 }
 
