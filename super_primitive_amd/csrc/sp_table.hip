@@ -491,6 +491,213 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* _
     segment_row_scan(generic(t.row_counts[k] + (size_t)blockIdx.x * t.H), t.H, generic(t.counts[k] + blockIdx.x));
 }
 
+#define SP_FILL_ROWS 256
+
+// does the fill pass of this keyframe read the bit words the count pass wrote (k_prep_fill_bits) instead of the masks (k_prep_fill)?
+__device__ __forceinline__ bool prep_fill_bits_path(const PrepTable& t) {
+    return t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0 && (long long)t.N * t.H < (1ll << 22);
+}
+
+// inclusive prefix sum over the 64 lanes of a wave in six DPP additions (row shifts by 1 / 2 / 4 / 8 inside the rows of 16 lanes, then
+// lane 15 of a row broadcast into the next row, lane 31 into the upper half): no LDS traffic, no barrier
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// the set pixels i = 0, STEP, 2 STEP, ... of an octet, in order, into the staging list from position q on
+template <int STEP>
+__device__ __forceinline__ void stage_octet(uint2* stage, uint32_t sel, int q, uint32_t pw0, const float (&Lq)[8], int lane) {
+#pragma unroll
+    for (int i = 0; i < 8; i += STEP) {
+        const uint32_t bit = (sel >> i) & 1u;
+        stage[bit ? q : 512 + lane] = make_uint2(pw0 + (uint32_t)i, __float_as_uint(Lq[i]));
+        q += (int)bit;
+    }
+}
+
+// Ordered compaction on the bit words of the count pass, by OCTETS (8 pixels = half a bit word), every WAVE on its own rows.
+// A row at a time -- a lane per 4 pixels, ballots for the ranks -- is ~330 instructions per row of which a segment fills a fifth of
+// the lanes (bound by instruction issue at 0.11-0.19 of the HBM roofline); octets of 32 rows through block-wide stages (list, scan
+// across the four waves, deltas: five barriers per 256 octets) left the waves parked three quarters of the time (0.25).  The start
+// of every ROW in every lattice's table is known from the row counts, so rows -- and waves -- are independent: a wave takes every
+// fourth row of the workgroup's SP_FILL_ROWS (a segment's non-empty rows are consecutive: they spread evenly over the waves),
+// keeps the non-empty ones, and runs batches of SP_FILL_WAVE_ROWS of them through (a) the rows' bit words into LDS, (b) the ordered
+// list of the batch's non-empty octets (ballots), (c) 64 listed octets at a time, one per lane: the log-depths of the octet (two
+// 16-byte loads, requested one chunk ahead), its point counts per lattice, a wave-wide prefix sum of those (DPP) = the rank of its
+// first point in list order, minus the value at the row's first octet = the rank inside the row, plus the row's start = where its
+// points go, in torch.where order.  All LDS is private to the wave: no barrier anywhere.
+#define SP_FILL_WAVE_ROWS 8
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* __restrict__ tables) {
+    const PrepTable& t = table_of(tables, blockIdx.y);
+    if (!prep_fill_bits_path(t)) return;
+    const int rows = t.N * t.H;
+    const int row_base = blockIdx.x * SP_FILL_ROWS;
+    if (row_base >= rows) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RB = SP_FILL_WAVE_ROWS;
+    __shared__ int s_rows[SP_WAVES][64];                              // the wave's non-empty rows
+    __shared__ int s_r[SP_WAVES][64];                                 // ... their row of the image
+    __shared__ int s_base[SP_WAVES][SP_PREP_MAX_STRIDES][64];         // first table position of the row per lattice, -1: not on the lattice
+    __shared__ uint32_t s_bits[SP_WAVES][RB][64];
+    constexpr int LIST = 640;                                         // (RB rows of 640 pixels; fewer rows per batch when they are longer: the
+    __shared__ uint16_t s_list[SP_WAVES][LIST];                       //  workgroup's LDS stays under a quarter of the CU's) octet = row of the batch << 7 | octet of the row
+    __shared__ int s_delta[SP_WAVES][SP_PREP_MAX_STRIDES][RB];
+    __shared__ uint2 s_stage[SP_WAVES][512 + 64];                     // the points of a chunk of 64 octets in list order {pixel word, log-depth}; + a slot per lane for the unset pixels
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int s_n;
+    {   // one lane per row: is it empty?  The row's start in every lattice's table is requested together with the counts that say so
+        const int row = row_base + SP_WAVES * lane + wave;
+        const bool in_range = row < rows;
+        // segment and image row without an integer division per lane: rows < 2^22 are exact in fp32, the quotient is off by one at most
+        const int H = t.H;
+        int n = (int)((float)row * (1.f / (float)H)), r = row - n * H;
+        if (r < 0) { --n; r += H; }
+        if (r >= H) { ++n; r -= H; }
+        if (!in_range) n = 0;
+        int b[SP_PREP_MAX_STRIDES];
+#pragma unroll
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)      // (the strides of this path are powers of two)
+            b[k] = (in_range && k < t.n_strides && (r & (t.stride[k] - 1)) == 0) ? t.seg_off[k][n] + t.row_counts[k][row] : -1;
+        bool todo = in_range;
+        if (todo && t.stride[0] == 1) {      // lattice 0 holds every mask pixel: its row count says whether the row is empty
+            const SP_GLOBAL int32_t* rc = t.row_counts[0];
+            const int next = (r + 1 < H) ? rc[row + 1] : t.counts[0][n];
+            todo = next != rc[row];
+        }
+        const unsigned long long bal = __ballot(todo);
+        s_n = __popcll(bal);
+        if (todo) {
+            const int slot = __popcll(bal & below);
+            s_rows[wave][slot] = row;
+            s_r[wave][slot] = r;
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_base[wave][k][slot] = b[k];
+        }
+    }
+    if (s_n == 0) return;
+    // (record fields in registers before the first store: the compiler cannot know that the stores leave the record alone)
+    SP_GLOBAL uint32_t* pix_k[SP_PREP_MAX_STRIDES];
+    SP_GLOBAL float* baseL_k[SP_PREP_MAX_STRIDES];
+    uint32_t lmask[SP_PREP_MAX_STRIDES];            // pixels of an octet on lattice k, bit i = pixel i (strides 8, 16: pixel 0, and only
+    bool even_only[SP_PREP_MAX_STRIDES];            //  of even octets for 16)
+    int step_k[SP_PREP_MAX_STRIDES];
+    const int n_strides = t.n_strides;
+#pragma unroll
+    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+        pix_k[k] = t.pix[k]; baseL_k[k] = t.baseL[k];
+        const int st = t.stride[k];
+        lmask[k] = k < n_strides ? (st == 1 ? 0xffu : (st == 2 ? 0x55u : (st == 4 ? 0x11u : 0x01u))) : 0u;
+        even_only[k] = st == 16;
+        step_k[k] = st >= 8 ? 8 : st;
+    }
+    const SP_GLOBAL uint32_t* const bits_p = t.bits;
+    const SP_GLOBAL float* const logdepth_p = t.logdepth;
+    const int W = t.W, qpr = W >> 4;
+
+    struct Octet {               // one listed octet of a chunk, its log-depths requested
+        int sl, oct;
+        bool valid, first;
+        uint32_t m8;
+        float4 La, Lb;
+    };
+    int n_w = 0;
+    auto fetch = [&](int s0, int g0, Octet& o) {
+        const int g = g0 + lane;
+        o.valid = g < n_w;
+        const int c = o.valid ? s_list[wave][g] : 0;
+        o.sl = c >> 7; o.oct = c & 127;
+        o.first = o.valid && (g == 0 || (s_list[wave][g - 1] >> 7) != o.sl);            // first octet of its row
+        const uint32_t e = o.valid ? ((s_bits[wave][o.sl][o.oct >> 1] >> (2 * (o.oct & 1))) & 0x03030303u) : 0u;
+        // pixel i of the octet sits at bit 8 i of e (i < 4) or 8 (i - 4) + 1: bring it to bit i
+        o.m8 = (((e & 0x01010101u) * 0x10204080u) >> 28) | ((((e >> 1) & 0x01010101u) * 0x10204080u) >> 24 & 0xf0u);
+        const SP_GLOBAL float* Lp = logdepth_p + ((uint32_t)s_rows[wave][s0 + o.sl] * (uint32_t)W + (uint32_t)(8 * o.oct));
+        o.La = load4((const SP_GLOBAL f32x4*)Lp);        // (both halves, whatever the bits say, and for the lanes past the list the first
+        o.Lb = load4((const SP_GLOBAL f32x4*)(Lp + 4));  //  octet of the batch's first row: no control flow around the loads)
+    };
+    const int rb = min(RB, LIST / (2 * qpr));
+    for (int s0 = 0; s0 < s_n; s0 += rb) {
+        const int n_rows = min(rb, s_n - s0);
+        // (a) the bit words of the batch's rows
+        uint32_t bw[RB];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) bw[i] = (i < n_rows && lane < qpr) ? bits_p[(uint32_t)s_rows[wave][s0 + i] * (uint32_t)qpr + (uint32_t)lane] : 0u;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) s_bits[wave][i][lane] = bw[i];
+        // (b) the ordered list of its non-empty octets: row by row from the registers, a lane per bit word = two octets
+        n_w = 0;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            if (i >= n_rows) break;
+            const bool lo = (bw[i] & 0x03030303u) != 0u, hi = (bw[i] & 0x0c0c0c0cu) != 0u;
+            const unsigned long long bal_lo = __ballot(lo), bal_hi = __ballot(hi);
+            const int at = n_w + __popcll(bal_lo & below) + __popcll(bal_hi & below);
+            if (lo) s_list[wave][at] = (uint16_t)((i << 7) | (2 * lane));
+            if (hi) s_list[wave][at + (lo ? 1 : 0)] = (uint16_t)((i << 7) | (2 * lane + 1));
+            n_w += __popcll(bal_lo) + __popcll(bal_hi);
+        }
+        // (c) 64 listed octets at a time
+        int run[SP_PREP_MAX_STRIDES] = {0, 0, 0, 0};        // points of the batch before this chunk, per lattice
+        Octet cur, nxt;
+        fetch(s0, 0, cur);
+        for (int g0 = 0; g0 < n_w; g0 += 64) {
+            if (g0 + 64 < n_w) fetch(s0, g0 + 64, nxt);
+            const int slot = s0 + cur.sl;
+            const int r = s_r[wave][slot];
+            int bk[SP_PREP_MAX_STRIDES];
+            uint32_t sel[SP_PREP_MAX_STRIDES];
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+                bk[k] = cur.valid ? s_base[wave][k][slot] : -1;
+                sel[k] = (bk[k] >= 0 && !(even_only[k] && (cur.oct & 1))) ? (cur.m8 & lmask[k]) : 0u;
+            }
+            // wave-wide prefix sums of the four counts (two words of 16-bit fields: a chunk holds at most 512 points)
+            const uint32_t p0 = (uint32_t)__popc(sel[0]) | ((uint32_t)__popc(sel[1]) << 16), p1 = (uint32_t)__popc(sel[2]) | ((uint32_t)__popc(sel[3]) << 16);
+            const uint32_t i0 = wave_inclusive_scan(p0), i1 = wave_inclusive_scan(p1);
+            const uint32_t e0 = i0 - p0, e1 = i1 - p1;
+            const int G[SP_PREP_MAX_STRIDES] = {run[0] + (int)(e0 & 0xffffu), run[1] + (int)(e0 >> 16), run[2] + (int)(e1 & 0xffffu), run[3] + (int)(e1 >> 16)};
+            if (cur.first) {
+#pragma unroll
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_delta[wave][k][cur.sl] = bk[k] - G[k];
+            }
+            const float Lq[8] = {cur.La.x, cur.La.y, cur.La.z, cur.La.w, cur.Lb.x, cur.Lb.y, cur.Lb.z, cur.Lb.w};
+            const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
+            const int T[SP_PREP_MAX_STRIDES] = {(int)(t0 & 0xffffu), (int)(t0 >> 16), (int)(t1 & 0xffffu), (int)(t1 >> 16)};
+            const int E[SP_PREP_MAX_STRIDES] = {(int)(e0 & 0xffffu), (int)(e0 >> 16), (int)(e1 & 0xffffu), (int)(e1 >> 16)};
+            // The points of the chunk go to the tables THROUGH LDS, in list order: a lane's points sit 4 to 32 bytes from its neighbour's
+            // in the table, so storing them lane by lane (one store per pixel of the octet) made 16 partial write requests of every
+            // store instruction -- 58 M requests to the L2 for 128 keyframes, half its request rate, with the waves stalled on the
+            // issue of the next store; staged, consecutive lanes store consecutive points (two full lines per instruction).  The
+            // staged word carries the row of the batch in the free bits 10..15 (rows of at most 1024 pixels on this path).
+            const uint32_t pw0 = ((uint32_t)r << 16) | ((uint32_t)cur.sl << 10) | (uint32_t)(8 * cur.oct);
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
+                if (k >= n_strides) break;
+                if (T[k] == 0) continue;
+                // (no control flow around the staging stores: an unset pixel goes to the lane's own spare slot; only the pixels the
+                //  lattice can hold are looked at)
+                if (step_k[k] == 1) stage_octet<1>(&s_stage[wave][0], sel[k], E[k], pw0, Lq, lane);
+                else if (step_k[k] == 2) stage_octet<2>(&s_stage[wave][0], sel[k], E[k], pw0, Lq, lane);
+                else if (step_k[k] == 4) stage_octet<4>(&s_stage[wave][0], sel[k], E[k], pw0, Lq, lane);
+                else stage_octet<8>(&s_stage[wave][0], sel[k], E[k], pw0, Lq, lane);
+                for (int j = lane; j < T[k]; j += 64) {
+                    const uint2 v = s_stage[wave][j];
+                    const int dest = s_delta[wave][k][(v.x >> 10) & 0x3fu] + run[k] + j;
+                    pix_k[k][(uint32_t)dest] = v.x & 0xffff03ffu;
+                    baseL_k[k][(uint32_t)dest] = __uint_as_float(v.y);
+                }
+            }
+            run[0] += (int)(t0 & 0xffffu); run[1] += (int)(t0 >> 16); run[2] += (int)(t1 & 0xffffu); run[3] += (int)(t1 >> 16);
+            cur = nxt;
+        }
+    }
+}
+
 // Ordered compaction of (segment,row) rows into every lattice's table.  A workgroup takes SP_FILL_ROWS consecutive rows; one thread
 // per row decides from the row counts alone whether its row is empty (a segment covers a small part of the image: ~85 % of its
 // mask rows are empty and are not read again) and, if not, fetches where the row's points start in every lattice's table: those
@@ -499,19 +706,19 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* _
 // consecutive pixels; its rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken from
 // three ballots of the count's bits.  (Gathering a row's points in LDS and storing them by consecutive lanes -- full
 // lines per store instead of 4-byte stores 4 to 16 bytes apart -- was slower: 1.86 ms against 1.36 ms for 384 keyframes.)
-#define SP_FILL_ROWS 256
-#define SP_FILL_BATCH 32            /* rows of a workgroup's non-empty rows per batch of the bits path (k_prep_fill) */
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __restrict__ tables) {
     const PrepTable& t = table_of(tables, blockIdx.y);
+    if (prep_fill_bits_path(t)) return;       // (k_prep_fill_bits takes those keyframes)
     const int rows = t.N * t.H;
-    const int row_base = blockIdx.x * SP_FILL_ROWS;
-    if (row_base >= rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __shared__ int s_rows[SP_FILL_ROWS];                             // row id << 16 | row of the image
     __shared__ int s_r[SP_FILL_ROWS];
     __shared__ int s_base[SP_PREP_MAX_STRIDES][SP_FILL_ROWS];       // first table position of the row per lattice, -1: not on the lattice
     __shared__ int s_cnt[SP_WAVES];
     const unsigned long long below = (1ull << lane) - 1ull;
+    // (a bounded grid per keyframe whose workgroups walk the rows: the launch costs nothing when every keyframe is on the bits path)
+    for (int row_base = blockIdx.x * SP_FILL_ROWS; row_base < rows; row_base += gridDim.x * SP_FILL_ROWS) {
+    __syncthreads();                                                 // (the previous round is done with the lists)
     {   // one thread per row: is it empty?  then a block-wide ordered compaction of the non-empty ones.  The row's start in every
         // lattice's table is requested together with the counts that say whether it is empty (not after: one round trip to
         // memory per workgroup less, for 24 bytes per row more)
@@ -543,9 +750,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
         __syncthreads();
     }
     const int s_n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    if (s_n == 0) return;
+    if (s_n == 0) continue;
     const bool words = (t.W & 3) == 0 && ((uintptr_t)t.masks & 3) == 0;
-    const bool use_bits = t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0;       // (the count pass wrote them)
     // The fields of the record the row loop uses, read ONCE into registers: the compiler cannot know that the stores through
     // pix / baseL leave the record alone and read a field again after every one of them -- 200 scalar loads in the kernel, each
     // a wait inside the row loop, which is where the waves were parked.
@@ -554,7 +760,6 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
     int stride_k[SP_PREP_MAX_STRIDES];
 #pragma unroll
     for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) { pix_k[k] = t.pix[k]; baseL_k[k] = t.baseL[k]; stride_k[k] = t.stride[k]; }
-    const SP_GLOBAL uint32_t* const bits_p = t.bits;
     const SP_GLOBAL float* const logdepth_p = t.logdepth;
     const SP_GLOBAL uint8_t* const masks_p = t.masks;
     const int W = t.W;
@@ -592,129 +797,6 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
             }
         }
     };
-    if (use_bits) {
-        // Bits path, by OCTETS (8 pixels = half a bit word) instead of by rows.  A row at a time -- a lane per 4 pixels, ballots
-        // for the ranks -- is ~330 instructions per row of which a segment fills a fifth of the lanes, and the pass was bound by
-        // instruction issue (SIMDs ~80 % busy issuing at 0.19 of the HBM roofline; deeper prefetch and rows in batches changed
-        // nothing or lost).  Here a batch of SP_FILL_BATCH rows goes through three block-wide stages: (a) its bit words into LDS
-        // (all loads in flight together), (b) the ordered list of its NON-EMPTY octets, (c) 256 listed octets at a time, one per
-        // thread: the log-depths of the octet (two 16-byte loads), its point counts per lattice, a block-wide exclusive scan
-        // of those = the rank of its first point in table order, minus the scan value at the row's first octet = the rank inside
-        // the row, plus the row's start = where its points go.
-        const int qpr = W >> 4;
-        const int n_strides = t.n_strides;
-        uint32_t lmask[SP_PREP_MAX_STRIDES];            // pixels of an octet on lattice k, bit i = pixel i (strides 8, 16: pixel 0, and only
-#pragma unroll                                         //  of even octets for 16)
-        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-            const int st = stride_k[k];
-            lmask[k] = k < n_strides ? (st == 1 ? 0xffu : (st == 2 ? 0x55u : (st == 4 ? 0x11u : 0x01u))) : 0u;
-        }
-        __shared__ uint32_t s_bits[SP_FILL_BATCH][64];
-        __shared__ uint16_t s_list[SP_WAVES][SP_FILL_BATCH * 128 / SP_WAVES];      // octet = row of the batch << 7 | octet of the row
-        __shared__ int s_nlist[SP_WAVES];
-        __shared__ uint32_t s_wsum[2][SP_WAVES];
-        __shared__ int s_delta[SP_PREP_MAX_STRIDES][SP_FILL_BATCH];
-        constexpr int ROWS_PER_WAVE = SP_FILL_BATCH / SP_WAVES;
-        // (a) + (b): every wave for its own ROWS_PER_WAVE rows of the batch; the words of the NEXT batch are requested as soon as
-        // this one's are in LDS
-        uint32_t bw[ROWS_PER_WAVE];
-        auto request_bits = [&](int s0) {
-#pragma unroll
-            for (int i = 0; i < ROWS_PER_WAVE; ++i) {
-                const int sl = s0 + wave * ROWS_PER_WAVE + i;
-                bw[i] = (sl < min(s0 + SP_FILL_BATCH, s_n) && lane < qpr) ? bits_p[(size_t)s_rows[sl] * qpr + lane] : 0u;
-            }
-        };
-        request_bits(0);
-        for (int s0 = 0; s0 < s_n; s0 += SP_FILL_BATCH) {
-            __syncthreads();                         // (the previous batch is done with s_bits / s_list)
-#pragma unroll
-            for (int i = 0; i < ROWS_PER_WAVE; ++i) s_bits[wave * ROWS_PER_WAVE + i][lane] = bw[i];
-            __syncthreads();
-            if (s0 + SP_FILL_BATCH < s_n) request_bits(s0 + SP_FILL_BATCH);
-            int n_w = 0;
-#pragma unroll 4
-            for (int it = 0; it < ROWS_PER_WAVE * 2; ++it) {
-                const int c = (wave * ROWS_PER_WAVE * 2 + it) * 64 + lane;
-                const uint32_t m = s_bits[c >> 7][(c & 127) >> 1];
-                const bool on = ((m >> (2 * (c & 1))) & 0x03030303u) != 0u;
-                const unsigned long long bal = __ballot(on);
-                if (on) s_list[wave][n_w + __popcll(bal & below)] = (uint16_t)c;
-                n_w += __popcll(bal);
-            }
-            if (lane == 0) s_nlist[wave] = n_w;
-            __syncthreads();
-            const int n0 = s_nlist[0], n1 = n0 + s_nlist[1], n2 = n1 + s_nlist[2], n_total = n2 + s_nlist[3];
-            auto listed = [&](int g) -> int {     // g-th non-empty octet of the batch
-                const int w = (g >= n0) + (g >= n1) + (g >= n2);
-                return s_list[w][g - (w == 0 ? 0 : (w == 1 ? n0 : (w == 2 ? n1 : n2)))];
-            };
-            int run[SP_PREP_MAX_STRIDES] = {0, 0, 0, 0};        // points of the batch before this chunk, per lattice
-            for (int g0 = 0; g0 < n_total; g0 += SP_BLOCK) {
-                const int g = g0 + (int)threadIdx.x;
-                const bool valid = g < n_total;
-                const int c = valid ? listed(g) : 0;
-                const int sl = c >> 7, oct = c & 127;
-                const bool first = valid && (g == 0 || (listed(g - 1) >> 7) != sl);            // first octet of its row
-                const int slot = s0 + sl;
-                const uint32_t e = valid ? ((s_bits[sl][oct >> 1] >> (2 * (oct & 1))) & 0x03030303u) : 0u;
-                // pixel i of the octet sits at bit 8 i of e (i < 4) or 8 (i - 4) + 1: bring it to bit i
-                const uint32_t m8 = (((e & 0x01010101u) * 0x10204080u) >> 28) | ((((e >> 1) & 0x01010101u) * 0x10204080u) >> 24 & 0xf0u);
-                const int row = s_rows[slot], r = s_r[slot];
-                const SP_GLOBAL float* Lp = logdepth_p + (size_t)row * W + 8 * oct;
-                const float4 La = (m8 & 0x0fu) ? load4((const SP_GLOBAL f32x4*)Lp) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 Lb = (m8 & 0xf0u) ? load4((const SP_GLOBAL f32x4*)(Lp + 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
-                int bk[SP_PREP_MAX_STRIDES];
-                uint32_t sel[SP_PREP_MAX_STRIDES];
-#pragma unroll
-                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-                    bk[k] = valid ? s_base[k][slot] : -1;
-                    sel[k] = (bk[k] >= 0 && !(stride_k[k] == 16 && (oct & 1))) ? (m8 & lmask[k]) : 0u;
-                }
-                // block-wide exclusive scan of the four counts (two words of 16-bit fields: a chunk holds at most 2048 points)
-                const uint32_t p0 = (uint32_t)__popc(sel[0]) | ((uint32_t)__popc(sel[1]) << 16), p1 = (uint32_t)__popc(sel[2]) | ((uint32_t)__popc(sel[3]) << 16);
-                uint32_t i0 = p0, i1 = p1;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t u0 = __shfl_up(i0, d, 64), u1 = __shfl_up(i1, d, 64);
-                    if (lane >= d) { i0 += u0; i1 += u1; }
-                }
-                if (lane == 63) { s_wsum[0][wave] = i0; s_wsum[1][wave] = i1; }
-                __syncthreads();
-                uint32_t o0 = 0u, o1 = 0u, t0 = 0u, t1 = 0u;
-#pragma unroll
-                for (int w = 0; w < SP_WAVES; ++w) {
-                    const uint32_t a0 = s_wsum[0][w], a1 = s_wsum[1][w];
-                    if (w < wave) { o0 += a0; o1 += a1; }
-                    t0 += a0; t1 += a1;
-                }
-                const uint32_t e0 = i0 - p0 + o0, e1 = i1 - p1 + o1;
-                const int G[SP_PREP_MAX_STRIDES] = {run[0] + (int)(e0 & 0xffffu), run[1] + (int)(e0 >> 16), run[2] + (int)(e1 & 0xffffu), run[3] + (int)(e1 >> 16)};
-                if (first) {
-#pragma unroll
-                    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_delta[k][sl] = bk[k] - G[k];
-                }
-                __syncthreads();
-                const float Lq[8] = {La.x, La.y, La.z, La.w, Lb.x, Lb.y, Lb.z, Lb.w};
-                const uint32_t pw0 = ((uint32_t)r << 16) | (uint32_t)(8 * oct);
-#pragma unroll
-                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-                    if (k >= n_strides) break;
-                    if (__ballot(sel[k] != 0u) == 0ull) continue;
-                    int pos = sel[k] ? s_delta[k][sl] + G[k] : 0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if ((sel[k] >> i) & 1u) {
-                            pix_k[k][pos] = pw0 + (uint32_t)i;
-                            baseL_k[k][pos] = Lq[i];
-                            ++pos;
-                        }
-                }
-                run[0] += (int)(t0 & 0xffffu); run[1] += (int)(t0 >> 16); run[2] += (int)(t1 & 0xffffu); run[3] += (int)(t1 >> 16);
-            }
-        }
-        return;
-    }
     for (int i = wave; i < s_n; i += SP_WAVES) {
         const int row_id = s_rows[i];
         if (!words) {
@@ -742,6 +824,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
             }
             emit_groups(w0, nz, Lv);
         }
+    }
     }
 }
 
@@ -954,7 +1037,9 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
 int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_prep_fill, dim3((max_rows + SP_FILL_ROWS - 1) / SP_FILL_ROWS, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    hipLaunchKernelGGL(k_prep_fill_bits, dim3((max_rows + SP_FILL_ROWS - 1) / SP_FILL_ROWS, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    SP_CHECK_LAUNCH();
+    hipLaunchKernelGGL(k_prep_fill, dim3(std::min((max_rows + SP_FILL_ROWS - 1) / SP_FILL_ROWS, SP_PREP_GENERAL_BLOCKS), n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     hipLaunchKernelGGL(k_prep_keypoint_L, dim3((max_N + 63) / 64, n_tables), dim3(64), 0, s, tables);
     SP_CHECK_LAUNCH();
