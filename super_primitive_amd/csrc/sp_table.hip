@@ -495,7 +495,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* _
 
 // does the fill pass of this keyframe read the bit words the count pass wrote (k_prep_fill_bits) instead of the masks (k_prep_fill)?
 __device__ __forceinline__ bool prep_fill_bits_path(const PrepTable& t) {
-    return t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0 && (long long)t.N * t.H < (1ll << 22);
+    return t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0 && (long long)t.N * t.H < (1ll << 22) && t.H <= 1024;
 }
 
 // inclusive prefix sum over the 64 lanes of a wave in six DPP additions (row shifts by 1 / 2 / 4 / 8 inside the rows of 16 lanes, then
@@ -541,17 +541,21 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
     if (row_base >= rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RB = SP_FILL_WAVE_ROWS;
-    __shared__ int s_rows[SP_WAVES][64];                              // the wave's non-empty rows
-    __shared__ int s_r[SP_WAVES][64];                                 // ... their row of the image
-    __shared__ int s_base[SP_WAVES][SP_PREP_MAX_STRIDES][64];         // first table position of the row per lattice, -1: not on the lattice
+    constexpr int LIST = 640;                                         // (RB rows of 640 pixels; fewer rows per batch when they are longer)
     __shared__ uint32_t s_bits[SP_WAVES][RB][64];
-    constexpr int LIST = 640;                                         // (RB rows of 640 pixels; fewer rows per batch when they are longer: the
-    __shared__ uint16_t s_list[SP_WAVES][LIST];                       //  workgroup's LDS stays under a quarter of the CU's) octet = row of the batch << 7 | octet of the row
+    __shared__ uint16_t s_list[SP_WAVES][LIST];                       // octet = row of the batch << 13 | lane that holds the row << 7 | octet of the row
     __shared__ int s_delta[SP_WAVES][SP_PREP_MAX_STRIDES][RB];
     __shared__ uint2 s_stage[SP_WAVES][512 + 64];                     // the points of a chunk of 64 octets in list order {pixel word, log-depth}; + a slot per lane for the unset pixels
+    static_assert(sizeof(uint32_t) * SP_WAVES * RB * 64 + sizeof(uint16_t) * SP_WAVES * LIST + sizeof(int) * SP_WAVES * SP_PREP_MAX_STRIDES * RB
+                  + sizeof(uint2) * SP_WAVES * (512 + 64) <= 32768, "five workgroups per CU");
     const unsigned long long below = (1ull << lane) - 1ull;
-    int s_n;
-    {   // one lane per row: is it empty?  The row's start in every lattice's table is requested together with the counts that say so
+    // One lane per row: is it empty?  The row's start in every lattice's table is requested together with the counts that say so.
+    // What the pass needs of a row -- its index, its row of the image, its starts -- STAYS in the registers of that lane and is
+    // fetched by lane index (readlane for the batch's loads, ds_bpermute per listed octet): no LDS arrays for it (6 KB a workgroup).
+    uint32_t my_row;                                 // row | row of the image << 22
+    int my_b[SP_PREP_MAX_STRIDES];                   // first table position of the row per lattice, -1: not on the lattice
+    unsigned long long rem;                          // lanes whose rows are still to do
+    {
         const int row = row_base + SP_WAVES * lane + wave;
         const bool in_range = row < rows;
         // segment and image row without an integer division per lane: rows < 2^22 are exact in fp32, the quotient is off by one at most
@@ -560,27 +564,19 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
         if (r < 0) { --n; r += H; }
         if (r >= H) { ++n; r -= H; }
         if (!in_range) n = 0;
-        int b[SP_PREP_MAX_STRIDES];
 #pragma unroll
         for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)      // (the strides of this path are powers of two)
-            b[k] = (in_range && k < t.n_strides && (r & (t.stride[k] - 1)) == 0) ? t.seg_off[k][n] + t.row_counts[k][row] : -1;
+            my_b[k] = (in_range && k < t.n_strides && (r & (t.stride[k] - 1)) == 0) ? t.seg_off[k][n] + t.row_counts[k][row] : -1;
         bool todo = in_range;
         if (todo && t.stride[0] == 1) {      // lattice 0 holds every mask pixel: its row count says whether the row is empty
             const SP_GLOBAL int32_t* rc = t.row_counts[0];
             const int next = (r + 1 < H) ? rc[row + 1] : t.counts[0][n];
             todo = next != rc[row];
         }
-        const unsigned long long bal = __ballot(todo);
-        s_n = __popcll(bal);
-        if (todo) {
-            const int slot = __popcll(bal & below);
-            s_rows[wave][slot] = row;
-            s_r[wave][slot] = r;
-#pragma unroll
-            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_base[wave][k][slot] = b[k];
-        }
+        my_row = in_range ? ((uint32_t)row | ((uint32_t)r << 22)) : 0u;
+        rem = __ballot(todo);
     }
-    if (s_n == 0) return;
+    if (rem == 0ull) return;
     // (record fields in registers before the first store: the compiler cannot know that the stores leave the record alone)
     SP_GLOBAL uint32_t* pix_k[SP_PREP_MAX_STRIDES];
     SP_GLOBAL float* baseL_k[SP_PREP_MAX_STRIDES];
@@ -599,82 +595,101 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
     const SP_GLOBAL uint32_t* const bits_p = t.bits;
     const SP_GLOBAL float* const logdepth_p = t.logdepth;
     const int W = t.W, qpr = W >> 4;
+    const int rb = min(RB, LIST / (2 * qpr));
 
+    struct Batch {               // up to RB rows: the lanes that hold them and their bit words (a lane per word)
+        int n_rows;
+        int src[RB];
+        uint32_t bw[RB];
+    };
+    auto request = [&](Batch& b) {      // the next rb rows still to do: their bit words requested
+        b.n_rows = 0;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            b.src[i] = 0; b.bw[i] = 0u;
+            if (i < rb && rem != 0ull) {
+                b.src[i] = __builtin_ctzll(rem);
+                rem &= rem - 1ull;
+                b.n_rows = i + 1;
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, b.src[i]) & 0x3fffffu;
+                if (lane < qpr) b.bw[i] = bits_p[row * (uint32_t)qpr + (uint32_t)lane];
+            }
+        }
+    };
     struct Octet {               // one listed octet of a chunk, its log-depths requested
-        int sl, oct;
+        int i, src, oct, r;
         bool valid, first;
         uint32_t m8;
         float4 La, Lb;
     };
     int n_w = 0;
-    auto fetch = [&](int s0, int g0, Octet& o) {
+    auto fetch = [&](int g0, Octet& o) {
         const int g = g0 + lane;
         o.valid = g < n_w;
-        const int c = o.valid ? s_list[wave][g] : 0;
-        o.sl = c >> 7; o.oct = c & 127;
-        o.first = o.valid && (g == 0 || (s_list[wave][g - 1] >> 7) != o.sl);            // first octet of its row
-        const uint32_t e = o.valid ? ((s_bits[wave][o.sl][o.oct >> 1] >> (2 * (o.oct & 1))) & 0x03030303u) : 0u;
+        const int c = o.valid ? s_list[wave][g] : s_list[wave][0];
+        o.oct = c & 127; o.src = (c >> 7) & 63; o.i = c >> 13;
+        o.first = o.valid && (g == 0 || (s_list[wave][g - 1] >> 7) != (c >> 7));            // first octet of its row
+        const uint32_t e = o.valid ? ((s_bits[wave][o.i][o.oct >> 1] >> (2 * (o.oct & 1))) & 0x03030303u) : 0u;
         // pixel i of the octet sits at bit 8 i of e (i < 4) or 8 (i - 4) + 1: bring it to bit i
         o.m8 = (((e & 0x01010101u) * 0x10204080u) >> 28) | ((((e >> 1) & 0x01010101u) * 0x10204080u) >> 24 & 0xf0u);
-        const SP_GLOBAL float* Lp = logdepth_p + ((uint32_t)s_rows[wave][s0 + o.sl] * (uint32_t)W + (uint32_t)(8 * o.oct));
+        const uint32_t rr = (uint32_t)__shfl((int)my_row, o.src, 64);
+        o.r = (int)(rr >> 22);
+        const SP_GLOBAL float* Lp = logdepth_p + ((rr & 0x3fffffu) * (uint32_t)W + (uint32_t)(8 * o.oct));
         o.La = load4((const SP_GLOBAL f32x4*)Lp);        // (both halves, whatever the bits say, and for the lanes past the list the first
-        o.Lb = load4((const SP_GLOBAL f32x4*)(Lp + 4));  //  octet of the batch's first row: no control flow around the loads)
+        o.Lb = load4((const SP_GLOBAL f32x4*)(Lp + 4));  //  octet of the list: no control flow around the loads)
     };
-    const int rb = min(RB, LIST / (2 * qpr));
-    for (int s0 = 0; s0 < s_n; s0 += rb) {
-        const int n_rows = min(rb, s_n - s0);
-        // (a) the bit words of the batch's rows
-        uint32_t bw[RB];
+    Batch bt, bt_next;
+    request(bt);
+    while (bt.n_rows > 0) {
+        // (a) the bit words of the batch's rows into LDS; the next batch's are requested at once
 #pragma unroll
-        for (int i = 0; i < RB; ++i) bw[i] = (i < n_rows && lane < qpr) ? bits_p[(uint32_t)s_rows[wave][s0 + i] * (uint32_t)qpr + (uint32_t)lane] : 0u;
-#pragma unroll
-        for (int i = 0; i < RB; ++i) s_bits[wave][i][lane] = bw[i];
+        for (int i = 0; i < RB; ++i) s_bits[wave][i][lane] = bt.bw[i];
         // (b) the ordered list of its non-empty octets: row by row from the registers, a lane per bit word = two octets
         n_w = 0;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            if (i >= n_rows) break;
-            const bool lo = (bw[i] & 0x03030303u) != 0u, hi = (bw[i] & 0x0c0c0c0cu) != 0u;
+            if (i >= bt.n_rows) break;
+            const bool lo = (bt.bw[i] & 0x03030303u) != 0u, hi = (bt.bw[i] & 0x0c0c0c0cu) != 0u;
             const unsigned long long bal_lo = __ballot(lo), bal_hi = __ballot(hi);
             const int at = n_w + __popcll(bal_lo & below) + __popcll(bal_hi & below);
-            if (lo) s_list[wave][at] = (uint16_t)((i << 7) | (2 * lane));
-            if (hi) s_list[wave][at + (lo ? 1 : 0)] = (uint16_t)((i << 7) | (2 * lane + 1));
+            const int head = (i << 13) | (bt.src[i] << 7);
+            if (lo) s_list[wave][at] = (uint16_t)(head | (2 * lane));
+            if (hi) s_list[wave][at + (lo ? 1 : 0)] = (uint16_t)(head | (2 * lane + 1));
             n_w += __popcll(bal_lo) + __popcll(bal_hi);
         }
+        request(bt_next);
         // (c) 64 listed octets at a time
         int run[SP_PREP_MAX_STRIDES] = {0, 0, 0, 0};        // points of the batch before this chunk, per lattice
         Octet cur, nxt;
-        fetch(s0, 0, cur);
+        if (n_w > 0) fetch(0, cur);
         for (int g0 = 0; g0 < n_w; g0 += 64) {
-            if (g0 + 64 < n_w) fetch(s0, g0 + 64, nxt);
-            const int slot = s0 + cur.sl;
-            const int r = s_r[wave][slot];
+            if (g0 + 64 < n_w) fetch(g0 + 64, nxt);
             int bk[SP_PREP_MAX_STRIDES];
             uint32_t sel[SP_PREP_MAX_STRIDES];
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
-                bk[k] = cur.valid ? s_base[wave][k][slot] : -1;
-                sel[k] = (bk[k] >= 0 && !(even_only[k] && (cur.oct & 1))) ? (cur.m8 & lmask[k]) : 0u;
+                bk[k] = -1;
+                if (k < n_strides) bk[k] = __shfl(my_b[k], cur.src, 64);
+                sel[k] = (cur.valid && bk[k] >= 0 && !(even_only[k] && (cur.oct & 1))) ? (cur.m8 & lmask[k]) : 0u;
             }
             // wave-wide prefix sums of the four counts (two words of 16-bit fields: a chunk holds at most 512 points)
             const uint32_t p0 = (uint32_t)__popc(sel[0]) | ((uint32_t)__popc(sel[1]) << 16), p1 = (uint32_t)__popc(sel[2]) | ((uint32_t)__popc(sel[3]) << 16);
             const uint32_t i0 = wave_inclusive_scan(p0), i1 = wave_inclusive_scan(p1);
             const uint32_t e0 = i0 - p0, e1 = i1 - p1;
-            const int G[SP_PREP_MAX_STRIDES] = {run[0] + (int)(e0 & 0xffffu), run[1] + (int)(e0 >> 16), run[2] + (int)(e1 & 0xffffu), run[3] + (int)(e1 >> 16)};
+            const int E[SP_PREP_MAX_STRIDES] = {(int)(e0 & 0xffffu), (int)(e0 >> 16), (int)(e1 & 0xffffu), (int)(e1 >> 16)};
             if (cur.first) {
 #pragma unroll
-                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_delta[wave][k][cur.sl] = bk[k] - G[k];
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_delta[wave][k][cur.i] = bk[k] - (run[k] + E[k]);
             }
             const float Lq[8] = {cur.La.x, cur.La.y, cur.La.z, cur.La.w, cur.Lb.x, cur.Lb.y, cur.Lb.z, cur.Lb.w};
             const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
             const int T[SP_PREP_MAX_STRIDES] = {(int)(t0 & 0xffffu), (int)(t0 >> 16), (int)(t1 & 0xffffu), (int)(t1 >> 16)};
-            const int E[SP_PREP_MAX_STRIDES] = {(int)(e0 & 0xffffu), (int)(e0 >> 16), (int)(e1 & 0xffffu), (int)(e1 >> 16)};
             // The points of the chunk go to the tables THROUGH LDS, in list order: a lane's points sit 4 to 32 bytes from its neighbour's
             // in the table, so storing them lane by lane (one store per pixel of the octet) made 16 partial write requests of every
             // store instruction -- 58 M requests to the L2 for 128 keyframes, half its request rate, with the waves stalled on the
             // issue of the next store; staged, consecutive lanes store consecutive points (two full lines per instruction).  The
             // staged word carries the row of the batch in the free bits 10..15 (rows of at most 1024 pixels on this path).
-            const uint32_t pw0 = ((uint32_t)r << 16) | ((uint32_t)cur.sl << 10) | (uint32_t)(8 * cur.oct);
+            const uint32_t pw0 = ((uint32_t)cur.r << 16) | ((uint32_t)cur.i << 10) | (uint32_t)(8 * cur.oct);
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
                 if (k >= n_strides) break;
@@ -692,9 +707,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
                     baseL_k[k][(uint32_t)dest] = __uint_as_float(v.y);
                 }
             }
-            run[0] += (int)(t0 & 0xffffu); run[1] += (int)(t0 >> 16); run[2] += (int)(t1 & 0xffffu); run[3] += (int)(t1 >> 16);
+            run[0] += T[0]; run[1] += T[1]; run[2] += T[2]; run[3] += T[3];
             cur = nxt;
         }
+        bt = bt_next;
     }
 }
 
