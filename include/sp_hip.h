@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 9
+#define SP_ABI_VERSION 10
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -97,6 +97,10 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
  *   sp_prepare_fill  : pix / baseL at seg_off[n] + rank inside the segment; kp_L[N] where kp_L != NULL
  *   sp_prepare_blur  : one pyramid step (sp_blur_decimate) of every job image
  *   sp_prepare_pack  : planar (3,H,W) -> HWC3 of every job image
+ *   sp_prepare_gather: n small float vectors, one DEVICE pointer each (src[i], off[i + 1] - off[i] floats), into one flat array
+ *                      (out + off[i]); src and off are device arrays.  What the host side otherwise does with one torch.cat /
+ *                      torch.stack over hundreds of per-pair tensors (the intrinsics and initial log-depths of a batch: 0.7 us of
+ *                      interpreter time per tensor); no counterpart in the reference, which optimises one pair per call
  *   sp_prepare_sample: sp_table_sample_source of every job at all its levels, and the source-validity bit of pix.  Every
  *                      segment's run must start at a multiple of 256 (the padded layout of the many-pairs work list; of 64 when
  *                      SpPrepSample.granule is 64);
@@ -149,6 +153,7 @@ int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int m
 int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream);
 int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixels, void* stream);
 int sp_prepare_pack(const SpPrepImage* jobs, int n_jobs, int max_pixels, void* stream);
+int sp_prepare_gather(const float* const* src, const long long* off, int n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * The cost: one source keyframe against B target frames (B = 1: core/dense_optim.py:265-363

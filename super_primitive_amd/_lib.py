@@ -39,6 +39,7 @@ SIGNATURES = {
     "sp_prepare_sample": [P, I, I, P],
     "sp_prepare_blur": [P, I, I, I, P],
     "sp_prepare_pack": [P, I, I, P],
+    "sp_prepare_gather": [P, P, I, P, P],
     "sp_host_work_list_chunks": [P, I, I, I],
     "sp_host_work_list": [P, P, P, I, I, I, I, I, P, P, P, P, P, P],
     "sp_pairs_schedule_cost": [P, P, P],
@@ -71,7 +72,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 9
+SP_ABI_VERSION = 10
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GNA_PARTIAL_FLOATS = 48

@@ -532,7 +532,7 @@ __device__ __forceinline__ void stage_octet(uint2* stage, uint32_t sel, int q, u
 // 16-byte loads, requested one chunk ahead), its point counts per lattice, a wave-wide prefix sum of those (DPP) = the rank of its
 // first point in list order, minus the value at the row's first octet = the rank inside the row, plus the row's start = where its
 // points go, in torch.where order.  All LDS is private to the wave: no barrier anywhere.
-#define SP_FILL_WAVE_ROWS 8
+#define SP_FILL_WAVE_ROWS 16
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* __restrict__ tables) {
     const PrepTable& t = table_of(tables, blockIdx.y);
     if (!prep_fill_bits_path(t)) return;
@@ -541,13 +541,12 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
     if (row_base >= rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int RB = SP_FILL_WAVE_ROWS;
-    constexpr int LIST = 640;                                         // (RB rows of 640 pixels; fewer rows per batch when they are longer)
-    __shared__ uint32_t s_bits[SP_WAVES][RB][64];
-    __shared__ uint16_t s_list[SP_WAVES][LIST];                       // octet = row of the batch << 13 | lane that holds the row << 7 | octet of the row
-    __shared__ int s_delta[SP_WAVES][SP_PREP_MAX_STRIDES][RB];
+    constexpr int LIST = 1152;                                        // (14 rows of 640 pixels a batch; fewer when they are longer)
+    __shared__ uint16_t s_list[SP_WAVES][LIST];                       // octet = lane that holds the row << 7 | octet of the row
+    __shared__ int s_delta[SP_WAVES][SP_PREP_MAX_STRIDES][64];        // per row (by the lane that holds it): table position minus list rank
     __shared__ uint2 s_stage[SP_WAVES][512 + 64];                     // the points of a chunk of 64 octets in list order {pixel word, log-depth}; + a slot per lane for the unset pixels
-    static_assert(sizeof(uint32_t) * SP_WAVES * RB * 64 + sizeof(uint16_t) * SP_WAVES * LIST + sizeof(int) * SP_WAVES * SP_PREP_MAX_STRIDES * RB
-                  + sizeof(uint2) * SP_WAVES * (512 + 64) <= 32768, "five workgroups per CU");
+    static_assert(sizeof(uint16_t) * SP_WAVES * LIST + sizeof(int) * SP_WAVES * SP_PREP_MAX_STRIDES * 64 + sizeof(uint2) * SP_WAVES * (512 + 64) <= 32768,
+                  "five workgroups per CU");
     const unsigned long long below = (1ull << lane) - 1ull;
     // One lane per row: is it empty?  The row's start in every lattice's table is requested together with the counts that say so.
     // What the pass needs of a row -- its index, its row of the image, its starts -- STAYS in the registers of that lane and is
@@ -597,29 +596,30 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
     const int W = t.W, qpr = W >> 4;
     const int rb = min(RB, LIST / (2 * qpr));
 
-    struct Batch {               // up to RB rows: the lanes that hold them and their bit words (a lane per word)
+    struct Batch {               // up to RB rows: the lanes that hold them (the lowest set bits of `lanes`) and their bit words (a lane per word)
         int n_rows;
-        int src[RB];
+        unsigned long long lanes;
         uint32_t bw[RB];
     };
     auto request = [&](Batch& b) {      // the next rb rows still to do: their bit words requested
         b.n_rows = 0;
+        b.lanes = rem;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            b.src[i] = 0; b.bw[i] = 0u;
+            b.bw[i] = 0u;
             if (i < rb && rem != 0ull) {
-                b.src[i] = __builtin_ctzll(rem);
+                const int src = __builtin_ctzll(rem);
                 rem &= rem - 1ull;
                 b.n_rows = i + 1;
-                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, b.src[i]) & 0x3fffffu;
+                const uint32_t row = (uint32_t)__builtin_amdgcn_readlane((int)my_row, src) & 0x3fffffu;
                 if (lane < qpr) b.bw[i] = bits_p[row * (uint32_t)qpr + (uint32_t)lane];
             }
         }
     };
-    struct Octet {               // one listed octet of a chunk, its log-depths requested
-        int i, src, oct, r;
+    struct Octet {               // one listed octet of a chunk, its bit word and log-depths requested
+        int src, oct, r;
         bool valid, first;
-        uint32_t m8;
+        uint32_t word;
         float4 La, Lb;
     };
     int n_w = 0;
@@ -627,13 +627,12 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
         const int g = g0 + lane;
         o.valid = g < n_w;
         const int c = o.valid ? s_list[wave][g] : s_list[wave][0];
-        o.oct = c & 127; o.src = (c >> 7) & 63; o.i = c >> 13;
-        o.first = o.valid && (g == 0 || (s_list[wave][g - 1] >> 7) != (c >> 7));            // first octet of its row
-        const uint32_t e = o.valid ? ((s_bits[wave][o.i][o.oct >> 1] >> (2 * (o.oct & 1))) & 0x03030303u) : 0u;
-        // pixel i of the octet sits at bit 8 i of e (i < 4) or 8 (i - 4) + 1: bring it to bit i
-        o.m8 = (((e & 0x01010101u) * 0x10204080u) >> 28) | ((((e >> 1) & 0x01010101u) * 0x10204080u) >> 24 & 0xf0u);
+        o.oct = c & 127; o.src = c >> 7;
+        o.first = o.valid && (g == 0 || (s_list[wave][g - 1] >> 7) != o.src);            // first octet of its row
         const uint32_t rr = (uint32_t)__shfl((int)my_row, o.src, 64);
         o.r = (int)(rr >> 22);
+        // (the bit word again, from the L2 this time -- the wave just read it -- next to the log-depths: no LDS copy of the batch's words)
+        o.word = bits_p[(rr & 0x3fffffu) * (uint32_t)qpr + (uint32_t)(o.oct >> 1)];
         const SP_GLOBAL float* Lp = logdepth_p + ((rr & 0x3fffffu) * (uint32_t)W + (uint32_t)(8 * o.oct));
         o.La = load4((const SP_GLOBAL f32x4*)Lp);        // (both halves, whatever the bits say, and for the lanes past the list the first
         o.Lb = load4((const SP_GLOBAL f32x4*)(Lp + 4));  //  octet of the list: no control flow around the loads)
@@ -641,24 +640,25 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
     Batch bt, bt_next;
     request(bt);
     while (bt.n_rows > 0) {
-        // (a) the bit words of the batch's rows into LDS; the next batch's are requested at once
-#pragma unroll
-        for (int i = 0; i < RB; ++i) s_bits[wave][i][lane] = bt.bw[i];
-        // (b) the ordered list of its non-empty octets: row by row from the registers, a lane per bit word = two octets
+        // (a) the ordered list of its non-empty octets: row by row from the registers, a lane per bit word = two octets
         n_w = 0;
+        unsigned long long walk = bt.lanes;
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
-            if (i >= bt.n_rows) break;
-            const bool lo = (bt.bw[i] & 0x03030303u) != 0u, hi = (bt.bw[i] & 0x0c0c0c0cu) != 0u;
-            const unsigned long long bal_lo = __ballot(lo), bal_hi = __ballot(hi);
-            const int at = n_w + __popcll(bal_lo & below) + __popcll(bal_hi & below);
-            const int head = (i << 13) | (bt.src[i] << 7);
-            if (lo) s_list[wave][at] = (uint16_t)(head | (2 * lane));
-            if (hi) s_list[wave][at + (lo ? 1 : 0)] = (uint16_t)(head | (2 * lane + 1));
-            n_w += __popcll(bal_lo) + __popcll(bal_hi);
+            if (i < bt.n_rows) {
+                const int src = __builtin_ctzll(walk);
+                walk &= walk - 1ull;
+                const bool lo = (bt.bw[i] & 0x03030303u) != 0u, hi = (bt.bw[i] & 0x0c0c0c0cu) != 0u;
+                const unsigned long long bal_lo = __ballot(lo), bal_hi = __ballot(hi);
+                const int at = n_w + __popcll(bal_lo & below) + __popcll(bal_hi & below);
+                const int head = src << 7;
+                if (lo) s_list[wave][at] = (uint16_t)(head | (2 * lane));
+                if (hi) s_list[wave][at + (lo ? 1 : 0)] = (uint16_t)(head | (2 * lane + 1));
+                n_w += __popcll(bal_lo) + __popcll(bal_hi);
+            }
         }
-        request(bt_next);
-        // (c) 64 listed octets at a time
+        request(bt_next);                                   // (the next batch's bit words are on their way during this one's chunks)
+        // (b) 64 listed octets at a time
         int run[SP_PREP_MAX_STRIDES] = {0, 0, 0, 0};        // points of the batch before this chunk, per lattice
         Octet cur, nxt;
         if (n_w > 0) fetch(0, cur);
@@ -666,11 +666,14 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
             if (g0 + 64 < n_w) fetch(g0 + 64, nxt);
             int bk[SP_PREP_MAX_STRIDES];
             uint32_t sel[SP_PREP_MAX_STRIDES];
+            // pixel i of the octet sits at bit 8 i of e (i < 4) or 8 (i - 4) + 1: bring it to bit i
+            const uint32_t e = (cur.word >> (2 * (cur.oct & 1))) & 0x03030303u;
+            const uint32_t m8 = (((e & 0x01010101u) * 0x10204080u) >> 28) | ((((e >> 1) & 0x01010101u) * 0x10204080u) >> 24 & 0xf0u);
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
                 bk[k] = -1;
                 if (k < n_strides) bk[k] = __shfl(my_b[k], cur.src, 64);
-                sel[k] = (cur.valid && bk[k] >= 0 && !(even_only[k] && (cur.oct & 1))) ? (cur.m8 & lmask[k]) : 0u;
+                sel[k] = (cur.valid && bk[k] >= 0 && !(even_only[k] && (cur.oct & 1))) ? (m8 & lmask[k]) : 0u;
             }
             // wave-wide prefix sums of the four counts (two words of 16-bit fields: a chunk holds at most 512 points)
             const uint32_t p0 = (uint32_t)__popc(sel[0]) | ((uint32_t)__popc(sel[1]) << 16), p1 = (uint32_t)__popc(sel[2]) | ((uint32_t)__popc(sel[3]) << 16);
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
             const int E[SP_PREP_MAX_STRIDES] = {(int)(e0 & 0xffffu), (int)(e0 >> 16), (int)(e1 & 0xffffu), (int)(e1 >> 16)};
             if (cur.first) {
 #pragma unroll
-                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_delta[wave][k][cur.i] = bk[k] - (run[k] + E[k]);
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) s_delta[wave][k][cur.src] = bk[k] - (run[k] + E[k]);
             }
             const float Lq[8] = {cur.La.x, cur.La.y, cur.La.z, cur.La.w, cur.Lb.x, cur.Lb.y, cur.Lb.z, cur.Lb.w};
             const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63), t1 = (uint32_t)__builtin_amdgcn_readlane((int)i1, 63);
@@ -688,8 +691,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
             // in the table, so storing them lane by lane (one store per pixel of the octet) made 16 partial write requests of every
             // store instruction -- 58 M requests to the L2 for 128 keyframes, half its request rate, with the waves stalled on the
             // issue of the next store; staged, consecutive lanes store consecutive points (two full lines per instruction).  The
-            // staged word carries the row of the batch in the free bits 10..15 (rows of at most 1024 pixels on this path).
-            const uint32_t pw0 = ((uint32_t)cur.r << 16) | ((uint32_t)cur.i << 10) | (uint32_t)(8 * cur.oct);
+            // staged word carries the lane that holds the row in the free bits 10..15 (rows of at most 1024 pixels on this path).
+            const uint32_t pw0 = ((uint32_t)cur.r << 16) | ((uint32_t)cur.src << 10) | (uint32_t)(8 * cur.oct);
 #pragma unroll
             for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) {
                 if (k >= n_strides) break;
@@ -961,6 +964,13 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_blur(const SpPrepImage* __res
     for (int o = i; o < Ho * Wo; o += n_threads) out[o] = blur_decimate_at(generic(in), j.H, j.W, Wo, o);
 }
 
+// many small float vectors (one pointer each) -> one flat array: out[off[i] .. off[i + 1]) = src[i][0 .. off[i + 1] - off[i])
+__global__ __launch_bounds__(64) void k_prep_gather(const float* const* __restrict__ src, const long long* __restrict__ off, float* __restrict__ out) {
+    const float* p = src[blockIdx.x];
+    const long long o0 = off[blockIdx.x], n = off[blockIdx.x + 1] - o0;
+    for (long long i = threadIdx.x; i < n; i += 64) out[o0 + i] = p[i];
+}
+
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_pack(const SpPrepImage* __restrict__ jobs) {
     const PrepImage& j = reinterpret_cast<const PrepImage*>(jobs)[blockIdx.y];
     const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
@@ -1083,6 +1093,13 @@ int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixe
 int sp_prepare_pack(const SpPrepImage* jobs, int n_jobs, int max_pixels, void* stream) {
     if (!jobs || check_grid(max_pixels, n_jobs)) return SP_EINVAL;
     hipLaunchKernelGGL(k_prep_pack, dim3((max_pixels + SP_BLOCK - 1) / SP_BLOCK, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_prepare_gather(const float* const* src, const long long* off, int n, float* out, void* stream) {
+    if (!src || !off || !out || n <= 0) return SP_EINVAL;
+    hipLaunchKernelGGL(k_prep_gather, dim3(n), dim3(64), 0, static_cast<hipStream_t>(stream), src, off, out);
     SP_CHECK_LAUNCH();
     return 0;
 }

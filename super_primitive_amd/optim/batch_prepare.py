@@ -13,7 +13,7 @@ order as the per-keyframe kernels (shared device functions, sp_table.hip)."""
 from __future__ import annotations
 
 import ctypes
-
+import operator
 import time
 
 import numpy as np
@@ -34,6 +34,48 @@ def _dev(t, dev):
     if t.dtype != torch.float32:
         t = t.float()
     return t if t.is_contiguous() else t.contiguous()
+
+
+_data_ptr, _is_contiguous, _numel = torch.Tensor.data_ptr, torch.Tensor.is_contiguous, torch.Tensor.numel
+_dtype_of, _device_of = operator.attrgetter('dtype'), operator.attrgetter('device')
+
+
+def handles(tensors, dev, dtype=torch.float32):
+    """Device pointers of a list of tensors as a uint64 array, plus the tensors that own them.  The checks run through C-level
+    ``map`` calls (0.3 us per tensor); only a list that fails one goes through the per-tensor conversion (``_dev``: 1.2 us each --
+    3 ms of a 384-pair build when every input took it)."""
+    n = len(tensors)
+    if n and set(map(_dtype_of, tensors)) == {dtype} and set(map(_device_of, tensors)) == {dev} and all(map(_is_contiguous, tensors)):
+        return np.fromiter(map(_data_ptr, tensors), dtype=np.uint64, count=n), tensors
+    own = [_dev(t, dev) if dtype == torch.float32 else t.to(dev).contiguous() for t in tensors]
+    return np.fromiter(map(_data_ptr, own), dtype=np.uint64, count=n), own
+
+
+_FRAME_DT = np.dtype([('masks', '<u8'), ('image', '<u8'), ('logdepth', '<u8'), ('keypoints', '<u8'), ('K', '<u8'), ('N', '<i8'), ('H', '<i8'), ('W', '<i8')])
+
+
+def frame_records(frames, dev):
+    """What the set-up needs of every source keyframe -- the device pointers of its masks, image, log-depths, keypoints and intrinsics
+    and the mask shape -- as one structured array.  A keyframe's record is made once and kept ON THE KEYFRAME (``_sp_prep``; valid for
+    as long as the five attributes are the same tensor objects): a keyframe is the source of many pairs -- every tracked frame, every
+    window it is part of -- and validating five tensors per pair again was a third of the interpreter time of a build."""
+    out = []
+    for f in frames:
+        c = f.__dict__.get('_sp_prep') if hasattr(f, '__dict__') else None
+        if (c is None or c[0] is not f.keypoint_regions or c[1] is not f.image or c[2] is not f.logdepth_perseg or c[3] is not f.keypoints
+                or c[4] is not f.K or c[5] != dev):
+            m = f.keypoint_regions
+            assert m.dtype == torch.bool and m.dim() == 3
+            own = (m.contiguous(), _dev(f.image, dev), _dev(f.logdepth_perseg, dev), _dev(f.keypoints, dev), _dev(f.K, dev))
+            _lib.require_device(*own)
+            rec = np.zeros(1, dtype=_FRAME_DT)
+            rec[0] = tuple(t.data_ptr() for t in own) + tuple(m.shape)
+            c = (f.keypoint_regions, f.image, f.logdepth_perseg, f.keypoints, f.K, dev, rec.tobytes(), own)
+            if hasattr(f, '__dict__'):
+                f.__dict__['_sp_prep'] = c
+        out.append(c)
+    recs = np.frombuffer(b''.join([c[6] for c in out]), dtype=_FRAME_DT)
+    return recs, [c[7] for c in out]
 
 
 def flat_layout(counts, n_off, granule=GRANULE):
@@ -73,6 +115,46 @@ def flat_work_list(pc, seg_pos, n_off, span_points, tile_points, granule=GRANULE
     if ns < 0:
         _lib.check(ns, "sp_host_work_list")
     return dict(chunks=chunks[:C], spans=spans[:ns], seg_tile_off=seg_tile_off, sto_off=sto_off, c_off=c_off, s_off=s_off)
+
+
+def work_lists_staged(specs, tile_points, granule, dev):
+    """The work lists of several lattices of one batch -- ``specs`` = [(pc, seg_pos, n_off, span_points)] -- written by
+    ``sp_host_work_list`` STRAIGHT INTO one pinned staging buffer and sent to the device with one asynchronous copy (fresh numpy arrays
+    of a megabyte each cost more in page faults than the helper's loops, and were then copied into the staging buffer anyway).
+    Returns one dict per spec: device ``chunks`` (C,4), ``spans`` (S,4), ``seg_tile_off``; host ``sto_off``, ``c_off``, ``s_off``."""
+    lib = _lib.load()
+    rec = 4 if granule == GRANULE else 1
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    prepared, total = [], 0
+    for pc, seg_pos, n_off, span_points in specs:
+        pc = np.ascontiguousarray(pc, dtype=np.int64)
+        seg_pos = np.ascontiguousarray(seg_pos, dtype=np.int64)
+        n_off = np.ascontiguousarray(n_off, dtype=np.int64)
+        M, S = len(n_off) - 1, len(pc)
+        C = lib.sp_host_work_list_chunks(vp(pc), S, int(tile_points), int(granule))
+        if C < 0:
+            _lib.check(C, "sp_host_work_list_chunks")
+        sizes = (16 * max(C, 1), 16 * max(C, 1), (4 * (S + M) + 15) // 16 * 16)
+        prepared.append((pc, seg_pos, n_off, int(span_points), M, S, C, total, sizes))
+        total += sum(sizes)
+    host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
+    base = host.data_ptr()
+    heads = []
+    for pc, seg_pos, n_off, span_points, M, S, C, off, sizes in prepared:
+        sto_off, c_off, s_off = (np.empty(M + 1, dtype=np.int64) for _ in range(3))
+        at = lambda k: ctypes.c_void_p(base + off + sum(sizes[:k]))
+        ns = lib.sp_host_work_list(vp(pc), vp(seg_pos), vp(n_off), M, span_points, int(tile_points), int(granule), rec, at(0), at(1), at(2),
+                                   vp(sto_off), vp(c_off), vp(s_off))
+        if ns < 0:
+            _lib.check(ns, "sp_host_work_list")
+        heads.append((sto_off, c_off, s_off, ns))
+    d = host.to(dev, non_blocking=True)
+    out = []
+    for (pc, seg_pos, n_off, span_points, M, S, C, off, sizes), (sto_off, c_off, s_off, ns) in zip(prepared, heads):
+        i32 = lambda k, n: d[off + sum(sizes[:k]): off + sum(sizes[:k]) + 4 * n].view(torch.int32)
+        out.append(dict(chunks=i32(0, 4 * C).reshape(C, 4), spans=i32(1, 4 * ns).reshape(ns, 4), seg_tile_off=i32(2, S + M),
+                        sto_off=sto_off, c_off=c_off, s_off=s_off, n_chunks=C, n_spans=ns))
+    return out
 
 
 def flat_work_list_numpy(pc, seg_pos, n_off, span_points, tile_points):
@@ -223,13 +305,10 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     lib = _lib.load()
     M0 = len(src_frames)
     s_ptr = _lib.stream_ptr()
-    masks = [f.keypoint_regions.contiguous() for f in src_frames]
-    for m in masks:
-        assert m.dtype == torch.bool and m.dim() == 3
-    _lib.require_device(*masks)
-    shape0 = masks[0].shape                                                      # (M0, 3): N, H, W
-    shp = (np.tile(np.array(shape0, dtype=np.int64), (M0, 1)) if all(m.shape == shape0 for m in masks)
-           else np.array([m.shape for m in masks], dtype=np.int64))
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError("super_primitive_amd: the frames live on a device that is not the current one")
+    frec, frame_keep = frame_records(src_frames, dev)
+    shp = np.stack((frec['N'], frec['H'], frec['W']), axis=1)                    # (M0, 3): N, H, W
     Ns, Hs, Ws = shp[:, 0], shp[:, 1], shp[:, 2]
     if (Hs > 32767).any() or (Ws > 65535).any():
         raise ValueError("image too large for the packed pixel word")
@@ -248,7 +327,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     row_counts = torch.empty(nS * int(rc_off[-1]), dtype=torch.int32, device=dev)
     counts_d = torch.empty(nS * S, dtype=torch.int32, device=dev)
     recs = np.zeros(M0, dtype=_TABLE_DT)
-    recs['masks'] = _ptrs(masks)
+    recs['masks'] = frec['masks']
     recs['N'], recs['H'], recs['W'], recs['n_strides'] = Ns, Hs, Ws, nS
     for si, s in enumerate(all_strides):
         recs['stride'][:, si] = s
@@ -262,6 +341,25 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     w_off = np.concatenate(([0], np.cumsum(words)))
     bits = torch.empty(max(int(w_off[-1]), 1), dtype=torch.int32, device=dev)
     recs['bits'] = np.where(fast, bits.data_ptr() + 4 * w_off[:-1], 0).astype(np.uint64)
+    recs['logdepth'], recs['keypoints'] = frec['logdepth'], frec['keypoints']
+    # the per-pair inputs: initial log-depths and target intrinsics (FIRST on the stream: the intrinsics come back to the host for the
+    # descriptors, and a copy enqueued behind the count and pyramid passes would make the host wait for those).  The intrinsics of
+    # both frames and the log-depths (one flat array, the optimisation variable) are collected by ONE gather launch each from the
+    # pointer lists -- torch.stack / torch.cat over hundreds of small tensors cost 0.7 us of interpreter time per tensor
+    kld_ptr, kld = handles(klds, dev)
+    Ktrg_ptr, Ktrg = handles(trg_Ks, dev)
+    if sum(map(_numel, klds)) != S or sum(map(_numel, trg_Ks)) != 9 * M0:
+        raise ValueError("one (N_m,) log-depth vector and one (3,3) target intrinsics matrix per pair")
+    kld_flat = torch.empty(S, dtype=torch.float32, device=dev)
+    Ks_d = torch.empty(2 * M0, 3, 3, dtype=torch.float32, device=dev)
+    g = stage([np.concatenate((frec['K'], Ktrg_ptr)), 9 * np.arange(2 * M0 + 1, dtype=np.int64), kld_ptr, n_off.astype(np.int64)], dev)
+    _lib.check(lib.sp_prepare_gather(_lib.ptr(g[0]), _lib.ptr(g[1]), 2 * M0, _lib.ptr(Ks_d), s_ptr), "sp_prepare_gather")
+    _lib.check(lib.sp_prepare_gather(_lib.ptr(g[2]), _lib.ptr(g[3]), M0, _lib.ptr(kld_flat), s_ptr), "sp_prepare_gather")
+    Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)      # complete once the counts have been waited for
+    Ks_pinned.copy_(Ks_d, non_blocking=True)
+    Ks_ready = torch.cuda.Event()
+    Ks_ready.record()
+
     staged = stage([recs], dev)
     timer.mark('count launch')
     with timer('count'):
@@ -272,13 +370,12 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     counts_ready.record()
 
     # image pyramids of both frames and packed targets: independent of the counts, enqueued right behind the count pass
-    rgb = lambda im: im if im.shape[0] == 3 else im[:3]
-    simg = [_dev(rgb(f.image), dev) for f in src_frames]
-    timg = [_dev(rgb(t), dev) for t in trg_images]
-    _lib.require_device(*simg, *timg)
+    # (the first three channels of a contiguous (C, H, W) image start where the image starts: no slicing of images with extra channels)
+    timg_ptr, timg = handles(trg_images, dev)
+    simg_ptr = frec['image']
     max_level = max(level_ids)
     pyramid, blur_jobs = [], []
-    ptr_lv = {0: (_ptrs(simg), _ptrs(timg))}                                     # level -> (source, target) image pointers
+    ptr_lv = {0: (simg_ptr, timg_ptr)}                                          # level -> (source, target) image pointers
     hw = {0: np.stack((Hs, Ws), axis=1)}
     for l in range(1, max_level + 1):
         hw[l] = (hw[l - 1] + 1) // 2
@@ -301,7 +398,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         jb = pack_jobs[li * M0: (li + 1) * M0]
         jb['inp'], jb['out'] = ptr_lv[l][1], buf.data_ptr() + 4 * off[:-1]
         jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
-        trg[l] = (buf, off, [(int(h), int(w)) for h, w in hw[l]])
+        trg[l] = (buf, off, list(map(tuple, hw[l].tolist())))
     staged = stage([pack_jobs] + blur_jobs, dev)
     with timer('pyramid'):
         for l in range(1, max_level + 1):
@@ -310,22 +407,11 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
                    "sp_prepare_pack")
 
-    # the other inputs are gathered while the masks are being counted and the pyramids built (~2 us of interpreter time per
-    # tensor: with hundreds of pairs this is milliseconds, and the GPU must not wait for it with an empty queue)
-    logd = [_dev(f.logdepth_perseg, dev) for f in src_frames]
-    kps = [_dev(f.keypoints, dev) for f in src_frames]
-    Ksrc = [_dev(f.K, dev) for f in src_frames]
-    kld = [_dev(k, dev) for k in klds]
-    _lib.require_device(*logd)
-    recs['logdepth'], recs['keypoints'] = _ptrs(logd), _ptrs(kps)
-    Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)      # complete once the counts have been waited for
-    Ks_pinned.copy_(torch.stack([k if k.dim() == 2 else k.reshape(3, 3) for k in Ksrc + [_dev(k, dev) for k in trg_Ks]]), non_blocking=True)
-    Ks_ready = torch.cuda.Event()
-    Ks_ready.record()
-
     # ---- host: padded layouts; device: fill straight into them ----
     timer.mark('wait for counts')
+    t_wait = time.perf_counter()
     counts_ready.synchronize()                    # the one host synchronisation of the set-up (the pyramids keep the GPU busy)
+    waited = time.perf_counter() - t_wait
     timer.mark('counts here')
     counts_h = counts_pinned.numpy().reshape(nS, S)
     tabs = {}
@@ -374,7 +460,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
             jb['seg_off'] = t.seg_off.data_ptr() + 4 * (S + n_off[:-1])              # the pair-relative half
             jb['counts'] = t.counts_d.data_ptr() + 4 * n_off[:-1]
             jb['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
-            jb['kld'], jb['K'] = _ptrs(kld), _ptrs(Ksrc)
+            jb['kld'], jb['K'] = kld_ptr, frec['K']
             jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'] = Ns, P, Hs, Ws, len(lv)
             jb['granule'] = granule | (_lib.SP_PREP_DEPTH_TABLE if depth_table else 0)      # (depth tables: src4.w = exp(L), include/sp_hip.h)
             for k, l in enumerate(lv):
@@ -407,7 +493,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
             _lib.check(lib.sp_prepare_sample(_lib.ptr(st[0]), len(jb), mp, _lib.stream_ptr()), "sp_prepare_sample")
         return tabs[1].src4
 
-    sample_full._keep = (pyramid, simg, kld, Ksrc)
+    sample_full._keep = (pyramid, frame_keep, kld)
     # algorithmic bytes of every pass: what it must read and write once
     n_pts = {s: int(t.counts.sum()) for s, t in tabs.items()}
     img_px = {l: int((hw[l][:, 0] * hw[l][:, 1]).sum()) for l in hw}
@@ -423,6 +509,9 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     del pyramid
     # (temporaries -- job records, row counts -- are released here; the caching allocator orders their reuse after the launches
     #  above on this stream)
+    t_wait = time.perf_counter()
     Ks_ready.synchronize()
+    waited += time.perf_counter() - t_wait
     timer.mark('prepare_pairs returns')
-    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp, Ks=Ks_pinned.numpy(), sample_full=sample_full, bytes=nbytes)
+    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp, Ks=Ks_pinned.numpy(), kld=kld_flat, sample_full=sample_full, bytes=nbytes,
+                host_wait_s=waited)

@@ -209,6 +209,7 @@ class PairBatch:
         prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev, full_levels=full_levels,
                                            timer=timer, granule=self.granule, depth_table=self.depth_table)
         self.setup_bytes = prep['bytes']
+        self.setup_host_wait_s = prep['host_wait_s']          # of the constructor's wall time, what the host spent WAITING for the GPU (the counts)
         mark = timer.mark if timer is not None else (lambda name: None)
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
         rep = (lambda x: x) if R == 1 else (lambda x: x.repeat(*([R] + [1] * (x.dim() - 1))))
@@ -220,16 +221,16 @@ class PairBatch:
         counts, pc, seg_pos = tile(full.counts), tile(full.pc), tile(full.seg_pos)
         Ppad = tile(np.diff(full.p_off))
         p_off = np.concatenate(([0], np.cumsum(Ppad)))
-        self.Ns = [int(n) for n in Ns]
-        self.Ps = [int(p) for p in np.add.reduceat(counts, n_off[:-1])]
-        self.Ppads = [int(p) for p in Ppad]
+        self.Ns = Ns.tolist()
+        self.Ps = np.add.reduceat(counts, n_off[:-1]).tolist()
+        self.Ppads = Ppad.tolist()
         self.max_N = int(Ns.max())
         self.n_off, self.p_off = n_off, p_off
 
         # flat, pair-major device arrays
         self.kp_L = rep(kp_L)
         if klds_all is None:
-            self.kld = rep(torch.cat([batch_prepare._dev(k, dev).reshape(-1) for k in klds])).contiguous()
+            self.kld = rep(prep['kld']) if R > 1 else prep['kld']          # (gathered into one flat array by the set-up: owned, updated in place)
         else:
             self.kld = torch.cat([batch_prepare._dev(k, dev).reshape(-1) for k in klds_all]).contiguous()
             assert self.kld.numel() == int(n_off[-1]), "one (N_m,) log-depth vector per replicated pair"
@@ -247,48 +248,47 @@ class PairBatch:
         if span_points is None:
             span_points = min(DEFAULT_SPAN_POINTS, int(p_off[-1]) // MIN_SPANS) // span_div
         self.span_points = max(int(span_points), self.granule)
-        # work list: chunks {pair, seg, start, count} and spans {first chunk, n chunks, points, pair}
-        wl = batch_prepare.flat_work_list(pc, seg_pos, n_off, self.span_points, tile_points, self.granule)
-        chunks, spans = wl['chunks'], wl['spans']
-        self.n_chunks, self.n_spans = len(chunks), len(spans)
-        self._s_off = wl['s_off']
-        # every pair with the same padded layout (in every lattice): a work list prefix then fits ANY of the pairs (run_scheduled(slots=...))
-        same = lambda a: len(set(Ns.tolist())) == 1 and bool((np.asarray(a).reshape(M, -1) == np.asarray(a).reshape(M, -1)[0]).all())
+        # work lists: chunks {pair, seg, start, count}, spans {first chunk, n chunks, points, pair} and the per-pair CSR of the segment
+        # records of the all-points tables and of every decimated lattice (the levels that share a lattice share its list), made by
+        # the library's host helper straight into one staging buffer and sent asynchronously (the preparation kernels are still running)
+        same = lambda a: len(set(self.Ns)) == 1 and bool((np.asarray(a).reshape(M, -1) == np.asarray(a).reshape(M, -1)[0]).all())
         self._uniform_layout = same(pc)
+        self.coarse = {}
+        specs, spec_of, c_host = [(pc, seg_pos, n_off, self.span_points)], {}, {}
+        for l, stride in coarse_keys:
+            if stride not in spec_of:
+                t = tabs[stride]
+                c_pc, c_seg_pos = tile(t.pc), tile(t.seg_pos)
+                c_p_off = np.concatenate(([0], np.cumsum(tile(np.diff(t.p_off)))))
+                c_span = max(self.granule, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS) // span_div)
+                spec_of[stride] = len(specs)
+                specs.append((c_pc, c_seg_pos, n_off, c_span))
+                c_host[stride] = (c_p_off, np.add.reduceat(tile(t.counts), n_off[:-1]))
+                self._uniform_layout = self._uniform_layout and same(c_pc)
+        lists = batch_prepare.work_lists_staged(specs, tile_points, self.granule, dev)
+        wl = lists[0]
+        self.chunks, self.spans, self.seg_tile_off = wl['chunks'], wl['spans'], wl['seg_tile_off']
+        self.n_chunks, self.n_spans = wl['n_chunks'], wl['n_spans']
+        self._s_off = wl['s_off']
+        self.span_pair = self.spans[:, 3].long()
         self.n_seg_records = self.rec_per_chunk * self.n_chunks
         # decimated point sets of the coarse levels (run_scheduled): own tables, work list, descriptors, partial buffers
-        self.coarse = {}
         coarse_host = {}
         for l, stride in coarse_keys:
             t = tabs[stride]
             lay = _Layout()
             lay.stride = stride
-            c_counts, c_pc, c_seg_pos = tile(t.counts), tile(t.pc), tile(t.seg_pos)
-            c_p_off = np.concatenate(([0], np.cumsum(tile(np.diff(t.p_off)))))
-            lay.points = [int(p) for p in np.add.reduceat(c_counts, n_off[:-1])]
+            c_wl = lists[spec_of[stride]]
+            c_p_off, c_points = c_host[stride]
+            lay.points = c_points.tolist()
             shared = next((o for (l2, s2), o in self.coarse.items() if s2 == stride), None)
             lay.pix = shared.pix if shared is not None else rep(t.pix)
             lay.src4 = rep(t.src4[l]).reshape(-1)
-            c_span = max(self.granule, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS) // span_div)
-            c_wl = batch_prepare.flat_work_list(c_pc, c_seg_pos, n_off, c_span, tile_points, self.granule)
-            lay.n_chunks, lay.n_spans = len(c_wl['chunks']), len(c_wl['spans'])
+            lay.n_chunks, lay.n_spans = c_wl['n_chunks'], c_wl['n_spans']
             lay.s_off = c_wl['s_off']
-            self._uniform_layout = self._uniform_layout and same(c_pc)
+            lay.chunks, lay.spans, lay.seg_tile_off = c_wl['chunks'], c_wl['spans'], c_wl['seg_tile_off']
             coarse_host[(l, stride)] = (c_wl, c_p_off)
             self.coarse[(l, stride)] = lay
-        # every host-made array goes to the device through one staging buffer (asynchronously: the preparation kernels are
-        # still running): chunks {pair, seg, start, count}, spans {first chunk, n chunks, points, pair}, the per-pair CSR of
-        # the segment records, and -- for host-side consumers (tests, evaluate()) -- the owner (pair, segment) of every
-        # segment record
-        host = [chunks, spans, wl['seg_tile_off'], np.repeat(chunks[:, :2], self.rec_per_chunk, axis=0)]
-        for key in self.coarse:
-            c_wl = coarse_host[key][0]
-            host += [c_wl['chunks'], c_wl['spans'], c_wl['seg_tile_off']]
-        staged = batch_prepare.stage(host, dev)
-        self.chunks, self.spans, self.seg_tile_off, self.seg_records = staged[:4]
-        self.span_pair = self.spans[:, 3].long()
-        for i, lay in enumerate(self.coarse.values()):
-            lay.chunks, lay.spans, lay.seg_tile_off = staged[4 + 3 * i: 7 + 3 * i]
 
         # descriptors, one array per level (numpy view of struct SpPair, filled column-wise)
         Ks = prep['Ks']
@@ -332,10 +332,17 @@ class PairBatch:
         src4_d, seg_tile_off_t = self.src4, self.seg_tile_off
         self.desc = _Lazy(lambda l: batch_prepare.stage([descriptors(l, pix_t, src4_d[l], seg_tile_off_t, p_off, wl, Ps_a)], dev)[0],
                           dict(zip(full_levels, staged)))
+        by_stride = {}
         for i, lay in enumerate(self.coarse.values()):
             lay.desc = staged[len(full_levels) + i]
-            lay.partials = torch.empty(max(lay.n_spans, 1) * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
-            lay.seg_partials = torch.empty(max(self.rec_per_chunk * lay.n_chunks, 1) * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
+            # (the levels of one lattice share its work list AND its partial buffers: a pair is at one level at a time, and the
+            #  scheduled run makes one launch of the phases that share a work list)
+            first = by_stride.setdefault(lay.stride, lay)
+            if first is lay:
+                lay.partials = torch.empty(max(lay.n_spans, 1) * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
+                lay.seg_partials = torch.empty(max(self.rec_per_chunk * lay.n_chunks, 1) * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
+            else:
+                lay.partials, lay.seg_partials = first.partials, first.seg_partials
 
         # optimiser state / workspaces
         self.partials = torch.empty(self.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
@@ -353,6 +360,11 @@ class PairBatch:
         self._graphs = {}
         self._flag = None
         self._initial = (self.pose.clone(), self.kld.clone())
+
+    @property
+    def seg_records(self):
+        """(pair, segment) owner of every segment record, for host-side consumers (tests, ``evaluate``)."""
+        return torch.repeat_interleave(self.chunks[:, :2], self.rec_per_chunk, dim=0)
 
     def restore_initial(self):
         """Poses, log-depths, affine pairs and optimiser state back to what the batch was built with."""
