@@ -634,17 +634,28 @@ def main(argv=None):
                 t0 = time.perf_counter()
                 b = PairBatch(frames, [r["trg"] for r in raw], [r["K"] for r in raw], poses0, [r["kld"] for r in raw], levels=(0, 3),
                               tile_points=args.tile_points, point_stride=STRIDE, timer=timer, granule=args.granule)
+                t_host = time.perf_counter() - t0 - b.setup_host_wait_s        # the interpreter's own time: constructor minus its wait for the counts
                 sync()
                 t1 = time.perf_counter()
                 b.run_scheduled(**sched_kw)
                 sync()
+                from_raw.host_busy = t_host
                 return t1 - t0, time.perf_counter() - t1, b.setup_bytes
 
             from_raw()
             t_setup, t_opt, _ = from_raw()
+            host_warm = from_raw.host_busy
+            for f in frames:                                 # keyframes seen for the first time: their records (pointers, shapes) are made and validated
+                f.__dict__.pop("_sp_prep", None)
+            from_raw()
+            host_new = from_raw.host_busy
             line["frame_pairs_per_sec_from_raw_frames"] = n_raw / (t_setup + t_opt)
             line["from_raw_frames"] = {"pairs": n_raw, "setup_ms": 1e3 * t_setup, "optimise_ms": 1e3 * t_opt,
-                                       "setup_us_per_pair": 1e6 * t_setup / n_raw}
+                                       "setup_us_per_pair": 1e6 * t_setup / n_raw, "setup_host_busy_ms": 1e3 * host_warm,
+                                       "setup_host_busy_ms_new_keyframes": 1e3 * host_new,
+                                       "setup_host_busy_what": "interpreter time of the PairBatch constructor (wall time minus its one wait for the "
+                                                               "per-segment counts); new keyframes: with the per-keyframe records (optim/batch_prepare.py "
+                                                               "frame_records) made in the same call instead of found on the keyframes"}
             # HBM roofline of the set-up passes: algorithmic bytes of every pass (optim/batch_prepare.py) over
             # its duration between HIP events on the launch stream (a third, instrumented build)
             from super_primitive_amd.optim.batch_prepare import _Timer
