@@ -9,7 +9,8 @@ pairs = [("bench_n1.json", "bench_n1.json"), ("bench_n1_log_depth_tables.json", 
          ("stats_window/wb_kernel_stats.csv", "window_bench_kernel_stats.csv"), ("stats_setup/setup_kernel_stats.csv", "setup_kernel_stats.csv"),
          ("configs.txt", "configs.txt"), ("parity.txt", "parity.txt"), ("pytest.txt", "pytest.txt"), ("cost_kernel_pmc.txt", "cost_kernel_pmc.txt"),
          ("kbench_depth_table_ab.txt", "kbench_depth_table_ab.txt"), ("window_bench.txt", "window_bench.txt"), ("phase_sweep.txt", "phase_sweep.txt"),
-         ("reference_start.txt", "reference_start.txt"), ("stream_bench.txt", "stream_bench.txt"), ("setup.txt", "setup.txt"), ("power_clock_trace.txt", "power_clock_trace.txt")]
+         ("reference_start.txt", "reference_start.txt"), ("stream_bench.txt", "stream_bench.txt"), ("setup.txt", "setup.txt"), ("power_clock_trace.txt", "power_clock_trace.txt"),
+         ("host_profile.txt", "setup_host_profile.txt"), ("setup_kernels_128.txt", "setup_kernels_128_keyframes.txt"), ("fill_pmc.txt", "fill_pmc.txt")]
 for a, b in pairs:
     src = os.path.join(R, a)
     if os.path.exists(src):
