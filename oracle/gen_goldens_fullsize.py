@@ -560,6 +560,10 @@ def main():
         golden_sigma05(ref)
     if "g20x" in which:
         golden_bench_pair(ref)
+    for w in which:
+        # g20x:<pair index> -- any other pair of bench.py's reference-start leg (the bench line lists the ones Gauss-Newton loses)
+        if w.startswith("g20x:"):
+            golden_bench_pair(ref, pair_index=int(w[5:]), name=f"g20x_sigma05_bench_pair{int(w[5:])}")
     if "g20" in which:
         # the same at BASELINE configs[1] size (640x480x64) on the first three scenes of bench.py's reference-start leg
         # (bench.py:_render_sigma05: seeds 5000 + s, overlap 4; replica 0 of a scene starts from the pair's own pose_init / kld_init)

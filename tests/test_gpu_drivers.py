@@ -29,9 +29,15 @@ def test_two_frame_sfm_loop_matches_reference_trajectory():
     assert losses.shape == want.shape
     np.testing.assert_allclose(losses[:3], want[:3], rtol=2e-5)
     assert losses[0] == losses[1], "no update on the very first iteration (count > 0)"
-    np.testing.assert_allclose(losses, want, rtol=2e-2)
-    np.testing.assert_allclose(npy(sfm.keypoint_logdepths()), g["final_kld"], atol=2e-4)
-    np.testing.assert_allclose(npy(sfm.poses()[0]), g["final_pose"], atol=5e-4)
+    # (measured on MI355X, deterministic: losses 5.97e-3 relative, end log-depths 3.35e-5, end pose entries 1.08e-4 -- a 2 x 500-step Adam
+    #  trajectory amplifies fp32 summation-order differences; the assertions hold the measured figures with a factor of two)
+    np.testing.assert_allclose(losses, want, rtol=1.2e-2)
+    d_kld = float(np.abs(npy(sfm.keypoint_logdepths()) - g["final_kld"]).max())
+    d_pose = float(np.abs(npy(sfm.poses()[0]) - g["final_pose"]).max())
+    d_loss = float(np.abs(losses / want - 1).max())
+    print(f"\ng9a, eager loop vs the reference's trajectory: losses within {d_loss:.2e} (relative), end log-depths {d_kld:.2e}, end pose entries {d_pose:.2e}")
+    np.testing.assert_allclose(npy(sfm.keypoint_logdepths()), g["final_kld"], atol=7e-5)
+    np.testing.assert_allclose(npy(sfm.poses()[0]), g["final_pose"], atol=2.2e-4)
 
 
 def test_two_frame_sfm_loop_as_a_hipgraph_matches_reference_trajectory():
