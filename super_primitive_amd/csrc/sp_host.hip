@@ -39,9 +39,10 @@ int sp_host_work_list(const long long* pc, const long long* seg_pos, const long 
         for (int64_t s = n_off[m]; s < n_off[m + 1]; ++s) {
             *sto++ = (int32_t)(R * (nc - first));
             const int64_t p = pc[s];
-            const int64_t k = (p + cm - 1) / cm;                 // pieces of (nearly) equal, granule-aligned length
+            // pieces of (nearly) equal, granule-aligned length; a segment that fits one chunk -- the usual case -- without the divisions
+            const int64_t k = p <= cm ? (p > 0) : (p + cm - 1) / cm;
             if (k > 0) {
-                const int64_t per = ((p / kGranule + k - 1) / k) * kGranule;
+                const int64_t per = k == 1 ? p : ((p / kGranule + k - 1) / k) * kGranule;
                 for (int64_t done = 0; done < p; done += per) {
                     int32_t* c = chunks + 4 * nc++;
                     c[0] = m; c[1] = (int32_t)(s - n_off[m]); c[2] = (int32_t)(seg_pos[s] + done);

@@ -24,7 +24,23 @@ def infer_spatial_size(logdepth_perseg):
     return logdepth_perseg.shape
 
 
+_PREP_FIELDS = frozenset(("image", "K", "logdepth_perseg", "keypoints", "keypoint_regions"))
+
+
 class KeyFrame(nn.Module):
+    def __setattr__(self, name, value):
+        # the batched set-up keeps a record of the five tensors it reads on the keyframe (optim/batch_prepare.py frame_records):
+        # assigning any of them drops it
+        if name in _PREP_FIELDS:
+            self.__dict__.pop("_sp_prep", None)
+        super().__setattr__(name, value)
+
+    def __getstate__(self):
+        # (copies and pickles must not carry the record: it holds the device addresses of THIS keyframe's tensors)
+        state = self.__dict__.copy()
+        state.pop("_sp_prep", None)
+        return state
+
     def __init__(self, image, K, logdepth_perseg=None, keypoints=None, keypoint_regions=None, K_img=None, id=None):
         super().__init__()
         self.image = image

@@ -59,26 +59,33 @@ def frame_records(frames, dev):
     and the mask shape -- as one structured array.  A keyframe's record is made once and kept ON THE KEYFRAME (``_sp_prep``; valid for
     as long as the five attributes are the same tensor objects): a keyframe is the source of many pairs -- every tracked frame, every
     window it is part of -- and validating five tensors per pair again was a third of the interpreter time of a build."""
+    from ..image.keyframe import KeyFrame
     out = []
     for f in frames:
-        c = f.__dict__.get('_sp_prep') if hasattr(f, '__dict__') else None
-        if (c is None or c[0] is not f.keypoint_regions or c[1] is not f.image or c[2] is not f.logdepth_perseg or c[3] is not f.keypoints
-                or c[4] is not f.K or c[5] != dev):
+        hooked = type(f) is KeyFrame                 # (its __setattr__ drops the record when one of the five attributes is assigned)
+        try:
+            c = f.__dict__.get('_sp_prep')
+        except AttributeError:
+            c = None
+        if c is None or c[5] != dev or not (hooked or (c[0] is f.keypoint_regions and c[1] is f.image and c[2] is f.logdepth_perseg
+                                                       and c[3] is f.keypoints and c[4] is f.K and c[7][0].data_ptr() == c[8])):
             m = f.keypoint_regions
             assert m.dtype == torch.bool and m.dim() == 3
             own = (m.contiguous(), _dev(f.image, dev), _dev(f.logdepth_perseg, dev), _dev(f.keypoints, dev), _dev(f.K, dev))
             _lib.require_device(*own)
             rec = np.zeros(1, dtype=_FRAME_DT)
             rec[0] = tuple(t.data_ptr() for t in own) + tuple(m.shape)
-            c = (f.keypoint_regions, f.image, f.logdepth_perseg, f.keypoints, f.K, dev, rec.tobytes(), own)
-            if hasattr(f, '__dict__'):
+            c = (f.keypoint_regions, f.image, f.logdepth_perseg, f.keypoints, f.K, dev, rec.tobytes(), own, own[0].data_ptr())
+            try:
                 f.__dict__['_sp_prep'] = c
+            except AttributeError:
+                pass
         out.append(c)
     recs = np.frombuffer(b''.join([c[6] for c in out]), dtype=_FRAME_DT)
     return recs, [c[7] for c in out]
 
 
-def flat_layout(counts, n_off, granule=GRANULE):
+def flat_layout(counts, n_off, granule=GRANULE, table=None):
     """Padded layout of many tables at once.  counts: real points of every segment, all tables concatenated; n_off[t]:
     first segment of table t.  Returns (pc, seg_pos, p_off): padded run length of every segment, its position relative to
     its own table, and the tables' offsets into one flat array.  ``granule``: 256, or 64 for wave-span work lists."""
@@ -86,7 +93,8 @@ def flat_layout(counts, n_off, granule=GRANULE):
     pc = (counts + granule - 1) // granule * granule
     cum = np.concatenate(([0], np.cumsum(pc)))
     p_off = cum[n_off]
-    table = np.repeat(np.arange(len(n_off) - 1), np.diff(n_off))
+    if table is None:
+        table = np.repeat(np.arange(len(n_off) - 1), np.diff(n_off))
     return pc, cum[:-1] - p_off[table], p_off
 
 
@@ -131,26 +139,31 @@ def work_lists_staged(specs, tile_points, granule, dev):
         seg_pos = np.ascontiguousarray(seg_pos, dtype=np.int64)
         n_off = np.ascontiguousarray(n_off, dtype=np.int64)
         M, S = len(n_off) - 1, len(pc)
-        C = lib.sp_host_work_list_chunks(vp(pc), S, int(tile_points), int(granule))
-        if C < 0:
-            _lib.check(C, "sp_host_work_list_chunks")
+        # (an upper bound of the number of chunks sizes the buffer: one more pass over the segments saved; the helper returns the count)
+        chunk_max = max(int(granule), int(tile_points) // int(granule) * int(granule))
+        C = S + int(pc.sum()) // chunk_max
         sizes = (16 * max(C, 1), 16 * max(C, 1), (4 * (S + M) + 15) // 16 * 16)
         prepared.append((pc, seg_pos, n_off, int(span_points), M, S, C, total, sizes))
         total += sum(sizes)
     host = torch.empty(max(total, 16), dtype=torch.uint8, pin_memory=True)
     base = host.data_ptr()
-    heads = []
-    for pc, seg_pos, n_off, span_points, M, S, C, off, sizes in prepared:
+    def fill(item):
+        pc, seg_pos, n_off, span_points, M, S, C, off, sizes = item
         sto_off, c_off, s_off = (np.empty(M + 1, dtype=np.int64) for _ in range(3))
         at = lambda k: ctypes.c_void_p(base + off + sum(sizes[:k]))
         ns = lib.sp_host_work_list(vp(pc), vp(seg_pos), vp(n_off), M, span_points, int(tile_points), int(granule), rec, at(0), at(1), at(2),
                                    vp(sto_off), vp(c_off), vp(s_off))
-        if ns < 0:
-            _lib.check(ns, "sp_host_work_list")
-        heads.append((sto_off, c_off, s_off, ns))
+        return sto_off, c_off, s_off, ns, int(c_off[-1])
+
+    # (the lattices' lists on pool threads side by side -- the helper runs without the interpreter lock -- measured slower than one after
+    #  the other: 0.32 against 0.26 ms for three lists of 24 576 segments)
+    heads = [fill(item) for item in prepared]
+    for h in heads:
+        if h[3] < 0:
+            _lib.check(h[3], "sp_host_work_list")
     d = host.to(dev, non_blocking=True)
     out = []
-    for (pc, seg_pos, n_off, span_points, M, S, C, off, sizes), (sto_off, c_off, s_off, ns) in zip(prepared, heads):
+    for (pc, seg_pos, n_off, span_points, M, S, _, off, sizes), (sto_off, c_off, s_off, ns, C) in zip(prepared, heads):
         i32 = lambda k, n: d[off + sum(sizes[:k]): off + sum(sizes[:k]) + 4 * n].view(torch.int32)
         out.append(dict(chunks=i32(0, 4 * C).reshape(C, 4), spans=i32(1, 4 * ns).reshape(ns, 4), seg_tile_off=i32(2, S + M),
                         sto_off=sto_off, c_off=c_off, s_off=s_off, n_chunks=C, n_spans=ns))
@@ -308,6 +321,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     if dev.index is not None and dev.index != torch.cuda.current_device():
         raise RuntimeError("super_primitive_amd: the frames live on a device that is not the current one")
     frec, frame_keep = frame_records(src_frames, dev)
+    timer.mark('frame records')
     shp = np.stack((frec['N'], frec['H'], frec['W']), axis=1)                    # (M0, 3): N, H, W
     Ns, Hs, Ws = shp[:, 0], shp[:, 1], shp[:, 2]
     if (Hs > 32767).any() or (Ws > 65535).any():
@@ -342,12 +356,14 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     bits = torch.empty(max(int(w_off[-1]), 1), dtype=torch.int32, device=dev)
     recs['bits'] = np.where(fast, bits.data_ptr() + 4 * w_off[:-1], 0).astype(np.uint64)
     recs['logdepth'], recs['keypoints'] = frec['logdepth'], frec['keypoints']
+    timer.mark('count records')
     # the per-pair inputs: initial log-depths and target intrinsics (FIRST on the stream: the intrinsics come back to the host for the
     # descriptors, and a copy enqueued behind the count and pyramid passes would make the host wait for those).  The intrinsics of
     # both frames and the log-depths (one flat array, the optimisation variable) are collected by ONE gather launch each from the
     # pointer lists -- torch.stack / torch.cat over hundreds of small tensors cost 0.7 us of interpreter time per tensor
     kld_ptr, kld = handles(klds, dev)
     Ktrg_ptr, Ktrg = handles(trg_Ks, dev)
+    timer.mark('kld / K handles')
     if sum(map(_numel, klds)) != S or sum(map(_numel, trg_Ks)) != 9 * M0:
         raise ValueError("one (N_m,) log-depth vector and one (3,3) target intrinsics matrix per pair")
     kld_flat = torch.empty(S, dtype=torch.float32, device=dev)
@@ -360,6 +376,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     Ks_ready = torch.cuda.Event()
     Ks_ready.record()
 
+    timer.mark('gathers enqueued')
     staged = stage([recs], dev)
     timer.mark('count launch')
     with timer('count'):
@@ -372,6 +389,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     # image pyramids of both frames and packed targets: independent of the counts, enqueued right behind the count pass
     # (the first three channels of a contiguous (C, H, W) image start where the image starts: no slicing of images with extra channels)
     timg_ptr, timg = handles(trg_images, dev)
+    timer.mark('image handles')
     simg_ptr = frec['image']
     max_level = max(level_ids)
     pyramid, blur_jobs = [], []
@@ -398,8 +416,9 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         jb = pack_jobs[li * M0: (li + 1) * M0]
         jb['inp'], jb['out'] = ptr_lv[l][1], buf.data_ptr() + 4 * off[:-1]
         jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
-        trg[l] = (buf, off, list(map(tuple, hw[l].tolist())))
+        trg[l] = (buf, off, hw[l])                   # (flat packed targets, their offsets, (M0, 2) level sizes)
     staged = stage([pack_jobs] + blur_jobs, dev)
+    timer.mark('pyramid jobs staged')
     with timer('pyramid'):
         for l in range(1, max_level + 1):
             _lib.check(lib.sp_prepare_blur(_lib.ptr(staged[l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
@@ -419,10 +438,11 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     recs['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
     pair_of_seg = np.repeat(np.arange(M0), Ns)
     for si, s in enumerate(all_strides):
+        # (the three lattices one after the other: the same arithmetic on (lattices, segments) arrays measured slower, 0.43 against 0.35 ms)
         t = PreparedTables()
         t.stride = s
         t.counts = counts_h[si].astype(np.int64)
-        t.pc, t.seg_pos, t.p_off = flat_layout(t.counts, n_off, granule)
+        t.pc, t.seg_pos, t.p_off = flat_layout(t.counts, n_off, granule, table=pair_of_seg)
         if s == 1 and (np.add.reduceat(t.counts, n_off[:-1]) == 0).any():
             raise ValueError("keyframe has no segment pixels")
         total = max(int(t.p_off[-1]), 1)
@@ -438,6 +458,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     for si, t in enumerate(tabs.values()):
         t.seg_off = seg_off[si]
         recs['seg_off'][:, si] = t.seg_off.data_ptr() + 4 * n_off[:-1]
+    timer.mark('layouts')
 
     # ---- source samples: the stride-1 tables at every level, a decimated table at its own level(s), all levels of a table
     #      in one pass (which also sets the table's source-validity bits) ----
@@ -471,6 +492,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         return jobs, max_P
 
     jobs, max_P = sample_jobs(levels_of)
+    timer.mark('sample jobs')
     staged = stage([recs, jobs], dev)
     timer.mark('fill launch')
     with timer('fill'):

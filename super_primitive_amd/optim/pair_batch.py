@@ -241,7 +241,8 @@ class PairBatch:
         self.src4 = _Lazy(lambda l: rep(sample_full([l])[l]).reshape(-1), {l: rep(full.src4[l]).reshape(-1) for l in full_levels})
         self.trg4 = {l: rep(trg[l][0]) for l in self.level_ids}
         trg_off = {l: np.concatenate(([0], np.cumsum(tile(np.diff(trg[l][1]))))) for l in self.level_ids}
-        self.level_hw = {l: list(trg[l][2]) * R for l in self.level_ids}
+        hl_of = {l: np.tile(trg[l][2].astype(np.int32), (R, 1)) for l in self.level_ids}                    # (M, 2) level sizes
+        self.level_hw = _Lazy(lambda l: list(map(tuple, hl_of[l].tolist())))                                  # {level: [(Hl, Wl)] per pair}
 
         # (wave spans: a span is a quarter of a workgroup's worth of work, so four times as many of them)
         span_div = 1 if self.granule == GRANULE else 4
@@ -265,7 +266,9 @@ class PairBatch:
                 specs.append((c_pc, c_seg_pos, n_off, c_span))
                 c_host[stride] = (c_p_off, np.add.reduceat(tile(t.counts), n_off[:-1]))
                 self._uniform_layout = self._uniform_layout and same(c_pc)
+        mark('device arrays')
         lists = batch_prepare.work_lists_staged(specs, tile_points, self.granule, dev)
+        mark('work lists')
         wl = lists[0]
         self.chunks, self.spans, self.seg_tile_off = wl['chunks'], wl['spans'], wl['seg_tile_off']
         self.n_chunks, self.n_spans = wl['n_chunks'], wl['n_spans']
@@ -294,13 +297,14 @@ class PairBatch:
         Ks = prep['Ks']
         Ks_src, Ks_trg = Ks[:M0], Ks[M0:]
         k4 = lambda K: np.tile(np.stack((K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]), axis=1).astype(np.float32), (R, 1))
+        K4_src, K4_trg = k4(Ks_src), k4(Ks_trg)
         HW = np.tile(prep['shapes'][:, 1:].astype(np.int32), (R, 1))                    # full-resolution source size
         pair_idx = np.arange(M, dtype=np.int64)
 
         # (everything the descriptor maker needs is bound to LOCALS: the lazily evaluated entries of self.src4 / self.desc keep this
         #  closure alive, and a closure over ``self`` would make every PairBatch a reference cycle -- its ~25 MB per pair of tables
         #  would then wait for the cyclic garbage collector instead of being freed when the last reference goes)
-        kp_L_t, trg4_t, kld_t, pose_t, aff_t, level_hw = self.kp_L, self.trg4, self.kld, self.pose, self.aff, self.level_hw
+        kp_L_t, trg4_t, kld_t, pose_t, aff_t = self.kp_L, self.trg4, self.kld, self.pose, self.aff
         pix_t, seg_tile_off_t, Ps_a, rec_per_chunk = self.pix, None, np.asarray(self.Ps), self.rec_per_chunk
 
         def descriptors(level, pix, src4, seg_tile_off, lay_p_off, lay_wl, real_points):
@@ -313,11 +317,10 @@ class PairBatch:
             d['pose'] = pose_t.data_ptr() + 64 * pair_idx
             d['aff'] = (aff_t.data_ptr() + 16 * pair_idx) if use_affine else 0
             d['seg_tile_off'] = seg_tile_off.data_ptr() + 4 * lay_wl['sto_off'][:-1]
-            d['K_src'], d['K_trg'] = k4(Ks_src), k4(Ks_trg)
+            d['K_src'], d['K_trg'] = K4_src, K4_trg
             d['N'], d['P'] = Ns, real_points
             d['H'], d['W'] = HW[:, 0], HW[:, 1]
-            hl = np.array(level_hw[level], dtype=np.int32).reshape(M, 2)
-            d['Hl'], d['Wl'] = hl[:, 0], hl[:, 1]
+            d['Hl'], d['Wl'] = hl_of[level][:, 0], hl_of[level][:, 1]
             d['tile0'], d['n_tiles'] = lay_wl['s_off'][:-1], np.diff(lay_wl['s_off'])
             d['zmin'] = zmin
             d['rec0'] = rec_per_chunk * lay_wl['c_off'][:-1]
@@ -328,6 +331,7 @@ class PairBatch:
         for (l, stride), lay in self.coarse.items():
             c_wl, c_p_off = coarse_host[(l, stride)]
             host.append(descriptors(l, lay.pix, lay.src4, lay.seg_tile_off, c_p_off, c_wl, np.maximum(np.asarray(lay.points), 1)))
+        mark('descriptors')
         staged = batch_prepare.stage(host, dev)
         src4_d, seg_tile_off_t = self.src4, self.seg_tile_off
         self.desc = _Lazy(lambda l: batch_prepare.stage([descriptors(l, pix_t, src4_d[l], seg_tile_off_t, p_off, wl, Ps_a)], dev)[0],
@@ -360,6 +364,7 @@ class PairBatch:
         self._graphs = {}
         self._flag = None
         self._initial = (self.pose.clone(), self.kld.clone())
+        mark('constructor returns')
 
     @property
     def seg_records(self):
