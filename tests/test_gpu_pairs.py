@@ -577,7 +577,11 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
             Hl, Wl = batch.level_hw[l][m]
             off = sum(3 * h * w for h, w in batch.level_hw[l][:m])
             assert np.array_equal(npy(batch.trg4[l][off: off + 3 * Hl * Wl]), npy(packed_target(lv_t[l]).reshape(-1)))
-    # decimated tables: lattice points of the full table, in order, same validity bits, same source samples
+    _check_decimated_tables(batch)
+
+
+def _check_decimated_tables(batch):
+    """decimated tables: lattice points of the full table, in order, same validity bits, same source samples"""
     for (level, stride), lay in batch.coarse.items():
         chunks = npy(lay.chunks)
         for m in range(batch.M):
@@ -594,8 +598,33 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
             mpix = npy(lay.pix).view(np.uint32)[mine]
             msrc = npy(lay.src4.reshape(-1, 4))[mine]
             keep_valid = on & ((full_pix >> 31) == 1)
-            assert np.array_equal(mpix[(mpix >> 31) == 1], full_pix[keep_valid])
-            assert np.array_equal(msrc[(mpix >> 31) == 1], full_src[keep_valid])
+            assert np.array_equal(mpix[(mpix >> 31) == 1], full_pix[keep_valid]), (level, stride, m)
+            assert np.array_equal(msrc[(mpix >> 31) == 1], full_src[keep_valid]), (level, stride, m)
+
+
+def test_fill_pass_on_bit_words_with_every_lattice_stride_and_the_widest_rows():
+    """The wave-private fill pass (k_prep_fill_bits) on what the headline batch does not exercise: lattice strides 8 and 16 (one candidate
+    pixel per octet, every second octet), rows of 1024 pixels (64 bit words: the widest the path takes, fewer rows per batch), a segment
+    that covers whole rows (every octet listed), images taller than a workgroup's 256 rows, and 4 lattices at once: the all-points
+    tables equal the per-keyframe tables bit for bit, the decimated ones are their lattice points in order."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.segment_table import SegmentTable
+    prs = [synth.make_pair(48, 1024, 3, seed=201), synth.make_pair(300, 64, 2, seed=202), synth.make_pair(64, 128, 1, seed=203)]
+    for strides, extra in (((1, 8, 16), []), ((1, 2, 4), [(0, 8)])):
+        batch = make_batch(prs, levels=(0, 3), tile_points=2048, point_stride=strides, extra_tables=extra, depth_table=False, lazy_levels=False)
+        dev = batch.device
+        for m, pr in enumerate(prs):
+            tab = SegmentTable(T(pr.keypoint_regions).to(dev), T(pr.logdepth_perseg).to(dev), T(pr.keypoints).to(dev))
+            pc = (tab.counts + 255) // 256 * 256
+            pos = np.concatenate(([0], np.cumsum(pc)))[:-1]
+            idx = np.concatenate([np.arange(p, p + c) for p, c in zip(pos, tab.counts)])
+            lo, hi = batch.p_off[m], batch.p_off[m + 1]
+            assert hi - lo == int(pc.sum()) and batch.Ps[m] == tab.P
+            pix = npy(batch.pix[lo:hi]).view(np.uint32) & 0x7fffffff
+            assert np.array_equal(pix[idx], npy(tab.pix).view(np.uint32) & 0x7fffffff), m
+            pad = np.ones(hi - lo, bool); pad[idx] = False
+            assert not pix[pad].any()
+        _check_decimated_tables(batch)
 
 
 @pytest.mark.parametrize("optimisers", [1, 3])
