@@ -253,6 +253,13 @@ typedef struct SpPair {
  * records per chunk; sum N + n_pairs entries, pair m at sto_off[m]), c_off / s_off (first chunk / span of every pair) and returns
  * the number of spans. */
 int sp_host_work_list_chunks(const long long* pc, int n_segs, int tile_points, int granule);
+/* The padded layout of every lattice of a batch from the per-segment point counts (counts[l * n_segs + s], as sp_prepare_count leaves
+ * them): pc = the count rounded up to the granule, seg_pos = the segment's first point relative to its pair's table, p_off[l * (n_pairs +
+ * 1) + m] = first point of pair m in the lattice's flat arrays, seg_off[l * 2 n_segs ...] = the segment positions as int32, first inside
+ * the flat array (sp_prepare_fill), then relative to the pair (sp_prepare_sample, SpPair.seg_tile_off's companion), points[l * n_pairs +
+ * m] = real points of pair m.  One pass where the numpy form takes a dozen array operations per lattice. */
+int sp_host_layout(const int32_t* counts, int n_lattices, int n_segs, const long long* n_off, int n_pairs, int granule,
+                   long long* pc, long long* seg_pos, long long* p_off, int32_t* seg_off, long long* points);
 int sp_host_work_list(const long long* pc, const long long* seg_pos, const long long* n_off, int n_pairs, int span_points,
                       int tile_points, int granule /* 256, or 64 for wave spans */, int records_per_chunk /* 4, or 1 for wave spans */,
                       int32_t* chunks, int32_t* spans, int32_t* seg_tile_off, long long* sto_off, long long* c_off, long long* s_off);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "sp_prepare_pack": [P, I, I, P],
     "sp_prepare_gather": [P, P, I, P, P],
     "sp_host_work_list_chunks": [P, I, I, I],
+    "sp_host_layout": [P, I, I, P, I, I, P, P, P, P, P],
     "sp_host_work_list": [P, P, P, I, I, I, I, I, P, P, P, P, P, P],
     "sp_pairs_schedule_cost": [P, P, P],
     "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P],

@@ -14,6 +14,40 @@ inline int64_t chunk_max_of(int tile_points, int64_t granule) {
 
 extern "C" {
 
+int sp_host_layout(const int32_t* counts, int n_lattices, int n_segs, const long long* n_off, int n_pairs, int granule,
+                   long long* pc, long long* seg_pos, long long* p_off, int32_t* seg_off, long long* points) {
+    if (!counts || !n_off || !pc || !seg_pos || !p_off || !seg_off || !points) return SP_EINVAL;
+    if (n_lattices <= 0 || n_segs < 0 || n_pairs < 0 || (granule != 64 && granule != 256) || n_off[n_pairs] != n_segs) return SP_EINVAL;
+    const int64_t g = granule, S = n_segs, M = n_pairs;
+    for (int l = 0; l < n_lattices; ++l) {
+        const int32_t* c = counts + (int64_t)l * S;
+        long long* pcl = pc + (int64_t)l * S;
+        long long* spl = seg_pos + (int64_t)l * S;
+        long long* pol = p_off + (int64_t)l * (M + 1);
+        int32_t* flat = seg_off + (int64_t)l * 2 * S;
+        int32_t* rel = flat + S;
+        int64_t at = 0;
+        for (int64_t m = 0; m < M; ++m) {
+            const int64_t first = at;
+            int64_t real = 0;
+            pol[m] = at;
+            for (int64_t s = n_off[m]; s < n_off[m + 1]; ++s) {
+                const int64_t p = ((int64_t)c[s] + g - 1) / g * g;
+                pcl[s] = p;
+                spl[s] = at - first;
+                if (at > 0x7fffffffLL) return SP_ELIMIT;
+                flat[s] = (int32_t)at;
+                rel[s] = (int32_t)(at - first);
+                real += c[s];
+                at += p;
+            }
+            points[(int64_t)l * M + m] = real;
+        }
+        pol[M] = at;
+    }
+    return 0;
+}
+
 int sp_host_work_list_chunks(const long long* pc, int n_segs, int tile_points, int granule) {
     if (!pc || n_segs < 0 || tile_points <= 0 || (granule != 64 && granule != 256)) return SP_EINVAL;
     const int64_t cm = chunk_max_of(tile_points, granule);

@@ -98,6 +98,24 @@ def flat_layout(counts, n_off, granule=GRANULE, table=None):
     return pc, cum[:-1] - p_off[table], p_off
 
 
+def host_layout(counts, n_off, granule=GRANULE):
+    """``flat_layout`` of several lattices at once through ``sp_host_layout``.  counts: (lattices, segments) int32.  Returns dict(counts
+    int64, pc, seg_pos (lattices, segments), p_off (lattices, pairs + 1), points (lattices, pairs), seg_off_pinned: (lattices, 2 segments)
+    int32 in pinned memory -- positions inside the flat array, then relative to the pair)."""
+    lib = _lib.load()
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    n_off = np.ascontiguousarray(n_off, dtype=np.int64)
+    nL, S = counts.shape
+    M = len(n_off) - 1
+    pc, seg_pos = np.empty((nL, S), dtype=np.int64), np.empty((nL, S), dtype=np.int64)
+    p_off, points = np.empty((nL, M + 1), dtype=np.int64), np.empty((nL, M), dtype=np.int64)
+    seg_off = torch.empty((nL, 2 * S), dtype=torch.int32, pin_memory=True)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    _lib.check(lib.sp_host_layout(vp(counts), nL, S, vp(n_off), M, int(granule), vp(pc), vp(seg_pos), vp(p_off), ctypes.c_void_p(seg_off.data_ptr()), vp(points)),
+               "sp_host_layout")
+    return dict(counts=counts.astype(np.int64), pc=pc, seg_pos=seg_pos, p_off=p_off, points=points, seg_off_pinned=seg_off)
+
+
 def flat_work_list(pc, seg_pos, n_off, span_points, tile_points, granule=GRANULE):
     """Chunks, spans and record offsets (include/sp_hip.h, "Work list") of all pairs at once (same chunks, same greedy spans,
     same order as ``pair_batch.build_work_list``), built by the library's host helper ``sp_host_work_list`` -- tens of
@@ -436,28 +454,26 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     tabs = {}
     kp_L = torch.empty(S, dtype=torch.float32, device=dev)
     recs['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
-    pair_of_seg = np.repeat(np.arange(M0), Ns)
+    # padded layouts of all lattices by the library's host helper (one pass; the numpy form -- flat_layout -- took a dozen array
+    # operations per lattice), the segment positions straight into a pinned buffer
+    lay = host_layout(counts_h, n_off, granule)
+    if (lay['points'][all_strides.index(1)] == 0).any():
+        raise ValueError("keyframe has no segment pixels")
+    seg_off_d = lay['seg_off_pinned'].to(dev, non_blocking=True)
     for si, s in enumerate(all_strides):
-        # (the three lattices one after the other: the same arithmetic on (lattices, segments) arrays measured slower, 0.43 against 0.35 ms)
         t = PreparedTables()
         t.stride = s
-        t.counts = counts_h[si].astype(np.int64)
-        t.pc, t.seg_pos, t.p_off = flat_layout(t.counts, n_off, granule, table=pair_of_seg)
-        if s == 1 and (np.add.reduceat(t.counts, n_off[:-1]) == 0).any():
-            raise ValueError("keyframe has no segment pixels")
+        t.counts, t.pc, t.seg_pos, t.p_off, t.points = lay['counts'][si], lay['pc'][si], lay['seg_pos'][si], lay['p_off'][si], lay['points'][si]
         total = max(int(t.p_off[-1]), 1)
         t.pix = torch.empty(total, dtype=torch.int32, device=dev)               # (the sampler writes the padding: zero = invalid point)
         t.baseL = torch.empty(total, dtype=torch.float32, device=dev)
         # segment positions: inside the flat array (fill) and relative to the pair's own table (sampler, cost kernels)
         t.counts_d = counts_d[si * S: (si + 1) * S]
+        t.seg_off = seg_off_d[si]
         recs['pix'][:, si], recs['baseL'][:, si] = t.pix.data_ptr(), t.baseL.data_ptr()
+        recs['seg_off'][:, si] = t.seg_off.data_ptr() + 4 * n_off[:-1]
         t.src4 = {}
         tabs[s] = t
-    # segment positions: inside the flat array (fill) and relative to the pair's own table (sampler)
-    seg_off = stage([np.concatenate((t.seg_pos + t.p_off[pair_of_seg], t.seg_pos)).astype(np.int32) for t in tabs.values()], dev)
-    for si, t in enumerate(tabs.values()):
-        t.seg_off = seg_off[si]
-        recs['seg_off'][:, si] = t.seg_off.data_ptr() + 4 * n_off[:-1]
     timer.mark('layouts')
 
     # ---- source samples: the stride-1 tables at every level, a decimated table at its own level(s), all levels of a table

@@ -222,7 +222,7 @@ class PairBatch:
         Ppad = tile(np.diff(full.p_off))
         p_off = np.concatenate(([0], np.cumsum(Ppad)))
         self.Ns = Ns.tolist()
-        self.Ps = np.add.reduceat(counts, n_off[:-1]).tolist()
+        self.Ps = tile(full.points).tolist()
         self.Ppads = Ppad.tolist()
         self.max_N = int(Ns.max())
         self.n_off, self.p_off = n_off, p_off
@@ -264,7 +264,7 @@ class PairBatch:
                 c_span = max(self.granule, min(DEFAULT_SPAN_POINTS, int(c_p_off[-1]) // MIN_SPANS) // span_div)
                 spec_of[stride] = len(specs)
                 specs.append((c_pc, c_seg_pos, n_off, c_span))
-                c_host[stride] = (c_p_off, np.add.reduceat(tile(t.counts), n_off[:-1]))
+                c_host[stride] = (c_p_off, tile(t.points))
                 self._uniform_layout = self._uniform_layout and same(c_pc)
         mark('device arrays')
         lists = batch_prepare.work_lists_staged(specs, tile_points, self.granule, dev)

@@ -368,3 +368,32 @@ def test_vectorised_work_list_equals_the_loop_on_random_layouts():
         assert np.array_equal(np.diff(p_off), [pd['Ppad'] for pd in pads])
 
     check()
+
+
+def test_host_layout_helper_equals_the_numpy_layout():
+    """sp_host_layout (one pass in C over all lattices) against optim.batch_prepare.flat_layout (the numpy statement), ragged pairs, empty
+    segments, both granules."""
+    import ctypes
+    import numpy as np
+    from super_primitive_amd import _lib
+    from super_primitive_amd.optim.batch_prepare import flat_layout
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    Ns = np.array([6, 1, 9, 4, 64], dtype=np.int64)
+    n_off = np.concatenate(([0], np.cumsum(Ns)))
+    S, M, nL = int(n_off[-1]), len(Ns), 3
+    counts = rng.integers(0, 2000, size=(nL, S)).astype(np.int32)
+    counts[1, ::5] = 0
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for granule in (256, 64):
+        pc, seg_pos = np.empty((nL, S), np.int64), np.empty((nL, S), np.int64)
+        p_off, points = np.empty((nL, M + 1), np.int64), np.empty((nL, M), np.int64)
+        seg_off = np.empty((nL, 2 * S), np.int32)
+        assert lib.sp_host_layout(vp(counts), nL, S, vp(n_off), M, granule, vp(pc), vp(seg_pos), vp(p_off), vp(seg_off), vp(points)) == 0
+        pair_of_seg = np.repeat(np.arange(M), Ns)
+        for l in range(nL):
+            w_pc, w_pos, w_off = flat_layout(counts[l], n_off, granule)
+            assert np.array_equal(pc[l], w_pc) and np.array_equal(seg_pos[l], w_pos) and np.array_equal(p_off[l], w_off)
+            assert np.array_equal(seg_off[l, :S], w_pos + w_off[pair_of_seg]) and np.array_equal(seg_off[l, S:], w_pos)
+            assert np.array_equal(points[l], np.add.reduceat(counts[l].astype(np.int64), n_off[:-1]))
+    assert lib.sp_host_layout(vp(counts), nL, S, vp(n_off), M, 100, vp(pc), vp(seg_pos), vp(p_off), vp(seg_off), vp(points)) == -1          # SP_EINVAL: not a granule
