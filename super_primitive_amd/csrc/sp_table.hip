@@ -717,14 +717,13 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
     }
 }
 
-// Ordered compaction of (segment,row) rows into every lattice's table.  A workgroup takes SP_FILL_ROWS consecutive rows; one thread
-// per row decides from the row counts alone whether its row is empty (a segment covers a small part of the image: ~85 % of its
-// mask rows are empty and are not read again) and, if not, fetches where the row's points start in every lattice's table: those
-// loads are in flight together, once per workgroup, and the row loop takes row and starts from LDS (fetched inside the loop they
-// were a dependent global load per row and wave).  The four waves share the non-empty rows.  Word path: a lane owns 4
-// consecutive pixels; its rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken from
-// three ballots of the count's bits.  (Gathering a row's points in LDS and storing them by consecutive lanes -- full
-// lines per store instead of 4-byte stores 4 to 16 bytes apart -- was slower: 1.86 ms against 1.36 ms for 384 keyframes.)
+// Ordered compaction of (segment,row) rows into every lattice's table for the keyframes OFF the bit-word path (any width, alignment
+// and stride; k_prep_fill_bits takes the others).  A workgroup takes SP_FILL_ROWS consecutive rows at a time; one thread per row decides
+// from the row counts alone whether its row is empty (a segment covers a small part of the image: ~85 % of its mask rows are empty and
+// are not read again) and, if not, fetches where the row's points start in every lattice's table: those loads are in flight together,
+// once per round, and the row loop takes row and starts from LDS.  The four waves share the non-empty rows.  Word path: a lane owns 4
+// consecutive pixels; its rank inside the row is the prefix sum over lower lanes of their set-pixel counts (0..4), taken from three
+// ballots of the count's bits.
 __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __restrict__ tables) {
     const PrepTable& t = table_of(tables, blockIdx.y);
     if (prep_fill_bits_path(t)) return;       // (k_prep_fill_bits takes those keyframes)

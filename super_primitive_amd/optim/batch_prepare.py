@@ -238,10 +238,6 @@ class PreparedTables:
 _TABLE_DT, _SAMPLE_DT, _IMAGE_DT = np.dtype(_lib.SpPrepTable), np.dtype(_lib.SpPrepSample), np.dtype(_lib.SpPrepImage)
 
 
-def _ptrs(tensors):
-    return np.array([t.data_ptr() for t in tensors], dtype=np.uint64)
-
-
 _TORCH_OF = {np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}
 
 
