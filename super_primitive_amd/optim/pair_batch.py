@@ -56,9 +56,12 @@ REFERENCE_START_LEVELS = (0, 3)
 REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 # pose_first_iters is a CAP (the phase ends by its convergence test): 15 cut the 2-4 sigma tail of the start distribution short (rotation
 # errors of 0.09-0.22 rad need ~20 pose-only iterations; 7 of bench.py's 1536 starts, among them the one of its first 384, diverged in the
-# joint phase -- while the real reference converges from that start, golden g20x); 30 loses 1 of 1536 (tools/hard_starts.py,
+# joint phase -- while the real reference converges from that start, golden g20x); 30 loses 2 of 1536 (tools/hard_starts.py,
 # profiles/r04_reference_start.txt).  Longer is not better without the convergence test: a pose fitted for 25 iterations to depth seeds
 # that are 50 % off (IRLS epsilon 1e-2, where the test triggers late) loses 12 %.
+# What is lost of 1536 starts is a matter of the schedule only in WHICH pairs: a fourth pyramid level with pose-only phases at levels 3 and 2
+# (``pose_first_iters=(15, 15), joint_levels=3`` on levels (0, 4)) brings home the ten hard starts found so far (tools/hard_starts.py,
+# tools/lost_starts.py) at the same rate -- and loses two others (450 and 1218).
 REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=30)
 
 
@@ -507,22 +510,27 @@ class PairBatch:
         return launched
 
     def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3, phases=None,
-                 use_coarse=True, pose_first_iters=0, pose_first_eps=None):
+                 use_coarse=True, pose_first_iters=0, pose_first_eps=None, joint_levels=None):
         """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
         built with a ``point_stride`` run on their decimated point set unless ``use_coarse=False``.  ``phases``: an explicit
         list of dict(level, stride, max_iters, irls_eps, conv_tol) instead (every (level, stride > 1) needs its table:
         ``point_stride`` / ``extra_tables`` of the constructor; optional ``pose_only=True``).  ``pose_first_iters`` > 0 puts a
         POSE-ONLY phase of at most that many iterations in front, at the coarsest level (SP_PHASE_POSE_ONLY, include/sp_hip.h): the
         depths keep their seeds while the pose is aligned -- what makes the schedule converge from the reference's own starting
-        distribution (REFERENCE_START_SCHEDULE)."""
+        distribution (REFERENCE_START_SCHEDULE).  A TUPLE of caps puts one pose-only phase per entry at the coarsest levels in turn
+        (coarsest first); ``joint_levels`` = k restricts the joint (pose + depth) phases to the k finest levels: a level above those only
+        aligns the pose."""
         if phases is None:
             phases = []
-            if pose_first_iters > 0:
-                coarsest = max(self.level_ids)
-                phases.append(dict(level=coarsest, stride=self.point_stride[coarsest] if use_coarse else 1, max_iters=pose_first_iters,
+            caps = tuple(pose_first_iters) if isinstance(pose_first_iters, (tuple, list)) else ((int(pose_first_iters),) if pose_first_iters > 0 else ())
+            coarse_first = sorted(self.level_ids, reverse=True)
+            assert len(caps) <= len(coarse_first)
+            for level, cap in zip(coarse_first, caps):
+                phases.append(dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=int(cap),
                                    irls_eps=irls_eps if pose_first_eps is None else pose_first_eps, conv_tol=conv_tol, pose_only=True))
+            joint = coarse_first if joint_levels is None else coarse_first[len(coarse_first) - int(joint_levels):]
             phases += [dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=max_iters_per_level, irls_eps=irls_eps,
-                           conv_tol=conv_tol) for level in reversed(self.level_ids)]
+                           conv_tol=conv_tol) for level in joint]
             if polish_max > 0:
                 phases.append(dict(level=min(self.level_ids), stride=1, max_iters=polish_max, irls_eps=polish_eps, conv_tol=polish_tol))
         if len(phases) > _lib.SP_MAX_PHASES:

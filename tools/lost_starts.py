@@ -63,3 +63,12 @@ for name, phases in VARIANTS.items():
     b.run_scheduled(phases=phases)
     torch.cuda.synchronize()
     print(f"{name}: {errors(b)}")
+# a fourth pyramid level in front (80x60, stride-8 lattice)
+for name, phases in {"pose-only 15 @L3 + 15 @L2, then shipped tail": [po(3, 15), po(2, 15), joint(2), joint(1), joint(0), pol],
+                     "pose-only 15 @L3 + 30 @L2, then shipped tail": [po(3, 15), po(2, 30), joint(2), joint(1), joint(0), pol],
+                     "pose-only 15 @L3, joint L3, pose-only 15 @L2, then shipped tail": [po(3, 15), joint(3), po(2, 15), joint(2), joint(1), joint(0), pol]}.items():
+    b = PairBatch.from_synth(pairs, levels=(0, 4), point_stride=(2, 2, 4, 8), granule=64)
+    b.run_scheduled(phases=phases)
+    torch.cuda.synchronize()
+    its = (b.lm_state[:, 2] + b.lm_state[:, 3]).cpu().numpy()
+    print(f"{name}: {errors(b)}; iterations {its}")
