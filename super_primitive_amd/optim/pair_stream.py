@@ -10,6 +10,8 @@ its results have been read.  Frame pairs are independent problems (SURVEY.md sec
 Measured (round 3, profiles/r03_stream_bench.txt: 640x480x64 pairs from raw frames, distinct frames per batch, a long-lived
 PairStream): 384 pairs per batch 17.1 k pairs/s one batch at a time, 18.2 / 20.9 / 21.2 k with 1 / 2 / 3 schedules in flight
 (``optimisers``); 128 pairs per batch 13.8 k -> 19.9 k.  In bench.py (the same frames every batch) 21.9 k -> 24-26 k.
+Round 4 (profiles/r04_stream_bench.txt, r04_bench_n1.json; three rotating distinct input sets, reaper thread, level 0 on its stride-2
+lattice): 21.2 k one batch at a time, 24.4 / 27.9 / 29.1 k with 1 / 2 / 3 schedules in flight in the tool; 33 k sustained in bench.py.
 """
 from __future__ import annotations
 
