@@ -287,6 +287,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <class T> __device__ __forceinline__ T* generic(SP_GLOBAL T* p) { return (T*)p; }      // for the helpers shared with the per-keyframe kernels
 __device__ __forceinline__ uint4 load4(const SP_GLOBAL u32x4* p) { const u32x4 v = *p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ float4 load4(const SP_GLOBAL f32x4* p) { const f32x4 v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+// ... of data that is read exactly once (the masks): non-temporal, so that 20 MB per keyframe do not push the row counts and bit words
+// the next passes read out of the L2
+__device__ __forceinline__ uint4 load4_once(const SP_GLOBAL u32x4* p) { const u32x4 v = __builtin_nontemporal_load(p); return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void store4(SP_GLOBAL f32x4* p, const float4& v) { const f32x4 w = {v.x, v.y, v.z, v.w}; *p = w; }
 
 struct PrepTable {
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
 #pragma unroll
         for (int u = 0; u < SP_PREP_LOADS; ++u) {
             const int p = p0 + u * 64 + lane;
-            w[u] = p < n_pieces ? load4(mq + p) : make_uint4(0u, 0u, 0u, 0u);
+            w[u] = p < n_pieces ? load4_once(mq + p) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < SP_PREP_LOADS; ++u) {
@@ -483,21 +486,6 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts_general(const SpPr
     }
 }
 
-__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* __restrict__ tables) {
-    const PrepTable& t = table_of(tables, blockIdx.y);
-    if ((int)blockIdx.x >= t.N) return;
-    const int k = blockIdx.z;
-    if (k >= t.n_strides) return;
-    segment_row_scan(generic(t.row_counts[k] + (size_t)blockIdx.x * t.H), t.H, generic(t.counts[k] + blockIdx.x));
-}
-
-#define SP_FILL_ROWS 256
-
-// does the fill pass of this keyframe read the bit words the count pass wrote (k_prep_fill_bits) instead of the masks (k_prep_fill)?
-__device__ __forceinline__ bool prep_fill_bits_path(const PrepTable& t) {
-    return t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0 && (long long)t.N * t.H < (1ll << 22) && t.H <= 1024;
-}
-
 // inclusive prefix sum over the 64 lanes of a wave in six DPP additions (row shifts by 1 / 2 / 4 / 8 inside the rows of 16 lanes, then
 // lane 15 of a row broadcast into the next row, lane 31 into the upper half): no LDS traffic, no barrier
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
@@ -508,6 +496,47 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
     return v;
+}
+
+// Exclusive scan of the H row counts of every (segment, lattice) in place, total to counts[n]: one WAVE each, 64 rows per trip, the
+// prefix sum across the lanes by DPP, the carry in a scalar -- no LDS, no barrier.  (A workgroup per segment with thread 0 adding up 256
+// partial sums one after the other -- the per-keyframe kernel's form -- took 45 us per 128 keyframes, 7 % of the count pass.)
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* __restrict__ tables) {
+    const PrepTable& t = table_of(tables, blockIdx.y);
+    const int lane = threadIdx.x & 63, n = blockIdx.x * SP_WAVES + (threadIdx.x >> 6);
+    const int k = blockIdx.z;
+    if (n >= t.N || k >= t.n_strides) return;
+    const int H = t.H;
+    SP_GLOBAL int32_t* rc = t.row_counts[k] + (size_t)n * H;
+    uint32_t carry = 0u;
+    if (H <= 512) {                  // all trips' loads in flight together
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (64 * i + lane < H) ? (uint32_t)rc[64 * i + lane] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (64 * i >= H) break;
+            const uint32_t incl = wave_inclusive_scan(v[i]);
+            if (64 * i + lane < H) rc[64 * i + lane] = (int32_t)(carry + incl - v[i]);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    } else {
+        for (int r0 = 0; r0 < H; r0 += 64) {
+            const int r = r0 + lane;
+            const uint32_t v = r < H ? (uint32_t)rc[r] : 0u;
+            const uint32_t incl = wave_inclusive_scan(v);
+            if (r < H) rc[r] = (int32_t)(carry + incl - v);
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    if (lane == 0) t.counts[k][n] = (int32_t)carry;
+}
+
+#define SP_FILL_ROWS 256
+
+// does the fill pass of this keyframe read the bit words the count pass wrote (k_prep_fill_bits) instead of the masks (k_prep_fill)?
+__device__ __forceinline__ bool prep_fill_bits_path(const PrepTable& t) {
+    return t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0 && (long long)t.N * t.H < (1ll << 22) && t.H <= 1024;
 }
 
 // the set pixels i = 0, STEP, 2 STEP, ... of an octet, in order, into the staging list from position q on
@@ -706,7 +735,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
                 for (int j = lane; j < T[k]; j += 64) {
                     const uint2 v = s_stage[wave][j];
                     const int dest = s_delta[wave][k][(v.x >> 10) & 0x3fu] + run[k] + j;
-                    pix_k[k][(uint32_t)dest] = v.x & 0xffff03ffu;
+                    pix_k[k][(uint32_t)dest] = v.x & 0xffff03ffu;            // (non-temporal stores and log-depth loads here: 215 -> 270 us)
                     baseL_k[k][(uint32_t)dest] = __uint_as_float(v.y);
                 }
             }
@@ -1054,7 +1083,7 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
     const int general_rows = SP_WAVES * SP_PREP_ROWS;
     hipLaunchKernelGGL(k_prep_row_counts_general, dim3(std::min((max_rows + general_rows - 1) / general_rows, SP_PREP_GENERAL_BLOCKS), n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
-    hipLaunchKernelGGL(k_prep_row_scan, dim3(max_N, n_tables, SP_PREP_MAX_STRIDES), dim3(SP_BLOCK), 0, s, tables);
+    hipLaunchKernelGGL(k_prep_row_scan, dim3((max_N + SP_WAVES - 1) / SP_WAVES, n_tables, SP_PREP_MAX_STRIDES), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     return 0;
 }
