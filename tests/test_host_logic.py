@@ -397,3 +397,39 @@ def test_host_layout_helper_equals_the_numpy_layout():
             assert np.array_equal(seg_off[l, :S], w_pos + w_off[pair_of_seg]) and np.array_equal(seg_off[l, S:], w_pos)
             assert np.array_equal(points[l], np.add.reduceat(counts[l].astype(np.int64), n_off[:-1]))
     assert lib.sp_host_layout(vp(counts), nL, S, vp(n_off), M, 100, vp(pc), vp(seg_pos), vp(p_off), vp(seg_off), vp(points)) == -1          # SP_EINVAL: not a granule
+
+
+def test_tensor_list_handles_fast_path_and_conversion():
+    """optim.batch_prepare.handles: a list that passes the C-level checks comes back as it is (pointers of the tensors themselves); one
+    non-contiguous or non-float32 member sends the list through the per-tensor conversion, and the pointers are those of the copies."""
+    import numpy as np
+    import torch
+    from super_primitive_amd.optim.batch_prepare import handles
+    dev = torch.device("cpu")
+    good = [torch.arange(9, dtype=torch.float32).reshape(3, 3) + i for i in range(5)]
+    ptr, own = handles(good, dev)
+    assert own is good and ptr.dtype == np.uint64 and ptr.tolist() == [t.data_ptr() for t in good]
+    mixed = list(good)
+    mixed[2] = torch.arange(18, dtype=torch.float64).reshape(3, 6)[:, ::2]          # wrong dtype, not contiguous
+    ptr2, own2 = handles(mixed, dev)
+    assert own2 is not mixed and own2[2].dtype == torch.float32 and own2[2].is_contiguous()
+    assert torch.equal(own2[2], mixed[2].float()) and ptr2[2] == own2[2].data_ptr() and ptr2[0] == good[0].data_ptr()
+
+
+def test_keyframe_drops_its_set_up_record_on_assignment_and_never_copies_it():
+    """image.keyframe.KeyFrame: the record the batched set-up keeps on a keyframe (device addresses of its tensors) goes away when one of the
+    five tensors is assigned, and is neither deep-copied nor pickled."""
+    import copy
+    import pickle
+    import torch
+    from super_primitive_amd.image.keyframe import KeyFrame
+    kf = KeyFrame(torch.zeros(3, 4, 4), torch.eye(3), torch.zeros(2, 4, 4), torch.zeros(2, 2), torch.zeros(2, 4, 4, dtype=torch.bool))
+    for name in ("image", "K", "logdepth_perseg", "keypoints", "keypoint_regions"):
+        kf.__dict__["_sp_prep"] = ("record",)
+        setattr(kf, name, getattr(kf, name).clone())
+        assert "_sp_prep" not in kf.__dict__, name
+    kf.__dict__["_sp_prep"] = ("record",)
+    kf.id = 7                                              # any other attribute leaves it alone
+    assert "_sp_prep" in kf.__dict__
+    assert "_sp_prep" not in copy.deepcopy(kf).__dict__ and "_sp_prep" not in pickle.loads(pickle.dumps(kf)).__dict__
+    assert "_sp_prep" in kf.__dict__
