@@ -774,3 +774,31 @@ def test_slot_level_continuous_batching_gives_every_pair_its_own_result(granule)
         assert n_q <= its_ref.sum() / slots + its_ref.max() + 2
     with pytest.raises(ValueError):
         make_batch([synth.make_pair(96, 128, 6, seed=1), synth.make_pair(96, 128, 9, seed=2)], **kw).run_scheduled(slots=1, **sch)
+
+
+def test_keyframe_record_of_the_set_up_follows_replaced_and_edited_tensors():
+    """The batched set-up finds the device addresses of a keyframe's tensors on the keyframe (optim.batch_prepare.frame_records).  A build
+    after one of them was REPLACED reads the new tensor, a build after an IN-PLACE edit reads the edited values -- both equal to a build from
+    fresh KeyFrame objects -- and a second build from untouched keyframes equals the first bit for bit."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.optim.pair_batch import PairBatch
+    dev = torch.device("cuda:0")
+    prs = [synth.make_pair(60, 80, 6, seed=301), synth.make_pair(48, 64, 4, seed=302)]
+    t = lambda a: T(a).to(dev)
+    tens = [dict(img=t(p.src_image), K=t(p.K), L=t(p.logdepth_perseg), kp=t(p.keypoints), m=t(p.keypoint_regions)) for p in prs]
+    frames = [KeyFrame(d["img"], d["K"], d["L"], d["kp"], d["m"]) for d in tens]
+    rest = ([t(p.trg_image) for p in prs], [t(p.K) for p in prs], torch.stack([t(p.pose_init) for p in prs]), [t(p.kld_init) for p in prs])
+    build = lambda fr: PairBatch(fr, *rest, levels=(0, 2), point_stride=(1, 2), depth_table=False)
+    a, a2 = build(frames), build(frames)
+    assert "_sp_prep" in frames[0].__dict__ and torch.equal(a.src4[0], a2.src4[0]) and torch.equal(a.pix, a2.pix)
+    frames[0].logdepth_perseg = tens[0]["L"] + 0.125                 # replaced: the record is dropped and made again
+    assert "_sp_prep" not in frames[0].__dict__
+    b = build(frames)
+    fresh = [KeyFrame(tens[0]["img"], tens[0]["K"], tens[0]["L"] + 0.125, tens[0]["kp"], tens[0]["m"]), KeyFrame(*[tens[1][k] for k in ("img", "K", "L", "kp", "m")])]
+    c = build(fresh)
+    assert torch.equal(b.src4[0], c.src4[0]) and not torch.equal(b.src4[0], a.src4[0])
+    frames[1].logdepth_perseg.mul_(1.5)                               # edited in place: same address, the record stays
+    assert "_sp_prep" in frames[1].__dict__
+    d, e = build(frames), build([fresh[0], KeyFrame(*[tens[1][k] for k in ("img", "K", "L", "kp", "m")])])
+    assert torch.equal(d.src4[0], e.src4[0]) and not torch.equal(d.src4[0], b.src4[0])
