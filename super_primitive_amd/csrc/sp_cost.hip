@@ -411,7 +411,7 @@ __device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& 
     const f32x2 it2{fmaf(p.wxy.y, Gr.y, fmaf(p.wxy.x, Er.x, a.x)), fmaf(p.wxy.y, Gg.y, fmaf(p.wxy.x, Eg.x, a.y))};
     const float itb = fmaf(p.wxy.y, Gb.y, fmaf(p.wxy.x, Eb.x, a.z));
     const f32x2 r2 = p.srg - pfma(k.gain, it2, k.bias2);
-    const float rb = p.sb - fmaf(k.gain, itb, k.bias);
+    const float rb = p.sb - fmaf(k.gain, itb, k.bias2.x);      // (the bias from its vector-register pair: gain is the instruction's one scalar operand)
     const float ar0 = fabsf(r2.x), ar1 = fabsf(r2.y), arb = fabsf(rb);
     const f32x2 wg2{__builtin_amdgcn_rcpf(fmaxf(ar0, eps)), __builtin_amdgcn_rcpf(fmaxf(ar1, eps))};
     const float wgb = __builtin_amdgcn_rcpf(fmaxf(arb, eps));
@@ -636,12 +636,15 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
     {
         const Warp& w = c.w;
         kc.ifxy = sgpr2(1.f / c.Ks.fx, 1.f / c.Ks.fy);
-        kc.nKc = sgpr2(-c.Ks.cx * (1.f / c.Ks.fx), -c.Ks.cy * (1.f / c.Ks.fy));
+        // (the two pairs that are the ADDEND of a packed fma whose multiplier is an SGPR pair already -- one scalar operand per instruction --
+        //  stay in vector registers: from SGPRs they were copied into a register pair again for every point)
+        kc.nKc = f32x2{-c.Ks.cx * (1.f / c.Ks.fx), -c.Ks.cy * (1.f / c.Ks.fy)};
         kc.R03 = sgpr2(w.R[0], w.R[3]);        kc.R14 = sgpr2(w.R[1], w.R[4]);      kc.R25 = sgpr2(w.R[2], w.R[5]);
         kc.t01 = sgpr2(w.t[0], w.t[1]);        kc.Kf = sgpr2(w.Kt.fx, w.Kt.fy);     kc.Ktc = sgpr2(w.Kt.cx, w.Kt.cy);
         kc.invWH = sgpr2(2.f * w.invWm1, 2.f * w.invHm1);  kc.sxy = sgpr2(w.sx, w.sy);
         kc.gab = sgpr2(c.gain * c.ax * w.Kt.fx, c.gain * c.ay * w.Kt.fy);
-        kc.bias2 = sgpr2(c.bias, c.bias);      kc.eps2 = sgpr2(irls_eps, irls_eps);
+        kc.bias2 = f32x2{c.bias, c.bias};      kc.eps2 = sgpr2(irls_eps, irls_eps);
+        asm volatile("" : "+v"(kc.nKc), "+v"(kc.bias2));      // (opaque: or the compiler puts the uniform pairs back into SGPRs)
         kc.R6 = sgpr(w.R[6]); kc.R7 = sgpr(w.R[7]); kc.R8 = sgpr(w.R[8]); kc.t2 = sgpr(w.t[2]);
         kc.gain = sgpr(c.gain); kc.bias = sgpr(c.bias); kc.zmin = sgpr(w.zmin); kc.eps = sgpr(irls_eps);
     }
