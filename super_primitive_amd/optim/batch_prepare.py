@@ -380,11 +380,11 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     timer.mark('kld / K handles')
     if sum(map(_numel, klds)) != S or sum(map(_numel, trg_Ks)) != 9 * M0:
         raise ValueError("one (N_m,) log-depth vector and one (3,3) target intrinsics matrix per pair")
-    kld_flat = torch.empty(S, dtype=torch.float32, device=dev)
-    Ks_d = torch.empty(2 * M0, 3, 3, dtype=torch.float32, device=dev)
-    g = stage([np.concatenate((frec['K'], Ktrg_ptr)), 9 * np.arange(2 * M0 + 1, dtype=np.int64), kld_ptr, n_off.astype(np.int64)], dev)
-    _lib.check(lib.sp_prepare_gather(_lib.ptr(g[0]), _lib.ptr(g[1]), 2 * M0, _lib.ptr(Ks_d), s_ptr), "sp_prepare_gather")
-    _lib.check(lib.sp_prepare_gather(_lib.ptr(g[2]), _lib.ptr(g[3]), M0, _lib.ptr(kld_flat), s_ptr), "sp_prepare_gather")
+    # (one output buffer -- the 2 M0 intrinsics matrices, then the S log-depths -- and ONE launch over the 3 M0 sources)
+    gathered = torch.empty(18 * M0 + S, dtype=torch.float32, device=dev)
+    Ks_d, kld_flat = gathered[:18 * M0].view(2 * M0, 3, 3), gathered[18 * M0:]
+    g = stage([np.concatenate((frec['K'], Ktrg_ptr, kld_ptr)), np.concatenate((9 * np.arange(2 * M0, dtype=np.int64), 18 * M0 + n_off.astype(np.int64)))], dev)
+    _lib.check(lib.sp_prepare_gather(_lib.ptr(g[0]), _lib.ptr(g[1]), 3 * M0, _lib.ptr(gathered), s_ptr), "sp_prepare_gather")
     Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)      # complete once the counts have been waited for
     Ks_pinned.copy_(Ks_d, non_blocking=True)
     Ks_ready = torch.cuda.Event()
@@ -528,18 +528,20 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         return tabs[1].src4
 
     sample_full._keep = (pyramid, frame_keep, kld)
-    # algorithmic bytes of every pass: what it must read and write once
-    n_pts = {s: int(t.counts.sum()) for s, t in tabs.items()}
-    img_px = {l: int((hw[l][:, 0] * hw[l][:, 1]).sum()) for l in hw}
-    sampled_levels = sorted({l for lv in levels_of.values() for l in lv})
-    nbytes = {
-        'count': int((Ns * Hs * Ws).sum()) + 4 * int(words.sum()),                       # masks in (1 B / pixel and segment), bit words out
-        'fill': 4 * n_pts[1] + 8 * sum(n_pts.values()) + n_pts[1] // 4,                  # L in (once per mask pixel), pix + baseL out per lattice point, set bits in
-        'sample': sum((12 + 16 * len(lv)) * n_pts[s] for s, lv in levels_of.items())     # pix + baseL in, pix out, one src4 per sampled level out
-                  + sum(12 * img_px[l] for l in sampled_levels),                         # ... and every sampled source level read once
-        'pyramid': sum(2 * 12 * (img_px[l - 1] + img_px[l]) for l in range(1, max_level + 1)),      # both frames: level l-1 in, level l out
-        'pack': sum(2 * 12 * img_px[l] for l in level_ids),                              # targets: planar in, HWC3 out
-    }
+    def pass_bytes():
+        """algorithmic bytes of every pass: what it must read and write once (made on demand: bench.py asks)"""
+        n_pts = {s: int(t.counts.sum()) for s, t in tabs.items()}
+        img_px = {l: int((hw[l][:, 0] * hw[l][:, 1]).sum()) for l in hw}
+        sampled_levels = sorted({l for lv in levels_of.values() for l in lv})
+        return {
+            'count': int((Ns * Hs * Ws).sum()) + 4 * int(words.sum()),                       # masks in (1 B / pixel and segment), bit words out
+            'fill': 4 * n_pts[1] + 8 * sum(n_pts.values()) + n_pts[1] // 4,                  # L in (once per mask pixel), pix + baseL out per lattice point, set bits in
+            'sample': sum((12 + 16 * len(lv)) * n_pts[s] for s, lv in levels_of.items())     # pix + baseL in, pix out, one src4 per sampled level out
+                      + sum(12 * img_px[l] for l in sampled_levels),                         # ... and every sampled source level read once
+            'pyramid': sum(2 * 12 * (img_px[l - 1] + img_px[l]) for l in range(1, max_level + 1)),      # both frames: level l-1 in, level l out
+            'pack': sum(2 * 12 * img_px[l] for l in level_ids),                              # targets: planar in, HWC3 out
+        }
+
     del pyramid
     # (temporaries -- job records, row counts -- are released here; the caching allocator orders their reuse after the launches
     #  above on this stream)
@@ -547,5 +549,5 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     Ks_ready.synchronize()
     waited += time.perf_counter() - t_wait
     timer.mark('prepare_pairs returns')
-    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp, Ks=Ks_pinned.numpy(), kld=kld_flat, sample_full=sample_full, bytes=nbytes,
+    return dict(tabs=tabs, kp_L=kp_L, trg=trg, n_off=n_off, shapes=shp, Ks=Ks_pinned.numpy(), kld=kld_flat, sample_full=sample_full, bytes=pass_bytes,
                 host_wait_s=waited)

@@ -211,7 +211,7 @@ class PairBatch:
         full_levels = [l for l in self.level_ids if not (lazy_levels and l in decimated)] or [min(self.level_ids)]
         prep = batch_prepare.prepare_pairs(src_frames, trg_images, trg_Ks, klds, self.level_ids, coarse_keys, dev, full_levels=full_levels,
                                            timer=timer, granule=self.granule, depth_table=self.depth_table)
-        self.setup_bytes = prep['bytes']
+        self._setup_bytes = prep['bytes']                      # (callable: the algorithmic bytes of every set-up pass, made on demand)
         self.setup_host_wait_s = prep['host_wait_s']          # of the constructor's wall time, what the host spent WAITING for the GPU (the counts)
         mark = timer.mark if timer is not None else (lambda name: None)
         tabs, kp_L, trg, n_off0 = prep['tabs'], prep['kp_L'], prep['trg'], prep['n_off']
@@ -354,20 +354,33 @@ class PairBatch:
         # optimiser state / workspaces
         self.partials = torch.empty(self.n_spans * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
         self.seg_partials = torch.empty(self.n_seg_records * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=dev)
-        self._costs = torch.zeros(M, dtype=torch.float32, device=dev)
-        self.adam_state = torch.zeros(M, 2 + 2 * (self.max_N + 8), dtype=torch.float32, device=dev)
-        self.lm_state = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
-        self.backup = torch.zeros(M, 16 + self.max_N, dtype=torch.float32, device=dev)
-        self.arrivals = torch.zeros(M, dtype=torch.int32, device=dev)     # per-pair tile-arrival counters (fused launch)
-        self.done = torch.zeros(M, dtype=torch.int32, device=dev)         # per-pair convergence flags (gn_step(conv_tol=...))
-        self.phase = torch.zeros(M, dtype=torch.int32, device=dev)        # per-pair position in a device-side schedule (run_scheduled)
+        # (one zeroed allocation per type, cut into the per-pair arrays: eight fill launches less per build)
+        widths = (1, 2 + 2 * (self.max_N + 8), _lib.SP_LM_STATE_FLOATS, 16 + self.max_N)
+        sizes = [(M * w + 3) // 4 * 4 for w in widths]                      # (every array starts on a 16-byte boundary)
+        cuts = np.concatenate(([0], np.cumsum(sizes)))
+        state_f = torch.zeros(int(cuts[-1]), dtype=torch.float32, device=dev)
+        self._costs = state_f[cuts[0]: cuts[0] + M]
+        self.adam_state = state_f[cuts[1]: cuts[1] + M * widths[1]].view(M, widths[1])
+        self.lm_state = state_f[cuts[2]: cuts[2] + M * widths[2]].view(M, widths[2])
+        self.backup = state_f[cuts[3]: cuts[3] + M * widths[3]].view(M, widths[3])
+        state_i = torch.zeros(4, M, dtype=torch.int32, device=dev)
+        self.arrivals = state_i[0]        # per-pair tile-arrival counters (fused launch)
+        self.done = state_i[1]            # per-pair convergence flags (gn_step(conv_tol=...))
+        self.phase = state_i[2]           # per-pair position in a device-side schedule (run_scheduled)
+        self.phase_iters = state_i[3]
         mark('workspaces')
-        self.phase_iters = torch.zeros(M, dtype=torch.int32, device=dev)
         self.reset_lm()
         self._graphs = {}
         self._flag = None
         self._initial = (self.pose.clone(), self.kld.clone())
         mark('constructor returns')
+
+    @property
+    def setup_bytes(self):
+        """{pass: algorithmic bytes} of the set-up that built this batch (bench.py's ``roofline_setup``)."""
+        if callable(self._setup_bytes):
+            self._setup_bytes = self._setup_bytes()
+        return self._setup_bytes
 
     @property
     def seg_records(self):
