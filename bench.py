@@ -51,6 +51,10 @@ def parse(argv=None):
     ap.add_argument("--settle-ms", type=float, default=150.0,
                     help="untimed steps run for this long before the W warm-up steps, so the clocks of a box that was idle "
                          "have ramped to their steady state (DESIGN.md §6); 0 disables")
+    ap.add_argument("--min-timed-ms", type=float, default=200.0,
+                    help="the timed region of exactly --steps steps (barrier + synchronize on both sides) is REPEATED, each repetition bracketed "
+                         "the same way, until this much time has been timed in total; the line reports the mean over the repetitions "
+                         "(20 steps are 17 ms: one region alone moves with the clock state of the box); 0 = one region")
     ap.add_argument("--pairs", type=int, default=384, help="frame pairs resident per GPU (4.8 GB of tables and images)")
     ap.add_argument("--segments", type=int, default=64, help="segments per source keyframe (BASELINE config 5 uses 128)")
     ap.add_argument("--shape", choices=["grid", "blobs"], default="grid",
@@ -107,7 +111,8 @@ def build_batch(args, rank, dev):
 
 def _render_sigma05(a):
     from super_primitive_amd import synth
-    return synth.make_pair(H, W, a[0], seed=a[1], overlap=4, init_sigma=0.05, texture="octaves", init_mode="reference")
+    shape_kw = dict(overlap=4) if len(a) < 3 or a[2] == "grid" else dict(shape="blobs", blob_coverage=a[3])
+    return synth.make_pair(H, W, a[0], seed=a[1], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
 
 
 def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue_factor=4):
@@ -130,7 +135,7 @@ def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue
     G = max(1, min(args.sigma05_scenes, M))
     Q = queue_factor * M
     R = max(1, Q // G)
-    jobs = [(args.segments, 5000 + 1000 * rank + s) for s in range(G)]
+    jobs = [(args.segments, 5000 + 1000 * rank + s, getattr(args, "shape", "grid"), getattr(args, "coverage", 1.2)) for s in range(G)]
     if G > 1 and (os.cpu_count() or 1) > 2:
         with Pool(min(G, 16)) as pool:
             scenes = pool.map(_render_sigma05, jobs)
@@ -174,11 +179,21 @@ def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue
         conv = (err[:, 0] <= 2e-3) & (err[:, 1] <= 2e-3) & (err[:, 2] <= 2e-2)          # golden g19's convergence criterion (vs ground truth)
         bar = (err[:, 0] <= 2e-4) & (err[:, 1] <= 2e-4) & (err[:, 2] <= 2e-3)
         n_it = (batch.lm_state[:n, 2] + batch.lm_state[:n, 3]).double()
+        # the run's own verdict (SpVerdict; PairBatch.status / attempts): what it flagged, what it ran a second time, and -- the figure that
+        # must be zero -- pairs that are away from their ground truth WITHOUT a flag
+        from super_primitive_amd import _lib
+        st, at = batch.status[:n].cpu().numpy(), batch.attempts[:n].cpu().numpy()
+        flagged = (st & _lib.SP_STATUS_FAILED) != 0
         bad = [dict(pair=int(m), scene_seed=int(jobs[m % G][1]), replica=int(m // G), error_vs_ground_truth=[float(v) for v in err[m]],
-                    start_error=[float(v) for v in err0[m]], iterations=int(n_it[m])) for m in np.nonzero(~conv)[0][:8]]
+                    start_error=[float(v) for v in err0[m]], iterations=int(n_it[m]), status=int(st[m]), flagged=bool(flagged[m])) for m in np.nonzero(~conv)[0][:8]]
+        verdict = {"converged_first_attempt": int(((st == 0) & (at == 0)).sum()), "converged_second_attempt": int(((at > 0) & ~flagged).sum()),
+                   "second_attempts": int((at > 0).sum()), "second_attempt_pairs": np.nonzero(at > 0)[0][:16].tolist(),
+                   "flagged_failed": int(flagged.sum()), "flagged_failed_pairs": np.nonzero(flagged)[0][:16].tolist(),
+                   "false_alarms": int((flagged & conv).sum()), "silent_failures": int((~conv & ~flagged).sum()),
+                   "status_bits": {k: int(((st & getattr(_lib, "SP_STATUS_" + k)) != 0).sum()) for k in ("NONFINITE", "LAST_CAP", "DEPTH_RANGE", "COST", "VALID", "RETRIED", "UNFINISHED")}}
         return {"pairs": n, "frame_pairs_per_sec": n / dt, "converged_fraction": float(conv.mean()), "within_2x_bar_of_ground_truth_fraction": float(bar.mean()),
                 "iterations_per_pair": {"mean": float(n_it.mean()), "min": float(n_it.min()), "max": float(n_it.max())}, "iterations_launched": int(launched),
-                "unconverged": bad,
+                "unconverged": bad, "verdict": verdict,
                 "worst_error_of_converged_vs_ground_truth": ({"rot_rad": float(err[conv, 0].max()), "t": float(err[conv, 1].max()),
                                                               "depth_rel": float(err[conv, 2].max())} if conv.any() else None)}
 
@@ -396,27 +411,40 @@ def main(argv=None):
     for _ in range(args.warmup):
         step()
     K = args.steps
-    ev = [(new_event(), new_event()) for _ in range(K)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(K):
-        ev[k][0].record()
-        batch.cost_pass(0, mode_id)
-        ev[k][1].record()
-        if args.mode == "gn":
-            batch.solve_gn(0)                  # the second launch of the step (solver); gn_step() = cost_pass + this
-        else:
-            batch.solve_adam(0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    k_max = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    def timed_region():
+        """EXACTLY K steps between barrier + synchronize; returns (seconds, max over ranks; mean duration of the cost kernel, HIP events on its stream)."""
+        ev = [(new_event(), new_event()) for _ in range(K)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(K):
+            ev[k][0].record()
+            batch.cost_pass(0, mode_id)
+            ev[k][1].record()
+            if args.mode == "gn":
+                batch.solve_gn(0)                  # the second launch of the step (solver); gn_step() = cost_pass + this
+            else:
+                batch.solve_adam(0)
+        barrier()
+        el = time.perf_counter() - t0
+        km = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        tk = torch.tensor([el, km], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+        return float(tk[0]), float(tk[1]), el, km
+
+    regions = [timed_region()]
+    if args.min_timed_ms > 0 and not dry:
+        # (every rank sees the same max-reduced first region, so every rank repeats the same number of times)
+        more = int(min(200, max(0, np.ceil(1e-3 * args.min_timed_ms / max(regions[0][0], 1e-6)) - 1)))
+        regions += [timed_region() for _ in range(more)]
+    elapsed_max = float(np.mean([r[0] for r in regions]))
+    kern_max = float(np.mean([r[1] for r in regions]))
+    elapsed = float(np.mean([r[2] for r in regions]))           # this rank's own
+    kern_ms = float(np.mean([r[3] for r in regions]))
+
     ranks_proof, rccl_world = None, None
     if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(k_max, op=dist.ReduceOp.MAX)
         # proof that the collective really spanned `world` ranks on `world` different devices: an all_reduce(SUM) of ones, and
         # every rank's {rank, device index, PCI domain:bus:device, its own kernel time and elapsed time, pairs} gathered over
         # the group (the judge / driver can check distinct bus ids and per-rank timings without trusting n_gpus)
@@ -439,14 +467,15 @@ def main(argv=None):
         dist.all_gather(poses_all, batch.pose)
         dist.all_gather(klds_all, batch.kld)
         sync()
-    elapsed = float(t_max.item())
-    kern_ms = float(k_max.item())
+    elapsed = elapsed_max
+    kern_ms = kern_max
 
     alg_bytes = batch.algorithmic_bytes(0)
     value = world * M * K / elapsed
     line = {
         "metric": f"GN iters/sec (640x480x{args.segments}-seg frame pairs)" if args.mode == "gn" else f"Adam iters/sec (640x480x{args.segments}-seg frame pairs)",
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": K, "warmup": args.warmup, "settle_ms": args.settle_ms,
+        "timed_regions": len(regions), "timed_region_ms": [1e3 * r[0] for r in regions][:32],
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Replica-shaped two-frame SfM, 640x480, {args.segments} segments ({'grid, 4 px overlap' if args.shape == 'grid' else f'ragged overlapping ellipses, rho = {args.coverage:g}'}), pyramid "
@@ -775,6 +804,9 @@ def main(argv=None):
                 line["frame_pairs_per_sec_reference_start_all_resident"] = line["reference_start"]["frame_pairs_per_sec"]
                 line["frame_pairs_per_sec_reference_start"] = line["reference_start"]["slot_level_continuous_batching"]["frame_pairs_per_sec"]
                 line["frame_pairs_per_sec"] = line["frame_pairs_per_sec_reference_start"]
+                line["frame_pairs_status"] = dict(line["reference_start"]["slot_level_continuous_batching"]["verdict"],
+                                                  pairs=line["reference_start"]["slot_level_continuous_batching"]["pairs"],
+                                                  unconverged_vs_ground_truth=[u["pair"] for u in line["reference_start"]["slot_level_continuous_batching"]["unconverged"]])
                 line["frame_pairs_per_sec_what"] = ("reference start (pose T_gt Exp(0.05 randn), depth seeds log(2 + 2 rand), multi-octave texture), "
                                                     "REFERENCE_START_SCHEDULE, slot-level continuous batching on one stream; frame_pairs_per_sec_near_start = "
                                                     "round 3's sigma-0.004 figure")

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 10
+#define SP_ABI_VERSION 11
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -294,7 +294,9 @@ int sp_pairs_adam_step(const SpPair* pairs, int n_pairs, int max_N, const float*
 /* Gauss-Newton / Levenberg-Marquardt step from the mode-1 partials: per pair, reduce tiles, eliminate the
  * N diagonal log-depth unknowns (Schur complement onto the 6x6 pose block), solve in fp64, update
  * pose <- Exp(delta)*pose and kld += delta_d.  lm_state: per pair SP_LM_STATE_FLOATS floats {lambda, cost of
- * the last accepted point (init -1), n accepted, n rejected, rejected-last-call flag, last cost seen, 0, 0};
+ * the last accepted point (init -1), n accepted, n rejected, rejected-last-call flag, last cost seen, the valid points of that
+ * evaluation / P, and -- schedules only -- how the pair's last finished phase ended: +iterations = on its cap, -iterations = by
+ * its convergence test};
  * lambda adapts on device (cost up -> step undone from the backup, lambda*=lm_up, re-evaluated next call;
  * cost down -> lambda = max(lambda*lm_down, lm_min)).  backup: per pair (16+max_N) floats.  costs: [n_pairs]. */
 #define SP_LM_STATE_FLOATS 8
@@ -346,16 +348,58 @@ typedef struct SpPhase {
     float irls_eps;
     float conv_tol;
     int32_t flags;               /* SP_PHASE_* */
-    int32_t pad_;
+    int32_t next;                /* the phase a pair moves on to: 0 = the following one (p + 1), k > p = phase k (skips phases p+1..k-1) */
 } SpPhase;               /* 64 bytes */
+/* entry: the phase a fresh pair starts in.  retry_entry: the phase a pair RESTARTS in -- from its initial pose and log-depths, once --
+ * when its verdict at the end of the schedule says it failed (SpVerdict below); -1 = no second attempt.  The phases in front of
+ * `entry` belong to the second attempt only: with phases {R0, R1 (next = J), P0, J, ..., polish}, entry = 2 and retry_entry = 0 a
+ * first attempt runs P0, J, ..., polish and a second one R0, R1, J, ..., polish. */
 typedef struct SpSchedule {
     SpPhase phase[SP_MAX_PHASES];
     int32_t n_phases;
+    int32_t entry;
+    int32_t retry_entry;
     int32_t pad_;
-} SpSchedule;            /* 520 bytes */
+} SpSchedule;            /* 528 bytes */
+
+/* THE VERDICT of a scheduled run, per pair, on the device.  The reference asserts finiteness every iteration and nothing else
+ * (core/dense_optim.py:311,321,340-343); a Gauss-Newton schedule that ends in the wrong basin (about one of the reference's own
+ * starts in a thousand, odometery/two_frame_sfm.py:77-84,103-105) would otherwise hand back a wrong pose silently.  The solver
+ * workgroup that takes a pair out of its last phase writes
+ *   status[pair]  SP_STATUS_* bits; 0 = converged at the first attempt, SP_STATUS_RETRIED alone = converged at the second;
+ *   diag[pair * SP_DIAG_FLOATS]  {final cost, max_n |kld_n - kld0_n|, valid points / points of the last evaluated cost,
+ *                                 iterations spent in the last phase, attempts made, cost at the first evaluation, 0, 0}
+ * and, when (status & retry_mask) and the schedule has a retry_entry and the pair has made one attempt, puts pose and log-depths
+ * back to pose0 / kld0, resets its LM state (lambda = lam0) and restarts it at retry_entry IN THE SAME LAUNCH -- the pair keeps its
+ * slot, the resident set stays full.  A pair's verdict depends on the pair alone (no batch statistics): bitwise what it is alone.
+ * pose0 / kld0: the initial values, laid out like the batch's own pose / kld arrays (pose_base / kld_base: element 0 of those). */
+#define SP_STATUS_NONFINITE   1   /* a non-finite pose entry, log-depth or cost */
+#define SP_STATUS_LAST_CAP    2   /* the last phase ended on its iteration cap, not by its convergence test */
+#define SP_STATUS_DEPTH_RANGE 4   /* some |kld - kld0| > kld_bound: a segment's depth ran away */
+#define SP_STATUS_COST        8   /* final cost > cost_bound (absolute), or > cost_ratio * the cost at the first evaluation */
+#define SP_STATUS_VALID       16  /* valid points of the last evaluated cost < valid_min * points */
+#define SP_STATUS_RETRIED     0x100   /* the verdict is the second attempt's */
+#define SP_STATUS_UNFINISHED  0x200   /* the run ended (max_rounds) before the pair left its last phase */
+#define SP_DIAG_FLOATS 8
+typedef struct SpVerdict {
+    int32_t* status;             /* [pairs] written when a pair finishes (an attempt that is retried leaves nothing) */
+    float* diag;                 /* [pairs * SP_DIAG_FLOATS] */
+    int32_t* attempts;           /* [pairs] zeroed by the caller */
+    const float* pose0;          /* [pairs * 16] */
+    const float* kld0;           /* like the batch's flat log-depth array */
+    const float* pose_base;
+    const float* kld_base;
+    float kld_bound;             /* <= 0: not tested */
+    float cost_bound;            /* <= 0: not tested */
+    float cost_ratio;            /* <= 0: not tested */
+    float valid_min;             /* <= 0: not tested */
+    int32_t retry_mask;          /* status bits that send a pair into its second attempt */
+    float lam0;                  /* LM damping a second attempt starts with */
+} SpVerdict;             /* 80 bytes */
 int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream);
 int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
-                              float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, void* stream);
+                              float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, const SpVerdict* verdict /* or NULL */,
+                              void* stream);
 
 /* The host loop of a scheduled run, natively: issues (sp_pairs_schedule_cost, sp_pairs_schedule_gn_step) up to max_rounds times and,
  * every check_every iterations, reads min(phase) back (one tiny kernel, a 4-byte copy into flag_host -- PINNED host memory -- and a
@@ -367,22 +411,29 @@ int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, f
  * -(1000 + hipError_t) for a runtime error.  This is the one entry point that synchronises the host (with `stream` only). */
 int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
                           float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, int check_every,
-                          int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream);
+                          int max_rounds, int32_t* flag_dev, int32_t* flag_host, const SpVerdict* verdict /* or NULL */, void* stream);
 
 /* SLOT-LEVEL CONTINUOUS BATCHING of a scheduled run.  n_queue pairs are resident (tables, unknowns, descriptors of every phase's
- * level / lattice: qpairs[p][n_queue]); n_slots <= n_queue of them are worked on at a time -- the schedule's phase[p].pairs are the
- * SLOT descriptors (slot_pairs[p] = phase[p].pairs, writable, n_slots records, initially the first n_slots pairs'), its work lists
- * cover n_slots pairs, and lm_state / backup / costs / phase / iters are per slot.  The solver launch that finishes a pair files its
- * result under the pair's index (q_costs[pair], q_lm[pair * SP_LM_STATE_FLOATS]; pose and log-depths live in the pair's own storage),
- * takes the next waiting pair from `head` (device int32, initialised to n_slots; one atomic per finished pair), re-points the slot's
- * descriptors at it (seg_tile_off / tile0 / n_tiles / rec0 stay: the slot's work list fits every pair, which requires the SAME padded
- * layout for all pairs) and restarts the slot at phase 0 with lambda = lam0.  The resident set stays full until the queue is empty:
- * no launch works on a thinning batch except the very last ones.  Which pair lands in which slot depends on timing; every pair's
- * result does not (pairs never interact; bitwise what the pair gives alone).  slot_pair: device [n_slots], initialised 0..n_slots-1.
- * flag_dev / flag_host: TWO int32 each (min phase, queue head).  Otherwise as sp_pairs_schedule_run. */
+ * level / lattice: qpairs[p][n_queue], and the batch's work lists, which cover all n_queue pairs); n_slots <= n_queue of them are
+ * worked on at a time -- the schedule's phase[p].pairs are the SLOT descriptors (slot_pairs[p] = phase[p].pairs, writable, n_slots
+ * records, initially copies of the first n_slots pairs'), and lm_state / backup / costs / phase / iters are per slot.  The cost pass
+ * is launched over VIRTUAL spans: max_spans[p] per slot (the largest span count of any pair in phase p's work list; a multiple of 4
+ * for wave spans); virtual span v belongs to slot v / max_spans[p] and is span  slot descriptor's tile0 + v % max_spans[p]  of the
+ * batch's list when that is below the descriptor's n_tiles, nothing otherwise.  So pairs of DIFFERENT padded layouts (ragged
+ * segment sets: SAM masks, frontend/process_frame.py:207-250) share the slots, and every pair's partial sums are taken over its own
+ * spans in its own order.  The solver launch that finishes a pair files its result under the pair's index (q_costs[pair], q_lm[pair *
+ * SP_LM_STATE_FLOATS], the verdict's status / diag; pose and log-depths live in the pair's own storage), takes the next waiting pair
+ * from `head` (device int32, initialised to n_slots; one atomic per finished pair), copies that pair's descriptor of every phase over
+ * the slot's and restarts the slot at the schedule's entry phase with lambda = lam0.  The resident set stays full until the queue is
+ * empty: no launch works on a thinning batch except the very last ones.  Which pair lands in which slot depends on timing; every
+ * pair's result does not (pairs never interact; bitwise what the pair gives with all pairs resident).  slot_pair: device [n_slots],
+ * initialised 0..n_slots-1.  phase[p].n_spans is ignored (n_slots * max_spans[p] virtual spans are launched).
+ * flag_dev / flag_host: TWO int32 each (min phase, queue head).  Otherwise as sp_pairs_schedule_run; pairs still in a slot when the
+ * run ends on max_rounds get SP_STATUS_UNFINISHED in verdict->status (when given) and their state as it is. */
 typedef struct SpQueue {
     const SpPair* qpairs[SP_MAX_PHASES];
     SpPair* slot_pairs[SP_MAX_PHASES];
+    int32_t max_spans[SP_MAX_PHASES];
     int32_t n_queue;
     int32_t pad_;
     int32_t* head;
@@ -391,10 +442,11 @@ typedef struct SpQueue {
     float* q_lm;
     float lam0;
     int32_t pad2_;
-} SpQueue;               /* 176 bytes */
+} SpQueue;               /* 208 bytes */
 int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, int n_slots, int max_N, float lm_up, float lm_down,
                                 float lm_min, float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters,
-                                int check_every, int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream);
+                                int check_every, int max_rounds, int32_t* flag_dev, int32_t* flag_host, const SpVerdict* verdict /* or NULL */,
+                                void* stream);
 
 /* One optimiser iteration of every pair as a SINGLE launch: the workgroup that completes the last span of a pair
  * runs that pair's update in place (same arithmetic, same fixed reduction order as sp_pairs_cost followed by

@@ -133,10 +133,13 @@ class Chain:
         self.kf_poses = [T(p) for p in out["kf_poses"]]
         self.kf_klds = [T(np.asarray(k, dtype=np.float32)) for k in out["klds"]]
         self.kf_affs = [T(a) for a in out["affs"]]
+        # :949-960 -- ``for indx in range(len(self.supp_kfs_opt[src_id]))``: the latest keyframe's list is empty while it is mapped (:484-485),
+        # so its running supporting frames are optimised but NOT written back (curr_supp keeps the tracked poses)
         q = 0
-        for row in rows:
-            for s in row:
-                s.pose, s.aff = T(out["supp_poses"][q]), T(out["supp_affs"][q])
+        for k, row in enumerate(rows):
+            for j, s in enumerate(row):
+                if self.initialised and j < len(self.supp_opt[k]):
+                    s.pose, s.aff = T(out["supp_poses"][q]), T(out["supp_affs"][q])
                 q += 1
         self.update_track_pose(mode)
         self.initialised = True

@@ -44,9 +44,9 @@ SIGNATURES = {
     "sp_host_layout": [P, I, I, P, I, I, P, P, P, P, P],
     "sp_host_work_list": [P, P, P, I, I, I, I, I, P, P, P, P, P, P],
     "sp_pairs_schedule_cost": [P, P, P],
-    "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P],
-    "sp_pairs_schedule_run": [P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P],
-    "sp_pairs_schedule_run_queue": [P, P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P],
+    "sp_pairs_schedule_gn_step": [P, I, I, F, F, F, P, P, P, P, P, P, P],
+    "sp_pairs_schedule_run": [P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P, P],
+    "sp_pairs_schedule_run_queue": [P, P, I, I, F, F, F, P, P, P, P, P, I, I, P, P, P, P],
     "sp_pairs_adam_iterate": [P, P, P, I, I, I, P, P, P, F, F, F, P, P, P],
     "sp_pairs_gn_iterate": [P, P, P, I, I, I, F, P, P, P, F, F, F, P, P, P, P],
     "sp_window_scratch_doubles": [I, I],
@@ -73,7 +73,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 10
+SP_ABI_VERSION = 11
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GNA_PARTIAL_FLOATS = 48
@@ -130,17 +130,36 @@ class SpPrepImage(ctypes.Structure):
 class SpPhase(ctypes.Structure):
     """Mirror of ``struct SpPhase`` (include/sp_hip.h)."""
     _fields_ = [("pairs", c_void_p), ("chunks", c_void_p), ("spans", c_void_p), ("span_partials", c_void_p), ("seg_partials", c_void_p),
-                ("n_spans", c_int), ("max_iters", c_int), ("irls_eps", c_float), ("conv_tol", c_float), ("flags", c_int), ("pad_", c_int)]
+                ("n_spans", c_int), ("max_iters", c_int), ("irls_eps", c_float), ("conv_tol", c_float), ("flags", c_int), ("next", c_int)]
 
 
 class SpSchedule(ctypes.Structure):
     """Mirror of ``struct SpSchedule``; lives in host memory, passed by address (``ctypes.addressof``)."""
-    _fields_ = [("phase", SpPhase * SP_MAX_PHASES), ("n_phases", c_int), ("pad_", c_int)]
+    _fields_ = [("phase", SpPhase * SP_MAX_PHASES), ("n_phases", c_int), ("entry", c_int), ("retry_entry", c_int), ("pad_", c_int)]
+
+
+SP_STATUS_NONFINITE = 1
+SP_STATUS_LAST_CAP = 2
+SP_STATUS_DEPTH_RANGE = 4
+SP_STATUS_COST = 8
+SP_STATUS_VALID = 16
+SP_STATUS_RETRIED = 0x100
+SP_STATUS_UNFINISHED = 0x200
+SP_STATUS_FAILED = SP_STATUS_NONFINITE | SP_STATUS_LAST_CAP | SP_STATUS_DEPTH_RANGE | SP_STATUS_COST | SP_STATUS_VALID | SP_STATUS_UNFINISHED
+SP_DIAG_FLOATS = 8
+
+
+class SpVerdict(ctypes.Structure):
+    """Mirror of ``struct SpVerdict`` (include/sp_hip.h): the per-pair verdict of a scheduled run and its one second attempt."""
+    _fields_ = [("status", c_void_p), ("diag", c_void_p), ("attempts", c_void_p), ("pose0", c_void_p), ("kld0", c_void_p),
+                ("pose_base", c_void_p), ("kld_base", c_void_p), ("kld_bound", c_float), ("cost_bound", c_float), ("cost_ratio", c_float),
+                ("valid_min", c_float), ("retry_mask", c_int), ("lam0", c_float)]
 
 
 class SpQueue(ctypes.Structure):
     """Mirror of ``struct SpQueue`` (include/sp_hip.h): slot-level continuous batching of a scheduled run; host memory."""
-    _fields_ = [("qpairs", c_void_p * SP_MAX_PHASES), ("slot_pairs", c_void_p * SP_MAX_PHASES), ("n_queue", c_int), ("pad_", c_int),
+    _fields_ = [("qpairs", c_void_p * SP_MAX_PHASES), ("slot_pairs", c_void_p * SP_MAX_PHASES), ("max_spans", c_int * SP_MAX_PHASES),
+                ("n_queue", c_int), ("pad_", c_int),
                 ("head", c_void_p), ("slot_pair", c_void_p), ("q_costs", c_void_p), ("q_lm", c_void_p), ("lam0", c_float), ("pad2_", c_int)]
 
 

@@ -986,12 +986,13 @@ struct SchedList {            // one work list of a launch over SEVERAL (k_cost_
     int32_t n_spans;
     int32_t first_block;      // its workgroups are blockIdx.x - first_block (a multiple of 8: the XCD of a block stays blockIdx.x % 8)
     uint32_t mask;            // bit p: phase p runs on this list
-    int32_t pad_;
+    int32_t vspans;           // > 0: a queue run's VIRTUAL spans (SpQueue.max_spans): n_spans = slots * vspans, see k_cost_pairs
 };
 struct SchedCost {            // what the cost kernel needs of an SpSchedule
     const SpPair* pairs[SP_MAX_PHASES];
     float irls_eps[SP_MAX_PHASES];
     uint32_t mask;            // bit p: phase p runs on the work list of this launch (launch over ONE list)
+    int32_t vspans;           // ... and that list's virtual spans per slot (queue runs), 0 otherwise
     int32_t n_lists;          // > 0: the launch covers `list[0 .. n_lists)`, one after the other in block order
     SchedList list[SP_SCHED_LISTS];
 };
@@ -1012,6 +1013,7 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED != 0 ? 1 : (MODE == 2 ? 2 : 4)) voi
     __shared__ float lds[SP_WAVES * NV];
     int block = blockIdx.x;
     uint32_t phase_mask = f.sched.mask;
+    int vspans = f.sched.vspans;
     if (f.phase && f.sched.n_lists > 0) {
         // One launch over the work lists of a schedule's iteration (the coarse levels' decimated tables and the full one), which
         // took a launch each: the lists of an iteration are independent, mostly small, and one after the other each drained
@@ -1024,20 +1026,38 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED != 0 ? 1 : (MODE == 2 ? 2 : 4)) voi
         block -= sl.first_block;
         chunks = sl.chunks; spans = sl.spans; n_spans = sl.n_spans; partials = sl.partials; seg_partials = sl.seg_partials;
         phase_mask = sl.mask;
+        vspans = sl.vspans;
     }
     // (wave spans: the four waves of the workgroup take four consecutive spans)
-    const int w = W64 ? 4 * xcd_chunked_tile(block, (n_spans + 3) >> 2) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
-                      : xcd_chunked_tile(block, n_spans);
+    int w = W64 ? 4 * xcd_chunked_tile(block, (n_spans + 3) >> 2) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))
+                : xcd_chunked_tile(block, n_spans);
     if (w >= n_spans) return;
-    const int4 span = spans[w];             // {first chunk, number of chunks, points, pair}
-    if (f.done && f.done[span.w]) return;   // converged pair (sp_pairs_cost_active): nothing to evaluate
-    if (f.phase) {
-        const int ph = f.phase[span.w];
-        if (ph >= SP_MAX_PHASES || !((phase_mask >> ph) & 1u)) return;
+    int owner;                              // index of the span's pair in `pairs` / `phase` (a slot, in a queue run)
+    int4 span;                              // {first chunk, number of chunks, points, pair}
+    if (MODE == 1 && FUSED == 0 && f.phase && vspans > 0) {
+        // QUEUE RUN (SpQueue): the launch is over virtual spans, `vspans` per slot; virtual span j of a slot is span tile0 + j of the
+        // pair the slot works on right now (its descriptor carries the pair's own span range of the batch's list), or nothing
+        owner = w / vspans;
+        const int j = w - owner * vspans;
+        const int ph = f.phase[owner];
+        if (ph >= SP_MAX_PHASES || ph < 0 || !((phase_mask >> ph) & 1u)) return;
         pairs = f.sched.pairs[ph];
         irls_eps = f.sched.irls_eps[ph];
+        if (j >= pairs[owner].n_tiles) return;
+        w = pairs[owner].tile0 + j;
+        span = spans[w];
+    } else {
+        span = spans[w];
+        owner = span.w;
+        if (f.done && f.done[owner]) return;    // converged pair (sp_pairs_cost_active): nothing to evaluate
+        if (f.phase) {
+            const int ph = f.phase[owner];
+            if (ph >= SP_MAX_PHASES || ph < 0 || !((phase_mask >> ph) & 1u)) return;
+            pairs = f.sched.pairs[ph];
+            irls_eps = f.sched.irls_eps[ph];
+        }
     }
-    const SpPair& pr = pairs[span.w];
+    const SpPair& pr = pairs[owner];
     TileCtx c;
     c.pix = (gptr_u32)pr.pix;
     c.src4 = (gptr_f4)pr.src4;
@@ -1290,22 +1310,24 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
     return 0;
 }
 
-int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) { return schedule_cost_from(sched, phase, stream, 0); }
+int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) { return schedule_cost_from(sched, phase, stream, 0, nullptr, 0); }
 
 }  // extern "C"
 
 // first_phase: a phase every pair is known to have reached (pairs only move forward): work lists none of whose phases is at or
 // beyond it have no pair left and are not launched -- two of the three launches of a frame-pair schedule's iteration through
 // its long tail (sp_pairs_schedule_run).
-int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase) {
+// queue / n_slots: a queue run (sp_pairs_schedule_run_queue) -- every list is launched over n_slots * max_spans virtual spans.
+int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase, const SpQueue* queue, int n_slots) {
     if (!sched || !phase || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
+    if (queue && n_slots <= 0) return SP_EINVAL;
     for (int p = 0; p < sched->n_phases; ++p) {
         const SpPhase& ph = sched->phase[p];
         if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.n_spans < 0) return SP_EINVAL;
         if (ph.n_spans > 0 && (!ph.chunks || !ph.spans)) return SP_EINVAL;
     }
     // the distinct work lists that still have pairs (phases sharing `spans` share the list)
-    struct Lead { int p; uint32_t mask; };
+    struct Lead { int p; uint32_t mask; int n_spans; int vspans; };
     Lead leads[SP_MAX_PHASES];
     int n_leads = 0;
     uint32_t seen = 0;
@@ -1325,24 +1347,27 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
             if (ph.spans != lead.spans || ph.n_spans != lead.n_spans) continue;
             if (ph.chunks != lead.chunks || ph.span_partials != lead.span_partials || ph.seg_partials != lead.seg_partials ||
                 ((ph.flags ^ lead.flags) & (SP_PHASE_WAVE_SPANS | SP_PHASE_DEPTH_TABLE))) return SP_EINVAL;
+            if (queue && queue->max_spans[q] != queue->max_spans[p]) return SP_EINVAL;
             mask |= 1u << q;
         }
         seen |= mask;
         if ((mask >> first_phase) == 0u) continue;      // (every phase of this work list lies behind all pairs)
-        leads[n_leads++] = Lead{p, mask};
+        const int vspans = queue ? queue->max_spans[p] : 0;
+        if (queue && vspans == 0) continue;
+        leads[n_leads++] = Lead{p, mask, queue ? n_slots * vspans : lead.n_spans, vspans};
     }
     if (n_leads == 0) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const auto blocks_of = [&](const SpPhase& ph) { return (ph.flags & SP_PHASE_WAVE_SPANS) ? ((((ph.n_spans + 3) / 4) + 7) / 8) * 8 : ((ph.n_spans + 7) / 8) * 8; };
+    const auto blocks_of = [&](const SpPhase& ph, int n_spans) { return (ph.flags & SP_PHASE_WAVE_SPANS) ? ((((n_spans + 3) / 4) + 7) / 8) * 8 : ((n_spans + 7) / 8) * 8; };
     // the four kinds of a scheduled Gauss-Newton pass: wave spans or workgroup spans, depth tables or log-depth tables
-    const auto launch_sched = [&](const SpPhase& lead, int blocks) {
+    const auto launch_sched = [&](const SpPhase& lead, int n_spans, int blocks) {
         const int4* c4 = reinterpret_cast<const int4*>(lead.chunks);
         const int4* s4 = reinterpret_cast<const int4*>(lead.spans);
         const bool w64 = (lead.flags & SP_PHASE_WAVE_SPANS) != 0, dt = (lead.flags & SP_PHASE_DEPTH_TABLE) != 0;
-        if (w64 && dt) hipLaunchKernelGGL((k_cost_pairs<1, 6, 0, true>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
-        else if (w64) hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
-        else if (dt) hipLaunchKernelGGL((k_cost_pairs<1, 6>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
-        else hipLaunchKernelGGL(k_cost_pairs<1>, dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, lead.n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        if (w64 && dt) hipLaunchKernelGGL((k_cost_pairs<1, 6, 0, true>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        else if (w64) hipLaunchKernelGGL((k_cost_pairs<1, 0, 0, true>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        else if (dt) hipLaunchKernelGGL((k_cost_pairs<1, 6>), dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
+        else hipLaunchKernelGGL(k_cost_pairs<1>, dim3(blocks), dim3(SP_BLOCK), 0, s, lead.pairs, c4, s4, n_spans, lead.irls_eps, lead.span_partials, lead.seg_partials, f);
     };
     bool same_kind = n_leads <= SP_SCHED_LISTS;
     for (int i = 1; i < n_leads; ++i) same_kind = same_kind && !((sched->phase[leads[i].p].flags ^ sched->phase[leads[0].p].flags) & (SP_PHASE_WAVE_SPANS | SP_PHASE_DEPTH_TABLE));
@@ -1352,19 +1377,20 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
         for (int i = 0; i < n_leads; ++i) {
             const SpPhase& ph = sched->phase[leads[i].p];
             f.sched.list[i] = SchedList{reinterpret_cast<const int4*>(ph.chunks), reinterpret_cast<const int4*>(ph.spans), ph.span_partials, ph.seg_partials,
-                                        ph.n_spans, total, leads[i].mask, 0};
-            total += blocks_of(ph);
+                                        leads[i].n_spans, total, leads[i].mask, leads[i].vspans};
+            total += blocks_of(ph, leads[i].n_spans);
         }
         f.sched.n_lists = n_leads;
         const SpPhase& lead = sched->phase[leads[0].p];
-        launch_sched(lead, total);
+        launch_sched(lead, leads[0].n_spans, total);
         SP_CHECK_LAUNCH();
         return 0;
     }
     for (int i = 0; i < n_leads; ++i) {
         const SpPhase& lead = sched->phase[leads[i].p];
         f.sched.mask = leads[i].mask;
-        launch_sched(lead, blocks_of(lead));
+        f.sched.vspans = leads[i].vspans;
+        launch_sched(lead, leads[i].n_spans, blocks_of(lead, leads[i].n_spans));
         SP_CHECK_LAUNCH();
     }
     return 0;
@@ -1396,7 +1422,7 @@ int sp_pairs_gn_iterate(const SpPair* pairs, const int32_t* chunks, const int32_
         return SP_EINVAL;
     FuseArgs f{};
     f.arrivals = arrivals;
-    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, nullptr, nullptr, 0, 0};
+    f.gn = GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, nullptr, nullptr, 0, 0, 0};
     const int gx = ((n_spans + 7) / 8) * 8;
     hipLaunchKernelGGL((k_cost_pairs<1, 0, 2>), dim3(gx), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), pairs,
                        reinterpret_cast<const int4*>(chunks), reinterpret_cast<const int4*>(spans), n_spans, irls_eps, partials, seg_partials, f);

@@ -256,7 +256,17 @@ struct GnArgs {
     int32_t* iters;          // ... iterations spent in the current phase
     int max_iters;           // ... of at most this many
     int pose_only;           // SP_PHASE_POSE_ONLY: no Schur complement, no depth update
+    int next_phase;          // ... the phase that follows the current one (SpPhase.next)
 };
+
+// a pair leaves its current phase (thread 0): the next one starts afresh; lm_state[7] records how this one ended
+// (+iterations = on its cap, -iterations = by its convergence test)
+__device__ __forceinline__ void leave_phase(const GnArgs& h, int pi, float* __restrict__ ls, int spent, bool on_cap) {
+    h.phase[pi] = h.next_phase;
+    h.iters[pi] = 0;
+    ls[1] = -1.f;
+    ls[7] = on_cap ? (float)spent : -(float)spent;
+}
 
 // One workgroup: tile-partial reduction + Schur-complement LM step of pair `pi` (include/sp_hip.h sp_pairs_gn_step).
 __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int pi, const float* __restrict__ partials,
@@ -291,10 +301,11 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         if (!rej && (h.done || h.phase) && h.conv_tol > 0.f && last >= 0.f && ls[4] == 0.f && (last - (float)cost) <= h.conv_tol * last) {
             rej = 2;
             if (h.done) h.done[pi] = 1;
-            if (h.phase) { h.phase[pi] += 1; h.iters[pi] = 0; ls[1] = -1.f; ls[4] = 0.f; }      // next phase starts afresh
+            if (h.phase) { leave_phase(h, pi, ls, h.iters[pi], false); ls[4] = 0.f; }
         }
         decision = rej;
         ls[5] = (float)cost;
+        ls[6] = (float)(sums[28] / (double)pr.P);
         costs[pi] = (float)cost;
     }
     __syncthreads();
@@ -307,7 +318,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
             ls[0] *= lm_up; ls[3] += 1.f; ls[4] = 1.f;
             if (h.phase) {                          // a rejected iteration counts towards the phase's budget like an accepted one
                 const int n = h.iters[pi] + 1;
-                if (n >= h.max_iters) { h.phase[pi] += 1; h.iters[pi] = 0; ls[1] = -1.f; ls[4] = 0.f; }
+                if (n >= h.max_iters) { leave_phase(h, pi, ls, n, true); ls[4] = 0.f; }
                 else h.iters[pi] = n;
             }
         }
@@ -373,7 +384,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         ls[0] = lambda; ls[1] = (float)cost; ls[2] += 1.f; ls[4] = 0.f;
         if (h.phase) {                              // iteration budget of the phase (the step computed here is still applied)
             const int n = h.iters[pi] + 1;
-            if (n >= h.max_iters) { h.phase[pi] += 1; h.iters[pi] = 0; ls[1] = -1.f; }
+            if (n >= h.max_iters) leave_phase(h, pi, ls, n, true);
             else h.iters[pi] = n;
         }
     }

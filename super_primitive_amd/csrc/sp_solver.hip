@@ -17,32 +17,96 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
     solve_gn(pairs, blockIdx.x, partials, seg_partials, h);
 }
 
-static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 520, "SpSchedule is part of the ABI");
+static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 528 && sizeof(SpVerdict) == 80 && sizeof(SpQueue) == 208 && sizeof(SpPair) == 136,
+              "SpSchedule / SpVerdict / SpQueue / SpPair are part of the ABI");
 
 // per-pair schedules: the pair's current phase selects the level descriptors, the partial records of that level's work list,
 // the convergence threshold and the iteration budget.
+// THE VERDICT (SpVerdict, v.status != NULL): the workgroup that takes a pair out of its last phase looks at what it ended with --
+// finiteness, how the last phase ended, the largest log-depth excursion from the initial values, the final cost, the valid
+// fraction -- and either files status / diag under the pair's index or, once per pair, puts the pair back to its initial values
+// and restarts it at the schedule's retry_entry (a second attempt on a different phase list) in the slot it already has.
 // SLOT-LEVEL CONTINUOUS BATCHING (SpQueue, q.n_queue > 0): the launch's "pairs" are SLOTS of a resident set; the slot whose pair just
-// finished its last phase files the pair's result under the pair's own index, takes the next waiting pair off the queue (one atomic
-// per finished pair), re-points its descriptor of every phase at that pair's tables / unknowns and starts it at phase 0 -- in this very
-// launch, so the next cost pass already works on the new pair and the resident set stays full until the queue is empty.  Pairs never
-// interact and a slot's work list fits every pair (same padded layout): each pair's result is bitwise what it is alone.
-__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, GnArgs h, SpQueue q) {
+// finished files the pair's result under the pair's own index, takes the next waiting pair off the queue (one atomic per finished
+// pair), copies that pair's descriptor of every phase over its own and starts it at the entry phase -- in this very launch, so the
+// next cost pass already works on the new pair and the resident set stays full until the queue is empty.  Pairs never interact and a
+// descriptor carries the pair's own span range (the cost pass of a queue run is launched over virtual spans): each pair's result
+// is bitwise what it is with all pairs resident.
+__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, GnArgs h, SpQueue q, SpVerdict v) {
     const int slot = blockIdx.x;
     const int ph = h.phase[slot];
-    if (ph >= sched.n_phases) return;           // finished, and the queue was empty when it did
+    if (ph >= sched.n_phases || ph < 0) return;           // finished, and the queue was empty when it did
     {
         const SpPhase& s = sched.phase[ph];
         h.conv_tol = s.conv_tol;
         h.max_iters = s.max_iters;
         h.pose_only = s.flags & SP_PHASE_POSE_ONLY;
+        h.next_phase = s.next > 0 ? s.next : ph + 1;
         solve_gn(s.pairs, slot, s.span_partials, s.seg_partials, h);
     }
-    if (q.n_queue <= 0) return;
-    __shared__ int next_s;
+    if (q.n_queue <= 0 && !v.status) return;
+    __shared__ int next_s, retry_s;
+    __shared__ float dmax_s[SP_WAVES];
+    __shared__ int bad_s[SP_WAVES];
     __syncthreads();                            // every write of solve_gn (thread 0's phase update included) is visible
-    if (h.phase[slot] < sched.n_phases) return;
-    const int pid = q.slot_pair[slot];
+    const int pid = q.n_queue > 0 ? q.slot_pair[slot] : slot;
     float* ls = h.lm_state + (size_t)slot * SP_LM_STRIDE;
+    if (v.diag && threadIdx.x == 0) {           // the cost a pair's attempt starts from (diag[5], zeroed by the caller)
+        float* first = v.diag + (size_t)pid * SP_DIAG_FLOATS + 5;
+        if (*first == 0.f) *first = h.costs[slot];
+    }
+    if (h.phase[slot] < sched.n_phases) return;
+    // ---- the pair has just left its last phase ----
+    if (v.status) {
+        const SpPair& pr = sched.phase[ph].pairs[slot];
+        const float* kld0 = v.kld0 + (pr.kld - v.kld_base);
+        const float* pose0 = v.pose0 + (pr.pose - v.pose_base);
+        float dmax = 0.f;
+        int bad = 0;
+        for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
+            const float d = fabsf(pr.kld[n] - kld0[n]);
+            if (!(d <= 3.0e38f)) bad = 1;       // (NaN and infinity both fail the comparison)
+            else dmax = fmaxf(dmax, d);
+        }
+        if (threadIdx.x < 12 && !(fabsf(pr.pose[threadIdx.x]) <= 3.0e38f)) bad = 1;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); bad |= __shfl_xor(bad, o, 64); }
+        if ((threadIdx.x & 63) == 0) { dmax_s[threadIdx.x >> 6] = dmax; bad_s[threadIdx.x >> 6] = bad; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            dmax = fmaxf(fmaxf(dmax_s[0], dmax_s[1]), fmaxf(dmax_s[2], dmax_s[3]));
+            bad = bad_s[0] | bad_s[1] | bad_s[2] | bad_s[3];
+            const float cost = ls[5], first = v.diag ? v.diag[(size_t)pid * SP_DIAG_FLOATS + 5] : 0.f;
+            int st = 0;
+            if (bad || !(fabsf(cost) <= 3.0e38f)) st |= SP_STATUS_NONFINITE;
+            if (ls[7] > 0.f) st |= SP_STATUS_LAST_CAP;
+            if (v.kld_bound > 0.f && dmax > v.kld_bound) st |= SP_STATUS_DEPTH_RANGE;
+            if ((v.cost_bound > 0.f && cost > v.cost_bound) || (v.cost_ratio > 0.f && first > 0.f && cost > v.cost_ratio * first)) st |= SP_STATUS_COST;
+            if (v.valid_min > 0.f && ls[6] < v.valid_min) st |= SP_STATUS_VALID;
+            const int attempt = v.attempts ? v.attempts[pid] : 1;
+            const int again = (st & v.retry_mask) != 0 && attempt == 0 && sched.retry_entry >= 0 && sched.retry_entry < sched.n_phases;
+            retry_s = again;
+            if (again) {
+                v.attempts[pid] = 1;
+                h.phase[slot] = sched.retry_entry; h.iters[slot] = 0;
+                ls[0] = v.lam0; ls[1] = -1.f; ls[4] = 0.f; ls[7] = 0.f;       // (the iteration counts [2], [3] run on over both attempts)
+                if (v.diag) v.diag[(size_t)pid * SP_DIAG_FLOATS + 5] = 0.f;
+            } else {
+                v.status[pid] = st | (attempt > 0 && v.attempts ? SP_STATUS_RETRIED : 0);
+                if (v.diag) {
+                    float* d = v.diag + (size_t)pid * SP_DIAG_FLOATS;
+                    d[0] = cost; d[1] = dmax; d[2] = ls[6]; d[3] = fabsf(ls[7]); d[4] = (float)(attempt + (v.attempts ? 1 : 0)); d[6] = 0.f; d[7] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (retry_s) {
+            for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) pr.kld[n] = kld0[n];
+            if (threadIdx.x < 16) pr.pose[threadIdx.x] = pose0[threadIdx.x];
+            return;                             // the pair keeps its slot
+        }
+    }
+    if (q.n_queue <= 0) return;
     if (threadIdx.x < SP_LM_STRIDE) q.q_lm[(size_t)pid * SP_LM_STRIDE + threadIdx.x] = ls[threadIdx.x];
     if (threadIdx.x == 0) {
         q.q_costs[pid] = h.costs[slot];
@@ -51,24 +115,28 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
     __syncthreads();
     const int next = next_s;
     if (next >= q.n_queue) return;              // nothing is waiting: the slot stays finished
-    if (threadIdx.x < sched.n_phases) {
-        // (phases of one level / lattice share a descriptor array: they write the same values)
-        const SpPair& src = q.qpairs[threadIdx.x][next];
-        SpPair& dst = q.slot_pairs[threadIdx.x][slot];
-        dst.pix = src.pix; dst.src4 = src.src4; dst.kp_L = src.kp_L; dst.trg3 = src.trg3;
-        dst.kld = src.kld; dst.pose = src.pose; dst.aff = src.aff;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { dst.K_src[i] = src.K_src[i]; dst.K_trg[i] = src.K_trg[i]; }
-        dst.N = src.N; dst.P = src.P; dst.H = src.H; dst.W = src.W; dst.Hl = src.Hl; dst.Wl = src.Wl; dst.zmin = src.zmin;
-        // (seg_tile_off, tile0, n_tiles, rec0 belong to the slot's work list and stay)
+    {
+        // the waiting pair's descriptor of every phase over the slot's (phases of one level / lattice share a descriptor array: they
+        // write the same values) -- whole records: the pair brings its own span range and record offsets
+        constexpr int WORDS = (int)(sizeof(SpPair) / sizeof(uint32_t));
+        for (int i = threadIdx.x; i < sched.n_phases * WORDS; i += SP_BLOCK) {
+            const int p = i / WORDS, k = i - p * WORDS;
+            reinterpret_cast<uint32_t*>(q.slot_pairs[p] + slot)[k] = reinterpret_cast<const uint32_t*>(q.qpairs[p] + next)[k];
+        }
     }
     if (threadIdx.x == 0) {
-        h.phase[slot] = 0; h.iters[slot] = 0;
-        ls[0] = q.lam0; ls[1] = -1.f; ls[2] = 0.f; ls[3] = 0.f; ls[4] = 0.f;
+        h.phase[slot] = sched.entry; h.iters[slot] = 0;
+        ls[0] = q.lam0; ls[1] = -1.f; ls[2] = 0.f; ls[3] = 0.f; ls[4] = 0.f; ls[5] = 0.f; ls[6] = 0.f; ls[7] = 0.f;
         q.slot_pair[slot] = next;
     }
 }
 
+// pairs still in a slot when a queue run ends on its round limit: SP_STATUS_UNFINISHED under the pair's index
+__global__ void k_mark_unfinished(const int32_t* __restrict__ phase, const int32_t* __restrict__ slot_pair, int n_slots, int n_phases,
+                                  int32_t* __restrict__ status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_slots && phase[i] < n_phases) status[slot_pair ? slot_pair[i] : i] = SP_STATUS_UNFINISHED;
+}
 
 // min over the per-pair phases (one workgroup): what the host polls to end a scheduled run
 __global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restrict__ phase, int n, int32_t* __restrict__ out,
@@ -151,42 +219,61 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
     return 0;
 }
 
-int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
-                              float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, void* stream) {
-    if (!sched || !lm_state || !backup || !costs || !phase || !iters || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
-    if (sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
+// what every scheduled entry point checks of an SpSchedule (and of the verdict that goes with it)
+static int check_schedule(const SpSchedule* sched, const SpVerdict* v) {
+    if (!sched || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
+    if (sched->entry < 0 || sched->entry >= sched->n_phases || sched->retry_entry < -1 || sched->retry_entry >= sched->n_phases) return SP_EINVAL;
     for (int p = 0; p < sched->n_phases; ++p) {
         const SpPhase& ph = sched->phase[p];
         if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.max_iters <= 0) return SP_EINVAL;
+        if (ph.next != 0 && (ph.next <= p || ph.next > sched->n_phases)) return SP_EINVAL;      // pairs only move forward
     }
+    if (v && v->status) {
+        if (!v->pose0 || !v->kld0 || !v->pose_base || !v->kld_base) return SP_EINVAL;
+        if (sched->retry_entry >= 0 && v->retry_mask != 0 && !v->attempts) return SP_EINVAL;
+    }
+    return 0;
+}
+
+int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
+                              float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, const SpVerdict* verdict,
+                              void* stream) {
+    if (!sched || !lm_state || !backup || !costs || !phase || !iters || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
+    if (int rc = check_schedule(sched, verdict)) return rc;
     hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), *sched,
-                       GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0}, SpQueue{});
+                       GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0}, SpQueue{},
+                       verdict ? *verdict : SpVerdict{});
     SP_CHECK_LAUNCH();
     return 0;
 }
 
 int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, int n_slots, int max_N, float lm_up, float lm_down,
                                 float lm_min, float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters,
-                                int check_every, int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream) {
+                                int check_every, int max_rounds, int32_t* flag_dev, int32_t* flag_host, const SpVerdict* verdict, void* stream) {
     if (!sched || !queue || !phase || !iters || !flag_dev || !flag_host || !lm_state || !backup || !costs) return SP_EINVAL;
     if (check_every <= 0 || max_rounds < 0 || n_slots <= 0 || max_N <= 0 || queue->n_queue < n_slots) return SP_EINVAL;
-    if (sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
+    if (int rc = check_schedule(sched, verdict)) return rc;
     if (!queue->head || !queue->slot_pair || !queue->q_costs || !queue->q_lm) return SP_EINVAL;
     for (int p = 0; p < sched->n_phases; ++p) {
         const SpPhase& ph = sched->phase[p];
-        if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.max_iters <= 0) return SP_EINVAL;
-        if (!queue->qpairs[p] || queue->slot_pairs[p] != ph.pairs) return SP_EINVAL;
+        if (!queue->qpairs[p] || queue->slot_pairs[p] != ph.pairs || queue->max_spans[p] < 0) return SP_EINVAL;
+        if ((ph.flags & SP_PHASE_WAVE_SPANS) && (queue->max_spans[p] & 3)) return SP_EINVAL;
+        if ((long long)queue->max_spans[p] * n_slots > 0x7fffffffLL) return SP_ELIMIT;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const SpVerdict vd = verdict ? *verdict : SpVerdict{};
+    // a second attempt restarts a pair at retry_entry at any time: no work list can be left out while that may still happen
+    const bool may_retry = vd.status && vd.retry_mask != 0 && sched->retry_entry >= 0;
     int it = 0;
-    int reached = 0;                  // a phase every slot has passed -- only meaningful once the queue is empty (refilled slots restart at 0)
+    int reached = 0;                  // a phase every slot has passed -- only meaningful once the queue is empty (refilled slots restart at the entry)
+    int min_phase = 0;
     while (it < max_rounds) {
         const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
         for (int k = 0; k < n; ++k, ++it) {
-            int rc = schedule_cost_from(sched, phase, stream, reached);
+            int rc = schedule_cost_from(sched, phase, stream, reached, queue, n_slots);
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
             hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_slots), dim3(SP_BLOCK), 0, s, *sched,
-                               GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0}, *queue);
+                               GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0}, *queue, vd);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return -(1000 + (int)e);
         }
@@ -195,28 +282,37 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
         if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
-        const int min_phase = static_cast<volatile int32_t*>(flag_host)[0], head = static_cast<volatile int32_t*>(flag_host)[1];
+        min_phase = static_cast<volatile int32_t*>(flag_host)[0];
+        const int head = static_cast<volatile int32_t*>(flag_host)[1];
         if (min_phase >= sched->n_phases) break;          // (a slot only stays finished when the queue was empty)
-        reached = head >= queue->n_queue ? (min_phase < 0 ? 0 : min_phase) : 0;
+        reached = (head >= queue->n_queue && !may_retry) ? (min_phase < 0 ? 0 : min_phase) : 0;
+    }
+    if (min_phase < sched->n_phases && vd.status) {
+        hipLaunchKernelGGL(k_mark_unfinished, dim3((n_slots + 255) / 256), dim3(256), 0, s, phase, queue->slot_pair, n_slots, sched->n_phases, vd.status);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return -(1000 + (int)e);
     }
     return it;
 }
 
 int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
                           float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, int check_every,
-                          int max_rounds, int32_t* flag_dev, int32_t* flag_host, void* stream) {
+                          int max_rounds, int32_t* flag_dev, int32_t* flag_host, const SpVerdict* verdict, void* stream) {
     if (!sched || !phase || !iters || !flag_dev || !flag_host || check_every <= 0 || max_rounds < 0) return SP_EINVAL;
+    if (int rc = check_schedule(sched, verdict)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool may_retry = verdict && verdict->status && verdict->retry_mask != 0 && sched->retry_entry >= 0;
     int it = 0;
     int reached = 0;                  // min(phase) at the last poll: pairs only move forward, so work lists behind it are not launched
+    int min_phase = 0;
     // (Staying one group of iterations AHEAD of the poll being waited for -- events instead of a stream synchronisation, the GPU
     //  never idle while the host wakes up -- measured no better than this loop, 30.1 k against 30.7 k frame pairs/s: the tail of a
     //  schedule is bound by the latency of a few pairs' own iterations, ~50 us each, not by the launch path.)
     while (it < max_rounds) {
         const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
         for (int k = 0; k < n; ++k, ++it) {
-            int rc = schedule_cost_from(sched, phase, stream, reached);
-            if (rc == 0) rc = sp_pairs_schedule_gn_step(sched, n_pairs, max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, phase, iters, stream);
+            int rc = schedule_cost_from(sched, phase, stream, reached, nullptr, 0);
+            if (rc == 0) rc = sp_pairs_schedule_gn_step(sched, n_pairs, max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, phase, iters, verdict, stream);
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
         }
         hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_pairs, flag_dev);
@@ -224,9 +320,15 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
         if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
-        reached = *static_cast<volatile int32_t*>(flag_host);
+        reached = min_phase = *static_cast<volatile int32_t*>(flag_host);
         if (reached >= sched->n_phases) break;
-        if (reached < 0) reached = 0;
+        // (a second attempt restarts a pair at retry_entry at any time: no work list can be left out while that may still happen)
+        if (reached < 0 || may_retry) reached = 0;
+    }
+    if (verdict && verdict->status && min_phase < sched->n_phases) {
+        hipLaunchKernelGGL(k_mark_unfinished, dim3((n_pairs + 255) / 256), dim3(256), 0, s, phase, (const int32_t*)nullptr, n_pairs, sched->n_phases, verdict->status);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return -(1000 + (int)e);
     }
     return it;
 }

@@ -13,7 +13,8 @@ sits on the hot path, with the reference's own bookkeeping of keyframes, support
     supporting frames       at most ``supp_every_n - 1`` evenly spaced frames of the tracked pool become the supporting frames of a
                             keyframe when its successor is created (``collect_tracking_frames(last=False)``, ``:1327-1360``); the
                             latest keyframe is supported by the last two tracked frames (``last=True``); ``update_track_pose``
-                            (``:969-983``) hands the mapped pose of the newest frame back to the tracker
+                            (``:969-983``) hands the newest frame's pose back to the tracker -- its TRACKED pose: the write-back after
+                            a mapping (``:949-960``) skips the latest keyframe's running supporting frames
 
 on the HIP kernels, with nothing of the reference's frontend, GUI queues, checkpoints or dataset loaders (out of scope, SURVEY.md
 section 2).  Every step is one of the drop-in functions the reference's driver calls (``core.depth_render.estimate_depth_kf_native``,
@@ -170,11 +171,16 @@ class MonoVO:
         self.kf_klds = [k.clone() for k in out['klds']]
         if self.affine:
             self.kf_affs = [a.clone() for a in out['affs']]
-        for k, row in enumerate(rows):                            # (:949-960; rows are empty when the system was not initialised)
-            for j, s in enumerate(row):
-                s.pose = out['supp_poses'][k][j].clone()
-                if self.affine:
-                    s.aff = out['supp_affs'][k][j].clone()
+        # write-back of the supporting frames, odometery.py:949-960: the loop runs over ``range(len(self.supp_kfs_opt[src_id]))``, and the
+        # latest keyframe's entry of that list is empty while it is being mapped (asserted, :484-485) -- so the RUNNING supporting frames of
+        # the latest keyframe take part in the optimisation but keep their tracked poses and affine pairs afterwards, and
+        # ``update_track_pose`` hands the tracker the un-mapped pose of the newest frame.  Mirrored exactly.
+        if self.initialised:
+            for k in range(K):
+                for j, s in enumerate(self.supp_opt[k]):
+                    s.pose = out['supp_poses'][k][j].clone()
+                    if self.affine:
+                        s.aff = out['supp_affs'][k][j].clone()
         self.n_map[mode] += 1
         if self.tracker is not None:                              # the latest keyframe moved
             self.tracker.update_keyframe(self.kf_klds[-1], self.kf_poses[-1], self.kf_affs[-1] if self.affine else None)

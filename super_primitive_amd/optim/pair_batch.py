@@ -52,17 +52,29 @@ FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps
 # randn(6)), depth seeds log(2 + 2 rand)): tests/test_gpu_sigma05.py requires it to converge wherever the real reference loop does
 # (golden g19), inside the north-star bar of the reference's end state; bench.py quotes ``frame_pairs_per_sec`` on it next to the
 # near-start figure (tools/sigma05_sweep.py holds the sweep it was chosen from, profiles/r03_sigma05_sweep.txt its results).
-REFERENCE_START_LEVELS = (0, 3)
-REFERENCE_START_POINT_STRIDE = (2, 2, 4)
+# Round 5: the batch carries a FOURTH pyramid level (80x60 at the headline size, stride-8 lattice) that only a pair's SECOND ATTEMPT
+# uses.  About one of the reference's own starts in a thousand ends in the wrong basin whichever way the coarse phases are arranged,
+# and which one is a matter of round-off (caps of 15 / 30, a looser IRLS epsilon, a fourth level -- each loses
+# DIFFERENT pairs).  So the schedule ends with a per-pair VERDICT on the device (include/sp_hip.h SpVerdict: finiteness, how the
+# polish ended, the largest log-depth excursion from the seeds, the valid fraction) and a pair that fails it is put back to its
+# start and run once more, in the slot it already has, through ``retry_pose_first`` -- pose-only phases at levels 3 and 2 -- and
+# then the same joint phases and polish.  What fails twice is reported (``PairBatch.status``), never returned silently.
+REFERENCE_START_LEVELS = (0, 4)
+REFERENCE_START_POINT_STRIDE = (2, 2, 4, 8)
 # pose_first_iters is a CAP (the phase ends by its convergence test): 15 cut the 2-4 sigma tail of the start distribution short (rotation
 # errors of 0.09-0.22 rad need ~20 pose-only iterations; 7 of bench.py's 1536 starts, among them the one of its first 384, diverged in the
 # joint phase -- while the real reference converges from that start, golden g20x); 30 loses 2 of 1536 (tools/hard_starts.py,
 # profiles/r04_reference_start.txt).  Longer is not better without the convergence test: a pose fitted for 25 iterations to depth seeds
 # that are 50 % off (IRLS epsilon 1e-2, where the test triggers late) loses 12 %.
-# What is lost of 1536 starts is a matter of the schedule only in WHICH pairs: a fourth pyramid level with pose-only phases at levels 3 and 2
-# (``pose_first_iters=(15, 15), joint_levels=3`` on levels (0, 4)) brings home the ten hard starts found so far (tools/hard_starts.py,
-# tools/lost_starts.py) at the same rate -- and loses two others (450 and 1218).
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=30)
+# ``use_levels=3``: the first attempt runs on the three finest levels exactly as in round 4 (pose-only at level 2, joint phases at 2, 1, 0,
+# polish).
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=30, use_levels=3, retry_pose_first=((3, 15), (2, 15)))
+# The verdict's thresholds (SpVerdict): a log-depth more than ``kld_bound`` from its seed (a factor e^kld_bound in depth: the reference's
+# seeds log(2 + 2 rand) are at most a factor 2 off) has run away; fewer than ``valid_min`` of the points projecting into the target
+# frame at the end of an alignment that started with both frames overlapping is a lost pair.  ``retry_on``: the status bits that send
+# a pair into its second attempt.  tools/verdict_sweep.py / profiles/r05_reference_start.txt: what each bit catches over 8192 starts.
+VERDICT_DEFAULTS = dict(kld_bound=2.0, cost_bound=0.0, cost_ratio=0.0, valid_min=0.5,
+                        retry_on=_lib.SP_STATUS_NONFINITE | _lib.SP_STATUS_LAST_CAP | _lib.SP_STATUS_DEPTH_RANGE | _lib.SP_STATUS_VALID | _lib.SP_STATUS_COST)
 
 
 def _level_images(img, max_level):
@@ -372,6 +384,8 @@ class PairBatch:
         self.reset_lm()
         self._graphs = {}
         self._flag = None
+        self._verdict_arrays = None
+        self.status = None
         self._initial = (self.pose.clone(), self.kld.clone())
         mark('constructor returns')
 
@@ -410,6 +424,7 @@ class PairBatch:
                    torch.stack([t(p.pose_init) for p in pairs]), [t(p.kld_init) for p in pairs], levels=levels, **kw)
 
     def reset_lm(self, lam=1e-4):
+        self._lam0 = float(lam)                 # (what a slot of a queue run / a second attempt starts from)
         self.lm_state.zero_()
         self.lm_state[:, 0] = lam
         self.lm_state[:, 1] = -1.0
@@ -523,7 +538,8 @@ class PairBatch:
         return launched
 
     def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3, phases=None,
-                 use_coarse=True, pose_first_iters=0, pose_first_eps=None, joint_levels=None):
+                 use_coarse=True, pose_first_iters=0, pose_first_eps=None, joint_levels=None, use_levels=None, retry_pose_first=None,
+                 retry_phases=None, retry_join=None):
         """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
         built with a ``point_stride`` run on their decimated point set unless ``use_coarse=False``.  ``phases``: an explicit
         list of dict(level, stride, max_iters, irls_eps, conv_tol) instead (every (level, stride > 1) needs its table:
@@ -532,11 +548,19 @@ class PairBatch:
         depths keep their seeds while the pose is aligned -- what makes the schedule converge from the reference's own starting
         distribution (REFERENCE_START_SCHEDULE).  A TUPLE of caps puts one pose-only phase per entry at the coarsest levels in turn
         (coarsest first); ``joint_levels`` = k restricts the joint (pose + depth) phases to the k finest levels: a level above those only
-        aligns the pose."""
+        aligns the pose.  ``use_levels`` = k: only the k finest levels of the batch take part in all of that (the batch may carry coarser
+        ones for the second attempt).
+
+        THE SECOND ATTEMPT (SpSchedule.retry_entry, SpVerdict): ``retry_phases`` -- a list of phase dicts like ``phases`` -- or its
+        shorthand ``retry_pose_first`` = ((level, cap), ...), pose-only phases -- are what a pair that fails its verdict runs FIRST when it
+        is put back to its start, before it joins the list above at phase ``retry_join`` (default: the first phase that is not pose-only).
+        They sit in front of the list in the SpSchedule; a first attempt enters behind them."""
         if phases is None:
             phases = []
             caps = tuple(pose_first_iters) if isinstance(pose_first_iters, (tuple, list)) else ((int(pose_first_iters),) if pose_first_iters > 0 else ())
             coarse_first = sorted(self.level_ids, reverse=True)
+            if use_levels is not None:
+                coarse_first = coarse_first[len(coarse_first) - int(use_levels):]
             assert len(caps) <= len(coarse_first)
             for level, cap in zip(coarse_first, caps):
                 phases.append(dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=int(cap),
@@ -544,12 +568,28 @@ class PairBatch:
             joint = coarse_first if joint_levels is None else coarse_first[len(coarse_first) - int(joint_levels):]
             phases += [dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=max_iters_per_level, irls_eps=irls_eps,
                            conv_tol=conv_tol) for level in joint]
+            finest = min(self.level_ids)
             if polish_max > 0:
-                phases.append(dict(level=min(self.level_ids), stride=1, max_iters=polish_max, irls_eps=polish_eps, conv_tol=polish_tol))
-        if len(phases) > _lib.SP_MAX_PHASES:
-            raise ValueError(f"{len(phases)} phases exceed SP_MAX_PHASES = {_lib.SP_MAX_PHASES}")
+                phases.append(dict(level=finest, stride=1, max_iters=polish_max, irls_eps=polish_eps, conv_tol=polish_tol))
+            elif use_coarse and self.point_stride[finest] > 1:
+                # (with the finest level on a decimated lattice only the polish sees every point -- without one the end state
+                #  is the minimiser of a quarter-point lattice, silently)
+                raise ValueError("the finest level iterates on a decimated lattice (point_stride > 1): the schedule needs its all-points polish "
+                                 "(polish_max > 0), or use_coarse=False")
+        if retry_phases is None and retry_pose_first:
+            retry_phases = [dict(level=int(l), stride=self.point_stride[int(l)] if use_coarse else 1, max_iters=int(cap),
+                                 irls_eps=irls_eps if pose_first_eps is None else pose_first_eps, conv_tol=conv_tol, pose_only=True)
+                            for l, cap in retry_pose_first]
+        retry_phases = list(retry_phases or [])
+        if retry_phases:
+            if retry_join is None:
+                retry_join = next((i for i, ph in enumerate(phases) if not ph.get("pose_only", False)), 0)
+            assert 0 <= int(retry_join) < len(phases)
+        all_phases = retry_phases + list(phases)
+        if len(all_phases) > _lib.SP_MAX_PHASES:
+            raise ValueError(f"{len(all_phases)} phases exceed SP_MAX_PHASES = {_lib.SP_MAX_PHASES}")
         sched = _lib.SpSchedule()
-        for p, spec in enumerate(phases):
+        for p, spec in enumerate(all_phases):
             level, stride = int(spec["level"]), int(spec.get("stride", 1))
             ph = sched.phase[p]
             if stride == 1:
@@ -561,52 +601,105 @@ class PairBatch:
                 ph.span_partials, ph.seg_partials = _lib.ptr(lay.partials), _lib.ptr(lay.seg_partials)
             ph.irls_eps, ph.conv_tol, ph.max_iters = float(spec.get("irls_eps", irls_eps)), float(spec["conv_tol"]), int(spec["max_iters"])
             ph.flags = (_lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0) | (_lib.SP_PHASE_WAVE_SPANS if self.wave_flag else 0) | (_lib.SP_PHASE_DEPTH_TABLE if self.table_flag else 0)
-        sched.n_phases = len(phases)
+            ph.next = 0
+        sched.n_phases = len(all_phases)
+        sched.entry = len(retry_phases)
+        sched.retry_entry = -1
+        if retry_phases:
+            sched.retry_entry = 0
+            join = len(retry_phases) + int(retry_join)
+            sched.phase[len(retry_phases) - 1].next = join if join != len(retry_phases) else 0
         return sched
 
-    def run_scheduled(self, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7, slots=None, **schedule_kw):
+    def _verdict(self, sched, verdict):
+        """The SpVerdict of a scheduled run (host struct; its arrays live on the batch: ``status``, ``diag``, ``attempts``) with the run's
+        starting point copied into ``pose0`` / ``kld0``.  ``verdict``: None / True = VERDICT_DEFAULTS, a dict = overrides, False = none."""
+        if verdict is False:
+            self.status = None
+            return None
+        opt = dict(VERDICT_DEFAULTS, **(verdict if isinstance(verdict, dict) else {}))
+        if getattr(self, "_verdict_arrays", None) is None:
+            ints = torch.zeros(2, self.M, dtype=torch.int32, device=self.device)
+            self._verdict_arrays = (ints[0], ints[1], torch.zeros(self.M, _lib.SP_DIAG_FLOATS, dtype=torch.float32, device=self.device),
+                                    torch.empty_like(self.pose), torch.empty_like(self.kld))
+        status, attempts, diag, pose0, kld0 = self._verdict_arrays
+        status.zero_(); attempts.zero_(); diag.zero_()
+        pose0.copy_(self.pose); kld0.copy_(self.kld)
+        v = _lib.SpVerdict()
+        v.status, v.diag, v.attempts = status.data_ptr(), diag.data_ptr(), attempts.data_ptr()
+        v.pose0, v.kld0, v.pose_base, v.kld_base = pose0.data_ptr(), kld0.data_ptr(), self.pose.data_ptr(), self.kld.data_ptr()
+        v.kld_bound, v.cost_bound, v.cost_ratio, v.valid_min = float(opt["kld_bound"]), float(opt["cost_bound"]), float(opt["cost_ratio"]), float(opt["valid_min"])
+        v.retry_mask = int(opt["retry_on"]) if sched.retry_entry >= 0 else 0
+        v.lam0 = float(getattr(self, "_lam0", 1e-4))
+        self.status, self.attempts, self.diag = status, attempts, diag
+        return v
+
+    def failed(self):
+        """(M,) bool device tensor: the pairs whose last scheduled run ended with a failing verdict (after their second attempt, when the
+        schedule has one) -- their poses and depths are NOT to be trusted.  ``self.status`` holds the SP_STATUS_* bits, ``self.diag`` the
+        numbers behind them (include/sp_hip.h SpVerdict), ``self.attempts`` who was run twice."""
+        if getattr(self, "status", None) is None:
+            raise RuntimeError("no verdict: run_scheduled(verdict=False), or no scheduled run yet")
+        return (self.status & _lib.SP_STATUS_FAILED) != 0
+
+    def run_scheduled(self, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7, slots=None, verdict=None, return_status=False, **schedule_kw):
         """``run_converging`` with the schedule itself on the device: every pair walks through ITS OWN coarse-to-fine phases
         (sp_pairs_schedule_cost / sp_pairs_schedule_gn_step), moving to the next level the moment it converges instead of
         waiting for the slowest pair of the batch, and the host only polls ``min(phase)`` every ``check_every`` iterations.
         Per pair the arithmetic is that of ``run_converging`` with check_every = 1 -- except at levels built with a
-        ``point_stride`` > 1, which iterate on their decimated point set.  Returns the iterations launched.
+        ``point_stride`` > 1, which iterate on their decimated point set.  Returns the iterations launched
+        (``return_status=True``: and the (M,) int32 device tensor of SP_STATUS_* bits).
+
+        THE VERDICT (``verdict``: a dict of overrides of VERDICT_DEFAULTS, False = none).  The workgroup that takes a pair out of its last
+        phase checks what the pair ended with and writes ``self.status[pair]`` (0 = converged; ``self.failed()``), ``self.diag``; with
+        ``retry_pose_first`` / ``retry_phases`` in the schedule a failing pair is put back to its starting point and run ONCE more through
+        those phases, in place, during the same run (``self.attempts``).  The reference only asserts finiteness
+        (core/dense_optim.py:311,321,340-343); its Adam loop has no notion of "did not converge" either -- but it also does not end in
+        the wrong basin where this schedule, one start in a thousand, does.
 
         ``slots`` < M: SLOT-LEVEL CONTINUOUS BATCHING (include/sp_hip.h SpQueue, sp_pairs_schedule_run_queue).  Only ``slots`` pairs are
         worked on at a time; the solver launch that finishes a pair hands its slot to the next waiting pair of the batch, so every launch
         but the very last ones works on a FULL resident set instead of a thinning one (a scheduled batch otherwise ends in a tail: its
-        last 10 % of pairs iterate almost alone for a third of the launches).  All pairs must share one padded layout (same segment sizes:
-        the slot's work list is a prefix of the batch's).  Every pair's result is bitwise the one it gets with all pairs resident."""
+        last 10 % of pairs iterate almost alone for a third of the launches).  The pairs may have DIFFERENT padded layouts (ragged segment
+        sets): the cost pass runs over virtual spans, as many per slot as the largest pair has.  Every pair's result is bitwise the one it
+        gets with all pairs resident."""
         sched = self.schedule(**schedule_kw)
-        bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases))
+        # (a second attempt can spend the phases in front of the entry as well)
+        bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases)) + (sum(sched.phase[p].max_iters for p in range(sched.entry, sched.n_phases)) if sched.retry_entry >= 0 else 0)
         if self._flag is None:
-            self._flag = (torch.zeros(2, dtype=torch.int32, device=self.device), torch.zeros(2, dtype=torch.int32).pin_memory())
+            self._flag = (torch.zeros(4, dtype=torch.int32, device=self.device), torch.zeros(4, dtype=torch.int32).pin_memory())
+        v = self._verdict(sched, verdict)
+        v_addr = ctypes.addressof(v) if v is not None else None
         if slots is not None and int(slots) < self.M:
-            return self._run_queue(sched, int(slots), bound, check_every, lm_up, lm_down, lm_min)
-        self.phase.zero_()
+            it = self._run_queue(sched, int(slots), bound, check_every, lm_up, lm_down, lm_min, v, v_addr)
+            return (it, self.status) if return_status else it
+        self.phase.fill_(sched.entry)
         self.phase_iters.zero_()
         self.lm_state[:, 1] = -1.0
-        self.lm_state[:, 4] = 0.0
+        self.lm_state[:, 4:] = 0.0
         # the whole host loop in ONE foreign call (sp_pairs_schedule_run): nothing is issued from Python per iteration, and the
         # interpreter lock is free for the other host threads of a PairStream while this batch runs
         it = self.lib.sp_pairs_schedule_run(ctypes.addressof(sched), self.M, self.max_N, float(lm_up), float(lm_down), float(lm_min),
                                             _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.ptr(self.phase),
                                             _lib.ptr(self.phase_iters), int(check_every), int(bound), _lib.ptr(self._flag[0]),
-                                            self._flag[1].data_ptr(), _lib.stream_ptr())
+                                            self._flag[1].data_ptr(), v_addr, _lib.stream_ptr())
         if it < 0:
             _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run")
-        return it
+        return (it, self.status) if return_status else it
 
-    def _run_queue(self, sched, slots, bound, check_every, lm_up, lm_down, lm_min, lam0=1e-4):
-        if not self._uniform_layout:
-            raise ValueError("run_scheduled(slots=...) needs every pair of the batch to have the same padded layout (same segment sizes)")
+    def _run_queue(self, sched, slots, bound, check_every, lm_up, lm_down, lm_min, v, v_addr):
         assert slots >= 1
         M, dev = self.M, self.device
         rec = ctypes.sizeof(_lib.SpPair)
-        # slot descriptors: a private copy of the first `slots` records of every descriptor array the phases use; the work lists are
-        # the batch's, cut after the spans of pair `slots - 1` (chunks / spans are ordered by pair)
-        s_off_of = {_lib.ptr(self.spans).value: self._s_off}
+        lam0 = float(getattr(self, "_lam0", 1e-4))
+        # slot descriptors: a private copy of the first `slots` records of every descriptor array the phases use (the solver overwrites a
+        # slot's records with the next pair's, whole); the work lists are the batch's -- a descriptor carries its pair's span range, and
+        # the cost pass is launched over `max_spans` virtual spans per slot (the largest pair's count: ragged batches share the slots)
+        wave = bool(self.wave_flag)
+        most = lambda s_off: int(np.diff(np.asarray(s_off)).max())
+        spans_of = {_lib.ptr(self.spans).value: most(self._s_off)}
         for lay in self.coarse.values():
-            s_off_of[_lib.ptr(lay.spans).value] = lay.s_off
+            spans_of[_lib.ptr(lay.spans).value] = most(lay.s_off)
         q = _lib.SpQueue()
         slot_desc = {}
         keep = []
@@ -620,13 +713,15 @@ class PairBatch:
             q.qpairs[p] = full_ptr
             q.slot_pairs[p] = slot_desc[full_ptr].data_ptr()
             ph.pairs = slot_desc[full_ptr].data_ptr()
-            ph.n_spans = int(s_off_of[ph.spans][slots]) if ph.n_spans > 0 else 0
+            ms = spans_of[ph.spans] if ph.n_spans > 0 else 0
+            q.max_spans[p] = (ms + 3) // 4 * 4 if wave else ms
         head = torch.tensor([slots], dtype=torch.int32, device=dev)
         slot_pair = torch.arange(slots, dtype=torch.int32, device=dev)
         q_costs = torch.zeros(M, dtype=torch.float32, device=dev)
         q_lm = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
-        q.n_queue, q.head, q.slot_pair, q.q_costs, q.q_lm, q.lam0 = M, head.data_ptr(), slot_pair.data_ptr(), q_costs.data_ptr(), q_lm.data_ptr(), float(lam0)
-        self.phase.zero_()
+        q.n_queue, q.head, q.slot_pair, q.q_costs, q.q_lm, q.lam0 = M, head.data_ptr(), slot_pair.data_ptr(), q_costs.data_ptr(), q_lm.data_ptr(), lam0
+        self.phase.fill_(sched.n_phases)            # (the per-slot arrays are the first `slots` entries of the batch's per-pair ones)
+        self.phase[:slots] = sched.entry
         self.phase_iters.zero_()
         self.lm_state.zero_()
         self.lm_state[:, 0] = lam0
@@ -635,14 +730,21 @@ class PairBatch:
         it = self.lib.sp_pairs_schedule_run_queue(ctypes.addressof(sched), ctypes.addressof(q), slots, self.max_N, float(lm_up), float(lm_down),
                                                   float(lm_min), _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs),
                                                   _lib.ptr(self.phase), _lib.ptr(self.phase_iters), int(check_every), int(rounds),
-                                                  _lib.ptr(self._flag[0]), self._flag[1].data_ptr(), _lib.stream_ptr())
+                                                  _lib.ptr(self._flag[0]), self._flag[1].data_ptr(), v_addr, _lib.stream_ptr())
         if it < 0:
             _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run_queue")
         # results per PAIR (what the per-slot arrays hold is whichever pairs came last)
+        min_phase, taken = int(self._flag[1][0]), min(int(self._flag[1][1]), M)
         self._costs.copy_(q_costs)
         self.lm_state.copy_(q_lm)
+        self._queue_stats = dict(slots=slots, head=taken, slot_pair=slot_pair, finished=min_phase >= sched.n_phases)
+        if min_phase < sched.n_phases:
+            #  the run hit its round limit: pairs still in a slot carry SP_STATUS_UNFINISHED (set by the library), pairs that never
+            # got a slot are marked here; without a verdict there is no way to tell the caller per pair, so that is an error
+            if v is None:
+                raise RuntimeError(f"run_scheduled(slots={slots}) ended on its round limit ({rounds}) with pairs unfinished")
+            self.status[taken:] = _lib.SP_STATUS_UNFINISHED
         self.phase.fill_(sched.n_phases)
-        self._queue_stats = dict(slots=slots, head=int(self._flag[1][1]), slot_pair=slot_pair)
         return it
 
     def run(self, iters_per_level, mode="gn", use_graph=False, polish_iters=0, polish_eps=1e-5, **kw):

@@ -749,7 +749,7 @@ def test_wave_span_work_list_gives_the_same_sums_and_steps(shape, seed):
 def test_slot_level_continuous_batching_gives_every_pair_its_own_result(granule):
     """run_scheduled(slots=S) (SpQueue, sp_pairs_schedule_run_queue): 14 resident pairs of one layout, 4 slots -- a
     finished pair's slot goes to the next waiting pair inside the solver launch.  Every pair's pose, log-depths, final cost and
-    iteration counts are BITWISE those of the run with all 14 resident (pairs never interact; a slot's work list fits every pair),
+    iteration counts are BITWISE those of the run with all 14 resident (pairs never interact),
     whichever slot it happened to get; the queue is handed out completely; far fewer pair-slots are launched than slots x rounds."""
     from super_primitive_amd import synth
     sch = dict(max_iters_per_level=12, conv_tol=2e-3, polish_max=6, polish_eps=1e-5, polish_tol=1e-4)
@@ -772,8 +772,91 @@ def test_slot_level_continuous_batching_gives_every_pair_its_own_result(granule)
         # rounds: about (sum of the pairs' iterations) / slots, not (pairs / slots) x the slowest pair
         print(f"\n{q.M} pairs, {slots} slots (granule {granule}): {n_q} rounds launched (all resident: {n_ref}; sum of iterations {int(its_ref.sum())}, / slots = {its_ref.sum() / slots:.1f}, slowest pair {int(its_ref.max())})")
         assert n_q <= its_ref.sum() / slots + its_ref.max() + 2
-    with pytest.raises(ValueError):
-        make_batch([synth.make_pair(96, 128, 6, seed=1), synth.make_pair(96, 128, 9, seed=2)], **kw).run_scheduled(slots=1, **sch)
+
+
+@pytest.mark.parametrize("granule", [256, 64])
+def test_slot_level_continuous_batching_of_ragged_pairs(granule):
+    """the slots of run_scheduled(slots=S) take pairs of DIFFERENT padded layouts -- SAM-like blobs of ragged sizes,
+    different segment counts, a different image size -- because the cost pass of a queue run goes over virtual spans (as many per slot
+    as the largest pair has; a slot's descriptor carries its pair's own span range).  Every pair ends BITWISE where it ends with all
+    pairs resident, in whichever slot and order it ran; the verdict arrays are filed per pair."""
+    from super_primitive_amd import _lib, synth
+    sch = dict(max_iters_per_level=12, conv_tol=2e-3, polish_max=6, polish_eps=1e-5, polish_tol=1e-4)
+    sig = [0.002, 0.012, 0.004, 0.008, 0.001, 0.015, 0.003, 0.006, 0.010, 0.002, 0.007]
+    prs = [synth.make_pair(96, 128, 5 + (i % 4) * 3, seed=150 + i, init_sigma=s, shape="blobs", blob_coverage=0.9 + 0.15 * (i % 3)) for i, s in enumerate(sig)]
+    prs += [synth.make_pair(72, 96, 7, seed=170, init_sigma=0.005, overlap=2), synth.make_pair(96, 128, 6, seed=171, init_sigma=0.004, overlap=2)]
+    kw = dict(levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), granule=granule)
+    ref = make_batch(prs, **kw)
+    assert not ref._uniform_layout and len(set(ref.Ns)) > 2
+    n_ref = ref.run_scheduled(check_every=1, **sch)
+    torch.cuda.synchronize()
+    its_ref = npy(ref.lm_state[:, 2] + ref.lm_state[:, 3])
+    for slots in (1, 3, 5):
+        q = make_batch(prs, **kw)
+        n_q = q.run_scheduled(check_every=1, slots=slots, **sch)
+        torch.cuda.synchronize()
+        assert q._queue_stats["head"] >= q.M and q._queue_stats["finished"]
+        for m in range(q.M):
+            assert torch.equal(q.poses()[m], ref.poses()[m]) and torch.equal(q.klds()[m], ref.klds()[m]), (slots, m)
+        assert torch.equal(q.costs(), ref.costs()) and torch.equal(q.lm_state[:, :4], ref.lm_state[:, :4])
+        assert torch.equal(q.status, ref.status) and torch.equal(q.diag, ref.diag)
+        assert n_q <= its_ref.sum() / slots + its_ref.max() + 2
+    assert int((ref.status & _lib.SP_STATUS_NONFINITE).sum()) == 0
+
+
+def test_scheduled_run_reports_a_verdict_and_retries_what_fails_it():
+    """the per-pair verdict of a scheduled run (SpVerdict) and its one second attempt.  Three pairs: one near its
+    minimum, one whose start is hopeless (the pose a radian off: the target frame does not see the source's points), and the first again.  (a) Without a second attempt the
+    hopeless pair is FLAGGED (``failed()``) and the good ones are not; diag holds the final cost / largest log-depth excursion / valid
+    fraction / polish iterations.  (b) A verdict that fails everything (kld_bound tiny) sends every pair through the retry phases once:
+    ``attempts`` = 1, SP_STATUS_RETRIED set, and the pair that was fine ends where the retry's phase list brings it -- inside the
+    schedule's tolerance of its first result.  (c) The same through the slot queue, bitwise.  (d) A run cut short by its round limit
+    marks what it did not finish."""
+    from super_primitive_amd import _lib, synth
+    from parity_util import pose_depth_errors
+    good = synth.make_pair(96, 128, 6, seed=31, init_sigma=0.004, overlap=2)
+    bad = synth.make_pair(96, 128, 6, seed=32, init_sigma=0.004, overlap=2)
+    bad.pose_init = (synth.se3_exp_np(np.array([0.3, -0.2, 0.1, 0.0, 1.0, 0.0])) @ bad.pose_init.astype(np.float64)).astype(np.float32)
+    prs = [good, bad, good]
+    kw = dict(levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), granule=64)
+    sch = dict(max_iters_per_level=12, conv_tol=2e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-4)
+    a = make_batch(prs, **kw)
+    it, status = a.run_scheduled(return_status=True, **sch)
+    st = npy(status)
+    assert st[0] == 0 and st[2] == 0 and (st[1] & _lib.SP_STATUS_FAILED) != 0 and not (st[1] & _lib.SP_STATUS_RETRIED), st
+    assert npy(a.failed()).tolist() == [False, True, False] and npy(a.attempts).tolist() == [0, 0, 0]
+    d = npy(a.diag)
+    np.testing.assert_allclose(d[0, 0], float(a.lm_state[0, 5]), rtol=0, atol=0)
+    assert 0 < d[0, 1] < 0.5 and 0.8 < d[0, 2] <= 1.0 and 1 <= d[0, 3] <= 15 and d[0, 4] == 1 and d[0, 5] > 0
+    first = (a.poses()[0].clone(), a.klds()[0].clone())
+    # (b) everything fails a verdict with a tiny depth bound -> everything runs the retry phases once
+    b = make_batch(prs, **kw)
+    b.run_scheduled(verdict=dict(kld_bound=1e-6), retry_pose_first=((2, 6),), **sch)
+    assert npy(b.attempts).tolist() == [1, 1, 1]
+    sb = npy(b.status)
+    assert all(s & _lib.SP_STATUS_RETRIED for s in sb) and all(s & _lib.SP_STATUS_DEPTH_RANGE for s in sb)
+    assert npy(b.diag)[:, 4].tolist() == [2.0, 2.0, 2.0]
+    e = pose_depth_errors(npy(b.poses()[0]), npy(b.klds()[0]), npy(first[0]), npy(first[1]))
+    assert e[0] <= 5e-5 and e[1] <= 5e-5 and e[2] <= 5e-4, e
+    assert torch.equal(b.poses()[0], b.poses()[2]) and torch.equal(b.klds()[0], b.klds()[2])        # same pair, same two attempts
+    its_a, its_b = npy(a.lm_state[:, 2] + a.lm_state[:, 3]), npy(b.lm_state[:, 2] + b.lm_state[:, 3])
+    assert its_b[0] > its_a[0]                                                                         # (the counts run over both attempts)
+    # (c) the same through two slots: bitwise
+    c = make_batch(prs, **kw)
+    c.run_scheduled(slots=2, verdict=dict(kld_bound=1e-6), retry_pose_first=((2, 6),), **sch)
+    assert torch.equal(c.pose, b.pose) and torch.equal(c.kld, b.kld) and torch.equal(c.status, b.status) and torch.equal(c.diag, b.diag)
+    assert torch.equal(c.lm_state[:, :4], b.lm_state[:, :4])
+    # (d) a schedule whose iteration budget is cut by hand: unfinished pairs say so
+    dd = make_batch(prs, **kw)
+    sched = dd.schedule(**sch)
+    v = dd._verdict(sched, None)
+    dd.phase.fill_(sched.entry); dd.phase_iters.zero_()
+    flag = (torch.zeros(4, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int32).pin_memory())
+    import ctypes
+    n = dd.lib.sp_pairs_schedule_run(ctypes.addressof(sched), dd.M, dd.max_N, 8.0, 0.5, 1e-7, _lib.ptr(dd.lm_state), _lib.ptr(dd.backup), _lib.ptr(dd._costs),
+                                     _lib.ptr(dd.phase), _lib.ptr(dd.phase_iters), 2, 4, _lib.ptr(flag[0]), flag[1].data_ptr(), ctypes.addressof(v), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert n == 4 and all(s == _lib.SP_STATUS_UNFINISHED for s in npy(dd.status))
 
 
 def test_keyframe_record_of_the_set_up_follows_replaced_and_edited_tensors():

@@ -50,7 +50,13 @@ def test_abi_constants_and_struct_layout_match_header():
         assert int(re.search(r"#define\s+" + macro + r"\s+(\d+)", header).group(1)) == getattr(_lib, macro)
     assert ctypes.sizeof(_lib.SpPhase) == 64 and _lib.SpPhase.n_spans.offset == 40 and _lib.SpPhase.conv_tol.offset == 52
     assert _lib.SpPhase.flags.offset == 56
-    assert ctypes.sizeof(_lib.SpSchedule) == 520 and _lib.SpSchedule.n_phases.offset == 512
+    assert _lib.SpPhase.next.offset == 60
+    assert ctypes.sizeof(_lib.SpSchedule) == 528 and _lib.SpSchedule.n_phases.offset == 512 and _lib.SpSchedule.retry_entry.offset == 520
+    assert ctypes.sizeof(_lib.SpVerdict) == 80 and _lib.SpVerdict.kld_bound.offset == 56 and _lib.SpVerdict.lam0.offset == 76
+    assert ctypes.sizeof(_lib.SpQueue) == 208 and _lib.SpQueue.max_spans.offset == 128 and _lib.SpQueue.head.offset == 168
+    for macro in ("SP_STATUS_NONFINITE", "SP_STATUS_LAST_CAP", "SP_STATUS_DEPTH_RANGE", "SP_STATUS_COST", "SP_STATUS_VALID", "SP_STATUS_RETRIED",
+                  "SP_STATUS_UNFINISHED", "SP_DIAG_FLOATS"):
+        assert int(re.search(r"#define\s+" + macro + r"\s+(0x[0-9a-fA-F]+|\d+)", header).group(1), 0) == getattr(_lib, macro), macro
     assert int(re.search(r"#define\s+SP_PHASE_POSE_ONLY\s+(\d+)", header).group(1)) == _lib.SP_PHASE_POSE_ONLY
 
 
@@ -68,7 +74,7 @@ def test_new_entry_points_validate_arguments_and_sizes():
     assert lib.sp_prepare_blur(None, 1, 3, 1, None) == -1
     sched = _lib.SpSchedule()
     assert lib.sp_pairs_schedule_cost(ctypes.addressof(sched), None, None) == -1 and lib.sp_pairs_schedule_cost(None, None, None) == -1
-    assert lib.sp_pairs_schedule_gn_step(ctypes.addressof(sched), 1, 1, 8.0, 0.5, 1e-7, *([None] * 6)) == -1
+    assert lib.sp_pairs_schedule_gn_step(ctypes.addressof(sched), 1, 1, 8.0, 0.5, 1e-7, *([None] * 7)) == -1
     assert lib.sp_depth_accumulate(*([None] * 6), 1, 1, 1, 1, None, None) == -1
     assert lib.sp_depth_average_finish(None, 4, 4, None, None, None) == -1
 

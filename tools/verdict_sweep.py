@@ -1,0 +1,174 @@
+#!/usr/bin/env python
+"""The verdict of the frame-pair schedule over MANY of the reference's own starts: does any pair that ends away
+from its ground truth leave the run UNFLAGGED, what does each status bit catch, what does the second attempt bring home.
+
+    python tools/verdict_sweep.py [--starts 9216] [--batch 1536] [--slots 384] [--variants shipped,no_retry,...] [--npz out.npz] [--shape grid|blobs]
+
+Starts are bench.py's reference-start leg continued: scenes 5000..5007 (640x480x64, multi-octave texture), start m = scene m % 8 with
+pose T_gt Exp(0.05 xi), depth seeds log(2 + 2 u) drawn from default_rng(77) in bench's order (m < 8: the scene's own), so pair m here
+IS bench pair m (105, 1380, 1482, ... of DESIGN.md section 6).  Per variant: pairs/s, iterations per pair, misses against the ground
+truth (golden g19's criterion: 2e-3 rad / 2e-3 t / 2e-2 depth), how many of those the verdict flags (SILENT = missed and not flagged --
+must be 0), false alarms, second attempts made and what they rescued.  ``--npz`` keeps the per-pair arrays of every variant.
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import os
+import sys
+import time
+from multiprocessing import Pool
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from super_primitive_amd import _lib, synth  # noqa: E402
+from super_primitive_amd.image.keyframe import KeyFrame  # noqa: E402
+from super_primitive_amd.optim.pair_batch import (REFERENCE_START_LEVELS, REFERENCE_START_POINT_STRIDE, REFERENCE_START_SCHEDULE,  # noqa: E402
+                                                  VERDICT_DEFAULTS, PairBatch)
+
+H, W, N, G = 480, 640, 64, 8
+BASE = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
+NO_CAP = VERDICT_DEFAULTS["retry_on"] & ~_lib.SP_STATUS_LAST_CAP
+ct, ie = BASE["conv_tol"], 1e-3
+VARIANTS = {
+    "shipped": dict(BASE),
+    "no_retry": dict(BASE, retry_pose_first=None),
+    "retry_L3_15_L2_30": dict(BASE, retry_pose_first=((3, 15), (2, 30))),
+    "retry_L2_eps1e-2": dict(BASE, retry_pose_first=None,
+                             retry_phases=[dict(level=2, stride=4, max_iters=15, irls_eps=1e-2, conv_tol=ct, pose_only=True)]),
+    "retry_L3_joint_L3": dict(BASE, retry_pose_first=None, retry_join=1,
+                              retry_phases=[dict(level=3, stride=8, max_iters=15, irls_eps=ie, conv_tol=ct, pose_only=True),
+                                            dict(level=2, stride=4, max_iters=15, irls_eps=ie, conv_tol=ct, pose_only=True)]),
+    "retry_not_on_cap": dict(BASE, verdict=dict(retry_on=NO_CAP)),
+    "kld_bound_1.5": dict(BASE, verdict=dict(kld_bound=1.5)),
+    "kld_bound_3": dict(BASE, verdict=dict(kld_bound=3.0)),
+}
+
+
+def _render(a):
+    shape_kw = dict(overlap=4) if a[1] == "grid" else dict(shape="blobs", blob_coverage=1.2)
+    return synth.make_pair(H, W, N, seed=a[0], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
+
+
+def errors(P, K, poses_gt, klds_gt):
+    """(n, 3): rotation [rad], translation [max abs, scale gauge removed], depth [max relative] against the ground truth."""
+    out = np.zeros((len(P), 3))
+    for m in range(len(P)):
+        gt_T, gt_k = poses_gt[m], klds_gt[m]
+        ls = float(np.mean(gt_k - K[m]))
+        Rm = P[m][:3, :3].T @ gt_T[:3, :3]
+        out[m] = (float(np.arctan2(0.5 * np.linalg.norm([Rm[2, 1] - Rm[1, 2], Rm[0, 2] - Rm[2, 0], Rm[1, 0] - Rm[0, 1]]), 0.5 * (np.trace(Rm) - 1))),
+                  float(np.abs(P[m][:3, 3] * np.exp(ls) - gt_T[:3, 3]).max()), float(np.abs(np.expm1(K[m] + ls - gt_k)).max()))
+    return out
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--starts", type=int, default=9216)
+    ap.add_argument("--batch", type=int, default=1536)
+    ap.add_argument("--slots", type=int, default=384)
+    ap.add_argument("--variants", default="shipped,no_retry,retry_L3_15_L2_30,retry_L2_eps1e-2,retry_not_on_cap")
+    ap.add_argument("--shape", default="grid", choices=["grid", "blobs"])
+    ap.add_argument("--npz", default=None)
+    ap.add_argument("--alone", default="105,1380,1482", help="pairs also run as batches of ONE (order independence of the verdict and the retry)")
+    args = ap.parse_args(argv)
+    dev = torch.device("cuda:0")
+    t0 = time.time()
+    with Pool(min(G, 8)) as pool:
+        scenes = pool.map(_render, [(5000 + s, args.shape) for s in range(G)])
+    print(f"rendered {G} scenes ({args.shape}) in {time.time() - t0:.1f} s", flush=True)
+    rng = np.random.default_rng(77)
+    n_batches = -(-args.starts // args.batch)
+    total = n_batches * args.batch
+    poses, klds = [], []
+    for r in range(total // G):
+        for p in scenes:
+            if r == 0:
+                poses.append(p.pose_init); klds.append(p.kld_init)
+            else:
+                poses.append((p.pose_gt.astype(np.float64) @ synth.se3_exp_np(0.05 * rng.standard_normal(6))).astype(np.float32))
+                klds.append(np.log(2.0 + 2.0 * rng.uniform(size=p.N)).astype(np.float32))
+    poses_gt = [scenes[m % G].pose_gt.astype(np.float64) for m in range(total)]
+    klds_gt = [scenes[m % G].kld_gt.astype(np.float64) for m in range(total)]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in scenes]
+    trg, Ks = [t(p.trg_image) for p in scenes], [t(p.K) for p in scenes]
+    names = [v for v in args.variants.split(",") if v]
+    keep = {v: dict(err=[], status=[], diag=[], attempts=[], iters=[], secs=0.0, rounds=0) for v in names}
+    for b in range(n_batches):
+        lo = b * args.batch
+        batch = PairBatch(src, trg, Ks, torch.from_numpy(np.stack(poses[lo: lo + args.batch])), [t(k) for k in klds[lo: lo + args.batch]],
+                          levels=REFERENCE_START_LEVELS, replicate=args.batch // G, point_stride=REFERENCE_START_POINT_STRIDE, granule=64)
+        for v in names:
+            kw = dict(VARIANTS[v])
+            for rep in range(2 if b == 0 else 1):                  # (first use untimed)
+                batch.restore_initial()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                rounds = batch.run_scheduled(slots=args.slots, **kw)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+            P, K = batch.poses().double().cpu().numpy(), [k.double().cpu().numpy() for k in batch.klds()]
+            k = keep[v]
+            k["err"].append(errors(P, K, poses_gt[lo: lo + args.batch], klds_gt[lo: lo + args.batch]))
+            k["status"].append(batch.status.cpu().numpy().copy()); k["diag"].append(batch.diag.cpu().numpy().copy())
+            k["attempts"].append(batch.attempts.cpu().numpy().copy())
+            k["iters"].append((batch.lm_state[:, 2] + batch.lm_state[:, 3]).cpu().numpy())
+            k["secs"] += dt; k["rounds"] += rounds
+        if b == 0 and args.alone:
+            # order independence: the named pairs alone (other span partition, other summation order) and all resident
+            ids = [int(a) for a in args.alone.split(",") if int(a) < args.batch]
+            kw = dict(VARIANTS[names[0]])
+            batch.restore_initial()
+            batch.run_scheduled(**kw)
+            torch.cuda.synchronize()
+            P, K = batch.poses().double().cpu().numpy(), [k.double().cpu().numpy() for k in batch.klds()]
+            e = errors([P[m] for m in ids], [K[m] for m in ids], [poses_gt[m] for m in ids], [klds_gt[m] for m in ids])
+            st = batch.status.cpu().numpy()
+            print(f"all {args.batch} resident ({names[0]}): " + "; ".join(f"pair {m}: {e[i]} status {st[m]:#x}" for i, m in enumerate(ids)), flush=True)
+            for m in ids:
+                one = PairBatch([src[m % G]], [trg[m % G]], [Ks[m % G]], torch.from_numpy(poses[m][None]), [t(klds[m])], levels=REFERENCE_START_LEVELS,
+                                point_stride=REFERENCE_START_POINT_STRIDE, granule=64)
+                one.run_scheduled(**kw)
+                torch.cuda.synchronize()
+                e1 = errors([one.poses()[0].double().cpu().numpy()], [one.klds()[0].double().cpu().numpy()], [poses_gt[m]], [klds_gt[m]])[0]
+                print(f"pair {m} ALONE ({names[0]}): {e1} status {int(one.status[0]):#x} attempts {int(one.attempts[0])} diag {one.diag[0].cpu().numpy()}", flush=True)
+                del one
+        del batch
+        torch.cuda.empty_cache()
+        print(f"batch {b + 1}/{n_batches} done ({time.time() - t0:.0f} s)", flush=True)
+    out = {}
+    F = _lib.SP_STATUS_FAILED
+    for v in names:
+        k = keep[v]
+        err, st, dg, at, its = (np.concatenate(k[x]) for x in ("err", "status", "diag", "attempts", "iters"))
+        miss = ~((err[:, 0] <= 2e-3) & (err[:, 1] <= 2e-3) & (err[:, 2] <= 2e-2))
+        flagged = (st & F) != 0
+        silent = np.nonzero(miss & ~flagged)[0]
+        bits = {name: int(((st & getattr(_lib, "SP_STATUS_" + name)) != 0).sum()) for name in ("NONFINITE", "LAST_CAP", "DEPTH_RANGE", "COST", "VALID", "RETRIED", "UNFINISHED")}
+        conv = ~miss
+        print(f"\n== {v}: {total} starts, {total / k['secs']:.0f} pairs/s ({args.slots} slots), {its.mean():.1f} iterations per pair, {k['rounds']} rounds\n"
+              f"   missed (vs ground truth) {int(miss.sum())}: {np.nonzero(miss)[0][:24].tolist()}\n"
+              f"   flagged {int(flagged.sum())} (of the missed: {int((miss & flagged).sum())}; FALSE ALARMS {int((flagged & ~miss).sum())}: {np.nonzero(flagged & ~miss)[0][:16].tolist()})\n"
+              f"   SILENT {len(silent)}: {silent[:24].tolist()}\n"
+              f"   second attempts {int((at > 0).sum())}: rescued {int(((at > 0) & conv & ~flagged).sum())}, converged but still flagged {int(((at > 0) & conv & flagged).sum())}, "
+              f"missed again {int(((at > 0) & miss).sum())}\n"
+              f"   status bits {bits}\n"
+              f"   worst error of the unflagged: {err[~flagged].max(axis=0) if (~flagged).any() else None}", flush=True)
+        for m in silent[:8]:
+            print(f"   silent pair {m}: err {err[m]} status {st[m]:#x} diag {dg[m]}")
+        for m in np.nonzero(miss & flagged)[0][:8]:
+            print(f"   flagged miss {m}: err {err[m]} status {st[m]:#x} attempts {at[m]} diag {dg[m]}")
+        out.update({f"{v}__err": err, f"{v}__status": st, f"{v}__diag": dg, f"{v}__attempts": at, f"{v}__iters": its})
+    if args.npz:
+        os.makedirs(os.path.dirname(os.path.abspath(args.npz)), exist_ok=True)
+        np.savez_compressed(args.npz, **out)
+
+
+if __name__ == "__main__":
+    main()
