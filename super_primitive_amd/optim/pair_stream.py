@@ -26,6 +26,40 @@ import torch
 from .pair_batch import FRAME_PAIR_POINT_STRIDE, FRAME_PAIR_SCHEDULE, PairBatch
 
 
+class PairResult(tuple):
+    """What ``PairStream.run`` yields per batch: unpacks as ``(poses, klds)``; ``.status`` = the (M,) int32 device tensor of SP_STATUS_*
+    bits of the batch's scheduled run (include/sp_hip.h SpVerdict; 0 = converged, ``status & _lib.SP_STATUS_FAILED`` = do not trust the
+    pair's pose and depths), ``.attempts`` = who was run a second time; both None when the schedule was run with ``verdict=False``."""
+
+    def __new__(cls, poses, klds, status=None, attempts=None):
+        self = super().__new__(cls, (poses, klds))
+        self.status, self.attempts = status, attempts
+        return self
+
+
+class _SwitchInterval:
+    """The interpreter's thread switch interval, lowered while any PairStream has host threads at work and put back when the last one is
+    done -- or hands control to its caller (reference counted: nested / concurrent streams do not restore it under each other)."""
+    _lock = threading.Lock()
+    _count = 0
+    _saved = None
+
+    @classmethod
+    def acquire(cls, value=2e-4):
+        with cls._lock:
+            if cls._count == 0:
+                cls._saved = sys.getswitchinterval()
+                sys.setswitchinterval(min(cls._saved, value))
+            cls._count += 1
+
+    @classmethod
+    def release(cls):
+        with cls._lock:
+            cls._count -= 1
+            if cls._count == 0:
+                sys.setswitchinterval(cls._saved)
+
+
 class PairStream:
     def __init__(self, levels=(0, 3), point_stride=FRAME_PAIR_POINT_STRIDE, schedule=None, device="cuda:0", depth=1, optimisers=1, **batch_kw):
         """``schedule``: keyword arguments of ``PairBatch.run_scheduled`` (default: FRAME_PAIR_SCHEDULE); ``depth``: how many
@@ -126,12 +160,16 @@ class PairStream:
                     # caller-stream work on it is still queued
                     poses.record_stream(caller)
                     kld_flat.record_stream(caller)
+                    status = attempts = None
+                    if batch.status is not None:                 # the run's verdict travels with its results
+                        status, attempts = batch.status.clone(), batch.attempts.clone()
+                        status.record_stream(caller); attempts.record_stream(caller)
                     done = torch.cuda.Event()
                     done.record(stream)
                 # the batch (allocated on the set-up stream, used on this stream) is released only after the optimiser has finished with
                 # it -- by the REAPER thread: waiting for `done` and tearing down a PairBatch (a few thousand tensor handles, ~3 ms of
                 # interpreter time) here would keep this stream idle for that long after every batch
-                results.put((idx, poses, klds, done))
+                results.put((idx, PairResult(poses, klds, status, attempts), None, done))
                 self._reap.put((batch, done))
                 del batch
         except BaseException as e:
@@ -171,21 +209,21 @@ class PairStream:
                 errors.append(e)
 
         threads = [threading.Thread(target=worker, args=(st,), daemon=True) for st in self.optim_streams]
-        switch_interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(switch_interval, 2e-4))           # (see run())
+        _SwitchInterval.acquire()                                    # (see run())
         try:
             for t in threads:
                 t.start()
             for t in threads:
                 t.join()
         finally:
-            sys.setswitchinterval(switch_interval)
+            _SwitchInterval.release()
         if errors:
             raise errors[0]
 
     def run(self, inputs):
         """inputs: iterable of dict(src_frames, trg_images, trg_Ks, poses, klds) -- the arguments of PairBatch, device resident.
-        Yields (poses (M,4,4), [klds]) of every batch, in input order, as device tensors valid on the caller's current stream."""
+        Yields a ``PairResult`` -- (poses (M,4,4), [klds]) with the run's per-pair ``.status`` / ``.attempts`` -- of every batch, in input
+        order, as device tensors valid on the caller's current stream."""
         caller = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(caller)                 # the inputs may still be in flight on the caller's stream
@@ -198,8 +236,10 @@ class PairStream:
         # The producer is interpreter-bound for milliseconds at a time (a few thousand tensor handles per batch) and CPython hands
         # the GIL over only every sys.getswitchinterval() = 5 ms: an optimiser thread that has just come back from the native
         # schedule loop would wait that long before it can even take the next batch (measured: a 7 ms hole after every batch).
-        switch_interval = sys.getswitchinterval()
-        sys.setswitchinterval(min(switch_interval, 2e-4))
+        # The lowered interval is process wide: it is reference counted over all streams at work and handed back whenever this
+        # generator hands control to its caller (ADVICE r03 / VERDICT r04: the caller's own threads run at the interval they chose).
+        _SwitchInterval.acquire()
+        held = True
         reaper = threading.Thread(target=self._reaper_loop, daemon=True)
         reaper.start()
         for w in workers:
@@ -208,10 +248,12 @@ class PairStream:
             pending, nxt, finished = {}, 0, 0
             while finished < K or pending:
                 if nxt in pending:
-                    poses, klds, done = pending.pop(nxt)
+                    res, _, done = pending.pop(nxt)
                     caller.wait_event(done)
                     nxt += 1
-                    yield poses, klds
+                    _SwitchInterval.release(); held = False
+                    yield res
+                    _SwitchInterval.acquire(); held = True
                     continue
                 if finished == K:            # every optimiser has ended and the next index never came
                     raise RuntimeError("PairStream lost a batch")
@@ -223,7 +265,8 @@ class PairStream:
                 else:
                     pending[got[0]] = got[1:]
         finally:                            # also when the caller abandons the generator early
-            sys.setswitchinterval(switch_interval)
+            if held:
+                _SwitchInterval.release()
             stop.set()
             for w in workers:
                 w.join(timeout=60)

@@ -656,13 +656,22 @@ def test_pair_stream_overlaps_batches_and_returns_each_batch_s_own_result(optimi
     got = list(stream.run(iter(items)))
     torch.cuda.synchronize()
     assert len(got) == len(items)
-    for item, (poses, klds) in zip(items, got):
+    import sys
+    interval = sys.getswitchinterval()
+    for item, res in zip(items, got):
+        poses, klds = res
         ref = PairBatch(item["src_frames"], item["trg_images"], item["trg_Ks"], item["poses"], item["klds"], levels=(0, 3),
                         point_stride=(1, 2, 4), tile_points=1024)
         ref.run_scheduled(**sch)
         torch.cuda.synchronize()
         assert torch.equal(poses, ref.poses())
         assert all(torch.equal(a, b) for a, b in zip(klds, ref.klds()))
+        assert torch.equal(res.status, ref.status) and torch.equal(res.attempts, ref.attempts)      # the verdict travels with the results
+    # the lowered thread switch interval is handed back at every yield and at the end (reference counted)
+    gen = stream.run(iter(items))
+    for _ in gen:
+        assert sys.getswitchinterval() == interval
+    assert sys.getswitchinterval() == interval
     # an error in the producer thread reaches the caller
     bad = dict(items[0]); bad["klds"] = bad["klds"][:1]
     with pytest.raises(AssertionError):
