@@ -489,11 +489,12 @@ def golden_sigma05(ref, name="g19_sigma05_320x240x8", H=240, W=320, N=8, seeds=t
     print(f"{name}: {time.time() - t0:.0f} s; converged {int(save['converged'].sum())} of {len(rows)}", flush=True)
 
 
-def bench_reference_start(scene, replica, G=8, N=64, rank=0, H=480, W=640):
+def bench_reference_start(scene, replica, G=8, N=64, rank=0, H=480, W=640, shape="grid"):
     """The start bench.py's reference-start leg gives pair ``replica * G + scene`` (bench.py:reference_start_leg: scenes
     ``5000 + 1000 rank + s``, overlap 4; replica 0 = the pair's own pose_init / kld_init, replica r > 0 drawn from
     ``default_rng(77 + rank)`` in (replica, scene) order: 6 normals for the pose, N uniforms for the depth seeds)."""
-    pair = synth.make_pair(H, W, N, seed=5000 + 1000 * rank + scene, **dict(SIGMA05_ARGS, overlap=4))
+    shape_kw = dict(overlap=4) if shape == "grid" else dict(shape="blobs", blob_coverage=1.2, overlap=None)       # (bench.py --shape blobs)
+    pair = synth.make_pair(H, W, N, seed=5000 + 1000 * rank + scene, **{k: v for k, v in dict(SIGMA05_ARGS, **shape_kw).items() if v is not None})
     if replica > 0:
         rng = np.random.default_rng(77 + rank)
         for r in range(1, replica + 1):
@@ -505,13 +506,13 @@ def bench_reference_start(scene, replica, G=8, N=64, rank=0, H=480, W=640):
     return pair
 
 
-def golden_bench_pair(ref, pair_index=105, name="g20x_sigma05_bench_pair105"):
+def golden_bench_pair(ref, pair_index=105, name="g20x_sigma05_bench_pair105", shape="grid"):
     """the ONE pair of bench.py's 384 reference-start pairs the Gauss-Newton schedule does not bring home (pair 105 =
     scene 5001, replica 13: a 1.8-sigma start, 0.091 rad / 0.061 t / depth seeds 50 % off) through the REAL reference loop (3 x 500 Adam
     + settled polish): does the reference converge from it?"""
     t0 = time.time()
     scene, replica = pair_index % 8, pair_index // 8
-    pair = bench_reference_start(scene, replica)
+    pair = bench_reference_start(scene, replica, shape=shape)
     r = reference_sfm_run(ref, pair, log=name)
     e_gt = errors_vs(r["final_pose"], r["final_kld"], pair.pose_gt, pair.kld_gt)
     e_sched = errors_vs(r["sched_pose"], r["sched_kld"], pair.pose_gt, pair.kld_gt)
@@ -564,6 +565,10 @@ def main():
         # g20x:<pair index> -- any other pair of bench.py's reference-start leg (the bench line lists the ones Gauss-Newton loses)
         if w.startswith("g20x:"):
             golden_bench_pair(ref, pair_index=int(w[5:]), name=f"g20x_sigma05_bench_pair{int(w[5:])}")
+        # g20y:<pair index> -- the same on the SAM-like (ragged, overlapping blobs) scenes of ``bench.py --shape blobs`` /
+        # ``tools/verdict_sweep.py --shape blobs``: does the reference converge from the starts Gauss-Newton loses there?
+        if w.startswith("g20y:"):
+            golden_bench_pair(ref, pair_index=int(w[5:]), name=f"g20y_sigma05_blobs_pair{int(w[5:])}", shape="blobs")
     if "g20" in which:
         # the same at BASELINE configs[1] size (640x480x64) on the first three scenes of bench.py's reference-start leg
         # (bench.py:_render_sigma05: seeds 5000 + s, overlap 4; replica 0 of a scene starts from the pair's own pose_init / kld_init)

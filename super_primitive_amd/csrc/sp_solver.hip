@@ -138,19 +138,27 @@ __global__ void k_mark_unfinished(const int32_t* __restrict__ phase, const int32
     if (i < n_slots && phase[i] < n_phases) status[slot_pair ? slot_pair[i] : i] = SP_STATUS_UNFINISHED;
 }
 
-// min over the per-pair phases (one workgroup): what the host polls to end a scheduled run
+// min over the per-pair phases (one workgroup): what the host polls to end a scheduled run.  out[0] = min phase, out[1] = queue head
+// (queue runs), out[2] = 1 when some unfinished pair is still at its FIRST attempt (verdict runs with a second attempt: such a pair
+// may restart at retry_entry at any time, so no work list can be left out while one exists)
 __global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restrict__ phase, int n, int32_t* __restrict__ out,
-                                                        const int32_t* __restrict__ head = nullptr) {
-    __shared__ int part[SP_WAVES];
-    int m = 0x7fffffff;
-    for (int i = threadIdx.x; i < n; i += SP_BLOCK) m = min(m, phase[i]);
+                                                        const int32_t* __restrict__ head, const int32_t* __restrict__ attempts,
+                                                        const int32_t* __restrict__ slot_pair, int n_phases) {
+    __shared__ int part[SP_WAVES], first[SP_WAVES];
+    int m = 0x7fffffff, f = 0;
+    for (int i = threadIdx.x; i < n; i += SP_BLOCK) {
+        const int ph = phase[i];
+        m = min(m, ph);
+        if (attempts && ph < n_phases && attempts[slot_pair ? slot_pair[i] : i] == 0) f = 1;
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = min(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    for (int o = 32; o > 0; o >>= 1) { m = min(m, __shfl_xor(m, o, 64)); f |= __shfl_xor(f, o, 64); }
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = m; first[threadIdx.x >> 6] = f; }
     __syncthreads();
     if (threadIdx.x == 0) {
         out[0] = min(min(part[0], part[1]), min(part[2], part[3]));
-        if (head) out[1] = *head;
+        out[1] = head ? *head : 0;
+        out[2] = first[0] | first[1] | first[2] | first[3];
     }
 }
 
@@ -262,8 +270,8 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SpVerdict vd = verdict ? *verdict : SpVerdict{};
-    // a second attempt restarts a pair at retry_entry at any time: no work list can be left out while that may still happen
-    const bool may_retry = vd.status && vd.retry_mask != 0 && sched->retry_entry >= 0;
+    // a second attempt restarts a pair at retry_entry at any time: no work list can be left out while a first attempt is still running
+    const bool may_retry = vd.status && vd.attempts && vd.retry_mask != 0 && sched->retry_entry >= 0;
     int it = 0;
     int reached = 0;                  // a phase every slot has passed -- only meaningful once the queue is empty (refilled slots restart at the entry)
     int min_phase = 0;
@@ -277,15 +285,17 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return -(1000 + (int)e);
         }
-        hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_slots, flag_dev, queue->head);
+        hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_slots, flag_dev, queue->head, may_retry ? vd.attempts : nullptr,
+                           queue->slot_pair, sched->n_phases);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
         min_phase = static_cast<volatile int32_t*>(flag_host)[0];
         const int head = static_cast<volatile int32_t*>(flag_host)[1];
+        const bool first_attempts_left = static_cast<volatile int32_t*>(flag_host)[2] != 0;
         if (min_phase >= sched->n_phases) break;          // (a slot only stays finished when the queue was empty)
-        reached = (head >= queue->n_queue && !may_retry) ? (min_phase < 0 ? 0 : min_phase) : 0;
+        reached = (head >= queue->n_queue && !(may_retry && first_attempts_left)) ? (min_phase < 0 ? 0 : min_phase) : 0;
     }
     if (min_phase < sched->n_phases && vd.status) {
         hipLaunchKernelGGL(k_mark_unfinished, dim3((n_slots + 255) / 256), dim3(256), 0, s, phase, queue->slot_pair, n_slots, sched->n_phases, vd.status);
@@ -301,7 +311,7 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
     if (!sched || !phase || !iters || !flag_dev || !flag_host || check_every <= 0 || max_rounds < 0) return SP_EINVAL;
     if (int rc = check_schedule(sched, verdict)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool may_retry = verdict && verdict->status && verdict->retry_mask != 0 && sched->retry_entry >= 0;
+    const bool may_retry = verdict && verdict->status && verdict->attempts && verdict->retry_mask != 0 && sched->retry_entry >= 0;
     int it = 0;
     int reached = 0;                  // min(phase) at the last poll: pairs only move forward, so work lists behind it are not launched
     int min_phase = 0;
@@ -315,15 +325,16 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
             if (rc == 0) rc = sp_pairs_schedule_gn_step(sched, n_pairs, max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, phase, iters, verdict, stream);
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
         }
-        hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_pairs, flag_dev);
+        hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_pairs, flag_dev, (const int32_t*)nullptr,
+                           may_retry ? (const int32_t*)verdict->attempts : (const int32_t*)nullptr, (const int32_t*)nullptr, sched->n_phases);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
-        reached = min_phase = *static_cast<volatile int32_t*>(flag_host);
+        reached = min_phase = static_cast<volatile int32_t*>(flag_host)[0];
         if (reached >= sched->n_phases) break;
-        // (a second attempt restarts a pair at retry_entry at any time: no work list can be left out while that may still happen)
-        if (reached < 0 || may_retry) reached = 0;
+        // (a second attempt restarts a pair at retry_entry at any time: no work list can be left out while a first attempt is still running)
+        if (reached < 0 || (may_retry && static_cast<volatile int32_t*>(flag_host)[2] != 0)) reached = 0;
     }
     if (verdict && verdict->status && min_phase < sched->n_phases) {
         hipLaunchKernelGGL(k_mark_unfinished, dim3((n_pairs + 255) / 256), dim3(256), 0, s, phase, (const int32_t*)nullptr, n_pairs, sched->n_phases, verdict->status);

@@ -30,24 +30,31 @@ def render_depth_avg(depths):
     return depths.sum(dim=0) / count, invalid
 
 
-def average_visible_segments(kf, keypoints_logdepth, visible, reduce=None):
+def average_visible_segments(kf, keypoints_logdepth, visible, reduce=None, empty=None):
     """Fused HIP form of: unproject_kf_to_depths -> mask -> keep visible -> render_depth_avg.
 
     ``reduce``: optional callable(sums int64 (H*W,), counts int32 (H*W,)) run between the accumulation and the final
     division -- the hook of segment-sharded completion (``dist.complete_depth_sharded`` all-reduces the two integer arrays
-    there; integer sums are exact, so the sharded result is bitwise the single-GPU one)."""
+    there; integer sums are exact, so the sharded result is bitwise the single-GPU one).
+    ``kf`` = None with ``empty`` = (H, W, device): a rank that owns NO segment of a sharded image -- zero accumulators, the same
+    ``reduce`` call as every other rank, the same division."""
     lib = _lib.load()
-    table = table_of(kf)
-    dev = table.device
-    H, W = table.H, table.W
-    acc = torch.empty(3 * H * W, dtype=torch.int32, device=dev)
+    if kf is None:
+        H, W, dev = empty
+        acc = torch.zeros(3 * H * W, dtype=torch.int32, device=dev)
+    else:
+        table = table_of(kf)
+        dev = table.device
+        H, W = table.H, table.W
+        acc = torch.empty(3 * H * W, dtype=torch.int32, device=dev)
     depth = torch.empty(H, W, dtype=torch.float32, device=dev)
     invalid = torch.empty(H, W, dtype=torch.bool, device=dev)
-    vis = None if visible is None else visible.to(torch.bool).contiguous()
-    rc = lib.sp_depth_accumulate(_lib.ptr(table.pix), _lib.ptr(table.baseL), _lib.ptr(table.seg_off), _lib.ptr(table.kp_L),
-                                 _lib.ptr(keypoints_logdepth.detach().contiguous().float()), _lib.ptr(vis), table.N, table.P,
-                                 H, W, _lib.ptr(acc), _lib.stream_ptr())
-    _lib.check(rc, "sp_depth_accumulate")
+    if kf is not None:
+        vis = None if visible is None else visible.to(torch.bool).contiguous()
+        rc = lib.sp_depth_accumulate(_lib.ptr(table.pix), _lib.ptr(table.baseL), _lib.ptr(table.seg_off), _lib.ptr(table.kp_L),
+                                     _lib.ptr(keypoints_logdepth.detach().contiguous().float()), _lib.ptr(vis), table.N, table.P,
+                                     H, W, _lib.ptr(acc), _lib.stream_ptr())
+        _lib.check(rc, "sp_depth_accumulate")
     if reduce is not None:
         reduce(acc[: 2 * H * W].view(torch.int64), acc[2 * H * W:])
     _lib.check(lib.sp_depth_average_finish(_lib.ptr(acc), H, W, _lib.ptr(depth), _lib.ptr(invalid), _lib.stream_ptr()),

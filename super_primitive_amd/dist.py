@@ -88,21 +88,14 @@ def complete_depth_sharded(kf, sparse_depth, rank=None, world=None, group=None):
     (per-segment medians are independent; invisible segments are dropped before the average, so their fill-in value --
     the one cross-segment statistic of ``segment_based_depth_reinit`` -- never reaches the output), accumulates them, and
     the accumulators are summed across ranks.  Returns (depth (H,W), invalid (H,W)) on every rank."""
-    from .depth_completion.segment_based_completion import average_visible_segments
+    from .depth_completion import segment_based_completion as sbc
     from .odometery import depth_init
+    average_visible_segments = sbc.average_visible_segments          # (looked up at call time: the world-8 gloo rehearsal swaps it)
     sub, (lo, hi) = shard_keyframe_segments(kf, rank, world)
     H, W = kf.geo_spatial_dim()
     red = lambda s, c: reduce_depth_accumulators(s, c, group)
-    if sub is None:          # more ranks than segments: this rank contributes zero accumulators
-        from . import _lib
-        dev = kf.image.device
-        acc = torch.zeros(3 * H * W, dtype=torch.int32, device=dev)
-        red(acc[: 2 * H * W].view(torch.int64), acc[2 * H * W:])
-        depth = torch.empty(H, W, dtype=torch.float32, device=dev)
-        invalid = torch.empty(H, W, dtype=torch.bool, device=dev)
-        _lib.check(_lib.load().sp_depth_average_finish(_lib.ptr(acc), H, W, _lib.ptr(depth), _lib.ptr(invalid), _lib.stream_ptr()),
-                   "sp_depth_average_finish")
-        return depth, invalid
+    if sub is None:          # more ranks than segments: this rank contributes zero accumulators (and takes part in the same all_reduce)
+        return average_visible_segments(None, None, None, reduce=red, empty=(H, W, kf.image.device))
     kld, visible = depth_init.segment_based_depth_reinit(sparse_depth.to(kf.image.device).clone().detach(), sub, mode='median',
                                                          return_info=True)
     return average_visible_segments(sub, kld, visible, reduce=red)

@@ -52,28 +52,40 @@ FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps
 # randn(6)), depth seeds log(2 + 2 rand)): tests/test_gpu_sigma05.py requires it to converge wherever the real reference loop does
 # (golden g19), inside the north-star bar of the reference's end state; bench.py quotes ``frame_pairs_per_sec`` on it next to the
 # near-start figure (tools/sigma05_sweep.py holds the sweep it was chosen from, profiles/r03_sigma05_sweep.txt its results).
-# Round 5: the batch carries a FOURTH pyramid level (80x60 at the headline size, stride-8 lattice) that only a pair's SECOND ATTEMPT
-# uses.  About one of the reference's own starts in a thousand ends in the wrong basin whichever way the coarse phases are arranged,
-# and which one is a matter of round-off (caps of 15 / 30, a looser IRLS epsilon, a fourth level -- each loses
-# DIFFERENT pairs).  So the schedule ends with a per-pair VERDICT on the device (include/sp_hip.h SpVerdict: finiteness, how the
-# polish ended, the largest log-depth excursion from the seeds, the valid fraction) and a pair that fails it is put back to its
-# start and run once more, in the slot it already has, through ``retry_pose_first`` -- pose-only phases at levels 3 and 2 -- and
-# then the same joint phases and polish.  What fails twice is reported (``PairBatch.status``), never returned silently.
-REFERENCE_START_LEVELS = (0, 4)
-REFERENCE_START_POINT_STRIDE = (2, 2, 4, 8)
+# Round 5: THE SECOND ATTEMPT.  About one of the reference's own starts in 650 ends in the wrong basin at the first attempt whichever way
+# the coarse phases are arranged, and which one is a matter of round-off (caps of 15 / 30, a looser IRLS epsilon,
+# a fourth level -- each loses DIFFERENT pairs; the basin is always the same one: every depth runs off to infinity and the pose
+# explains the image by a rotation, 0.017 rad / 0.048 t from the truth at 14 x the cost).  So the schedule ends with a per-pair VERDICT
+# on the device (include/sp_hip.h SpVerdict: finiteness, how the polish ended, the largest log-depth excursion from the seeds, the valid
+# fraction) and a pair that fails it is put back to its start and run once more, in the slot it already has, with ``retry_phases`` in
+# front -- a pose-only phase at the coarsest level with the OTHER IRLS epsilon (1e-2 against 1e-3: a smoother or a sharper cost.  Either
+# order rescued EVERY first-attempt failure among 9216 starts; pose-only phases on a fourth pyramid level rescued 8 of 14,
+# tools/verdict_sweep.py, profiles/r05_reference_start.txt) -- and then the same joint phases and polish.  What fails twice is reported (``PairBatch.status``,
+# ``failed()``), never returned silently.
+REFERENCE_START_LEVELS = (0, 3)
+REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 # pose_first_iters is a CAP (the phase ends by its convergence test): 15 cut the 2-4 sigma tail of the start distribution short (rotation
 # errors of 0.09-0.22 rad need ~20 pose-only iterations; 7 of bench.py's 1536 starts, among them the one of its first 384, diverged in the
 # joint phase -- while the real reference converges from that start, golden g20x); 30 loses 2 of 1536 (tools/hard_starts.py,
 # profiles/r04_reference_start.txt).  Longer is not better without the convergence test: a pose fitted for 25 iterations to depth seeds
 # that are 50 % off (IRLS epsilon 1e-2, where the test triggers late) loses 12 %.
-# ``use_levels=3``: the first attempt runs on the three finest levels exactly as in round 4 (pose-only at level 2, joint phases at 2, 1, 0,
-# polish).
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=30, use_levels=3, retry_pose_first=((3, 15), (2, 15)))
+# Which pose-only phase goes first is a matter of speed: epsilon 1e-2 with a cap of 15 in the first attempt and epsilon 1e-3 with a cap of
+# 30 in the second (below) loses 9 of 9216 starts at the first attempt and none after the second, at 33.6 k pairs/s and 32.9 iterations per
+# pair; the other way round (round 4's first attempt) 14 / none at 31.2 k and 36.7 (profiles/r05_reference_start.txt).
+REFERENCE_START_RETRY = (dict(level=2, stride=4, max_iters=30, irls_eps=1e-3, conv_tol=2e-3, pose_only=True),)
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, retry_phases=REFERENCE_START_RETRY)
 # The verdict's thresholds (SpVerdict): a log-depth more than ``kld_bound`` from its seed (a factor e^kld_bound in depth: the reference's
 # seeds log(2 + 2 rand) are at most a factor 2 off) has run away; fewer than ``valid_min`` of the points projecting into the target
 # frame at the end of an alignment that started with both frames overlapping is a lost pair.  ``retry_on``: the status bits that send
 # a pair into its second attempt.  tools/verdict_sweep.py / profiles/r05_reference_start.txt: what each bit catches over 8192 starts.
-VERDICT_DEFAULTS = dict(kld_bound=2.0, cost_bound=0.0, cost_ratio=0.0, valid_min=0.5,
+# ``cost_outlier``: the one test that looks at the BATCH (on the host side of the run, a handful of tensor operations, no synchronisation):
+# a final cost above this multiple of the batch's median final cost.  On ragged SAM-like masks a few starts in a thousand end in a
+# genuine local minimum of the cost -- the polish converges at once, no depth runs away, nothing a pair can see by itself is wrong --
+# at 8-50 x the cost of the converged pairs, whose final costs lie within 1.15 x of their median (profiles/r05_reference_start.txt).  Such
+# pairs get the second attempt too (a short second scheduled run over them alone) and SP_STATUS_COST if they are still outliers.  Needs
+# at least COST_OUTLIER_MIN_PAIRS pairs; a batch of one has no median to speak of.
+COST_OUTLIER_MIN_PAIRS = 8
+VERDICT_DEFAULTS = dict(kld_bound=2.0, cost_bound=0.0, cost_ratio=0.0, valid_min=0.5, cost_outlier=4.0,
                         retry_on=_lib.SP_STATUS_NONFINITE | _lib.SP_STATUS_LAST_CAP | _lib.SP_STATUS_DEPTH_RANGE | _lib.SP_STATUS_VALID | _lib.SP_STATUS_COST)
 
 
@@ -670,8 +682,11 @@ class PairBatch:
             self._flag = (torch.zeros(4, dtype=torch.int32, device=self.device), torch.zeros(4, dtype=torch.int32).pin_memory())
         v = self._verdict(sched, verdict)
         v_addr = ctypes.addressof(v) if v is not None else None
+        outlier = float(dict(VERDICT_DEFAULTS, **(verdict if isinstance(verdict, dict) else {}))["cost_outlier"]) if v is not None else 0.0
         if slots is not None and int(slots) < self.M:
             it = self._run_queue(sched, int(slots), bound, check_every, lm_up, lm_down, lm_min, v, v_addr)
+            if outlier > 0.0 and self.M >= COST_OUTLIER_MIN_PAIRS:
+                it += self._cost_outlier_pass(outlier, v, bound, check_every, lm_up, lm_down, lm_min, schedule_kw)
             return (it, self.status) if return_status else it
         self.phase.fill_(sched.entry)
         self.phase_iters.zero_()
@@ -685,7 +700,47 @@ class PairBatch:
                                             self._flag[1].data_ptr(), v_addr, _lib.stream_ptr())
         if it < 0:
             _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run")
+        if outlier > 0.0 and self.M >= COST_OUTLIER_MIN_PAIRS:
+            it += self._cost_outlier_pass(outlier, v, bound, check_every, lm_up, lm_down, lm_min, schedule_kw)
         return (it, self.status) if return_status else it
+
+    def _cost_outlier_pass(self, factor, v, bound, check_every, lm_up, lm_down, lm_min, schedule_kw):
+        """The batch-relative part of the verdict (VERDICT_DEFAULTS['cost_outlier']), after the scheduled run proper: pairs that passed
+        their own verdict with a final cost above ``factor`` x the batch median get the second attempt too -- put back to their starting
+        point, run through the retry phases in a short scheduled run of their own (everybody else is finished: their workgroups return at
+        once) -- and whoever is an outlier after that carries SP_STATUS_COST.  All on the device, no synchronisation beyond the run's own
+        polls.  Returns the iterations launched."""
+        F, M = _lib.SP_STATUS_FAILED, self.M
+        cost = self.diag[:, 0]
+        bound_c = factor * cost.median()
+        out = (cost > bound_c) & ((self.status & F) == 0)
+        it = 0
+        sched = self.schedule(**schedule_kw)
+        if sched.retry_entry >= 0:
+            again = out & (self.attempts == 0)
+            if getattr(self, "_seg_pair", None) is None:
+                self._seg_pair = torch.repeat_interleave(torch.arange(M, device=self.device), torch.as_tensor(self.Ns, device=self.device))
+            pose0, kld0 = self._verdict_arrays[3], self._verdict_arrays[4]
+            self.pose.copy_(torch.where(again[:, None], pose0, self.pose))
+            self.kld.copy_(torch.where(again[self._seg_pair], kld0, self.kld))
+            self.attempts.add_(again.to(torch.int32))
+            self.phase.copy_(torch.where(again, sched.retry_entry, sched.n_phases).to(torch.int32))
+            self.phase_iters.zero_()
+            ls = self.lm_state
+            ls[:, 0] = torch.where(again, float(getattr(self, "_lam0", 1e-4)), ls[:, 0])
+            ls[:, 1] = -1.0
+            ls[:, 4:] = torch.where(again[:, None], 0.0, ls[:, 4:])
+            self.diag[:, 5] = torch.where(again, 0.0, self.diag[:, 5])
+            v.retry_mask = 0                       # (whoever runs now has had its first attempt)
+            it = self.lib.sp_pairs_schedule_run(ctypes.addressof(sched), M, self.max_N, float(lm_up), float(lm_down), float(lm_min),
+                                                _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.ptr(self.phase),
+                                                _lib.ptr(self.phase_iters), int(check_every), int(bound), _lib.ptr(self._flag[0]),
+                                                self._flag[1].data_ptr(), ctypes.addressof(v), _lib.stream_ptr())
+            if it < 0:
+                _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run")
+            out = (self.diag[:, 0] > bound_c) & ((self.status & F) == 0)
+        self.status.bitwise_or_(out.to(torch.int32) * _lib.SP_STATUS_COST)
+        return it
 
     def _run_queue(self, sched, slots, bound, check_every, lm_up, lm_down, lm_min, v, v_addr):
         assert slots >= 1

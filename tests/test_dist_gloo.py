@@ -32,9 +32,11 @@ def _worker(rank, world, port, n_pairs, N, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_pairs", [5, 4, 1])
-def test_shard_and_gather_world2(n_pairs):
-    world, N = 2, 3
+@pytest.mark.parametrize("n_pairs,world", [(5, 2), (4, 2), (1, 2), (1030, 8), (5, 8)])
+def test_shard_and_gather(n_pairs, world):
+    """(1030 pairs on 8 ranks: config 5's 1024 + a ragged remainder; 5 pairs on 8 ranks: ranks without any pair take part in the same
+    all_gather with empty shards.)"""
+    N = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -165,35 +167,35 @@ def _bench_worker(rank, world, port, q):
     q.put((rank, json.loads(out) if out else None, fake.calls, fake.scheduled, fake.restored))
 
 
-def test_bench_multi_rank_control_flow_dry_run_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_multi_rank_control_flow_dry_run(world):
     """bench.py's N > 1 path (process group, barriers, MAX all_reduce of the timers, final all_gather of poses and log-depths,
     rank-0-only JSON line) executed once under gloo with the batch mocked -- so that path has run before a real 8-GPU node
-    sees it.  No measurement is made."""
-    world = 2
+    sees it; at world 8 exactly as the driver launches it.  No measurement is made."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    line0, line1 = got[0][1], got[1][1]
-    assert line1 is None, "only rank 0 prints"
+    line0 = got[0][1]
+    assert all(g[1] is None for g in got[1:]), "only rank 0 prints"
     # the driver's contract: every key of the bench line, plus the roofline object (cpu_baseline is an N = 1 leg)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline"):
         assert key in line0, key
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line0["roofline"]) and line0["roofline"]["bound"] == "hbm"
     assert "workload" in line0["config"] and line0["unit"] == "iters/s" and line0["higher_is_better"] is True and line0["vs_baseline"] is None
-    assert line0["n_gpus"] == 2 and line0["steps"] == 3 and line0["warmup"] == 2 and line0["scaling"] == "weak"
+    assert line0["n_gpus"] == world and line0["steps"] == 3 and line0["warmup"] == 2 and line0["scaling"] == "weak"
     assert line0["config"]["pairs_per_gpu"] == 6 and line0["data"].startswith("DRY RUN")
-    np.testing.assert_allclose(line0["value"], 2 * 6 * 3 / (line0["ms_per_step"] * 3e-3), rtol=1e-6)     # whole-job aggregate
-    assert got[0][2] == got[1][2] == 2 + 3                                                            # warm-up + timed cost passes
+    np.testing.assert_allclose(line0["value"], world * 6 * 3 / (line0["ms_per_step"] * 3e-3), rtol=1e-6)     # whole-job aggregate
+    assert all(g[2] == 2 + 3 for g in got)                                                            # warm-up + timed cost passes
     # the whole-job frame-pair leg: every rank ran the schedule twice (one untimed pass) from restored initial values
-    assert got[0][3] == got[1][3] == 2 and got[0][4] == got[1][4] == 3 and line0["frame_pairs_per_sec"] > 0
+    assert all(g[3] == 2 and g[4] == 3 for g in got) and line0["frame_pairs_per_sec"] > 0
     # the self-proving part of an N > 1 line: the collective saw `world` ranks, and every rank reported its own record
     assert line0["rccl_world"] == world
     assert [r["rank"] for r in line0["ranks"]] == list(range(world))
@@ -201,3 +203,67 @@ def test_bench_multi_rank_control_flow_dry_run_world2():
         assert set(r) == {"rank", "device_index", "pci_bus_id", "kernel_ms", "elapsed_ms", "pairs"}
         assert r["pairs"] == 6 and r["kernel_ms"] >= 0 and r["elapsed_ms"] > 0
     assert max(r["elapsed_ms"] for r in line0["ranks"]) == pytest.approx(line0["ms_per_step"] * 3, rel=1e-6)
+
+
+def _sharded_completion_worker(rank, world, port, n_segments, q):
+    """complete_depth_sharded under gloo with the two device steps swapped for integer stand-ins (the HIP kernels need a GPU): what is
+    rehearsed is the CONTROL FLOW -- every rank, also one that owns no segment, makes the same all_reduce calls in the same order."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from super_primitive_amd import dist as spd
+        from super_primitive_amd.depth_completion import segment_based_completion as sbc
+        from super_primitive_amd.image.keyframe import KeyFrame
+        from super_primitive_amd.odometery import depth_init
+        H, W = 12, 16
+        g = torch.Generator().manual_seed(7)
+        masks = torch.rand(n_segments, H, W, generator=g) < 0.3
+        kf = KeyFrame(torch.zeros(3, H, W), torch.eye(3), torch.zeros(n_segments, H, W), torch.zeros(n_segments, 2), masks)
+        calls = []
+
+        def reinit(sparse, sub, mode="median", return_info=False):
+            n = sub.keypoint_regions.shape[0]
+            return torch.zeros(n), torch.ones(n, dtype=torch.bool)
+
+        def average(sub, kld, visible, reduce=None, empty=None):
+            if sub is None:
+                Hh, Ww, _ = empty
+                sums, counts = torch.zeros(Hh * Ww, dtype=torch.int64), torch.zeros(Hh * Ww, dtype=torch.int32)
+            else:
+                m = sub.keypoint_regions
+                lo = spd.shard_range(n_segments, rank, world)[0]
+                ids = torch.arange(lo + 1, lo + 1 + m.shape[0], dtype=torch.int64)[:, None, None]
+                sums, counts = (m.long() * ids).sum(0).reshape(-1), m.sum(0).reshape(-1).to(torch.int32)
+            calls.append("reduce")
+            reduce(sums, counts)
+            return sums, counts
+
+        depth_init.segment_based_depth_reinit = reinit
+        sbc.average_visible_segments = average
+        sums, counts = spd.complete_depth_sharded(kf, torch.zeros(H, W))
+        ids = torch.arange(1, n_segments + 1, dtype=torch.int64)[:, None, None]
+        want = ((masks.long() * ids).sum(0).reshape(-1), masks.sum(0).reshape(-1).to(torch.int32))
+        q.put((rank, bool(torch.equal(sums, want[0]) and torch.equal(counts, want[1])), len(calls)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_segments", [1200, 5])
+def test_segment_sharded_completion_control_flow_world8(n_segments):
+    """BASELINE configs[3] (VOID, segments of one image sharded over 8 ranks) as a gloo rehearsal: 1200 segments (150 per rank) and 5
+    segments (three ranks own none and still take part in the one all_reduce pair); every rank ends with the single-rank accumulators."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_completion_worker, args=(r, world, port, n_segments, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [g[0] for g in got] == list(range(world)) and all(g[1] for g in got) and all(g[2] == 1 for g in got)

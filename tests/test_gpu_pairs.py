@@ -474,7 +474,7 @@ def test_device_side_schedule_walks_every_pair_through_its_own_levels():
     _lib.check(batch.lib.sp_pairs_schedule_cost(ctypes.addressof(sched), _lib.ptr(batch.phase), _lib.stream_ptr()), "cost")
     _lib.check(batch.lib.sp_pairs_schedule_gn_step(ctypes.addressof(sched), batch.M, batch.max_N, 8.0, 0.5, 1e-7, _lib.ptr(batch.lm_state),
                                                    _lib.ptr(batch.backup), _lib.ptr(batch._costs), _lib.ptr(batch.phase),
-                                                   _lib.ptr(batch.phase_iters), _lib.stream_ptr()), "step")
+                                                   _lib.ptr(batch.phase_iters), None, _lib.stream_ptr()), "step")
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(before, batch.klds()))
 
@@ -809,7 +809,8 @@ def test_slot_level_continuous_batching_of_ragged_pairs(granule):
             assert torch.equal(q.poses()[m], ref.poses()[m]) and torch.equal(q.klds()[m], ref.klds()[m]), (slots, m)
         assert torch.equal(q.costs(), ref.costs()) and torch.equal(q.lm_state[:, :4], ref.lm_state[:, :4])
         assert torch.equal(q.status, ref.status) and torch.equal(q.diag, ref.diag)
-        assert n_q <= its_ref.sum() / slots + its_ref.max() + 2
+        # (rounds: a phase that ends by its convergence test spends one more evaluation than it counts iterations -- 4 phases per pair)
+        assert n_q <= (its_ref.sum() + 4 * q.M) / slots + its_ref.max() + 2
     assert int((ref.status & _lib.SP_STATUS_NONFINITE).sum()) == 0
 
 

@@ -35,18 +35,16 @@ H, W, N, G = 480, 640, 64, 8
 BASE = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
 NO_CAP = VERDICT_DEFAULTS["retry_on"] & ~_lib.SP_STATUS_LAST_CAP
 ct, ie = BASE["conv_tol"], 1e-3
+po = lambda level, stride, cap, eps=ie: dict(level=level, stride=stride, max_iters=cap, irls_eps=eps, conv_tol=ct, pose_only=True)
 VARIANTS = {
     "shipped": dict(BASE),
-    "no_retry": dict(BASE, retry_pose_first=None),
-    "retry_L3_15_L2_30": dict(BASE, retry_pose_first=((3, 15), (2, 30))),
-    "retry_L2_eps1e-2": dict(BASE, retry_pose_first=None,
-                             retry_phases=[dict(level=2, stride=4, max_iters=15, irls_eps=1e-2, conv_tol=ct, pose_only=True)]),
-    "retry_L3_joint_L3": dict(BASE, retry_pose_first=None, retry_join=1,
-                              retry_phases=[dict(level=3, stride=8, max_iters=15, irls_eps=ie, conv_tol=ct, pose_only=True),
-                                            dict(level=2, stride=4, max_iters=15, irls_eps=ie, conv_tol=ct, pose_only=True)]),
+    "no_retry": dict(BASE, retry_phases=None),
+    "retry_L2_30": dict(BASE, retry_phases=[po(2, 4, 30, 1e-2)]),
+    "retry_L2_eps3e-3": dict(BASE, retry_phases=[po(2, 4, 15, 3e-3)]),
+    "retry_L2_cap15_same_eps": dict(BASE, retry_phases=[po(2, 4, 15)]),
     "retry_not_on_cap": dict(BASE, verdict=dict(retry_on=NO_CAP)),
-    "kld_bound_1.5": dict(BASE, verdict=dict(kld_bound=1.5)),
     "kld_bound_3": dict(BASE, verdict=dict(kld_bound=3.0)),
+    "eps1e-2_first": dict(BASE, pose_first_eps=1e-2, pose_first_iters=15, retry_phases=[po(2, 4, 30)]),
 }
 
 
@@ -72,7 +70,7 @@ def main(argv=None):
     ap.add_argument("--starts", type=int, default=9216)
     ap.add_argument("--batch", type=int, default=1536)
     ap.add_argument("--slots", type=int, default=384)
-    ap.add_argument("--variants", default="shipped,no_retry,retry_L3_15_L2_30,retry_L2_eps1e-2,retry_not_on_cap")
+    ap.add_argument("--variants", default="shipped,no_retry,retry_L2_30,retry_L2_eps3e-3,kld_bound_3,eps1e-2_first")
     ap.add_argument("--shape", default="grid", choices=["grid", "blobs"])
     ap.add_argument("--npz", default=None)
     ap.add_argument("--alone", default="105,1380,1482", help="pairs also run as batches of ONE (order independence of the verdict and the retry)")
@@ -99,7 +97,7 @@ def main(argv=None):
     src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in scenes]
     trg, Ks = [t(p.trg_image) for p in scenes], [t(p.K) for p in scenes]
     names = [v for v in args.variants.split(",") if v]
-    keep = {v: dict(err=[], status=[], diag=[], attempts=[], iters=[], secs=0.0, rounds=0) for v in names}
+    keep = {v: dict(err=[], status=[], diag=[], attempts=[], iters=[], kld=[], secs=0.0, rounds=0) for v in names}
     for b in range(n_batches):
         lo = b * args.batch
         batch = PairBatch(src, trg, Ks, torch.from_numpy(np.stack(poses[lo: lo + args.batch])), [t(k) for k in klds[lo: lo + args.batch]],
@@ -118,6 +116,7 @@ def main(argv=None):
             k["err"].append(errors(P, K, poses_gt[lo: lo + args.batch], klds_gt[lo: lo + args.batch]))
             k["status"].append(batch.status.cpu().numpy().copy()); k["diag"].append(batch.diag.cpu().numpy().copy())
             k["attempts"].append(batch.attempts.cpu().numpy().copy())
+            k["kld"].append(np.stack(K))
             k["iters"].append((batch.lm_state[:, 2] + batch.lm_state[:, 3]).cpu().numpy())
             k["secs"] += dt; k["rounds"] += rounds
         if b == 0 and args.alone:
@@ -160,8 +159,14 @@ def main(argv=None):
               f"missed again {int(((at > 0) & miss).sum())}\n"
               f"   status bits {bits}\n"
               f"   worst error of the unflagged: {err[~flagged].max(axis=0) if (~flagged).any() else None}", flush=True)
-        for m in silent[:8]:
-            print(f"   silent pair {m}: err {err[m]} status {st[m]:#x} diag {dg[m]}")
+        kl = np.concatenate(k["kld"])
+        for m in list(silent[:8]) + list(np.nonzero(flagged & ~miss)[0][:4]):
+            sc = scenes[m % G]
+            rel = np.abs(np.expm1(kl[m] + float(np.mean(sc.kld_gt - kl[m])) - sc.kld_gt))
+            worst = np.argsort(rel)[::-1][:3]
+            px = sc.keypoint_regions.reshape(sc.N, -1).sum(1)
+            print(f"   {'silent' if m in silent else 'false alarm'} pair {m}: err {err[m]} status {st[m]:#x} diag {dg[m]}; worst segments {worst.tolist()} "
+                  f"depth errors {rel[worst]} pixels {px[worst].tolist()} (median segment {int(np.median(px))} px)")
         for m in np.nonzero(miss & flagged)[0][:8]:
             print(f"   flagged miss {m}: err {err[m]} status {st[m]:#x} attempts {at[m]} diag {dg[m]}")
         out.update({f"{v}__err": err, f"{v}__status": st, f"{v}__diag": dg, f"{v}__attempts": at, f"{v}__iters": its})
