@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 11
+#define SP_ABI_VERSION 12
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -126,7 +126,14 @@ typedef struct SpPrepTable {     /* one keyframe: its masks are read once per pa
                                     read by sp_prepare_fill INSTEAD of the masks (4 instead of 16 bytes per 16 pixels); NULL, or a
                                     keyframe off the fast path: the fill pass reads the masks.  logdepth must be 16-byte aligned
                                     when bits is given */
-} SpPrepTable;                   /* 232 bytes */
+    const int32_t* boxes;        /* NULL, or N x {row0, col0, row1, col1} (half open, pixels): a HINT from whoever made the masks -- SAM's
+                                    frontend computes and NMS-filters exactly these (frontend/segment/mask_generation.py:93,155-180) --
+                                    that segment n has no set pixel outside its box.  The count pass then reads the masks inside
+                                    the boxes only (the 16-pixel pieces that meet them), ~1 MB of a 640x480x64 keyframe's 19.7 MB;
+                                    boxes are clamped to the image, an empty or inverted box is an empty segment, and a mask pixel
+                                    outside its box is NOT SEEN (the caller's contract).  Fast path only (see bits); ignored on the
+                                    general path, which scans everything */
+} SpPrepTable;                   /* 240 bytes */
 typedef struct SpPrepSample {    /* one table, sampled at up to SP_PREP_MAX_LEVELS pyramid levels in one pass; sets pix bit 31 */
     uint32_t* pix;
     const float* baseL;

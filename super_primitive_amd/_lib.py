@@ -73,7 +73,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 11
+SP_ABI_VERSION = 12
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GNA_PARTIAL_FLOATS = 48
@@ -113,7 +113,7 @@ class SpPrepTable(ctypes.Structure):
                 ("row_counts", c_void_p * SP_PREP_MAX_STRIDES), ("counts", c_void_p * SP_PREP_MAX_STRIDES),
                 ("seg_off", c_void_p * SP_PREP_MAX_STRIDES), ("pix", c_void_p * SP_PREP_MAX_STRIDES),
                 ("baseL", c_void_p * SP_PREP_MAX_STRIDES), ("stride", c_int * SP_PREP_MAX_STRIDES),
-                ("N", c_int), ("H", c_int), ("W", c_int), ("n_strides", c_int), ("bits", c_void_p)]
+                ("N", c_int), ("H", c_int), ("W", c_int), ("n_strides", c_int), ("bits", c_void_p), ("boxes", c_void_p)]
 
 
 class SpPrepSample(ctypes.Structure):

@@ -305,6 +305,7 @@ struct PrepTable {
     int32_t stride[SP_PREP_MAX_STRIDES];
     int32_t N, H, W, n_strides;
     SP_GLOBAL uint32_t* bits;
+    const SP_GLOBAL int32_t* boxes;
 };
 struct PrepSample {
     SP_GLOBAL uint32_t* pix;
@@ -384,7 +385,28 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
     const int row_base = (blockIdx.x * SP_WAVES + wave) * SP_PREP_WAVE_ROWS;
     const int qpr = t.W >> 4;
     const int n_rows = min(SP_PREP_WAVE_ROWS, rows - row_base);          // (<= 0: a wave past the end, which still meets the barrier)
-    const int n_pieces = n_rows * qpr;
+    // BOXES (SpPrepTable.boxes): lane r < n_rows holds the box of the wave's row r -- is the row inside its segment's box rows, and
+    // which columns.  A wave none of whose rows is inside any box reads nothing and writes zero counts; in the others only the
+    // 16-pixel pieces that meet the row's box columns are loaded, the rest are zero words.
+    const SP_GLOBAL int32_t* const boxes = t.boxes;
+    int my_c0 = 0, my_c1 = t.W;
+    unsigned long long row_in = ~0ull;
+    if (boxes) {
+        bool in = false;
+        if (lane < n_rows) {
+            const int row = row_base + lane, H = t.H;
+            int n = (int)((float)row * (1.f / (float)H)), r = row - n * H;      // (rows < 2^22 on this path: the quotient is off by one at most)
+            if (r < 0) { --n; r += H; }
+            if (r >= H) { ++n; r -= H; }
+            const int r0 = boxes[4 * n], c0 = boxes[4 * n + 1], r1 = boxes[4 * n + 2], c1 = boxes[4 * n + 3];
+            my_c0 = max(c0, 0); my_c1 = min(c1, t.W);
+            in = r >= r0 && r < r1 && my_c0 < my_c1;
+        }
+        row_in = __ballot(in);
+    }
+    const bool skip = row_in == 0ull;
+    const int n_pieces = skip ? 0 : n_rows * qpr;
+    const uint32_t q_magic = (1u << 20) / (uint32_t)qpr + 1u;                // p / qpr = (p * q_magic) >> 20 for p < 2^20 / qpr (p < 1024 here)
     __shared__ uint32_t s_c[SP_WAVES][SP_PREP_WAVE_ROWS * 64];
     uint32_t sel[SP_PREP_MAX_STRIDES];
 #pragma unroll
@@ -396,7 +418,13 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
 #pragma unroll
         for (int u = 0; u < SP_PREP_LOADS; ++u) {
             const int p = p0 + u * 64 + lane;
-            w[u] = p < n_pieces ? load4_once(mq + p) : make_uint4(0u, 0u, 0u, 0u);
+            bool want = p < n_pieces;
+            if (boxes) {
+                const int row_l = min((int)(((uint32_t)min(p, 1023) * q_magic) >> 20), SP_PREP_WAVE_ROWS - 1), x0 = 16 * (p - row_l * qpr);
+                const int c0 = __shfl(my_c0, row_l, 64), c1 = __shfl(my_c1, row_l, 64);
+                want = want && ((row_in >> row_l) & 1ull) != 0ull && x0 < c1 && x0 + 16 > c0;
+            }
+            w[u] = want ? load4_once(mq + p) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < SP_PREP_LOADS; ++u) {
@@ -410,11 +438,15 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
             }
         }
     }
+    // (rows of a skipped wave are found empty through lattice 0's row counts and their bit words never read -- unless the first lattice
+    //  is not the full one: then the fill pass looks at every row, and the words must be there)
+    if (skip && bits && t.stride[0] != 1)
+        for (int p = lane; p < n_rows * qpr; p += 64) bits[p] = 0u;
     __syncthreads();
     // four lanes per row: bytes -> two words of 16-bit fields (a row's count is at most 1024), summed over the row's pieces
     const int row_l = lane >> 2, sub = lane & 3;
     uint32_t a0 = 0u, a1 = 0u;
-    if (row_l < n_rows)
+    if (row_l < n_rows && !skip)
         for (int i = sub; i < qpr; i += 4) {
             const uint32_t c = s_c[wave][row_l * qpr + i];
             a0 += (c & 0xffu) | ((c & 0xff00u) << 8);
@@ -1069,7 +1101,7 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
 }
 
 
-static_assert(sizeof(SpPrepTable) == 232 && sizeof(SpPrepSample) == 176 && sizeof(SpPrepImage) == 24, "preparation job records are part of the ABI");
+static_assert(sizeof(SpPrepTable) == 240 && sizeof(SpPrepSample) == 176 && sizeof(SpPrepImage) == 24, "preparation job records are part of the ABI");
 
 // ---- batched preparation ----
 static int check_grid(long x, long y) { return (x <= 0 || y <= 0 || y > 65535) ? SP_EINVAL : 0; }

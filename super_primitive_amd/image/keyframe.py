@@ -24,7 +24,7 @@ def infer_spatial_size(logdepth_perseg):
     return logdepth_perseg.shape
 
 
-_PREP_FIELDS = frozenset(("image", "K", "logdepth_perseg", "keypoints", "keypoint_regions"))
+_PREP_FIELDS = frozenset(("image", "K", "logdepth_perseg", "keypoints", "keypoint_regions", "segment_boxes"))
 
 
 class KeyFrame(nn.Module):
@@ -48,6 +48,10 @@ class KeyFrame(nn.Module):
         self.K_img = K if K_img is None else K_img
         self.id = id
         self.supporting = logdepth_perseg is None or keypoints is None or keypoint_regions is None
+        # optional HINT for the batched set-up (not part of the reference's container): (N,4) int32 {row0, col0, row1, col1}, half open --
+        # segment n has no mask pixel outside its box (SAM's frontend has exactly these: frontend/segment/mask_generation.py:93,155-180).
+        # The count pass of optim/batch_prepare.py then reads the masks inside the boxes only; assign after construction.
+        self.segment_boxes = None
         self.logdepth_perseg = None
         self.keypoints = None
         self.keypoint_regions = None

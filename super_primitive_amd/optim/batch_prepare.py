@@ -51,7 +51,8 @@ def handles(tensors, dev, dtype=torch.float32):
     return np.fromiter(map(_data_ptr, own), dtype=np.uint64, count=n), own
 
 
-_FRAME_DT = np.dtype([('masks', '<u8'), ('image', '<u8'), ('logdepth', '<u8'), ('keypoints', '<u8'), ('K', '<u8'), ('N', '<i8'), ('H', '<i8'), ('W', '<i8')])
+_FRAME_DT = np.dtype([('masks', '<u8'), ('image', '<u8'), ('logdepth', '<u8'), ('keypoints', '<u8'), ('K', '<u8'), ('N', '<i8'), ('H', '<i8'), ('W', '<i8'),
+                      ('boxes', '<u8')])
 
 
 def frame_records(frames, dev):
@@ -67,15 +68,20 @@ def frame_records(frames, dev):
             c = f.__dict__.get('_sp_prep')
         except AttributeError:
             c = None
+        boxes = getattr(f, 'segment_boxes', None)
         if c is None or c[5] != dev or not (hooked or (c[0] is f.keypoint_regions and c[1] is f.image and c[2] is f.logdepth_perseg
-                                                       and c[3] is f.keypoints and c[4] is f.K and c[7][0].data_ptr() == c[8])):
+                                                       and c[3] is f.keypoints and c[4] is f.K and c[7][0].data_ptr() == c[8] and c[9] is boxes)):
             m = f.keypoint_regions
             assert m.dtype == torch.bool and m.dim() == 3
             own = (m.contiguous(), _dev(f.image, dev), _dev(f.logdepth_perseg, dev), _dev(f.keypoints, dev), _dev(f.K, dev))
+            if boxes is not None:                    # the optional segment-box hint of the count pass (SpPrepTable.boxes)
+                if tuple(boxes.shape) != (m.shape[0], 4):
+                    raise ValueError("segment_boxes: (N, 4) {row0, col0, row1, col1} per segment")
+                own = own + (boxes.to(device=dev, dtype=torch.int32).contiguous(),)
             _lib.require_device(*own)
             rec = np.zeros(1, dtype=_FRAME_DT)
-            rec[0] = tuple(t.data_ptr() for t in own) + tuple(m.shape)
-            c = (f.keypoint_regions, f.image, f.logdepth_perseg, f.keypoints, f.K, dev, rec.tobytes(), own, own[0].data_ptr())
+            rec[0] = tuple(t.data_ptr() for t in own[:5]) + tuple(m.shape) + ((own[5].data_ptr(),) if boxes is not None else (0,))
+            c = (f.keypoint_regions, f.image, f.logdepth_perseg, f.keypoints, f.K, dev, rec.tobytes(), own, own[0].data_ptr(), boxes)
             try:
                 f.__dict__['_sp_prep'] = c
             except AttributeError:
@@ -369,6 +375,7 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     w_off = np.concatenate(([0], np.cumsum(words)))
     bits = torch.empty(max(int(w_off[-1]), 1), dtype=torch.int32, device=dev)
     recs['bits'] = np.where(fast, bits.data_ptr() + 4 * w_off[:-1], 0).astype(np.uint64)
+    recs['boxes'] = np.where(fast, frec['boxes'], 0).astype(np.uint64)         # (the segment-box hint: fast path only)
     recs['logdepth'], recs['keypoints'] = frec['logdepth'], frec['keypoints']
     timer.mark('count records')
     # the per-pair inputs: initial log-depths and target intrinsics (FIRST on the stream: the intrinsics come back to the host for the

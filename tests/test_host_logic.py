@@ -43,8 +43,8 @@ def test_abi_constants_and_struct_layout_match_header():
     assert _lib.SpWindowNode.kind.offset == 168 and _lib.SpWindowBlock.N.offset == 24
     # per-pair schedule, passed by value
     assert int(re.search(r"#define\s+SP_MAX_PHASES\s+(\d+)", header).group(1)) == _lib.SP_MAX_PHASES
-    assert ctypes.sizeof(_lib.SpPrepTable) == 232 and _lib.SpPrepTable.bits.offset == 224
-    assert ctypes.sizeof(_lib.SpPrepTable) == 232 and ctypes.sizeof(_lib.SpPrepSample) == 176 and ctypes.sizeof(_lib.SpPrepImage) == 24
+    assert ctypes.sizeof(_lib.SpPrepTable) == 240 and _lib.SpPrepTable.bits.offset == 224 and _lib.SpPrepTable.boxes.offset == 232
+    assert ctypes.sizeof(_lib.SpPrepTable) == 240 and ctypes.sizeof(_lib.SpPrepSample) == 176 and ctypes.sizeof(_lib.SpPrepImage) == 24
     assert _lib.SpPrepTable.stride.offset == 192 and _lib.SpPrepSample.N.offset == 152 and _lib.SpPrepImage.H.offset == 16
     for macro in ("SP_PREP_MAX_STRIDES", "SP_PREP_MAX_LEVELS"):
         assert int(re.search(r"#define\s+" + macro + r"\s+(\d+)", header).group(1)) == getattr(_lib, macro)
