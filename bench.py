@@ -698,6 +698,28 @@ def main(argv=None):
                                       "achieved": tot_b / (tot_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                       "frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                       "algorithmic_bytes_per_pair": int(tot_b / n_raw), "pairs": n_raw}
+            # (d') the same with the SEGMENT-BOX HINT on every keyframe (KeyFrame.segment_boxes: the (N,4) boxes a SAM-like frontend computes
+            #      anyway, frontend/segment/mask_generation.py:93,155-180): the count pass reads the masks inside the boxes only.  The hint
+            #      changes the algorithmic bytes of that pass (said in the record); the boxes are made here outside the timed region.
+            from super_primitive_amd.optim.batch_prepare import segment_boxes_of
+            for f, r in zip(frames, raw):
+                f.segment_boxes = segment_boxes_of(r["m"])
+            from_raw()
+            t_setup_b, t_opt_b, _ = from_raw()
+            tm = _Timer()
+            _, _, nbytes_b = from_raw(tm)
+            ms_b = tm.milliseconds()
+            tot_bb, tot_msb = sum(nbytes_b[k] for k in ms_b), sum(ms_b.values())
+            line["from_raw_frames"]["with_segment_boxes"] = {
+                "setup_ms": 1e3 * t_setup_b, "optimise_ms": 1e3 * t_opt_b, "frame_pairs_per_sec": n_raw / (t_setup_b + t_opt_b),
+                "roofline_setup": {"kernels_ms": tot_msb, "algorithmic_bytes": int(tot_bb), "frac": tot_bb / (tot_msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                   "count": {"ms": ms_b["count"], "algorithmic_bytes": int(nbytes_b["count"]),
+                                             "frac": nbytes_b["count"] / (ms_b["count"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}},
+                "what": "KeyFrame.segment_boxes given: the count pass reads the 16-pixel pieces of the masks that meet each segment's box "
+                        "(its algorithmic bytes shrink accordingly), everything else as above; tables bitwise the same "
+                        "(tests/test_gpu_pairs.py::test_segment_box_hint_builds_the_same_tables)"}
+            for f in frames:
+                f.segment_boxes = None
             # (e) batches back to back, the set-up of the next one overlapped with the optimisation of the current one on a
             #     second HIP stream (optim.pair_stream.PairStream): 4 batches of the same raw frames
             from super_primitive_amd.optim.pair_stream import PairStream

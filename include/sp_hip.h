@@ -130,9 +130,10 @@ typedef struct SpPrepTable {     /* one keyframe: its masks are read once per pa
                                     frontend computes and NMS-filters exactly these (frontend/segment/mask_generation.py:93,155-180) --
                                     that segment n has no set pixel outside its box.  The count pass then reads the masks inside
                                     the boxes only (the 16-pixel pieces that meet them), ~1 MB of a 640x480x64 keyframe's 19.7 MB;
-                                    boxes are clamped to the image, an empty or inverted box is an empty segment, and a mask pixel
-                                    outside its box is NOT SEEN (the caller's contract).  Fast path only (see bits); ignored on the
-                                    general path, which scans everything */
+                                    boxes are clamped to the image, an empty or inverted box is an empty segment.  A mask pixel that
+                                    breaks the contract is not seen when its ROW is outside the box or its 16-pixel piece does not
+                                    meet the box columns, and seen otherwise (deterministic either way).  Fast path only (see
+                                    bits); ignored on the general path, which scans everything */
 } SpPrepTable;                   /* 240 bytes */
 typedef struct SpPrepSample {    /* one table, sampled at up to SP_PREP_MAX_LEVELS pyramid levels in one pass; sets pix bit 31 */
     uint32_t* pix;
@@ -344,6 +345,13 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
 #define SP_PHASE_WAVE_SPANS 2
 /* SP_PHASE_DEPTH_TABLE: the phase's tables are depth tables (see SP_COST_DEPTH_TABLE); all phases of one schedule alike. */
 #define SP_PHASE_DEPTH_TABLE 4
+/* SP_PHASE_DEPTH_DAMP(k), k = 0..255: the phase's Gauss-Newton step damps the log-depth block by k / 8 on top of the LM lambda --
+ * (H_dd (1 + lambda + k/8)) -- so that the depths follow the pose at a fraction of their Gauss-Newton step, the way the reference's
+ * Adam moves them at a tenth of the pose's rate (odometery/two_frame_sfm.py:116-123: lr 1e-3 against 1e-2).  On near-planar scenes
+ * (a narrow depth range: the two-fold ambiguity of a plane's homography) the undamped joint step walks into the second solution from
+ * the reference's own starts; a damped coarse phase in front of the undamped ones does not (profiles/r05_reference_start.txt). */
+#define SP_PHASE_DEPTH_DAMP_SHIFT 8
+#define SP_PHASE_DEPTH_DAMP(k) (((k) & 0xff) << SP_PHASE_DEPTH_DAMP_SHIFT)
 typedef struct SpPhase {
     const SpPair* pairs;
     const int32_t* chunks;

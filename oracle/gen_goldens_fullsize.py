@@ -370,6 +370,64 @@ def golden_config3_window5_min(ref, name="g22min_config3_window5_minimiser", see
           f"minimiser is {from_gt[0]:.1e} (pose entries) / {from_gt[1]:.1e} (log-depths) from the ground truth", flush=True)
 
 
+def mono_init_inputs(seed=31, H=224, W=288, N=40, second=7):
+    """The two keyframes of the reference's mono initialisation on the config-3 sequence (tests/test_gpu_sequence.py::make_sequence_inputs with
+    rot_scale = 0.5: frames 0 and ``second``), as the mapping sees them: UNIT depths at every keypoint (odometery.py:136-139), the first pose
+    the ground truth, the second the ground truth with its translation from the first divided by 3 (what tracking against unit depths
+    hands over for a plane ~3 away: the monocular scale), zero affine pairs.  Returns (frame 0, frame ``second``, poses (2,4,4))."""
+    rng = np.random.default_rng(seed)
+    base = 0.6 * np.array([0.05, -0.02, 0.015, 0.01 * 0.5, -0.015 * 0.5, 0.008 * 0.5])
+    twists = [k * base + 0.003 * rng.standard_normal(6) * (k > 0) for k in range(24)]
+    seq = synth.make_sequence(H, W, N, [twists[0], twists[second]], keyframe_ids=[0, 1], seed=seed, overlap=1)
+    P = np.stack([seq[0].T_wc, seq[1].T_wc]).astype(np.float64)
+    P[1, :3, 3] = P[0, :3, 3] + (P[1, :3, 3] - P[0, :3, 3]) / 3.0
+    return seq[0], seq[1], P.astype(np.float32)
+
+
+def golden_mono_init_min(ref, name="g23min_config3_mono_init_minimiser", seed=31):
+    """the reference's MONO INITIALISATION mapping (odometery.py:134-139,578-581,1064-1071, config/tum/odom_desk.yaml
+    ``mono_init: True``) run to a settled end state: two keyframes with unit depths, no supporting frames, first pose fixed, ALL depths
+    free (the window is not full), pose rate 1e-2, ``init_steps`` = 1000 iterations without early stop -- the reference's own run -- and
+    then, like g17min / g22min, phases of decaying learning rates (fresh Adam per phase) until the state stops moving.  The problem has
+    one gauge, the monocular scale; everything is stored as the loop leaves it and compared after removing that scale.  The
+    Gauss-Newton window optimiser must reach this point from the same start (tests/test_gpu_window_gn.py)."""
+    from gen_goldens import reference_mapping_loop
+    H, W, N = 224, 288, 40
+    f0, f1, poses = mono_init_inputs(seed, H, W, N)
+    t0 = time.time()
+    mk = lambda f: ref.kf.KeyFrame(T(f.image), T(f.K), T(f.logdepth_perseg), T(f.keypoints), torch.from_numpy(f.keypoint_regions.copy()))
+    kfs = [mk(f0), mk(f1)]
+    zero2 = np.zeros(2, np.float32)
+    state = dict(kf_poses=poses.copy(), klds=np.zeros((2, N), np.float32), affs=np.stack([zero2] * 2))
+    losses, moved = [], None
+    phases = ((1e-2, 1e-2, 1e-5, 1000),) + tuple((lk, lk, lk * 1e-2, n) for lk, n in ((3e-3, 300), (1e-3, 300), (3e-4, 250), (1e-4, 200), (3e-5, 150), (1e-5, 100)))
+    first = None
+    for lr_kld, lr_pose, lr_aff, steps in phases:
+        out = reference_mapping_loop(ref, kfs, [T(p) for p in state["kf_poses"]], [T(k) for k in state["klds"]], [T(a) for a in state["affs"]],
+                                     [[], []], steps, lr_pose, 5, True, False, lr_kld=lr_kld, lr_aff=lr_aff)
+        ls = float(np.mean(out["klds"] - state["klds"]))           # (movement with the scale gauge removed)
+        moved = (float(np.abs(out["kf_poses"][1, :3, :3] - state["kf_poses"][1, :3, :3]).max()),
+                 float(np.abs(out["klds"] - ls - state["klds"]).max()))
+        state = {k: out[k] for k in state}
+        if first is None:
+            first = {k: v.copy() for k, v in state.items()}        # the reference's own 1000 iterations
+        losses += list(out["losses"])
+        print(f"  {name} lr {lr_kld:g}/{lr_pose:g}: loss {out['losses'][0]:.8f} -> {out['losses'][-1]:.8f}, moved rot {moved[0]:.1e} kld {moved[1]:.1e} "
+              f"({time.time() - t0:.0f} s)", flush=True)
+    # against the ground truth, scale removed
+    ls = float(np.mean(np.stack([f0.kld_gt, f1.kld_gt]) - state["klds"]))
+    t_rel = (state["kf_poses"][1, :3, 3] - state["kf_poses"][0, :3, 3]) * np.exp(ls)
+    gt_rel = f1.T_wc[:3, 3] - f0.T_wc[:3, 3]
+    err = (float(np.abs(state["kf_poses"][1, :3, :3] - f1.T_wc[:3, :3]).max()), float(np.abs(t_rel - gt_rel).max()),
+           float(np.abs(np.expm1(state["klds"] + ls - np.stack([f0.kld_gt, f1.kld_gt]))).max()))
+    save = dict(seed=np.array(seed), HWN=np.array([H, W, N]), second=np.array(7), start_poses=poses, losses=np.array(losses), last_phase_moved=np.array(moved),
+                scale=np.array(np.exp(ls)), err_gt_scale_removed=np.array(err), spread40=np.array(np.ptp(losses[-40:])),
+                **{f"ref1000_{k}": v for k, v in first.items()}, **{f"min_{k}": v for k, v in state.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print(f"{name}: {time.time() - t0:.0f} s; final loss {losses[-1]:.8f}, spread of the last 40 losses {np.ptp(losses[-40:]):.1e}; monocular scale {np.exp(ls):.3f}; "
+          f"vs ground truth (scale removed): rot entries {err[0]:.1e}, t {err[1]:.1e}, depth {err[2]:.1e}", flush=True)
+
+
 def golden_config4(ref, name="g18_config4_void_shaped", seed=4, n_segments=1200):
     """BASELINE configs[3] shape (VOID-1500 depth completion, 480x640, ~1200 sparse-depth segments): the reference's
     per-image pipeline after the frontend (segment_based_completion.py:45-55) -- segment_based_depth_reinit (median),
@@ -555,6 +613,8 @@ def main():
         golden_config3_min(ref)
     if "g22min" in which:
         golden_config3_window5_min(ref)
+    if "g23min" in which:
+        golden_mono_init_min(ref)
     if "g18" in which:
         golden_config4(ref)
     if "g19" in which:

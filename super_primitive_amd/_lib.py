@@ -100,6 +100,7 @@ SP_PHASE_WAVE_SPANS = 2
 SP_COST_WAVE_SPANS = 0x100
 SP_COST_DEPTH_TABLE = 0x200
 SP_PHASE_DEPTH_TABLE = 4
+SP_PHASE_DEPTH_DAMP_SHIFT = 8
 SP_PREP_DEPTH_TABLE = 0x10000
 
 

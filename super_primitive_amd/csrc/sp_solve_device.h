@@ -257,6 +257,7 @@ struct GnArgs {
     int max_iters;           // ... of at most this many
     int pose_only;           // SP_PHASE_POSE_ONLY: no Schur complement, no depth update
     int next_phase;          // ... the phase that follows the current one (SpPhase.next)
+    float depth_damp;        // ... extra LM damping of the log-depth block (SP_PHASE_DEPTH_DAMP): D (1 + lambda + depth_damp)
 };
 
 // a pair leaves its current phase (thread 0): the next one starts afresh; lm_state[7] records how this one ended
@@ -334,7 +335,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
     const int n_cached = min(pr.N, SP_SEG_CACHE);
     for (int n = threadIdx.x; n < n_cached; n += SP_BLOCK) {
         double o[8];
-        segment_system(sp, pr.seg_tile_off, n, lam, o, h.pose_only != 0);
+        segment_system(sp, pr.seg_tile_off, n, lam + (double)h.depth_damp, o, h.pose_only != 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) seg[n][i] = o[i];
     }
@@ -354,7 +355,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
                 if (n < SP_SEG_CACHE) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
-                } else segment_system(sp, pr.seg_tile_off, n, lam, o, h.pose_only != 0);
+                } else segment_system(sp, pr.seg_tile_off, n, lam + (double)h.depth_damp, o, h.pose_only != 0);
                 acc += o[a] * (k < 21 ? o[b] : o[7]) * o[6];
             }
             schur_part[j][k] = acc;
@@ -394,7 +395,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         if (n < SP_SEG_CACHE) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) o[i] = seg[n][i];
-        } else segment_system(sp, pr.seg_tile_off, n, lam, o, h.pose_only != 0);
+        } else segment_system(sp, pr.seg_tile_off, n, lam + (double)h.depth_damp, o, h.pose_only != 0);
         if (o[6] > 0.0) {
             double r = -o[7];
 #pragma unroll

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
         h.max_iters = s.max_iters;
         h.pose_only = s.flags & SP_PHASE_POSE_ONLY;
         h.next_phase = s.next > 0 ? s.next : ph + 1;
+        h.depth_damp = 0.125f * (float)((s.flags >> SP_PHASE_DEPTH_DAMP_SHIFT) & 0xff);
         solve_gn(s.pairs, slot, s.span_partials, s.seg_partials, h);
     }
     if (q.n_queue <= 0 && !v.status) return;

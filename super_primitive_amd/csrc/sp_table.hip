@@ -382,15 +382,48 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
     if (!prep_fast_path(t)) return;          // (k_prep_row_counts_general takes those keyframes)
     const int rows = t.N * t.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row_base = (blockIdx.x * SP_WAVES + wave) * SP_PREP_WAVE_ROWS;
     const int qpr = t.W >> 4;
-    const int n_rows = min(SP_PREP_WAVE_ROWS, rows - row_base);          // (<= 0: a wave past the end, which still meets the barrier)
-    // BOXES (SpPrepTable.boxes): lane r < n_rows holds the box of the wave's row r -- is the row inside its segment's box rows, and
-    // which columns.  A wave none of whose rows is inside any box reads nothing and writes zero counts; in the others only the
-    // 16-pixel pieces that meet the row's box columns are loaded, the rest are zero words.
+    constexpr int BLOCK_ROWS = SP_WAVES * SP_PREP_WAVE_ROWS;
     const SP_GLOBAL int32_t* const boxes = t.boxes;
+    if (boxes && t.H >= BLOCK_ROWS) {
+        // SEGMENT BOXES (SpPrepTable.boxes), the whole workgroup first (its 64 rows lie in at most two segments): most workgroups of
+        // a boxed keyframe are outside every box -- a segment covers a small part of the image -- and leave with three coalesced
+        // stores of zero counts, before any LDS
+        const int B0 = blockIdx.x * BLOCK_ROWS, B1 = min(B0 + BLOCK_ROWS, rows) - 1;
+        if (B0 >= rows) return;
+        const int H = t.H, n0 = B0 / H, n1 = B1 / H;
+        bool any = false;
+        {
+            const int lo = B0 - n0 * H, hi = (n1 == n0 ? B1 - n0 * H : H - 1) + 1;      // rows [lo, hi) of segment n0
+            const int r0 = boxes[4 * n0], c0 = boxes[4 * n0 + 1], r1 = boxes[4 * n0 + 2], c1 = boxes[4 * n0 + 3];
+            any = max(r0, lo) < min(r1, hi) && max(c0, 0) < min(c1, t.W);
+        }
+        if (n1 != n0) {
+            const int hi = B1 - n1 * H + 1;                                           // rows [0, hi) of segment n1
+            const int r0 = boxes[4 * n1], c0 = boxes[4 * n1 + 1], r1 = boxes[4 * n1 + 2], c1 = boxes[4 * n1 + 3];
+            any = any || (max(r0, 0) < min(r1, hi) && max(c0, 0) < min(c1, t.W));
+        }
+        if (!any) {
+            const int row = B0 + (int)threadIdx.x;
+            if ((int)threadIdx.x < BLOCK_ROWS && row < rows) {
+#pragma unroll
+                for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                    if (k < t.n_strides) t.row_counts[k][row] = 0;
+            }
+            if (t.bits && t.stride[0] != 1)      // (the bit words of empty rows are only read when lattice 0 is not the full one: see below)
+                for (int p = threadIdx.x; p < (B1 - B0 + 1) * qpr; p += SP_BLOCK) t.bits[(size_t)B0 * qpr + p] = 0u;
+            return;
+        }
+    }
+    const int row_base = (blockIdx.x * SP_WAVES + wave) * SP_PREP_WAVE_ROWS;
+    const int n_rows = min(SP_PREP_WAVE_ROWS, rows - row_base);          // (<= 0: a wave past the end, which still meets the barrier)
+    // ... then per wave: lane r < n_rows holds the box of the wave's row r -- is the row inside its segment's box rows, and which
+    // columns.  A wave none of whose rows is inside any box reads nothing and writes zero counts; the others walk only the 16-pixel
+    // pieces [q0, q1) of their rows that some box of theirs meets (the rest of those rows' bit words are written as zeros), and of
+    // those load the ones the row's own box meets.
     int my_c0 = 0, my_c1 = t.W;
     unsigned long long row_in = ~0ull;
+    int q0 = 0, q1 = qpr;
     if (boxes) {
         bool in = false;
         if (lane < n_rows) {
@@ -403,28 +436,38 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
             in = r >= r0 && r < r1 && my_c0 < my_c1;
         }
         row_in = __ballot(in);
+        int lo = in ? (my_c0 >> 4) : qpr, hi = in ? ((my_c1 + 15) >> 4) : 0;
+#pragma unroll
+        for (int o = 1; o < SP_PREP_WAVE_ROWS; o <<= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+        q0 = __builtin_amdgcn_readfirstlane(lo); q1 = __builtin_amdgcn_readfirstlane(hi);
     }
     const bool skip = row_in == 0ull;
-    const int n_pieces = skip ? 0 : n_rows * qpr;
-    const uint32_t q_magic = (1u << 20) / (uint32_t)qpr + 1u;                // p / qpr = (p * q_magic) >> 20 for p < 2^20 / qpr (p < 1024 here)
+    const int nq = skip ? 1 : q1 - q0;                                       // pieces walked per row
+    const int n_pieces = skip ? 0 : n_rows * nq;
+    const uint32_t q_magic = (1u << 20) / (uint32_t)nq + 1u;                 // p / nq = (p * q_magic) >> 20 for p < 2^20 / nq (p < 1024 here)
     __shared__ uint32_t s_c[SP_WAVES][SP_PREP_WAVE_ROWS * 64];
     uint32_t sel[SP_PREP_MAX_STRIDES];
 #pragma unroll
     for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) sel[k] = k < t.n_strides ? lattice_piece(t.stride[k]) : 0u;
     const SP_GLOBAL u32x4* mq = (const SP_GLOBAL u32x4*)t.masks + (size_t)max(row_base, 0) * qpr;
     SP_GLOBAL uint32_t* bits = t.bits ? t.bits + (size_t)row_base * qpr : nullptr;
+    if (boxes && bits && !skip && lane < qpr && (lane < q0 || lane >= q1)) {      // the walked rows' bit words outside [q0, q1): zeros
+        for (int r = 0; r < n_rows; ++r) bits[r * qpr + lane] = 0u;
+    }
     for (int p0 = 0; p0 < n_pieces; p0 += SP_PREP_LOADS * 64) {
         uint4 w[SP_PREP_LOADS];
 #pragma unroll
         for (int u = 0; u < SP_PREP_LOADS; ++u) {
             const int p = p0 + u * 64 + lane;
             bool want = p < n_pieces;
+            int at = p;                                                      // the piece's index in the wave's run of rows
             if (boxes) {
-                const int row_l = min((int)(((uint32_t)min(p, 1023) * q_magic) >> 20), SP_PREP_WAVE_ROWS - 1), x0 = 16 * (p - row_l * qpr);
+                const int row_l = min((int)(((uint32_t)min(p, 1023) * q_magic) >> 20), SP_PREP_WAVE_ROWS - 1), xq = q0 + (p - row_l * nq);
                 const int c0 = __shfl(my_c0, row_l, 64), c1 = __shfl(my_c1, row_l, 64);
-                want = want && ((row_in >> row_l) & 1ull) != 0ull && x0 < c1 && x0 + 16 > c0;
+                want = want && ((row_in >> row_l) & 1ull) != 0ull && 16 * xq < c1 && 16 * xq + 16 > c0;
+                at = row_l * qpr + xq;
             }
-            w[u] = want ? load4_once(mq + p) : make_uint4(0u, 0u, 0u, 0u);
+            w[u] = want ? load4_once(mq + at) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < SP_PREP_LOADS; ++u) {
@@ -432,7 +475,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
             if (p0 + u * 64 >= n_pieces) break;
             const uint32_t m = piece_bits(nonzero_bytes(w[u].x), nonzero_bytes(w[u].y), nonzero_bytes(w[u].z), nonzero_bytes(w[u].w));
             if (p < n_pieces) {
-                if (bits) bits[p] = m;
+                if (bits) {
+                    int at = p;
+                    if (boxes) { const int row_l = (int)(((uint32_t)p * q_magic) >> 20); at = row_l * qpr + q0 + (p - row_l * nq); }
+                    bits[at] = m;
+                }
                 s_c[wave][p] = (uint32_t)__popc(m & sel[0]) | ((uint32_t)__popc(m & sel[1]) << 8) | ((uint32_t)__popc(m & sel[2]) << 16)
                                | ((uint32_t)__popc(m & sel[3]) << 24);
             }
@@ -443,12 +490,12 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
     if (skip && bits && t.stride[0] != 1)
         for (int p = lane; p < n_rows * qpr; p += 64) bits[p] = 0u;
     __syncthreads();
-    // four lanes per row: bytes -> two words of 16-bit fields (a row's count is at most 1024), summed over the row's pieces
+    // four lanes per row: bytes -> two words of 16-bit fields (a row's count is at most 1024), summed over the row's walked pieces
     const int row_l = lane >> 2, sub = lane & 3;
     uint32_t a0 = 0u, a1 = 0u;
     if (row_l < n_rows && !skip)
-        for (int i = sub; i < qpr; i += 4) {
-            const uint32_t c = s_c[wave][row_l * qpr + i];
+        for (int i = sub; i < nq; i += 4) {
+            const uint32_t c = s_c[wave][row_l * nq + i];
             a0 += (c & 0xffu) | ((c & 0xff00u) << 8);
             a1 += ((c >> 16) & 0xffu) | ((c >> 8) & 0xff0000u);
         }

@@ -91,6 +91,18 @@ def frame_records(frames, dev):
     return recs, [c[7] for c in out]
 
 
+def segment_boxes_of(masks):
+    """(N,4) int32 {row0, col0, row1, col1} (half open) of a bool (N,H,W) mask stack -- what ``KeyFrame.segment_boxes`` holds; an empty
+    mask gets an empty box.  A frontend that made the masks has these already (frontend/segment/mask_generation.py:93,155-180); this is
+    for callers that do not (two reductions over the stack: as much traffic as the count pass the hint saves -- worth it for a keyframe
+    that is the source of many pairs)."""
+    rows, cols = masks.any(dim=2), masks.any(dim=1)
+    H, W = masks.shape[1:]
+    first = lambda b: torch.where(b.any(1), b.float().argmax(1), torch.zeros_like(b[:, 0], dtype=torch.long))
+    last = lambda b, n: torch.where(b.any(1), n - b.flip(1).float().argmax(1), torch.zeros_like(b[:, 0], dtype=torch.long))
+    return torch.stack((first(rows), first(cols), last(rows, H), last(cols, W)), dim=1).to(torch.int32)
+
+
 def flat_layout(counts, n_off, granule=GRANULE, table=None):
     """Padded layout of many tables at once.  counts: real points of every segment, all tables concatenated; n_off[t]:
     first segment of table t.  Returns (pc, seg_pos, p_off): padded run length of every segment, its position relative to
@@ -540,8 +552,22 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         n_pts = {s: int(t.counts.sum()) for s, t in tabs.items()}
         img_px = {l: int((hw[l][:, 0] * hw[l][:, 1]).sum()) for l in hw}
         sampled_levels = sorted({l for lv in levels_of.values() for l in lv})
+        # count pass: masks in (1 B / pixel and segment), bit words out -- with the segment-box hint only the 16-pixel pieces that meet a
+        # segment's box, and the bit words of its box rows
+        count_bytes = 0
+        for i in range(M0):
+            own = frame_keep[i]
+            if fast[i] and len(own) > 5:
+                b = own[5].cpu().numpy().astype(np.int64)
+                r0, r1 = np.clip(b[:, 0], 0, Hs[i]), np.clip(b[:, 2], 0, Hs[i])
+                c0, c1 = np.clip(b[:, 1], 0, Ws[i]), np.clip(b[:, 3], 0, Ws[i])
+                box_rows = np.where((r1 > r0) & (c1 > c0), r1 - r0, 0)
+                pieces = np.where(c1 > c0, -(-c1 // 16) - c0 // 16, 0)
+                count_bytes += int((box_rows * pieces * 16).sum()) + 4 * int(box_rows.sum()) * int(Ws[i] // 16)
+            else:
+                count_bytes += int(Ns[i] * Hs[i] * Ws[i]) + 4 * int(words[i])
         return {
-            'count': int((Ns * Hs * Ws).sum()) + 4 * int(words.sum()),                       # masks in (1 B / pixel and segment), bit words out
+            'count': count_bytes,
             'fill': 4 * n_pts[1] + 8 * sum(n_pts.values()) + n_pts[1] // 4,                  # L in (once per mask pixel), pix + baseL out per lattice point, set bits in
             'sample': sum((12 + 16 * len(lv)) * n_pts[s] for s, lv in levels_of.items())     # pix + baseL in, pix out, one src4 per sampled level out
                       + sum(12 * img_px[l] for l in sampled_levels),                         # ... and every sampled source level read once

@@ -551,7 +551,7 @@ class PairBatch:
 
     def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3, phases=None,
                  use_coarse=True, pose_first_iters=0, pose_first_eps=None, joint_levels=None, use_levels=None, retry_pose_first=None,
-                 retry_phases=None, retry_join=None):
+                 retry_phases=None, retry_join=None, depth_damp=None):
         """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
         built with a ``point_stride`` run on their decimated point set unless ``use_coarse=False``.  ``phases``: an explicit
         list of dict(level, stride, max_iters, irls_eps, conv_tol) instead (every (level, stride > 1) needs its table:
@@ -560,7 +560,8 @@ class PairBatch:
         depths keep their seeds while the pose is aligned -- what makes the schedule converge from the reference's own starting
         distribution (REFERENCE_START_SCHEDULE).  A TUPLE of caps puts one pose-only phase per entry at the coarsest levels in turn
         (coarsest first); ``joint_levels`` = k restricts the joint (pose + depth) phases to the k finest levels: a level above those only
-        aligns the pose.  ``use_levels`` = k: only the k finest levels of the batch take part in all of that (the batch may carry coarser
+        aligns the pose.  ``depth_damp`` = (d_coarsest, ...): extra LM damping of the log-depth block in the joint phases, coarsest level
+        first (include/sp_hip.h SP_PHASE_DEPTH_DAMP; levels not named: none).  ``use_levels`` = k: only the k finest levels of the batch take part in all of that (the batch may carry coarser
         ones for the second attempt).
 
         THE SECOND ATTEMPT (SpSchedule.retry_entry, SpVerdict): ``retry_phases`` -- a list of phase dicts like ``phases`` -- or its
@@ -578,8 +579,9 @@ class PairBatch:
                 phases.append(dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=int(cap),
                                    irls_eps=irls_eps if pose_first_eps is None else pose_first_eps, conv_tol=conv_tol, pose_only=True))
             joint = coarse_first if joint_levels is None else coarse_first[len(coarse_first) - int(joint_levels):]
+            damps = dict(zip(joint, depth_damp)) if depth_damp else {}              # (coarsest joint level first)
             phases += [dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=max_iters_per_level, irls_eps=irls_eps,
-                           conv_tol=conv_tol) for level in joint]
+                           conv_tol=conv_tol, depth_damp=damps.get(level, 0.0)) for level in joint]
             finest = min(self.level_ids)
             if polish_max > 0:
                 phases.append(dict(level=finest, stride=1, max_iters=polish_max, irls_eps=polish_eps, conv_tol=polish_tol))
@@ -612,7 +614,11 @@ class PairBatch:
                 ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(lay.desc), _lib.ptr(lay.chunks), _lib.ptr(lay.spans), lay.n_spans
                 ph.span_partials, ph.seg_partials = _lib.ptr(lay.partials), _lib.ptr(lay.seg_partials)
             ph.irls_eps, ph.conv_tol, ph.max_iters = float(spec.get("irls_eps", irls_eps)), float(spec["conv_tol"]), int(spec["max_iters"])
-            ph.flags = (_lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0) | (_lib.SP_PHASE_WAVE_SPANS if self.wave_flag else 0) | (_lib.SP_PHASE_DEPTH_TABLE if self.table_flag else 0)
+            damp = int(round(8.0 * float(spec.get("depth_damp", 0.0))))            # (SP_PHASE_DEPTH_DAMP: eighths, at most 31.875)
+            if not 0 <= damp <= 255:
+                raise ValueError("depth_damp: 0 .. 31.875 in steps of 1/8")
+            ph.flags = ((_lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0) | (_lib.SP_PHASE_WAVE_SPANS if self.wave_flag else 0)
+                        | (_lib.SP_PHASE_DEPTH_TABLE if self.table_flag else 0) | (damp << _lib.SP_PHASE_DEPTH_DAMP_SHIFT))
             ph.next = 0
         sched.n_phases = len(all_phases)
         sched.entry = len(retry_phases)

@@ -869,6 +869,71 @@ def test_scheduled_run_reports_a_verdict_and_retries_what_fails_it():
     assert n == 4 and all(s == _lib.SP_STATUS_UNFINISHED for s in npy(dd.status))
 
 
+def _mask_boxes(masks):
+    """(N,4) int32 {row0, col0, row1, col1} (half open) of a bool (N,H,W) mask stack; an empty mask gets an empty box."""
+    rows, cols = masks.any(dim=2), masks.any(dim=1)
+    H, W = masks.shape[1:]
+    first = lambda b: torch.where(b.any(1), b.float().argmax(1), torch.zeros_like(b[:, 0], dtype=torch.long))
+    last = lambda b, n: torch.where(b.any(1), n - b.flip(1).float().argmax(1), torch.zeros_like(b[:, 0], dtype=torch.long))
+    return torch.stack((first(rows), first(cols), last(rows, H), last(cols, W)), dim=1).to(torch.int32)
+
+
+@pytest.mark.parametrize("granule", [256, 64])
+def test_segment_box_hint_builds_the_same_tables(granule):
+    """``KeyFrame.segment_boxes`` -- the (N,4) boxes a SAM-like frontend has anyway
+    (frontend/segment/mask_generation.py:93,155-180) -- lets the count pass of the batched set-up read the masks inside the boxes only.
+    Every table, every lattice, every sampled level and the work lists are BITWISE what the full scan builds: grid tiles and ragged blobs,
+    tight boxes, boxes larger than the mask, boxes reaching over the image (clamped), an empty segment with an inverted box; a keyframe
+    off the fast path (width 84) ignores its hint.  A box that cuts its mask -- at the granularity the pass reads the masks with: rows, and
+    16-pixel pieces along a row -- loses exactly the pixels outside."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.optim.pair_batch import PairBatch
+    dev = torch.device("cuda:0")
+    prs = [synth.make_pair(96, 128, 6, seed=401, overlap=2), synth.make_pair(96, 128, 9, seed=402, shape="blobs", blob_coverage=1.1),
+           synth.make_pair(50, 84, 4, seed=403), synth.make_pair(128, 160, 7, seed=404, shape="blobs", blob_coverage=0.8)]
+    prs[1].keypoint_regions[3] = False                      # an empty segment
+    t = lambda a: T(a).to(dev)
+
+    def frames(with_boxes, grow=0, cut=False):
+        out = []
+        for i, p in enumerate(prs):
+            kf = KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions))
+            if with_boxes:
+                b = _mask_boxes(kf.keypoint_regions)
+                b[:, :2] -= grow; b[:, 2:] += grow                         # (boxes beyond the image are clamped on the device)
+                if i == 1:
+                    b[3] = torch.tensor([40, 50, 10, 20], dtype=torch.int32)      # inverted: an empty segment
+                if cut and i == 0:
+                    b[2, 3] = (b[2, 1] // 16 + 1) * 16                      # segment 2 of pair 0: only up to the next 16-pixel boundary
+                    b[2, 2] = b[2, 0] + 5                                   # ... and its first 5 rows
+                kf.segment_boxes = b.to(dev)
+            out.append(kf)
+        return out
+
+    rest = ([t(p.trg_image) for p in prs], [t(p.K) for p in prs], torch.stack([t(p.pose_init) for p in prs]), [t(p.kld_init) for p in prs])
+    build = lambda fr: PairBatch(fr, *rest, levels=(0, 3), point_stride=(2, 2, 4), granule=granule, tile_points=1024)
+    ref = build(frames(False))
+    for grow in (0, 5, 1000):
+        got = build(frames(True, grow))
+        assert got.Ps == ref.Ps and torch.equal(got.pix, ref.pix) and torch.equal(got.kp_L, ref.kp_L)
+        assert torch.equal(got.src4[0], ref.src4[0]) and torch.equal(got.chunks, ref.chunks) and torch.equal(got.spans, ref.spans)
+        for key, lay in ref.coarse.items():
+            assert torch.equal(got.coarse[key].pix, lay.pix) and torch.equal(got.coarse[key].src4, lay.src4), (grow, key)
+    # a box that cuts its mask: exactly the mask pixels outside are gone (compare with the masks cut by hand, no hint)
+    cut = build(frames(True, 0, cut=True))
+    bx = _mask_boxes(t(prs[0].keypoint_regions))[2]
+    hand = frames(False)
+    m = hand[0].keypoint_regions.clone(); m[2, :, (int(bx[1]) // 16 + 1) * 16:] = False; m[2, int(bx[0]) + 5:] = False
+    hand[0].keypoint_regions = m
+    want = build(hand)
+    assert cut.Ps[0] < ref.Ps[0] and cut.Ps == want.Ps and torch.equal(cut.pix, want.pix) and torch.equal(cut.src4[0], want.src4[0])
+    with pytest.raises(ValueError):
+        bad = frames(False)
+        bad[0].segment_boxes = torch.zeros(3, 4, dtype=torch.int32, device=dev)
+        build(bad)
+
+
 def test_keyframe_record_of_the_set_up_follows_replaced_and_edited_tensors():
     """The batched set-up finds the device addresses of a keyframe's tensors on the keyframe (optim.batch_prepare.frame_records).  A build
     after one of them was REPLACED reads the new tensor, a build after an IN-PLACE edit reads the edited values -- both equal to a build from

@@ -180,3 +180,88 @@ def test_config3_sequence_with_mono_initialisation(engine):
     assert 2.0 < s < 4.0
     bar = (5e-4, 5e-3, 1e-2) if engine == "gn" else (6e-3, 1.5e-2, 3e-2)
     assert rot <= bar[0] and tt <= bar[1] and kld_err <= bar[2], (rot, tt, kld_err)
+
+
+class _LazySequence:
+    """Frames of a long synthetic sequence made on demand (``synth.make_sequence`` one frame at a time: the plane and its texture are a
+    function of the seed alone) and dropped again: ``frames[i]`` = supporting-frame-like KeyFrame (image + K), ``keyframe(i)`` = with the
+    segment data; the host copies of the last few frames only are kept."""
+
+    def __init__(self, twists, H=224, W=288, N=40, seed=31):
+        self.twists, self.H, self.W, self.N, self.seed = twists, H, W, N, seed
+        self._host = {}
+
+    def __len__(self):
+        return len(self.twists)
+
+    def host(self, i, keyframe=False):
+        from super_primitive_amd import synth
+        key = (i, keyframe)
+        if key not in self._host:
+            if len(self._host) > 16:
+                self._host.pop(next(iter(self._host)))
+            self._host[key] = synth.make_sequence(self.H, self.W, self.N, [self.twists[i]], keyframe_ids=[0] if keyframe else [], seed=self.seed, overlap=1)[0]
+        return self._host[key]
+
+    def __getitem__(self, i):
+        from super_primitive_amd.image.keyframe import KeyFrame
+        f = self.host(i)
+        return KeyFrame(T(f.image), T(f.K))
+
+    def keyframe(self, i):
+        from super_primitive_amd.image.keyframe import KeyFrame
+        f = self.host(i, True)
+        return KeyFrame(T(f.image), T(f.K), T(f.logdepth_perseg), T(f.keypoints), T(f.keypoint_regions))
+
+
+def test_config3_at_sequence_length():
+    """BASELINE configs[2] names the FULL fr1/desk sequence (config/tum/odom_desk.yaml:6; ~600 frames).  640 frames of
+    the synthetic plane on a bounded (Lissajous) trajectory at the fr1/desk frame-to-frame motion through the whole MonoVO chain with the
+    reference's extent (window 5, two supporting frames per keyframe, supplementary mapping after every frame), Gauss-Newton engine:
+    drift stays bounded -- every tracked pose against the ground truth after ONE similarity alignment, and frame to frame -- the device
+    memory pool does not grow after frame 100 (per-keyframe caches, windows and trackers are released with their keyframes), and the
+    stage timings do not creep."""
+    import time
+    from super_primitive_amd import synth
+    from super_primitive_amd.odometery.sequence import MonoVO
+    n = 640
+    k = np.arange(n, dtype=np.float64)
+    tw = np.stack([0.8 * np.sin(2 * np.pi * k / 200.0), 0.5 * np.sin(2 * np.pi * k / 140.0 + 1.0) - 0.5 * np.sin(1.0), 0.3 * np.sin(2 * np.pi * k / 260.0),
+                   0.05 * np.sin(2 * np.pi * k / 170.0), 0.06 * np.sin(2 * np.pi * k / 230.0), 0.04 * np.sin(2 * np.pi * k / 190.0)], axis=1)
+    seq = _LazySequence([t for t in tw])
+    f0 = seq.host(0, True)
+    assert np.abs(tw[0]).max() == 0.0
+    vo = MonoVO(seq, seq.keyframe, T(f0.T_wc), T(f0.kld_gt), engine="gn", translation_thresh=0.095, window_size=5,
+                depth_of=lambda i: T(seq.host(i, True).kld_gt))
+    mem, stage = {}, {}
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(1, n):
+        vo.step(i)
+        if i in (100, 300, n - 1):
+            torch.cuda.synchronize()
+            mem[i] = (torch.cuda.memory_allocated(), torch.cuda.memory_reserved())
+            stage[i] = dict(vo.secs, wall=time.perf_counter() - t0, keyframes=len(vo.all_kf_ids))
+    out = vo.result()
+    P = npy(out["track_poses"]).astype(np.float64)
+    G = np.stack([synth.se3_exp_np(t) for t in tw])
+    s, rot, tt = _aligned_errors(P, G)
+    # frame-to-frame: the relative motion of consecutive tracked poses against the ground truth's (scale aligned)
+    rel = lambda X: [np.linalg.inv(X[i]) @ X[i + 1] for i in range(len(X) - 1)]
+    rp, rg = rel(P), rel(G)
+    rel_rot = max(rot_angle(a, b) for a, b in zip(rp, rg))
+    rel_t = max(float(np.abs(s * a[:3, 3] - b[:3, 3]).max()) for a, b in zip(rp, rg))
+    per = lambda a, b: {key: 1e3 * (stage[b][key] - stage[a][key]) / (b - a) for key in ("track", "supp_mapping", "keyframe")}
+    early, late = per(100, 300), per(300, n - 1)
+    n_map = out["n_mappings"]
+    print(f"\nconfig 3 at sequence length: {n} frames, {len(out['all_kf_ids'])} keyframes, {n_map} scheduled + {out['n_supp_mappings']} supplementary mappings, "
+          f"{(n - 1) / stage[n - 1]['wall']:.0f} frames/s end to end (wall, frame synthesis included), {(n - 1) / sum(vo.secs.values()):.0f} frames/s in the chain; vs ground truth "
+          f"after one similarity alignment: rot {rot:.2e} rad, t {tt:.2e} (scale {s:.4f}); frame to frame: rot {rel_rot:.2e}, t {rel_t:.2e}; "
+          f"ms per frame (track / supplementary mapping / keyframe work) frames 100-300: {early['track']:.2f} / {early['supp_mapping']:.2f} / {early['keyframe']:.2f}, "
+          f"frames 300-{n - 1}: {late['track']:.2f} / {late['supp_mapping']:.2f} / {late['keyframe']:.2f}; scheduled mapping {1e3 * vo.secs['mapping'] / max(n_map, 1):.1f} ms per window; "
+          f"device memory (allocated / reserved MB) at frame 100: {mem[100][0] / 1e6:.0f} / {mem[100][1] / 1e6:.0f}, 300: {mem[300][0] / 1e6:.0f} / {mem[300][1] / 1e6:.0f}, "
+          f"{n - 1}: {mem[n - 1][0] / 1e6:.0f} / {mem[n - 1][1] / 1e6:.0f}")
+    assert len(out["all_kf_ids"]) >= 40 and len(out["kf_ids"]) == 5 and n_map >= 35
+    assert rel_rot <= 1e-3 and rel_t <= 2e-3, (rel_rot, rel_t)                      # every frame tracked
+    assert rot <= 2e-2 and tt <= 6e-2 and abs(s - 1.0) <= 0.1, (rot, tt, s)         # drift over 640 frames and ~60 keyframe hand-overs: bounded
+    assert mem[n - 1][0] <= mem[100][0] * 1.1 + 32e6 and mem[n - 1][1] <= mem[100][1] + 64e6, mem      # no growth after frame 100
+    assert late["track"] <= 1.5 * early["track"] + 0.2 and late["supp_mapping"] <= 1.5 * early["supp_mapping"] + 0.2

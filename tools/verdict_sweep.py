@@ -36,15 +36,24 @@ BASE = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
 NO_CAP = VERDICT_DEFAULTS["retry_on"] & ~_lib.SP_STATUS_LAST_CAP
 ct, ie = BASE["conv_tol"], 1e-3
 po = lambda level, stride, cap, eps=ie: dict(level=level, stride=stride, max_iters=cap, irls_eps=eps, conv_tol=ct, pose_only=True)
+jt = lambda level, stride, damp=0.0, cap=25: dict(level=level, stride=stride, max_iters=cap, irls_eps=ie, conv_tol=ct, depth_damp=damp)
 VARIANTS = {
     "shipped": dict(BASE),
     "no_retry": dict(BASE, retry_phases=None),
-    "retry_L2_30": dict(BASE, retry_phases=[po(2, 4, 30, 1e-2)]),
-    "retry_L2_eps3e-3": dict(BASE, retry_phases=[po(2, 4, 15, 3e-3)]),
-    "retry_L2_cap15_same_eps": dict(BASE, retry_phases=[po(2, 4, 15)]),
-    "retry_not_on_cap": dict(BASE, verdict=dict(retry_on=NO_CAP)),
-    "kld_bound_3": dict(BASE, verdict=dict(kld_bound=3.0)),
-    "eps1e-2_first": dict(BASE, pose_first_eps=1e-2, pose_first_iters=15, retry_phases=[po(2, 4, 30)]),
+    "round4": dict(BASE, pose_first_iters=30, pose_first_eps=None, retry_phases=None, depth_damp=None),
+    "undamped": dict(BASE, depth_damp=None),
+    "d8": dict(BASE, depth_damp=(8.0,)),
+    "d4": dict(BASE, depth_damp=(4.0,)),
+    "d16": dict(BASE, depth_damp=(16.0,)),
+    "d8_0.25": dict(BASE, depth_damp=(8.0, 0.25)),
+    "d4_0.5": dict(BASE, depth_damp=(4.0, 0.5)),
+    "d8_1": dict(BASE, depth_damp=(8.0, 1.0)),
+    "d8_then_L2": dict(BASE, phases=[po(2, 4, 15, 1e-2), jt(2, 4, 8.0), jt(2, 4), jt(1, 2), jt(0, 2),
+                                      dict(level=0, stride=1, max_iters=15, irls_eps=1e-5, conv_tol=1e-4)]),
+    "d8_cap12_then_L2": dict(BASE, phases=[po(2, 4, 15, 1e-2), jt(2, 4, 8.0, 12), jt(2, 4), jt(1, 2), jt(0, 2),
+                                            dict(level=0, stride=1, max_iters=15, irls_eps=1e-5, conv_tol=1e-4)]),
+    "undamped_retry_d8_1": dict(BASE, depth_damp=None, retry_join=1,
+                                retry_phases=[po(2, 4, 30), jt(2, 4, 8.0), jt(1, 2, 1.0)]),
 }
 
 
@@ -70,7 +79,7 @@ def main(argv=None):
     ap.add_argument("--starts", type=int, default=9216)
     ap.add_argument("--batch", type=int, default=1536)
     ap.add_argument("--slots", type=int, default=384)
-    ap.add_argument("--variants", default="shipped,no_retry,retry_L2_30,retry_L2_eps3e-3,kld_bound_3,eps1e-2_first")
+    ap.add_argument("--variants", default="shipped,no_retry")
     ap.add_argument("--shape", default="grid", choices=["grid", "blobs"])
     ap.add_argument("--npz", default=None)
     ap.add_argument("--alone", default="105,1380,1482", help="pairs also run as batches of ONE (order independence of the verdict and the retry)")
