@@ -247,7 +247,53 @@ def map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose=1e-4, w
     return _map_window_eager(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode)
 
 
-def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode='map', gn=None):
+class GnSuppMapper:
+    """The SUPPLEMENTARY mapping after every tracked frame (``mapping(mode='supp')``, odometery/odometery.py:1038-1042: only the latest
+    keyframe is a source, only ITS log-depths move) by Gauss-Newton with ONE window per latest keyframe.  Between two keyframes the
+    window of that mapping is the same graph every frame -- the latest keyframe against its predecessor, their stored supporting frames
+    and the TWO RUNNING supporting frames (the last two tracked frames, ``collect_tracking_frames(last=True)``) -- and only the two
+    running frames change: their images move through two slots of the window in place (the one that stays is copied from slot to slot,
+    the new one is packed), their poses and affine pairs are overwritten, the LM state is reset.  Tables, source samples, work list,
+    descriptors and packed targets of everything else are built once per keyframe instead of once per frame (1 ms of interpreter time
+    per frame).  Same launches, same arithmetic and the same result as ``map_window(..., mode='supp',
+    optimiser='gn')`` on the same inputs (tests/test_gpu_sequence.py)."""
+
+    def __init__(self, kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, window_size=5, gn_schedule=None):
+        assert len(supp[-1]) == 2, "built once the latest keyframe has its two running supporting frames"
+        self.K = K = len(kfs)
+        self.affine = kf_affs is not None
+        self.gn = dict(MAP_GN_SCHEDULE, **(gn_schedule or {}))
+        self.num_iters = int(num_iters)
+        self.win, self.supp_node, src_ids = _build_map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, 1e-4, K == window_size, self.affine, True,
+                                                              1e-8, 'supp', self.gn)
+        assert src_ids == [K - 1]
+        self.slots = [self.supp_node[(K - 1, 0)], self.supp_node[(K - 1, 1)]]
+        self.frames = [supp[-1][0][0], supp[-1][1][0]]               # the frame objects whose images sit in the slots
+
+    def __call__(self, running):
+        """running: the latest keyframe's two running supporting frames [(frame, pose, aff)], older first.  Returns (the latest keyframe's
+        new log-depths, losses, iterations)."""
+        win, gn = self.win, self.gn
+        assert len(running) == 2
+        if running[0][0] is self.frames[1] and running[1][0] is not self.frames[1]:
+            win.copy_target_image(self.slots[0], self.slots[1])      # yesterday's newest frame is today's older one
+            self.frames[0] = self.frames[1]
+        for j in range(2):
+            if running[j][0] is not self.frames[j]:
+                win.set_target_image(self.slots[j], running[j][0].image)
+                self.frames[j] = running[j][0]
+        win.set_nodes({self.slots[j]: dict(T=running[j][1], aff=running[j][2] if self.affine else None) for j in range(2)})
+        win.reset_gn()
+        n = win.run_gn(0, min(self.num_iters, gn['max_iters']), irls_eps=gn['irls_eps'], conv_tol=gn['conv_tol'])
+        if gn['polish_max'] > 0 and self.num_iters > gn['max_iters'] // 2:
+            n += win.run_gn(0, gn['polish_max'], irls_eps=gn['polish_eps'], conv_tol=gn['polish_tol'])
+        return win.klds()[0], win.gn_losses(), n
+
+
+def _build_map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode, gn):
+    """The PoseWindow of one mapping (nodes = keyframes then supporting frames, sources = the keyframes that are sources in ``mode``,
+    one edge per photometric term): (window or None when there is nothing to match, {(k, j): node of supporting frame j of keyframe k},
+    source keyframe ids)."""
     from ..optim.window import KIND_WINDOW, PoseWindow
     K = len(kfs)
     free_pose, free_kld, free_supp = _free_parts(K, mode, frozen0)
@@ -268,13 +314,21 @@ def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose,
         for t in trg:
             node = t[1] if t[0] == 'kf' else supp_node[(t[1], t[2])]
             edges.append((b, node, 1.0 / len(trg), dense_optim.Z_MIN_BATCH))
+    if not edges:
+        return None, supp_node, src_ids
+    win = PoseWindow(sources, nodes, edges, (0, 1), abs_loss=False, rel_tol=rel_tol if initialised else 0.0, use_affine=affine,
+                     max_iters=max(1, num_iters) + (gn['polish_max'] + 8 if gn else 0))
+    return win, supp_node, src_ids
+
+
+def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode='map', gn=None):
+    K = len(kfs)
+    win, supp_node, src_ids = _build_map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode, gn)
     det = lambda x: x.detach().clone()
-    if not edges:                                                  # a single keyframe without supporting frames: nothing to match
+    if win is None:                                                # a single keyframe without supporting frames: nothing to match
         return dict(kf_poses=torch.stack([det(p) for p in kf_poses]), klds=[det(k) for k in kf_klds],
                     affs=torch.stack([det(a) for a in kf_affs]) if affine else None, supp_poses=[[] for _ in range(K)],
                     supp_affs=[[] for _ in range(K)] if affine else None, losses=[torch.zeros((), device=kf_poses[0].device)], stopped=-1)
-    win = PoseWindow(sources, nodes, edges, (0, 1), abs_loss=False, rel_tol=rel_tol if initialised else 0.0, use_affine=affine,
-                     max_iters=max(1, num_iters) + (gn['polish_max'] + 8 if gn else 0))
     if gn:
         n = win.run_gn(0, min(num_iters, gn['max_iters']), irls_eps=gn['irls_eps'], conv_tol=gn['conv_tol'])
         if gn['polish_max'] > 0 and num_iters > gn['max_iters'] // 2:      # (a short budget -- the supplementary mapping -- gets no polish)

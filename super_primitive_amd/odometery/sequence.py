@@ -33,12 +33,12 @@ from ..core.depth_render import estimate_depth_kf_native
 from ..lie.lie_algebra import invertSE3
 from .depth_init import segment_based_depth_reinit
 from .kf_criteria import keyframe_criterion
-from .loops import GnTracker, map_window, track_frame_fused, track_frame_gn  # noqa: F401
+from .loops import GnSuppMapper, GnTracker, map_window, track_frame_fused, track_frame_gn  # noqa: F401
 
 # config/tum/odom_desk.yaml (aligment.track / aligment.mapping / kf / window_size)
 DEFAULTS = dict(track_steps=(0, 0, 300), track_levels=(0, 3), track_lr=5e-3, map_steps=500, continual_steps=10, init_steps=1000,
                 map_lr_pose=1e-4, window_size=5, supp_every_n=3, depth_validity_ratio=0.60, translation_thresh=0.2,
-                affine_compensation=True, mono_init=False, init_frames=7, motion_prior=False)
+                affine_compensation=True, mono_init=False, init_frames=7, motion_prior=False, persistent_supp=True)
 
 
 class _Supp:
@@ -67,6 +67,7 @@ class MonoVO:
         self.n_map = dict(supp=0, map=0, init=0)
         self.secs = dict(track=0.0, keyframe=0.0, mapping=0.0, supp_mapping=0.0)
         self.tracker = None                   # (Gauss-Newton engine: one window per keyframe, re-used for every frame tracked against it)
+        self.supp_mapper = None               # (... and one window per latest keyframe for the supplementary mapping after every frame)
         self.current_aff = torch.zeros(2, device=self.dev)
         self.add_kf(to_keyframe(0), pose0.clone(), kld0.clone(), 0, self.current_aff.clone())
         self.update_track_pose('init')
@@ -78,8 +79,10 @@ class MonoVO:
         self.supp_opt.append([])
         self.all_kf_ids.append(ts)
         self.tracker = None
+        self.supp_mapper = None
 
     def pop_kf(self, i):
+        self.supp_mapper = None
         for lst in (self.kfs, self.kf_ids, self.kf_poses, self.kf_klds, self.kf_affs, self.supp_opt):
             lst.pop(i)
 
@@ -163,6 +166,22 @@ class MonoVO:
         rows = [(self.curr_supp if k == K - 1 else self.supp_opt[k]) if self.initialised else [] for k in range(K)]
         supp = [[(s.frame, s.pose, s.aff) for s in row] for row in rows]
         lr_pose = 1e-2 if (mode == 'init' and c['mono_init']) else c['map_lr_pose']
+        if mode == 'supp' and self.engine == "gn" and c['persistent_supp'] and self.initialised and len(self.curr_supp) == 2:
+            # the supplementary mapping between two keyframes is the same window every frame but for the two running supporting frames:
+            # ONE window per latest keyframe, re-pointed in place (loops.GnSuppMapper) -- same arithmetic, same result as the branch below
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            if self.supp_mapper is None:
+                self.supp_mapper = GnSuppMapper(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, supp, num_iters,
+                                                window_size=c['window_size'])
+            kld, _, _ = self.supp_mapper([(s.frame, s.pose, s.aff) for s in self.curr_supp])
+            torch.cuda.synchronize(); self.secs['supp_mapping'] += time.perf_counter() - t0
+            self.kf_klds[-1] = kld
+            self.n_map[mode] += 1
+            if self.tracker is not None:
+                self.tracker.update_keyframe(self.kf_klds[-1])
+            self.update_track_pose(mode)
+            return
+        self.supp_mapper = None                                   # (whatever follows moves poses / depths the persistent window holds)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = map_window(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, supp, num_iters, lr_pose=lr_pose,
                          window_size=c['window_size'], initialised=self.initialised, optimiser="gn" if self.engine == "gn" else "adam", mode=mode)

@@ -72,8 +72,17 @@ REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 # Which pose-only phase goes first is a matter of speed: epsilon 1e-2 with a cap of 15 in the first attempt and epsilon 1e-3 with a cap of
 # 30 in the second (below) loses 9 of 9216 starts at the first attempt and none after the second, at 33.6 k pairs/s and 32.9 iterations per
 # pair; the other way round (round 4's first attempt) 14 / none at 31.2 k and 36.7 (profiles/r05_reference_start.txt).
+# ``coarse_damped`` = (16, 12): between the pose-only phase and the joint phases, 12 iterations at the coarsest level with the log-depth
+# block DAMPED by 16 (include/sp_hip.h SP_PHASE_DEPTH_DAMP: the depths follow at 1/17 of their Gauss-Newton step -- the reference's Adam
+# moves them at a tenth of the pose's rate).  On the grid tiling the undamped schedule is enough (8 second attempts per 4608 starts, all
+# rescued); on SAM-like ragged masks over near-planar scenes (bench.py --shape blobs: depth range e^0.2) it walks into the second solution
+# of the plane's homography from 6 % of the reference's starts and the second attempt brings home only half of those -- 88 of 3072 flagged,
+# where the real reference converges (goldens g20y).  With the damped phase: 4 second attempts and ONE flagged pair of 3072, at a HIGHER
+# rate there (24.9 k against 21.8 k pairs/s: no time lost in failing attempts) and 30.0 k against 32.7 k on the grid, no second attempt
+# among 4608 starts (tools/verdict_sweep.py; damping 4 / 8 / 16, caps 8 / 12 / 16 / 25, with and without the undamped phase at the same
+# level: profiles/r05_reference_start.txt).
 REFERENCE_START_RETRY = (dict(level=2, stride=4, max_iters=30, irls_eps=1e-3, conv_tol=2e-3, pose_only=True),)
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, retry_phases=REFERENCE_START_RETRY)
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(16.0, 12), retry_phases=REFERENCE_START_RETRY)
 # The verdict's thresholds (SpVerdict): a log-depth more than ``kld_bound`` from its seed (a factor e^kld_bound in depth: the reference's
 # seeds log(2 + 2 rand) are at most a factor 2 off) has run away; fewer than ``valid_min`` of the points projecting into the target
 # frame at the end of an alignment that started with both frames overlapping is a lost pair.  ``retry_on``: the status bits that send
@@ -551,7 +560,7 @@ class PairBatch:
 
     def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3, phases=None,
                  use_coarse=True, pose_first_iters=0, pose_first_eps=None, joint_levels=None, use_levels=None, retry_pose_first=None,
-                 retry_phases=None, retry_join=None, depth_damp=None):
+                 retry_phases=None, retry_join=None, depth_damp=None, coarse_damped=None):
         """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
         built with a ``point_stride`` run on their decimated point set unless ``use_coarse=False``.  ``phases``: an explicit
         list of dict(level, stride, max_iters, irls_eps, conv_tol) instead (every (level, stride > 1) needs its table:
@@ -561,7 +570,9 @@ class PairBatch:
         distribution (REFERENCE_START_SCHEDULE).  A TUPLE of caps puts one pose-only phase per entry at the coarsest levels in turn
         (coarsest first); ``joint_levels`` = k restricts the joint (pose + depth) phases to the k finest levels: a level above those only
         aligns the pose.  ``depth_damp`` = (d_coarsest, ...): extra LM damping of the log-depth block in the joint phases, coarsest level
-        first (include/sp_hip.h SP_PHASE_DEPTH_DAMP; levels not named: none).  ``use_levels`` = k: only the k finest levels of the batch take part in all of that (the batch may carry coarser
+        first (include/sp_hip.h SP_PHASE_DEPTH_DAMP; levels not named: none); ``coarse_damped`` = (damping, cap): one more joint phase IN FRONT
+        of the joint phases, at the coarsest of their levels, with that depth damping and iteration cap (REFERENCE_START_SCHEDULE).
+        ``use_levels`` = k: only the k finest levels of the batch take part in all of that (the batch may carry coarser
         ones for the second attempt).
 
         THE SECOND ATTEMPT (SpSchedule.retry_entry, SpVerdict): ``retry_phases`` -- a list of phase dicts like ``phases`` -- or its
@@ -580,6 +591,9 @@ class PairBatch:
                                    irls_eps=irls_eps if pose_first_eps is None else pose_first_eps, conv_tol=conv_tol, pose_only=True))
             joint = coarse_first if joint_levels is None else coarse_first[len(coarse_first) - int(joint_levels):]
             damps = dict(zip(joint, depth_damp)) if depth_damp else {}              # (coarsest joint level first)
+            if coarse_damped:
+                phases.append(dict(level=joint[0], stride=self.point_stride[joint[0]] if use_coarse else 1, max_iters=int(coarse_damped[1]), irls_eps=irls_eps,
+                                   conv_tol=conv_tol, depth_damp=float(coarse_damped[0])))
             phases += [dict(level=level, stride=self.point_stride[level] if use_coarse else 1, max_iters=max_iters_per_level, irls_eps=irls_eps,
                            conv_tol=conv_tol, depth_damp=damps.get(level, 0.0)) for level in joint]
             finest = min(self.level_ids)

@@ -196,6 +196,13 @@ class PoseWindow:
             assert (Hl, Wl) == self.level_hw[(node, l)], "set_target_image: the frame size changed; build a new window"
             _lib.check(self.lib.sp_pack_rgb(_lib.ptr(lv[l].contiguous()), 1, Hl, Wl, _lib.ptr(self.trg3[(node, l)]), _lib.stream_ptr()), "sp_pack_rgb")
 
+    def copy_target_image(self, dst_node, src_node):
+        """The packed pyramid of target node ``src_node`` into ``dst_node``'s buffers (same size): a frame that moves from one slot of
+        a persistent window to another is not packed twice."""
+        for l in self.level_ids:
+            assert self.level_hw[(dst_node, l)] == self.level_hw[(src_node, l)]
+            self.trg3[(dst_node, l)].copy_(self.trg3[(src_node, l)])
+
     def set_nodes(self, updates):
         """updates: {node index: dict(T=(4,4) [, aff=(2,)])}: overwrite poses / affine pairs (tangents and Adam moments cleared), then
         re-compose every edge's relative pose.  One small upload."""

@@ -265,3 +265,26 @@ def test_config3_at_sequence_length():
     assert rot <= 2e-2 and tt <= 6e-2 and abs(s - 1.0) <= 0.1, (rot, tt, s)         # drift over 640 frames and ~60 keyframe hand-overs: bounded
     assert mem[n - 1][0] <= mem[100][0] * 1.1 + 32e6 and mem[n - 1][1] <= mem[100][1] + 64e6, mem      # no growth after frame 100
     assert late["track"] <= 1.5 * early["track"] + 0.2 and late["supp_mapping"] <= 1.5 * early["supp_mapping"] + 0.2
+
+
+def test_persistent_supplementary_mapping_window_equals_a_rebuilt_one():
+    """``loops.GnSuppMapper`` -- ONE window per latest keyframe for the supplementary mapping after every tracked
+    frame, the two running supporting frames moved through its slots in place -- against the window rebuilt every frame
+    (``persistent_supp=False``): the same chain, BITWISE (tracked poses, keyframe poses and log-depths, keyframe decisions), at a
+    fraction of the per-frame cost."""
+    from super_primitive_amd.odometery.sequence import run_sequence
+    n = 40
+    seq, frames, to_kf = make_sequence_inputs(n, rot_scale=0.3)
+    run_sequence(frames[:4], to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn")
+    outs = {}
+    for persistent in (False, True):
+        outs[persistent] = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn", translation_thresh=0.095, window_size=5,
+                                        depth_of=lambda i: T(seq[i].kld_gt), persistent_supp=persistent)
+    a, b = outs[False], outs[True]
+    assert a["all_kf_ids"] == b["all_kf_ids"] and a["supp_ids"] == b["supp_ids"] and a["n_supp_mappings"] == b["n_supp_mappings"] == n - 1
+    assert torch.equal(a["track_poses"], b["track_poses"]) and torch.equal(a["kf_poses"], b["kf_poses"])
+    assert all(torch.equal(x, y) for x, y in zip(a["kf_klds"], b["kf_klds"]))
+    sa, sb = a["seconds"], b["seconds"]
+    print(f"\nsupplementary mapping per frame: rebuilt {1e3 * sa['supp_mapping'] / (n - 1):.2f} ms, persistent {1e3 * sb['supp_mapping'] / (n - 1):.2f} ms; "
+          f"chain {(n - 1) / sum(sa.values()):.0f} -> {(n - 1) / sum(sb.values()):.0f} frames/s")
+    assert sb["supp_mapping"] < sa["supp_mapping"]

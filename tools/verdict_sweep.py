@@ -35,25 +35,23 @@ H, W, N, G = 480, 640, 64, 8
 BASE = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
 NO_CAP = VERDICT_DEFAULTS["retry_on"] & ~_lib.SP_STATUS_LAST_CAP
 ct, ie = BASE["conv_tol"], 1e-3
-po = lambda level, stride, cap, eps=ie: dict(level=level, stride=stride, max_iters=cap, irls_eps=eps, conv_tol=ct, pose_only=True)
 jt = lambda level, stride, damp=0.0, cap=25: dict(level=level, stride=stride, max_iters=cap, irls_eps=ie, conv_tol=ct, depth_damp=damp)
+po = lambda level, stride, cap, eps=ie: dict(level=level, stride=stride, max_iters=cap, irls_eps=eps, conv_tol=ct, pose_only=True)
+pol = dict(level=0, stride=1, max_iters=15, irls_eps=1e-5, conv_tol=1e-4)
+def damped(damp, cap, tol=ct, second_L2=True, eps=ie):
+    return [po(2, 4, 15, 1e-2), dict(level=2, stride=4, max_iters=cap, irls_eps=eps, conv_tol=tol, depth_damp=damp)] + ([jt(2, 4)] if second_L2 else []) + [jt(1, 2), jt(0, 2), pol]
 VARIANTS = {
     "shipped": dict(BASE),
     "no_retry": dict(BASE, retry_phases=None),
-    "round4": dict(BASE, pose_first_iters=30, pose_first_eps=None, retry_phases=None, depth_damp=None),
-    "undamped": dict(BASE, depth_damp=None),
-    "d8": dict(BASE, depth_damp=(8.0,)),
-    "d4": dict(BASE, depth_damp=(4.0,)),
-    "d16": dict(BASE, depth_damp=(16.0,)),
-    "d8_0.25": dict(BASE, depth_damp=(8.0, 0.25)),
-    "d4_0.5": dict(BASE, depth_damp=(4.0, 0.5)),
-    "d8_1": dict(BASE, depth_damp=(8.0, 1.0)),
-    "d8_then_L2": dict(BASE, phases=[po(2, 4, 15, 1e-2), jt(2, 4, 8.0), jt(2, 4), jt(1, 2), jt(0, 2),
-                                      dict(level=0, stride=1, max_iters=15, irls_eps=1e-5, conv_tol=1e-4)]),
-    "d8_cap12_then_L2": dict(BASE, phases=[po(2, 4, 15, 1e-2), jt(2, 4, 8.0, 12), jt(2, 4), jt(1, 2), jt(0, 2),
-                                            dict(level=0, stride=1, max_iters=15, irls_eps=1e-5, conv_tol=1e-4)]),
-    "undamped_retry_d8_1": dict(BASE, depth_damp=None, retry_join=1,
-                                retry_phases=[po(2, 4, 30), jt(2, 4, 8.0), jt(1, 2, 1.0)]),
+    "undamped": dict(BASE, phases=None, depth_damp=None, coarse_damped=None),
+    "d8c12": dict(BASE, phases=damped(8.0, 12)),
+    "d8c8": dict(BASE, phases=damped(8.0, 8)),
+    "d8c16": dict(BASE, phases=damped(8.0, 16)),
+    "d16c12": dict(BASE, phases=damped(16.0, 12)),
+    "d4c12": dict(BASE, phases=damped(4.0, 12)),
+    "d8c25_tol1e-2": dict(BASE, phases=damped(8.0, 25, tol=1e-2)),
+    "d8c12_direct_L1": dict(BASE, phases=damped(8.0, 12, second_L2=False)),
+    "d8c12_eps1e-2": dict(BASE, phases=damped(8.0, 12, eps=1e-2)),
 }
 
 
