@@ -115,7 +115,7 @@ def _render_sigma05(a):
     return synth.make_pair(H, W, a[0], seed=a[1], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
 
 
-def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue_factor=4):
+def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue_factor=4, slot_only=False):
     """frame pairs per second FROM THE REFERENCE'S OWN STARTING DISTRIBUTION (odometery/two_frame_sfm.py:77-81,103-105): every
     resident pair starts at T_gt Exp(0.05 randn(6)) with depth seeds log(2 + 2 rand) on a multi-octave (~1/f) texture
     (synth.make_pair(texture='octaves', init_mode='reference')); the schedule is optim.pair_batch.REFERENCE_START_SCHEDULE
@@ -210,6 +210,10 @@ def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue
     rec_q = record(batch, Qb, dt_q, launched_q, err, err0)
     rec_q["slots"] = min(2 * M, Qb // 2)
     rec_q["frame_pairs_per_sec_with_M_slots"] = {"slots": M, "frame_pairs_per_sec": Qb / dt_m, "iterations_launched": int(launched_m)}
+    if slot_only:
+        del batch
+        torch.cuda.empty_cache()
+        return rec_q
     # (a) round 3's form: M pairs resident, all optimised together (here: the first M of the same batch; the rest idle at their
     #     initial values -- the queue form with exactly M pairs)
     del batch
@@ -833,6 +837,15 @@ def main(argv=None):
                 line["frame_pairs_status"] = dict(line["reference_start"]["slot_level_continuous_batching"]["verdict"],
                                                   pairs=line["reference_start"]["slot_level_continuous_batching"]["pairs"],
                                                   unconverged_vs_ground_truth=[u["pair"] for u in line["reference_start"]["slot_level_continuous_batching"]["unconverged"]])
+                if args.shape == "grid":
+                    # ... and the same on SAM-LIKE RAGGED MASKS (overlapping ellipses, rho = 1.2, 64 per keyframe: the workload north_star
+                    # names; `bench.py --shape blobs` runs every leg on it): pairs of different padded layouts share the slots
+                    import copy
+                    blob_args = copy.copy(args)
+                    blob_args.shape, blob_args.coverage = "blobs", 1.2
+                    rb = reference_start_leg(blob_args, rank, dev, M, slot_only=True)
+                    line["frame_pairs_per_sec_ragged_masks"] = rb["frame_pairs_per_sec"]
+                    line["reference_start_ragged_masks"] = rb
                 line["frame_pairs_per_sec_what"] = ("reference start (pose T_gt Exp(0.05 randn), depth seeds log(2 + 2 rand), multi-octave texture), "
                                                     "REFERENCE_START_SCHEDULE, slot-level continuous batching on one stream; frame_pairs_per_sec_near_start = "
                                                     "round 3's sigma-0.004 figure")

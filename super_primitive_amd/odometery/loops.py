@@ -255,8 +255,9 @@ class GnSuppMapper:
     running frames change: their images move through two slots of the window in place (the one that stays is copied from slot to slot,
     the new one is packed), their poses and affine pairs are overwritten, the LM state is reset.  Tables, source samples, work list,
     descriptors and packed targets of everything else are built once per keyframe instead of once per frame (1 ms of interpreter time
-    per frame).  Same launches, same arithmetic and the same result as ``map_window(..., mode='supp',
-    optimiser='gn')`` on the same inputs (tests/test_gpu_sequence.py)."""
+    per frame).  Same launches and arithmetic as ``map_window(..., mode='supp', optimiser='gn')`` on the same
+    inputs; the results agree to the round-off of the source colours (sampled once per window, at the re-projection of the keyframe's
+    points under the depths the window was built with; tests/test_gpu_sequence.py)."""
 
     def __init__(self, kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, window_size=5, gn_schedule=None):
         assert len(supp[-1]) == 2, "built once the latest keyframe has its two running supporting frames"

@@ -270,8 +270,8 @@ def test_config3_at_sequence_length():
 def test_persistent_supplementary_mapping_window_equals_a_rebuilt_one():
     """``loops.GnSuppMapper`` -- ONE window per latest keyframe for the supplementary mapping after every tracked
     frame, the two running supporting frames moved through its slots in place -- against the window rebuilt every frame
-    (``persistent_supp=False``): the same chain, BITWISE (tracked poses, keyframe poses and log-depths, keyframe decisions), at a
-    fraction of the per-frame cost."""
+    (``persistent_supp=False``): the same chain -- the same keyframe decisions and supporting frames, tracked poses, keyframe poses and
+    log-depths equal to the round-off of the source colours -- at a fraction of the per-frame cost."""
     from super_primitive_amd.odometery.sequence import run_sequence
     n = 40
     seq, frames, to_kf = make_sequence_inputs(n, rot_scale=0.3)
@@ -282,9 +282,14 @@ def test_persistent_supplementary_mapping_window_equals_a_rebuilt_one():
                                         depth_of=lambda i: T(seq[i].kld_gt), persistent_supp=persistent)
     a, b = outs[False], outs[True]
     assert a["all_kf_ids"] == b["all_kf_ids"] and a["supp_ids"] == b["supp_ids"] and a["n_supp_mappings"] == b["n_supp_mappings"] == n - 1
-    assert torch.equal(a["track_poses"], b["track_poses"]) and torch.equal(a["kf_poses"], b["kf_poses"])
-    assert all(torch.equal(x, y) for x, y in zip(a["kf_klds"], b["kf_klds"]))
+    # (not bitwise: the source colours of a window are sampled where the reference samples them -- at the re-projection of the keyframe's
+    #  own points, whose last bit depends on the depths, core/dense_optim.py:143-162 -- ONCE, when the window is built: the rebuilt window
+    #  samples with this frame's depths, the persistent one with those of the keyframe's second frame.  Round-off of the colours, 1e-7)
+    dp = float((a["track_poses"] - b["track_poses"]).abs().max()), float((a["kf_poses"] - b["kf_poses"]).abs().max())
+    dk = max(float((x - y).abs().max()) for x, y in zip(a["kf_klds"], b["kf_klds"]))
+    assert dp[0] <= 5e-6 and dp[1] <= 5e-6 and dk <= 5e-5, (dp, dk)
     sa, sb = a["seconds"], b["seconds"]
     print(f"\nsupplementary mapping per frame: rebuilt {1e3 * sa['supp_mapping'] / (n - 1):.2f} ms, persistent {1e3 * sb['supp_mapping'] / (n - 1):.2f} ms; "
-          f"chain {(n - 1) / sum(sa.values()):.0f} -> {(n - 1) / sum(sb.values()):.0f} frames/s")
+          f"chain {(n - 1) / sum(sa.values()):.0f} -> {(n - 1) / sum(sb.values()):.0f} frames/s; largest differences: tracked poses {dp[0]:.1e}, keyframe poses {dp[1]:.1e}, "
+          f"log-depths {dk:.1e}")
     assert sb["supp_mapping"] < sa["supp_mapping"]
