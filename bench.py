@@ -554,9 +554,11 @@ def main(argv=None):
             line["reference_start"] = rs
             line["frame_pairs_per_sec"] = world * rs["slot_level_continuous_batching"]["frame_pairs_per_sec"]
             line["frame_pairs_per_sec_what"] = "reference start (sigma 0.05, depth seeds log(2 + 2 rand)), slot-level continuous batching, all ranks at once"
-    if rank == 0 and not args.no_extras and not dry:
+    if rank == 0 and world == 1 and not args.no_extras and not dry:
         # side measurements outside the timed region: (a) one pair alone (launch/latency bound, lives in the
-        # Infinity Cache), (b) full coarse-to-fine schedule -> frame pairs per second
+        # Infinity Cache), (b) full coarse-to-fine schedule -> frame pairs per second.  ONE-GPU LINE ONLY: under torch.distributed.run
+        # (N > 1) the other ranks would sit at the closing barrier for the half minute these take on rank 0; the
+        # N > 1 line carries the whole-job legs above (all ranks at once) and nothing else
         from super_primitive_amd.optim.pair_batch import PairBatch
         from super_primitive_amd.image.keyframe import KeyFrame
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
