@@ -477,8 +477,10 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
     WGN_STAMP(2);
     // ---- assembly: scatter every edge's 16 x 16 node-coordinate block (k_window_gn_reduce), thread (i, j), one edge at a time (edges
     //      share entries: a fixed order keeps the sums reproducible); the loads of a group of edges are issued before its barriers
-    if (n_y > 0 && tid < 256) {
-        const int li = tid >> 4, lj = tid & 15;
+    // (ONE loop with ONE barrier site, executed by every thread -- the scatter is what is guarded, not the barrier)
+    if (n_y > 0) {
+        const bool worker = tid < 256;
+        const int li = (tid >> 4) & 15, lj = tid & 15;
         for (int e0 = 0; e0 < w.n_edges; e0 += 8) {
             double v[8], t[8];
             int gi[8], gj[8];
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
             for (int q = 0; q < 8; ++q) {
                 const int e = e0 + q;
                 gi[q] = gj[q] = -1; v[q] = t[q] = 0.0;
-                if (e >= w.n_edges) continue;
+                if (!worker || e >= w.n_edges) continue;
                 const SpWindowEdge ed = w.edges[e];
                 auto global_index = [&](int l) -> int {
                     const int node = l < 8 ? ed.trg_node : ed.src_node;
@@ -502,16 +504,13 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (e0 + q < w.n_edges) {
+                if (worker && e0 + q < w.n_edges) {
                     if (gi[q] >= 0 && gj[q] >= 0 && gi[q] >= gj[q]) H[ltri(gi[q], gj[q])] += v[q];
                     if (gi[q] >= 0 && lj == 0) g[gi[q]] += t[q];
                 }
                 __syncthreads();
             }
         }
-    } else if (n_y > 0) {
-        for (int e0 = 0; e0 < w.n_edges; e0 += 8)
-            for (int q = 0; q < 8; ++q) __syncthreads();
     }
     WGN_STAMP(3);
     // ---- LM damping of the camera block, then minus the blocks' Schur terms (k_window_gn_schur), block after block ----

@@ -82,10 +82,15 @@ def frame_records(frames, dev):
             rec = np.zeros(1, dtype=_FRAME_DT)
             rec[0] = tuple(t.data_ptr() for t in own[:5]) + tuple(m.shape) + ((own[5].data_ptr(),) if boxes is not None else (0,))
             c = (f.keypoint_regions, f.image, f.logdepth_perseg, f.keypoints, f.K, dev, rec.tobytes(), own, own[0].data_ptr(), boxes)
-            try:
-                f.__dict__['_sp_prep'] = c
-            except AttributeError:
-                pass
+            # (the record is kept only when it points at the keyframe's OWN tensors -- a converted copy (other dtype, device or
+            #  layout) would go stale at the caller's next in-place edit of the original, which no hook sees; such keyframes are converted
+            #  again on every build)
+            originals = (f.keypoint_regions, f.image, f.logdepth_perseg, f.keypoints, f.K)
+            if all(o is t for o, t in zip(own[:5], originals)) and (boxes is None or own[5] is boxes):
+                try:
+                    f.__dict__['_sp_prep'] = c
+                except AttributeError:
+                    pass
         out.append(c)
     recs = np.frombuffer(b''.join([c[6] for c in out]), dtype=_FRAME_DT)
     return recs, [c[7] for c in out]

@@ -269,6 +269,7 @@ class PoseWindow:
                                               _lib.ptr(gn['kld_backup']), 1 if pose_only else 0, float(lm_up), float(lm_down), float(lm_min),
                                               float(conv_tol), _lib.ptr(gn['state']), _lib.ptr(gn['losses']), self.max_iters,
                                               _lib.stream_ptr()), "sp_window_gn_step")
+        gn['host_stale'] = True
 
     def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7):
         """Up to ``max_iters`` LM iterations at ``level`` as ONE phase: stops once an accepted step lowers the loss by less than
@@ -277,6 +278,8 @@ class PoseWindow:
         (evaluations of the cost, rejected ones and the final converged-test evaluation included), from the device's counter."""
         gn = self._gn_state()
         self.begin_gn_phase()
+        if gn.pop('host_stale', False):             # (ADVICE r04: gn_step() moved the device's counter since the host last saw it)
+            gn['state_host'].copy_(gn['state'])
         n0 = int(gn['state_host'][5])
         d = self.desc[level]
         rc = self.lib.sp_window_gn_run(_lib.ptr(d), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, float(irls_eps), _lib.ptr(self.edges),
