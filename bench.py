@@ -136,7 +136,10 @@ def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue
     Q = queue_factor * M
     R = max(1, Q // G)
     jobs = [(args.segments, 5000 + 1000 * rank + s, getattr(args, "shape", "grid"), getattr(args, "coverage", 1.2)) for s in range(G)]
-    if G > 1 and (os.cpu_count() or 1) > 2:
+    import torch.distributed as _dist
+    # (a process pool forks: fine next to the HIP runtime of a one-GPU run -- the children only run numpy -- but not next to the proxy
+    #  threads of an initialised RCCL communicator: under torch.distributed.run the scenes are rendered one after the other)
+    if G > 1 and (os.cpu_count() or 1) > 2 and not (_dist.is_available() and _dist.is_initialized()):
         with Pool(min(G, 16)) as pool:
             scenes = pool.map(_render_sigma05, jobs)
     else:

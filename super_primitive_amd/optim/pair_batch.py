@@ -72,17 +72,19 @@ REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 # Which pose-only phase goes first is a matter of speed: epsilon 1e-2 with a cap of 15 in the first attempt and epsilon 1e-3 with a cap of
 # 30 in the second (below) loses 9 of 9216 starts at the first attempt and none after the second, at 33.6 k pairs/s and 32.9 iterations per
 # pair; the other way round (round 4's first attempt) 14 / none at 31.2 k and 36.7 (profiles/r05_reference_start.txt).
-# ``coarse_damped`` = (16, 12): between the pose-only phase and the joint phases, 12 iterations at the coarsest level with the log-depth
-# block DAMPED by 16 (include/sp_hip.h SP_PHASE_DEPTH_DAMP: the depths follow at 1/17 of their Gauss-Newton step -- the reference's Adam
+# ``coarse_damped`` = (31, 12): between the pose-only phase and the joint phases, 12 iterations at the coarsest level with the log-depth
+# block DAMPED by 31 (include/sp_hip.h SP_PHASE_DEPTH_DAMP: the depths follow at 1/32 of their Gauss-Newton step -- the reference's Adam
 # moves them at a tenth of the pose's rate).  On the grid tiling the undamped schedule is enough (8 second attempts per 4608 starts, all
 # rescued); on SAM-like ragged masks over near-planar scenes (bench.py --shape blobs: depth range e^0.2) it walks into the second solution
 # of the plane's homography from 6 % of the reference's starts and the second attempt brings home only half of those -- 88 of 3072 flagged,
-# where the real reference converges (goldens g20y).  With the damped phase: 4 second attempts and ONE flagged pair of 3072, at a HIGHER
-# rate there (24.9 k against 21.8 k pairs/s: no time lost in failing attempts) and 30.0 k against 32.7 k on the grid, no second attempt
-# among 4608 starts (tools/verdict_sweep.py; damping 4 / 8 / 16, caps 8 / 12 / 16 / 25, with and without the undamped phase at the same
-# level: profiles/r05_reference_start.txt).
+# where the real reference converges (goldens g20y).  With the damped phase: 10 second attempts and TWO flagged pairs of 12288 (damping 16:
+# 13 and 3; one of g20y's pairs fails with 16 as a batch of one and passes in a large batch -- the outcome of a start near the basin
+# boundary turns with the summation order; with 31 it passes either way), at a HIGHER rate there (24.4 k against 21.8 k pairs/s: no time
+# lost in failing attempts) and 30.0 k against 32.7 k on the grid, no second attempt among 4608 starts (tools/verdict_sweep.py; damping
+# 4 / 8 / 16 / 31, caps 8 / 12 / 16 / 25, with and without the undamped phase at the same level, damped second attempts:
+# profiles/r05_reference_start*.txt).
 REFERENCE_START_RETRY = (dict(level=2, stride=4, max_iters=30, irls_eps=1e-3, conv_tol=2e-3, pose_only=True),)
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(16.0, 12), retry_phases=REFERENCE_START_RETRY)
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(31.0, 12), retry_phases=REFERENCE_START_RETRY)
 # The verdict's thresholds (SpVerdict): a log-depth more than ``kld_bound`` from its seed (a factor e^kld_bound in depth: the reference's
 # seeds log(2 + 2 rand) are at most a factor 2 off) has run away; fewer than ``valid_min`` of the points projecting into the target
 # frame at the end of an alignment that started with both frames overlapping is a lost pair.  ``retry_on``: the status bits that send

@@ -867,6 +867,13 @@ def test_scheduled_run_reports_a_verdict_and_retries_what_fails_it():
                                      _lib.ptr(dd.phase), _lib.ptr(dd.phase_iters), 2, 4, _lib.ptr(flag[0]), flag[1].data_ptr(), ctypes.addressof(v), _lib.stream_ptr())
     torch.cuda.synchronize()
     assert n == 4 and all(s == _lib.SP_STATUS_UNFINISHED for s in npy(dd.status))
+    # (e) a non-finite unknown (the one thing the reference asserts on, core/dense_optim.py:311,321,340-343) is reported for THAT pair only
+    ee = make_batch(prs, **kw)
+    ee.kld[ee.n_off[2] + 1] = float("nan")
+    ee.run_scheduled(**sch)
+    se = npy(ee.status)
+    assert (se[2] & _lib.SP_STATUS_NONFINITE) != 0 and se[0] == 0 and npy(ee.failed()).tolist() == [False, True, True]
+    assert torch.equal(ee.poses()[0], a.poses()[0]) and torch.equal(ee.klds()[0], a.klds()[0])          # (pairs never interact)
 
 
 def _mask_boxes(masks):

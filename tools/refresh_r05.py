@@ -14,7 +14,8 @@ pairs = [("r05/bench_n1.json", "bench_n1.json"), ("r05/bench_under_rocprof.json"
          # the sweeps the round's decisions were made on (earlier calls of the round)
          ("r05a/verdict_sweep.txt", "reference_start_sweep_1_second_attempts.txt"), ("r05b/verdict_sweep_blobs.txt", "reference_start_sweep_2_ragged_undamped.txt"),
          ("r05e/verdict_sweep.txt", "reference_start_sweep_3_damping_grid.txt"), ("r05e/verdict_sweep_blobs.txt", "reference_start_sweep_3_damping_ragged.txt"),
-         ("r05e/verdict_sweep_768.txt", "reference_start_sweep_3_damping_768_slots.txt"), ("r05d/ab_onercp.txt", "kernel_experiments_one_rcp_ab.txt")]
+         ("r05e/verdict_sweep_768.txt", "reference_start_sweep_3_damping_768_slots.txt"), ("r05d/ab_onercp.txt", "kernel_experiments_one_rcp_ab.txt"), ("r05k/ab_occupancy.txt", "kernel_experiments_occupancy_ab.txt"),
+         ("r05k/alone_probe.txt", "reference_start_g20y_pairs_alone.txt")]
 for a, b in pairs:
     src = os.path.join(G, a)
     if os.path.exists(src):

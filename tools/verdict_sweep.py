@@ -44,14 +44,13 @@ VARIANTS = {
     "shipped": dict(BASE),
     "no_retry": dict(BASE, retry_phases=None),
     "undamped": dict(BASE, phases=None, depth_damp=None, coarse_damped=None),
-    "d8c12": dict(BASE, phases=damped(8.0, 12)),
-    "d8c8": dict(BASE, phases=damped(8.0, 8)),
-    "d8c16": dict(BASE, phases=damped(8.0, 16)),
-    "d16c12": dict(BASE, phases=damped(16.0, 12)),
-    "d4c12": dict(BASE, phases=damped(4.0, 12)),
-    "d8c25_tol1e-2": dict(BASE, phases=damped(8.0, 25, tol=1e-2)),
-    "d8c12_direct_L1": dict(BASE, phases=damped(8.0, 12, second_L2=False)),
-    "d8c12_eps1e-2": dict(BASE, phases=damped(8.0, 12, eps=1e-2)),
+    "d16c12": dict(BASE, coarse_damped=(16.0, 12)),
+    "d16c16": dict(BASE, coarse_damped=(16.0, 16)),
+    "d31c12": dict(BASE, coarse_damped=(31.0, 12)),
+    "d31c16": dict(BASE, coarse_damped=(31.0, 16)),
+    "d16c12_retry_d31c16": dict(BASE, coarse_damped=(16.0, 12), retry_phases=[po(2, 4, 30), jt(2, 4, 31.0, 16)], retry_join=2),
+    "d16c12_retry_d8c16": dict(BASE, coarse_damped=(16.0, 12), retry_phases=[po(2, 4, 30), jt(2, 4, 8.0, 16)], retry_join=2),
+    "d16c16_retry_d31c16": dict(BASE, coarse_damped=(16.0, 16), retry_phases=[po(2, 4, 30), jt(2, 4, 31.0, 16)], retry_join=2),
 }
 
 
