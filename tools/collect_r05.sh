@@ -26,7 +26,7 @@ done
 # the verdict over many reference starts: grid on 384 and 768 slots, ragged masks
 (echo "### grid tiling, 9216 starts, 384 slots"; timeout 600 python tools/verdict_sweep.py --variants shipped,no_retry,undamped 2>&1 | grep -v "^make\|amdgpu.ids\|^batch\|^rendered" | cut -c1-700
  echo "### grid tiling, 9216 starts, 768 slots"; timeout 600 python tools/verdict_sweep.py --slots 768 --alone "" --variants shipped,undamped 2>&1 | grep -v "^make\|amdgpu.ids\|^batch\|^rendered" | cut -c1-700
- echo "### ragged masks (64 overlapping ellipses, rho 1.2), 3072 starts, 384 slots"; timeout 600 python tools/verdict_sweep.py --shape blobs --starts 3072 --alone "" --variants shipped,no_retry,undamped 2>&1 | grep -v "^make\|amdgpu.ids\|^batch\|^rendered" | cut -c1-700) > $OUT/reference_start.txt
+ echo "### ragged masks (64 overlapping ellipses, rho 1.2), 12288 starts, 384 slots"; timeout 900 python tools/verdict_sweep.py --shape blobs --starts 12288 --alone "" --variants shipped,no_retry,undamped 2>&1 | grep -v "^make\|amdgpu.ids\|^batch\|^rendered" | cut -c1-700) > $OUT/reference_start.txt
 timeout 400 python tools/run_configs.py 2>/dev/null | grep config > $OUT/configs.txt
 timeout 300 python tools/window_bench.py 1 2 3 4 2>&1 | grep -v "^make\|amdgpu.ids" > $OUT/window_bench.txt
 timeout 300 python tools/stream_bench.py 384 3 2>&1 | grep batches > $OUT/stream_bench.txt
