@@ -529,7 +529,9 @@ def main(argv=None):
         line["rccl_world"] = rccl_world
     if dry:
         line["data"] = "DRY RUN (no measurement)"
-    if world > 1 and args.mode == "gn" and not args.no_extras:
+    # (SP_BENCH_REHEARSE_MULTI=1 under torch.distributed.run with ONE rank: the N > 1 legs below on the one GPU there is -- tests/test_gpu_rccl.py)
+    multi = world > 1 or (dist is not None and os.environ.get("SP_BENCH_REHEARSE_MULTI") == "1")
+    if multi and args.mode == "gn" and not args.no_extras:
         # whole-job frame pairs per second: every rank runs the quoted schedule on its own pairs at the same time (barrier, max
         # over ranks), from the initial values; one untimed pass first.  (On one GPU this is leg (c) of the extras below.)
         from super_primitive_amd.optim.pair_batch import FRAME_PAIR_SCHEDULE
@@ -553,11 +555,12 @@ def main(argv=None):
                 tx = torch.tensor([x], dtype=torch.float64, device=dev)
                 dist.all_reduce(tx, op=dist.ReduceOp.MAX)
                 return float(tx.item())
-            rs = reference_start_leg(args, rank, dev, M, barrier=barrier, reduce_max=reduce_max)
-            line["reference_start"] = rs
-            line["frame_pairs_per_sec"] = world * rs["slot_level_continuous_batching"]["frame_pairs_per_sec"]
+            rs = reference_start_leg(args, rank, dev, M, barrier=barrier, reduce_max=reduce_max, slot_only=True)      # (the slot forms only: bounded time per rank)
+            line["reference_start"] = {"slot_level_continuous_batching": rs}
+            line["frame_pairs_status"] = dict(rs["verdict"], pairs=rs["pairs"], of="rank 0's pairs")
+            line["frame_pairs_per_sec"] = world * rs["frame_pairs_per_sec"]
             line["frame_pairs_per_sec_what"] = "reference start (sigma 0.05, depth seeds log(2 + 2 rand)), slot-level continuous batching, all ranks at once"
-    if rank == 0 and world == 1 and not args.no_extras and not dry:
+    if rank == 0 and not multi and not args.no_extras and not dry:
         # side measurements outside the timed region: (a) one pair alone (launch/latency bound, lives in the
         # Infinity Cache), (b) full coarse-to-fine schedule -> frame pairs per second.  ONE-GPU LINE ONLY: under torch.distributed.run
         # (N > 1) the other ranks would sit at the closing barrier for the half minute these take on rank 0; the

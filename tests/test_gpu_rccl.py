@@ -21,8 +21,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _torchrun(script_args, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+def _torchrun(script_args, timeout=600, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
@@ -49,3 +49,18 @@ def test_package_collectives_run_under_the_nccl_backend():
     assert rec["backend"] == "nccl" and rec["world"] == 1 and rec["all_reduce_of_ones"] == 1.0
     assert rec["gather_results_ok"] and rec["complete_depth_sharded_equals_single_process"]
     assert rec["gathered_shapes"] == [[6, 4, 4], [6, 7]]
+
+
+def test_the_legs_of_an_n_gpu_bench_line_run_on_the_one_gpu_there_is():
+    """what ``bench.py --gpus N`` does AFTER its timed steps when N > 1 -- the near-start schedule and the
+    reference-start leg with slot-level continuous batching on every rank at once, timed between barriers with a MAX all_reduce over the
+    group -- rehearsed under torch.distributed.run with the one rank there is (``SP_BENCH_REHEARSE_MULTI=1``): hooks, collectives and the
+    verdict counts of the line have executed on hardware before an 8-GPU node sees them; the one-GPU side measurements are skipped."""
+    line = _torchrun(["bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--pairs", "32", "--settle-ms", "20", "--sigma05-scenes", "2",
+                      "--no-cpu-baseline", "--no-pmc"], SP_BENCH_REHEARSE_MULTI="1")
+    print("\nN > 1 legs, 1 rank:", {k: line.get(k) for k in ("frame_pairs_per_sec", "frame_pairs_per_sec_near_start", "frame_pairs_status")})
+    assert line["rccl_world"] == 1 and line["frame_pairs_per_sec"] > 0 and line["frame_pairs_per_sec_near_start"] > 0
+    st = line["frame_pairs_status"]
+    assert st["pairs"] == 128 and st["silent_failures"] == 0 and st["converged_first_attempt"] + st["converged_second_attempt"] + st["flagged_failed"] == 128
+    assert "single_pair_gn_iters_per_sec" not in line and "from_raw_frames" not in line          # (the one-GPU side measurements)
+    assert "slot_level_continuous_batching" in line["reference_start"]
