@@ -72,19 +72,27 @@ REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 # Which pose-only phase goes first is a matter of speed: epsilon 1e-2 with a cap of 15 in the first attempt and epsilon 1e-3 with a cap of
 # 30 in the second (below) loses 9 of 9216 starts at the first attempt and none after the second, at 33.6 k pairs/s and 32.9 iterations per
 # pair; the other way round (round 4's first attempt) 14 / none at 31.2 k and 36.7 (profiles/r05_reference_start.txt).
-# ``coarse_damped`` = (31, 12): between the pose-only phase and the joint phases, 12 iterations at the coarsest level with the log-depth
-# block DAMPED by 31 (include/sp_hip.h SP_PHASE_DEPTH_DAMP: the depths follow at 1/32 of their Gauss-Newton step -- the reference's Adam
-# moves them at a tenth of the pose's rate).  On the grid tiling the undamped schedule is enough (8 second attempts per 4608 starts, all
+# ``coarse_damped`` = (16, 12): between the pose-only phase and the joint phases, 12 iterations at the coarsest level with the log-depth
+# block DAMPED by 16 (include/sp_hip.h SP_PHASE_DEPTH_DAMP: the depths follow at 1/17 of their Gauss-Newton step -- the reference's Adam
+# moves them at a tenth of the pose's rate).  On the grid tiling the undamped schedule is enough (9 second attempts per 9216 starts, all
 # rescued); on SAM-like ragged masks over near-planar scenes (bench.py --shape blobs: depth range e^0.2) it walks into the second solution
-# of the plane's homography from 6 % of the reference's starts and the second attempt brings home only half of those -- 88 of 3072 flagged,
-# where the real reference converges (goldens g20y).  With the damped phase: 10 second attempts and TWO flagged pairs of 12288 (damping 16:
-# 13 and 3; one of g20y's pairs fails with 16 as a batch of one and passes in a large batch -- the outcome of a start near the basin
-# boundary turns with the summation order; with 31 it passes either way), at a HIGHER rate there (24.4 k against 21.8 k pairs/s: no time
-# lost in failing attempts) and 30.0 k against 32.7 k on the grid, no second attempt among 4608 starts (tools/verdict_sweep.py; damping
-# 4 / 8 / 16 / 31, caps 8 / 12 / 16 / 25, with and without the undamped phase at the same level, damped second attempts:
-# profiles/r05_reference_start*.txt).
+# of the plane's homography from 6 % of the reference's starts and the second attempt brings home only half of those -- 375 of 12288
+# flagged, where the real reference converges (goldens g20y).  With the damped phase: 13 second attempts and THREE flagged pairs of 12288,
+# at a HIGHER rate there (24.4 k against 21.4 k pairs/s: no time lost in failing attempts) and 30 k against 32.7 k on the grid, no second
+# attempt among 9216 starts.  The strength is a compromise over workloads (flagged after the second attempt; tools/verdict_sweep.py,
+# profiles/r05_reference_start_sweep_5_*.txt):
+#     damping     64 ragged segments (of 12288)   300 ragged (of 3072)   1200 ragged (of 1536)   128 grid segments (of 3072)
+#        8                 ~24                            9                     31                       0
+#       12                   6                            7                     23                       0
+#       16                   3                            7                     35                       0
+#       20                   4                           17                     71                       0
+#       24                   4                           34                     97                       0
+#       31                   2                           82                    129                       0
+# (many small segments have few points each on the coarse lattice: depths held still for 12 iterations there let the pose settle on a
+# biased optimum.)  Outcomes of starts near the basin boundary turn with the summation order: golden g20y's pair 90 converges with 16 in
+# the span partition of a large batch and fails -- flagged -- as a batch of one (64-point spans); tests/test_gpu_sigma05.py runs both.
 REFERENCE_START_RETRY = (dict(level=2, stride=4, max_iters=30, irls_eps=1e-3, conv_tol=2e-3, pose_only=True),)
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(31.0, 12), retry_phases=REFERENCE_START_RETRY)
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(16.0, 12), retry_phases=REFERENCE_START_RETRY)
 # The verdict's thresholds (SpVerdict): a log-depth more than ``kld_bound`` from its seed (a factor e^kld_bound in depth: the reference's
 # seeds log(2 + 2 rand) are at most a factor 2 off) has run away; fewer than ``valid_min`` of the points projecting into the target
 # frame at the end of an alignment that started with both frames overlapping is a lost pair.  ``retry_on``: the status bits that send

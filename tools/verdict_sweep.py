@@ -44,6 +44,10 @@ VARIANTS = {
     "shipped": dict(BASE),
     "no_retry": dict(BASE, retry_phases=None),
     "undamped": dict(BASE, phases=None, depth_damp=None, coarse_damped=None),
+    "d8c12": dict(BASE, coarse_damped=(8.0, 12)),
+    "d12c12": dict(BASE, coarse_damped=(12.0, 12)),
+    "d20c12": dict(BASE, coarse_damped=(20.0, 12)),
+    "d24c12": dict(BASE, coarse_damped=(24.0, 12)),
     "d16c12": dict(BASE, coarse_damped=(16.0, 12)),
     "d16c16": dict(BASE, coarse_damped=(16.0, 16)),
     "d31c12": dict(BASE, coarse_damped=(31.0, 12)),
@@ -56,7 +60,7 @@ VARIANTS = {
 
 def _render(a):
     shape_kw = dict(overlap=4) if a[1] == "grid" else dict(shape="blobs", blob_coverage=1.2)
-    return synth.make_pair(H, W, N, seed=a[0], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
+    return synth.make_pair(H, W, a[2], seed=a[0], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
 
 
 def errors(P, K, poses_gt, klds_gt):
@@ -79,12 +83,13 @@ def main(argv=None):
     ap.add_argument("--variants", default="shipped,no_retry")
     ap.add_argument("--shape", default="grid", choices=["grid", "blobs"])
     ap.add_argument("--npz", default=None)
+    ap.add_argument("--segments", type=int, default=N, help="segments per keyframe (bench.py --segments)")
     ap.add_argument("--alone", default="105,1380,1482", help="pairs also run as batches of ONE (order independence of the verdict and the retry)")
     args = ap.parse_args(argv)
     dev = torch.device("cuda:0")
     t0 = time.time()
     with Pool(min(G, 8)) as pool:
-        scenes = pool.map(_render, [(5000 + s, args.shape) for s in range(G)])
+        scenes = pool.map(_render, [(5000 + s, args.shape, args.segments) for s in range(G)])
     print(f"rendered {G} scenes ({args.shape}) in {time.time() - t0:.1f} s", flush=True)
     rng = np.random.default_rng(77)
     n_batches = -(-args.starts // args.batch)
