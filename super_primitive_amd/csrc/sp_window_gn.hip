@@ -415,14 +415,20 @@ __device__ void wgn_compose_edge(const WGnArgs& w, int e) {
 #define SP_WGN_THREADS 1024     // threads of the update kernel: 4 waves per SIMD -- its phases are chains of LDS / global latencies, not throughput
 #define SP_WGN_GRID 32          // ... as a SP_WGN_GRID x SP_WGN_GRID grid over the trailing block of the factorisation
 #define WGN_STAMP(i) do { if (tid == 0) w.prof[i] = (double)wall_clock64(); } while (0)      // 100 MHz constant clock; phase boundaries of the last step
+// threads of the update kernel: 1024 (4 waves per SIMD -- its phases are chains of LDS / global latencies, not throughput) except the
+// 128-unknown instantiation, whose factorisation keeps 36 doubles of the matrix per thread in registers: 512 threads = 256 VGPRs each
+__host__ __device__ constexpr int wgn_update_threads(int lds_y) { return lds_y == 128 ? 512 : lds_y == 192 ? 256 : SP_WGN_THREADS; }
 template <int LDS_Y>
-__global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) {
+__global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(WGnArgs w) {
     constexpr int CAP = LDS_Y > 0 ? LDS_Y : SP_WGN_MAX_Y;
+    constexpr int NTHR = wgn_update_threads(LDS_Y);
     __shared__ double Hs[LDS_Y > 0 ? LDS_Y * (LDS_Y + 1) / 2 : 1];
     __shared__ double g[CAP], dy[CAP], dinvs[CAP];
+    constexpr int PANELS = LDS_Y == 0 ? 0 : (LDS_Y > 128 ? 1 : 2);      // column panels of the factorisation (two: written while the other is read)
+    __shared__ __align__(16) double panel[PANELS > 0 ? PANELS : 1][LDS_Y > 0 ? LDS_Y : 1][4];      // [row][column of the panel]
     __shared__ int pose_off[SP_WGN_MAX_NODES], aff_off[SP_WGN_MAX_NODES];
     __shared__ int blk_off[SP_WGN_MAX_NODES + 1];
-    __shared__ int n_y_s, decision;
+    __shared__ int n_y_s, decision, fail_s;
     __shared__ double lam_s;
     double* H;
     if constexpr (LDS_Y > 0) H = Hs; else H = w.Hg;
@@ -432,6 +438,7 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
     if (tid == 0) {
         const int ny = wgn_number_unknowns(w, pose_off, aff_off);
         n_y_s = ny;
+        fail_s = 0;
         int off = 0;
         for (int b = 0; b < w.n_blocks; ++b) { blk_off[b] = off; off += w.blocks[b].N; }
         blk_off[w.n_blocks] = off;
@@ -457,22 +464,22 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
     if (decision == 2) return;
     if (decision == 1) {
         // undo the previous step: nodes (pose, tangent, affine) and log-depths back to the stored point
-        for (int i = tid; i < w.n_nodes * 44; i += SP_WGN_THREADS) reinterpret_cast<uint32_t*>(w.nodes)[i] = reinterpret_cast<const uint32_t*>(w.nodes_backup)[i];
+        for (int i = tid; i < w.n_nodes * 44; i += NTHR) reinterpret_cast<uint32_t*>(w.nodes)[i] = reinterpret_cast<const uint32_t*>(w.nodes_backup)[i];
         for (int b = 0; b < w.n_blocks; ++b)
-            for (int n = tid; n < w.blocks[b].N; n += SP_WGN_THREADS) w.blocks[b].kld[n] = w.kld_backup[blk_off[b] + n];
+            for (int n = tid; n < w.blocks[b].N; n += NTHR) w.blocks[b].kld[n] = w.kld_backup[blk_off[b] + n];
         __threadfence_block();
         __syncthreads();
-        for (int e = tid; e < w.n_edges; e += SP_WGN_THREADS) wgn_compose_edge(w, e);
+        for (int e = tid; e < w.n_edges; e += NTHR) wgn_compose_edge(w, e);
         return;
     }
     const double lam = lam_s;
     // ---- back up the point we are about to leave; clear the system ------------------------------------------------
-    for (int i = tid; i < w.n_nodes * 44; i += SP_WGN_THREADS) reinterpret_cast<uint32_t*>(w.nodes_backup)[i] = reinterpret_cast<const uint32_t*>(w.nodes)[i];
+    for (int i = tid; i < w.n_nodes * 44; i += NTHR) reinterpret_cast<uint32_t*>(w.nodes_backup)[i] = reinterpret_cast<const uint32_t*>(w.nodes)[i];
     for (int b = 0; b < w.n_blocks; ++b)
-        for (int n = tid; n < w.blocks[b].N; n += SP_WGN_THREADS) w.kld_backup[blk_off[b] + n] = w.blocks[b].kld[n];
+        for (int n = tid; n < w.blocks[b].N; n += NTHR) w.kld_backup[blk_off[b] + n] = w.blocks[b].kld[n];
     const int n_tri = (n_y * (n_y + 1)) >> 1;
-    for (int i = tid; i < n_tri; i += SP_WGN_THREADS) H[i] = 0.0;
-    for (int i = tid; i < n_y; i += SP_WGN_THREADS) g[i] = 0.0;
+    for (int i = tid; i < n_tri; i += NTHR) H[i] = 0.0;
+    for (int i = tid; i < n_y; i += NTHR) g[i] = 0.0;
     __syncthreads();
     WGN_STAMP(2);
     // ---- assembly: scatter every edge's 16 x 16 node-coordinate block (k_window_gn_reduce), thread (i, j), one edge at a time (edges
@@ -514,29 +521,159 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
     }
     WGN_STAMP(3);
     // ---- LM damping of the camera block, then minus the blocks' Schur terms (k_window_gn_schur), block after block ----
-    for (int i = tid; i < n_y; i += SP_WGN_THREADS) { H[ltri(i, i)] = H[ltri(i, i)] * (1.0 + lam) + 1e-12; g[i] = -g[i]; }
+    for (int i = tid; i < n_y; i += NTHR) { H[ltri(i, i)] = H[ltri(i, i)] * (1.0 + lam) + 1e-12; g[i] = -g[i]; }
     __syncthreads();
     for (int b = 0; b < w.n_blocks; ++b) {
         const int nc = w.nc[b];
         const int* cb = w.cols + (size_t)b * ldc;
         const double* Sb = w.S + (size_t)b * w.lds;
         const int np = (nc * (nc + 1)) >> 1;
-        for (int p = tid; p < np; p += SP_WGN_THREADS) {
+        for (int p = tid; p < np; p += NTHR) {
             const int i = ltri_row(p), j = p - ((i * (i + 1)) >> 1);
             H[ltri(cb[i], cb[j])] -= Sb[p];                            // cols ascending: cb[i] >= cb[j]
         }
-        for (int i = tid; i < nc; i += SP_WGN_THREADS) g[cb[i]] += w.Rhs[(size_t)b * ldc + i];
+        for (int i = tid; i < nc; i += NTHR) g[cb[i]] += w.Rhs[(size_t)b * ldc + i];
         __syncthreads();
     }
-    for (int i = tid; i < n_y; i += SP_WGN_THREADS) dy[i] = g[i];      // right-hand side of S dy = -(g - C^T D^-1 b_d)
+    for (int i = tid; i < n_y; i += NTHR) dy[i] = g[i];      // right-hand side of S dy = -(g - C^T D^-1 b_d)
     __syncthreads();
     WGN_STAMP(4);
-    // ---- S = L D L^T in place, right-looking by blocks of 4 columns.  Column j keeps the UNSCALED entries c_ij = l_ij d_j.  Per block:
-    //      (1) every thread factors the 4 x 4 diagonal block in registers (10 broadcast LDS reads) -- so the positive-definiteness test
-    //      is uniform without a barrier -- and eliminates inside ITS row of the panel (rows are independent given the diagonal block);
-    //      (2) rank-4 update of the trailing triangle, thread (ti, tj) of a 32 x 32 grid over rows = ti, columns = tj (mod 32): 4 + 1 LDS
-    //      accesses per 4 multiply-adds.  Two barriers per 4 columns.
+    // ---- S = L D L^T, right-looking by blocks of 4 columns; column j keeps the UNSCALED entries c_ij = l_ij d_j.
+    //      LDS-resident systems (LDS_Y > 0): the trailing matrix lives in REGISTERS -- thread (ti, tj) of a G x G grid owns the entries
+    //      (G a + ti, G b + tj), a >= b, of the symmetric matrix (block-cyclic: every thread stays busy until the last columns; 36
+    //      doubles at 128 unknowns) -- and only the 4-column panel of a step travels through LDS:
+    //        (a) the four thread columns that own the panel write it (all rows);                                         barrier
+    //        (b) every thread factors the 4 x 4 diagonal block in registers (10 broadcast reads: the positive-definiteness test is
+    //            uniform); thread i eliminates inside ITS row of the panel, leaves the final c_i. in the panel and in H (the
+    //            substitutions read L there) and takes the row's right-hand side along: y_i -= sum_q l_iq y~_q, i.e. the forward
+    //            substitution L y = rhs is done when the factorisation is;                                                barrier
+    //        (c) rank-4 update of the register tiles: per panel column T + T LDS reads (rows broadcast, columns consecutive) for
+    //            T (T + 1) / 2 multiply-adds, no load / store of the matrix.
+    //      The global-scratch instantiation (LDS_Y = 0, > 192 unknowns) keeps the in-place form: (1) every thread factors the diagonal
+    //      block and eliminates inside its row of the panel, (2) rank-4 update of the trailing triangle, thread (ti, tj) of a 32 x 32 grid
+    //      over rows = ti, columns = tj (mod 32): 4 + 1 accesses per 4 multiply-adds.  Two barriers per 4 columns.
     bool fail = false;
+    if constexpr (LDS_Y > 0) {
+        constexpr int G = 16, T = CAP / G;
+        static_assert(G * G <= NTHR && NTHR >= CAP && CAP % G == 0 && G % 4 == 0, "tile grid of the register-resident factorisation");
+        const int ti = tid / G, tj = tid % G;
+        const bool owner = tid < G * G;
+        double R[T][T];                       // (a, b), b <= a only
+        double rhs_keep = 0.0;
+        if (owner) {
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) {
+                    const int i = G * a + ti, j = G * b + tj;      // a diagonal tile holds both triangles (the update is symmetric)
+                    R[a][b] = (i < n_y && j < n_y) ? H[ltri(max(i, j), min(i, j))] : (i == j ? 1.0 : 0.0);     // identity beyond n_y
+                }
+        }
+        int buf = 0;
+        auto row4 = [](const double (*P)[4], int i, double (&v)[4]) {          // one panel row: two 16-byte LDS reads
+            const double2 lo = *reinterpret_cast<const double2*>(&P[i][0]), hi = *reinterpret_cast<const double2*>(&P[i][2]);
+            v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+        };
+#pragma unroll
+        for (int b0 = 0; b0 < T; ++b0) {      // tile column of the panel: STATIC, so that the tiles a step touches are known at compile time
+        for (int k = G * b0; k < min(G * (b0 + 1), n_y); k += 4) {
+            double (*P)[4] = panel[buf];
+            const int c0 = k - G * b0;
+            const bool detail = tid == 0 && k == 4;           // phase stamps of the second block step (diagnostics)
+            if (detail) w.prof[10] = (double)wall_clock64();
+            if (owner && (unsigned)(tj - c0) < 4u) {
+                const int q = tj - c0;
+#pragma unroll
+                for (int a = b0; a < T; ++a) P[G * a + ti][q] = R[a][b0];      // (tile rows above the panel's are finished and never read)
+            }
+            __syncthreads();
+            if (detail) w.prof[11] = (double)wall_clock64();
+            double dinv[4];
+            if (owner) {
+                double c[4][4], yt[4], r[4];
+                const int i = tid;
+                const bool below = i >= k + 4 && i < n_y;             // a row of the panel under the diagonal block
+#pragma unroll
+                for (int a = 0; a < 4; ++a) row4(P, k + a, c[a]);      // (the upper triangle comes along, unused)
+                row4(P, i < CAP ? i : 0, r);                           // (issued with the block's loads: the row's latency hides behind the block's chain)
+                double yi = i < CAP ? dy[i] : 0.0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) yt[a] = k + a < n_y ? dy[k + a] : 0.0;
+                bool bad = false;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                    for (int q = 0; q < a; ++q) {
+                        const double l = c[a][q] * dinv[q];
+#pragma unroll
+                        for (int q2 = q + 1; q2 <= a; ++q2) c[a][q2] -= l * c[q2][q];
+                        yt[a] -= l * yt[q];
+                    }
+                    if (!(c[a][a] > 0.0)) bad = true;                 // (columns beyond n_y: the identity)
+                    // 1 / d by v_rcp_f64 and two Newton steps: a third of the IEEE division's dependent chain, which every block step waits for
+                    const double d = c[a][a];
+                    double y = __builtin_amdgcn_rcp(d);
+                    y = fma(fma(-d, y, 1.0), y, y);
+                    dinv[a] = fma(fma(-d, y, 1.0), y, y);
+                }
+                if (detail) w.prof[12] = (double)wall_clock64();
+                if (bad) { if (tid == 0) fail_s = 1; }
+                else if (below) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const double l = r[q] * dinv[q];
+#pragma unroll
+                        for (int q2 = q + 1; q2 < 4; ++q2) r[q2] -= l * c[q2][q];
+                        yi -= l * yt[q];
+                    }
+                    *reinterpret_cast<double2*>(&P[i][0]) = double2{r[0], r[1]};
+                    *reinterpret_cast<double2*>(&P[i][2]) = double2{r[2], r[3]};
+                    const int rowi = ltri(i, k);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (k + q < n_y) H[rowi + q] = r[q];
+                    dy[i] = yi;
+                } else if (i >= k && i < n_y) {                       // a row of the diagonal block: its final entries
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        if (i == k + a) {
+#pragma unroll
+                            for (int q = 0; q <= a; ++q) H[ltri(i, k + q)] = c[a][q];
+                            dinvs[i] = dinv[a];
+                            rhs_keep = yt[a];
+                        }
+                }
+            }
+            if (detail) w.prof[13] = (double)wall_clock64();
+            __syncthreads();
+            if (detail) w.prof[14] = (double)wall_clock64();
+            if (fail_s) { fail = true; break; }
+            if (tid >= k && tid < k + 4 && tid < n_y) dy[tid] = rhs_keep;       // (after the barrier: every thread has read the block's right-hand side)
+            if (owner) {
+                // entries (i, j) with i or j up to the diagonal block's rows are final -- never read from the registers again -- so nothing
+                // is masked: tile rows / columns before the panel's are skipped (statically), the panel's own are updated whole.
+                // Straight-line code: the loads of all tile rows are in flight before the first multiply-add
+                double cv[T][4];
+#pragma unroll
+                for (int a = b0; a < T; ++a) row4(P, G * a + tj, cv[a]);
+#pragma unroll
+                for (int a = b0; a < T; ++a) {
+                    double rv[4];
+                    row4(P, G * a + ti, rv);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rv[q] *= dinv[q];
+#pragma unroll
+                    for (int b = b0; b <= a; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) R[a][b] -= rv[q] * cv[b][q];
+                }
+            }
+            if (detail) w.prof[15] = (double)wall_clock64();
+            if constexpr (PANELS == 2) buf ^= 1; else __syncthreads();
+        }
+        if (fail) break;
+        }
+        __syncthreads();                      // (the last block's right-hand side entries, before the substitution reads them)
+    } else {
     {
         const int ti = tid / SP_WGN_GRID, tj = tid % SP_WGN_GRID;
         for (int k = 0; k < n_y && !fail; k += 4) {
@@ -558,7 +695,7 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
             }
             if (fail) break;
             if (tid < B) dinvs[k + tid] = tid == 0 ? dinv[0] : tid == 1 ? dinv[1] : tid == 2 ? dinv[2] : dinv[3];
-            for (int i = k + B + tid; i < n_y; i += SP_WGN_THREADS) {
+            for (int i = k + B + tid; i < n_y; i += NTHR) {
                 double r[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) r[q] = q < B ? H[ltri(i, k + q)] : 0.0;
@@ -608,6 +745,7 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
             __syncthreads();
         }
     }
+    }
     WGN_STAMP(5);
     if (!fail) {
         // L y = rhs, z = D^-1 y, L^T x = z by ONE wave, wave-synchronously: lane l holds entries l, l + 64, ... of the vector in registers,
@@ -626,43 +764,57 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
             for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; x[q] = i < n_y ? dy[i] : 0.0; }
             // (the matrix entries and 1 / d_k of step k + 1 are loaded while step k's pivot travels: the loop-carried chain is
             //  readlane -> multiply -> fma only)
-            double hn[PER], dn = n_y > 0 ? dinvs[0] : 0.0;
+            double hn[PER];
+            if constexpr (LDS_Y == 0) {        // (LDS-resident systems: the factorisation took the right-hand side along)
+                double dn = n_y > 0 ? dinvs[0] : 0.0;
 #pragma unroll
-            for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = (i > 0 && i < n_y) ? H[ltri(i, 0)] : 0.0; }
-            for (int k = 0; k < n_y; ++k) {                  // forward: y_i -= (c_ik / d_k) y_k for i > k
-                double hc[PER];
-                const double dc = dn;
+                for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = (i > 0 && i < n_y) ? H[ltri(i, 0)] : 0.0; }
+                for (int k = 0; k < n_y; ++k) {                  // forward: y_i -= (c_ik / d_k) y_k for i > k
+                    double hc[PER];
+                    const double dc = dn;
 #pragma unroll
-                for (int q = 0; q < PER; ++q) hc[q] = hn[q];
-                if (k + 1 < n_y) {
-                    dn = dinvs[k + 1];
+                    for (int q = 0; q < PER; ++q) hc[q] = hn[q];
+                    if (k + 1 < n_y) {
+                        dn = dinvs[k + 1];
 #pragma unroll
-                    for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = (i > k + 1 && i < n_y) ? H[ltri(i, k + 1)] : 0.0; }
+                        for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = (i > k + 1 && i < n_y) ? H[ltri(i, k + 1)] : 0.0; }
+                    }
+                    const double f = bcast(k) * dc;
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) x[q] -= hc[q] * f;
                 }
-                const double f = bcast(k) * dc;
-#pragma unroll
-                for (int q = 0; q < PER; ++q) x[q] -= hc[q] * f;
             }
             double rd[PER];
 #pragma unroll
             for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; rd[q] = i < n_y ? dinvs[i] : 0.0; x[q] *= rd[q]; }
-            if (n_y > 0) {
-                const int rl = ((n_y - 1) * n_y) >> 1;
+            // backward: x_i -= (c_ki / d_i) x_k for i < k, GS columns (rows of the packed triangle) per trip; the raw entries of the
+            // NEXT ones are loaded while this trip's chain (readlane -> fma) runs, and scaled when they are used
+            constexpr int GS = PER <= 3 ? 4 : 1;          // (columns per trip: what the registers hold)
+            double hraw[GS][PER];
+            auto load4 = [&](int ktop) {
 #pragma unroll
-                for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = i < n_y - 1 ? H[rl + i] * rd[q] : 0.0; }
-            }
-            for (int k = n_y - 1; k >= 0; --k) {             // backward: x_i -= (c_ki / d_i) x_k for i < k
-                double hc[PER];
+                for (int u = 0; u < GS; ++u) {
+                    const int k = ktop - u, rowk = k > 0 ? ((k * (k + 1)) >> 1) : 0;
 #pragma unroll
-                for (int q = 0; q < PER; ++q) hc[q] = hn[q];
-                if (k > 0) {
-                    const int rowk = ((k - 1) * k) >> 1;
-#pragma unroll
-                    for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hn[q] = i < k - 1 ? H[rowk + i] * rd[q] : 0.0; }
+                    for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; hraw[u][q] = (k > 0 && i < k) ? H[rowk + i] : 0.0; }
                 }
-                const double xk = bcast(k);
+            };
+            load4(n_y - 1);
+            for (int ktop = n_y - 1; ktop >= 0; ktop -= GS) {
+                double hc[GS][PER];
 #pragma unroll
-                for (int q = 0; q < PER; ++q) x[q] -= hc[q] * xk;
+                for (int u = 0; u < GS; ++u)
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) hc[u][q] = hraw[u][q] * rd[q];
+                load4(ktop - GS);
+#pragma unroll
+                for (int u = 0; u < GS; ++u) {
+                    const int k = ktop - u;
+                    if (k < 0) break;
+                    const double xk = bcast(k);
+#pragma unroll
+                    for (int q = 0; q < PER; ++q) x[q] -= hc[u][q] * xk;
+                }
             }
 #pragma unroll
             for (int q = 0; q < PER; ++q) { const int i = q * 64 + tid; if (i < n_y) dy[i] = x[q]; }
@@ -673,7 +825,7 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
         // evaluates the same point, must neither test it for convergence (its loss equals the stored one) nor lower lambda, and solves
         // again with the larger damping.
         if (tid == 0) { st[0] *= w.lm_up; st[8] += 1.f; st[4] = 1.f; st[2] -= 1.f; }
-        for (int i = tid; i < n_y; i += SP_WGN_THREADS) dy[i] = 0.0;
+        for (int i = tid; i < n_y; i += NTHR) dy[i] = 0.0;
         __syncthreads();
     }
     WGN_STAMP(6);
@@ -683,7 +835,7 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
             const SpWindowBlock bk = w.blocks[b];
             const int nc = w.nc[b];
             const int* cb = w.cols + (size_t)b * ldc;
-            for (int n0 = 0; n0 < bk.N; n0 += SP_WGN_THREADS / 4) {        // four lanes per row, their partial sums added in a fixed order
+            for (int n0 = 0; n0 < bk.N; n0 += NTHR / 4) {        // four lanes per row, their partial sums added in a fixed order
                 const int n = n0 + (tid >> 2), part = tid & 3;
                 const bool row_ok = n < bk.N;
                 const int r = blk_off[b] + (row_ok ? n : 0);
@@ -705,7 +857,7 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
         }
         WGN_STAMP(7);
         // ---- poses and affine pairs ---------------------------------------------------------------------------------
-        for (int i = tid; i < w.n_nodes; i += SP_WGN_THREADS) {
+        for (int i = tid; i < w.n_nodes; i += NTHR) {
             SpWindowNode& nd = w.nodes[i];
             if (aff_off[i] >= 0) { nd.aff[0] += (float)dy[aff_off[i]]; nd.aff[1] += (float)dy[aff_off[i] + 1]; }
             if (pose_off[i] < 0) continue;
@@ -746,7 +898,7 @@ __global__ __launch_bounds__(SP_WGN_THREADS) void k_window_gn_update(WGnArgs w) 
     __threadfence_block();
     __syncthreads();
     WGN_STAMP(8);
-    for (int e = tid; e < w.n_edges; e += SP_WGN_THREADS) wgn_compose_edge(w, e);
+    for (int e = tid; e < w.n_edges; e += NTHR) wgn_compose_edge(w, e);
     WGN_STAMP(9);
 }
 
@@ -812,10 +964,10 @@ int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edge
     const int tiles = max(1, (w.lds + SP_BLOCK * SP_WGN_PPT - 1) / (SP_BLOCK * SP_WGN_PPT));
     hipLaunchKernelGGL(k_window_gn_schur, dim3(n_blocks, tiles), dim3(SP_BLOCK), 0, s, w);
     SP_CHECK_LAUNCH();
-    if (n_unknowns <= 64) hipLaunchKernelGGL(k_window_gn_update<64>, dim3(1), dim3(SP_WGN_THREADS), 0, s, w);
-    else if (n_unknowns <= 128) hipLaunchKernelGGL(k_window_gn_update<128>, dim3(1), dim3(SP_WGN_THREADS), 0, s, w);
-    else if (n_unknowns <= SP_WGN_LDS_Y) hipLaunchKernelGGL(k_window_gn_update<SP_WGN_LDS_Y>, dim3(1), dim3(SP_WGN_THREADS), 0, s, w);
-    else hipLaunchKernelGGL(k_window_gn_update<0>, dim3(1), dim3(SP_WGN_THREADS), 0, s, w);
+    if (n_unknowns <= 64) hipLaunchKernelGGL(k_window_gn_update<64>, dim3(1), dim3(wgn_update_threads(64)), 0, s, w);
+    else if (n_unknowns <= 128) hipLaunchKernelGGL(k_window_gn_update<128>, dim3(1), dim3(wgn_update_threads(128)), 0, s, w);
+    else if (n_unknowns <= SP_WGN_LDS_Y) hipLaunchKernelGGL(k_window_gn_update<SP_WGN_LDS_Y>, dim3(1), dim3(wgn_update_threads(SP_WGN_LDS_Y)), 0, s, w);
+    else hipLaunchKernelGGL(k_window_gn_update<0>, dim3(1), dim3(wgn_update_threads(0)), 0, s, w);
     SP_CHECK_LAUNCH();
     return 0;
 }

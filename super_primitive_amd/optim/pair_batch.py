@@ -89,8 +89,9 @@ REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 #       24                   4                           34                     97                       0
 #       31                   2                           82                    129                       0
 # (many small segments have few points each on the coarse lattice: depths held still for 12 iterations there let the pose settle on a
-# biased optimum.)  Outcomes of starts near the basin boundary turn with the summation order: golden g20y's pair 90 converges with 16 in
-# the span partition of a large batch and fails -- flagged -- as a batch of one (64-point spans); tests/test_gpu_sigma05.py runs both.
+# biased optimum.)  Outcomes of starts near the basin boundary turn with round-off: golden g20y's pair 90 converges with 16 in bench's
+# layout (replicas share replica 0's source samples: colours one ulp apart) and fails -- flagged -- as a batch of one built from its own
+# depth seeds; tests/test_gpu_sigma05.py runs both.
 REFERENCE_START_RETRY = (dict(level=2, stride=4, max_iters=30, irls_eps=1e-3, conv_tol=2e-3, pose_only=True),)
 REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(16.0, 12), retry_phases=REFERENCE_START_RETRY)
 # The verdict's thresholds (SpVerdict): a log-depth more than ``kld_bound`` from its seed (a factor e^kld_bound in depth: the reference's

@@ -306,9 +306,13 @@ class PoseWindow:
         """Microseconds the LAST update kernel spent in its phases (diagnostics): dict of phase -> us."""
         gn = self._gn_state()
         off = self.lib.sp_window_gn_profile_offset(self.n_edges, self.n_sources, gn['sum_N'], self.max_N, gn['n_y'])
-        t = gn['scratch'][off: off + 10].cpu().numpy()
+        t = gn['scratch'][off: off + 16].cpu().numpy()
         names = ("decision", "backup+clear", "assembly", "schur terms", "factorisation", "substitutions", "depth steps", "poses", "compose")
-        return {n: float(t[i + 1] - t[i]) / 100.0 for i, n in enumerate(names)}
+        out = {n: float(t[i + 1] - t[i]) / 100.0 for i, n in enumerate(names)}
+        if t[15] > t[10] > 0:          # one block step of the factorisation (the second), phase by phase
+            for i, n in enumerate(("panel out", "diagonal block", "panel rows", "barrier", "trailing update")):
+                out["step:" + n] = float(t[11 + i] - t[10 + i]) / 100.0
+        return out
 
     def gn_stats(self):
         st = self._gn_state()['state'].cpu().numpy()
