@@ -158,32 +158,46 @@ struct WGnArgs {
 };
 
 // ---- what every kernel of a step must agree on: the numbering of the camera unknowns and the LM decision ---------------------------------
-// offsets of node i's pose (6) / affine (2) unknowns in y, -1 = fixed; returns n_y
-__device__ int wgn_number_unknowns(const WGnArgs& w, int* pose_off, int* aff_off) {
+// The head of both kernels is COOPERATIVE: the node flags, the block sizes and the edges' losses are fetched by one thread each (a serial
+// walk by thread 0 paid one global-memory latency per node / block / edge: 8 us of each kernel at the reference's extent), staged in LDS,
+// and thread 0 only does the ordered arithmetic on them.
+// node flags -> offsets of node i's pose (6) / affine (2) unknowns in y, -1 = fixed; returns n_y.  flags[i]: bit 0 = pose free, bit 1 = affine free
+__device__ __forceinline__ int wgn_node_flags(const SpWindowNode& nd) { return (nd.lr_pose > 0.f ? 1 : 0) | (nd.lr_aff > 0.f ? 2 : 0); }
+__device__ int wgn_number_unknowns(int n_nodes, const int* flags, int* pose_off, int* aff_off) {
     int ny = 0;
-    for (int i = 0; i < w.n_nodes; ++i) {
-        const SpWindowNode& nd = w.nodes[i];
-        pose_off[i] = nd.lr_pose > 0.f ? ny : -1;
-        if (nd.lr_pose > 0.f) ny += 6;
-        aff_off[i] = nd.lr_aff > 0.f ? ny : -1;
-        if (nd.lr_aff > 0.f) ny += 2;
+    for (int i = 0; i < n_nodes; ++i) {
+        const int f = flags[i];               // (flags may alias aff_off: read before the write)
+        pose_off[i] = (f & 1) ? ny : -1;
+        if (f & 1) ny += 6;
+        aff_off[i] = (f & 2) ? ny : -1;
+        if (f & 2) ny += 2;
     }
     return ny;
+}
+// the window's loss, sum_e weight_e * loss_e in edge order: EB edges at a time through `ebuf` (LDS).  Every thread of the workgroup calls it
+// (barriers inside); the value is thread 0's.
+template <int EB>
+__device__ double wgn_loss_sum(const WGnArgs& w, int tid, double* ebuf) {
+    double total = 0.0;
+    for (int e0 = 0; e0 < w.n_edges; e0 += EB) {
+        const int e = e0 + tid;
+        if (tid < EB && e < w.n_edges) ebuf[tid] = (double)w.edges[e].weight * w.scratch[(size_t)e * w.stride];
+        __syncthreads();
+        if (tid == 0) { const int m = min(EB, w.n_edges - e0); for (int q = 0; q < m; ++q) total += ebuf[q]; }
+        __syncthreads();
+    }
+    return total;
 }
 
 struct WGnDecision { int dec; int too_many; int converged; float lam; double loss; };      // dec: 0 = step, 1 = reject (restore), 2 = frozen
 
-// PURE (reads the state, writes nothing): k_window_gn_schur of every block and k_window_gn_update evaluate it on the same state
-__device__ WGnDecision wgn_decide(const WGnArgs& w, int ny, int cap) {
+// PURE (reads the state, writes nothing): k_window_gn_schur of every block and k_window_gn_update evaluate it on the same state.
+// loss = wgn_loss_sum; free_depths = depth unknowns that may move (0 in a pose-only phase)
+__device__ WGnDecision wgn_decide(const WGnArgs& w, int ny, int cap, double loss, int free_depths) {
     WGnDecision d;
     d.dec = 0; d.too_many = 0; d.converged = 0; d.lam = 0.f;
-    double loss = 0.0;
-    for (int e = 0; e < w.n_edges; ++e) loss += (double)w.edges[e].weight * w.scratch[(size_t)e * w.stride];
     d.loss = loss;
     const float* st = w.state;
-    int free_depths = 0;
-    if (!(w.flags & 1))
-        for (int b = 0; b < w.n_blocks; ++b) free_depths += w.blocks[b].lr > 0.f ? w.blocks[b].N : 0;
     if (ny > cap || ny > w.cap_y) { d.too_many = 1; d.dec = 2; return d; }        // more camera unknowns than the caller sized the scratch for: refuse
     if ((ny == 0 && free_depths == 0) || st[6] != 0.f) { d.dec = 2; return d; }    // nothing to optimise / frozen earlier
     const float last = st[1];
@@ -227,24 +241,32 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w) {
     const int tid = threadIdx.x, b = blockIdx.x, tile = blockIdx.y;
     const SpWindowBlock bk = w.blocks[b];
     const bool frozen = (w.flags & 1) || !(bk.lr > 0.f);
+    __shared__ int bN[SP_WGN_MAX_NODES];          // a block's N, negative if its depths are fixed
+    for (int i = tid; i < w.n_nodes; i += SP_BLOCK) { aff_off[i] = wgn_node_flags(w.nodes[i]); lpose[i] = -1; laff[i] = -1; }
+    for (int q = tid; q < w.n_blocks; q += SP_BLOCK) { const SpWindowBlock bq = w.blocks[q]; bN[q] = bq.lr > 0.f ? bq.N : -bq.N; }
+    const double loss = wgn_loss_sum<SP_BLOCK>(w, tid, Cs);
+    __syncthreads();
+    // nodes this block's edges touch (every writer stores the same value)
+    if (!frozen)
+        for (int e = tid; e < w.n_edges; e += SP_BLOCK) {
+            const SpWindowEdge ed = w.edges[e];
+            if (ed.block != b) continue;
+            lpose[ed.trg_node] = 0;
+            if (ed.src_node >= 0) lpose[ed.src_node] = 0;
+        }
+    __syncthreads();
     if (tid == 0) {
-        const int ny = wgn_number_unknowns(w, pose_off, aff_off);
-        const WGnDecision d = wgn_decide(w, ny, SP_WGN_MAX_Y);
+        const int ny = wgn_number_unknowns(w.n_nodes, aff_off, pose_off, aff_off);
+        int off = 0, free_depths = 0;
+        for (int q = 0; q < w.n_blocks; ++q) {
+            if (q == b) row0_s = off;
+            off += abs(bN[q]);
+            if (!(w.flags & 1) && bN[q] > 0) free_depths += bN[q];
+        }
+        const WGnDecision d = wgn_decide(w, ny, SP_WGN_MAX_Y, loss, free_depths);
         dec_s = d.dec;
         lam_s = (double)d.lam;
-        int off = 0;
-        for (int q = 0; q < b; ++q) off += w.blocks[q].N;
-        row0_s = off;
-        // nodes this block's edges touch, in node order => cols ascending
-        for (int i = 0; i < w.n_nodes; ++i) { lpose[i] = -1; laff[i] = -1; }
-        if (!frozen)
-            for (int e = 0; e < w.n_edges; ++e) {
-                const SpWindowEdge ed = w.edges[e];
-                if (ed.block != b) continue;
-                lpose[ed.trg_node] = 0;
-                if (ed.src_node >= 0) lpose[ed.src_node] = 0;
-            }
-        int nc = 0;
+        int nc = 0;                               // touched nodes in node order => cols ascending
         for (int i = 0; i < w.n_nodes; ++i) {
             const bool touched = lpose[i] == 0;
             lpose[i] = -1;
@@ -435,15 +457,24 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
     const int tid = threadIdx.x;
     float* st = w.state;
     WGN_STAMP(0);
+    for (int i = tid; i < w.n_nodes; i += NTHR) aff_off[i] = wgn_node_flags(w.nodes[i]);
+    for (int b = tid; b < w.n_blocks; b += NTHR) { const SpWindowBlock bq = w.blocks[b]; blk_off[b] = bq.lr > 0.f ? bq.N : -bq.N; }
+    const double loss_now = wgn_loss_sum<64>(w, tid, g);
+    __syncthreads();
     if (tid == 0) {
-        const int ny = wgn_number_unknowns(w, pose_off, aff_off);
+        const int ny = wgn_number_unknowns(w.n_nodes, aff_off, pose_off, aff_off);
         n_y_s = ny;
         fail_s = 0;
-        int off = 0;
-        for (int b = 0; b < w.n_blocks; ++b) { blk_off[b] = off; off += w.blocks[b].N; }
+        int off = 0, free_depths = 0;
+        for (int b = 0; b < w.n_blocks; ++b) {
+            const int N = blk_off[b];
+            if (!(w.flags & 1) && N > 0) free_depths += N;
+            blk_off[b] = off;
+            off += abs(N);
+        }
         blk_off[w.n_blocks] = off;
         // ---- loss, LM decision (the one k_window_gn_schur took), committed to the state ---------------------------------
-        const WGnDecision d = wgn_decide(w, ny, CAP);
+        const WGnDecision d = wgn_decide(w, ny, CAP, loss_now, free_depths);
         if (d.too_many) { st[9] = 1.f; st[6] = 1.f; }
         if (d.dec != 2 || d.converged) {
             const int it = (int)st[5];
