@@ -218,8 +218,10 @@ def ptr(t):
 
 
 def stream_ptr():
+    """The current device's current HIP stream (what ``torch.cuda.current_stream().cuda_stream`` returns, without building the
+    Stream object: 0.4 us instead of 10 -- a tracked frame of the config-3 chain asks twenty times)."""
     import torch
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def require_device(*tensors):

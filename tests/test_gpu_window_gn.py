@@ -256,6 +256,27 @@ def test_windows_beyond_the_reference_extent_solve_without_exception(n_supp, n_y
     assert L[-1] < 0.1 * L[0] and rot <= 5e-4 and tt <= 1e-3 and dd <= 3e-3
 
 
+@pytest.mark.parametrize("n_kf,n_supp,n_run,affine,n_y", [(3, 2, 2, True, 64), (4, 4, 1, True, 128), (5, 5, 0, True, 192), (5, 2, 1, False, 78)])
+def test_camera_systems_at_the_edges_of_the_factorisation(n_kf, n_supp, n_run, affine, n_y):
+    """The update kernel's factorisation keeps the reduced camera system in registers over a 16 x 16 thread grid, one instantiation per
+    capacity (64 / 128 / 192 unknowns in LDS) and four pivots per block step: windows whose system FILLS an instantiation (no spare row
+    or column) and one whose size is not a multiple of four (13 free poses without affine pairs = 78: a last block of two pivots)."""
+    from super_primitive_amd.odometery.loops import map_window
+    frames, kfi, si, est, klds, affs, kfs, supp = _extent_window(311, n_kf, n_supp, n_run)
+    if not affine:
+        supp = [[(kf, pose, None) for kf, pose, _ in row] for row in supp]
+    out = map_window(kfs, [T(est[i]) for i in kfi], [T(k) for k in klds], [T(affs[i]) for i in kfi] if affine else None, supp, 40,
+                     window_size=n_kf, initialised=True, optimiser="gn")
+    assert (8 if affine else 6) * (n_kf - 1 + sum(len(r) for r in si)) == n_y
+    gt_kf = np.stack([frames[i].T_wc for i in kfi]); gt_supp = np.stack([frames[j].T_wc for row in si for j in row])
+    gt_kld = np.stack([frames[i].kld_gt for i in kfi]).astype(np.float64)
+    rot, tt, dd = _window_errors(out, gt_kf, gt_supp, gt_kld)
+    L = [float(l) for l in out["losses"]]
+    print(f"\n{n_y} camera unknowns: {out['stopped']} iterations, loss {L[0]:.6f} -> {L[-1]:.6f}, vs ground truth rot {rot:.2e} t {tt:.2e} depth {dd:.2e}; {out['gn']}")
+    assert not out["gn"]["too_many_unknowns"] and out["gn"]["failed_solves"] == 0
+    assert L[-1] < 0.1 * L[0] and rot <= 5e-4 and tt <= 1e-3 and dd <= 3e-3
+
+
 def test_supplementary_mapping_moves_only_the_latest_keyframes_depths():
     """mode 'supp' (odometery.py:1038-1042; parameter groups :616-619,628-635; connectivity :467-469) against golden g9e (the real
     ``photomeric_cost_batch`` loop, 12 Adam steps): eager and fused engines follow the reference's losses and end depths, nothing but the
