@@ -320,11 +320,9 @@ def cpu_baseline(pair2, iters):
             "config1_320x240x8_one_thread_level0": c1_one}
 
 
-def measure_traffic(args, kernel_substr):
-    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two child runs of this script (10 steps, no extras)
-    under rocprofv3 --pmc, one counter per pass with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not
-    fit one pass).  gfx950 correction of the guide's HBM section: FETCH_SIZE counts 128-byte read requests at 64 B, so read bytes
-    = 2 x FETCH_SIZE; both counters are in KB.  Returns (bytes_per_launch, detail) or (None, reason)."""
+def _pmc_pass(args, kernel_substr, counter):
+    """Mean of ``counter`` per launch of the kernel whose name contains ``kernel_substr``: a child run of this script (10 steps, no extras)
+    under rocprofv3 --pmc <counter> with --kernel-trace only.  Returns (mean, dispatches); raises on failure."""
     import csv
     import glob
     import shutil
@@ -332,38 +330,82 @@ def measure_traffic(args, kernel_substr):
     import tempfile
     exe = shutil.which("rocprofv3")
     if exe is None:
-        return None, "rocprofv3 not on PATH"
+        raise RuntimeError("rocprofv3 not on PATH")
+    out = tempfile.mkdtemp(prefix="sp_pmc_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
+           os.path.join(ROOT, "bench.py"), "--settle-ms", "0", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extras",
+           "--no-pmc", "--pairs", str(args.pairs), "--segments", str(args.segments), "--distinct", str(args.distinct),
+           "--tile-points", str(args.tile_points), "--mode", args.mode, "--shape", args.shape, "--coverage", str(args.coverage),
+           "--granule", str(args.granule)]
+    if args.span_points is not None:
+        cmd += ["--span-points", str(args.span_points)]
+    if args.no_depth_table:
+        cmd += ["--no-depth-table"]
+    try:
+        proc = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                              timeout=240, start_new_session=True)
+        per = {}
+        for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+        if proc.returncode != 0 or not per:
+            raise RuntimeError(f"rc {proc.returncode}, {len(per)} dispatches of {kernel_substr}")
+        return sum(per.values()) / len(per), len(per)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def measure_traffic(args, kernel_substr):
+    """HBM bytes per launch of the dominant kernel, measured IN THIS RUN: two child runs of this script (10 steps, no extras)
+    under rocprofv3 --pmc, one counter per pass with --kernel-trace only (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not
+    fit one pass).  gfx950 correction of the guide's HBM section: FETCH_SIZE counts 128-byte read requests at 64 B, so read bytes
+    = 2 x FETCH_SIZE; both counters are in KB.  Returns (bytes_per_launch, detail) or (None, reason)."""
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-        out = tempfile.mkdtemp(prefix="sp_pmc_", dir="/tmp")
-        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
-               os.path.join(ROOT, "bench.py"), "--settle-ms", "0", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-extras",
-               "--no-pmc", "--pairs", str(args.pairs), "--segments", str(args.segments), "--distinct", str(args.distinct),
-               "--tile-points", str(args.tile_points), "--mode", args.mode, "--shape", args.shape, "--coverage", str(args.coverage),
-               "--granule", str(args.granule)]
-        if args.span_points is not None:
-            cmd += ["--span-points", str(args.span_points)]
-        if args.no_depth_table:
-            cmd += ["--no-depth-table"]
         try:
-            proc = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                                  timeout=240, start_new_session=True)
-            per = {}
-            for path in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
-                with open(path) as f:
-                    for row in csv.DictReader(f):
-                        if kernel_substr in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                            per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
-            if proc.returncode != 0 or not per:
-                return None, f"rocprofv3 --pmc {counter}: rc {proc.returncode}, {len(per)} dispatches of {kernel_substr}"
-            vals[counter] = (sum(per.values()) / len(per), len(per))
+            vals[counter] = _pmc_pass(args, kernel_substr, counter)
         except Exception as e:                       # noqa: BLE001  (a failed profile pass must not take the bench line down)
-            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__}"
-        finally:
-            shutil.rmtree(out, ignore_errors=True)
+            return None, f"rocprofv3 --pmc {counter}: {type(e).__name__} {e}"
     hbm = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
     return hbm, {"FETCH_SIZE_KB_mean": vals["FETCH_SIZE"][0], "WRITE_SIZE_KB_mean": vals["WRITE_SIZE"][0], "dispatches": vals["FETCH_SIZE"][1],
                  "formula": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 B (gfx950: FETCH_SIZE tallies 128-B read requests at 64 B)"}
+
+
+def sample_shader_clock(step, seconds=1.6):
+    """The shader clock the GPU SUSTAINS under this step (it is power-limited: profiles/r05_power_clock_trace.txt): ``step`` is launched
+    back to back for ``seconds`` while a helper thread reads ``rocm-smi --showclocks`` twice after the first half second.  MHz or None."""
+    import re
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi")
+    if exe is None:
+        return None
+    got, stop = [], threading.Event()
+
+    def reader():
+        time.sleep(0.5)
+        for _ in range(2):
+            try:
+                txt = subprocess.run([exe, "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                m = re.search(r"sclk clock level:\s*\d*:?\s*\((\d+)Mhz\)", txt)
+                if m:
+                    got.append(float(m.group(1)))
+            except Exception:                        # noqa: BLE001
+                pass
+        stop.set()
+
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while not stop.is_set() and time.perf_counter() - t0 < 20.0:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
+    th.join(timeout=15)
+    return float(np.mean(got)) if got else None
 
 
 class _HostEvent:
@@ -514,6 +556,26 @@ def main(argv=None):
             line["roofline"]["traffic_over_algorithmic"] = hbm / alg_bytes
         else:
             line["roofline"]["traffic_note"] = detail
+        # The SECOND ceiling, stated instead of inferred: vector instructions per launch (SQ_INSTS_VALU, its own
+        # pass) x 4 cycles per wave instruction -- 16 for the 4 transcendentals per point (three IRLS reciprocals and 1 / z: sp_cost.hip
+        # finish_gn2 / prepare2) -- over the chip's 1024 SIMDs, at the shader clock the chip sustains under this very step
+        if args.mode == "gn":
+            try:
+                valu, n_disp = _pmc_pass(args, line["roofline"]["kernel"], "SQ_INSTS_VALU")
+                sclk = sample_shader_clock(lambda: (batch.cost_pass(0, mode_id), batch.solve_gn(0)))
+                points = float(sum(batch.Ppads)) if hasattr(batch, "Ppads") else None
+                trans = 4.0 * points / 64.0 if points else 0.0
+                cycles = (valu * 4.0 + trans * 12.0) / 1024.0
+                ceil = {"valu_wave_instructions_per_launch": valu, "dispatches": n_disp, "transcendental_wave_instructions_per_launch": trans,
+                        "simds": 1024, "cycles_per_launch": cycles, "sclk_mhz_sustained": sclk,
+                        "source": "this run: rocprofv3 --pmc SQ_INSTS_VALU (own pass); rocm-smi --showclocks while the step runs back to back"}
+                if sclk:
+                    ceil["kernel_ms_at_ceiling"] = cycles / (sclk * 1e3)
+                    ceil["kernel_over_ceiling"] = kern_ms / ceil["kernel_ms_at_ceiling"]
+                    ceil["hbm_frac_at_ceiling"] = alg_bytes / (ceil["kernel_ms_at_ceiling"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                line["roofline"]["valu_ceiling"] = ceil
+            except Exception as e:                   # noqa: BLE001
+                line["roofline"]["valu_ceiling"] = {"note": f"not measured: {type(e).__name__} {e}"}
     if line["roofline"]["traffic"] is None and os.path.exists(pmc):
         try:
             rec = json.load(open(pmc))
