@@ -29,6 +29,8 @@ done
  echo "### ragged masks (64 overlapping ellipses, rho 1.2), 12288 starts, 384 slots"; timeout 900 python tools/verdict_sweep.py --shape blobs --starts 12288 --alone "" --variants shipped,no_retry,undamped 2>&1 | grep -v "^make\|amdgpu.ids\|^batch\|^rendered" | cut -c1-700) > $OUT/reference_start.txt
 timeout 400 python tools/run_configs.py 2>/dev/null | grep config > $OUT/configs.txt
 timeout 300 python tools/window_bench.py 1 2 3 4 2>&1 | grep -v "^make\|amdgpu.ids" > $OUT/window_bench.txt
+(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/stats_window -o w -- python $GRAFT_REPO_ROOT/tools/window_bench.py 2 > /dev/null 2>&1)
+timeout 300 python tools/chain_profile.py 40 2>&1 | grep -v "^make\|amdgpu.ids" | head -64 | cut -c1-200 > $OUT/chain_profile.txt
 timeout 300 python tools/stream_bench.py 384 3 2>&1 | grep batches > $OUT/stream_bench.txt
 SP_GRANULE=64 timeout 200 python tools/setup_bench.py 2>/dev/null | grep "set-up\|timeline" > $OUT/setup.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_setup -o setup -- python tools/setup_profile.py 128 > /dev/null 2>&1

@@ -11,6 +11,7 @@ pairs = [("r05/bench_n1.json", "bench_n1.json"), ("r05/bench_under_rocprof.json"
          ("r05/configs.txt", "configs.txt"), ("r05/parity.txt", "parity.txt"), ("r05/pytest.txt", "pytest.txt"), ("r05/cost_kernel_pmc.txt", "cost_kernel_pmc.txt"),
          ("r05/reference_start.txt", "reference_start.txt"), ("r05/window_bench.txt", "window_bench.txt"), ("r05/stream_bench.txt", "stream_bench.txt"),
          ("r05/setup.txt", "setup.txt"), ("r05/power_clock_trace.txt", "power_clock_trace.txt"),
+         ("r05/stats_window/w_kernel_stats.csv", "window_bench_kernel_stats.csv"), ("r05/chain_profile.txt", "config3_chain_host_profile.txt"),
          # the sweeps the round's decisions were made on (earlier calls of the round)
          ("r05a/verdict_sweep.txt", "reference_start_sweep_1_second_attempts.txt"), ("r05b/verdict_sweep_blobs.txt", "reference_start_sweep_2_ragged_undamped.txt"),
          ("r05e/verdict_sweep.txt", "reference_start_sweep_3_damping_grid.txt"), ("r05e/verdict_sweep_blobs.txt", "reference_start_sweep_3_damping_ragged.txt"),
