@@ -279,7 +279,7 @@ __device__ __forceinline__ f32x2 sgpr2(float a, float b) {
 }
 struct PairConsts {            // the uniform operand pairs of prepare2 / fold_gn2 / finish_gn2
     f32x2 nKc, ifxy, R03, R14, R25, t01, Kf, Ktc, invWH, sxy, gab, bias2, eps2;
-    float R6, R7, R8, t2, gain, bias, zmin, eps;
+    float R6, R7, R8, t2, gain, bias, zmin, eps, row_bytes_f;
 };
 __device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 // a.y * b (+ c): the HIGH half of an aligned pair broadcast to both lanes through op_sel.  hipcc broadcasts a pair's low half this way by
@@ -288,6 +288,16 @@ __device__ __forceinline__ f32x2 pfma(f32x2 a, f32x2 b, f32x2 c) { return __buil
 __device__ __forceinline__ f32x2 pfma_hi(f32x2 a, f32x2 b, f32x2 c) {
     f32x2 d;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 padd2(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 psub2(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
 __device__ __forceinline__ f32x2 pmul_hi(f32x2 a, f32x2 b) {
@@ -374,10 +384,9 @@ __device__ __forceinline__ void prepare2(const TileCtx& c, const PairConsts& k, 
     const f32x2 ixy{ok ? i0.x : 0.f, ok ? i0.y : 0.f};
     const f32x2 fl{floorf(ixy.x), floorf(ixy.y)};
     p.wxy = ixy - fl;
-    uint32_t texel, off0;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(texel) : "v"((uint32_t)(int)fl.y), "s"((uint32_t)c.Wl), "v"((uint32_t)(int)fl.x));
-    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(off0) : "v"(texel), "s"(4u * SP_TEXEL_FLOATS));
-    p.off0 = off0;
+    // byte offset of the upper-left tap, in float arithmetic (exact: below 2^24 for any image the packed pixel word can address at 12 bytes
+    // per texel... checked by the host, sp_pairs_cost) and ONE conversion: multiply, fma, convert instead of two conversions, mad, multiply
+    p.off0 = (uint32_t)fmaf(fl.y, k.row_bytes_f, fl.x * (float)(4u * SP_TEXEL_FLOATS));
 }
 
 struct Mix2 { f32x2 wa, wb, v; };      // {w00, w01}, {w01, w11}, {v0, v1}
@@ -403,7 +412,8 @@ __device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& 
     // channels of w G G^T and of w r G are then pair operations whose results ARE the pairs fold_gn2 consumes (a pairing across the
     // channels needs horizontal sums and copies to build them).  e3 of red and green is one pair, used half by half.
     const f32x2 a2{a.x, a.y}, b2{b.x, b.y}, c2{cc.x, cc.y}, d2{d.x, d.y};
-    const f32x2 e3 = ((d2 - c2) - b2) + a2;
+    // (spelled out: the compiler splits these three pair operations into six scalar ones)
+    const f32x2 e3 = padd2(psub2(psub2(d2, c2), b2), a2);
     const f32x2 Er{b.x - a.x, cc.x - a.x}, Eg{b.y - a.y, cc.y - a.y}, Eb{b.z - a.z, cc.z - a.z};
     f32x2 e3b;                                   // only the low half is read
     e3b.x = (d.z - cc.z) - Eb.x;
@@ -413,8 +423,11 @@ __device__ __forceinline__ void finish_gn2(const PairConsts& k, const Pending2& 
     const f32x2 r2 = p.srg - pfma(k.gain, it2, k.bias2);
     const float rb = p.sb - fmaf(k.gain, itb, k.bias2.x);      // (the bias from its vector-register pair: gain is the instruction's one scalar operand)
     const float ar0 = fabsf(r2.x), ar1 = fabsf(r2.y), arb = fabsf(rb);
-    const f32x2 wg2{__builtin_amdgcn_rcpf(fmaxf(ar0, eps)), __builtin_amdgcn_rcpf(fmaxf(ar1, eps))};
-    const float wgb = __builtin_amdgcn_rcpf(fmaxf(arb, eps));
+    // max(|r|, eps) with eps as the instruction's scalar operand (fmaxf() canonicalises the uniform eps into a vector register first: one
+    // v_max_f32 per point for nothing)
+    auto absmax = [&](float r) { float m; asm("v_max_f32 %0, |%1|, %2" : "=v"(m) : "v"(r), "s"(eps)); return m; };
+    const f32x2 wg2{__builtin_amdgcn_rcpf(absmax(r2.x)), __builtin_amdgcn_rcpf(absmax(r2.y))};
+    const float wgb = __builtin_amdgcn_rcpf(absmax(rb));
     const f32x2 wGr = pmul_lo(wg2, Gr), wGg = pmul_hi(wg2, Gg), wGb = Gb * wgb;
     o.wa = pfma_lo(wGb, Gb, pfma_lo(wGg, Gg, pmul_lo(wGr, Gr)));       // sum w Ix {Ix, Iy}
     o.wb = pfma_hi(wGb, Gb, pfma_hi(wGg, Gg, pmul_hi(wGr, Gr)));       // sum w Iy {Ix, Iy}
@@ -453,7 +466,9 @@ __device__ __forceinline__ void fold_gn2(const PairConsts& k, const GeoGn g, con
     // columns 2..5 of Ahat as pairs along the column index.  Columns 2 and 3 of row 0 and of row 1 are negative throughout: they are
     // kept with the sign flipped (nA00 = -Ahat0[2..3], nA10 = -Ahat1[2..3], hence nB00 = -B00, nB10 = -B10) and the sign goes into the
     // operand modifiers of the products below -- four v_xor_b32 per point otherwise
-    const f32x2 nA00{u.x, u.x * qxy.y}, A01{fmaf(u.x, qxy.x, g.qz), -qxy.y};
+    float nqy;                                  // (-qxy.y: as `-qxy.y` the compiler negates the whole pair and copies the half it wants)
+    asm("v_xor_b32 %0, 0x80000000, %1" : "=v"(nqy) : "v"(qxy.y));
+    const f32x2 nA00{u.x, u.x * qxy.y}, A01{fmaf(u.x, qxy.x, g.qz), nqy};
     const f32x2 nA10{u.y, fmaf(u.y, qxy.y, g.qz)}, A11{u.y * qxy.x, qxy.x};
     const f32x2 nB00 = pfma_lo(Wa, nA00, pmul_hi(Wa, nA10)), B01 = pfma_lo(Wa, A01, pmul_hi(Wa, A11));
     const f32x2 nB10 = pfma_lo(Wb, nA00, pmul_hi(Wb, nA10)), B11 = pfma_lo(Wb, A01, pmul_hi(Wb, A11));
@@ -647,6 +662,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         asm volatile("" : "+v"(kc.nKc), "+v"(kc.bias2));      // (opaque: or the compiler puts the uniform pairs back into SGPRs)
         kc.R6 = sgpr(w.R[6]); kc.R7 = sgpr(w.R[7]); kc.R8 = sgpr(w.R[8]); kc.t2 = sgpr(w.t[2]);
         kc.gain = sgpr(c.gain); kc.bias = sgpr(c.bias); kc.zmin = sgpr(w.zmin); kc.eps = sgpr(irls_eps);
+        kc.row_bytes_f = sgpr((float)(c.Wl * (int)(4u * SP_TEXEL_FLOATS)));
     }
     const rsrc_t r_pix = make_rsrc(c.pix + start, (uint32_t)total * 4u);
     const rsrc_t r_src = make_rsrc(c.src4 + start, (uint32_t)total * 16u);
