@@ -23,10 +23,11 @@ import torch
 
 from .. import _lib
 from ..segment_table import table_of
-from .batch_prepare import flat_work_list
+from .batch_prepare import flat_work_list, stage
 from .pair_batch import DEFAULT_BATCH_TILE_POINTS, DEFAULT_SPAN_POINTS, GRANULE, MIN_SPANS, _level_images, pad_layout, pad_points
 
 KIND_WINDOW, KIND_DIRECT = 0, 1
+_SP_PAIR_DT = np.dtype(_lib.SpPair)
 
 
 def _upload_struct_array(arr, device):
@@ -77,7 +78,6 @@ class PoseWindow:
             blocks[k].N = self.Ns[k]
             blocks[k].lr = float(s.get('lr', 0.0))
         self._blocks_host = blocks
-        self.blocks = _upload_struct_array(blocks, dev)
         # ---- pose nodes ----------------------------------------------------------------------------------------
         arr = (_lib.SpWindowNode * self.n_nodes)()
         # (ONE read-back for all poses and one for all affine pairs: a .cpu() per node was a host synchronisation each)
@@ -92,7 +92,7 @@ class PoseWindow:
             arr[i].flags = 1 if nd.get('renorm', False) else 0
         for j, i in enumerate(with_aff):
             arr[i].aff = (ctypes.c_float * 2)(*affs[j])
-        self.nodes = _upload_struct_array(arr, dev)
+        nodes_host = arr
         # ---- target images: packed per level -------------------------------------------------------------------
         self.trg3, self.level_hw = {}, {}
         targets = sorted({e[1] for e in edges})
@@ -112,7 +112,6 @@ class PoseWindow:
             assert 0 <= k < S and 0 <= i < self.n_nodes
             assert nodes[i].get('kind', KIND_WINDOW) == KIND_WINDOW or sources[k].get('node', -1) < 0
             earr[e].src_node, earr[e].trg_node, earr[e].block, earr[e].weight = int(sources[k].get('node', -1)), i, k, float(wgt)
-        self.edges = _upload_struct_array(earr, dev)
         self.edge_list = [(int(k), int(i), float(wgt), float(z)) for k, i, wgt, z in edges]
         epads = [pads[k] for k, _, _, _ in edges]
         total = sum(pd['Ppad'] for pd in epads)
@@ -124,37 +123,46 @@ class PoseWindow:
         wl = flat_work_list(np.concatenate([pd['pc'] for pd in epads]), np.concatenate([pd['pseg_off'][:-1] for pd in epads]),
                             np.concatenate(([0], np.cumsum(e_N))), self.span_points, tile_points, GRANULE)
         self.n_chunks, self.n_spans = len(wl['chunks']), len(wl['spans'])
-        self.chunks = torch.from_numpy(wl['chunks']).to(dev)
-        self.spans = torch.from_numpy(wl['spans']).to(dev)
         sto_off = wl['sto_off']
-        self.seg_tile_off = torch.from_numpy(wl['seg_tile_off']).to(dev)
+        # (every small host array of the window goes to the device through ONE pinned buffer and one copy at the end: a copy from pageable
+        #  memory each -- a dozen per window -- made the host wait for the stream every time)
+        self.seg_tile_off = torch.empty(max(len(wl['seg_tile_off']), 1), dtype=torch.int32, device=dev)
         self.pose_slots = torch.zeros(E, 16, dtype=torch.float32, device=dev)
         self.aff_slots = torch.zeros(E, 4, dtype=torch.float32, device=dev) if use_affine else None
         self.Ps = [tables[k].P for k, _, _, _ in edges]
         self.desc = {}
         Ks_src = torch.stack([s_['kf'].K.detach().float().to(dev) for s_ in sources]).cpu().numpy()
         Ks_trg = dict(zip(targets, torch.stack([nodes[i]['K'].detach().float().to(dev) for i in targets]).cpu().numpy()))
+        # (numpy records, one column at a time: a ctypes assignment per field, edge and level took 1.3 ms of a reference-sized window's 4)
+        e_src = np.array([k for k, _, _, _ in edges], dtype=np.int64)
+        e_trg = np.array([i for _, i, _, _ in edges], dtype=np.int64)
+        base = np.zeros(E, dtype=_SP_PAIR_DT)
+        base['pix'] = np.array([t.data_ptr() for t in self.pix], dtype=np.uint64)[e_src]
+        base['kp_L'] = np.array([t.data_ptr() for t in self.kp_L], dtype=np.uint64)[e_src]
+        base['kld'] = (self.kld.data_ptr() + 4 * n_off[e_src].astype(np.int64)).astype(np.uint64)
+        base['pose'] = (self.pose_slots.data_ptr() + 64 * np.arange(E, dtype=np.int64)).astype(np.uint64)
+        if use_affine:
+            base['aff'] = (self.aff_slots.data_ptr() + 16 * np.arange(E, dtype=np.int64)).astype(np.uint64)
+        base['seg_tile_off'] = (self.seg_tile_off.data_ptr() + 4 * np.asarray(sto_off, dtype=np.int64)[:E]).astype(np.uint64)
+        Kt_all = np.stack([Ks_trg[i] for i in targets])
+        t_pos = {i: q for q, i in enumerate(targets)}
+        e_tpos = np.array([t_pos[int(i)] for i in e_trg], dtype=np.int64)
+        base['K_src'] = np.stack((Ks_src[:, 0, 0], Ks_src[:, 1, 1], Ks_src[:, 0, 2], Ks_src[:, 1, 2]), axis=1)[e_src]
+        base['K_trg'] = np.stack((Kt_all[:, 0, 0], Kt_all[:, 1, 1], Kt_all[:, 0, 2], Kt_all[:, 1, 2]), axis=1)[e_tpos]
+        for name, vals in (('N', [t.N for t in tables]), ('P', [t.P for t in tables]), ('H', [t.H for t in tables]), ('W', [t.W for t in tables])):
+            base[name] = np.array(vals, dtype=np.int32)[e_src]
+        s_off, c_off = np.asarray(wl['s_off'], dtype=np.int64), np.asarray(wl['c_off'], dtype=np.int64)
+        base['tile0'], base['n_tiles'] = s_off[:E], s_off[1:E + 1] - s_off[:E]
+        base['zmin'] = np.array([z for _, _, _, z in edges], dtype=np.float32)
+        base['rec0'] = 4 * c_off[:E]
+        desc_host = {}
         for l in self.level_ids:
-            parr = (_lib.SpPair * E)()
-            for e, (k, i, _w, zmin) in enumerate(edges):
-                d, kf, tab = parr[e], sources[k]['kf'], tables[k]
-                d.pix = self.pix[k].data_ptr()
-                d.src4 = self.src4[(k, l)].data_ptr()
-                d.kp_L = self.kp_L[k].data_ptr()
-                d.trg3 = self.trg3[(i, l)].data_ptr()
-                d.kld = self.kld.data_ptr() + 4 * int(n_off[k])
-                d.pose = self.pose_slots.data_ptr() + 64 * e
-                d.aff = (self.aff_slots.data_ptr() + 16 * e) if use_affine else None
-                d.seg_tile_off = self.seg_tile_off.data_ptr() + 4 * int(sto_off[e])
-                Ks, Kt = Ks_src[k], Ks_trg[i]
-                d.K_src = (ctypes.c_float * 4)(Ks[0, 0], Ks[1, 1], Ks[0, 2], Ks[1, 2])
-                d.K_trg = (ctypes.c_float * 4)(Kt[0, 0], Kt[1, 1], Kt[0, 2], Kt[1, 2])
-                d.N, d.P, d.H, d.W = tab.N, tab.P, tab.H, tab.W
-                d.Hl, d.Wl = self.level_hw[(i, l)]
-                d.tile0, d.n_tiles = int(wl['s_off'][e]), int(wl['s_off'][e + 1] - wl['s_off'][e])
-                d.zmin = float(zmin)
-                d.rec0 = 4 * int(wl['c_off'][e])
-            self.desc[l] = _upload_struct_array(parr, dev)
+            parr = base.copy()
+            parr['src4'] = np.array([self.src4[(k, l)].data_ptr() for k in range(S)], dtype=np.uint64)[e_src]
+            parr['trg3'] = np.array([self.trg3[(i, l)].data_ptr() for i in targets], dtype=np.uint64)[e_tpos]
+            hw_l = np.array([self.level_hw[(i, l)] for i in targets], dtype=np.int32)[e_tpos]
+            parr['Hl'], parr['Wl'] = hw_l[:, 0], hw_l[:, 1]
+            desc_host[l] = parr.view(np.uint8).reshape(-1)
         # ---- workspaces / optimiser state ----------------------------------------------------------------------
         # (sized for the Gauss-Newton records, the larger of the two optimisers')
         self.partials = torch.empty(self.n_spans * _lib.SP_GNA_PARTIAL_FLOATS, dtype=torch.float32, device=dev)
@@ -165,7 +173,15 @@ class PoseWindow:
         self.max_iters = int(max_iters)
         self.loss_hist = torch.zeros(self.max_iters, dtype=torch.float32, device=dev)
         self._graphs = {}
-        self._keep = (tables, pads)
+        as_bytes = lambda a: np.frombuffer(bytes(a), dtype=np.uint8)
+        up = stage([as_bytes(blocks), as_bytes(nodes_host), as_bytes(earr), np.ascontiguousarray(wl['chunks'], dtype=np.int32),
+                    np.ascontiguousarray(wl['spans'], dtype=np.int32), np.ascontiguousarray(wl['seg_tile_off'], dtype=np.int32)]
+                   + [desc_host[l] for l in self.level_ids], dev)
+        self.blocks, self.nodes, self.edges, self.chunks, self.spans = up[:5]
+        self.seg_tile_off[: up[5].numel()].copy_(up[5])          # (the descriptors hold addresses inside this array: it was allocated above)
+        for l, d in zip(self.level_ids, up[6:]):
+            self.desc[l] = d
+        self._keep = (tables, pads, up)
         self.compose()
 
     # ----------------------------------------------------------------------------------------------------------
