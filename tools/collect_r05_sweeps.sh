@@ -15,3 +15,7 @@
 #   6  kernel experiments: one reciprocal for the three IRLS weights; occupancy 3 / 2 through an LDS allocation
 #      tools/build_variant.sh ... ;  bash tools/ab_kbench.sh "base onercp" 1 --granule 64 ;  bash tools/ab_kbench.sh "base occ3 occ2" 1 --granule 64
 echo "see the comments; the final record of the shipped schedule is made by tools/collect_r05.sh"
+
+# the largest sweep of the round (profiles/r05_reference_start_sweep_6_49152_starts.txt): shipped schedule only, 49152 starts each
+#   python tools/verdict_sweep.py --starts 49152 --slots 768 --alone "" --variants shipped
+#   python tools/verdict_sweep.py --shape blobs --starts 49152 --alone "" --variants shipped

@@ -17,7 +17,7 @@ pairs = [("r05/bench_n1.json", "bench_n1.json"), ("r05/bench_under_rocprof.json"
          ("r05e/verdict_sweep.txt", "reference_start_sweep_3_damping_grid.txt"), ("r05e/verdict_sweep_blobs.txt", "reference_start_sweep_3_damping_ragged.txt"),
          ("r05e/verdict_sweep_768.txt", "reference_start_sweep_3_damping_768_slots.txt"), ("r05d/ab_onercp.txt", "kernel_experiments_one_rcp_ab.txt"), ("r05k/ab_occupancy.txt", "kernel_experiments_occupancy_ab.txt"),
          ("r05k/alone_probe.txt", "reference_start_g20y_pairs_alone.txt"), ("r05k/verdict_sweep_blobs.txt", "reference_start_sweep_4_damping_ragged_12288.txt"),
-         ("r05m/hard_ragged_probe.txt", "reference_start_hard_ragged_starts.txt"), ("r05m/hard_ragged_probe2.txt", "reference_start_hard_ragged_starts_2.txt")]
+         ("r05v/reference_start_49152.txt", "reference_start_sweep_6_49152_starts.txt"), ("r05m/hard_ragged_probe.txt", "reference_start_hard_ragged_starts.txt"), ("r05m/hard_ragged_probe2.txt", "reference_start_hard_ragged_starts_2.txt")]
 for a, b in pairs:
     src = os.path.join(G, a)
     if os.path.exists(src):
