@@ -230,6 +230,7 @@ __device__ __forceinline__ int ltri_row(int t) {
 #define SP_WGN_SCHUR_LDS 8192      // doubles of a staged chunk of C
 #define SP_WGN_SCHUR_ROWS 512
 #define SP_WGN_PPT 2               // pairs per thread
+#define SP_WGN_BLOCK_EDGES 64     // edges of ONE source keyframe kept as a list in LDS
 
 __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w) {
     __shared__ double Cs[SP_WGN_SCHUR_LDS];
@@ -246,14 +247,37 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w) {
     for (int q = tid; q < w.n_blocks; q += SP_BLOCK) { const SpWindowBlock bq = w.blocks[q]; bN[q] = bq.lr > 0.f ? bq.N : -bq.N; }
     const double loss = wgn_loss_sum<SP_BLOCK>(w, tid, Cs);
     __syncthreads();
-    // nodes this block's edges touch (every writer stores the same value)
+    // this block's edges, in edge order (an ordered compaction, SP_BLOCK edges at a time: the rows below walk the LIST -- a walk over ALL
+    // edges paid a global-memory latency per edge and row for the test "is it mine"), and the nodes they touch (every writer stores the
+    // same value).  Beyond SP_WGN_BLOCK_EDGES edges of one block the rows fall back to the walk over all edges.
+    __shared__ int be_e[SP_WGN_BLOCK_EDGES], be_trg[SP_WGN_BLOCK_EDGES], be_src[SP_WGN_BLOCK_EDGES];
+    __shared__ int be_cnt[SP_BLOCK / 64], be_n;
+    __shared__ double be_Ad[SP_WGN_BLOCK_EDGES * 36];          // Ad of the listed edges' relative poses (every row multiplies by it)
+    if (tid == 0) be_n = 0;
+    __syncthreads();
     if (!frozen)
-        for (int e = tid; e < w.n_edges; e += SP_BLOCK) {
-            const SpWindowEdge ed = w.edges[e];
-            if (ed.block != b) continue;
-            lpose[ed.trg_node] = 0;
-            if (ed.src_node >= 0) lpose[ed.src_node] = 0;
+        for (int e0 = 0; e0 < w.n_edges; e0 += SP_BLOCK) {
+            const int e = e0 + tid;
+            SpWindowEdge ed{-1, -1, -1, 0.f};
+            if (e < w.n_edges) ed = w.edges[e];
+            const bool mine = e < w.n_edges && ed.block == b;
+            if (mine) {
+                lpose[ed.trg_node] = 0;
+                if (ed.src_node >= 0) lpose[ed.src_node] = 0;
+            }
+            const unsigned long long bal = __ballot(mine);
+            if ((tid & 63) == 0) be_cnt[tid >> 6] = __popcll(bal);
+            __syncthreads();
+            int off = be_n;
+            for (int q = 0; q < (tid >> 6); ++q) off += be_cnt[q];
+            const int slot = off + __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+            if (mine && slot < SP_WGN_BLOCK_EDGES) { be_e[slot] = e; be_trg[slot] = ed.trg_node; be_src[slot] = ed.src_node; }
+            __syncthreads();
+            if (tid == 0) { int tot = be_n; for (int q = 0; q < SP_BLOCK / 64; ++q) tot += be_cnt[q]; be_n = tot; }
+            __syncthreads();
         }
+    if (!frozen && be_n <= SP_WGN_BLOCK_EDGES)
+        for (int i = tid; i < be_n * 36; i += SP_BLOCK) be_Ad[i] = w.Ad[(size_t)be_e[i / 36] * 36 + (i % 36)];
     __syncthreads();
     if (tid == 0) {
         const int ny = wgn_number_unknowns(w.n_nodes, aff_off, pose_off, aff_off);
@@ -302,9 +326,13 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w) {
             double D = 0.0, bd = 0.0;
             if (!frozen) {
                 for (int i = 0; i < nc; ++i) Crow[i] = 0.0;
-                for (int e = 0; e < w.n_edges; ++e) {
-                    const SpWindowEdge ed = w.edges[e];
-                    if (ed.block != b) continue;
+                const bool listed = be_n <= SP_WGN_BLOCK_EDGES;
+                const int n_walk = listed ? be_n : w.n_edges;
+                for (int q = 0; q < n_walk; ++q) {
+                    SpWindowEdge ed;
+                    int e = q;
+                    if (listed) { e = be_e[q]; ed.trg_node = be_trg[q]; ed.src_node = be_src[q]; ed.block = b; }
+                    else { ed = w.edges[q]; if (ed.block != b) continue; }
                     const double* o = w.scratch + (size_t)e * w.stride + SP_WGN_REC + (size_t)(r0 + n) * SP_WGN_SEG;
                     D += o[8]; bd += o[9];
                     const int pt = lpose[ed.trg_node], at = laff[ed.trg_node];
@@ -313,7 +341,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w) {
                     if (ed.src_node >= 0) {
                         const int ps = lpose[ed.src_node], as = laff[ed.src_node];
                         if (ps >= 0) {
-                            const double* Ad = w.Ad + (size_t)e * 36;
+                            const double* Ad = listed ? be_Ad + q * 36 : w.Ad + (size_t)e * 36;
                             for (int k = 0; k < 6; ++k) {
                                 double s = 0.0;
                                 for (int p = 0; p < 6; ++p) s += Ad[6 * p + k] * o[p];
