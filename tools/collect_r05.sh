@@ -12,6 +12,7 @@ mkdir -p $OUT
 timeout 900 python bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python bench.py --no-cpu-baseline --no-extras --no-pmc > $OUT/bench_under_rocprof.json 2>/dev/null
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-pmc > $OUT/bench_n1_driver_flags.json 2>/dev/null
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_command.json 2>/dev/null      # the driver's own command (38 s)
 timeout 300 python bench.py --mode adam --no-cpu-baseline --no-extras > $OUT/bench_n1_adam.json 2>/dev/null
 timeout 500 python bench.py --segments 128 --no-cpu-baseline > $OUT/bench_n1_seg128.json 2>/dev/null
 for S in 64 300 1200; do

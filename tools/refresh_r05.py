@@ -3,7 +3,7 @@
 import os, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-pairs = [("r05/bench_n1.json", "bench_n1.json"), ("r05/bench_under_rocprof.json", "bench_n1_under_rocprof.json"), ("r05/bench_n1_driver_flags.json", "bench_n1_driver_flags.json"),
+pairs = [("r05/bench_n1.json", "bench_n1.json"), ("r05/bench_under_rocprof.json", "bench_n1_under_rocprof.json"), ("r05/bench_n1_driver_flags.json", "bench_n1_driver_flags.json"), ("r05/bench_driver_command.json", "bench_n1_driver_command.json"),
          ("r05/bench_n1_adam.json", "bench_n1_adam.json"), ("r05/bench_n1_seg128.json", "bench_n1_seg128.json"), ("r05/bench_long.json", "bench_n1_long_run.json"),
          ("r05/bench_blobs_64.json", "bench_blobs_64.json"), ("r05/bench_blobs_300.json", "bench_blobs_300.json"), ("r05/bench_blobs_1200.json", "bench_blobs_1200.json"),
          ("r05/stats/bench_kernel_stats.csv", "bench_n1_kernel_stats.csv"), ("r05/stats_blobs64/bench_kernel_stats.csv", "bench_blobs_64_kernel_stats.csv"),
