@@ -57,8 +57,9 @@ def parse(argv=None):
                          "(20 steps are 17 ms: one region alone moves with the clock state of the box); 0 = one region")
     ap.add_argument("--pairs", type=int, default=384, help="frame pairs resident per GPU (4.8 GB of tables and images)")
     ap.add_argument("--segments", type=int, default=64, help="segments per source keyframe (BASELINE config 5 uses 128)")
-    ap.add_argument("--shape", choices=["grid", "blobs"], default="grid",
-                    help="segment masks: the grid tiling of the headline workload, or ragged overlapping ellipses (SAM-like; --coverage)")
+    ap.add_argument("--shape", choices=["grid", "blobs", "sam"], default="grid",
+                    help="segment masks: the grid tiling of the headline workload, ragged overlapping ellipses (SAM-like; --coverage), or 'sam' = "
+                         "SAM-REALISTIC sets (synth.make_pair(shape='sam'): areas over three decades, holes, nested masks, split lobes; N differs per scene)")
     ap.add_argument("--coverage", type=float, default=1.2, help="--shape blobs: total mask area in image areas (rho)")
     ap.add_argument("--granule", type=int, choices=[256, 64], default=64,
                     help="padding granule of the point tables: 64 = wave spans (SP_COST_WAVE_SPANS: a span per wave; the default since "
@@ -90,7 +91,7 @@ def build_batch(args, rank, dev):
     from super_primitive_amd.optim.pair_batch import FRAME_PAIR_POINT_STRIDE, PairBatch
     G = max(1, min(args.distinct, args.pairs))
     R = max(1, args.pairs // G)
-    shape_kw = dict(overlap=4) if getattr(args, "shape", "grid") == "grid" else dict(shape="blobs", blob_coverage=args.coverage)
+    shape_kw = dict(overlap=4) if getattr(args, "shape", "grid") == "grid" else dict(shape=args.shape, blob_coverage=args.coverage)
     pairs = [synth.make_pair(H, W, args.segments, seed=1000 * rank + s, init_sigma=0.004, **shape_kw) for s in range(G)]
     rng = np.random.default_rng(rank)
     poses = []
@@ -111,7 +112,7 @@ def build_batch(args, rank, dev):
 
 def _render_sigma05(a):
     from super_primitive_amd import synth
-    shape_kw = dict(overlap=4) if len(a) < 3 or a[2] == "grid" else dict(shape="blobs", blob_coverage=a[3])
+    shape_kw = dict(overlap=4) if len(a) < 3 or a[2] == "grid" else dict(shape=a[2], blob_coverage=a[3])
     return synth.make_pair(H, W, a[0], seed=a[1], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
 
 
@@ -207,12 +208,39 @@ def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue
     # (b) slot-level continuous batching over all Q resident pairs: 2 M slots (the quoted one) and M slots (rounds 3-4's choice: with the
     #     damped coarse phase in the schedule a pair spends more of its rounds in cheap phases, and the rounds of a thin resident set
     #     are bound by their launch latency: 35 k against 30 k pairs/s, tools/verdict_sweep.py --slots)
+    #     Round 6: the slots are driven as TWO groups on two HIP streams sharing the one queue (run_scheduled(streams=2)): one group's
+    #     launches fill the other's launch gaps, polls and cost-pass tails -- 33.5 k -> 38.3 k pairs/s (tools/phase_cost.py); per pair
+    #     bitwise the one-stream result.  The one-stream figures are reported next to it.
+    S = min(2 * M, Qb // 2)
     dt_m, launched_m = timed(batch, slots=M)
-    dt_q, launched_q = timed(batch, slots=min(2 * M, Qb // 2))
+    dt_1, launched_1 = timed(batch, slots=S)
+    dt_q, launched_q = timed(batch, slots=S, streams=2)
     err, err0 = errors_of(batch, Qb)
     rec_q = record(batch, Qb, dt_q, launched_q, err, err0)
-    rec_q["slots"] = min(2 * M, Qb // 2)
-    rec_q["frame_pairs_per_sec_with_M_slots"] = {"slots": M, "frame_pairs_per_sec": Qb / dt_m, "iterations_launched": int(launched_m)}
+    rec_q["slots"], rec_q["streams"] = S, 2
+    rec_q["frame_pairs_per_sec_one_stream"] = {"slots": S, "frame_pairs_per_sec": Qb / dt_1, "iterations_launched": int(launched_1)}
+    rec_q["frame_pairs_per_sec_with_M_slots"] = {"slots": M, "streams": 1, "frame_pairs_per_sec": Qb / dt_m, "iterations_launched": int(launched_m)}
+    # ROOFLINE OF THE SCHEDULE: the algorithmic bytes of every cost evaluation of every pair actually executed (counted
+    # on the device per pair and phase in one more, untimed run: per pair bitwise the timed one) over the timed run's wall time
+    batch.restore_initial()
+    batch.run_scheduled(**kw, slots=S, streams=2, verdict=dict(count_evaluations=True))
+    sync()
+    tr = batch.schedule_traffic(**kw)
+    n_it = float((batch.lm_state[:, 2] + batch.lm_state[:, 3]).double().sum())
+    rec_q["roofline_schedule"] = {
+        "bound": "hbm", "achieved": tr["total_bytes"] / dt_q / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": tr["total_bytes"] / dt_q / 1e9 / HBM_PEAK_GBPS,
+        "algorithmic_bytes": tr["total_bytes"], "algorithmic_bytes_per_pair": tr["total_bytes"] / Qb, "wall_ms": 1e3 * dt_q,
+        "frac_one_stream": tr["total_bytes"] / dt_1 / 1e9 / HBM_PEAK_GBPS,
+        "cost_evaluations": tr["evaluations"], "cost_evaluations_per_pair": tr["evaluations"] / Qb, "steps_per_pair": n_it / Qb,
+        "phases": [dict(p, share_of_bytes=p["bytes"] / max(tr["total_bytes"], 1.0)) for p in tr["phases"] if p["evaluations"] > 0],
+        "rounds": int(launched_1), "slots": S,
+        "slot_utilisation": tr["evaluations"] / max(float(launched_1) * S, 1.0),
+        "slot_utilisation_what": ("cost evaluations / (rounds x slots) of the one-stream run.  A slot-round is one cost evaluation of the slot's pair: the steps "
+                                  "(accepted + rejected: iterations_per_pair) PLUS one evaluation per phase left by its convergence test -- the evaluation that "
+                                  "finds the last step bought less than the tolerance takes no step and is not counted as an iteration.  What is left are "
+                                  "the slots that stand empty once the queue has run dry (the tail of ONE batch: 2 pairs per slot here)"),
+        "what": "sum over pairs and phases of (cost evaluations) x (20 B per point of the phase's lattice + 12 B per pixel of its target level), / wall time of "
+                "the quoted run / 8 TB/s; per-phase kernel times when every pair is in the same phase: profiles/r06_phase_cost.txt"}
     if slot_only:
         del batch
         torch.cuda.empty_cache()
@@ -531,7 +559,7 @@ def main(argv=None):
         "timed_regions": len(regions), "timed_region_ms": [1e3 * r[0] for r in regions][:32],
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"Replica-shaped two-frame SfM, 640x480, {args.segments} segments ({'grid, 4 px overlap' if args.shape == 'grid' else f'ragged overlapping ellipses, rho = {args.coverage:g}'}), pyramid "
+        "config": {"workload": f"Replica-shaped two-frame SfM, 640x480, {args.segments} segments ({'grid, 4 px overlap' if args.shape == 'grid' else (f'ragged overlapping ellipses, rho = {args.coverage:g}' if args.shape == 'blobs' else f'SAM-realistic masks (heavy-tailed areas, holes, nested, split), rho ~ {args.coverage:g}')}), pyramid "
                                "level 0 of a 3-level pyramid; BASELINE.json configs[1]",
                    "pairs_per_gpu": M, "segment_pixels_per_pair": int(batch.Ps[0]), "optimiser": args.mode,
                    "texture": (f"single-octave band, shortest period {pairs[0].meta['texture_period_px']:g} px; initial pose Exp(0.004 xi) T_gt (+0.002 per copy)"
@@ -621,6 +649,7 @@ def main(argv=None):
             line["reference_start"] = {"slot_level_continuous_batching": rs}
             line["frame_pairs_status"] = dict(rs["verdict"], pairs=rs["pairs"], of="rank 0's pairs")
             line["frame_pairs_per_sec"] = world * rs["frame_pairs_per_sec"]
+            line["roofline_schedule"] = rs.get("roofline_schedule")
             line["frame_pairs_per_sec_what"] = "reference start (sigma 0.05, depth seeds log(2 + 2 rand)), slot-level continuous batching, all ranks at once"
     if rank == 0 and not multi and not args.no_extras and not dry:
         # side measurements outside the timed region: (a) one pair alone (launch/latency bound, lives in the
@@ -771,8 +800,13 @@ def main(argv=None):
             ms = tm.milliseconds()
             rs = {k: {"ms": ms[k], "algorithmic_bytes": int(nbytes[k]), "achieved": nbytes[k] / (ms[k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                       "unit": "GB/s", "frac": nbytes[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for k in ms if ms[k] > 0}
-            tot_b, tot_ms = sum(nbytes[k] for k in ms), sum(ms.values())
-            line["roofline_setup"] = {"bound": "hbm", "passes": rs, "kernels_ms": tot_ms, "algorithmic_bytes": int(tot_b),
+            # (round 6: the image passes run on a side stream next to the table passes, so the passes OVERLAP: the set-up's GPU time is the
+            #  span from the first pass's start to the last one's end, not the sum of the passes; a pass's own duration is taken while its
+            #  neighbour runs and shares the memory system with it)
+            spans, _ = tm.timeline()
+            tot_b, tot_ms = sum(nbytes[k] for k in ms), max(e for _, _, e in spans) - min(a for _, a, _ in spans)
+            line["roofline_setup"] = {"bound": "hbm", "passes": rs, "kernels_ms": tot_ms, "sum_of_pass_durations_ms": sum(ms.values()),
+                                      "overlap": "pyramid + pack on a side stream, concurrent with count and fill", "algorithmic_bytes": int(tot_b),
                                       "achieved": tot_b / (tot_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                       "frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                       "algorithmic_bytes_per_pair": int(tot_b / n_raw), "pairs": n_raw}
@@ -787,7 +821,8 @@ def main(argv=None):
             tm = _Timer()
             _, _, nbytes_b = from_raw(tm)
             ms_b = tm.milliseconds()
-            tot_bb, tot_msb = sum(nbytes_b[k] for k in ms_b), sum(ms_b.values())
+            spans_b, _ = tm.timeline()
+            tot_bb, tot_msb = sum(nbytes_b[k] for k in ms_b), max(e for _, _, e in spans_b) - min(a for _, a, _ in spans_b)
             line["from_raw_frames"]["with_segment_boxes"] = {
                 "setup_ms": 1e3 * t_setup_b, "optimise_ms": 1e3 * t_opt_b, "frame_pairs_per_sec": n_raw / (t_setup_b + t_opt_b),
                 "roofline_setup": {"kernels_ms": tot_msb, "algorithmic_bytes": int(tot_bb), "frac": tot_bb / (tot_msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -904,6 +939,7 @@ def main(argv=None):
                 line["frame_pairs_per_sec_reference_start_all_resident"] = line["reference_start"]["frame_pairs_per_sec"]
                 line["frame_pairs_per_sec_reference_start"] = line["reference_start"]["slot_level_continuous_batching"]["frame_pairs_per_sec"]
                 line["frame_pairs_per_sec"] = line["frame_pairs_per_sec_reference_start"]
+                line["roofline_schedule"] = line["reference_start"]["slot_level_continuous_batching"].get("roofline_schedule")
                 line["frame_pairs_status"] = dict(line["reference_start"]["slot_level_continuous_batching"]["verdict"],
                                                   pairs=line["reference_start"]["slot_level_continuous_batching"]["pairs"],
                                                   unconverged_vs_ground_truth=[u["pair"] for u in line["reference_start"]["slot_level_continuous_batching"]["unconverged"]])

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 12
+#define SP_ABI_VERSION 13
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -228,12 +228,14 @@ int sp_photo_stats(const uint32_t* pix, const float* src4, const int32_t* seg_of
  *                         belong to the PAIR (mode 0: as sp_photo_cost_grad's tile record with column 13 unused;
  *                         mode 1: [0] sum|r|, [1..21] H_pp upper triangle, [22..27] b_p, [28] valid points);
  *   seg_partials[4 * C]   one record of (SP_GRAD_SEG_FLOATS | SP_GN_SEG_FLOATS) floats per (chunk, wave), record
- *                         4 * chunk + wave: the sums that belong to the SEGMENT (mode 0: d/dkld; mode 1: h_pd(6), D, b_d).
+ *                         4 * chunk + wave: the sums that belong to the SEGMENT (mode 0: d/dkld; mode 1: h_pd(6), D, b_d, and -- ABI 13 --
+ *                         [8] the record's own sum |r|, [9] its valid points: the cost PER SEGMENT, what the verdict's within-pair
+ *                         test reads; [10], [11] unused).
  * The solvers sum records in index order.  Per pair they need its span range (SpPair.tile0, n_tiles), the index of
  * its first segment record (rec0) and, per segment, the record range of its chunks (seg_tile_off, relative to rec0).
  * ---------------------------------------------------------------------------------------------------- */
 #define SP_GRAD_SEG_FLOATS 1
-#define SP_GN_SEG_FLOATS 8
+#define SP_GN_SEG_FLOATS 12
 #define SP_GNA_SEG_FLOATS 12
 typedef struct SpPair {
     const uint32_t* pix;      /* [P_padded] */
@@ -333,7 +335,7 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
  * sp_pairs_schedule_cost runs the Gauss-Newton cost pass over every DISTINCT work list (phases sharing `spans` share the list) in
  * ONE launch -- up to four lists of the same kind (wave spans or workgroup spans), one after the other in block order; otherwise a
  * launch per list; partial buffers of different work lists must not alias.  The struct lives in host memory. */
-#define SP_MAX_PHASES 8
+#define SP_MAX_PHASES 12
 /* SP_PHASE_POSE_ONLY: the phase moves the pose alone, the log-depths stay where they are (the solver skips the Schur complement
  * and the depth update; the cost pass is unchanged).  From the reference's own starting distribution (pose off by SE3.Random(sigma =
  * 0.05), depth seeds log(2 + 2 rand), odometery/two_frame_sfm.py:77-81,103-105) a joint Gauss-Newton step lets single segments run
@@ -352,6 +354,22 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
  * the reference's own starts; a damped coarse phase in front of the undamped ones does not (profiles/r05_reference_start.txt). */
 #define SP_PHASE_DEPTH_DAMP_SHIFT 8
 #define SP_PHASE_DEPTH_DAMP(k) (((k) & 0xff) << SP_PHASE_DEPTH_DAMP_SHIFT)
+/* SP_PHASE_ADAM (ABI 13): the phase's update is THE REFERENCE'S OWN OPTIMISER instead of a Gauss-Newton step -- one torch.optim.Adam
+ * step (betas 0.9 / 0.999, eps 1e-8, bias correction) on {left pose tangent, log-depths} at the rates SpSchedule.adam_lr_pose /
+ * adam_lr_kld (odometery/two_frame_sfm.py:116-123: 1e-2 / 1e-3), pose <- Exp(step) pose.  The gradient is that of the phase's cost pass:
+ * b_p and b_d of the IRLS normal equations are sum sign(r) J wherever |r| > irls_eps, i.e. the gradient of the reference's mean |r|
+ * (two_frame_sfm.py:201) up to the smoothing inside irls_eps; no Hessian is used, no step is ever rejected.  The phase ends on max_iters
+ * (conv_tol is ignored).  Moments: SpSchedule.adam_state, per pair / slot 2 + 2 (max_N + 8) floats laid out like sp_pairs_adam_step's;
+ * they persist over consecutive phases (the reference keeps one optimiser over its three pyramid levels, :128-155) and are zeroed whenever
+ * a pair (re)starts an attempt.  What it is for: the THIRD attempt of a pair whose two Gauss-Newton attempts failed their verdict
+ * (SpSchedule.retry2_entry) -- Gauss-Newton's path from a few of the reference's own starts in ten thousand leads into the second solution
+ * of a near-plane's homography under every damping tried, the reference's Adam path from the same starts does not (goldens g20y). */
+#define SP_PHASE_ADAM 8
+/* SP_PHASE_PREDICTED_EXIT (ABI 13): a pair also leaves the phase right after a step that is PREDICTED to buy less than conv_tol of its cost
+ * -- the first-order change of sum |r| along the step, b . delta, which the solver has at hand -- instead of only after the NEXT evaluation
+ * has shown that it did: one cost evaluation per phase saved (the all-points polish's is a tenth of a frame pair's work).  Skipped while
+ * the LM lambda is above 1e-2 or the phase damps the depth block (a short step is then the damping's doing).  The step is applied. */
+#define SP_PHASE_PREDICTED_EXIT 16
 typedef struct SpPhase {
     const SpPair* pairs;
     const int32_t* chunks;
@@ -367,15 +385,19 @@ typedef struct SpPhase {
 } SpPhase;               /* 64 bytes */
 /* entry: the phase a fresh pair starts in.  retry_entry: the phase a pair RESTARTS in -- from its initial pose and log-depths, once --
  * when its verdict at the end of the schedule says it failed (SpVerdict below); -1 = no second attempt.  The phases in front of
- * `entry` belong to the second attempt only: with phases {R0, R1 (next = J), P0, J, ..., polish}, entry = 2 and retry_entry = 0 a
- * first attempt runs P0, J, ..., polish and a second one R0, R1, J, ..., polish. */
+ * `entry` belong to the later attempts only: with phases {R0, R1 (next = J), P0, J, ..., polish}, entry = 2 and retry_entry = 0 a
+ * first attempt runs P0, J, ..., polish and a second one R0, R1, J, ..., polish.  retry2_entry (ABI 13): where a pair restarts, from
+ * its initial values again, when the SECOND attempt fails its verdict too -- -1 = no third attempt; with {A0, A1 (next = J'), R0, ...}
+ * and retry2_entry = 0 the third attempt runs A0, A1, J', ..., polish (A* = SP_PHASE_ADAM phases in REFERENCE_START_SCHEDULE). */
 typedef struct SpSchedule {
     SpPhase phase[SP_MAX_PHASES];
     int32_t n_phases;
     int32_t entry;
     int32_t retry_entry;
-    int32_t pad_;
-} SpSchedule;            /* 528 bytes */
+    int32_t retry2_entry;
+    float adam_lr_pose, adam_lr_kld;     /* SP_PHASE_ADAM phases */
+    float* adam_state;                   /* [pairs or slots][2 + 2 (max_N + 8)], device; NULL when no phase is SP_PHASE_ADAM */
+} SpSchedule;            /* 800 bytes */
 
 /* THE VERDICT of a scheduled run, per pair, on the device.  The reference asserts finiteness every iteration and nothing else
  * (core/dense_optim.py:311,321,340-343); a Gauss-Newton schedule that ends in the wrong basin (about one of the reference's own
@@ -383,7 +405,8 @@ typedef struct SpSchedule {
  * workgroup that takes a pair out of its last phase writes
  *   status[pair]  SP_STATUS_* bits; 0 = converged at the first attempt, SP_STATUS_RETRIED alone = converged at the second;
  *   diag[pair * SP_DIAG_FLOATS]  {final cost, max_n |kld_n - kld0_n|, valid points / points of the last evaluated cost,
- *                                 iterations spent in the last phase, attempts made, cost at the first evaluation, 0, 0}
+ *                                 iterations spent in the last phase, attempts made, cost at the first evaluation,
+ *                                 median and maximum over the pair's segments of the segment's mean |r| (0 = not judged)}
  * and, when (status & retry_mask) and the schedule has a retry_entry and the pair has made one attempt, puts pose and log-depths
  * back to pose0 / kld0, resets its LM state (lambda = lam0) and restarts it at retry_entry IN THE SAME LAUNCH -- the pair keeps its
  * slot, the resident set stays full.  A pair's verdict depends on the pair alone (no batch statistics): bitwise what it is alone.
@@ -394,7 +417,11 @@ typedef struct SpSchedule {
 #define SP_STATUS_COST        8   /* final cost > cost_bound (absolute), or > cost_ratio * the cost at the first evaluation; the host layer also sets it
                                    * for a final cost far above the batch median (optim/pair_batch.py VERDICT_DEFAULTS['cost_outlier']) */
 #define SP_STATUS_VALID       16  /* valid points of the last evaluated cost < valid_min * points */
-#define SP_STATUS_RETRIED     0x100   /* the verdict is the second attempt's */
+#define SP_STATUS_SEGMENTS    32  /* (ABI 13) the cost is UNEVEN over the pair's own segments: the worst segment's mean |r| > seg_max_ratio x the median
+                                   * segment's, or the pair's cost > seg_mean_ratio x the median segment's -- what the second solution of a near-plane's
+                                   * homography looks like from the inside (some segments explained, others not); needs no other pair to compare with */
+#define SP_STATUS_RETRIED     0x100   /* the verdict is a later attempt's (second or third) */
+#define SP_STATUS_ADAM        0x400   /* ... the third one's: the pair went through the schedule's SP_PHASE_ADAM phases (retry2_entry) */
 #define SP_STATUS_UNFINISHED  0x200   /* the run ended (max_rounds) before the pair left its last phase */
 #define SP_DIAG_FLOATS 8
 typedef struct SpVerdict {
@@ -409,9 +436,16 @@ typedef struct SpVerdict {
     float cost_bound;            /* <= 0: not tested */
     float cost_ratio;            /* <= 0: not tested */
     float valid_min;             /* <= 0: not tested */
-    int32_t retry_mask;          /* status bits that send a pair into its second attempt */
-    float lam0;                  /* LM damping a second attempt starts with */
-} SpVerdict;             /* 80 bytes */
+    int32_t retry_mask;          /* status bits that send a pair into its next attempt */
+    float lam0;                  /* LM damping a later attempt starts with */
+    float seg_max_ratio;         /* <= 0: not tested.  Segments with fewer than SP_VERDICT_SEGMENT_POINTS valid points in the last cost pass are not */
+    float seg_mean_ratio;        /* judged (of the pair's first SP_VERDICT_SEGMENTS segments); pairs with fewer than SP_VERDICT_MIN_SEGMENTS judged segments are not tested */
+    int32_t* evals;              /* [pairs * SP_MAX_PHASES] or NULL, zeroed by the caller: cost evaluations of every pair in every phase (diagnostics:
+                                  * bench.py prices a scheduled run's algorithmic bytes with it, roofline_schedule) */
+} SpVerdict;             /* 96 bytes */
+#define SP_VERDICT_SEGMENTS 2048
+#define SP_VERDICT_SEGMENT_POINTS 64
+#define SP_VERDICT_MIN_SEGMENTS 8
 int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream);
 int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
                               float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, const SpVerdict* verdict /* or NULL */,
@@ -458,7 +492,7 @@ typedef struct SpQueue {
     float* q_lm;
     float lam0;
     int32_t pad2_;
-} SpQueue;               /* 208 bytes */
+} SpQueue;               /* 288 bytes */
 int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, int n_slots, int max_N, float lm_up, float lm_down,
                                 float lm_min, float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters,
                                 int check_every, int max_rounds, int32_t* flag_dev, int32_t* flag_host, const SpVerdict* verdict /* or NULL */,

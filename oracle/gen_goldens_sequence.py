@@ -22,6 +22,12 @@ lietorch's Exp is the oracle's (parity unpinned at that boundary).  Config = con
 mapping steps 500 / continual_steps 10, supp_every_n 3, window_size 5, affine compensation, depth_validity_ratio 0.6) except
 ``translation_thresh`` (0.095: the synthetic camera moves 0.03 per frame in front of a plane at depth 3, so keyframes come every ~9 frames).
 The frames are ``tests/test_gpu_sequence.py::make_sequence_inputs`` (regenerated there from the recorded arguments).
+
+Round 6, TEACHER FORCING: the golden also holds the chain's COMPLETE state before and after every stage of every
+frame (``f<i>_s<k>_*``: s0 = before tracking, s1 = after tracking, s2 = after the supplementary mapping, s3 = after the scheduled
+mapping when there was one, s4 = after the keyframe decision / creation; ``snapshot`` below) so that a test can restart ANY stage from
+the reference's own recorded input and compare that stage's output at the north-star bar -- a free-running comparison of 24 frames
+inherits the jitter of every un-converged Adam stage before it (300 steps at lr 5e-3), a single stage does not.
 """
 from __future__ import annotations
 
@@ -169,20 +175,43 @@ class Chain:
                 lst.pop(0)
         return kld, vis
 
+    def snapshot(self, rec, tag):
+        """The chain's complete state (everything a stage reads or writes) under ``<tag>_*``: keyframes in the window, their supporting
+        frames (odometery.py ``supp_kfs_opt``), the tracked pool, the running supporting frames, the tracker's hand-over."""
+        def frames(key, row):
+            rec[f"{tag}_{key}_ts"] = np.array([s.ts for s in row], dtype=np.int64)
+            rec[f"{tag}_{key}_poses"] = np.stack([s.pose.numpy() for s in row]).astype(np.float32) if row else np.zeros((0, 4, 4), np.float32)
+            rec[f"{tag}_{key}_affs"] = np.stack([s.aff.numpy() for s in row]).astype(np.float32) if row else np.zeros((0, 2), np.float32)
+        rec[f"{tag}_kf_ids"] = np.array(self.kf_ids, dtype=np.int64)
+        rec[f"{tag}_kf_poses"] = np.stack([p.numpy() for p in self.kf_poses]).astype(np.float32)
+        rec[f"{tag}_kf_klds"] = np.stack([k.detach().numpy() for k in self.kf_klds]).astype(np.float32)
+        rec[f"{tag}_kf_affs"] = np.stack([a.numpy() for a in self.kf_affs]).astype(np.float32)
+        rec[f"{tag}_supp_counts"] = np.array([len(row) for row in self.supp_opt], dtype=np.int64)
+        frames("supp", [s for row in self.supp_opt for s in row])
+        frames("tracked", self.tracked)
+        frames("curr", self.curr_supp)
+        rec[f"{tag}_current_track"] = self.current_track.numpy().astype(np.float32).copy()
+        rec[f"{tag}_current_aff"] = self.current_aff.numpy().astype(np.float32).copy()
+        rec[f"{tag}_flags"] = np.array([self.current_ts, int(self.initialised), int(self.mapping_scheduled)], dtype=np.int64)
+
     def step(self, i, rec):                                                 # the body of Odometery.run, :1027-1075
         t0 = time.time()
+        self.snapshot(rec, "s0")
         rec["track_loss"] = self.track_frame(i)
+        self.snapshot(rec, "s1")
         rec["tracked_pose"] = self.current_track.numpy().copy(); rec["tracked_aff"] = self.current_aff.numpy().copy()
         if self.initialised and C["continual_steps"] > 0:
             out = self.mapping(C["continual_steps"], "supp")
             rec["supp_losses"] = out["losses"]
             rec["supp_kld_last"] = self.kf_klds[-1].numpy().copy()
+            self.snapshot(rec, "s2")
         if self.mapping_scheduled and len(self.curr_supp) >= 2:
             out = self.mapping(C["map_steps"], "map")
             self.mapping_scheduled = False
             self.tracked, self.curr_supp = [], []
             rec["map"] = dict(kf_ids=np.array(self.kf_ids), kf_poses=out["kf_poses"], klds=np.stack([np.asarray(k, np.float32) for k in out["klds"]]),
                               affs=out["affs"], supp_poses=out["supp_poses"], supp_affs=out["supp_affs"], losses=out["losses"], stopped=out["stopped"])
+            self.snapshot(rec, "s3")
         assert self.current_ts == i
         new_kf, est, crit = self.is_kf()
         rec["criterion"] = np.array(crit)
@@ -196,6 +225,7 @@ class Chain:
             rec["kf_kld"] = kld.numpy().copy(); rec["kf_visible"] = vis
             self.tracked, self.curr_supp = [], []
             self.mapping_scheduled = True
+        self.snapshot(rec, "s4")
         print(f"  frame {i}: track loss {rec['track_loss']:.6f}, criterion {crit}, {'NEW KEYFRAME ' if new_kf else ''}{'mapped ' if 'map' in rec else ''}"
               f"keyframes {self.kf_ids} ({time.time() - t0:.0f} s)", flush=True)
 

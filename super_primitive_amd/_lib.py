@@ -73,13 +73,13 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 12
+SP_ABI_VERSION = 13
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GNA_PARTIAL_FLOATS = 48
 SP_GNA_SEG_FLOATS = 12
 SP_GRAD_SEG_FLOATS = 1
-SP_GN_SEG_FLOATS = 8
+SP_GN_SEG_FLOATS = 12
 SP_LM_STATE_FLOATS = 8
 
 
@@ -94,12 +94,14 @@ class SpPair(ctypes.Structure):
     ]
 
 
-SP_MAX_PHASES = 8
+SP_MAX_PHASES = 12
 SP_PHASE_POSE_ONLY = 1
 SP_PHASE_WAVE_SPANS = 2
 SP_COST_WAVE_SPANS = 0x100
 SP_COST_DEPTH_TABLE = 0x200
 SP_PHASE_DEPTH_TABLE = 4
+SP_PHASE_ADAM = 8
+SP_PHASE_PREDICTED_EXIT = 16
 SP_PHASE_DEPTH_DAMP_SHIFT = 8
 SP_PREP_DEPTH_TABLE = 0x10000
 
@@ -136,7 +138,8 @@ class SpPhase(ctypes.Structure):
 
 class SpSchedule(ctypes.Structure):
     """Mirror of ``struct SpSchedule``; lives in host memory, passed by address (``ctypes.addressof``)."""
-    _fields_ = [("phase", SpPhase * SP_MAX_PHASES), ("n_phases", c_int), ("entry", c_int), ("retry_entry", c_int), ("pad_", c_int)]
+    _fields_ = [("phase", SpPhase * SP_MAX_PHASES), ("n_phases", c_int), ("entry", c_int), ("retry_entry", c_int), ("retry2_entry", c_int),
+                ("adam_lr_pose", c_float), ("adam_lr_kld", c_float), ("adam_state", c_void_p)]
 
 
 SP_STATUS_NONFINITE = 1
@@ -144,17 +147,22 @@ SP_STATUS_LAST_CAP = 2
 SP_STATUS_DEPTH_RANGE = 4
 SP_STATUS_COST = 8
 SP_STATUS_VALID = 16
+SP_STATUS_SEGMENTS = 32
 SP_STATUS_RETRIED = 0x100
 SP_STATUS_UNFINISHED = 0x200
-SP_STATUS_FAILED = SP_STATUS_NONFINITE | SP_STATUS_LAST_CAP | SP_STATUS_DEPTH_RANGE | SP_STATUS_COST | SP_STATUS_VALID | SP_STATUS_UNFINISHED
+SP_STATUS_ADAM = 0x400
+SP_STATUS_FAILED = SP_STATUS_NONFINITE | SP_STATUS_LAST_CAP | SP_STATUS_DEPTH_RANGE | SP_STATUS_COST | SP_STATUS_VALID | SP_STATUS_SEGMENTS | SP_STATUS_UNFINISHED
+SP_VERDICT_SEGMENTS = 2048
+SP_VERDICT_SEGMENT_POINTS = 64
+SP_VERDICT_MIN_SEGMENTS = 8
 SP_DIAG_FLOATS = 8
 
 
 class SpVerdict(ctypes.Structure):
-    """Mirror of ``struct SpVerdict`` (include/sp_hip.h): the per-pair verdict of a scheduled run and its one second attempt."""
+    """Mirror of ``struct SpVerdict`` (include/sp_hip.h): the per-pair verdict of a scheduled run and its later attempts."""
     _fields_ = [("status", c_void_p), ("diag", c_void_p), ("attempts", c_void_p), ("pose0", c_void_p), ("kld0", c_void_p),
                 ("pose_base", c_void_p), ("kld_base", c_void_p), ("kld_bound", c_float), ("cost_bound", c_float), ("cost_ratio", c_float),
-                ("valid_min", c_float), ("retry_mask", c_int), ("lam0", c_float)]
+                ("valid_min", c_float), ("retry_mask", c_int), ("lam0", c_float), ("seg_max_ratio", c_float), ("seg_mean_ratio", c_float), ("evals", c_void_p)]
 
 
 class SpQueue(ctypes.Structure):
@@ -217,11 +225,22 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = None
+
+
 def stream_ptr():
     """The current device's current HIP stream (what ``torch.cuda.current_stream().cuda_stream`` returns, without building the
-    Stream object: 0.4 us instead of 10 -- a tracked frame of the config-3 chain asks twenty times)."""
-    import torch
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    Stream object: 0.4 us instead of 10 -- a tracked frame of the config-3 chain asks twenty times).  The fast path uses two private
+    torch entry points, resolved ONCE; a torch that no longer has them falls back to the public API."""
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        raw, cur = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        if raw is not None and cur is not None:
+            _raw_stream = lambda: raw(cur())
+        else:
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return ctypes.c_void_p(_raw_stream())
 
 
 def require_device(*tensors):

@@ -352,6 +352,7 @@ struct GnAcc {
     float h11;        // acc[7]
     f32x2 D, bd;      // acc[34], acc[35]: x + y (the two rows' products accumulate side by side: one v_pk_fma_f32 each; added at the flush)
     float cost, n;    // acc[0], acc[36]
+    float cost_mark, n_mark;   // cost / n at the last segment flush (flush_segment_gn)
 };
 
 struct Pending2 {          // Pending, with the x/y quantities as register pairs
@@ -595,9 +596,14 @@ __device__ __forceinline__ void flush_segment_gn(GnAcc& A, float* __restrict__ r
         if (ok) store_partial<WT>(rec + pos, v[0]);
         aa->hda = 0.f; aa->hdb = 0.f;
     } else {
-        float v[8] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D.x + A.D.y, A.bd.x + A.bd.y};
-        wave_sum_to_lanes<8>(v, lane, pos, ok);
+        // [8], [9]: the chunk's own sum |r| and valid points (round 6: the verdict's WITHIN-PAIR test looks at the cost per segment).
+        // The pair-level accumulators run on through the span; what they held at the previous flush is kept in two registers (the
+        // fold of a chunk's last point comes after that point's finish_gn2, so at this moment they cover exactly the chunks so far)
+        float v[10] = {A.hd01.x, A.hd01.y, A.hd[0].x, A.hd[0].y, A.hd[1].x, A.hd[1].y, A.D.x + A.D.y, A.bd.x + A.bd.y,
+                       A.cost - A.cost_mark, A.n - A.n_mark};
+        wave_sum_to_lanes<10>(v, lane, pos, ok);
         if (ok) store_partial<WT>(rec + pos, v[0]);
+        A.cost_mark = A.cost; A.n_mark = A.n;
     }
     const f32x2 z{0.f, 0.f};
     A.hd01 = z; A.hd[0] = z; A.hd[1] = z; A.D = z; A.bd = z;
@@ -641,7 +647,7 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
 #pragma unroll
         for (int k = 0; k < 6; ++k) A.blk[k] = z;
         A.D = z; A.bd = z;
-        A.h11 = A.cost = A.n = 0.f;
+        A.h11 = A.cost = A.n = A.cost_mark = A.n_mark = 0.f;
     }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     SpanCursor k;

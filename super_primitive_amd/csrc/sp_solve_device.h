@@ -258,6 +258,9 @@ struct GnArgs {
     int pose_only;           // SP_PHASE_POSE_ONLY: no Schur complement, no depth update
     int next_phase;          // ... the phase that follows the current one (SpPhase.next)
     float depth_damp;        // ... extra LM damping of the log-depth block (SP_PHASE_DEPTH_DAMP): D (1 + lambda + depth_damp)
+    float adam_lr_pose, adam_lr_kld;   // SP_PHASE_ADAM phases (solve_adam_sched): the rates and the moments (SpSchedule.adam_state)
+    float* adam_state;
+    int predicted_exit;      // SP_PHASE_PREDICTED_EXIT: leave the phase when the step just taken is PREDICTED to buy less than conv_tol of the cost
 };
 
 // a pair leaves its current phase (thread 0): the next one starts afresh; lm_state[7] records how this one ended
@@ -284,6 +287,7 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
     __shared__ double schur_part[8][27];
     __shared__ double schur[27];     // 21 + 6
     __shared__ double dxi[6];
+    __shared__ double gain_part[SP_WAVES];
     __shared__ int decision;         // 0 = step, 1 = rejected (restore)
     const SpPair& pr = pairs[pi];
     if (h.done && h.done[pi]) return;          // converged earlier (its spans were not evaluated either)
@@ -383,13 +387,10 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
         const bool ok = ldlt6_solve(S, rhs);
         for (int i = 0; i < 6; ++i) dxi[i] = ok ? rhs[i] : 0.0;
         ls[0] = lambda; ls[1] = (float)cost; ls[2] += 1.f; ls[4] = 0.f;
-        if (h.phase) {                              // iteration budget of the phase (the step computed here is still applied)
-            const int n = h.iters[pi] + 1;
-            if (n >= h.max_iters) leave_phase(h, pi, ls, n, true);
-            else h.iters[pi] = n;
-        }
     }
     __syncthreads();
+    // the first-order change of sum |r| along the step, b . delta (b = sum sign(r) J where |r| > eps): what the step is PREDICTED to buy
+    double gain = 0.0;
     for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
         double o[8];
         if (n < SP_SEG_CACHE) {
@@ -403,12 +404,81 @@ __device__ __forceinline__ void solve_gn(const SpPair* __restrict__ pairs, int p
             double dd = r * o[6];
             dd = fmin(fmax(dd, -0.5), 0.5);   // trust region on one log-depth step (factor e^0.5 in depth)
             pr.kld[n] += (float)dd;
+            gain -= o[7] * dd;
         }
     }
     if (threadIdx.x == 64) {                  // a different wave than the one that just solved: no reason, just parallel
         double xi[6];
         for (int i = 0; i < 6; ++i) xi[i] = dxi[i];
         se3_retract_left(xi, pr.pose);
+    }
+    if (h.phase) {
+        // iteration budget of the phase (the step computed here has been applied), and -- SP_PHASE_PREDICTED_EXIT -- its PREDICTED end: the
+        // convergence test above needs one more evaluation to SEE that the last step bought less than conv_tol of the cost, a quarter
+        // of a frame pair's work when that evaluation is the all-points polish; b . delta says so beforehand (the IRLS quadratic
+        // majorises sum |r|: the linearised cost falls by between half of it and all of it).  Not under a heavy damping, where a short
+        // step is the damping's doing: lambda <= 1e-2 and no SP_PHASE_DEPTH_DAMP.
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gain += __shfl_xor(gain, o, 64);
+        if ((threadIdx.x & 63) == 0) gain_part[threadIdx.x >> 6] = gain;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int n = h.iters[pi] + 1;
+            bool done = false;
+            if (h.predicted_exit && h.conv_tol > 0.f && h.depth_damp == 0.f && lambda <= 1e-2f) {
+                double g = gain_part[0] + gain_part[1] + gain_part[2] + gain_part[3];
+                for (int i = 0; i < 6; ++i) g -= sums[22 + i] * dxi[i];
+                done = g / (3.0 * (double)pr.P) <= (double)h.conv_tol * cost;
+            }
+            if (done) leave_phase(h, pi, ls, n, false);
+            else if (n >= h.max_iters) leave_phase(h, pi, ls, n, true);
+            else h.iters[pi] = n;
+        }
+    }
+}
+
+// One workgroup: an SP_PHASE_ADAM iteration of pair / slot `pi` (include/sp_hip.h): one torch.optim.Adam step on {left pose tangent,
+// log-depths} from the sums of the phase's Gauss-Newton cost pass -- b_p and b_d of the IRLS normal equations are the gradient of
+// sum |r| (exactly sum sign(r) J where |r| > irls_eps), and the reference's loss is that sum over 3 P (odometery/two_frame_sfm.py:201).
+// Rates 1e-2 / 1e-3 as :116-123; no step is rejected; the phase ends on its cap.  Adam arithmetic: adam_torch above, like solve_adam.
+__device__ __forceinline__ void solve_adam_sched(const SpPair* __restrict__ pairs, int pi, const float* __restrict__ partials,
+                                                 const float* __restrict__ seg_partials, const GnArgs& h) {
+    constexpr int NV = SP_GN_PARTIAL_FLOATS;
+    __shared__ double sums[NV];
+    __shared__ double scratch[(SP_BLOCK / NV) * NV];
+    const SpPair& pr = pairs[pi];
+    const int max_N = h.max_N;
+    const float* p = partials + (size_t)pr.tile0 * NV;
+    const float* sp = seg_partials + (size_t)pr.rec0 * SP_GN_SEG_FLOATS;
+    float* ls = h.lm_state + (size_t)pi * SP_LM_STRIDE;
+    reduce_columns<NV>(p, pr.n_tiles, sums, scratch);
+    const double scale = 1.0 / (3.0 * (double)pr.P);
+    float* st = h.adam_state + (size_t)pi * (2 + 2 * (max_N + 8));
+    float* m_kld = st + 2; float* v_kld = m_kld + max_N;
+    float* m_xi = v_kld + max_N; float* v_xi = m_xi + 6;
+    const float step = st[0] + 1.f;
+    const double bc1 = 1.0 - pow(0.9, (double)step);
+    const float bc2s = (float)sqrt(1.0 - pow(0.999, (double)step));
+    const float ns_kld = (float)(-(double)h.adam_lr_kld / bc1), ns_pose = (float)(-(double)h.adam_lr_pose / bc1);
+    __syncthreads();            // every thread has read st[0] before thread 0 stores the new step count below
+    for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
+        double o[8];
+        segment_system(sp, pr.seg_tile_off, n, 0.0, o);
+        const float g = (float)(o[7] * scale);
+        pr.kld[n] += adam_torch(g, m_kld[n], v_kld[n], ns_kld, bc2s);
+    }
+    if (threadIdx.x == 0) {
+        double xi[6];
+        for (int i = 0; i < 6; ++i) xi[i] = adam_torch((float)(sums[22 + i] * scale), m_xi[i], v_xi[i], ns_pose, bc2s);
+        se3_retract_left(xi, pr.pose);
+        st[0] = step;
+        const float cost = (float)(sums[0] * scale);
+        ls[1] = cost; ls[2] += 1.f; ls[4] = 0.f; ls[5] = cost;
+        ls[6] = (float)(sums[28] / (double)pr.P);
+        h.costs[pi] = cost;
+        const int n = h.iters[pi] + 1;
+        if (n >= h.max_iters) leave_phase(h, pi, ls, n, true);
+        else h.iters[pi] = n;
     }
 }
 

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
     solve_gn(pairs, blockIdx.x, partials, seg_partials, h);
 }
 
-static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 528 && sizeof(SpVerdict) == 80 && sizeof(SpQueue) == 208 && sizeof(SpPair) == 136,
+static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 800 && sizeof(SpVerdict) == 96 && sizeof(SpQueue) == 288 && sizeof(SpPair) == 136,
               "SpSchedule / SpVerdict / SpQueue / SpPair are part of the ABI");
 
 // per-pair schedules: the pair's current phase selects the level descriptors, the partial records of that level's work list,
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
     const int slot = blockIdx.x;
     const int ph = h.phase[slot];
     if (ph >= sched.n_phases || ph < 0) return;           // finished, and the queue was empty when it did
+    if (v.evals && threadIdx.x == 0) v.evals[(size_t)(q.n_queue > 0 ? q.slot_pair[slot] : slot) * SP_MAX_PHASES + ph] += 1;
     {
         const SpPhase& s = sched.phase[ph];
         h.conv_tol = s.conv_tol;
@@ -43,12 +44,18 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
         h.pose_only = s.flags & SP_PHASE_POSE_ONLY;
         h.next_phase = s.next > 0 ? s.next : ph + 1;
         h.depth_damp = 0.125f * (float)((s.flags >> SP_PHASE_DEPTH_DAMP_SHIFT) & 0xff);
-        solve_gn(s.pairs, slot, s.span_partials, s.seg_partials, h);
+        h.adam_lr_pose = sched.adam_lr_pose; h.adam_lr_kld = sched.adam_lr_kld; h.adam_state = sched.adam_state;
+        h.predicted_exit = s.flags & SP_PHASE_PREDICTED_EXIT;
+        if ((s.flags & SP_PHASE_ADAM) && sched.adam_state) solve_adam_sched(s.pairs, slot, s.span_partials, s.seg_partials, h);
+        else solve_gn(s.pairs, slot, s.span_partials, s.seg_partials, h);
     }
     if (q.n_queue <= 0 && !v.status) return;
     __shared__ int next_s, retry_s;
     __shared__ float dmax_s[SP_WAVES];
     __shared__ int bad_s[SP_WAVES];
+    __shared__ float segc_s[SP_VERDICT_SEGMENTS];      // cost per segment (the within-pair test); < 0 = too few valid points to say
+    __shared__ float seg_med_s, seg_max_s[SP_WAVES];
+    __shared__ int seg_n_s[SP_WAVES];
     __syncthreads();                            // every write of solve_gn (thread 0's phase update included) is visible
     const int pid = q.n_queue > 0 ? q.slot_pair[slot] : slot;
     float* ls = h.lm_state + (size_t)slot * SP_LM_STRIDE;
@@ -70,9 +77,49 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
             else dmax = fmaxf(dmax, d);
         }
         if (threadIdx.x < 12 && !(fabsf(pr.pose[threadIdx.x]) <= 3.0e38f)) bad = 1;
+        // THE WITHIN-PAIR TEST (ABI 13): mean |r| of every segment at the last evaluated point, from the segment records of the last phase's
+        // cost pass ([8] sum |r|, [9] valid points) -- a pair that sits in the second solution of a near-plane's homography explains some
+        // segments and not others (worst segment 3-40 x the median one; a converged pair's lie within 3 x), whatever the other pairs of
+        // the batch do: the one test a batch of ONE has against a well-behaved local minimum
+        const int n_seg = min(pr.N, SP_VERDICT_SEGMENTS);
+        float smax = 0.f;
+        int sn = 0;
+        {
+            const float* sp = sched.phase[ph].seg_partials + (size_t)pr.rec0 * SP_GN_SEG_FLOATS;
+            for (int n = threadIdx.x; n < n_seg; n += SP_BLOCK) {
+                double a = 0.0, c = 0.0;
+                for (int t = pr.seg_tile_off[n]; t < pr.seg_tile_off[n + 1]; ++t) {
+                    a += (double)sp[(size_t)t * SP_GN_SEG_FLOATS + 8];
+                    c += (double)sp[(size_t)t * SP_GN_SEG_FLOATS + 9];
+                }
+                const float sc = c >= (double)SP_VERDICT_SEGMENT_POINTS ? (float)(a / (3.0 * c)) : -1.f;
+                segc_s[n] = sc;
+                if (sc >= 0.f) { smax = fmaxf(smax, sc); ++sn; }
+            }
+        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); bad |= __shfl_xor(bad, o, 64); }
-        if ((threadIdx.x & 63) == 0) { dmax_s[threadIdx.x >> 6] = dmax; bad_s[threadIdx.x >> 6] = bad; }
+        for (int o = 32; o > 0; o >>= 1) {
+            dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64)); bad |= __shfl_xor(bad, o, 64);
+            smax = fmaxf(smax, __shfl_xor(smax, o, 64)); sn += __shfl_xor(sn, o, 64);
+        }
+        if ((threadIdx.x & 63) == 0) { dmax_s[threadIdx.x >> 6] = dmax; bad_s[threadIdx.x >> 6] = bad; seg_max_s[threadIdx.x >> 6] = smax; seg_n_s[threadIdx.x >> 6] = sn; }
+        if (threadIdx.x == 0) seg_med_s = 0.f;
+        __syncthreads();
+        {
+            // lower median of the judged segments by rank counting (N^2 / 256 comparisons per thread, once per pair)
+            const int n_judged = seg_n_s[0] + seg_n_s[1] + seg_n_s[2] + seg_n_s[3];
+            const int want = (n_judged - 1) >> 1;
+            for (int n = threadIdx.x; n < n_seg && n_judged >= SP_VERDICT_MIN_SEGMENTS; n += SP_BLOCK) {
+                const float x = segc_s[n];
+                if (x < 0.f) continue;
+                int rank = 0;
+                for (int j = 0; j < n_seg; ++j) {
+                    const float y = segc_s[j];
+                    rank += (y >= 0.f && (y < x || (y == x && j < n))) ? 1 : 0;
+                }
+                if (rank == want) seg_med_s = x;
+            }
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             dmax = fmaxf(fmaxf(dmax_s[0], dmax_s[1]), fmaxf(dmax_s[2], dmax_s[3]));
@@ -84,19 +131,27 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
             if (v.kld_bound > 0.f && dmax > v.kld_bound) st |= SP_STATUS_DEPTH_RANGE;
             if ((v.cost_bound > 0.f && cost > v.cost_bound) || (v.cost_ratio > 0.f && first > 0.f && cost > v.cost_ratio * first)) st |= SP_STATUS_COST;
             if (v.valid_min > 0.f && ls[6] < v.valid_min) st |= SP_STATUS_VALID;
-            const int attempt = v.attempts ? v.attempts[pid] : 1;
-            const int again = (st & v.retry_mask) != 0 && attempt == 0 && sched.retry_entry >= 0 && sched.retry_entry < sched.n_phases;
+            const float seg_med = seg_med_s, seg_max = fmaxf(fmaxf(seg_max_s[0], seg_max_s[1]), fmaxf(seg_max_s[2], seg_max_s[3]));
+            if (seg_med > 0.f && ((v.seg_max_ratio > 0.f && seg_max > v.seg_max_ratio * seg_med) || (v.seg_mean_ratio > 0.f && cost > v.seg_mean_ratio * seg_med)))
+                st |= SP_STATUS_SEGMENTS;
+            // attempts[pair]: 0 = first attempt, 1 = restarted at retry_entry, 2 = restarted at retry2_entry (the last one there is)
+            const int attempt = v.attempts ? v.attempts[pid] : 2;
+            const bool failed = (st & v.retry_mask) != 0;
+            const bool has1 = sched.retry_entry >= 0 && sched.retry_entry < sched.n_phases, has2 = sched.retry2_entry >= 0 && sched.retry2_entry < sched.n_phases;
+            int again = 0;
+            if (failed && attempt == 0 && has1) again = 1;
+            else if (failed && attempt <= 1 && has2) again = 2;
             retry_s = again;
             if (again) {
-                v.attempts[pid] = 1;
-                h.phase[slot] = sched.retry_entry; h.iters[slot] = 0;
-                ls[0] = v.lam0; ls[1] = -1.f; ls[4] = 0.f; ls[7] = 0.f;       // (the iteration counts [2], [3] run on over both attempts)
+                v.attempts[pid] = again;
+                h.phase[slot] = again == 1 ? sched.retry_entry : sched.retry2_entry; h.iters[slot] = 0;
+                ls[0] = v.lam0; ls[1] = -1.f; ls[4] = 0.f; ls[7] = 0.f;       // (the iteration counts [2], [3] run on over all attempts)
                 if (v.diag) v.diag[(size_t)pid * SP_DIAG_FLOATS + 5] = 0.f;
             } else {
-                v.status[pid] = st | (attempt > 0 && v.attempts ? SP_STATUS_RETRIED : 0);
+                v.status[pid] = st | (attempt > 0 && v.attempts ? SP_STATUS_RETRIED : 0) | (attempt > 1 && v.attempts ? SP_STATUS_ADAM : 0);
                 if (v.diag) {
                     float* d = v.diag + (size_t)pid * SP_DIAG_FLOATS;
-                    d[0] = cost; d[1] = dmax; d[2] = ls[6]; d[3] = fabsf(ls[7]); d[4] = (float)(attempt + (v.attempts ? 1 : 0)); d[6] = 0.f; d[7] = 0.f;
+                    d[0] = cost; d[1] = dmax; d[2] = ls[6]; d[3] = fabsf(ls[7]); d[4] = (float)(v.attempts ? attempt + 1 : 1); d[6] = seg_med; d[7] = seg_max;
                 }
             }
         }
@@ -104,6 +159,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
         if (retry_s) {
             for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) pr.kld[n] = kld0[n];
             if (threadIdx.x < 16) pr.pose[threadIdx.x] = pose0[threadIdx.x];
+            if (sched.adam_state) {             // the moments of SP_PHASE_ADAM phases start every attempt at zero
+                float* st = sched.adam_state + (size_t)slot * (2 + 2 * (h.max_N + 8));
+                for (int i = threadIdx.x; i < 2 + 2 * (h.max_N + 8); i += SP_BLOCK) st[i] = 0.f;
+            }
             return;                             // the pair keeps its slot
         }
     }
@@ -125,6 +184,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
             reinterpret_cast<uint32_t*>(q.slot_pairs[p] + slot)[k] = reinterpret_cast<const uint32_t*>(q.qpairs[p] + next)[k];
         }
     }
+    if (sched.adam_state) {
+        float* st = sched.adam_state + (size_t)slot * (2 + 2 * (h.max_N + 8));
+        for (int i = threadIdx.x; i < 2 + 2 * (h.max_N + 8); i += SP_BLOCK) st[i] = 0.f;
+    }
     if (threadIdx.x == 0) {
         h.phase[slot] = sched.entry; h.iters[slot] = 0;
         ls[0] = q.lam0; ls[1] = -1.f; ls[2] = 0.f; ls[3] = 0.f; ls[4] = 0.f; ls[5] = 0.f; ls[6] = 0.f; ls[7] = 0.f;
@@ -140,17 +203,17 @@ __global__ void k_mark_unfinished(const int32_t* __restrict__ phase, const int32
 }
 
 // min over the per-pair phases (one workgroup): what the host polls to end a scheduled run.  out[0] = min phase, out[1] = queue head
-// (queue runs), out[2] = 1 when some unfinished pair is still at its FIRST attempt (verdict runs with a second attempt: such a pair
-// may restart at retry_entry at any time, so no work list can be left out while one exists)
+// (queue runs), out[2] = 1 when some unfinished pair has an attempt left (verdict runs with a second / third attempt: such a pair
+// may restart at retry_entry / retry2_entry at any time, so no work list can be left out while one exists)
 __global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restrict__ phase, int n, int32_t* __restrict__ out,
                                                         const int32_t* __restrict__ head, const int32_t* __restrict__ attempts,
-                                                        const int32_t* __restrict__ slot_pair, int n_phases) {
+                                                        const int32_t* __restrict__ slot_pair, int n_phases, int last_attempt) {
     __shared__ int part[SP_WAVES], first[SP_WAVES];
     int m = 0x7fffffff, f = 0;
     for (int i = threadIdx.x; i < n; i += SP_BLOCK) {
         const int ph = phase[i];
         m = min(m, ph);
-        if (attempts && ph < n_phases && attempts[slot_pair ? slot_pair[i] : i] == 0) f = 1;
+        if (attempts && ph < n_phases && attempts[slot_pair ? slot_pair[i] : i] < last_attempt) f = 1;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m = min(m, __shfl_xor(m, o, 64)); f |= __shfl_xor(f, o, 64); }
@@ -232,14 +295,16 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
 static int check_schedule(const SpSchedule* sched, const SpVerdict* v) {
     if (!sched || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
     if (sched->entry < 0 || sched->entry >= sched->n_phases || sched->retry_entry < -1 || sched->retry_entry >= sched->n_phases) return SP_EINVAL;
+    if (sched->retry2_entry < -1 || sched->retry2_entry >= sched->n_phases) return SP_EINVAL;
     for (int p = 0; p < sched->n_phases; ++p) {
         const SpPhase& ph = sched->phase[p];
         if (!ph.pairs || !ph.span_partials || !ph.seg_partials || ph.max_iters <= 0) return SP_EINVAL;
+        if ((ph.flags & SP_PHASE_ADAM) && (!sched->adam_state || !(sched->adam_lr_pose > 0.f) || !(sched->adam_lr_kld > 0.f))) return SP_EINVAL;
         if (ph.next != 0 && (ph.next <= p || ph.next > sched->n_phases)) return SP_EINVAL;      // pairs only move forward
     }
     if (v && v->status) {
         if (!v->pose0 || !v->kld0 || !v->pose_base || !v->kld_base) return SP_EINVAL;
-        if (sched->retry_entry >= 0 && v->retry_mask != 0 && !v->attempts) return SP_EINVAL;
+        if ((sched->retry_entry >= 0 || sched->retry2_entry >= 0) && v->retry_mask != 0 && !v->attempts) return SP_EINVAL;
     }
     return 0;
 }
@@ -272,7 +337,8 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
     hipStream_t s = static_cast<hipStream_t>(stream);
     const SpVerdict vd = verdict ? *verdict : SpVerdict{};
     // a second attempt restarts a pair at retry_entry at any time: no work list can be left out while a first attempt is still running
-    const bool may_retry = vd.status && vd.attempts && vd.retry_mask != 0 && sched->retry_entry >= 0;
+    const bool may_retry = vd.status && vd.attempts && vd.retry_mask != 0 && (sched->retry_entry >= 0 || sched->retry2_entry >= 0);
+    const int last_attempt = sched->retry2_entry >= 0 ? 2 : 1;
     int it = 0;
     int reached = 0;                  // a phase every slot has passed -- only meaningful once the queue is empty (refilled slots restart at the entry)
     int min_phase = 0;
@@ -287,7 +353,7 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
             if (e != hipSuccess) return -(1000 + (int)e);
         }
         hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_slots, flag_dev, queue->head, may_retry ? vd.attempts : nullptr,
-                           queue->slot_pair, sched->n_phases);
+                           queue->slot_pair, sched->n_phases, last_attempt);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -312,7 +378,8 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
     if (!sched || !phase || !iters || !flag_dev || !flag_host || check_every <= 0 || max_rounds < 0) return SP_EINVAL;
     if (int rc = check_schedule(sched, verdict)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const bool may_retry = verdict && verdict->status && verdict->attempts && verdict->retry_mask != 0 && sched->retry_entry >= 0;
+    const bool may_retry = verdict && verdict->status && verdict->attempts && verdict->retry_mask != 0 && (sched->retry_entry >= 0 || sched->retry2_entry >= 0);
+    const int last_attempt = sched->retry2_entry >= 0 ? 2 : 1;
     int it = 0;
     int reached = 0;                  // min(phase) at the last poll: pairs only move forward, so work lists behind it are not launched
     int min_phase = 0;
@@ -327,7 +394,7 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
         }
         hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_pairs, flag_dev, (const int32_t*)nullptr,
-                           may_retry ? (const int32_t*)verdict->attempts : (const int32_t*)nullptr, (const int32_t*)nullptr, sched->n_phases);
+                           may_retry ? (const int32_t*)verdict->attempts : (const int32_t*)nullptr, (const int32_t*)nullptr, sched->n_phases, last_attempt);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);

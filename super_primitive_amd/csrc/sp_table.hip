@@ -384,7 +384,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qpr = t.W >> 4;
     constexpr int BLOCK_ROWS = SP_WAVES * SP_PREP_WAVE_ROWS;
-    const SP_GLOBAL int32_t* const boxes = t.boxes;
+    // (the box hint only counts pixels INSIDE the boxes; the fill pass honours that only on its bit-word path (it then fills
+    //  from the bit words this pass writes) -- a keyframe that k_prep_fill will scan mask by mask ignores the hint, so that a mask pixel
+    //  outside its box, a contract violation, is still counted before it is filled)
+    const bool fill_reads_bits = t.bits && ((uintptr_t)t.logdepth & 15) == 0 && (long long)t.N * t.H < (1ll << 22) && t.H <= 1024;
+    const SP_GLOBAL int32_t* const boxes = fill_reads_bits ? t.boxes : nullptr;
     if (boxes && t.H >= BLOCK_ROWS) {
         // SEGMENT BOXES (SpPrepTable.boxes), the whole workgroup first (its 64 rows lie in at most two segments): most workgroups of
         // a boxed keyframe are outside every box -- a segment covers a small part of the image -- and leave with three coalesced
@@ -614,6 +618,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_scan(const SpPrepTable* _
 #define SP_FILL_ROWS 256
 
 // does the fill pass of this keyframe read the bit words the count pass wrote (k_prep_fill_bits) instead of the masks (k_prep_fill)?
+// (k_prep_row_counts spells the same condition out for its use of the segment boxes)
 __device__ __forceinline__ bool prep_fill_bits_path(const PrepTable& t) {
     return t.bits && prep_fast_path(t) && ((uintptr_t)t.logdepth & 15) == 0 && (long long)t.N * t.H < (1ll << 22) && t.H <= 1024;
 }

@@ -38,7 +38,7 @@ from .loops import GnSuppMapper, GnTracker, map_window, track_frame_fused, track
 # config/tum/odom_desk.yaml (aligment.track / aligment.mapping / kf / window_size)
 DEFAULTS = dict(track_steps=(0, 0, 300), track_levels=(0, 3), track_lr=5e-3, map_steps=500, continual_steps=10, init_steps=1000,
                 map_lr_pose=1e-4, window_size=5, supp_every_n=3, depth_validity_ratio=0.60, translation_thresh=0.2,
-                affine_compensation=True, mono_init=False, init_frames=7, motion_prior=False, persistent_supp=True)
+                affine_compensation=True, mono_init=False, init_frames=7, motion_prior=False, persistent_supp=True, map_rel_tol=1e-8)
 
 
 class _Supp:
@@ -184,7 +184,8 @@ class MonoVO:
         self.supp_mapper = None                                   # (whatever follows moves poses / depths the persistent window holds)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = map_window(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, supp, num_iters, lr_pose=lr_pose,
-                         window_size=c['window_size'], initialised=self.initialised, optimiser="gn" if self.engine == "gn" else "adam", mode=mode)
+                         window_size=c['window_size'], initialised=self.initialised, optimiser="gn" if self.engine == "gn" else "adam", mode=mode,
+                         rel_tol=c['map_rel_tol'])
         torch.cuda.synchronize(); self.secs['supp_mapping' if mode == 'supp' else 'mapping'] += time.perf_counter() - t0
         self.kf_poses = [p.clone() for p in out['kf_poses']]
         self.kf_klds = [k.clone() for k in out['klds']]
@@ -253,6 +254,12 @@ class MonoVO:
             self.reset_tracked_poses()
             self.reset_running_supp_kfs()
         assert self.current_ts == i
+        self.keyframe_stage(i)
+
+    def keyframe_stage(self, i):
+        """The tail of one pass of the driver loop (odometery.py:1056-1075): keyframe decision, creation, what it schedules.  Returns
+        (new keyframe?, the criterion's values or None)."""
+        c = self.c
         torch.cuda.synchronize(); t0 = time.perf_counter()
         new_kf, info = self.is_kf(i)
         if new_kf:
@@ -266,6 +273,7 @@ class MonoVO:
                 self.mapping(c['init_steps'], mode='init')
             else:
                 self.mapping_scheduled = True
+        return new_kf, (info[1] if info is not None else None)
 
     def run(self):
         for i in range(1, len(self.frames)):

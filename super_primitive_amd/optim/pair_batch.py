@@ -93,7 +93,21 @@ REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 # layout (replicas share replica 0's source samples: colours one ulp apart) and fails -- flagged -- as a batch of one built from its own
 # depth seeds; tests/test_gpu_sigma05.py runs both.
 REFERENCE_START_RETRY = (dict(level=2, stride=4, max_iters=30, irls_eps=1e-3, conv_tol=2e-3, pose_only=True),)
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(16.0, 12), retry_phases=REFERENCE_START_RETRY)
+# Round 6: THE THIRD ATTEMPT IS THE REFERENCE'S OWN OPTIMISER.  Thirteen of 49152 of the reference's starts on ragged masks end both
+# Gauss-Newton attempts in the second solution of the near-plane's homography (all flagged; profiles/r05_reference_start_sweep_6_*) --
+# and the real reference loop converges from them (goldens g20y: 2437 and, this round, three more).  Adam at the reference's rates and
+# budget (lr 1e-2 on the pose tangent, 1e-3 on the log-depths, 500 iterations per pyramid level coarse to fine, one optimiser over the
+# three levels: odometery/two_frame_sfm.py:116-123,128-155) brings home 12 of the 13 on the device (tools/third_attempt_probe.py,
+# profiles/r06_third_attempt_probe.txt: 500 at the coarsest level alone 10, 500 + 300 at the two coarsest 11, 300 + 200: 11): so a pair
+# that fails its verdict twice restarts from its initial values once more through SP_PHASE_ADAM phases (include/sp_hip.h) -- the same
+# cost pass, an Adam step instead of the Schur solve -- on the level's lattice, then joins the schedule at its finest joint phase and is
+# polished like everybody else.  It keeps its slot for those 1500 rounds; at 3 pairs in 10000 the throughput does not notice.
+REFERENCE_START_ADAM = (dict(level=2, stride=4, max_iters=500, irls_eps=1e-5, conv_tol=0.0, adam=True),
+                        dict(level=1, stride=2, max_iters=500, irls_eps=1e-5, conv_tol=0.0, adam=True),
+                        dict(level=0, stride=2, max_iters=500, irls_eps=1e-5, conv_tol=0.0, adam=True))
+ADAM_LR_POSE, ADAM_LR_KLD = 1e-2, 1e-3          # odometery/two_frame_sfm.py:116-123
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(16.0, 12), retry_phases=REFERENCE_START_RETRY,
+                                retry2_phases=REFERENCE_START_ADAM)
 # The verdict's thresholds (SpVerdict): a log-depth more than ``kld_bound`` from its seed (a factor e^kld_bound in depth: the reference's
 # seeds log(2 + 2 rand) are at most a factor 2 off) has run away; fewer than ``valid_min`` of the points projecting into the target
 # frame at the end of an alignment that started with both frames overlapping is a lost pair.  ``retry_on``: the status bits that send
@@ -104,9 +118,19 @@ REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_f
 # at 8-50 x the cost of the converged pairs, whose final costs lie within 1.15 x of their median (profiles/r05_reference_start.txt).  Such
 # pairs get the second attempt too (a short second scheduled run over them alone) and SP_STATUS_COST if they are still outliers.  Needs
 # at least COST_OUTLIER_MIN_PAIRS pairs; a batch of one has no median to speak of.
+# ``seg_max_ratio`` / ``seg_mean_ratio`` (round 6, SP_STATUS_SEGMENTS): THE WITHIN-PAIR TEST -- the worst segment's mean |r| against the
+# pair's own median segment, and the pair's cost against that median.  What a pair in the plane's second solution looks like from the
+# inside: some segments explained, others not.  Over the 13 known misses of 49152 ragged starts: worst / median 3.1-44, cost / median
+# 1.12-2.7 (the well-behaved local minimum of start 9847, which no other per-pair test sees: 4.4 / 1.49); over every CONVERGED pair of
+# the sweeps of round 6 (grid 64 segments, ragged 64 / 300 / 1200: 32 k pairs, profiles/r06_reference_start_*): worst / median at most
+# 2.75 / 2.96 / 3.34 / 3.78, cost / median at most 1.09 / 1.14 / 1.10 / 1.11.  Shipped: 8 and 1.3 -- the cost ratio does the work (a
+# third above the largest converged value, a seventh below 9847's), the worst-segment ratio only catches the grossly uneven.  It needs
+# no second pair: a batch of ONE is judged like a batch of thousands.  (The three misses below 1.3 -- 2437, 35432 and one more -- carry
+# run-away depths, SP_STATUS_DEPTH_RANGE.)
 COST_OUTLIER_MIN_PAIRS = 8
-VERDICT_DEFAULTS = dict(kld_bound=2.0, cost_bound=0.0, cost_ratio=0.0, valid_min=0.5, cost_outlier=4.0,
-                        retry_on=_lib.SP_STATUS_NONFINITE | _lib.SP_STATUS_LAST_CAP | _lib.SP_STATUS_DEPTH_RANGE | _lib.SP_STATUS_VALID | _lib.SP_STATUS_COST)
+VERDICT_DEFAULTS = dict(kld_bound=2.0, cost_bound=0.0, cost_ratio=0.0, valid_min=0.5, cost_outlier=4.0, seg_max_ratio=8.0, seg_mean_ratio=1.3,
+                        retry_on=_lib.SP_STATUS_NONFINITE | _lib.SP_STATUS_LAST_CAP | _lib.SP_STATUS_DEPTH_RANGE | _lib.SP_STATUS_VALID | _lib.SP_STATUS_COST
+                        | _lib.SP_STATUS_SEGMENTS)
 
 
 def _level_images(img, max_level):
@@ -415,6 +439,7 @@ class PairBatch:
         mark('workspaces')
         self.reset_lm()
         self._graphs = {}
+        self._flags_more, self._side_streams = [], []
         self._flag = None
         self._verdict_arrays = None
         self.status = None
@@ -571,7 +596,8 @@ class PairBatch:
 
     def schedule(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, irls_eps=1e-3, phases=None,
                  use_coarse=True, pose_first_iters=0, pose_first_eps=None, joint_levels=None, use_levels=None, retry_pose_first=None,
-                 retry_phases=None, retry_join=None, depth_damp=None, coarse_damped=None):
+                 retry_phases=None, retry_join=None, depth_damp=None, coarse_damped=None, retry2_phases=None, retry2_join=None,
+                 adam_lr_pose=ADAM_LR_POSE, adam_lr_kld=ADAM_LR_KLD, predicted_exit=False):
         """The coarse-to-fine phases of ``run_converging`` as the ``SpSchedule`` of sp_pairs_schedule_* (host memory); levels
         built with a ``point_stride`` run on their decimated point set unless ``use_coarse=False``.  ``phases``: an explicit
         list of dict(level, stride, max_iters, irls_eps, conv_tol) instead (every (level, stride > 1) needs its table:
@@ -589,7 +615,15 @@ class PairBatch:
         THE SECOND ATTEMPT (SpSchedule.retry_entry, SpVerdict): ``retry_phases`` -- a list of phase dicts like ``phases`` -- or its
         shorthand ``retry_pose_first`` = ((level, cap), ...), pose-only phases -- are what a pair that fails its verdict runs FIRST when it
         is put back to its start, before it joins the list above at phase ``retry_join`` (default: the first phase that is not pose-only).
-        They sit in front of the list in the SpSchedule; a first attempt enters behind them."""
+        They sit in front of the list in the SpSchedule; a first attempt enters behind them.
+
+        THE THIRD ATTEMPT (SpSchedule.retry2_entry): ``retry2_phases`` -- phase dicts with ``adam=True`` (SP_PHASE_ADAM: one Adam step of
+        the reference's optimiser per iteration at ``adam_lr_pose`` / ``adam_lr_kld`` instead of a Gauss-Newton step; ``max_iters`` is the
+        budget, there is no convergence test) -- are what a pair runs when its second attempt fails too, from its initial values again,
+        before it joins the list at phase ``retry2_join`` (default: the last phase in front of the polish, i.e. the finest joint phase).
+        ``adam=True`` phases may also stand in ``phases`` / ``retry_phases``.  ``predicted_exit`` (SP_PHASE_PREDICTED_EXIT; per phase dict
+        or for all phases): a pair leaves a phase right after a step PREDICTED to buy less than the phase's tolerance, without the evaluation
+        that confirms it."""
         if phases is None:
             phases = []
             caps = tuple(pose_first_iters) if isinstance(pose_first_iters, (tuple, list)) else ((int(pose_first_iters),) if pose_first_iters > 0 else ())
@@ -624,7 +658,12 @@ class PairBatch:
             if retry_join is None:
                 retry_join = next((i for i, ph in enumerate(phases) if not ph.get("pose_only", False)), 0)
             assert 0 <= int(retry_join) < len(phases)
-        all_phases = retry_phases + list(phases)
+        retry2_phases = list(retry2_phases or [])
+        if retry2_phases:
+            if retry2_join is None:
+                retry2_join = max(0, len(phases) - 2)
+            assert 0 <= int(retry2_join) < len(phases)
+        all_phases = retry2_phases + retry_phases + list(phases)
         if len(all_phases) > _lib.SP_MAX_PHASES:
             raise ValueError(f"{len(all_phases)} phases exceed SP_MAX_PHASES = {_lib.SP_MAX_PHASES}")
         sched = _lib.SpSchedule()
@@ -643,15 +682,26 @@ class PairBatch:
             if not 0 <= damp <= 255:
                 raise ValueError("depth_damp: 0 .. 31.875 in steps of 1/8")
             ph.flags = ((_lib.SP_PHASE_POSE_ONLY if spec.get("pose_only", False) else 0) | (_lib.SP_PHASE_WAVE_SPANS if self.wave_flag else 0)
-                        | (_lib.SP_PHASE_DEPTH_TABLE if self.table_flag else 0) | (damp << _lib.SP_PHASE_DEPTH_DAMP_SHIFT))
+                        | (_lib.SP_PHASE_DEPTH_TABLE if self.table_flag else 0) | (damp << _lib.SP_PHASE_DEPTH_DAMP_SHIFT)
+                        | (_lib.SP_PHASE_ADAM if spec.get("adam", False) else 0)
+                        | (_lib.SP_PHASE_PREDICTED_EXIT if spec.get("predicted_exit", predicted_exit) else 0))
             ph.next = 0
+        n2, n1 = len(retry2_phases), len(retry_phases)
         sched.n_phases = len(all_phases)
-        sched.entry = len(retry_phases)
+        sched.entry = n2 + n1
         sched.retry_entry = -1
+        sched.retry2_entry = -1
         if retry_phases:
-            sched.retry_entry = 0
-            join = len(retry_phases) + int(retry_join)
-            sched.phase[len(retry_phases) - 1].next = join if join != len(retry_phases) else 0
+            sched.retry_entry = n2
+            join = n2 + n1 + int(retry_join)
+            sched.phase[n2 + n1 - 1].next = join if join != n2 + n1 else 0
+        if retry2_phases:
+            sched.retry2_entry = 0
+            sched.phase[n2 - 1].next = n2 + n1 + int(retry2_join)          # (never the following phase unless there is no second attempt and join 0)
+            if sched.phase[n2 - 1].next == n2:
+                sched.phase[n2 - 1].next = 0
+        sched.adam_lr_pose, sched.adam_lr_kld = float(adam_lr_pose), float(adam_lr_kld)
+        sched.adam_state = self.adam_state.data_ptr() if any(spec.get("adam", False) for spec in all_phases) else None
         return sched
 
     def _verdict(self, sched, verdict):
@@ -672,8 +722,14 @@ class PairBatch:
         v.status, v.diag, v.attempts = status.data_ptr(), diag.data_ptr(), attempts.data_ptr()
         v.pose0, v.kld0, v.pose_base, v.kld_base = pose0.data_ptr(), kld0.data_ptr(), self.pose.data_ptr(), self.kld.data_ptr()
         v.kld_bound, v.cost_bound, v.cost_ratio, v.valid_min = float(opt["kld_bound"]), float(opt["cost_bound"]), float(opt["cost_ratio"]), float(opt["valid_min"])
-        v.retry_mask = int(opt["retry_on"]) if sched.retry_entry >= 0 else 0
+        v.retry_mask = int(opt["retry_on"]) if (sched.retry_entry >= 0 or sched.retry2_entry >= 0) else 0
         v.lam0 = float(getattr(self, "_lam0", 1e-4))
+        v.seg_max_ratio, v.seg_mean_ratio = float(opt["seg_max_ratio"]), float(opt["seg_mean_ratio"])
+        # (diagnostics, ``count_evaluations=True`` in the verdict options: cost evaluations per pair and phase -> ``self.evals`` (M, SP_MAX_PHASES))
+        self.evals = None
+        if opt.get("count_evaluations", False):
+            self.evals = torch.zeros(self.M, _lib.SP_MAX_PHASES, dtype=torch.int32, device=self.device)
+            v.evals = self.evals.data_ptr()
         self.status, self.attempts, self.diag = status, attempts, diag
         return v
 
@@ -685,7 +741,7 @@ class PairBatch:
             raise RuntimeError("no verdict: run_scheduled(verdict=False), or no scheduled run yet")
         return (self.status & _lib.SP_STATUS_FAILED) != 0
 
-    def run_scheduled(self, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7, slots=None, verdict=None, return_status=False, **schedule_kw):
+    def run_scheduled(self, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7, slots=None, verdict=None, return_status=False, streams=1, **schedule_kw):
         """``run_converging`` with the schedule itself on the device: every pair walks through ITS OWN coarse-to-fine phases
         (sp_pairs_schedule_cost / sp_pairs_schedule_gn_step), moving to the next level the moment it converges instead of
         waiting for the slowest pair of the batch, and the host only polls ``min(phase)`` every ``check_every`` iterations.
@@ -705,17 +761,22 @@ class PairBatch:
         but the very last ones works on a FULL resident set instead of a thinning one (a scheduled batch otherwise ends in a tail: its
         last 10 % of pairs iterate almost alone for a third of the launches).  The pairs may have DIFFERENT padded layouts (ragged segment
         sets): the cost pass runs over virtual spans, as many per slot as the largest pair has.  Every pair's result is bitwise the one it
-        gets with all pairs resident."""
+        gets with all pairs resident.  ``streams`` = K > 1 (queue runs): the slots are driven as K groups on K HIP streams by K host
+        loops that share the one queue -- same results per pair, the groups fill each other's launch gaps and tails."""
         sched = self.schedule(**schedule_kw)
         # (a second attempt can spend the phases in front of the entry as well)
-        bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases)) + (sum(sched.phase[p].max_iters for p in range(sched.entry, sched.n_phases)) if sched.retry_entry >= 0 else 0)
+        # (every later attempt can spend the phases in front of the entry and then the list proper once more)
+        tail = sum(sched.phase[p].max_iters for p in range(sched.entry, sched.n_phases))
+        bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases)) + tail * ((sched.retry_entry >= 0) + (sched.retry2_entry >= 0))
         if self._flag is None:
             self._flag = (torch.zeros(4, dtype=torch.int32, device=self.device), torch.zeros(4, dtype=torch.int32).pin_memory())
         v = self._verdict(sched, verdict)
         v_addr = ctypes.addressof(v) if v is not None else None
         outlier = float(dict(VERDICT_DEFAULTS, **(verdict if isinstance(verdict, dict) else {}))["cost_outlier"]) if v is not None else 0.0
+        if sched.adam_state:
+            self.adam_state.zero_()
         if slots is not None and int(slots) < self.M:
-            it = self._run_queue(sched, int(slots), bound, check_every, lm_up, lm_down, lm_min, v, v_addr)
+            it = self._run_queue(sched, int(slots), bound, check_every, lm_up, lm_down, lm_min, v, v_addr, streams=streams, schedule_kw=schedule_kw)
             if outlier > 0.0 and self.M >= COST_OUTLIER_MIN_PAIRS:
                 it += self._cost_outlier_pass(outlier, v, bound, check_every, lm_up, lm_down, lm_min, schedule_kw)
             return (it, self.status) if return_status else it
@@ -737,43 +798,61 @@ class PairBatch:
 
     def _cost_outlier_pass(self, factor, v, bound, check_every, lm_up, lm_down, lm_min, schedule_kw):
         """The batch-relative part of the verdict (VERDICT_DEFAULTS['cost_outlier']), after the scheduled run proper: pairs that passed
-        their own verdict with a final cost above ``factor`` x the batch median get the second attempt too -- put back to their starting
-        point, run through the retry phases in a short scheduled run of their own (everybody else is finished: their workgroups return at
-        once) -- and whoever is an outlier after that carries SP_STATUS_COST.  All on the device, no synchronisation beyond the run's own
-        polls.  Returns the iterations launched."""
+        their own verdict with a final cost above ``factor`` x the batch median get their next attempt too -- put back to their starting
+        point and run through the retry phases (the second attempt's, or the third's for a pair that has had its second) in a short
+        scheduled run of their own (everybody else is finished: their workgroups return at once) -- and whoever is an outlier after
+        its last attempt carries SP_STATUS_COST.  The median is taken over the pairs that FINISHED CLEANLY with a finite cost (ADVICE
+        r05: one NaN cost made the median NaN and switched the test off for the whole batch; unfinished pairs pulled it down); fewer
+        than COST_OUTLIER_MIN_PAIRS of those: no test.  No second run is issued when nobody retries.  Returns the iterations launched."""
         F, M = _lib.SP_STATUS_FAILED, self.M
         cost = self.diag[:, 0]
-        bound_c = factor * cost.median()
-        out = (cost > bound_c) & ((self.status & F) == 0)
+        clean = ((self.status & F) == 0) & torch.isfinite(cost) & (cost > 0)
+        n_clean = int(clean.sum())
+        if n_clean < COST_OUTLIER_MIN_PAIRS:
+            return 0
+        bound_c = factor * cost[clean].median()
         it = 0
         sched = self.schedule(**schedule_kw)
-        if sched.retry_entry >= 0:
-            again = out & (self.attempts == 0)
+        entries = [e for e in (sched.retry_entry, sched.retry2_entry) if e >= 0]
+        for _ in range(len(entries)):
+            out = (self.diag[:, 0] > bound_c) & ((self.status & F) == 0)
+            # (an outlier restarts at the attempt after the last one it has made: attempts 0 -> retry_entry, 1 -> retry2_entry)
+            nxt = torch.full_like(self.attempts, -1)
+            if sched.retry_entry >= 0:
+                nxt = torch.where(self.attempts == 0, 1, nxt)
+            if sched.retry2_entry >= 0:
+                nxt = torch.where((self.attempts == 1) | ((self.attempts == 0) & (nxt < 0)), 2, nxt)
+            again = out & (nxt > 0)
+            if not bool(again.any()):
+                break
             if getattr(self, "_seg_pair", None) is None:
                 self._seg_pair = torch.repeat_interleave(torch.arange(M, device=self.device), torch.as_tensor(self.Ns, device=self.device))
             pose0, kld0 = self._verdict_arrays[3], self._verdict_arrays[4]
             self.pose.copy_(torch.where(again[:, None], pose0, self.pose))
             self.kld.copy_(torch.where(again[self._seg_pair], kld0, self.kld))
-            self.attempts.add_(again.to(torch.int32))
-            self.phase.copy_(torch.where(again, sched.retry_entry, sched.n_phases).to(torch.int32))
+            self.attempts.copy_(torch.where(again, nxt, self.attempts))
+            entry = torch.where(nxt == 1, sched.retry_entry, sched.retry2_entry)
+            self.phase.copy_(torch.where(again, entry, sched.n_phases).to(torch.int32))
             self.phase_iters.zero_()
             ls = self.lm_state
             ls[:, 0] = torch.where(again, float(getattr(self, "_lam0", 1e-4)), ls[:, 0])
-            ls[:, 1] = -1.0
+            ls[:, 1] = torch.where(again, -1.0, ls[:, 1])
             ls[:, 4:] = torch.where(again[:, None], 0.0, ls[:, 4:])
             self.diag[:, 5] = torch.where(again, 0.0, self.diag[:, 5])
-            v.retry_mask = 0                       # (whoever runs now has had its first attempt)
-            it = self.lib.sp_pairs_schedule_run(ctypes.addressof(sched), M, self.max_N, float(lm_up), float(lm_down), float(lm_min),
-                                                _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.ptr(self.phase),
-                                                _lib.ptr(self.phase_iters), int(check_every), int(bound), _lib.ptr(self._flag[0]),
-                                                self._flag[1].data_ptr(), ctypes.addressof(v), _lib.stream_ptr())
-            if it < 0:
-                _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run")
-            out = (self.diag[:, 0] > bound_c) & ((self.status & F) == 0)
+            if sched.adam_state:
+                self.adam_state.zero_()
+            n = self.lib.sp_pairs_schedule_run(ctypes.addressof(sched), M, self.max_N, float(lm_up), float(lm_down), float(lm_min),
+                                               _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs), _lib.ptr(self.phase),
+                                               _lib.ptr(self.phase_iters), int(check_every), int(bound), _lib.ptr(self._flag[0]),
+                                               self._flag[1].data_ptr(), ctypes.addressof(v), _lib.stream_ptr())
+            if n < 0:
+                _lib.check(n if n > -1000 else -(n + 1000), "sp_pairs_schedule_run")
+            it += n
+        out = (self.diag[:, 0] > bound_c) & ((self.status & F) == 0)
         self.status.bitwise_or_(out.to(torch.int32) * _lib.SP_STATUS_COST)
         return it
 
-    def _run_queue(self, sched, slots, bound, check_every, lm_up, lm_down, lm_min, v, v_addr):
+    def _run_queue(self, sched, slots, bound, check_every, lm_up, lm_down, lm_min, v, v_addr, streams=1, schedule_kw=None):
         assert slots >= 1
         M, dev = self.M, self.device
         rec = ctypes.sizeof(_lib.SpPair)
@@ -786,26 +865,17 @@ class PairBatch:
         spans_of = {_lib.ptr(self.spans).value: most(self._s_off)}
         for lay in self.coarse.values():
             spans_of[_lib.ptr(lay.spans).value] = most(lay.s_off)
-        q = _lib.SpQueue()
-        slot_desc = {}
-        keep = []
-        for p in range(sched.n_phases):
-            ph = sched.phase[p]
-            full_ptr = ph.pairs
-            if full_ptr not in slot_desc:
-                full = next(t for t in list(self.desc.values()) + [lay.desc for lay in self.coarse.values()] if t.data_ptr() == full_ptr)
-                slot_desc[full_ptr] = full[: slots * rec].clone()
-                keep.append(full)
-            q.qpairs[p] = full_ptr
-            q.slot_pairs[p] = slot_desc[full_ptr].data_ptr()
-            ph.pairs = slot_desc[full_ptr].data_ptr()
-            ms = spans_of[ph.spans] if ph.n_spans > 0 else 0
-            q.max_spans[p] = (ms + 3) // 4 * 4 if wave else ms
+        # SEVERAL STREAMS (round 6): the slots are cut into `streams` groups, each driven by its own host loop (a thread in
+        # sp_pairs_schedule_run_queue: the foreign call releases the interpreter lock) on its own HIP stream, all taking pairs off the ONE
+        # queue (`head` is shared; a pair's partial records, unknowns and verdict are its own wherever it runs).  The launches of one group
+        # fill the other's launch gaps, poll waits and the tails of its cost passes: a round of ONE group leaves a tenth of the GPU's
+        # time unused (profiles/r06_schedule_kernel_stats.csv: 89 % busy)
+        n_groups = max(1, min(int(streams), slots))
+        cuts = [slots * g // n_groups for g in range(n_groups + 1)]
         head = torch.tensor([slots], dtype=torch.int32, device=dev)
         slot_pair = torch.arange(slots, dtype=torch.int32, device=dev)
         q_costs = torch.zeros(M, dtype=torch.float32, device=dev)
         q_lm = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
-        q.n_queue, q.head, q.slot_pair, q.q_costs, q.q_lm, q.lam0 = M, head.data_ptr(), slot_pair.data_ptr(), q_costs.data_ptr(), q_lm.data_ptr(), lam0
         self.phase.fill_(sched.n_phases)            # (the per-slot arrays are the first `slots` entries of the batch's per-pair ones)
         self.phase[:slots] = sched.entry
         self.phase_iters.zero_()
@@ -813,17 +883,74 @@ class PairBatch:
         self.lm_state[:, 0] = lam0
         self.lm_state[:, 1] = -1.0
         rounds = bound * (-(-M // slots) + 1)
-        it = self.lib.sp_pairs_schedule_run_queue(ctypes.addressof(sched), ctypes.addressof(q), slots, self.max_N, float(lm_up), float(lm_down),
-                                                  float(lm_min), _lib.ptr(self.lm_state), _lib.ptr(self.backup), _lib.ptr(self._costs),
-                                                  _lib.ptr(self.phase), _lib.ptr(self.phase_iters), int(check_every), int(rounds),
-                                                  _lib.ptr(self._flag[0]), self._flag[1].data_ptr(), v_addr, _lib.stream_ptr())
-        if it < 0:
-            _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run_queue")
+        while len(self._flags_more) < n_groups - 1:
+            self._flags_more.append((torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32).pin_memory()))
+        flags = [self._flag] + self._flags_more[: n_groups - 1]
+        keep, groups = [], []
+        for g in range(n_groups):
+            lo, n_g = cuts[g], cuts[g + 1] - cuts[g]
+            sg = sched if g == 0 else self.schedule(**(schedule_kw or {}))
+            q = _lib.SpQueue()
+            slot_desc = {}
+            for p in range(sg.n_phases):
+                ph = sg.phase[p]
+                full_ptr = ph.pairs
+                if full_ptr not in slot_desc:
+                    full = next(t for t in list(self.desc.values()) + [lay.desc for lay in self.coarse.values()] if t.data_ptr() == full_ptr)
+                    slot_desc[full_ptr] = full[lo * rec: (lo + n_g) * rec].clone()
+                    keep.append(full)
+                q.qpairs[p] = full_ptr
+                q.slot_pairs[p] = slot_desc[full_ptr].data_ptr()
+                ph.pairs = slot_desc[full_ptr].data_ptr()
+                ms = spans_of[ph.spans] if ph.n_spans > 0 else 0
+                q.max_spans[p] = (ms + 3) // 4 * 4 if wave else ms
+            q.n_queue, q.head, q.slot_pair, q.q_costs, q.q_lm, q.lam0 = M, head.data_ptr(), slot_pair[lo:].data_ptr(), q_costs.data_ptr(), q_lm.data_ptr(), lam0
+            if sg.adam_state:
+                sg.adam_state = self.adam_state[lo:].data_ptr()
+            keep.append(slot_desc)
+            groups.append((sg, q, lo, n_g))
+
+        def drive(g, stream):
+            sg, q, lo, n_g = groups[g]
+            return self.lib.sp_pairs_schedule_run_queue(ctypes.addressof(sg), ctypes.addressof(q), n_g, self.max_N, float(lm_up), float(lm_down),
+                                                        float(lm_min), _lib.ptr(self.lm_state[lo:]), _lib.ptr(self.backup[lo:]), _lib.ptr(self._costs[lo:]),
+                                                        _lib.ptr(self.phase[lo:]), _lib.ptr(self.phase_iters[lo:]), int(check_every), int(rounds),
+                                                        _lib.ptr(flags[g][0]), flags[g][1].data_ptr(), v_addr, stream)
+
+        if n_groups == 1:
+            its = [drive(0, _lib.stream_ptr())]
+        else:
+            import threading
+            main = torch.cuda.current_stream()
+            while len(self._side_streams) < n_groups - 1:
+                self._side_streams.append(torch.cuda.Stream(device=dev))
+            side = self._side_streams[: n_groups - 1]
+            its = [0] * n_groups
+            for st in side:
+                st.wait_stream(main)
+
+            def work(g):
+                torch.cuda.set_device(dev)             # (a new host thread starts on device 0)
+                its[g] = drive(g, ctypes.c_void_p(side[g - 1].cuda_stream))
+
+            threads = [threading.Thread(target=work, args=(g,)) for g in range(1, n_groups)]
+            for t in threads:
+                t.start()
+            its[0] = drive(0, _lib.stream_ptr())
+            for t in threads:
+                t.join()
+            for st in side:
+                main.wait_stream(st)
+        for it in its:
+            if it < 0:
+                _lib.check(it if it > -1000 else -(it + 1000), "sp_pairs_schedule_run_queue")
+        it = max(its)
         # results per PAIR (what the per-slot arrays hold is whichever pairs came last)
-        min_phase, taken = int(self._flag[1][0]), min(int(self._flag[1][1]), M)
+        min_phase = min(int(f[1][0]) for f in flags)
+        taken = min(max(int(f[1][1]) for f in flags), M)
         self._costs.copy_(q_costs)
         self.lm_state.copy_(q_lm)
-        self._queue_stats = dict(slots=slots, head=taken, slot_pair=slot_pair, finished=min_phase >= sched.n_phases)
+        self._queue_stats = dict(slots=slots, head=taken, slot_pair=slot_pair, finished=min_phase >= sched.n_phases, rounds_by_stream=list(its))
         if min_phase < sched.n_phases:
             #  the run hit its round limit: pairs still in a slot carry SP_STATUS_UNFINISHED (set by the library), pairs that never
             # got a slot are marked here; without a verdict there is no way to tell the caller per pair, so that is an error
@@ -879,6 +1006,34 @@ class PairBatch:
 
     def klds(self):
         return [self.kld[self.n_off[m]: self.n_off[m + 1]] for m in range(self.M)]
+
+    def schedule_traffic(self, **schedule_kw):
+        """ALGORITHMIC bytes of the last scheduled run (``run_scheduled(verdict=dict(count_evaluations=True), **schedule_kw)``): every
+        cost evaluation of every pair in every phase (``self.evals``) priced like the level-0 pass is: 20 B per point of
+        the phase's point set + 12 B per pixel of the phase's target level.  Returns dict(total_bytes, evaluations, phases=[dict(phase, level,
+        stride, kind, evaluations, bytes)])."""
+        assert getattr(self, "evals", None) is not None, "run_scheduled(verdict=dict(count_evaluations=True)) first"
+        sched = self.schedule(**schedule_kw)
+        ev = self.evals.cpu().numpy().astype(np.float64)
+        where = {self.desc[l].data_ptr(): (l, 1) for l in list(self.desc.keys())}
+        where.update({lay.desc.data_ptr(): key for key, lay in self.coarse.items()})
+        phases, total = [], 0.0
+        for p in range(sched.n_phases):
+            level, stride = where[sched.phase[p].pairs]
+            pts = np.asarray(self.Ps if stride == 1 else self.coarse[(level, stride)].points, dtype=np.float64)
+            hw = np.asarray(self.level_hw[level], dtype=np.float64)
+            per_pair = 20.0 * pts + 12.0 * hw[:, 0] * hw[:, 1]
+            fl = sched.phase[p].flags
+            kind = ("adam" if fl & _lib.SP_PHASE_ADAM else "pose-only" if fl & _lib.SP_PHASE_POSE_ONLY else
+                    "damped" if (fl >> _lib.SP_PHASE_DEPTH_DAMP_SHIFT) & 0xff else "joint")
+            if p == sched.n_phases - 1 and stride == 1:
+                kind = "polish"
+            nbytes = float((ev[:, p] * per_pair).sum())
+            total += nbytes
+            phases.append(dict(phase=p, level=int(level), stride=int(stride), kind=kind, attempt=("third" if p < max(sched.retry_entry, 0) and sched.retry2_entry >= 0 else
+                                                                                                   "second" if p < sched.entry else "first"),
+                               evaluations=int(ev[:, p].sum()), bytes=nbytes, bytes_per_evaluation=float(per_pair.mean())))
+        return dict(total_bytes=total, evaluations=int(ev.sum()), phases=phases)
 
     def algorithmic_bytes(self, level):
         """20 B per segment pixel + 12 B per target-image pixel, per pair per iteration."""

@@ -213,6 +213,62 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
             kp_rc[k, 0] = min(max(kp_rc[k, 0], 0), H - 1)
             kp_rc[k, 1] = min(max(kp_rc[k, 1], 0), W - 1)
             masks[k, kp_rc[k, 0], kp_rc[k, 1]] = True
+    elif shape == "sam":
+        # SAM-REALISTIC SEGMENT SETS (round 6; what the reference's frontend emits: frontend/segment/mask_generation.py:143-312 -> masks of
+        # any size from tens of pixels to a third of the frame, nested, with holes; post_processer.py:160-181 splits what is not connected,
+        # so N differs from keyframe to keyframe): areas log-uniform between 30 px and 0.3 HW (a power law: many small masks, a few large
+        # ones) scaled towards a total coverage of ``blob_coverage`` image areas; a fifth of the masks have a HOLE, a fifth sit NESTED
+        # inside a larger one, a tenth consist of two separate lobes and are SPLIT into their connected components like the reference's
+        # post-processing does.  N is what comes out (the nominal N is the number of masks drawn).
+        from scipy import ndimage
+        rho = 1.2 if blob_coverage is None else float(blob_coverage)
+        a_min, a_max = 30.0, 0.3 * H * W
+        areas = np.exp(rng.uniform(math.log(a_min), math.log(a_max), N))
+        for _ in range(8):
+            areas = np.clip(areas * (rho * H * W / areas.sum()), a_min, a_max)
+
+        def ellipse(cr, cc, a, b, ang):
+            dr, dc = rows - cr, cols - cc
+            u = (dc * math.cos(ang) + dr * math.sin(ang)) / max(a, 0.6)
+            v = (-dc * math.sin(ang) + dr * math.cos(ang)) / max(b, 0.6)
+            return (u * u + v * v) <= 1.0
+
+        parts = []
+        for k in np.argsort(-areas):                        # large first: a nested mask picks its parent among those drawn before
+            A, kind = float(areas[k]), rng.uniform()
+            aspect, ang = rng.uniform(1.0, 3.0), rng.uniform(0, math.pi)
+            b_ax = math.sqrt(A / (math.pi * aspect))
+            a_ax = aspect * b_ax
+            if kind < 0.2 and parts:
+                pr, pc = np.nonzero(parts[int(rng.integers(len(parts)))])
+                j = int(rng.integers(len(pr)))
+                cr, cc = float(pr[j]), float(pc[j])
+            else:
+                cr, cc = rng.uniform(0.05 * H, 0.95 * H), rng.uniform(0.05 * W, 0.95 * W)
+            if 0.4 <= kind < 0.5 and A > 200:               # two lobes
+                d = 1.6 * a_ax / math.sqrt(2.0)
+                off_r, off_c = d * math.sin(ang), d * math.cos(ang)
+                m = ellipse(cr - off_r, cc - off_c, a_ax / math.sqrt(2.0), b_ax / math.sqrt(2.0), ang) | \
+                    ellipse(cr + off_r, cc + off_c, a_ax / math.sqrt(2.0), b_ax / math.sqrt(2.0), ang)
+            else:
+                m = ellipse(cr, cc, a_ax, b_ax, ang)
+                if 0.2 <= kind < 0.4 and A > 400:           # a hole
+                    f = rng.uniform(0.3, 0.6)
+                    m &= ~ellipse(cr + 0.15 * b_ax * rng.standard_normal(), cc + 0.15 * b_ax * rng.standard_normal(), f * a_ax, f * b_ax, ang)
+            lab, n_lab = ndimage.label(m)
+            for c in range(1, n_lab + 1):
+                part = lab == c
+                if part.sum() >= 16:
+                    parts.append(part)
+        if not parts:
+            parts = [ellipse(0.5 * H, 0.5 * W, 0.2 * W, 0.2 * H, 0.0)]
+        N = len(parts)
+        masks = np.stack(parts)
+        kp_rc = np.zeros((N, 2), dtype=np.int64)
+        for k in range(N):                                  # keypoint: the mask pixel nearest the centroid (a ring's centroid is in its hole)
+            pr, pc = np.nonzero(masks[k])
+            j = int(np.argmin((pr - pr.mean()) ** 2 + (pc - pc.mean()) ** 2))
+            kp_rc[k] = (pr[j], pc[j])
     else:
         raise ValueError(shape)
 

@@ -51,7 +51,8 @@ def assemble_gn(batch, level=0, eps=1e-3):
             H[6 + seg, :6] += q[0:6]
             H[6 + seg, 6 + seg] += q[6]
             b[6 + seg] += q[7]
-        out.append(dict(H=H, b=b, cost=p[0] / (3.0 * batch.Ps[m]), n_valid=p[28]))
+        mine = segp[seg_rec[:, 0] == m]
+        out.append(dict(H=H, b=b, cost=p[0] / (3.0 * batch.Ps[m]), n_valid=p[28], seg_abs_sum=mine[:, 8].sum(), seg_valid_sum=mine[:, 9].sum(), abs_sum=p[0]))
     return out
 
 
@@ -391,9 +392,17 @@ def test_results_do_not_depend_on_how_chunks_are_grouped_into_spans():
             assert batch.n_spans == batch.n_chunks
             continue
         assert batch.n_spans < batch.n_chunks and batch.n_chunks * 4 == batch.n_seg_records
-        assert torch.equal(seg_cols, want[1])
+        # (ABI 13: a segment record is 12 floats -- [0..7] the Gauss-Newton sums, produced per chunk and wave: bitwise; [8], [9] the
+        #  record's own sum |r| and valid points, taken as DIFFERENCES of the span's running sums: fp32 noise of the sum |r|, the count exact;
+        #  [10], [11] unused)
+        NS = _lib.SP_GN_SEG_FLOATS
+        sc, sw = seg_cols.reshape(-1, NS), want[1].reshape(-1, NS)
+        assert torch.equal(sc[:, :8], sw[:, :8]) and torch.equal(sc[:, 9], sw[:, 9])
+        np.testing.assert_allclose(npy(sc[:, 8]), npy(sw[:, 8]), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(npy(g), npy(want[2]), rtol=2e-6)
         for a, b in zip(systems, want[0]):
+            # the per-segment cost columns add up to the pair's own sums (what the verdict's within-pair test relies on)
+            assert a["seg_valid_sum"] == a["n_valid"] and abs(a["seg_abs_sum"] - a["abs_sum"]) <= 1e-4 * a["abs_sum"]
             scale = np.abs(b["H"]).max()
             assert np.abs(a["H"] - b["H"]).max() <= 2e-6 * scale
             assert np.abs(a["b"] - b["b"]).max() <= 2e-6 * np.abs(b["b"]).max()

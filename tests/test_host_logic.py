@@ -51,11 +51,16 @@ def test_abi_constants_and_struct_layout_match_header():
     assert ctypes.sizeof(_lib.SpPhase) == 64 and _lib.SpPhase.n_spans.offset == 40 and _lib.SpPhase.conv_tol.offset == 52
     assert _lib.SpPhase.flags.offset == 56
     assert _lib.SpPhase.next.offset == 60
-    assert ctypes.sizeof(_lib.SpSchedule) == 528 and _lib.SpSchedule.n_phases.offset == 512 and _lib.SpSchedule.retry_entry.offset == 520
-    assert ctypes.sizeof(_lib.SpVerdict) == 80 and _lib.SpVerdict.kld_bound.offset == 56 and _lib.SpVerdict.lam0.offset == 76
-    assert ctypes.sizeof(_lib.SpQueue) == 208 and _lib.SpQueue.max_spans.offset == 128 and _lib.SpQueue.head.offset == 168
-    for macro in ("SP_STATUS_NONFINITE", "SP_STATUS_LAST_CAP", "SP_STATUS_DEPTH_RANGE", "SP_STATUS_COST", "SP_STATUS_VALID", "SP_STATUS_RETRIED",
-                  "SP_STATUS_UNFINISHED", "SP_DIAG_FLOATS"):
+    # (ABI 13: 12 phases, the third attempt's entry, the Adam phases' rates and moments; the within-pair thresholds of the verdict)
+    assert ctypes.sizeof(_lib.SpSchedule) == 800 and _lib.SpSchedule.n_phases.offset == 768 and _lib.SpSchedule.retry_entry.offset == 776
+    assert _lib.SpSchedule.retry2_entry.offset == 780 and _lib.SpSchedule.adam_lr_pose.offset == 784 and _lib.SpSchedule.adam_state.offset == 792
+    assert ctypes.sizeof(_lib.SpVerdict) == 96 and _lib.SpVerdict.evals.offset == 88 and _lib.SpVerdict.kld_bound.offset == 56 and _lib.SpVerdict.lam0.offset == 76
+    assert _lib.SpVerdict.seg_max_ratio.offset == 80 and _lib.SpVerdict.seg_mean_ratio.offset == 84
+    assert ctypes.sizeof(_lib.SpQueue) == 288 and _lib.SpQueue.max_spans.offset == 192 and _lib.SpQueue.head.offset == 248
+    for macro in ("SP_GN_SEG_FLOATS", "SP_GNA_SEG_FLOATS", "SP_PHASE_ADAM", "SP_VERDICT_SEGMENTS", "SP_VERDICT_SEGMENT_POINTS", "SP_VERDICT_MIN_SEGMENTS"):
+        assert int(re.search(r"#define\s+" + macro + r"\s+(\d+)", header).group(1)) == getattr(_lib, macro), macro
+    for macro in ("SP_STATUS_NONFINITE", "SP_STATUS_LAST_CAP", "SP_STATUS_DEPTH_RANGE", "SP_STATUS_COST", "SP_STATUS_VALID", "SP_STATUS_SEGMENTS",
+                  "SP_STATUS_RETRIED", "SP_STATUS_ADAM", "SP_STATUS_UNFINISHED", "SP_DIAG_FLOATS"):
         assert int(re.search(r"#define\s+" + macro + r"\s+(0x[0-9a-fA-F]+|\d+)", header).group(1), 0) == getattr(_lib, macro), macro
     assert int(re.search(r"#define\s+SP_PHASE_POSE_ONLY\s+(\d+)", header).group(1)) == _lib.SP_PHASE_POSE_ONLY
 

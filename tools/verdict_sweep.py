@@ -40,9 +40,17 @@ po = lambda level, stride, cap, eps=ie: dict(level=level, stride=stride, max_ite
 pol = dict(level=0, stride=1, max_iters=15, irls_eps=1e-5, conv_tol=1e-4)
 def damped(damp, cap, tol=ct, second_L2=True, eps=ie):
     return [po(2, 4, 15, 1e-2), dict(level=2, stride=4, max_iters=cap, irls_eps=eps, conv_tol=tol, depth_damp=damp)] + ([jt(2, 4)] if second_L2 else []) + [jt(1, 2), jt(0, 2), pol]
+adam = lambda level, stride, n=500, eps=1e-5: dict(level=level, stride=stride, max_iters=n, irls_eps=eps, conv_tol=0.0, adam=True)
 VARIANTS = {
     "shipped": dict(BASE),
-    "no_retry": dict(BASE, retry_phases=None),
+    "pred": dict(BASE, predicted_exit=True),                                          # SP_PHASE_PREDICTED_EXIT in every phase
+    "pred_tight": dict(BASE, predicted_exit=True, conv_tol=1e-3, polish_tol=5e-5),
+    "two_attempts": dict(BASE, retry2_phases=None),                                   # round 5's: no third attempt
+    "adam_all_points": dict(BASE, retry2_phases=[adam(2, 1), adam(1, 1), adam(0, 1)]),  # the reference's own point set at every level
+    "adam_L2_L1": dict(BASE, retry2_phases=[adam(2, 4), adam(1, 2)]),
+    "adam_300": dict(BASE, retry2_phases=[adam(2, 4, 300), adam(1, 2, 300), adam(0, 2, 300)]),
+    "adam_eps1e-3": dict(BASE, retry2_phases=[adam(2, 4, 500, 1e-3), adam(1, 2, 500, 1e-3), adam(0, 2, 500, 1e-3)]),
+    "no_retry": dict(BASE, retry_phases=None, retry2_phases=None),
     "undamped": dict(BASE, phases=None, depth_damp=None, coarse_damped=None),
     "d8c12": dict(BASE, coarse_damped=(8.0, 12)),
     "d12c12": dict(BASE, coarse_damped=(12.0, 12)),
@@ -59,7 +67,7 @@ VARIANTS = {
 
 
 def _render(a):
-    shape_kw = dict(overlap=4) if a[1] == "grid" else dict(shape="blobs", blob_coverage=1.2)
+    shape_kw = dict(overlap=4) if a[1] == "grid" else dict(shape=a[1], blob_coverage=1.2)
     return synth.make_pair(H, W, a[2], seed=a[0], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
 
 
@@ -81,10 +89,13 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=1536)
     ap.add_argument("--slots", type=int, default=384)
     ap.add_argument("--variants", default="shipped,no_retry")
-    ap.add_argument("--shape", default="grid", choices=["grid", "blobs"])
+    ap.add_argument("--shape", default="grid", choices=["grid", "blobs", "sam"])
     ap.add_argument("--npz", default=None)
     ap.add_argument("--segments", type=int, default=N, help="segments per keyframe (bench.py --segments)")
     ap.add_argument("--alone", default="105,1380,1482", help="pairs also run as batches of ONE (order independence of the verdict and the retry)")
+    ap.add_argument("--streams", type=int, default=1, help="run_scheduled(streams=...): groups of slots on their own HIP streams, one queue")
+    ap.add_argument("--verdict", default="", help="overrides of VERDICT_DEFAULTS, e.g. seg_max_ratio=4,seg_mean_ratio=1.3,cost_outlier=0")
+    ap.add_argument("--only-batches", default="", help="comma list of batch indices to run (the others are skipped): the known hard starts' batches")
     args = ap.parse_args(argv)
     dev = torch.device("cuda:0")
     t0 = time.time()
@@ -108,18 +119,24 @@ def main(argv=None):
     src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in scenes]
     trg, Ks = [t(p.trg_image) for p in scenes], [t(p.K) for p in scenes]
     names = [v for v in args.variants.split(",") if v]
+    verdict = {k: float(x) for k, x in (kv.split("=") for kv in args.verdict.split(",") if kv)} or None
+    only = {int(b) for b in args.only_batches.split(",") if b}
     keep = {v: dict(err=[], status=[], diag=[], attempts=[], iters=[], kld=[], secs=0.0, rounds=0) for v in names}
+    ran = []
     for b in range(n_batches):
+        if only and b not in only:
+            continue
+        ran.append(b)
         lo = b * args.batch
         batch = PairBatch(src, trg, Ks, torch.from_numpy(np.stack(poses[lo: lo + args.batch])), [t(k) for k in klds[lo: lo + args.batch]],
                           levels=REFERENCE_START_LEVELS, replicate=args.batch // G, point_stride=REFERENCE_START_POINT_STRIDE, granule=64)
         for v in names:
             kw = dict(VARIANTS[v])
-            for rep in range(2 if b == 0 else 1):                  # (first use untimed)
+            for rep in range(2 if b == ran[0] else 1):             # (first use untimed)
                 batch.restore_initial()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                rounds = batch.run_scheduled(slots=args.slots, **kw)
+                rounds = batch.run_scheduled(slots=args.slots, verdict=verdict, streams=args.streams, **kw)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
             P, K = batch.poses().double().cpu().numpy(), [k.double().cpu().numpy() for k in batch.klds()]
@@ -127,7 +144,7 @@ def main(argv=None):
             k["err"].append(errors(P, K, poses_gt[lo: lo + args.batch], klds_gt[lo: lo + args.batch]))
             k["status"].append(batch.status.cpu().numpy().copy()); k["diag"].append(batch.diag.cpu().numpy().copy())
             k["attempts"].append(batch.attempts.cpu().numpy().copy())
-            k["kld"].append(np.stack(K))
+            k["kld"].extend(K)
             k["iters"].append((batch.lm_state[:, 2] + batch.lm_state[:, 3]).cpu().numpy())
             k["secs"] += dt; k["rounds"] += rounds
         if b == 0 and args.alone:
@@ -135,7 +152,7 @@ def main(argv=None):
             ids = [int(a) for a in args.alone.split(",") if int(a) < args.batch]
             kw = dict(VARIANTS[names[0]])
             batch.restore_initial()
-            batch.run_scheduled(**kw)
+            batch.run_scheduled(verdict=verdict, **kw)
             torch.cuda.synchronize()
             P, K = batch.poses().double().cpu().numpy(), [k.double().cpu().numpy() for k in batch.klds()]
             e = errors([P[m] for m in ids], [K[m] for m in ids], [poses_gt[m] for m in ids], [klds_gt[m] for m in ids])
@@ -144,7 +161,7 @@ def main(argv=None):
             for m in ids:
                 one = PairBatch([src[m % G]], [trg[m % G]], [Ks[m % G]], torch.from_numpy(poses[m][None]), [t(klds[m])], levels=REFERENCE_START_LEVELS,
                                 point_stride=REFERENCE_START_POINT_STRIDE, granule=64)
-                one.run_scheduled(**kw)
+                one.run_scheduled(verdict=verdict, **kw)
                 torch.cuda.synchronize()
                 e1 = errors([one.poses()[0].double().cpu().numpy()], [one.klds()[0].double().cpu().numpy()], [poses_gt[m]], [klds_gt[m]])[0]
                 print(f"pair {m} ALONE ({names[0]}): {e1} status {int(one.status[0]):#x} attempts {int(one.attempts[0])} diag {one.diag[0].cpu().numpy()}", flush=True)
@@ -154,32 +171,43 @@ def main(argv=None):
         print(f"batch {b + 1}/{n_batches} done ({time.time() - t0:.0f} s)", flush=True)
     out = {}
     F = _lib.SP_STATUS_FAILED
+    index = np.concatenate([np.arange(b * args.batch, (b + 1) * args.batch) for b in ran])      # global pair index of every row
+    total = len(index)
     for v in names:
         k = keep[v]
         err, st, dg, at, its = (np.concatenate(k[x]) for x in ("err", "status", "diag", "attempts", "iters"))
         miss = ~((err[:, 0] <= 2e-3) & (err[:, 1] <= 2e-3) & (err[:, 2] <= 2e-2))
         flagged = (st & F) != 0
         silent = np.nonzero(miss & ~flagged)[0]
-        bits = {name: int(((st & getattr(_lib, "SP_STATUS_" + name)) != 0).sum()) for name in ("NONFINITE", "LAST_CAP", "DEPTH_RANGE", "COST", "VALID", "RETRIED", "UNFINISHED")}
+        bits = {name: int(((st & getattr(_lib, "SP_STATUS_" + name)) != 0).sum()) for name in ("NONFINITE", "LAST_CAP", "DEPTH_RANGE", "COST", "VALID", "SEGMENTS", "RETRIED", "ADAM", "UNFINISHED")}
         conv = ~miss
         print(f"\n== {v}: {total} starts, {total / k['secs']:.0f} pairs/s ({args.slots} slots), {its.mean():.1f} iterations per pair, {k['rounds']} rounds\n"
-              f"   missed (vs ground truth) {int(miss.sum())}: {np.nonzero(miss)[0][:24].tolist()}\n"
-              f"   flagged {int(flagged.sum())} (of the missed: {int((miss & flagged).sum())}; FALSE ALARMS {int((flagged & ~miss).sum())}: {np.nonzero(flagged & ~miss)[0][:16].tolist()})\n"
-              f"   SILENT {len(silent)}: {silent[:24].tolist()}\n"
-              f"   second attempts {int((at > 0).sum())}: rescued {int(((at > 0) & conv & ~flagged).sum())}, converged but still flagged {int(((at > 0) & conv & flagged).sum())}, "
-              f"missed again {int(((at > 0) & miss).sum())}\n"
+              f"   missed (vs ground truth) {int(miss.sum())}: {index[miss][:24].tolist()}\n"
+              f"   flagged {int(flagged.sum())} (of the missed: {int((miss & flagged).sum())}; FALSE ALARMS {int((flagged & ~miss).sum())}: {index[flagged & ~miss][:16].tolist()})\n"
+              f"   SILENT {len(silent)}: {index[silent][:24].tolist()}\n"
+              f"   later attempts {int((at > 0).sum())}: rescued {int(((at > 0) & conv & ~flagged).sum())}, converged but still flagged {int(((at > 0) & conv & flagged).sum())}, "
+              f"missed again {int(((at > 0) & miss).sum())}; THIRD attempts {int((at > 1).sum())}: {index[at > 1][:24].tolist()}, rescued {int(((at > 1) & conv & ~flagged).sum())}\n"
               f"   status bits {bits}\n"
               f"   worst error of the unflagged: {err[~flagged].max(axis=0) if (~flagged).any() else None}", flush=True)
-        kl = np.concatenate(k["kld"])
+        # the within-pair statistics (diag[6] = median, diag[7] = maximum over the pair's segments of the segment's mean |r|)
+        judged = dg[:, 6] > 0
+        if judged.any():
+            r_max, r_mean = dg[:, 7] / np.maximum(dg[:, 6], 1e-30), dg[:, 0] / np.maximum(dg[:, 6], 1e-30)
+            good = judged & conv & ~flagged
+            q = lambda a: "p50 %.2f p99 %.2f p99.9 %.2f p99.99 %.2f max %.2f" % tuple(np.percentile(a, [50, 99, 99.9, 99.99, 100])) if len(a) else "--"
+            print(f"   segment costs, converged unflagged pairs ({int(good.sum())}): worst / median {q(r_max[good])}; cost / median {q(r_mean[good])}\n"
+                  f"   ... pairs that END away from the ground truth ({int((judged & miss).sum())}): worst / median {np.sort(r_max[judged & miss])[:16].round(2).tolist()}; "
+                  f"cost / median {np.sort(r_mean[judged & miss])[:16].round(2).tolist()}", flush=True)
+        kl = k["kld"]
         for m in list(silent[:8]) + list(np.nonzero(flagged & ~miss)[0][:4]):
             sc = scenes[m % G]
             rel = np.abs(np.expm1(kl[m] + float(np.mean(sc.kld_gt - kl[m])) - sc.kld_gt))
             worst = np.argsort(rel)[::-1][:3]
             px = sc.keypoint_regions.reshape(sc.N, -1).sum(1)
-            print(f"   {'silent' if m in silent else 'false alarm'} pair {m}: err {err[m]} status {st[m]:#x} diag {dg[m]}; worst segments {worst.tolist()} "
+            print(f"   {'silent' if m in silent else 'false alarm'} pair {index[m]}: err {err[m]} status {st[m]:#x} diag {dg[m]}; worst segments {worst.tolist()} "
                   f"depth errors {rel[worst]} pixels {px[worst].tolist()} (median segment {int(np.median(px))} px)")
         for m in np.nonzero(miss & flagged)[0][:8]:
-            print(f"   flagged miss {m}: err {err[m]} status {st[m]:#x} attempts {at[m]} diag {dg[m]}")
+            print(f"   flagged miss {index[m]}: err {err[m]} status {st[m]:#x} attempts {at[m]} diag {dg[m]}")
         out.update({f"{v}__err": err, f"{v}__status": st, f"{v}__diag": dg, f"{v}__attempts": at, f"{v}__iters": its})
     if args.npz:
         os.makedirs(os.path.dirname(os.path.abspath(args.npz)), exist_ok=True)
