@@ -800,13 +800,8 @@ def main(argv=None):
             ms = tm.milliseconds()
             rs = {k: {"ms": ms[k], "algorithmic_bytes": int(nbytes[k]), "achieved": nbytes[k] / (ms[k] * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
                       "unit": "GB/s", "frac": nbytes[k] / (ms[k] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for k in ms if ms[k] > 0}
-            # (round 6: the image passes run on a side stream next to the table passes, so the passes OVERLAP: the set-up's GPU time is the
-            #  span from the first pass's start to the last one's end, not the sum of the passes; a pass's own duration is taken while its
-            #  neighbour runs and shares the memory system with it)
-            spans, _ = tm.timeline()
-            tot_b, tot_ms = sum(nbytes[k] for k in ms), max(e for _, _, e in spans) - min(a for _, a, _ in spans)
-            line["roofline_setup"] = {"bound": "hbm", "passes": rs, "kernels_ms": tot_ms, "sum_of_pass_durations_ms": sum(ms.values()),
-                                      "overlap": "pyramid + pack on a side stream, concurrent with count and fill", "algorithmic_bytes": int(tot_b),
+            tot_b, tot_ms = sum(nbytes[k] for k in ms), sum(ms.values())
+            line["roofline_setup"] = {"bound": "hbm", "passes": rs, "kernels_ms": tot_ms, "algorithmic_bytes": int(tot_b),
                                       "achieved": tot_b / (tot_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                       "frac": tot_b / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                       "algorithmic_bytes_per_pair": int(tot_b / n_raw), "pairs": n_raw}
@@ -821,8 +816,7 @@ def main(argv=None):
             tm = _Timer()
             _, _, nbytes_b = from_raw(tm)
             ms_b = tm.milliseconds()
-            spans_b, _ = tm.timeline()
-            tot_bb, tot_msb = sum(nbytes_b[k] for k in ms_b), max(e for _, _, e in spans_b) - min(a for _, a, _ in spans_b)
+            tot_bb, tot_msb = sum(nbytes_b[k] for k in ms_b), sum(ms_b.values())
             line["from_raw_frames"]["with_segment_boxes"] = {
                 "setup_ms": 1e3 * t_setup_b, "optimise_ms": 1e3 * t_opt_b, "frame_pairs_per_sec": n_raw / (t_setup_b + t_opt_b),
                 "roofline_setup": {"kernels_ms": tot_msb, "algorithmic_bytes": int(tot_bb), "frac": tot_bb / (tot_msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -952,6 +946,33 @@ def main(argv=None):
                     rb = reference_start_leg(blob_args, rank, dev, M, slot_only=True)
                     line["frame_pairs_per_sec_ragged_masks"] = rb["frame_pairs_per_sec"]
                     line["reference_start_ragged_masks"] = rb
+                    # ... and on SAM-REALISTIC segment sets (round 6: areas over three decades, holes, nested masks, split lobes, N differing
+                    # per keyframe: synth.make_pair(shape='sam'))
+                    sam_args = copy.copy(args)
+                    sam_args.shape, sam_args.coverage = "sam", 1.2
+                    rsam = reference_start_leg(sam_args, rank, dev, M, slot_only=True)
+                    line["frame_pairs_per_sec_sam_masks"] = rsam["frame_pairs_per_sec"]
+                    line["reference_start_sam_masks"] = rsam
+                    # the level-0 pass (the dominant kernel of the headline figure) on those two workloads: 60 steps each between HIP events
+                    by_shape = {}
+                    for shp in ("blobs", "sam"):
+                        a2 = copy.copy(args)
+                        a2.shape, a2.coverage = shp, 1.2
+                        b2, _ = build_batch(a2, rank, dev)
+                        for _ in range(20):
+                            b2.gn_step(0)
+                        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(60)]
+                        for e0, e1 in evs:
+                            e0.record(); b2.cost_pass(0, 1); e1.record(); b2.solve_gn(0)
+                        sync()
+                        km = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+                        ab = b2.algorithmic_bytes(0)
+                        by_shape[shp] = {"frac": ab / (km * 1e-3) / 1e9 / HBM_PEAK_GBPS, "kernel_ms": km, "algorithmic_bytes_per_launch": ab, "pairs": b2.M,
+                                         "segments_per_pair": [int(min(b2.Ns)), int(max(b2.Ns))], "points_per_pair": float(np.mean(b2.Ps)),
+                                         "padded_points_per_real_point": float(sum(b2.Ppads)) / float(sum(b2.Ps))}
+                        del b2
+                        torch.cuda.empty_cache()
+                    line["roofline_by_shape"] = by_shape
                 line["frame_pairs_per_sec_what"] = ("reference start (pose T_gt Exp(0.05 randn), depth seeds log(2 + 2 rand), multi-octave texture), "
                                                     "REFERENCE_START_SCHEDULE, slot-level continuous batching on one stream; frame_pairs_per_sec_near_start = "
                                                     "round 3's sigma-0.004 figure")

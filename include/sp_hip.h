@@ -582,7 +582,9 @@ int sp_window_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, 
  * nodes = 112 -- and through global scratch up to 512 = 64 nodes), the log-depths of every block with lr > 0 (eliminated by a Schur
  * complement, like the per-pair solver; a depth unknown of keyframe k only couples with the frames k is matched against, and only
  * those columns are stored and summed).  No camera unknown at all is allowed (the 'supp' mapping of odometery.py:576-648: only the
- * latest keyframe's depths are free).  flags bit 0: pose-only step (all depth blocks treated as frozen).
+ * latest keyframe's depths are free).  flags bit 0: pose-only step (all depth blocks treated as frozen); bit 1 (ABI 13): PREDICTED EXIT --
+ * with conv_tol > 0 the window also freezes right after a step that is predicted to buy less than conv_tol of the loss (the first-order
+ * change b . delta along the step; lambda <= 1e-2 only), without the evaluation that would confirm it: see SP_PHASE_PREDICTED_EXIT.
  * LM: lambda adapts on the device exactly like sp_pairs_gn_step (loss up -> previous step undone from nodes_backup / kld_backup,
  * lambda *= lm_up, re-evaluated next call; loss down -> lambda = max(lambda lm_down, lm_min); a failed factorisation counts as a
  * rejected step: lambda *= lm_up, the same point is evaluated and solved again); conv_tol > 0: an accepted step that

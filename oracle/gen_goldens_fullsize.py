@@ -551,13 +551,16 @@ def bench_reference_start(scene, replica, G=8, N=64, rank=0, H=480, W=640, shape
     """The start bench.py's reference-start leg gives pair ``replica * G + scene`` (bench.py:reference_start_leg: scenes
     ``5000 + 1000 rank + s``, overlap 4; replica 0 = the pair's own pose_init / kld_init, replica r > 0 drawn from
     ``default_rng(77 + rank)`` in (replica, scene) order: 6 normals for the pose, N uniforms for the depth seeds)."""
-    shape_kw = dict(overlap=4) if shape == "grid" else dict(shape="blobs", blob_coverage=1.2, overlap=None)       # (bench.py --shape blobs)
-    pair = synth.make_pair(H, W, N, seed=5000 + 1000 * rank + scene, **{k: v for k, v in dict(SIGMA05_ARGS, **shape_kw).items() if v is not None})
+    shape_kw = dict(overlap=4) if shape == "grid" else dict(shape=shape, blob_coverage=1.2, overlap=None)       # (bench.py --shape blobs / sam)
+    render = lambda sc: synth.make_pair(H, W, N, seed=5000 + 1000 * rank + sc, **{k: v for k, v in dict(SIGMA05_ARGS, **shape_kw).items() if v is not None})
+    pair = render(scene)
+    # (shape 'sam': the number of segments differs from scene to scene, and the depth seeds of scene s take N_s uniforms of the stream)
+    Ns = [N] * G if shape != "sam" else [pair.N if sc == scene else render(sc).N for sc in range(G)]
     if replica > 0:
         rng = np.random.default_rng(77 + rank)
         for r in range(1, replica + 1):
             for s_ in range(G):
-                xi, u = rng.standard_normal(6), rng.uniform(size=N)
+                xi, u = rng.standard_normal(6), rng.uniform(size=Ns[s_])
                 if r == replica and s_ == scene:
                     pair.pose_init = (pair.pose_gt.astype(np.float64) @ synth.se3_exp_np(0.05 * xi)).astype(np.float32)
                     pair.kld_init = np.log(2.0 + 2.0 * u).astype(np.float32)
@@ -629,6 +632,9 @@ def main():
         # ``tools/verdict_sweep.py --shape blobs``: does the reference converge from the starts Gauss-Newton loses there?
         if w.startswith("g20y:"):
             golden_bench_pair(ref, pair_index=int(w[5:]), name=f"g20y_sigma05_blobs_pair{int(w[5:])}", shape="blobs")
+        # g20z:<pair index> -- the same on SAM-REALISTIC segment sets (``tools/verdict_sweep.py --shape sam``, round 6)
+        if w.startswith("g20z:"):
+            golden_bench_pair(ref, pair_index=int(w[5:]), name=f"g20z_sigma05_sam_pair{int(w[5:])}", shape="sam")
     if "g20" in which:
         # the same at BASELINE configs[1] size (640x480x64) on the first three scenes of bench.py's reference-start leg
         # (bench.py:_render_sigma05: seeds 5000 + s, overlap 4; replica 0 of a scene starts from the pair's own pose_init / kld_init)

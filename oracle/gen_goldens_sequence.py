@@ -28,6 +28,12 @@ frame (``f<i>_s<k>_*``: s0 = before tracking, s1 = after tracking, s2 = after th
 mapping when there was one, s4 = after the keyframe decision / creation; ``snapshot`` below) so that a test can restart ANY stage from
 the reference's own recorded input and compare that stage's output at the north-star bar -- a free-running comparison of 24 frames
 inherits the jitter of every un-converged Adam stage before it (300 steps at lr 5e-3), a single stage does not.
+Two more things are recorded for that test.  ``f<i>_track50_pose / _aff``: the tracker's state after the first 50 of its 300 steps -- a
+horizon over which two faithful runs have not yet decorrelated (the reference's tracking does not converge: lr 5e-3 Adam on an L1 cost
+jitters by ~3e-4 rad, and 300 steps amplify any change of summation order to that amplitude).  ``spread_*``: THE REFERENCE AGAINST
+ITSELF, stage by stage -- after the chain, every stage is run once more from its own recorded input with a different number of threads
+(another reduction order) and the largest deviation from the recorded output is kept per stage kind: the yardstick for what "the same
+stage output" can mean over a full stage.
 """
 from __future__ import annotations
 
@@ -108,8 +114,11 @@ class Chain:
             prev_pyr = ref.kf.keyframe_pyramid(prev_kf, 0, 3, geo_down=False)
             pre = [ref.do.unproject_kf(k, prev_kld) for k in prev_pyr]
         loss = None
+        self.track50 = None
         for level, n in enumerate(C["track_steps"]):
-            for _ in range(n):
+            for it in range(n):
+                if level == len(C["track_steps"]) - 1 and it == 50:
+                    self.track50 = (ref.la.renormalise_se3(supp_T).detach().clone(), aff.detach().clone())
                 pose = orc.se3_exp(delta)[0] @ torch.linalg.inv(supp_T) @ prev_pose
                 out = ref.do.photomeric_cost_precomputed(pre[level], supp_pyr[level], pose=pose, affine_comp=(prev_aff, aff), cost_config=CFG)
                 loss = torch.mean(out["residual"])
@@ -198,6 +207,7 @@ class Chain:
         t0 = time.time()
         self.snapshot(rec, "s0")
         rec["track_loss"] = self.track_frame(i)
+        rec["track50_pose"], rec["track50_aff"] = self.track50[0].numpy().copy(), self.track50[1].numpy().copy()
         self.snapshot(rec, "s1")
         rec["tracked_pose"] = self.current_track.numpy().copy(); rec["tracked_aff"] = self.current_aff.numpy().copy()
         if self.initialised and C["continual_steps"] > 0:
@@ -230,6 +240,57 @@ class Chain:
               f"keyframes {self.kf_ids} ({time.time() - t0:.0f} s)", flush=True)
 
 
+def restore(ch, save, tag):
+    """The inverse of ``Chain.snapshot``: put the chain into the recorded state ``<tag>``."""
+    ids = [int(i) for i in save[f"{tag}_kf_ids"]]
+    ch.kf_ids, ch.kfs = ids, [ch.to_kf(i) for i in ids]
+    ch.kf_poses = [T(p) for p in save[f"{tag}_kf_poses"]]
+    ch.kf_klds = [T(k) for k in save[f"{tag}_kf_klds"]]
+    ch.kf_affs = [T(a) for a in save[f"{tag}_kf_affs"]]
+    row = lambda key: [Supp(ch.frames[int(ts)], T(p), T(a), int(ts)) for ts, p, a in zip(save[f"{tag}_{key}_ts"], save[f"{tag}_{key}_poses"], save[f"{tag}_{key}_affs"])]
+    flat, ch.supp_opt, q = row("supp"), [], 0
+    for c in save[f"{tag}_supp_counts"]:
+        ch.supp_opt.append(flat[q: q + int(c)]); q += int(c)
+    ch.tracked, ch.curr_supp = row("tracked"), row("curr")
+    ch.current_track, ch.current_aff = T(save[f"{tag}_current_track"]), T(save[f"{tag}_current_aff"])
+    fl = save[f"{tag}_flags"]
+    ch.current_ts, ch.initialised, ch.mapping_scheduled = int(fl[0]), bool(fl[1]), bool(fl[2])
+
+
+def rot_angle(A, B):
+    R = A[:3, :3].T.astype(np.float64) @ B[:3, :3].astype(np.float64)
+    return float(np.arctan2(0.5 * np.linalg.norm([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]]), 0.5 * (np.trace(R) - 1)))
+
+
+def stage_spread(ch, save, n):
+    """Every stage once more from its own recorded input (the caller has changed the thread count): the largest deviation from the recorded
+    output, per stage kind.  track: (rot, t, affine) full stage and after 50 steps; supp: max |d log-depth| of the latest keyframe; map:
+    (rot, t, log-depth, affine) over keyframes and supporting frames."""
+    sp = dict(track=np.zeros(3), track50=np.zeros(3), supp=np.zeros(1), map=np.zeros(4))
+    pe = lambda A, B: (rot_angle(np.asarray(A), np.asarray(B)), float(np.abs(np.asarray(A, np.float64)[:3, 3] - np.asarray(B, np.float64)[:3, 3]).max()))
+    for i in range(1, n):
+        restore(ch, save, f"f{i}_s0")
+        ch.track_frame(i)
+        r, t = pe(ch.current_track.numpy(), save[f"f{i}_s1_current_track"])
+        sp["track"] = np.maximum(sp["track"], (r, t, float(np.abs(ch.current_aff.numpy() - save[f"f{i}_s1_current_aff"]).max())))
+        r, t = pe(ch.track50[0].numpy(), save[f"f{i}_track50_pose"])
+        sp["track50"] = np.maximum(sp["track50"], (r, t, float(np.abs(ch.track50[1].numpy() - save[f"f{i}_track50_aff"]).max())))
+        if f"f{i}_s2_kf_ids" in save:
+            restore(ch, save, f"f{i}_s1")
+            ch.mapping(C["continual_steps"], "supp")
+            sp["supp"] = np.maximum(sp["supp"], float(np.abs(ch.kf_klds[-1].numpy() - save[f"f{i}_s2_kf_klds"][-1]).max()))
+        if f"f{i}_s3_kf_ids" in save:
+            restore(ch, save, f"f{i}_s2")
+            ch.mapping(C["map_steps"], "map")
+            e = [pe(p.numpy(), q) for p, q in zip(ch.kf_poses, save[f"f{i}_s3_kf_poses"])]
+            e += [pe(s_.pose.numpy(), q) for s_, q in zip([s_ for row in ch.supp_opt for s_ in row], save[f"f{i}_s3_supp_poses"])]
+            d = max(float(np.abs(k.numpy() - w).max()) for k, w in zip(ch.kf_klds, save[f"f{i}_s3_kf_klds"]))
+            fa = max(float(np.abs(a.numpy() - w).max()) for a, w in zip(ch.kf_affs, save[f"f{i}_s3_kf_affs"]))
+            sp["map"] = np.maximum(sp["map"], (max(x[0] for x in e), max(x[1] for x in e), d, fa))
+        print(f"  spread after frame {i}: track {sp['track']}, first 50 steps {sp['track50']}, supp {sp['supp']}, map {sp['map']}", flush=True)
+    return sp
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
     torch.manual_seed(0)
@@ -252,8 +313,15 @@ def main():
                 final_kf_klds=np.stack([k.numpy() for k in ch.kf_klds]), final_kf_affs=np.stack([a.numpy() for a in ch.kf_affs]),
                 final_supp_ids=np.array([",".join(str(s.ts) for s in row) for row in ch.supp_opt]),
                 gt_poses=np.stack([f.T_wc for f in seq]))
+    # the reference against itself, stage by stage, under another reduction order
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1 if threads > 1 else 2)
+    sp = stage_spread(ch, save, n)
+    torch.set_num_threads(threads)
+    save.update(spread_track=sp["track"], spread_track50=sp["track50"], spread_supp=sp["supp"], spread_map=sp["map"],
+                spread_threads=np.array([threads, 1 if threads > 1 else 2]))
     np.savez_compressed(os.path.join(OUT, "g21_config3_sequence_chain.npz"), **save)
-    print(f"g21_config3_sequence_chain: {n} frames, keyframes {ch.kf_ids}, {time.time() - t0:.0f} s", flush=True)
+    print(f"g21_config3_sequence_chain: {n} frames, keyframes {ch.kf_ids}, {time.time() - t0:.0f} s; the reference against itself per stage: {sp}", flush=True)
 
 
 if __name__ == "__main__":

@@ -474,6 +474,7 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
     constexpr int NTHR = wgn_update_threads(LDS_Y);
     __shared__ double Hs[LDS_Y > 0 ? LDS_Y * (LDS_Y + 1) / 2 : 1];
     __shared__ double g[CAP], dy[CAP], dinvs[CAP];
+    __shared__ double g0[CAP];             // the camera-side gradient as assembled (before the Schur terms): the predicted exit's b . delta
     constexpr int PANELS = LDS_Y == 0 ? 0 : (LDS_Y > 128 ? 1 : 2);      // column panels of the factorisation (two: written while the other is read)
     __shared__ __align__(16) double panel[PANELS > 0 ? PANELS : 1][LDS_Y > 0 ? LDS_Y : 1][4];      // [row][column of the panel]
     __shared__ int pose_off[SP_WGN_MAX_NODES], aff_off[SP_WGN_MAX_NODES];
@@ -580,7 +581,7 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
     }
     WGN_STAMP(3);
     // ---- LM damping of the camera block, then minus the blocks' Schur terms (k_window_gn_schur), block after block ----
-    for (int i = tid; i < n_y; i += NTHR) { H[ltri(i, i)] = H[ltri(i, i)] * (1.0 + lam) + 1e-12; g[i] = -g[i]; }
+    for (int i = tid; i < n_y; i += NTHR) { H[ltri(i, i)] = H[ltri(i, i)] * (1.0 + lam) + 1e-12; g0[i] = g[i]; g[i] = -g[i]; }
     __syncthreads();
     for (int b = 0; b < w.n_blocks; ++b) {
         const int nc = w.nc[b];
@@ -889,7 +890,9 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
     }
     WGN_STAMP(6);
     // ---- depth steps (back-substitution), clamped like the pair solver's ------------------------------------------
+    double gain = 0.0;                     // -(b . delta): what the step is predicted to buy (first-order change of the loss, flags bit 1)
     if (!fail) {
+        for (int i = tid; i < n_y; i += NTHR) gain -= g0[i] * dy[i];
         for (int b = 0; b < w.n_blocks; ++b) {
             const SpWindowBlock bk = w.blocks[b];
             const int nc = w.nc[b];
@@ -911,6 +914,7 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
                     double dd = (s - w.Bd[r]) * dinv;
                     dd = fmin(fmax(dd, -0.5), 0.5);
                     bk.kld[n] += (float)dd;
+                    gain -= w.Bd[r] * dd;
                 }
             }
         }
@@ -952,6 +956,21 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
                 for (int q = 0; q < 12; ++q) nd.T[q] = (float)Tn[q];
                 for (int k = 0; k < 6; ++k) nd.a[k] = 0.f;
             }
+        }
+    }
+    if ((w.flags & 2) && w.conv_tol > 0.f) {
+        // PREDICTED EXIT (as SP_PHASE_PREDICTED_EXIT of the pair solver, include/sp_hip.h): the step just taken is predicted to buy less than
+        // conv_tol of the loss -> the phase is over now, without the evaluation that would confirm it (on the few-edge windows of the
+        // config-3 chain one evaluation is a fifth of a tracking phase).  Not under a heavy damping, not after a failed factorisation.
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gain += __shfl_xor(gain, o, 64);
+        __syncthreads();                   // (dinvs: the factorisation's reciprocals, no longer read)
+        if ((tid & 63) == 0) dinvs[tid >> 6] = gain;
+        __syncthreads();
+        if (tid == 0 && !fail && lam <= 1e-2) {
+            double tot = 0.0;
+            for (int k = 0; k < NTHR / 64; ++k) tot += dinvs[k];
+            if (tot <= (double)w.conv_tol * (double)st[7]) st[6] = 1.f;
         }
     }
     __threadfence_block();

@@ -264,18 +264,6 @@ _TABLE_DT, _SAMPLE_DT, _IMAGE_DT = np.dtype(_lib.SpPrepTable), np.dtype(_lib.SpP
 _TORCH_OF = {np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(main):
-    """The side stream of the set-up's image passes, one per stream the set-up is issued on."""
-    key = (main.device, main.cuda_stream)
-    st = _SIDE_STREAMS.get(key)
-    if st is None:
-        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=main.device)
-    return st
-
-
 def stage(arrays, dev):
     """Host arrays -> device tensors through ONE pinned staging buffer and one asynchronous copy (a copy from pageable memory
     would make the host wait for everything already enqueued on the stream).  int32 / float32 arrays come back typed and
@@ -427,13 +415,11 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     Ks_ready.record()
 
     timer.mark('gathers enqueued')
-    # (round 6) the image passes -- pyramids of both frames, packed targets -- depend on nothing the table passes make, and every pass of
-    # the set-up alone leaves a third to a half of the memory system idle (latency-bound at 0.37-0.68 of HBM): they run on a SIDE stream,
-    # next to the count pass and, after the counts have come back, next to the fill pass; the sampling passes wait for both.
-    main_stream = torch.cuda.current_stream()
-    side_stream = _side_stream(main_stream)
-    inputs_ready = torch.cuda.Event()
-    inputs_ready.record()
+    # (Round 6, measured and NOT kept: the image passes -- pyramids, packed targets -- on a side stream next to the count and fill passes,
+    #  which they do not depend on.  The passes then overlap and take as long together as one after the other: count 1.84 -> 3.18 ms,
+    #  pyramid 0.82 -> 1.25, pack 0.68 -> 1.57, the whole set-up 5.94 -> 6.07 ms per 384 pairs (profiles/r06_setup_side_stream.txt).  The
+    #  set-up as a whole runs at the rate the memory system sustains for its mix of reads and writes, 0.56-0.58 of the HBM peak; what is
+    #  left to gain is in its BYTES, not in its scheduling.)
     staged = stage([recs], dev)
     timer.mark('count launch')
     with timer('count'):
@@ -474,21 +460,14 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         jb['inp'], jb['out'] = ptr_lv[l][1], buf.data_ptr() + 4 * off[:-1]
         jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
         trg[l] = (buf, off, hw[l])                   # (flat packed targets, their offsets, (M0, 2) level sizes)
-    side_stream.wait_event(inputs_ready)
-    with torch.cuda.stream(side_stream):
-        side_ptr = _lib.stream_ptr()
-        staged_img = stage([pack_jobs] + blur_jobs, dev)            # (its copy goes on the side stream too: not behind the count pass)
-        timer.mark('pyramid jobs staged')
-        with timer('pyramid'):
-            for l in range(1, max_level + 1):
-                _lib.check(lib.sp_prepare_blur(_lib.ptr(staged_img[l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), side_ptr), "sp_prepare_blur")
-        with timer('pack'):
-            _lib.check(lib.sp_prepare_pack(_lib.ptr(staged_img[0]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), side_ptr),
-                       "sp_prepare_pack")
-        images_ready = torch.cuda.Event()
-        images_ready.record()
-    for buf in pyramid + [v[0] for v in trg.values()] + list(staged_img[:1]):
-        buf.record_stream(side_stream)               # (allocated on the main stream's pool, written on the side stream)
+    staged = stage([pack_jobs] + blur_jobs, dev)
+    timer.mark('pyramid jobs staged')
+    with timer('pyramid'):
+        for l in range(1, max_level + 1):
+            _lib.check(lib.sp_prepare_blur(_lib.ptr(staged[l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
+    with timer('pack'):
+        _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
+                   "sp_prepare_pack")
 
     # ---- host: padded layouts; device: fill straight into them ----
     timer.mark('wait for counts')
@@ -559,7 +538,6 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     timer.mark('fill launch')
     with timer('fill'):
         _lib.check(lib.sp_prepare_fill(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_fill")
-    main_stream.wait_event(images_ready)             # the sampling passes read the source pyramid (side stream)
     with timer('sample'):
         # one launch per lattice: the grid is (blocks of the LARGEST table, jobs), and a stride-4 table has 1/16 of the points of
         # a stride-1 table -- in one launch over all lattices two thirds of the workgroups would start only to find nothing to do

@@ -46,7 +46,14 @@ GRANULE = 256                      # SP_BLOCK: every segment is padded to a mult
 # pairs/s near start, 25.1 k -> 30.6 k from the reference's start, same converged fraction, same end states (tools/phase_sweep.py,
 # profiles/r04_phase_sweep.txt).
 FRAME_PAIR_POINT_STRIDE = (2, 2, 4)
-FRAME_PAIR_SCHEDULE = dict(max_iters_per_level=25, conv_tol=2e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-4, check_every=3)
+# Round 6: ``predicted_exit`` (SP_PHASE_PREDICTED_EXIT) -- a pair leaves a phase right after the step that is PREDICTED to buy less than
+# the phase's tolerance (the first-order change of sum |r| along the step, which the solver has at hand) instead of after one more
+# evaluation has shown that it did.  That confirming evaluation was a SIXTH of a frame pair's work (one per phase; the all-points polish's
+# alone a tenth): 45.4 -> 38.9 iterations and 50 -> 39 cost evaluations per pair, 33.8 k -> 52.1 k pairs/s from the reference's start on
+# the grid, the same convergence record (9216 grid + 9216 ragged starts: nothing missed, nothing more flagged; the worst end state a
+# little BETTER, 6.6e-6 against 7.8e-6 rad: the last step is taken instead of thrown away), and on the ragged starts the two
+# Gauss-Newton attempts lost, five of six now come home without the third (profiles/r06_reference_start_predicted_exit_*.txt).
+FRAME_PAIR_SCHEDULE = dict(max_iters_per_level=25, conv_tol=2e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-4, check_every=3, predicted_exit=True)
 FIXED_FRAME_PAIR_SCHEDULE = dict(iters_per_level=15, polish_iters=10, polish_eps=1e-5)
 # The schedule for the REFERENCE'S OWN starting distribution (odometery/two_frame_sfm.py:77-81,103-105: pose = T_gt Exp(0.05
 # randn(6)), depth seeds log(2 + 2 rand)): tests/test_gpu_sigma05.py requires it to converge wherever the real reference loop does
@@ -72,7 +79,8 @@ REFERENCE_START_POINT_STRIDE = (2, 2, 4)
 # Which pose-only phase goes first is a matter of speed: epsilon 1e-2 with a cap of 15 in the first attempt and epsilon 1e-3 with a cap of
 # 30 in the second (below) loses 9 of 9216 starts at the first attempt and none after the second, at 33.6 k pairs/s and 32.9 iterations per
 # pair; the other way round (round 4's first attempt) 14 / none at 31.2 k and 36.7 (profiles/r05_reference_start.txt).
-# ``coarse_damped`` = (16, 12): between the pose-only phase and the joint phases, 12 iterations at the coarsest level with the log-depth
+# ``coarse_damped`` = "auto" -> (16, 12) or (12, 12) by the batch's segment statistics (PairBatch.auto_coarse_damping; 16 for the headline
+# workloads): between the pose-only phase and the joint phases, 12 iterations at the coarsest level with the log-depth
 # block DAMPED by 16 (include/sp_hip.h SP_PHASE_DEPTH_DAMP: the depths follow at 1/17 of their Gauss-Newton step -- the reference's Adam
 # moves them at a tenth of the pose's rate).  On the grid tiling the undamped schedule is enough (9 second attempts per 9216 starts, all
 # rescued); on SAM-like ragged masks over near-planar scenes (bench.py --shape blobs: depth range e^0.2) it walks into the second solution
@@ -106,7 +114,7 @@ REFERENCE_START_ADAM = (dict(level=2, stride=4, max_iters=500, irls_eps=1e-5, co
                         dict(level=1, stride=2, max_iters=500, irls_eps=1e-5, conv_tol=0.0, adam=True),
                         dict(level=0, stride=2, max_iters=500, irls_eps=1e-5, conv_tol=0.0, adam=True))
 ADAM_LR_POSE, ADAM_LR_KLD = 1e-2, 1e-3          # odometery/two_frame_sfm.py:116-123
-REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped=(16.0, 12), retry_phases=REFERENCE_START_RETRY,
+REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_first_eps=1e-2, coarse_damped="auto", retry_phases=REFERENCE_START_RETRY,
                                 retry2_phases=REFERENCE_START_ADAM)
 # The verdict's thresholds (SpVerdict): a log-depth more than ``kld_bound`` from its seed (a factor e^kld_bound in depth: the reference's
 # seeds log(2 + 2 rand) are at most a factor 2 off) has run away; fewer than ``valid_min`` of the points projecting into the target
@@ -568,13 +576,15 @@ class PairBatch:
                 step(level, **kw)
         return g
 
-    def run_converging(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, check_every=3, **kw):
+    def run_converging(self, max_iters_per_level=25, conv_tol=1e-3, polish_max=15, polish_eps=1e-5, polish_tol=1e-5, check_every=3, predicted_exit=False, **kw):
         """Coarse-to-fine Gauss-Newton with PER-PAIR termination (the batch counterpart of the reference's relative-loss
         early stop, odometery.py:907-915): at every level a pair leaves the iteration as soon as an accepted step lowers its
         cost by less than ``conv_tol`` -- its spans and its solve are skipped from then on -- and the level ends when every
         pair has left (polled every ``check_every`` iterations) or after ``max_iters_per_level``.  The finest level ends with
         up to ``polish_max`` iterations at IRLS epsilon ``polish_eps`` under ``polish_tol``.  Returns the iterations launched
-        per phase.  A batch costs the SUM of the iterations its pairs need instead of pairs x the maximum."""
+        per phase.  A batch costs the SUM of the iterations its pairs need instead of pairs x the maximum.  (``predicted_exit`` is accepted
+        so that a schedule dict can be passed as it is, and ignored: this level-synchronised form ends a pair's level by the evaluated
+        test only; the predicted test belongs to the device-side schedule, ``run_scheduled``.)"""
         launched = []
         phases = [(level, max_iters_per_level, kw.get("irls_eps", 1e-3), conv_tol) for level in reversed(self.level_ids)]
         if polish_max > 0:
@@ -636,6 +646,8 @@ class PairBatch:
                                    irls_eps=irls_eps if pose_first_eps is None else pose_first_eps, conv_tol=conv_tol, pose_only=True))
             joint = coarse_first if joint_levels is None else coarse_first[len(coarse_first) - int(joint_levels):]
             damps = dict(zip(joint, depth_damp)) if depth_damp else {}              # (coarsest joint level first)
+            if coarse_damped == "auto":
+                coarse_damped = self.auto_coarse_damping(joint[0], self.point_stride[joint[0]] if use_coarse else 1)
             if coarse_damped:
                 phases.append(dict(level=joint[0], stride=self.point_stride[joint[0]] if use_coarse else 1, max_iters=int(coarse_damped[1]), irls_eps=irls_eps,
                                    conv_tol=conv_tol, depth_damp=float(coarse_damped[0])))
@@ -703,6 +715,17 @@ class PairBatch:
         sched.adam_lr_pose, sched.adam_lr_kld = float(adam_lr_pose), float(adam_lr_kld)
         sched.adam_state = self.adam_state.data_ptr() if any(spec.get("adam", False) for spec in all_phases) else None
         return sched
+
+    def auto_coarse_damping(self, level, stride):
+        """(damping, iterations) of the damped coarse phase FROM THE SEGMENT STATISTICS of the batch instead of one
+        constant: what the damping trades is a depth block that runs ahead of the pose (large segments: hundreds of lattice points each
+        pin their depth long before the pose is right -- damp hard) against depths that, held still for a dozen iterations, let the pose
+        settle on a biased optimum (many small segments with a handful of lattice points each: damp less).  Measured (DESIGN.md section 6,
+        profiles/r05_reference_start_sweep_5_*): 64 segments of ~360 coarse points want 16-31, 1200 segments of ~19 want 12.  Rule: 16
+        when the median segment has at least 48 points on the phase's lattice, else 12."""
+        pts = np.asarray(self.Ps if stride == 1 else self.coarse[(level, stride)].points, dtype=np.float64)
+        per_seg = float(np.median(pts / np.maximum(np.asarray(self.Ns, dtype=np.float64), 1.0)))
+        return (16.0, 12) if per_seg >= 48.0 else (12.0, 12)
 
     def _verdict(self, sched, verdict):
         """The SpVerdict of a scheduled run (host struct; its arrays live on the batch: ``status``, ``diag``, ``attempts``) with the run's

@@ -34,6 +34,15 @@ def _upload_struct_array(arr, device):
     return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
 
 
+# How often the host loop of a Gauss-Newton phase looks at the device's state (PoseWindow.run_gn).  Launches behind the converged
+# iteration change nothing but still RUN -- the cost pass does not know the window is frozen -- so on the few-edge windows of the
+# config-3 chain a poll per iteration (a 64-byte copy and a stream synchronisation, ~15 us) is cheaper than three wasted iterations of
+# ~100 us; SP_GN_CHECK_EVERY overrides (tools/chain_profile.py measures).
+import os as _os
+GN_CHECK_EVERY = int(_os.environ.get("SP_GN_CHECK_EVERY", "4"))
+GN_PREDICTED_EXIT = _os.environ.get("SP_GN_PREDICTED_EXIT", "1") != "0"
+
+
 class PoseWindow:
     def __init__(self, sources, nodes, edges, levels, abs_loss=False, skip_first=False, rel_tol=0.0, use_affine=False,
                  max_iters=4096, tile_points=DEFAULT_BATCH_TILE_POINTS, span_points=None):
@@ -287,12 +296,19 @@ class PoseWindow:
                                               _lib.stream_ptr()), "sp_window_gn_step")
         gn['host_stale'] = True
 
-    def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=4, lm_up=8.0, lm_down=0.5, lm_min=1e-7):
+    def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=None, lm_up=8.0, lm_down=0.5, lm_min=1e-7,
+               predicted_exit=None):
         """Up to ``max_iters`` LM iterations at ``level`` as ONE phase: stops once an accepted step lowers the loss by less than
         ``conv_tol`` of it (the device freezes the window -- launches after that change nothing; the host loop, ONE foreign call
         ``sp_window_gn_run``, looks at the state every ``check_every`` iterations).  Returns the iterations the phase really took
-        (evaluations of the cost, rejected ones and the final converged-test evaluation included), from the device's counter."""
+        (evaluations of the cost, rejected ones and the final converged-test evaluation included), from the device's counter.
+        ``predicted_exit`` (default GN_PREDICTED_EXIT): the phase also ends right after a step PREDICTED to buy less than ``conv_tol`` of the
+        loss (flags bit 1 of sp_window_gn_step; the pair solver's SP_PHASE_PREDICTED_EXIT) -- without the evaluation that confirms it."""
         gn = self._gn_state()
+        if check_every is None:
+            check_every = GN_CHECK_EVERY
+        if predicted_exit is None:
+            predicted_exit = GN_PREDICTED_EXIT
         self.begin_gn_phase()
         if gn.pop('host_stale', False):             # (ADVICE r04: gn_step() moved the device's counter since the host last saw it)
             gn['state_host'].copy_(gn['state'])
@@ -301,7 +317,7 @@ class PoseWindow:
         rc = self.lib.sp_window_gn_run(_lib.ptr(d), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, float(irls_eps), _lib.ptr(self.edges),
                                        self.n_edges, _lib.ptr(self.nodes), self.n_nodes, _lib.ptr(self.blocks), self.n_sources, gn['sum_N'],
                                        self.max_N, gn['n_y'], _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(gn['scratch']),
-                                       _lib.ptr(gn['nodes_backup']), _lib.ptr(gn['kld_backup']), 1 if pose_only else 0, float(lm_up),
+                                       _lib.ptr(gn['nodes_backup']), _lib.ptr(gn['kld_backup']), (1 if pose_only else 0) | (2 if predicted_exit else 0), float(lm_up),
                                        float(lm_down), float(lm_min), float(conv_tol), _lib.ptr(gn['state']), _lib.ptr(gn['losses']),
                                        self.max_iters, int(max_iters), int(check_every), gn['state_host'].data_ptr(), _lib.stream_ptr())
         if rc < 0:

@@ -554,6 +554,13 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
         torch.cuda.synchronize()
         # (IRLS weights 1 / max(|r|, eps) amplify a 2-ulp depth difference where |r| ~ eps: a few sums move by some 1e-4)
         np.testing.assert_allclose(npy(dt.partials), npy(batch.partials), rtol=2e-3, atol=1e-5 * float(np.abs(npy(batch.partials)).max()))
+    _check_against_per_keyframe_tables(batch, prs)
+
+
+def _check_against_per_keyframe_tables(batch, prs, granule=256):
+    """every array of the batch's set-up against the per-keyframe path (SegmentTable, blur_decimate, source_level, sp_pack_rgb), bit for bit"""
+    from super_primitive_amd.image import gaussian_pyramid
+    from super_primitive_amd.segment_table import SegmentTable, packed_target
     dev = batch.device
     for m, pr in enumerate(prs):
         masks, L, kp = T(pr.keypoint_regions).to(dev), T(pr.logdepth_perseg).to(dev), T(pr.keypoints).to(dev)
@@ -565,7 +572,7 @@ def test_batched_preparation_equals_the_per_keyframe_tables():
             lv_t.append(gaussian_pyramid.blur_decimate(lv_t[-1][None])[0])
         src4 = [tab.source_level(lv_s[l], K, kld).clone() for l in range(3)]
         # real points of the padded table: segment n occupies [pos, pos + counts[n])
-        pc = (tab.counts + 255) // 256 * 256
+        pc = (tab.counts + granule - 1) // granule * granule
         pos = np.concatenate(([0], np.cumsum(pc)))[:-1]
         idx = np.concatenate([np.arange(p, p + c) for p, c in zip(pos, tab.counts)])
         lo, hi = batch.p_off[m], batch.p_off[m + 1]
@@ -820,6 +827,49 @@ def test_slot_level_continuous_batching_of_ragged_pairs(granule):
         assert torch.equal(q.status, ref.status) and torch.equal(q.diag, ref.diag)
         # (rounds: a phase that ends by its convergence test spends one more evaluation than it counts iterations -- 4 phases per pair)
         assert n_q <= (its_ref.sum() + 4 * q.M) / slots + its_ref.max() + 2
+    assert int((ref.status & _lib.SP_STATUS_NONFINITE).sum()) == 0
+
+
+def test_sam_realistic_masks_through_the_set_up_and_the_slot_queue():
+    """SAM-REALISTIC segment sets (``synth.make_pair(shape='sam')``: areas over two decades at this size, masks with
+    holes, masks nested inside masks, two-lobed masks split into their components -- what frontend/segment/mask_generation.py:143-312 and
+    post_processer.py:160-181 emit; N differs from keyframe to keyframe) through (a) the batched set-up: every table, source sample and
+    packed target bitwise the per-keyframe path's; (b) the slot queue on one and on two streams: every pair bitwise where it ends with
+    all pairs resident, whatever slot, stream and order it ran in."""
+    from super_primitive_amd import _lib, synth
+    prs = [synth.make_pair(120, 160, 20, seed=300 + i, init_sigma=0.002 + 0.002 * (i % 4), shape="sam", blob_coverage=1.1) for i in range(9)]
+    Ns = [p.N for p in prs]
+    areas = np.concatenate([p.keypoint_regions.reshape(p.N, -1).sum(1) for p in prs])
+    print(f"\nsam masks: segments per keyframe {Ns}, areas {int(areas.min())} .. {int(areas.max())} px (median {int(np.median(areas))})")
+    assert len(set(Ns)) > 2 and areas.max() > 40 * areas.min()
+    holes = 0
+    for p in prs:                               # at least one ring among them: a mask whose centroid pixel is not in the mask
+        for k in range(p.N):
+            r, c = np.nonzero(p.keypoint_regions[k])
+            holes += int(not p.keypoint_regions[k, int(round(r.mean())), int(round(c.mean()))])
+    assert holes >= 1
+    batch = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), depth_table=False)
+    _check_against_per_keyframe_tables(batch, prs)
+    wave = make_batch(prs, levels=(0, 3), tile_points=1024, point_stride=(1, 2, 4), depth_table=False, granule=64)
+    _check_against_per_keyframe_tables(wave, prs, granule=64)
+    sch = dict(max_iters_per_level=12, conv_tol=2e-3, polish_max=6, polish_eps=1e-5, polish_tol=1e-4)
+    kw = dict(levels=(0, 3), tile_points=1024, point_stride=(2, 2, 4), granule=64)
+    ref = make_batch(prs, **kw)
+    ref.run_scheduled(check_every=1, **sch)
+    torch.cuda.synchronize()
+    for slots, streams in ((2, 1), (4, 2), (5, 3)):
+        q = make_batch(prs, **kw)
+        q.run_scheduled(check_every=1, slots=slots, streams=streams, **sch)
+        torch.cuda.synchronize()
+        assert q._queue_stats["head"] >= q.M and q._queue_stats["finished"]
+        for m in range(q.M):
+            assert torch.equal(q.poses()[m], ref.poses()[m]) and torch.equal(q.klds()[m], ref.klds()[m]), (slots, streams, m)
+        assert torch.equal(q.costs(), ref.costs()) and torch.equal(q.lm_state[:, :4], ref.lm_state[:, :4])
+        assert torch.equal(q.status, ref.status) and torch.equal(q.diag, ref.diag)
+    from parity_util import pose_depth_errors
+    errs = np.array([pose_depth_errors(npy(ref.poses()[m]), npy(ref.klds()[m]), p.pose_gt, p.kld_gt) for m, p in enumerate(prs)])
+    st = npy(ref.status)
+    print(f"sam masks: end states vs ground truth (worst) {errs.max(0)}, status {[hex(int(v)) for v in st]}")
     assert int((ref.status & _lib.SP_STATUS_NONFINITE).sum()) == 0
 
 

@@ -181,11 +181,18 @@ def test_config3_chain_stage_by_stage_from_the_references_own_states():
     output compared with the reference's: tracking (300 Adam steps), supplementary mapping (10), scheduled mapping (the reference's own
     iteration count), keyframe decision + creation (depth render, criterion, per-segment median).  Free-running, the chain inherits the
     jitter of every un-converged stage before it (the 4e-3 / 1e-2 / 3e-2 of the test above); stage by stage it must hold
-    1e-4 rad / 1e-4 t / 1e-3 depth."""
+    1e-4 rad / 1e-4 t / 1e-3 depth -- with ONE qualification, measured, not assumed: the reference's tracking stage does not converge (300
+    Adam steps at lr 5e-3 on an L1 cost jitter by ~3e-4 rad), and the REFERENCE ITSELF, re-run from its own recorded input with another
+    thread count, ends 1.5e-4 rad / 1.3e-4 t from its first run (golden ``spread_track``, oracle/gen_goldens_sequence.py ``stage_spread``).
+    Adam's first steps move the pose by its learning rate, 5e-3 rad per step, whatever the gradient's size: the iterate overshoots and
+    rings, and a last-bit difference in one gradient flips a step's sign a few iterations later -- even the first 50 steps of the
+    reference's tracker differ by 3e-4 rad between two of its own runs (``spread_track50``).  So the tracker is held to max(bar, 3 x the
+    reference's own spread) over the first 50 steps and over the full stage; the mapping stages (whose loops the reference reproduces bit
+    for bit across thread counts: spread 0) and the keyframe stage are held to the bar."""
     from conftest import load_golden
     from super_primitive_amd.odometery.sequence import MonoVO
     g = load_golden("g21_config3_sequence_chain")
-    if "f1_s0_kf_ids" not in g:
+    if "f1_s0_kf_ids" not in g or "spread_track" not in g:
         pytest.skip("golden g21 without stage snapshots (regenerate: python oracle/gen_goldens_sequence.py)")
     n = int(g["n_frames"])
     H, W, N = (int(v) for v in g["HWN"])
@@ -194,18 +201,33 @@ def test_config3_chain_stage_by_stage_from_the_references_own_states():
     kf_of = lambda i: cache.setdefault(i, to_kf(i))
     vo = MonoVO(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="adam", translation_thresh=0.095, window_size=5, depth_of=lambda i: T(seq[i].kld_gt))
     BAR_R, BAR_T, BAR_D = 1e-4, 1e-4, 1e-3
-    worst = dict(track=[0.0, 0.0, 0.0], supp=[0.0], map=[0.0, 0.0, 0.0, 0.0], keyframe=[0.0, 0.0])
+    sp_track, sp_map = g["spread_track"], g["spread_map"]
+    tol_track = (max(BAR_R, 3 * float(sp_track[0])), max(BAR_T, 3 * float(sp_track[1])), max(5e-4, 3 * float(sp_track[2])))
+    sp50 = g["spread_track50"]
+    tol_track50 = (max(BAR_R, 3 * float(sp50[0])), max(BAR_T, 3 * float(sp50[1])), max(2e-4, 3 * float(sp50[2])))
+    tol_map = (max(BAR_R, 3 * float(sp_map[0])), max(BAR_T, 3 * float(sp_map[1])), max(BAR_D, 3 * float(sp_map[2])), max(5e-4, 3 * float(sp_map[3])))
+    print(f"\nthe reference against itself per stage (threads {g['spread_threads'].tolist()}): tracking {sp_track}, its first 50 steps {g['spread_track50']}, supplementary mapping "
+          f"{g['spread_supp']}, scheduled mapping {sp_map}")
+    worst = dict(track=[0.0, 0.0, 0.0], track50=[0.0, 0.0, 0.0], supp=[0.0], map=[0.0, 0.0, 0.0, 0.0], keyframe=[0.0, 0.0])
     n_stage = dict(track=0, supp=0, map=0, keyframe=0)
     pose_err = lambda A, B: (rot_angle(np.asarray(A, np.float64), np.asarray(B, np.float64)), float(np.abs(np.asarray(A, np.float64)[:3, 3] - np.asarray(B, np.float64)[:3, 3]).max()))
     for i in range(1, n):
-        # ---- tracking: s0 -> s1
+        # ---- tracking: s0 -> its first 50 steps (the bar), s0 -> s1 (the bar or 3 x the reference's own spread)
+        _load_chain_state(vo, g, f"f{i}_s0", frames, kf_of)
+        vo.c["track_steps"] = (0, 0, 50)
+        vo.track_frame(i)
+        vo.c["track_steps"] = (0, 0, 300)
+        r, t = pose_err(npy(vo.current_track), g[f"f{i}_track50_pose"])
+        a = float(np.abs(npy(vo.current_aff) - g[f"f{i}_track50_aff"]).max())
+        worst["track50"] = [max(x, y) for x, y in zip(worst["track50"], (r, t, a))]
+        assert r <= tol_track50[0] and t <= tol_track50[1] and a <= tol_track50[2], (i, "track, first 50 steps", r, t, a, tol_track50)
         _load_chain_state(vo, g, f"f{i}_s0", frames, kf_of)
         vo.track_frame(i)
         r, t = pose_err(npy(vo.current_track), g[f"f{i}_s1_current_track"])
         a = float(np.abs(npy(vo.current_aff) - g[f"f{i}_s1_current_aff"]).max())
         worst["track"] = [max(x, y) for x, y in zip(worst["track"], (r, t, a))]
         n_stage["track"] += 1
-        assert r <= BAR_R and t <= BAR_T and a <= 5e-4, (i, "track", r, t, a)
+        assert r <= tol_track[0] and t <= tol_track[1] and a <= tol_track[2], (i, "track", r, t, a, tol_track)
         last = "s1"
         # ---- supplementary mapping: s1 -> s2
         if f"f{i}_s2_kf_ids" in g:
@@ -232,7 +254,7 @@ def test_config3_chain_stage_by_stage_from_the_references_own_states():
             rr, tt = max(e[0] for e in pe + se), max(e[1] for e in pe + se)
             worst["map"] = [max(x, y) for x, y in zip(worst["map"], (rr, tt, d, fa))]
             n_stage["map"] += 1
-            assert rr <= BAR_R and tt <= BAR_T and d <= BAR_D and fa <= 5e-4, (i, "map", n_it, rr, tt, d, fa)
+            assert rr <= tol_map[0] and tt <= tol_map[1] and d <= tol_map[2] and fa <= tol_map[3], (i, "map", n_it, rr, tt, d, fa, tol_map)
             last = "s3"
         # ---- keyframe decision / creation: -> s4
         _load_chain_state(vo, g, f"f{i}_{last}", frames, kf_of)
@@ -252,8 +274,9 @@ def test_config3_chain_stage_by_stage_from_the_references_own_states():
             worst["keyframe"][1] = max(worst["keyframe"][1], d)
             assert d <= BAR_D, (i, "keyframe depths", d)
             assert vo.mapping_scheduled
-    print(f"\nteacher-forced chain, {n - 1} frames: stages compared {n_stage}; worst deviation from the reference's own stage output: tracking rot {worst['track'][0]:.1e} rad, "
-          f"t {worst['track'][1]:.1e}, affine {worst['track'][2]:.1e}; supplementary mapping depth {worst['supp'][0]:.1e}; scheduled mapping rot {worst['map'][0]:.1e}, t {worst['map'][1]:.1e}, "
+    print(f"\nteacher-forced chain, {n - 1} frames: stages compared {n_stage}; worst deviation from the reference's own stage output: tracking, first 50 steps, rot "
+          f"{worst['track50'][0]:.1e} rad, t {worst['track50'][1]:.1e}, affine {worst['track50'][2]:.1e}; tracking, all 300 steps, rot {worst['track'][0]:.1e} rad, "
+          f"t {worst['track'][1]:.1e}, affine {worst['track'][2]:.1e} (asserted {tol_track}); supplementary mapping depth {worst['supp'][0]:.1e}; scheduled mapping rot {worst['map'][0]:.1e}, t {worst['map'][1]:.1e}, "
           f"depth {worst['map'][2]:.1e}, affine {worst['map'][3]:.1e}; keyframe criterion (relative) {worst['keyframe'][0]:.1e}, new keyframe depths {worst['keyframe'][1]:.1e}")
     assert n_stage["track"] == n - 1 and n_stage["supp"] == n - 1 and n_stage["map"] >= 2 and n_stage["keyframe"] == n - 1
 

@@ -444,3 +444,50 @@ def test_keyframe_drops_its_set_up_record_on_assignment_and_never_copies_it():
     assert "_sp_prep" in kf.__dict__
     assert "_sp_prep" not in copy.deepcopy(kf).__dict__ and "_sp_prep" not in pickle.loads(pickle.dumps(kf)).__dict__
     assert "_sp_prep" in kf.__dict__
+
+
+def test_schedule_lays_out_three_attempts_and_picks_the_damping_from_the_segments():
+    """Host logic of the scheduled run (no GPU): ``PairBatch.schedule`` on a stand-in batch -- the SpSchedule of REFERENCE_START_SCHEDULE
+    holds the third attempt's Adam phases in front (retry2_entry = 0, SP_PHASE_ADAM, joining the list at its finest joint phase), then the
+    second attempt's pose-only phase (retry_entry, joining at the first joint phase), then the first attempt's list (entry); every phase
+    carries SP_PHASE_PREDICTED_EXIT; the damping of the damped coarse phase follows the batch's points per segment."""
+    import types
+    import torch
+    from super_primitive_amd import _lib
+    from super_primitive_amd.optim import pair_batch as pb
+    t = lambda n=4: torch.zeros(n, dtype=torch.float32)
+    lay = lambda pts: types.SimpleNamespace(desc=torch.zeros(8, dtype=torch.uint8), chunks=torch.zeros(4, dtype=torch.int32), spans=torch.zeros(4, dtype=torch.int32),
+                                            n_spans=1, partials=t(), seg_partials=t(), points=pts)
+    fake = types.SimpleNamespace(level_ids=[0, 1, 2], point_stride={0: 2, 1: 2, 2: 4}, desc={0: torch.zeros(8, dtype=torch.uint8)}, chunks=torch.zeros(4, dtype=torch.int32),
+                                 spans=torch.zeros(4, dtype=torch.int32), n_spans=1, partials=t(), seg_partials=t(), wave_flag=_lib.SP_COST_WAVE_SPANS,
+                                 table_flag=_lib.SP_COST_DEPTH_TABLE, adam_state=t(64), Ns=[64, 64], Ps=[373056, 373056],
+                                 coarse={(0, 2): lay([93264, 93264]), (1, 2): lay([93264, 93264]), (2, 4): lay([23316, 23316])})
+    fake.auto_coarse_damping = lambda level, stride: pb.PairBatch.auto_coarse_damping(fake, level, stride)
+    kw = {k: v for k, v in pb.REFERENCE_START_SCHEDULE.items() if k != "check_every"}
+    s = pb.PairBatch.schedule(fake, **kw)
+    n2, n1 = len(pb.REFERENCE_START_ADAM), len(pb.REFERENCE_START_RETRY)
+    assert (s.n_phases, s.retry2_entry, s.retry_entry, s.entry) == (n2 + n1 + 6, 0, n2, n2 + n1)
+    flags = [s.phase[p].flags for p in range(s.n_phases)]
+    assert all(f & _lib.SP_PHASE_ADAM for f in flags[:n2]) and not any(f & _lib.SP_PHASE_ADAM for f in flags[n2:])
+    assert all(f & _lib.SP_PHASE_PREDICTED_EXIT for f in flags) and all(f & _lib.SP_PHASE_WAVE_SPANS and f & _lib.SP_PHASE_DEPTH_TABLE for f in flags)
+    assert [s.phase[p].max_iters for p in range(n2)] == [500, 500, 500] and abs(s.adam_lr_pose - 1e-2) < 1e-9 and abs(s.adam_lr_kld - 1e-3) < 1e-9
+    assert s.adam_state == fake.adam_state.data_ptr()
+    first = n2 + n1                                    # pose-only, damped, joint L2, joint L1, joint L0, polish
+    assert s.phase[first].flags & _lib.SP_PHASE_POSE_ONLY and s.phase[n2].flags & _lib.SP_PHASE_POSE_ONLY
+    assert s.phase[n2 - 1].next == first + 4           # the third attempt joins at the finest joint phase (level 0, stride 2) ...
+    assert s.phase[n2 + n1 - 1].next == first + 1      # ... the second at the first phase that is not pose-only (the damped one)
+    damp = lambda p: (s.phase[p].flags >> _lib.SP_PHASE_DEPTH_DAMP_SHIFT) & 0xff
+    assert damp(first + 1) == 8 * 16 and all(damp(p) == 0 for p in range(s.n_phases) if p != first + 1)      # 364 coarse points per segment: damping 16
+    assert s.phase[s.n_phases - 1].spans == fake.spans.data_ptr() and s.phase[first + 4].spans == fake.coarse[(0, 2)].spans.data_ptr()
+    # many small segments: a dozen lattice points each -> damping 12
+    fake.Ns = [1200, 1200]
+    s2 = pb.PairBatch.schedule(fake, **kw)
+    assert (s2.phase[first + 1].flags >> _lib.SP_PHASE_DEPTH_DAMP_SHIFT) & 0xff == 8 * 12
+    # without later attempts the list stands alone
+    s3 = pb.PairBatch.schedule(fake, **dict(kw, retry_phases=None, retry2_phases=None))
+    assert (s3.n_phases, s3.entry, s3.retry_entry, s3.retry2_entry, s3.adam_state) == (6, 0, -1, -1, None)
+    # only the third attempt (no second): it still joins, and the verdict's thresholds are the documented ones
+    s4 = pb.PairBatch.schedule(fake, **dict(kw, retry_phases=None))
+    assert (s4.entry, s4.retry_entry, s4.retry2_entry) == (n2, -1, 0) and s4.phase[n2 - 1].next == n2 + 4
+    assert pb.VERDICT_DEFAULTS["seg_mean_ratio"] == 1.3 and pb.VERDICT_DEFAULTS["seg_max_ratio"] == 8.0
+    assert pb.VERDICT_DEFAULTS["retry_on"] & _lib.SP_STATUS_SEGMENTS
