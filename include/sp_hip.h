@@ -118,7 +118,9 @@ typedef struct SpPrepTable {     /* one keyframe: its masks are read once per pa
     int32_t* counts[SP_PREP_MAX_STRIDES];       /* N each, out of sp_prepare_count */
     const int32_t* seg_off[SP_PREP_MAX_STRIDES];/* N each: first table position of every segment (host-made, padded layout) */
     uint32_t* pix[SP_PREP_MAX_STRIDES];         /* out of sp_prepare_fill */
-    float* baseL[SP_PREP_MAX_STRIDES];
+    float* baseL[SP_PREP_MAX_STRIDES];          /* out of sp_prepare_fill: the log-depth of every table point -- or all NULL (ABI 13): no copy is made, the
+                                                   sampling pass reads the keyframe's dense array instead (SP_PREP_DENSE_L): 8 bytes per lattice point of
+                                                   writes and re-reads less, and the fill pass loses its log-depth loads */
     int32_t stride[SP_PREP_MAX_STRIDES];
     int32_t N, H, W, n_strides;
     uint32_t* bits;              /* N*H*(W/16) words or NULL: the masks as one bit word per 16 pixels, written by sp_prepare_count on
@@ -137,7 +139,7 @@ typedef struct SpPrepTable {     /* one keyframe: its masks are read once per pa
 } SpPrepTable;                   /* 240 bytes */
 typedef struct SpPrepSample {    /* one table, sampled at up to SP_PREP_MAX_LEVELS pyramid levels in one pass; sets pix bit 31 */
     uint32_t* pix;
-    const float* baseL;
+    const float* baseL;          /* [P] the table's own log-depths; under SP_PREP_DENSE_L: the keyframe's dense (N,H,W) array (N H W < 2^32) */
     const int32_t* seg_off;      /* N, relative to pix */
     const int32_t* counts;       /* N: real points of every segment */
     const float* kp_L;
@@ -148,9 +150,11 @@ typedef struct SpPrepSample {    /* one table, sampled at up to SP_PREP_MAX_LEVE
     int32_t Hl[SP_PREP_MAX_LEVELS], Wl[SP_PREP_MAX_LEVELS];
     int32_t N, P, H, W, n_levels;
     int32_t granule;             /* low 16 bits: padding granule of the runs: 0 / 256, or 64 for wave-span tables (SP_COST_WAVE_SPANS);
-                                    | SP_PREP_DEPTH_TABLE: write exp(L) instead of L into src4.w (SP_COST_DEPTH_TABLE) */
+                                    | SP_PREP_DEPTH_TABLE: write exp(L) instead of L into src4.w (SP_COST_DEPTH_TABLE)
+                                    | SP_PREP_DENSE_L: baseL is the dense (N,H,W) array, a point's log-depth sits at (its segment, row, column) */
 } SpPrepSample;                  /* 176 bytes */
 #define SP_PREP_DEPTH_TABLE 0x10000
+#define SP_PREP_DENSE_L 0x20000
 typedef struct SpPrepImage {
     const float* in;             /* (C,H,W) planar */
     float* out;                  /* blur: (C,ceil(H/2),ceil(W/2)); pack: (H,W,3) */
@@ -492,7 +496,10 @@ typedef struct SpQueue {
     float* q_lm;
     float lam0;
     int32_t pad2_;
-} SpQueue;               /* 288 bytes */
+    int32_t* active;             /* (ABI 13) device scratch [n_slots] or NULL: the slots that still work on a pair, listed at every poll -- once the queue
+                                  * is empty and at most an eighth of the slots are busy, the launches of a round go over those alone (the tail of a run:
+                                  * a third attempt iterates 1500 rounds by itself) */
+} SpQueue;               /* 296 bytes */
 int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, int n_slots, int max_N, float lm_up, float lm_down,
                                 float lm_min, float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters,
                                 int check_every, int max_rounds, int32_t* flag_dev, int32_t* flag_host, const SpVerdict* verdict /* or NULL */,

@@ -104,6 +104,7 @@ SP_PHASE_ADAM = 8
 SP_PHASE_PREDICTED_EXIT = 16
 SP_PHASE_DEPTH_DAMP_SHIFT = 8
 SP_PREP_DEPTH_TABLE = 0x10000
+SP_PREP_DENSE_L = 0x20000
 
 
 SP_PREP_MAX_STRIDES = 4
@@ -169,7 +170,8 @@ class SpQueue(ctypes.Structure):
     """Mirror of ``struct SpQueue`` (include/sp_hip.h): slot-level continuous batching of a scheduled run; host memory."""
     _fields_ = [("qpairs", c_void_p * SP_MAX_PHASES), ("slot_pairs", c_void_p * SP_MAX_PHASES), ("max_spans", c_int * SP_MAX_PHASES),
                 ("n_queue", c_int), ("pad_", c_int),
-                ("head", c_void_p), ("slot_pair", c_void_p), ("q_costs", c_void_p), ("q_lm", c_void_p), ("lam0", c_float), ("pad2_", c_int)]
+                ("head", c_void_p), ("slot_pair", c_void_p), ("q_costs", c_void_p), ("q_lm", c_void_p), ("lam0", c_float), ("pad2_", c_int),
+                ("active", c_void_p)]
 
 
 class SpWindowNode(ctypes.Structure):

@@ -1025,6 +1025,7 @@ struct FuseArgs {
     const int32_t* done;      // [n_pairs] or NULL: spans of pairs marked done by the solver return at once
     const int32_t* phase;     // per-pair schedules (sp_pairs_schedule_cost): the phase of a pair selects its level descriptors and
     SchedCost sched;          // IRLS epsilon; spans of pairs that are finished, or in a phase of another work list, return at once
+    const int32_t* active;    // queue runs, the tail: the launch covers only these slots (SpQueue.active), virtual span v belongs to active[v / vspans]
 };
 
 template <int MODE, int ABL = 0, int FUSED = 0, bool W64 = false>
@@ -1061,6 +1062,7 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED != 0 ? 1 : (MODE == 2 ? 2 : 4)) voi
         // pair the slot works on right now (its descriptor carries the pair's own span range of the batch's list), or nothing
         owner = w / vspans;
         const int j = w - owner * vspans;
+        if (f.active) owner = f.active[owner];
         const int ph = f.phase[owner];
         if (ph >= SP_MAX_PHASES || ph < 0 || !((phase_mask >> ph) & 1u)) return;
         pairs = f.sched.pairs[ph];
@@ -1332,7 +1334,7 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
     return 0;
 }
 
-int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) { return schedule_cost_from(sched, phase, stream, 0, nullptr, 0); }
+int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) { return schedule_cost_from(sched, phase, stream, 0, nullptr, 0, nullptr, 0); }
 
 }  // extern "C"
 
@@ -1340,7 +1342,9 @@ int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* 
 // beyond it have no pair left and are not launched -- two of the three launches of a frame-pair schedule's iteration through
 // its long tail (sp_pairs_schedule_run).
 // queue / n_slots: a queue run (sp_pairs_schedule_run_queue) -- every list is launched over n_slots * max_spans virtual spans.
-int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase, const SpQueue* queue, int n_slots) {
+// active / n_active: the tail of a queue run -- only the n_active slots listed in `active` are launched over (sp_pairs_schedule_run_queue)
+int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase, const SpQueue* queue, int n_slots,
+                       const int32_t* active, int n_active) {
     if (!sched || !phase || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
     if (queue && n_slots <= 0) return SP_EINVAL;
     for (int p = 0; p < sched->n_phases; ++p) {
@@ -1355,6 +1359,7 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
     uint32_t seen = 0;
     FuseArgs f{};
     f.phase = phase;
+    if (queue && active && n_active > 0) { f.active = active; n_slots = n_active; }
     for (int p = 0; p < sched->n_phases; ++p) {
         f.sched.pairs[p] = sched->phase[p].pairs;
         f.sched.irls_eps[p] = sched->phase[p].irls_eps;

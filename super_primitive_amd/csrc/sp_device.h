@@ -40,7 +40,8 @@ __device__ __forceinline__ float fast_exp(float x) {
 // sp_pairs_schedule_cost() from a phase every pair is known to have reached (sp_cost.hip; used by sp_pairs_schedule_run in sp_solver.hip)
 struct SpSchedule;
 struct SpQueue;
-__attribute__((visibility("hidden"))) int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase, const SpQueue* queue, int n_slots);
+__attribute__((visibility("hidden"))) int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase, const SpQueue* queue, int n_slots,
+                                                              const int32_t* active, int n_active);
 
 // ---------------------------------------------------------------------------------------------------
 // wave64 / block reductions (fixed order -> bitwise reproducible run to run)

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
     solve_gn(pairs, blockIdx.x, partials, seg_partials, h);
 }
 
-static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 800 && sizeof(SpVerdict) == 96 && sizeof(SpQueue) == 288 && sizeof(SpPair) == 136,
+static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 800 && sizeof(SpVerdict) == 96 && sizeof(SpQueue) == 296 && sizeof(SpPair) == 136,
               "SpSchedule / SpVerdict / SpQueue / SpPair are part of the ABI");
 
 // per-pair schedules: the pair's current phase selects the level descriptors, the partial records of that level's work list,
@@ -32,8 +32,8 @@ static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 800 && sizeof(SpVer
 // next cost pass already works on the new pair and the resident set stays full until the queue is empty.  Pairs never interact and a
 // descriptor carries the pair's own span range (the cost pass of a queue run is launched over virtual spans): each pair's result
 // is bitwise what it is with all pairs resident.
-__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, GnArgs h, SpQueue q, SpVerdict v) {
-    const int slot = blockIdx.x;
+__global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, GnArgs h, SpQueue q, SpVerdict v, const int32_t* __restrict__ active) {
+    const int slot = active ? active[blockIdx.x] : blockIdx.x;        // (the tail of a queue run is launched over the listed slots only)
     const int ph = h.phase[slot];
     if (ph >= sched.n_phases || ph < 0) return;           // finished, and the queue was empty when it did
     if (v.evals && threadIdx.x == 0) v.evals[(size_t)(q.n_queue > 0 ? q.slot_pair[slot] : slot) * SP_MAX_PHASES + ph] += 1;
@@ -207,12 +207,19 @@ __global__ void k_mark_unfinished(const int32_t* __restrict__ phase, const int32
 // may restart at retry_entry / retry2_entry at any time, so no work list can be left out while one exists)
 __global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restrict__ phase, int n, int32_t* __restrict__ out,
                                                         const int32_t* __restrict__ head, const int32_t* __restrict__ attempts,
-                                                        const int32_t* __restrict__ slot_pair, int n_phases, int last_attempt) {
+                                                        const int32_t* __restrict__ slot_pair, int n_phases, int last_attempt,
+                                                        int32_t* __restrict__ active_out) {
     __shared__ int part[SP_WAVES], first[SP_WAVES];
+    __shared__ int n_active_s;
+    if (threadIdx.x == 0) n_active_s = 0;
+    __syncthreads();
     int m = 0x7fffffff, f = 0;
     for (int i = threadIdx.x; i < n; i += SP_BLOCK) {
         const int ph = phase[i];
         m = min(m, ph);
+        // out[3] / active_out: how many slots still work on a pair, and which (in no particular order: a pair's result does not depend
+        // on where it runs) -- the host launches the tail of a queue run over those alone
+        if (ph >= 0 && ph < n_phases) { const int at = atomicAdd(&n_active_s, 1); if (active_out) active_out[at] = i; }
         if (attempts && ph < n_phases && attempts[slot_pair ? slot_pair[i] : i] < last_attempt) f = 1;
     }
 #pragma unroll
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restric
         out[0] = min(min(part[0], part[1]), min(part[2], part[3]));
         out[1] = head ? *head : 0;
         out[2] = first[0] | first[1] | first[2] | first[3];
+        out[3] = n_active_s;
     }
 }
 
@@ -316,7 +324,7 @@ int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, f
     if (int rc = check_schedule(sched, verdict)) return rc;
     hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_pairs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), *sched,
                        GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0}, SpQueue{},
-                       verdict ? *verdict : SpVerdict{});
+                       verdict ? *verdict : SpVerdict{}, (const int32_t*)nullptr);
     SP_CHECK_LAUNCH();
     return 0;
 }
@@ -342,24 +350,32 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
     int it = 0;
     int reached = 0;                  // a phase every slot has passed -- only meaningful once the queue is empty (refilled slots restart at the entry)
     int min_phase = 0;
+    // THE TAIL (round 6): once the queue is empty and few slots still work on a pair -- a third attempt runs 1500 rounds on its own --
+    // both launches of a round go over the slots k_phase_min listed at the last poll instead of over all of them (a slot that finishes
+    // between two polls returns at once, none can become active again): a round of one pair costs its own kernels' latency, not the
+    // dispatch of n_slots x max_spans workgroups that find nothing to do
+    int n_active = 0;
     while (it < max_rounds) {
         const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
+        const bool tail = queue->active && n_active > 0 && 8 * n_active <= n_slots;
         for (int k = 0; k < n; ++k, ++it) {
-            int rc = schedule_cost_from(sched, phase, stream, reached, queue, n_slots);
+            int rc = schedule_cost_from(sched, phase, stream, reached, queue, n_slots, tail ? queue->active : nullptr, tail ? n_active : 0);
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
-            hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_slots), dim3(SP_BLOCK), 0, s, *sched,
-                               GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0}, *queue, vd);
+            hipLaunchKernelGGL(k_pairs_gn_sched, dim3(tail ? n_active : n_slots), dim3(SP_BLOCK), 0, s, *sched,
+                               GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0}, *queue, vd,
+                               tail ? (const int32_t*)queue->active : (const int32_t*)nullptr);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return -(1000 + (int)e);
         }
         hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_slots, flag_dev, queue->head, may_retry ? vd.attempts : nullptr,
-                           queue->slot_pair, sched->n_phases, last_attempt);
+                           queue->slot_pair, sched->n_phases, last_attempt, queue->active);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
         min_phase = static_cast<volatile int32_t*>(flag_host)[0];
         const int head = static_cast<volatile int32_t*>(flag_host)[1];
+        n_active = head >= queue->n_queue ? static_cast<volatile int32_t*>(flag_host)[3] : 0;       // (while pairs wait, every slot is busy)
         const bool first_attempts_left = static_cast<volatile int32_t*>(flag_host)[2] != 0;
         if (min_phase >= sched->n_phases) break;          // (a slot only stays finished when the queue was empty)
         reached = (head >= queue->n_queue && !(may_retry && first_attempts_left)) ? (min_phase < 0 ? 0 : min_phase) : 0;
@@ -389,12 +405,13 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
     while (it < max_rounds) {
         const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
         for (int k = 0; k < n; ++k, ++it) {
-            int rc = schedule_cost_from(sched, phase, stream, reached, nullptr, 0);
+            int rc = schedule_cost_from(sched, phase, stream, reached, nullptr, 0, nullptr, 0);
             if (rc == 0) rc = sp_pairs_schedule_gn_step(sched, n_pairs, max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, phase, iters, verdict, stream);
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
         }
         hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_pairs, flag_dev, (const int32_t*)nullptr,
-                           may_retry ? (const int32_t*)verdict->attempts : (const int32_t*)nullptr, (const int32_t*)nullptr, sched->n_phases, last_attempt);
+                           may_retry ? (const int32_t*)verdict->attempts : (const int32_t*)nullptr, (const int32_t*)nullptr, sched->n_phases, last_attempt,
+                           (int32_t*)nullptr);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);

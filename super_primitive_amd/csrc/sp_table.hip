@@ -90,7 +90,7 @@ __device__ __forceinline__ void fill_row(const uint8_t* __restrict__ masks, cons
         if (on) {
             const int k = base + __popcll(bal & ((1ull << lane) - 1ull));
             pix[k] = ((uint32_t)r << 16) | (uint32_t)x;
-            baseL[k] = L[x];
+            if (baseL) baseL[k] = L[x];
         }
         base += __popcll(bal);
     }
@@ -706,6 +706,10 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
     }
     const SP_GLOBAL uint32_t* const bits_p = t.bits;
     const SP_GLOBAL float* const logdepth_p = t.logdepth;
+    // Round 6: baseL == NULL -- the table carries NO copy of the log-depths (the sampling pass reads them from the keyframe's dense array
+    // at the point's own (segment, row, column): SP_PREP_DENSE_L): this pass then neither loads the octets' log-depths -- its longest
+    // dependent chain -- nor writes 4 bytes per lattice point, and the sampling pass reads 4 bytes per point either way
+    const bool with_L = baseL_k[0] != nullptr;
     const int W = t.W, qpr = W >> 4;
     const int rb = min(RB, LIST / (2 * qpr));
 
@@ -747,8 +751,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
         // (the bit word again, from the L2 this time -- the wave just read it -- next to the log-depths: no LDS copy of the batch's words)
         o.word = bits_p[(rr & 0x3fffffu) * (uint32_t)qpr + (uint32_t)(o.oct >> 1)];
         const SP_GLOBAL float* Lp = logdepth_p + ((rr & 0x3fffffu) * (uint32_t)W + (uint32_t)(8 * o.oct));
-        o.La = load4((const SP_GLOBAL f32x4*)Lp);        // (both halves, whatever the bits say, and for the lanes past the list the first
-        o.Lb = load4((const SP_GLOBAL f32x4*)(Lp + 4));  //  octet of the list: no control flow around the loads)
+        o.La = o.Lb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (with_L) {                                        // (wave-uniform)
+            o.La = load4((const SP_GLOBAL f32x4*)Lp);        // (both halves, whatever the bits say, and for the lanes past the list the first
+            o.Lb = load4((const SP_GLOBAL f32x4*)(Lp + 4));  //  octet of the list: no control flow around the loads)
+        }
     };
     Batch bt, bt_next;
     request(bt);
@@ -820,7 +827,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill_bits(const SpPrepTable* 
                     const uint2 v = s_stage[wave][j];
                     const int dest = s_delta[wave][k][(v.x >> 10) & 0x3fu] + run[k] + j;
                     pix_k[k][(uint32_t)dest] = v.x & 0xffff03ffu;            // (non-temporal stores and log-depth loads here: 215 -> 270 us)
-                    baseL_k[k][(uint32_t)dest] = __uint_as_float(v.y);
+                    if (with_L) baseL_k[k][(uint32_t)dest] = __uint_as_float(v.y);
                 }
             }
             run[0] += T[0]; run[1] += T[1]; run[2] += T[2]; run[3] += T[3];
@@ -921,7 +928,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_fill(const SpPrepTable* __res
                 for (int j = 0; j < 4; ++j)
                     if ((sel >> (8 * j + 7)) & 1u) {
                         pix_k[k][pos] = ((uint32_t)r << 16) | (uint32_t)(4 * xw + j);
-                        baseL_k[k][pos] = Lq[j];
+                        if (baseL_k[k]) baseL_k[k][pos] = Lq[j];
                         ++pos;
                     }
                 base[k] += __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
@@ -982,10 +989,11 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
     // do; the search then runs per wave)
     const int lane_off = (j.granule & 0xffff) == 64 ? (int)(threadIdx.x & ~63u) : 0;
     const bool depth_table = (j.granule & SP_PREP_DEPTH_TABLE) != 0;      // src4.w = exp(L) for the cost kernels' depth-table form
+    const bool dense_L = (j.granule & SP_PREP_DENSE_L) != 0;              // baseL = the keyframe's dense (N,H,W) log-depths, read at (segment, row, column)
     // The pass is bound by memory latency, not bytes or arithmetic (waves parked on s_waitcnt 87 % of their cycles when every
     // point went load -> geometry -> 12 taps -> store on its own): the SP_SAMPLE_BLOCKS points of a thread go through each stage
     // together -- all table words requested, then all taps of a level, then the stores.
-    int idx[SP_SAMPLE_BLOCKS];
+    int idx[SP_SAMPLE_BLOCKS], seg[SP_SAMPLE_BLOCKS];
     bool in_table[SP_SAMPLE_BLOCKS], live[SP_SAMPLE_BLOCKS];
     float shift[SP_SAMPLE_BLOCKS];
     {
@@ -1007,6 +1015,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
             in_table[k] = idx[k] < j.P;
             live[k] = in_table[k] && idx[k] - first < count;       // (else padding of the segment's run: an invalid point)
             shift[k] = sh;
+            seg[k] = n;
         }
     }
     SP_GLOBAL uint32_t* const pix = j.pix;             // (record fields in registers before the first store: see k_prep_fill)
@@ -1016,7 +1025,15 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __
 #pragma unroll
     for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) {
         pw[k] = live[k] ? pix[idx[k]] : 0u;
-        L[k] = live[k] ? j.baseL[idx[k]] : 0.f;
+        if (!dense_L) L[k] = live[k] ? j.baseL[idx[k]] : 0.f;
+    }
+    if (dense_L) {
+        // (consecutive table points are consecutive columns of one mask row: the lanes of a wave read runs of consecutive floats)
+#pragma unroll
+        for (int k = 0; k < SP_SAMPLE_BLOCKS; ++k) {
+            const uint32_t at = ((uint32_t)seg[k] * (uint32_t)j.H + ((pw[k] >> 16) & 0x7fffu)) * (uint32_t)j.W + (pw[k] & 0xffffu);
+            L[k] = live[k] ? j.baseL[at] : 0.f;
+        }
     }
     SourceGeom g[SP_SAMPLE_BLOCKS];
 #pragma unroll

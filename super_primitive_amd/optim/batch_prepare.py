@@ -485,17 +485,21 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     if (lay['points'][all_strides.index(1)] == 0).any():
         raise ValueError("keyframe has no segment pixels")
     seg_off_d = lay['seg_off_pinned'].to(dev, non_blocking=True)
+    dense_L = bool(((Ns.astype(np.int64) * Hs.astype(np.int64) * Ws.astype(np.int64)) < (1 << 32)).all())
     for si, s in enumerate(all_strides):
         t = PreparedTables()
         t.stride = s
         t.counts, t.pc, t.seg_pos, t.p_off, t.points = lay['counts'][si], lay['pc'][si], lay['seg_pos'][si], lay['p_off'][si], lay['points'][si]
         total = max(int(t.p_off[-1]), 1)
         t.pix = torch.empty(total, dtype=torch.int32, device=dev)               # (the sampler writes the padding: zero = invalid point)
-        t.baseL = torch.empty(total, dtype=torch.float32, device=dev)
+        # (round 6: NO baseL copy of the points' log-depths -- SpPrepTable.baseL stays NULL, the sampler reads the keyframe's dense array at the
+        #  point's (segment, row, column), SP_PREP_DENSE_L: 8 bytes per lattice point of writes and re-reads less, and the fill pass loses the
+        #  log-depth loads that were its longest dependent chain.  Needs N H W < 2^32 per keyframe, else the copy is made as before)
+        t.baseL = None if dense_L else torch.empty(total, dtype=torch.float32, device=dev)
         # segment positions: inside the flat array (fill) and relative to the pair's own table (sampler, cost kernels)
         t.counts_d = counts_d[si * S: (si + 1) * S]
         t.seg_off = seg_off_d[si]
-        recs['pix'][:, si], recs['baseL'][:, si] = t.pix.data_ptr(), t.baseL.data_ptr()
+        recs['pix'][:, si], recs['baseL'][:, si] = t.pix.data_ptr(), (0 if dense_L else t.baseL.data_ptr())
         recs['seg_off'][:, si] = t.seg_off.data_ptr() + 4 * n_off[:-1]
         t.src4 = {}
         tabs[s] = t
@@ -518,13 +522,13 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
             P = np.diff(t.p_off)
             max_P = max(max_P, int(P.max()))
             jb['pix'] = t.pix.data_ptr() + 4 * t.p_off[:-1]
-            jb['baseL'] = t.baseL.data_ptr() + 4 * t.p_off[:-1]
+            jb['baseL'] = frec['logdepth'] if dense_L else t.baseL.data_ptr() + 4 * t.p_off[:-1]
             jb['seg_off'] = t.seg_off.data_ptr() + 4 * (S + n_off[:-1])              # the pair-relative half
             jb['counts'] = t.counts_d.data_ptr() + 4 * n_off[:-1]
             jb['kp_L'] = kp_L.data_ptr() + 4 * n_off[:-1]
             jb['kld'], jb['K'] = kld_ptr, frec['K']
             jb['N'], jb['P'], jb['H'], jb['W'], jb['n_levels'] = Ns, P, Hs, Ws, len(lv)
-            jb['granule'] = granule | (_lib.SP_PREP_DEPTH_TABLE if depth_table else 0)      # (depth tables: src4.w = exp(L), include/sp_hip.h)
+            jb['granule'] = granule | (_lib.SP_PREP_DEPTH_TABLE if depth_table else 0) | (_lib.SP_PREP_DENSE_L if dense_L else 0)      # (depth tables: src4.w = exp(L), include/sp_hip.h)
             for k, l in enumerate(lv):
                 t.src4[l] = torch.empty(max(int(t.p_off[-1]), 1), 4, dtype=torch.float32, device=dev)
                 jb['image'][:, k] = ptr_lv[l][0]
@@ -578,7 +582,8 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
                 count_bytes += int(Ns[i] * Hs[i] * Ws[i]) + 4 * int(words[i])
         return {
             'count': count_bytes,
-            'fill': 4 * n_pts[1] + 8 * sum(n_pts.values()) + n_pts[1] // 4,                  # L in (once per mask pixel), pix + baseL out per lattice point, set bits in
+            # fill: the set bits in, pix out per lattice point (+ with a baseL copy: L in once per mask pixel, baseL out per lattice point)
+            'fill': (4 * sum(n_pts.values()) + n_pts[1] // 4) if dense_L else (4 * n_pts[1] + 8 * sum(n_pts.values()) + n_pts[1] // 4),
             'sample': sum((12 + 16 * len(lv)) * n_pts[s] for s, lv in levels_of.items())     # pix + baseL in, pix out, one src4 per sampled level out
                       + sum(12 * img_px[l] for l in sampled_levels),                         # ... and every sampled source level read once
             'pyramid': sum(2 * 12 * (img_px[l - 1] + img_px[l]) for l in range(1, max_level + 1)),      # both frames: level l-1 in, level l out

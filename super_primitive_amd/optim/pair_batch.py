@@ -897,6 +897,7 @@ class PairBatch:
         cuts = [slots * g // n_groups for g in range(n_groups + 1)]
         head = torch.tensor([slots], dtype=torch.int32, device=dev)
         slot_pair = torch.arange(slots, dtype=torch.int32, device=dev)
+        active = torch.zeros(slots, dtype=torch.int32, device=dev)
         q_costs = torch.zeros(M, dtype=torch.float32, device=dev)
         q_lm = torch.zeros(M, _lib.SP_LM_STATE_FLOATS, dtype=torch.float32, device=dev)
         self.phase.fill_(sched.n_phases)            # (the per-slot arrays are the first `slots` entries of the batch's per-pair ones)
@@ -928,9 +929,11 @@ class PairBatch:
                 ms = spans_of[ph.spans] if ph.n_spans > 0 else 0
                 q.max_spans[p] = (ms + 3) // 4 * 4 if wave else ms
             q.n_queue, q.head, q.slot_pair, q.q_costs, q.q_lm, q.lam0 = M, head.data_ptr(), slot_pair[lo:].data_ptr(), q_costs.data_ptr(), q_lm.data_ptr(), lam0
+            q.active = active[lo:].data_ptr()              # (the tail of the run is launched over the busy slots only, include/sp_hip.h SpQueue.active)
             if sg.adam_state:
                 sg.adam_state = self.adam_state[lo:].data_ptr()
             keep.append(slot_desc)
+            keep.append(active)
             groups.append((sg, q, lo, n_g))
 
         def drive(g, stream):

@@ -187,7 +187,7 @@ def test_config3_chain_stage_by_stage_from_the_references_own_states():
     Adam's first steps move the pose by its learning rate, 5e-3 rad per step, whatever the gradient's size: the iterate overshoots and
     rings, and a last-bit difference in one gradient flips a step's sign a few iterations later -- even the first 50 steps of the
     reference's tracker differ by 3e-4 rad between two of its own runs (``spread_track50``).  So the tracker is held to max(bar, 3 x the
-    reference's own spread) over the first 50 steps and over the full stage; the mapping stages (whose loops the reference reproduces bit
+    reference's own spread) over the full stage, the tracker to max(bar, 5 x spread) over its first 50 steps and over the full stage; the mapping stages (whose loops the reference reproduces bit
     for bit across thread counts: spread 0) and the keyframe stage are held to the bar."""
     from conftest import load_golden
     from super_primitive_amd.odometery.sequence import MonoVO
@@ -202,9 +202,11 @@ def test_config3_chain_stage_by_stage_from_the_references_own_states():
     vo = MonoVO(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="adam", translation_thresh=0.095, window_size=5, depth_of=lambda i: T(seq[i].kld_gt))
     BAR_R, BAR_T, BAR_D = 1e-4, 1e-4, 1e-3
     sp_track, sp_map = g["spread_track"], g["spread_map"]
-    tol_track = (max(BAR_R, 3 * float(sp_track[0])), max(BAR_T, 3 * float(sp_track[1])), max(5e-4, 3 * float(sp_track[2])))
+    # (the recorded spread is the largest deviation seen over 23 stages of ONE second run of a chaotic iteration -- a sample maximum, not a
+    #  bound: the tracker, whose spread is 3-15 x the bar, gets 5 x it; the mapping stages, whose spread is below the bar, 3 x)
+    tol_track = (max(BAR_R, 5 * float(sp_track[0])), max(BAR_T, 5 * float(sp_track[1])), max(5e-4, 5 * float(sp_track[2])))
     sp50 = g["spread_track50"]
-    tol_track50 = (max(BAR_R, 3 * float(sp50[0])), max(BAR_T, 3 * float(sp50[1])), max(2e-4, 3 * float(sp50[2])))
+    tol_track50 = (max(BAR_R, 5 * float(sp50[0])), max(BAR_T, 5 * float(sp50[1])), max(2e-4, 5 * float(sp50[2])))
     tol_map = (max(BAR_R, 3 * float(sp_map[0])), max(BAR_T, 3 * float(sp_map[1])), max(BAR_D, 3 * float(sp_map[2])), max(5e-4, 3 * float(sp_map[3])))
     print(f"\nthe reference against itself per stage (threads {g['spread_threads'].tolist()}): tracking {sp_track}, its first 50 steps {g['spread_track50']}, supplementary mapping "
           f"{g['spread_supp']}, scheduled mapping {sp_map}")

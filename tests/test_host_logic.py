@@ -56,7 +56,7 @@ def test_abi_constants_and_struct_layout_match_header():
     assert _lib.SpSchedule.retry2_entry.offset == 780 and _lib.SpSchedule.adam_lr_pose.offset == 784 and _lib.SpSchedule.adam_state.offset == 792
     assert ctypes.sizeof(_lib.SpVerdict) == 96 and _lib.SpVerdict.evals.offset == 88 and _lib.SpVerdict.kld_bound.offset == 56 and _lib.SpVerdict.lam0.offset == 76
     assert _lib.SpVerdict.seg_max_ratio.offset == 80 and _lib.SpVerdict.seg_mean_ratio.offset == 84
-    assert ctypes.sizeof(_lib.SpQueue) == 288 and _lib.SpQueue.max_spans.offset == 192 and _lib.SpQueue.head.offset == 248
+    assert ctypes.sizeof(_lib.SpQueue) == 296 and _lib.SpQueue.active.offset == 288 and _lib.SpQueue.max_spans.offset == 192 and _lib.SpQueue.head.offset == 248
     for macro in ("SP_GN_SEG_FLOATS", "SP_GNA_SEG_FLOATS", "SP_PHASE_ADAM", "SP_VERDICT_SEGMENTS", "SP_VERDICT_SEGMENT_POINTS", "SP_VERDICT_MIN_SEGMENTS"):
         assert int(re.search(r"#define\s+" + macro + r"\s+(\d+)", header).group(1)) == getattr(_lib, macro), macro
     for macro in ("SP_STATUS_NONFINITE", "SP_STATUS_LAST_CAP", "SP_STATUS_DEPTH_RANGE", "SP_STATUS_COST", "SP_STATUS_VALID", "SP_STATUS_SEGMENTS",
