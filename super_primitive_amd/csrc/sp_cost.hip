@@ -369,8 +369,10 @@ __device__ __forceinline__ void prepare2(const TileCtx& c, const PairConsts& k, 
     const bool src_ok = (int32_t)pw < 0;
     const float d = DT ? s.w * shift : fast_exp(s.w + shift);
     const f32x2 xy = pfma(colrow, k.ifxy, k.nKc) * d;          // ((col, row) - (cx, cy)) / (fx, fy) * d, the subtraction folded into the multiply
-    const f32x2 qxy = pfma(k.R03, f32x2{xy.x, xy.x}, pfma(k.R14, f32x2{xy.y, xy.y}, k.R25 * d)) + k.t01;
-    const float qz = fmaf(k.R6, xy.x, fmaf(k.R7, xy.y, k.R8 * d)) + k.t2;
+    // (round 6: the translation rides in the innermost multiply-add -- R d + t as one fma -- instead of a trailing add: one packed and one
+    //  scalar instruction less per point; the sum is rounded in another order, a last-bit difference of q)
+    const f32x2 qxy = pfma(k.R03, f32x2{xy.x, xy.x}, pfma(k.R14, f32x2{xy.y, xy.y}, pfma(k.R25, f32x2{d, d}, k.t01)));
+    const float qz = fmaf(k.R6, xy.x, fmaf(k.R7, xy.y, fmaf(k.R8, d, k.t2)));
     const bool zguard = fabsf(qz) > 1e-6f;
     const float zinv = zguard ? __builtin_amdgcn_rcpf(qz) : 1e-6f;
     const f32x2 uv = qxy * k.Kf * zinv + k.Ktc;
@@ -381,8 +383,10 @@ __device__ __forceinline__ void prepare2(const TileCtx& c, const PairConsts& k, 
     p.zinv = ok ? zinv : 0.f;
     p.zi = (ok && zguard) ? zinv : 0.f;
     p.srg = f32x2{s.x, s.y}; p.sb = s.z;
-    const f32x2 i0 = pfma(n, k.sxy, k.sxy);
-    const f32x2 ixy{ok ? i0.x : 0.f, ok ? i0.y : 0.f};
+    // (round 6: an invalid point's sampling position is no longer forced to texel (0, 0) -- two selects per point.  It is finite whatever the
+    //  point (|q K / z| < 1e12 under the 1e-6 guard of z), its taps go through the buffer descriptor (out of range: zeros), its weights lie
+    //  in [0, 1), and everything it contributes is multiplied by the mask (p.m, p.zinv, p.zi = 0) downstream as before)
+    const f32x2 ixy = pfma(n, k.sxy, k.sxy);
     const f32x2 fl{floorf(ixy.x), floorf(ixy.y)};
     p.wxy = ixy - fl;
     // byte offset of the upper-left tap, in float arithmetic (exact: below 2^24 for any image the packed pixel word can address at 12 bytes
@@ -661,12 +665,13 @@ __device__ __forceinline__ void run_span_gn(const TileCtx& c, const SpPair& pr, 
         //  stay in vector registers: from SGPRs they were copied into a register pair again for every point)
         kc.nKc = f32x2{-c.Ks.cx * (1.f / c.Ks.fx), -c.Ks.cy * (1.f / c.Ks.fy)};
         kc.R03 = sgpr2(w.R[0], w.R[3]);        kc.R14 = sgpr2(w.R[1], w.R[4]);      kc.R25 = sgpr2(w.R[2], w.R[5]);
-        kc.t01 = sgpr2(w.t[0], w.t[1]);        kc.Kf = sgpr2(w.Kt.fx, w.Kt.fy);     kc.Ktc = sgpr2(w.Kt.cx, w.Kt.cy);
+        kc.t01 = f32x2{w.t[0], w.t[1]};        kc.Kf = sgpr2(w.Kt.fx, w.Kt.fy);     kc.Ktc = sgpr2(w.Kt.cx, w.Kt.cy);
         kc.invWH = sgpr2(2.f * w.invWm1, 2.f * w.invHm1);  kc.sxy = sgpr2(w.sx, w.sy);
         kc.gab = sgpr2(c.gain * c.ax * w.Kt.fx, c.gain * c.ay * w.Kt.fy);
         kc.bias2 = f32x2{c.bias, c.bias};      kc.eps2 = sgpr2(irls_eps, irls_eps);
-        asm volatile("" : "+v"(kc.nKc), "+v"(kc.bias2));      // (opaque: or the compiler puts the uniform pairs back into SGPRs)
-        kc.R6 = sgpr(w.R[6]); kc.R7 = sgpr(w.R[7]); kc.R8 = sgpr(w.R[8]); kc.t2 = sgpr(w.t[2]);
+        kc.R6 = sgpr(w.R[6]); kc.R7 = sgpr(w.R[7]); kc.R8 = sgpr(w.R[8]); kc.t2 = w.t[2];
+        // (the translation, too, is the addend of a multiply-add whose multiplier -- a row of R -- is the instruction's scalar operand)
+        asm volatile("" : "+v"(kc.nKc), "+v"(kc.bias2), "+v"(kc.t01), "+v"(kc.t2));      // (opaque: or the compiler puts the uniform pairs back into SGPRs)
         kc.gain = sgpr(c.gain); kc.bias = sgpr(c.bias); kc.zmin = sgpr(w.zmin); kc.eps = sgpr(irls_eps);
         kc.row_bytes_f = sgpr((float)(c.Wl * (int)(4u * SP_TEXEL_FLOATS)));
     }

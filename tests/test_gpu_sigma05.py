@@ -199,19 +199,23 @@ def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
                                                       PairBatch)
     paths = sorted(glob.glob(os.path.join(GOLDEN, "g20y_sigma05_blobs_pair*.npz")))
     assert len(paths) >= 5, "goldens g20y missing"
+    # ... and, when present, goldens g20z: the same on SAM-REALISTIC segment sets (``synth.make_pair(shape='sam')``; starts the sweep of
+    # round 6 flagged after all three attempts, through the real reference loop)
+    paths += sorted(glob.glob(os.path.join(GOLDEN, "g20z_sigma05_sam_pair*.npz")))
     sched = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
     n_conv = n_third = 0
     for path in paths:
         gx = np.load(path)
         ref_converged = bool(gx["converged"])
-        pair = synth.make_pair(480, 640, 64, seed=int(gx["scene_seed"]), init_sigma=0.05, texture="octaves", init_mode="reference", shape="blobs", blob_coverage=1.2)
+        shape = "sam" if "_sam_" in os.path.basename(path) else "blobs"
+        pair = synth.make_pair(480, 640, 64, seed=int(gx["scene_seed"]), init_sigma=0.05, texture="octaves", init_mode="reference", shape=shape, blob_coverage=1.2)
         pair.pose_init, pair.kld_init = gx["pose_init"].copy(), gx["kld_init"].copy()
         np.testing.assert_array_equal(input_digest(pair), gx["in_sha256"])
         # A start near the basin boundary turns with ROUND-OFF: the pair is run (i) as a batch of ONE and (ii) as ``bench.py --shape blobs`` /
         # ``tools/verdict_sweep.py`` lay it out -- a device copy of its scene's tables next to the scene's own start, the source colours
         # sampled once per scene (at the re-projection of the points under the FIRST replica's depth seeds: a last-bit difference from
         # sampling under the pair's own, core/dense_optim.py:143-162) -- the configuration the schedule was swept on.
-        own = synth.make_pair(480, 640, 64, seed=int(gx["scene_seed"]), init_sigma=0.05, texture="octaves", init_mode="reference", shape="blobs", blob_coverage=1.2)
+        own = synth.make_pair(480, 640, 64, seed=int(gx["scene_seed"]), init_sigma=0.05, texture="octaves", init_mode="reference", shape=shape, blob_coverage=1.2)
         for what in ("alone", "as the bench lays it out"):
             if what == "alone":
                 batch = PairBatch.from_synth([pair], levels=REFERENCE_START_LEVELS, point_stride=REFERENCE_START_POINT_STRIDE, granule=64)
@@ -227,7 +231,7 @@ def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
             e = pose_depth_errors(batch.poses()[i].double().cpu().numpy(), batch.klds()[i].double().cpu().numpy(), gx["final_pose"], gx["final_kld"])
             e_gt = pose_depth_errors(batch.poses()[i].double().cpu().numpy(), batch.klds()[i].double().cpu().numpy(), pair.pose_gt, pair.kld_gt)
             st, at = int(batch.status[i]), int(batch.attempts[i])
-            print(f"blobs pair {int(gx['pair_index'])} {what} (start {gx['err_init_gt']}; the reference {'CONVERGES' if ref_converged else 'does NOT converge'}: vs ground truth "
+            print(f"{shape} pair {int(gx['pair_index'])} {what} (start {gx['err_init_gt']}; the reference {'CONVERGES' if ref_converged else 'does NOT converge'}: vs ground truth "
                   f"{gx['err_gt']}): vs the reference's end state {e}, vs ground truth {e_gt}, status {st:#x}, attempts {at}, iterations "
                   f"{int(batch.lm_state[i, 2] + batch.lm_state[i, 3])}, segment costs worst / median {float(batch.diag[i, 7]) / max(float(batch.diag[i, 6]), 1e-30):.2f}, "
                   f"cost / median {float(batch.diag[i, 0]) / max(float(batch.diag[i, 6]), 1e-30):.2f}")
