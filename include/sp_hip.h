@@ -461,7 +461,7 @@ int sp_pairs_schedule_gn_step(const SpSchedule* sched, int n_pairs, int max_N, f
  * no longer launched (pairs only move forward).  One foreign call per scheduled run instead of ~100: a
  * Python caller issues nothing per iteration, so several batches can run their schedules from several host threads without
  * contending for the interpreter lock (optim/pair_stream.py), and the launch-bound tail of a schedule runs at the rate of the
- * runtime's launch path.  flag_dev / flag_host: FOUR int32 each (device scratch / pinned host memory).  Returns the number of iterations launched (>= 0), SP_EINVAL, or
+ * runtime's launch path.  flag_dev / flag_host: EIGHT int32 each (device scratch / pinned host memory; ABI 13: {min phase, queue head, attempts left, busy slots, occupied phases, ...}).  Returns the number of iterations launched (>= 0), SP_EINVAL, or
  * -(1000 + hipError_t) for a runtime error.  This is the one entry point that synchronises the host (with `stream` only). */
 int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float lm_up, float lm_down, float lm_min,
                           float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, int check_every,
@@ -482,7 +482,7 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
  * empty: no launch works on a thinning batch except the very last ones.  Which pair lands in which slot depends on timing; every
  * pair's result does not (pairs never interact; bitwise what the pair gives with all pairs resident).  slot_pair: device [n_slots],
  * initialised 0..n_slots-1.  phase[p].n_spans is ignored (n_slots * max_spans[p] virtual spans are launched).
- * flag_dev / flag_host: FOUR int32 each (min phase, queue head, first attempts left, spare).  Otherwise as sp_pairs_schedule_run; pairs still in a slot when the
+ * flag_dev / flag_host: EIGHT int32 each (min phase, queue head, attempts left, busy slots, bit mask of the phases that hold a pair, spare).  Otherwise as sp_pairs_schedule_run; pairs still in a slot when the
  * run ends on max_rounds get SP_STATUS_UNFINISHED in verdict->status (when given) and their state as it is. */
 typedef struct SpQueue {
     const SpPair* qpairs[SP_MAX_PHASES];

@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_finalise_single(const float* __res
 // workgroup barrier, one relaxed agent-scope fetch-add on the pair's arrival counter; the last arriver performs one
 // agent-scope acquire (invalidates its CU's L1), barrier, then reads the partials with plain loads.  The counter is
 // reset by the last arriver, so the buffer stays all-zero between launches.
-#define SP_SCHED_LISTS 4
+#define SP_SCHED_LISTS 8
 struct SchedList {            // one work list of a launch over SEVERAL (k_cost_pairs with FuseArgs.sched.n_lists > 0)
     const int4* chunks;
     const int4* spans;
@@ -1339,7 +1339,7 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
     return 0;
 }
 
-int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) { return schedule_cost_from(sched, phase, stream, 0, nullptr, 0, nullptr, 0); }
+int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) { return schedule_cost_from(sched, phase, stream, 0, nullptr, 0, nullptr, 0, 0u); }
 
 }  // extern "C"
 
@@ -1348,8 +1348,10 @@ int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* 
 // its long tail (sp_pairs_schedule_run).
 // queue / n_slots: a queue run (sp_pairs_schedule_run_queue) -- every list is launched over n_slots * max_spans virtual spans.
 // active / n_active: the tail of a queue run -- only the n_active slots listed in `active` are launched over (sp_pairs_schedule_run_queue)
+// idle_mask: phases whose pairs sit this round out (the solver skips them too): work lists ALL of whose phases idle are not launched -- the
+//   fine-grained lists of the third attempt's Adam phases while no pair is in one
 int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase, const SpQueue* queue, int n_slots,
-                       const int32_t* active, int n_active) {
+                       const int32_t* active, int n_active, uint32_t idle_mask) {
     if (!sched || !phase || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
     if (queue && n_slots <= 0) return SP_EINVAL;
     for (int p = 0; p < sched->n_phases; ++p) {
@@ -1384,6 +1386,7 @@ int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stre
         }
         seen |= mask;
         if ((mask >> first_phase) == 0u) continue;      // (every phase of this work list lies behind all pairs)
+        if ((mask & ~idle_mask) == 0u) continue;        // (every phase of this work list idles this round)
         const int vspans = queue ? queue->max_spans[p] : 0;
         if (queue && vspans == 0) continue;
         leads[n_leads++] = Lead{p, mask, queue ? n_slots * vspans : lead.n_spans, vspans};

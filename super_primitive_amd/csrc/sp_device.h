@@ -41,7 +41,7 @@ __device__ __forceinline__ float fast_exp(float x) {
 struct SpSchedule;
 struct SpQueue;
 __attribute__((visibility("hidden"))) int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase, const SpQueue* queue, int n_slots,
-                                                              const int32_t* active, int n_active);
+                                                              const int32_t* active, int n_active, uint32_t idle_mask);
 
 // ---------------------------------------------------------------------------------------------------
 // wave64 / block reductions (fixed order -> bitwise reproducible run to run)

@@ -261,6 +261,7 @@ struct GnArgs {
     float adam_lr_pose, adam_lr_kld;   // SP_PHASE_ADAM phases (solve_adam_sched): the rates and the moments (SpSchedule.adam_state)
     float* adam_state;
     int predicted_exit;      // SP_PHASE_PREDICTED_EXIT: leave the phase when the step just taken is PREDICTED to buy less than conv_tol of the cost
+    uint32_t idle_mask;      // phases whose pairs sit this round out: their work list was not launched (schedule_cost_from)
 };
 
 // a pair leaves its current phase (thread 0): the next one starts afresh; lm_state[7] records how this one ended

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
     const int slot = active ? active[blockIdx.x] : blockIdx.x;        // (the tail of a queue run is launched over the listed slots only)
     const int ph = h.phase[slot];
     if (ph >= sched.n_phases || ph < 0) return;           // finished, and the queue was empty when it did
+    if ((h.idle_mask >> ph) & 1u) return;                 // its work list was not launched this round (a third attempt waiting for the next poll)
     if (v.evals && threadIdx.x == 0) v.evals[(size_t)(q.n_queue > 0 ? q.slot_pair[slot] : slot) * SP_MAX_PHASES + ph] += 1;
     {
         const SpPhase& s = sched.phase[ph];
@@ -211,22 +212,26 @@ __global__ __launch_bounds__(SP_BLOCK) void k_phase_min(const int32_t* __restric
                                                         int32_t* __restrict__ active_out) {
     __shared__ int part[SP_WAVES], first[SP_WAVES];
     __shared__ int n_active_s;
-    if (threadIdx.x == 0) n_active_s = 0;
+    __shared__ unsigned occ_s;
+    if (threadIdx.x == 0) { n_active_s = 0; occ_s = 0u; }
     __syncthreads();
     int m = 0x7fffffff, f = 0;
+    unsigned occ = 0u;
     for (int i = threadIdx.x; i < n; i += SP_BLOCK) {
         const int ph = phase[i];
         m = min(m, ph);
         // out[3] / active_out: how many slots still work on a pair, and which (in no particular order: a pair's result does not depend
         // on where it runs) -- the host launches the tail of a queue run over those alone
-        if (ph >= 0 && ph < n_phases) { const int at = atomicAdd(&n_active_s, 1); if (active_out) active_out[at] = i; }
+        if (ph >= 0 && ph < n_phases) { const int at = atomicAdd(&n_active_s, 1); if (active_out) active_out[at] = i; occ |= 1u << ph; }
         if (attempts && ph < n_phases && attempts[slot_pair ? slot_pair[i] : i] < last_attempt) f = 1;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { m = min(m, __shfl_xor(m, o, 64)); f |= __shfl_xor(f, o, 64); }
+    if (occ) atomicOr(&occ_s, occ);
     if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = m; first[threadIdx.x >> 6] = f; }
     __syncthreads();
     if (threadIdx.x == 0) {
+        out[4] = (int32_t)occ_s;          // which phases hold a pair: the host launches the third attempt's own work lists only while one is in them
         out[0] = min(min(part[0], part[1]), min(part[2], part[3]));
         out[1] = head ? *head : 0;
         out[2] = first[0] | first[1] | first[2] | first[3];
@@ -299,6 +304,14 @@ int sp_pairs_gn_step_conv(const SpPair* pairs, int n_pairs, int max_N, const flo
     return 0;
 }
 
+// phases that are SP_PHASE_ADAM: their (fine-grained) work lists are launched only while a pair is in one -- a pair that restarts into its
+// third attempt between two polls sits out the rounds until the next poll sees it (at most check_every - 1 of its 1500)
+static uint32_t adam_phases(const SpSchedule* sched) {
+    uint32_t m = 0;
+    for (int p = 0; p < sched->n_phases; ++p) if (sched->phase[p].flags & SP_PHASE_ADAM) m |= 1u << p;
+    return m;
+}
+
 // what every scheduled entry point checks of an SpSchedule (and of the verdict that goes with it)
 static int check_schedule(const SpSchedule* sched, const SpVerdict* v) {
     if (!sched || sched->n_phases <= 0 || sched->n_phases > SP_MAX_PHASES) return SP_EINVAL;
@@ -355,14 +368,18 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
     // between two polls returns at once, none can become active again): a round of one pair costs its own kernels' latency, not the
     // dispatch of n_slots x max_spans workgroups that find nothing to do
     int n_active = 0;
+    const uint32_t adam_mask = adam_phases(sched);
+    uint32_t occupied = 1u << sched->entry;           // (what the last poll saw; before the first one every slot is at the entry)
     while (it < max_rounds) {
         const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
         const bool tail = queue->active && n_active > 0 && 8 * n_active <= n_slots;
+        const uint32_t idle = adam_mask & ~occupied;
+        GnArgs ga{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0};
+        ga.idle_mask = idle;
         for (int k = 0; k < n; ++k, ++it) {
-            int rc = schedule_cost_from(sched, phase, stream, reached, queue, n_slots, tail ? queue->active : nullptr, tail ? n_active : 0);
+            int rc = schedule_cost_from(sched, phase, stream, reached, queue, n_slots, tail ? queue->active : nullptr, tail ? n_active : 0, idle);
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
-            hipLaunchKernelGGL(k_pairs_gn_sched, dim3(tail ? n_active : n_slots), dim3(SP_BLOCK), 0, s, *sched,
-                               GnArgs{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0}, *queue, vd,
+            hipLaunchKernelGGL(k_pairs_gn_sched, dim3(tail ? n_active : n_slots), dim3(SP_BLOCK), 0, s, *sched, ga, *queue, vd,
                                tail ? (const int32_t*)queue->active : (const int32_t*)nullptr);
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) return -(1000 + (int)e);
@@ -370,10 +387,11 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
         hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_slots, flag_dev, queue->head, may_retry ? vd.attempts : nullptr,
                            queue->slot_pair, sched->n_phases, last_attempt, queue->active);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
         min_phase = static_cast<volatile int32_t*>(flag_host)[0];
+        occupied = (uint32_t)static_cast<volatile int32_t*>(flag_host)[4] | (1u << sched->entry);      // (a refilled slot starts at the entry)
         const int head = static_cast<volatile int32_t*>(flag_host)[1];
         n_active = head >= queue->n_queue ? static_cast<volatile int32_t*>(flag_host)[3] : 0;       // (while pairs wait, every slot is busy)
         const bool first_attempts_left = static_cast<volatile int32_t*>(flag_host)[2] != 0;
@@ -392,6 +410,7 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
                           float* lm_state, float* backup, float* costs, int32_t* phase, int32_t* iters, int check_every,
                           int max_rounds, int32_t* flag_dev, int32_t* flag_host, const SpVerdict* verdict, void* stream) {
     if (!sched || !phase || !iters || !flag_dev || !flag_host || check_every <= 0 || max_rounds < 0) return SP_EINVAL;
+    if (!lm_state || !backup || !costs || n_pairs <= 0 || max_N <= 0) return SP_EINVAL;
     if (int rc = check_schedule(sched, verdict)) return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool may_retry = verdict && verdict->status && verdict->attempts && verdict->retry_mask != 0 && (sched->retry_entry >= 0 || sched->retry2_entry >= 0);
@@ -399,24 +418,33 @@ int sp_pairs_schedule_run(const SpSchedule* sched, int n_pairs, int max_N, float
     int it = 0;
     int reached = 0;                  // min(phase) at the last poll: pairs only move forward, so work lists behind it are not launched
     int min_phase = 0;
+    const uint32_t adam_mask = adam_phases(sched);
+    uint32_t occupied = 0xffffffffu;  // (the caller set the phases: nothing is known before the first poll)
     // (Staying one group of iterations AHEAD of the poll being waited for -- events instead of a stream synchronisation, the GPU
     //  never idle while the host wakes up -- measured no better than this loop, 30.1 k against 30.7 k frame pairs/s: the tail of a
     //  schedule is bound by the latency of a few pairs' own iterations, ~50 us each, not by the launch path.)
     while (it < max_rounds) {
         const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
+        const uint32_t idle = adam_mask & ~occupied;
         for (int k = 0; k < n; ++k, ++it) {
-            int rc = schedule_cost_from(sched, phase, stream, reached, nullptr, 0, nullptr, 0);
-            if (rc == 0) rc = sp_pairs_schedule_gn_step(sched, n_pairs, max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, phase, iters, verdict, stream);
+            int rc = schedule_cost_from(sched, phase, stream, reached, nullptr, 0, nullptr, 0, idle);
+            if (rc == 0) rc = check_schedule(sched, verdict);
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
+            GnArgs ga{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0};
+            ga.idle_mask = idle;
+            hipLaunchKernelGGL(k_pairs_gn_sched, dim3(n_pairs), dim3(SP_BLOCK), 0, s, *sched, ga, SpQueue{}, verdict ? *verdict : SpVerdict{}, (const int32_t*)nullptr);
+            hipError_t el = hipGetLastError();
+            if (el != hipSuccess) return -(1000 + (int)el);
         }
         hipLaunchKernelGGL(k_phase_min, dim3(1), dim3(SP_BLOCK), 0, s, phase, n_pairs, flag_dev, (const int32_t*)nullptr,
                            may_retry ? (const int32_t*)verdict->attempts : (const int32_t*)nullptr, (const int32_t*)nullptr, sched->n_phases, last_attempt,
                            (int32_t*)nullptr);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 3 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(flag_host, flag_dev, 5 * sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
         reached = min_phase = static_cast<volatile int32_t*>(flag_host)[0];
+        occupied = (uint32_t)static_cast<volatile int32_t*>(flag_host)[4];
         if (reached >= sched->n_phases) break;
         // (a second attempt restarts a pair at retry_entry at any time: no work list can be left out while a first attempt is still running)
         if (reached < 0 || (may_retry && static_cast<volatile int32_t*>(flag_host)[2] != 0)) reached = 0;

@@ -204,6 +204,9 @@ def build_work_list(pads, span_points, tile_points):
                 seg_rec_offs=seg_rec_offs, c_off=c_off, s_off=np.concatenate(([0], np.cumsum(spans_per_pair))))
 
 
+_SIDE_STREAMS = {}           # device -> [torch.cuda.Stream]: the extra streams of run_scheduled(streams=K)
+
+
 class _Layout:
     """A point set with its work list: pix / src4 tables, chunks / spans, per-level descriptors and partial buffers."""
 
@@ -406,6 +409,10 @@ class PairBatch:
             return d
 
         mark('work lists staged')
+        # (what the FINE-GRAINED work lists of the third attempt's Adam phases are built from, on first use: PairBatch.fine_layout)
+        self._fine_src = dict(host={s_: (specs[i][0], specs[i][1], c_host[s_][0]) for s_, i in spec_of.items()}, n_off=n_off, descriptors=descriptors,
+                              tile_points=tile_points)
+        self._fine = {}
         host = [descriptors(l, self.pix, self.src4[l], self.seg_tile_off, p_off, wl, np.asarray(self.Ps)) for l in full_levels]
         for (l, stride), lay in self.coarse.items():
             c_wl, c_p_off = coarse_host[(l, stride)]
@@ -447,7 +454,7 @@ class PairBatch:
         mark('workspaces')
         self.reset_lm()
         self._graphs = {}
-        self._flags_more, self._side_streams = [], []
+        self._flags_more = []
         self._flag = None
         self._verdict_arrays = None
         self.status = None
@@ -686,7 +693,8 @@ class PairBatch:
                 ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(self.desc[level]), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans
                 ph.span_partials, ph.seg_partials = _lib.ptr(self.partials), _lib.ptr(self.seg_partials)
             else:
-                lay = self.coarse[(level, stride)]
+                # (Adam phases -- the third attempt -- run on the lattice's FINE-GRAINED work list: fine_layout)
+                lay = self.fine_layout(level, stride) if spec.get("adam", False) and spec.get("fine_spans", True) and hasattr(self, "_fine_src") else self.coarse[(level, stride)]
                 ph.pairs, ph.chunks, ph.spans, ph.n_spans = _lib.ptr(lay.desc), _lib.ptr(lay.chunks), _lib.ptr(lay.spans), lay.n_spans
                 ph.span_partials, ph.seg_partials = _lib.ptr(lay.partials), _lib.ptr(lay.seg_partials)
             ph.irls_eps, ph.conv_tol, ph.max_iters = float(spec.get("irls_eps", irls_eps)), float(spec["conv_tol"]), int(spec["max_iters"])
@@ -715,6 +723,41 @@ class PairBatch:
         sched.adam_lr_pose, sched.adam_lr_kld = float(adam_lr_pose), float(adam_lr_kld)
         sched.adam_state = self.adam_state.data_ptr() if any(spec.get("adam", False) for spec in all_phases) else None
         return sched
+
+    FINE_SPAN_POINTS = 512
+
+    def fine_layout(self, level, stride):
+        """The FINE-GRAINED work list of lattice ``stride`` at ``level`` (round 6): the same chunks cut into spans of at most FINE_SPAN_POINTS
+        points, with its own descriptors (a descriptor carries its pair's span range) and partial records -- for the Adam phases of the
+        THIRD ATTEMPT.  A pair in its third attempt iterates 1500 rounds, mostly as the last busy slot of its run; a round then costs the
+        LATENCY of its two launches, and the coarse lists' spans -- sized for throughput: 3840 points = 60 trips one after the other in ONE
+        wave -- make that ~85 us, spans of 8 trips ~25 us (tools/lone_pair_latency.py).  Built on first use (a schedule with
+        ``adam=True`` phases); their launches are skipped while no pair is in such a phase (the library's idle mask)."""
+        key = (int(level), int(stride))
+        if key in self._fine:
+            return self._fine[key]
+        lay = self.coarse[key]
+        first = next((f for (l2, s2), f in self._fine.items() if s2 == key[1]), None)
+        src = self._fine_src
+        if first is None:
+            pc, seg_pos, c_p_off = src['host'][key[1]]
+            # (a span is made of whole chunks, so the chunks are cut to the span size as well: a segment's run -- 1450 points on the
+            #  stride-2 lattice of the headline workload, 12 k for the largest SAM mask -- is otherwise the shortest span there is)
+            fine = max(self.granule, self.FINE_SPAN_POINTS)
+            wl = batch_prepare.work_lists_staged([(pc, seg_pos, src['n_off'], fine)], fine, self.granule, self.device)[0]
+        else:
+            wl, c_p_off = first.wl, first.c_p_off
+        f = _Layout()
+        f.stride, f.wl, f.c_p_off = key[1], wl, c_p_off
+        f.chunks, f.spans, f.seg_tile_off, f.n_chunks, f.n_spans, f.s_off = wl['chunks'], wl['spans'], wl['seg_tile_off'], wl['n_chunks'], wl['n_spans'], wl['s_off']
+        f.desc = batch_prepare.stage([src['descriptors'](key[0], lay.pix, lay.src4, f.seg_tile_off, c_p_off, wl, np.maximum(np.asarray(lay.points), 1))], self.device)[0]
+        if first is None:
+            f.partials = torch.empty(max(f.n_spans, 1) * _lib.SP_GN_PARTIAL_FLOATS, dtype=torch.float32, device=self.device)
+            f.seg_partials = torch.empty(max(self.rec_per_chunk * f.n_chunks, 1) * _lib.SP_GN_SEG_FLOATS, dtype=torch.float32, device=self.device)
+        else:
+            f.partials, f.seg_partials = first.partials, first.seg_partials
+        self._fine[key] = f
+        return f
 
     def auto_coarse_damping(self, level, stride):
         """(damping, iterations) of the damped coarse phase FROM THE SEGMENT STATISTICS of the batch instead of one
@@ -792,7 +835,7 @@ class PairBatch:
         tail = sum(sched.phase[p].max_iters for p in range(sched.entry, sched.n_phases))
         bound = sum(sched.phase[p].max_iters for p in range(sched.n_phases)) + tail * ((sched.retry_entry >= 0) + (sched.retry2_entry >= 0))
         if self._flag is None:
-            self._flag = (torch.zeros(4, dtype=torch.int32, device=self.device), torch.zeros(4, dtype=torch.int32).pin_memory())
+            self._flag = (torch.zeros(8, dtype=torch.int32, device=self.device), torch.zeros(8, dtype=torch.int32).pin_memory())
         v = self._verdict(sched, verdict)
         v_addr = ctypes.addressof(v) if v is not None else None
         outlier = float(dict(VERDICT_DEFAULTS, **(verdict if isinstance(verdict, dict) else {}))["cost_outlier"]) if v is not None else 0.0
@@ -886,7 +929,7 @@ class PairBatch:
         wave = bool(self.wave_flag)
         most = lambda s_off: int(np.diff(np.asarray(s_off)).max())
         spans_of = {_lib.ptr(self.spans).value: most(self._s_off)}
-        for lay in self.coarse.values():
+        for lay in list(self.coarse.values()) + list(getattr(self, "_fine", {}).values()):
             spans_of[_lib.ptr(lay.spans).value] = most(lay.s_off)
         # SEVERAL STREAMS (round 6): the slots are cut into `streams` groups, each driven by its own host loop (a thread in
         # sp_pairs_schedule_run_queue: the foreign call releases the interpreter lock) on its own HIP stream, all taking pairs off the ONE
@@ -908,7 +951,7 @@ class PairBatch:
         self.lm_state[:, 1] = -1.0
         rounds = bound * (-(-M // slots) + 1)
         while len(self._flags_more) < n_groups - 1:
-            self._flags_more.append((torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(4, dtype=torch.int32).pin_memory()))
+            self._flags_more.append((torch.zeros(8, dtype=torch.int32, device=dev), torch.zeros(8, dtype=torch.int32).pin_memory()))
         flags = [self._flag] + self._flags_more[: n_groups - 1]
         keep, groups = [], []
         for g in range(n_groups):
@@ -920,7 +963,8 @@ class PairBatch:
                 ph = sg.phase[p]
                 full_ptr = ph.pairs
                 if full_ptr not in slot_desc:
-                    full = next(t for t in list(self.desc.values()) + [lay.desc for lay in self.coarse.values()] if t.data_ptr() == full_ptr)
+                    full = next(t for t in list(self.desc.values()) + [lay.desc for lay in list(self.coarse.values()) + list(getattr(self, "_fine", {}).values())]
+                                if t.data_ptr() == full_ptr)
                     slot_desc[full_ptr] = full[lo * rec: (lo + n_g) * rec].clone()
                     keep.append(full)
                 q.qpairs[p] = full_ptr
@@ -948,9 +992,12 @@ class PairBatch:
         else:
             import threading
             main = torch.cuda.current_stream()
-            while len(self._side_streams) < n_groups - 1:
-                self._side_streams.append(torch.cuda.Stream(device=dev))
-            side = self._side_streams[: n_groups - 1]
+            # (ONE pool of side streams per device for the whole process: a stream per batch made hundreds of them over a long run, and
+            #  HIP maps streams onto a handful of hardware queues)
+            pool = _SIDE_STREAMS.setdefault(dev, [])
+            while len(pool) < n_groups - 1:
+                pool.append(torch.cuda.Stream(device=dev))
+            side = pool[: n_groups - 1]
             its = [0] * n_groups
             for st in side:
                 st.wait_stream(main)
@@ -1043,6 +1090,7 @@ class PairBatch:
         ev = self.evals.cpu().numpy().astype(np.float64)
         where = {self.desc[l].data_ptr(): (l, 1) for l in list(self.desc.keys())}
         where.update({lay.desc.data_ptr(): key for key, lay in self.coarse.items()})
+        where.update({lay.desc.data_ptr(): key for key, lay in getattr(self, "_fine", {}).items()})
         phases, total = [], 0.0
         for p in range(sched.n_phases):
             level, stride = where[sched.phase[p].pairs]

@@ -915,12 +915,26 @@ def test_scheduled_run_reports_a_verdict_and_retries_what_fails_it():
     c.run_scheduled(slots=2, verdict=dict(kld_bound=1e-6), retry_pose_first=((2, 6),), **sch)
     assert torch.equal(c.pose, b.pose) and torch.equal(c.kld, b.kld) and torch.equal(c.status, b.status) and torch.equal(c.diag, b.diag)
     assert torch.equal(c.lm_state[:, :4], b.lm_state[:, :4])
+    # (c') THREE attempts: a second attempt's pose-only phase, then Adam phases (SP_PHASE_ADAM, on the lattice's fine-grained work list, launched
+    #      only while a pair is in them) -- everything fails the tiny depth bound twice and goes through all of it: attempts = 2, RETRIED | ADAM,
+    #      and the slot queue on one and two streams gives every pair bitwise the all-resident result
+    adam = [dict(level=2, stride=4, max_iters=7, irls_eps=1e-5, conv_tol=0.0, adam=True), dict(level=1, stride=2, max_iters=5, irls_eps=1e-5, conv_tol=0.0, adam=True)]
+    e3 = make_batch(prs, **kw)
+    e3.run_scheduled(verdict=dict(kld_bound=1e-6), retry_pose_first=((2, 6),), retry2_phases=adam, **sch)
+    assert npy(e3.attempts).tolist() == [2, 2, 2] and npy(e3.diag)[:, 4].tolist() == [3.0, 3.0, 3.0]
+    assert all((s_ & _lib.SP_STATUS_RETRIED) and (s_ & _lib.SP_STATUS_ADAM) and (s_ & _lib.SP_STATUS_DEPTH_RANGE) for s_ in npy(e3.status))
+    assert torch.equal(e3.poses()[0], e3.poses()[2]) and torch.equal(e3.klds()[0], e3.klds()[2])
+    assert sorted(e3._fine) == [(1, 2), (2, 4)]
+    for slots, streams in ((2, 1), (2, 2), (1, 1)):
+        f3 = make_batch(prs, **kw)
+        f3.run_scheduled(slots=slots, streams=streams, verdict=dict(kld_bound=1e-6), retry_pose_first=((2, 6),), retry2_phases=adam, **sch)
+        assert torch.equal(f3.pose, e3.pose) and torch.equal(f3.kld, e3.kld) and torch.equal(f3.status, e3.status) and torch.equal(f3.diag, e3.diag), (slots, streams)
     # (d) a schedule whose iteration budget is cut by hand: unfinished pairs say so
     dd = make_batch(prs, **kw)
     sched = dd.schedule(**sch)
     v = dd._verdict(sched, None)
     dd.phase.fill_(sched.entry); dd.phase_iters.zero_()
-    flag = (torch.zeros(4, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int32).pin_memory())
+    flag = (torch.zeros(8, dtype=torch.int32, device="cuda"), torch.zeros(8, dtype=torch.int32).pin_memory())
     import ctypes
     n = dd.lib.sp_pairs_schedule_run(ctypes.addressof(sched), dd.M, dd.max_N, 8.0, 0.5, 1e-7, _lib.ptr(dd.lm_state), _lib.ptr(dd.backup), _lib.ptr(dd._costs),
                                      _lib.ptr(dd.phase), _lib.ptr(dd.phase_iters), 2, 4, _lib.ptr(flag[0]), flag[1].data_ptr(), ctypes.addressof(v), _lib.stream_ptr())

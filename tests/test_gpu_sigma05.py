@@ -240,8 +240,12 @@ def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
             assert home or flagged, (path, what, hex(st), e_gt)                                  # never a wrong pose with a clean status -- alone or not
             if ref_converged:
                 # the bar against the REFERENCE'S end state, clean status: required as the bench lays the pair out; alone, a flag is still
-                # accepted where round-off turns the outcome (never a silent miss: asserted above)
-                inside = all(x <= b for x, b in zip(e, BAR))
+                # accepted where round-off turns the outcome (never a silent miss: asserted above).  Where the reference's polish was cut off
+                # by the generator's round limit while still moving (``last_round_moved`` above a quarter of the bar: 2437, 18932 -- their end
+                # states are 1e-4 from the ground truth and converging on it), the yardstick is the point the reference is converging to: the
+                # ground truth, which the settled goldens (90, 2219, 8479) end 1.5e-5 from
+                settled = all(m <= 0.25 * b for m, b in zip(gx["last_round_moved"], BAR))
+                inside = all(x <= b for x, b in zip(e, BAR)) or (not settled and all(x <= b for x, b in zip(e_gt, BAR)))
                 if what != "alone":
                     assert inside and not flagged, (path, what, hex(st), e)
                     n_conv += 1
@@ -255,5 +259,57 @@ def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
                 if what == "alone":
                     assert st & (_lib.SP_STATUS_SEGMENTS | _lib.SP_STATUS_DEPTH_RANGE | _lib.SP_STATUS_LAST_CAP), hex(st)     # (by what the pair sees of itself)
             del batch
+    # (with the predicted exit of round 6 every one of these comes home at its first or second attempt; the third attempt has its own test below)
     print(f"{n_conv} starts the reference converges from: all inside the bar with a clean status, {n_third} of them through the third attempt")
-    assert n_third >= 1, "the third attempt was never exercised"
+
+
+def test_third_attempt_brings_home_what_two_gauss_newton_attempts_lose():
+    """the THIRD attempt -- the reference's own optimiser as phases of the device schedule (SP_PHASE_ADAM: 3 x 500 Adam
+    iterations at lr 1e-2 / 1e-3, odometery/two_frame_sfm.py:116-123,128-155, then the Gauss-Newton polish) -- on starts of the ragged 49152-start
+    sweep that end BOTH Gauss-Newton attempts of the shipped schedule in the wrong basin (profiles/r06_reference_start_sweep_ragged_49152.txt:
+    21595, 32875, 35432, 41662 ...), laid out as the sweep lays them out.  Each must end at its ground truth with a clean status that says
+    how it got there (RETRIED | ADAM); with ``retry2_phases=None`` the same starts come back FLAGGED (round 5's behaviour), never silent."""
+    import copy
+    from super_primitive_amd import _lib, synth
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.optim.pair_batch import (REFERENCE_START_LEVELS, REFERENCE_START_POINT_STRIDE, REFERENCE_START_SCHEDULE,
+                                                      PairBatch)
+    ids = [21595, 32875, 35432, 41662]
+    G, N = 8, 64
+    rng = np.random.default_rng(77)
+    starts = {}
+    for r in range(1, max(ids) // G + 1):
+        for s_ in range(G):
+            xi, u = rng.standard_normal(6), rng.uniform(size=N)
+            if r * G + s_ in ids:
+                starts[r * G + s_] = (xi, u)
+    sched = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    n_third = 0
+    for m in ids:
+        own = synth.make_pair(480, 640, N, seed=5000 + m % G, init_sigma=0.05, texture="octaves", init_mode="reference", shape="blobs", blob_coverage=1.2)
+        xi, u = starts[m]
+        pose = (own.pose_gt.astype(np.float64) @ synth.se3_exp_np(0.05 * xi)).astype(np.float32)
+        kld = np.log(2.0 + 2.0 * u).astype(np.float32)
+        outcome = {}
+        for what, kw in (("three attempts", sched), ("two attempts", dict(sched, retry2_phases=None))):
+            batch = PairBatch([KeyFrame(t(own.src_image), t(own.K), t(own.logdepth_perseg), t(own.keypoints), t(own.keypoint_regions))], [t(own.trg_image)], [t(own.K)],
+                              torch.from_numpy(np.stack([own.pose_init, pose])), [t(own.kld_init), t(kld)], levels=REFERENCE_START_LEVELS,
+                              point_stride=REFERENCE_START_POINT_STRIDE, granule=64, replicate=2, span_points=4096)
+            batch.run_scheduled(**kw)
+            e = pose_depth_errors(batch.poses()[1].double().cpu().numpy(), batch.klds()[1].double().cpu().numpy(), own.pose_gt, own.kld_gt)
+            st, at = int(batch.status[1]), int(batch.attempts[1])
+            outcome[what] = (e, st, at)
+            print(f"ragged start {m}, {what}: vs ground truth {e}, status {st:#x}, attempts made {at + 1}, iterations {int(batch.lm_state[1, 2] + batch.lm_state[1, 3])}")
+            home = e[0] <= 2e-3 and e[1] <= 2e-3 and e[2] <= 2e-2
+            assert home or (st & _lib.SP_STATUS_FAILED), (m, what, hex(st), e)
+            del batch
+        e, st, at = outcome["three attempts"]
+        assert (st & _lib.SP_STATUS_FAILED) == 0 and e[0] <= 1e-4 and e[1] <= 1.5e-4 and e[2] <= 1.5e-3, (m, hex(st), e)      # (bar + the minimiser's own offset)
+        if at == 2:
+            n_third += 1
+            assert (st & _lib.SP_STATUS_ADAM) and (st & _lib.SP_STATUS_RETRIED), hex(st)
+            e2, st2, at2 = outcome["two attempts"]
+            assert (st2 & _lib.SP_STATUS_FAILED) and at2 == 1, (m, hex(st2), e2)               # what round 5 returned: flagged after the second attempt
+    print(f"{n_third} of {len(ids)} through the third attempt")
+    assert n_third >= 2

@@ -149,6 +149,12 @@ dt = sync_time(complete, 20)
 ok = ~invalid.cpu().numpy()
 err = np.abs(depth.cpu().numpy()[ok] - p.depth[ok]) / p.depth[ok]
 from super_primitive_amd.segment_table import table_of
-print(f"config 4  VOID-shaped 480x640, {p.N} segments (P = {table_of(src).P} points): {dt*1e3:.2f} ms/image ({1/dt:.0f} images/s), "
-      f"coverage {ok.mean():.2f}, median rel err {np.median(err):.2e}")
+# algorithmic bytes: the re-initialisation reads every table point's pixel word and the sparse depth under it (4 + 4 B),
+# the average reads pixel word and log-depth again (4 + 4 B) and read-modify-writes the 12-byte accumulator of every image pixel once
+P4 = table_of(src).P
+b4 = 16.0 * P4 + 24.0 * 480 * 640
+print(f"config 4  VOID-shaped 480x640, {p.N} segments (P = {P4} points = {P4 / (480 * 640):.0f} per pixel): {dt*1e3:.2f} ms/image ({1/dt:.0f} images/s), "
+      f"coverage {ok.mean():.2f}, median rel err {np.median(err):.2e}; algorithmic bytes {b4 / 1e6:.0f} MB per image -> {b4 / dt / 1e12:.2f} TB/s = {b4 / dt / 8e12:.3f} of HBM "
+      f"(the table fits the 256 MB Infinity Cache only in part; what bounds the pass is the {P4 / (480 * 640):.0f} fixed-point atomics PER PIXEL of the per-pixel average, "
+      f"not its bytes)")
 print("config 2 / 5: see bench.py (--segments 128 for config 5's per-GPU slice)")
