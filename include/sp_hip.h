@@ -612,6 +612,34 @@ int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edge
                       float lm_up, float lm_down, float lm_min, float conv_tol, float* state, float* losses, int max_losses,
                       void* stream);
 
+/* S WINDOWS PER LAUNCH (ABI 13, config 3's throughput form: S independent sequences side by side, as PairBatch is config 2's).  One window's
+ * Gauss-Newton iteration is four small dependent launches that leave the chip empty; here every launch covers all the windows -- the cost
+ * pass goes over the S work lists one after the other in block order, the reduce / Schur / update kernels take the window from blockIdx.z
+ * (grids sized for the largest window) -- and the host loop polls ALL states with one copy.  windows: host array, one record per window
+ * (what sp_window_gn_run takes as arguments); args_dev: device scratch of n_windows * sp_window_gn_multi_bytes() bytes; states_dev / states_host
+ * (pinned): n_windows * 16 floats.  The update kernel's instantiation is that of the window with the most camera unknowns.  Per window the
+ * arithmetic is sp_window_gn_run's (bitwise: tests/test_gpu_window_gn.py).  With conv_tol > 0 the loop ends when EVERY window froze; a frozen
+ * window's launches return at once.  Returns the iterations launched or a negative error. */
+typedef struct SpWindowGn {
+    const SpPair* pairs;             /* the window's edges as frame pairs, at the pyramid level of this phase */
+    const int32_t* chunks;
+    const int32_t* spans;
+    const SpWindowEdge* edges;
+    SpWindowNode* nodes;
+    const SpWindowBlock* blocks;
+    float* span_partials;
+    float* seg_partials;
+    double* scratch;                 /* sp_window_gn_scratch_doubles(...) */
+    SpWindowNode* nodes_backup;
+    float* kld_backup;
+    float* state;                    /* 16 floats, as sp_window_gn_step */
+    float* losses;
+    int32_t n_spans, n_edges, n_nodes, n_blocks, sum_N, max_N, n_unknowns, max_losses;
+} SpWindowGn;                        /* 136 bytes */
+int sp_window_gn_multi_bytes(void);
+int sp_window_gn_run_multi(const SpWindowGn* windows, int n_windows, float irls_eps, int flags, float lm_up, float lm_down, float lm_min,
+                           float conv_tol, int max_iters, int check_every, void* args_dev, float* states_dev, float* states_host, void* stream);
+
 /* Up to max_iters iterations -- sp_pairs_cost(mode 2, irls_eps) over the window's work list + sp_window_gn_step -- as ONE foreign call
  * (the Python loop of optim/window.py run_gn): every check_every iterations the 16-float state is copied to state_host (pinned) and this
  * stream synchronised; with conv_tol > 0 the loop ends once the window froze.  Returns the iterations launched (>= 0), SP_EINVAL, or

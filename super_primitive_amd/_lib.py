@@ -55,6 +55,8 @@ SIGNATURES = {
     "sp_window_gn_scratch_doubles": [I, I, I, I, I],
     "sp_window_gn_profile_offset": [I, I, I, I, I],
     "sp_window_gn_run": [P, P, P, I, F, P, I, P, I, P, I, I, I, I, P, P, P, P, P, I, F, F, F, F, P, P, I, I, I, P, P],
+    "sp_window_gn_multi_bytes": [],
+    "sp_window_gn_run_multi": [P, I, F, I, F, F, F, F, I, I, P, P, P, P],
     "sp_window_gn_step": [P, P, I, P, I, P, I, I, I, I, P, P, P, P, P, I, F, F, F, F, P, P, I, P],
     "sp_depth_expand": [P, P, P, P, I, I, I, I, P, P],
     "sp_depth_splat_mean": [P, P, P, P, P, I, I, I, I, P, P, P, P, P],
@@ -172,6 +174,14 @@ class SpQueue(ctypes.Structure):
                 ("n_queue", c_int), ("pad_", c_int),
                 ("head", c_void_p), ("slot_pair", c_void_p), ("q_costs", c_void_p), ("q_lm", c_void_p), ("lam0", c_float), ("pad2_", c_int),
                 ("active", c_void_p)]
+
+
+class SpWindowGn(ctypes.Structure):
+    """Mirror of ``struct SpWindowGn`` (include/sp_hip.h): one window of a multi-window Gauss-Newton run; 136 bytes."""
+    _fields_ = [("pairs", c_void_p), ("chunks", c_void_p), ("spans", c_void_p), ("edges", c_void_p), ("nodes", c_void_p), ("blocks", c_void_p),
+                ("span_partials", c_void_p), ("seg_partials", c_void_p), ("scratch", c_void_p), ("nodes_backup", c_void_p), ("kld_backup", c_void_p),
+                ("state", c_void_p), ("losses", c_void_p), ("n_spans", c_int), ("n_edges", c_int), ("n_nodes", c_int), ("n_blocks", c_int),
+                ("sum_N", c_int), ("max_N", c_int), ("n_unknowns", c_int), ("max_losses", c_int)]
 
 
 class SpWindowNode(ctypes.Structure):

@@ -1031,6 +1031,8 @@ struct FuseArgs {
     const int32_t* phase;     // per-pair schedules (sp_pairs_schedule_cost): the phase of a pair selects its level descriptors and
     SchedCost sched;          // IRLS epsilon; spans of pairs that are finished, or in a phase of another work list, return at once
     const int32_t* active;    // queue runs, the tail: the launch covers only these slots (SpQueue.active), virtual span v belongs to active[v / vspans]
+    const MultiList* multi;   // the launch covers n_multi work lists of DIFFERENT batches (the windows of sp_window_gn_run_multi), one after the other
+    int32_t n_multi;
 };
 
 template <int MODE, int ABL = 0, int FUSED = 0, bool W64 = false>
@@ -1042,6 +1044,14 @@ __global__ __launch_bounds__(SP_BLOCK, FUSED != 0 ? 1 : (MODE == 2 ? 2 : 4)) voi
     int block = blockIdx.x;
     uint32_t phase_mask = f.sched.mask;
     int vspans = f.sched.vspans;
+    if (f.multi) {
+        int l = 0;
+        for (int i = 1; i < f.n_multi && block >= f.multi[i].first_block; ++i) l = i;      // (wave-uniform: scalar loads)
+        const MultiList& ml = f.multi[l];
+        block -= ml.first_block;
+        pairs = ml.pairs; chunks = reinterpret_cast<const int4*>(ml.chunks); spans = reinterpret_cast<const int4*>(ml.spans);
+        n_spans = ml.n_spans; partials = ml.partials; seg_partials = ml.seg_partials;
+    }
     if (f.phase && f.sched.n_lists > 0) {
         // One launch over the work lists of a schedule's iteration (the coarse levels' decimated tables and the full one), which
         // took a launch each: the lists of an iteration are independent, mostly small, and one after the other each drained
@@ -1338,6 +1348,24 @@ int sp_pairs_cost_active(const SpPair* pairs, const int32_t* chunks, const int32
     SP_CHECK_LAUNCH();
     return 0;
 }
+
+}  // extern "C"
+
+// the cost pass (mode 2: the window optimiser's, or 0 / 1) over n_lists work lists of different batches in ONE launch
+int cost_pairs_multi(const MultiList* lists_dev, int n_lists, int total_blocks, int mode, float irls_eps, void* stream) {
+    if (!lists_dev || n_lists <= 0 || total_blocks <= 0 || (mode != 0 && mode != 1 && mode != 2)) return SP_EINVAL;
+    FuseArgs f{};
+    f.multi = lists_dev; f.n_multi = n_lists;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const SpPair* np = nullptr; const int4* n4 = nullptr; float* nf = nullptr;
+    if (mode == 2) hipLaunchKernelGGL(k_cost_pairs<2>, dim3(total_blocks), dim3(SP_BLOCK), 0, s, np, n4, n4, 0, irls_eps, nf, nf, f);
+    else if (mode == 1) hipLaunchKernelGGL(k_cost_pairs<1>, dim3(total_blocks), dim3(SP_BLOCK), 0, s, np, n4, n4, 0, irls_eps, nf, nf, f);
+    else hipLaunchKernelGGL(k_cost_pairs<0>, dim3(total_blocks), dim3(SP_BLOCK), 0, s, np, n4, n4, 0, irls_eps, nf, nf, f);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" {
 
 int sp_pairs_schedule_cost(const SpSchedule* sched, const int32_t* phase, void* stream) { return schedule_cost_from(sched, phase, stream, 0, nullptr, 0, nullptr, 0, 0u); }
 

@@ -40,6 +40,17 @@ __device__ __forceinline__ float fast_exp(float x) {
 // sp_pairs_schedule_cost() from a phase every pair is known to have reached (sp_cost.hip; used by sp_pairs_schedule_run in sp_solver.hip)
 struct SpSchedule;
 struct SpQueue;
+// one work list of a launch over MANY (sp_window_gn_run_multi: the cost pass of S windows in one launch); device memory, ordered by first_block
+struct MultiList {
+    const SpPair* pairs;
+    const int32_t* chunks;
+    const int32_t* spans;
+    float* partials;
+    float* seg_partials;
+    int32_t n_spans;
+    int32_t first_block;      // its workgroups are blockIdx.x - first_block (a multiple of 8)
+};
+__attribute__((visibility("hidden"))) int cost_pairs_multi(const MultiList* lists_dev, int n_lists, int total_blocks, int mode, float irls_eps, void* stream);
 __attribute__((visibility("hidden"))) int schedule_cost_from(const SpSchedule* sched, const int32_t* phase, void* stream, int first_phase, const SpQueue* queue, int n_slots,
                                                               const int32_t* active, int n_active, uint32_t idle_mask);
 

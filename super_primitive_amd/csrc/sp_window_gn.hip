@@ -20,6 +20,8 @@
 //                                       renormalisation; relative poses and affine slots of every edge for the next cost pass.
 // No host synchronisation; the loss history and the converged flag live on the device like in sp_window_step.
 #include "sp_solve_device.h"
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -43,15 +45,14 @@ __device__ __forceinline__ void wgn_gcol(const double* __restrict__ Ad, int col,
 
 #define SP_WGN_LOC 272           // doubles per edge of its system in NODE coordinates: 16 x 16 block G^T H_z G over [y_trg (8) ; y_src (8)], then G^T b_z (16)
 
-__global__ __launch_bounds__(SP_BLOCK) void k_window_gn_reduce(const SpPair* __restrict__ pairs, const SpWindowEdge* __restrict__ edges,
-                                                               const float* __restrict__ partials, const float* __restrict__ seg_partials,
-                                                               double* __restrict__ scratch, int stride, double* __restrict__ Ad_all,
-                                                               double* __restrict__ loc_all) {
+__device__ __forceinline__ void wgn_reduce_edge(const SpPair* __restrict__ pairs, const SpWindowEdge* __restrict__ edges,
+                                                const float* __restrict__ partials, const float* __restrict__ seg_partials,
+                                                double* __restrict__ scratch, int stride, double* __restrict__ Ad_all,
+                                                double* __restrict__ loc_all, int e) {
     constexpr int NV = SP_GNA_PARTIAL_FLOATS, NS = SP_GNA_SEG_FLOATS;
     __shared__ double sums[NV];
     __shared__ double red[(SP_BLOCK / NV) * NV];
     __shared__ double Hz[36], bz[8], Ads[36];
-    const int e = blockIdx.x;
     const SpPair& pr = pairs[e];
     reduce_columns<NV>(partials + (size_t)pr.tile0 * NV, pr.n_tiles, sums, red);
     const double inv3P = 1.0 / (3.0 * (double)pr.P);
@@ -136,7 +137,15 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_reduce(const SpPair* __r
     }
 }
 
+__global__ __launch_bounds__(SP_BLOCK) void k_window_gn_reduce(const SpPair* __restrict__ pairs, const SpWindowEdge* __restrict__ edges,
+                                                               const float* __restrict__ partials, const float* __restrict__ seg_partials,
+                                                               double* __restrict__ scratch, int stride, double* __restrict__ Ad_all,
+                                                               double* __restrict__ loc_all) {
+    wgn_reduce_edge(pairs, edges, partials, seg_partials, scratch, stride, Ad_all, loc_all, blockIdx.x);
+}
+
 struct WGnArgs {
+    const float* span_partials; const float* seg_partials;      // (the per-edge reduction of a multi-window step reads them from here)
     const SpPair* pairs; const SpWindowEdge* edges; int n_edges;
     SpWindowNode* nodes; int n_nodes;
     const SpWindowBlock* blocks; int n_blocks; int max_N;
@@ -232,7 +241,16 @@ __device__ __forceinline__ int ltri_row(int t) {
 #define SP_WGN_PPT 2               // pairs per thread
 #define SP_WGN_BLOCK_EDGES 64     // edges of ONE source keyframe kept as a list in LDS
 
-__global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w) {
+// S WINDOWS PER LAUNCH (round 6, sp_window_gn_step_multi): `wins` = S argument records in device memory, window = blockIdx.z; the grid is sized
+// for the largest window, workgroups beyond a window's own edges / blocks / tiles return at once.  wins == NULL: the one window passed by value.
+__global__ __launch_bounds__(SP_BLOCK) void k_window_gn_reduce_multi(const WGnArgs* __restrict__ wins) {
+    const WGnArgs& w = wins[blockIdx.z];
+    if ((int)blockIdx.x >= w.n_edges) return;
+    wgn_reduce_edge(w.pairs, w.edges, w.span_partials, w.seg_partials, w.scratch, w.stride, w.Ad, w.loc, blockIdx.x);
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w, const WGnArgs* __restrict__ wins) {
+    if (wins) { w = wins[blockIdx.z]; if ((int)blockIdx.x >= w.n_blocks) return; }
     __shared__ double Cs[SP_WGN_SCHUR_LDS];
     __shared__ double Dv[SP_WGN_SCHUR_ROWS], Bv[SP_WGN_SCHUR_ROWS];
     __shared__ int pose_off[SP_WGN_MAX_NODES], aff_off[SP_WGN_MAX_NODES], lpose[SP_WGN_MAX_NODES], laff[SP_WGN_MAX_NODES];
@@ -469,7 +487,8 @@ __device__ void wgn_compose_edge(const WGnArgs& w, int e) {
 // 128-unknown instantiation, whose factorisation keeps 36 doubles of the matrix per thread in registers: 512 threads = 256 VGPRs each
 __host__ __device__ constexpr int wgn_update_threads(int lds_y) { return lds_y == 128 ? 512 : lds_y == 192 ? 256 : SP_WGN_THREADS; }
 template <int LDS_Y>
-__global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(WGnArgs w) {
+__global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(WGnArgs w, const WGnArgs* __restrict__ wins) {
+    if (wins) w = wins[blockIdx.z];
     constexpr int CAP = LDS_Y > 0 ? LDS_Y : SP_WGN_MAX_Y;
     constexpr int NTHR = wgn_update_threads(LDS_Y);
     __shared__ double Hs[LDS_Y > 0 ? LDS_Y * (LDS_Y + 1) / 2 : 1];
@@ -1005,19 +1024,18 @@ int sp_window_gn_profile_offset(int n_edges, int n_blocks, int sum_N, int max_N,
                  (long long)n_blocks * (tri + 2 * ldc) + n_blocks + 2);
 }
 
-int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes,
-                      const SpWindowBlock* blocks, int n_blocks, int sum_N, int max_N, int n_unknowns, const float* span_partials,
-                      const float* seg_partials, double* scratch, SpWindowNode* nodes_backup, float* kld_backup, int flags,
-                      float lm_up, float lm_down, float lm_min, float conv_tol, float* state, float* losses, int max_losses,
-                      void* stream) {
+// the argument record of one window (what sp_window_gn_step passes its kernels by value and sp_window_gn_run_multi keeps per window in device memory)
+static int wgn_fill_args(WGnArgs& w, const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes,
+                         const SpWindowBlock* blocks, int n_blocks, int sum_N, int max_N, int n_unknowns, const float* span_partials,
+                         const float* seg_partials, double* scratch, SpWindowNode* nodes_backup, float* kld_backup, int flags,
+                         float lm_up, float lm_down, float lm_min, float conv_tol, float* state, float* losses, int max_losses) {
     if (!pairs || !edges || !nodes || !blocks || !span_partials || !seg_partials || !scratch || !nodes_backup || !kld_backup || !state ||
         !losses)
         return SP_EINVAL;
     if (n_edges <= 0 || n_nodes <= 0 || n_blocks <= 0 || sum_N <= 0 || max_N <= 0 || max_losses < 0 || n_unknowns < 0) return SP_EINVAL;
     if (n_nodes > SP_WGN_MAX_NODES || n_blocks > SP_WGN_MAX_NODES || n_unknowns > SP_WGN_MAX_Y) return SP_ELIMIT;
-    hipStream_t s = static_cast<hipStream_t>(stream);
     const int stride = SP_WGN_REC + SP_WGN_SEG * max_N;
-    WGnArgs w;
+    w.span_partials = span_partials; w.seg_partials = seg_partials;
     w.pairs = pairs; w.edges = edges; w.n_edges = n_edges; w.nodes = nodes; w.n_nodes = n_nodes; w.blocks = blocks; w.n_blocks = n_blocks;
     w.max_N = max_N; w.scratch = scratch; w.stride = stride;
     w.ldc = (n_unknowns + 1) & ~1;
@@ -1037,15 +1055,30 @@ int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edge
     w.nodes_backup = nodes_backup; w.kld_backup = kld_backup; w.flags = flags;
     w.lm_up = lm_up; w.lm_down = lm_down; w.lm_min = lm_min; w.conv_tol = conv_tol;
     w.state = state; w.losses = losses; w.max_losses = max_losses;
+    return 0;
+}
+
+int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, SpWindowNode* nodes, int n_nodes,
+                      const SpWindowBlock* blocks, int n_blocks, int sum_N, int max_N, int n_unknowns, const float* span_partials,
+                      const float* seg_partials, double* scratch, SpWindowNode* nodes_backup, float* kld_backup, int flags,
+                      float lm_up, float lm_down, float lm_min, float conv_tol, float* state, float* losses, int max_losses,
+                      void* stream) {
+    WGnArgs w;
+    if (int rc = wgn_fill_args(w, pairs, edges, n_edges, nodes, n_nodes, blocks, n_blocks, sum_N, max_N, n_unknowns, span_partials, seg_partials, scratch,
+                               nodes_backup, kld_backup, flags, lm_up, lm_down, lm_min, conv_tol, state, losses, max_losses))
+        return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int stride = w.stride;
     hipLaunchKernelGGL(k_window_gn_reduce, dim3(n_edges), dim3(SP_BLOCK), 0, s, pairs, edges, span_partials, seg_partials, scratch, stride, w.Ad, w.loc);
     SP_CHECK_LAUNCH();
     const int tiles = max(1, (w.lds + SP_BLOCK * SP_WGN_PPT - 1) / (SP_BLOCK * SP_WGN_PPT));
-    hipLaunchKernelGGL(k_window_gn_schur, dim3(n_blocks, tiles), dim3(SP_BLOCK), 0, s, w);
+    const WGnArgs* none = nullptr;
+    hipLaunchKernelGGL(k_window_gn_schur, dim3(n_blocks, tiles), dim3(SP_BLOCK), 0, s, w, none);
     SP_CHECK_LAUNCH();
-    if (n_unknowns <= 64) hipLaunchKernelGGL(k_window_gn_update<64>, dim3(1), dim3(wgn_update_threads(64)), 0, s, w);
-    else if (n_unknowns <= 128) hipLaunchKernelGGL(k_window_gn_update<128>, dim3(1), dim3(wgn_update_threads(128)), 0, s, w);
-    else if (n_unknowns <= SP_WGN_LDS_Y) hipLaunchKernelGGL(k_window_gn_update<SP_WGN_LDS_Y>, dim3(1), dim3(wgn_update_threads(SP_WGN_LDS_Y)), 0, s, w);
-    else hipLaunchKernelGGL(k_window_gn_update<0>, dim3(1), dim3(wgn_update_threads(0)), 0, s, w);
+    if (n_unknowns <= 64) hipLaunchKernelGGL(k_window_gn_update<64>, dim3(1), dim3(wgn_update_threads(64)), 0, s, w, none);
+    else if (n_unknowns <= 128) hipLaunchKernelGGL(k_window_gn_update<128>, dim3(1), dim3(wgn_update_threads(128)), 0, s, w, none);
+    else if (n_unknowns <= SP_WGN_LDS_Y) hipLaunchKernelGGL(k_window_gn_update<SP_WGN_LDS_Y>, dim3(1), dim3(wgn_update_threads(SP_WGN_LDS_Y)), 0, s, w, none);
+    else hipLaunchKernelGGL(k_window_gn_update<0>, dim3(1), dim3(wgn_update_threads(0)), 0, s, w, none);
     SP_CHECK_LAUNCH();
     return 0;
 }
@@ -1075,6 +1108,74 @@ int sp_window_gn_run(const SpPair* pairs, const int32_t* chunks, const int32_t* 
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
         if (conv_tol > 0.f && static_cast<volatile float*>(state_host)[6] != 0.f) break;
+    }
+    return it;
+}
+
+// ---- S windows per launch (round 6, VERDICT r05 item 4b: config 3's throughput form) ---------------------------------------------------
+// gather the 16-float states of the windows into one array (one copy per poll instead of S)
+__global__ void k_wgn_gather_states(const WGnArgs* __restrict__ wins, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * SP_WGN_STATE) out[i] = wins[i / SP_WGN_STATE].state[i % SP_WGN_STATE];
+}
+
+int sp_window_gn_multi_bytes(void) { return (int)((sizeof(WGnArgs) + sizeof(MultiList) + 15) / 16 * 16); }
+
+int sp_window_gn_run_multi(const SpWindowGn* windows, int n_windows, float irls_eps, int flags, float lm_up, float lm_down, float lm_min,
+                           float conv_tol, int max_iters, int check_every, void* args_dev, float* states_dev, float* states_host, void* stream) {
+    if (!windows || n_windows <= 0 || n_windows > 65535 || !args_dev || !states_dev || !states_host || max_iters < 0 || check_every <= 0) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::vector<WGnArgs> host(n_windows);
+    std::vector<MultiList> lists(n_windows);
+    int max_edges = 0, max_blocks = 0, max_y = 0, total_blocks = 0;
+    for (int i = 0; i < n_windows; ++i) {
+        const SpWindowGn& g = windows[i];
+        if (!g.chunks || !g.spans || g.n_spans <= 0) return SP_EINVAL;
+        if (int rc = wgn_fill_args(host[i], g.pairs, g.edges, g.n_edges, g.nodes, g.n_nodes, g.blocks, g.n_blocks, g.sum_N, g.max_N, g.n_unknowns,
+                                   g.span_partials, g.seg_partials, g.scratch, g.nodes_backup, g.kld_backup, flags, lm_up, lm_down, lm_min, conv_tol,
+                                   g.state, g.losses, g.max_losses))
+            return rc;
+        lists[i] = MultiList{g.pairs, g.chunks, g.spans, g.span_partials, g.seg_partials, g.n_spans, total_blocks};
+        total_blocks += (g.n_spans + 7) / 8 * 8;
+        max_edges = std::max(max_edges, g.n_edges); max_blocks = std::max(max_blocks, g.n_blocks); max_y = std::max(max_y, g.n_unknowns);
+    }
+    // the update kernel's instantiation is chosen for the LARGEST window; every window must fit the scratch it was sized for (cap_y): a window
+    // whose own scratch has no room for the global-memory triangle cannot ride in a batch that needs it
+    if (max_y > SP_WGN_LDS_Y)
+        for (int i = 0; i < n_windows; ++i) if (windows[i].n_unknowns <= SP_WGN_LDS_Y) return SP_EINVAL;
+    WGnArgs* wins = static_cast<WGnArgs*>(args_dev);
+    MultiList* lists_dev = reinterpret_cast<MultiList*>(static_cast<char*>(args_dev) + (sizeof(WGnArgs) * (size_t)n_windows + 15) / 16 * 16);
+    hipError_t e = hipMemcpyAsync(wins, host.data(), sizeof(WGnArgs) * (size_t)n_windows, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(lists_dev, lists.data(), sizeof(MultiList) * (size_t)n_windows, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    const int lds = max_y * (max_y + 1) / 2;
+    const int tiles = std::max(1, (lds + SP_BLOCK * SP_WGN_PPT - 1) / (SP_BLOCK * SP_WGN_PPT));
+    const WGnArgs dummy{};
+    int it = 0;
+    while (it < max_iters) {
+        const int n = (max_iters - it) < check_every ? (max_iters - it) : check_every;
+        for (int k = 0; k < n; ++k, ++it) {
+            int rc = cost_pairs_multi(lists_dev, n_windows, total_blocks, 2, irls_eps, stream);
+            if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
+            hipLaunchKernelGGL(k_window_gn_reduce_multi, dim3(max_edges, 1, n_windows), dim3(SP_BLOCK), 0, s, (const WGnArgs*)wins);
+            hipLaunchKernelGGL(k_window_gn_schur, dim3(max_blocks, tiles, n_windows), dim3(SP_BLOCK), 0, s, dummy, (const WGnArgs*)wins);
+            if (max_y <= 64) hipLaunchKernelGGL(k_window_gn_update<64>, dim3(1, 1, n_windows), dim3(wgn_update_threads(64)), 0, s, dummy, (const WGnArgs*)wins);
+            else if (max_y <= 128) hipLaunchKernelGGL(k_window_gn_update<128>, dim3(1, 1, n_windows), dim3(wgn_update_threads(128)), 0, s, dummy, (const WGnArgs*)wins);
+            else if (max_y <= SP_WGN_LDS_Y) hipLaunchKernelGGL(k_window_gn_update<SP_WGN_LDS_Y>, dim3(1, 1, n_windows), dim3(wgn_update_threads(SP_WGN_LDS_Y)), 0, s, dummy, (const WGnArgs*)wins);
+            else hipLaunchKernelGGL(k_window_gn_update<0>, dim3(1, 1, n_windows), dim3(wgn_update_threads(0)), 0, s, dummy, (const WGnArgs*)wins);
+            hipError_t el = hipGetLastError();
+            if (el != hipSuccess) return -(1000 + (int)el);
+        }
+        hipLaunchKernelGGL(k_wgn_gather_states, dim3((n_windows * SP_WGN_STATE + 255) / 256), dim3(256), 0, s, (const WGnArgs*)wins, n_windows, states_dev);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(states_host, states_dev, sizeof(float) * SP_WGN_STATE * (size_t)n_windows, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return -(1000 + (int)e);
+        if (conv_tol > 0.f) {
+            bool all = true;
+            for (int i = 0; i < n_windows && all; ++i) all = static_cast<volatile float*>(states_host)[i * SP_WGN_STATE + 6] != 0.f;
+            if (all) break;
+        }
     }
     return it;
 }

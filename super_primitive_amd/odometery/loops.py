@@ -291,7 +291,7 @@ class GnSuppMapper:
         return win.klds()[0], win.gn_losses(), n
 
 
-def _build_map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode, gn):
+def _build_map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose, frozen0, affine, initialised, rel_tol, mode, gn, span_points=None):
     """The PoseWindow of one mapping (nodes = keyframes then supporting frames, sources = the keyframes that are sources in ``mode``,
     one edge per photometric term): (window or None when there is nothing to match, {(k, j): node of supporting frame j of keyframe k},
     source keyframe ids)."""
@@ -317,8 +317,10 @@ def _build_map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose,
             edges.append((b, node, 1.0 / len(trg), dense_optim.Z_MIN_BATCH))
     if not edges:
         return None, supp_node, src_ids
+    # (``span_points``: points per workgroup of the window's cost pass.  Default: sized for ONE window's latency -- ~2300 workgroups however
+    #  few the points; windows optimised side by side, ``PoseWindowBatch``, want the throughput size, 4096-16384)
     win = PoseWindow(sources, nodes, edges, (0, 1), abs_loss=False, rel_tol=rel_tol if initialised else 0.0, use_affine=affine,
-                     max_iters=max(1, num_iters) + (gn['polish_max'] + 8 if gn else 0))
+                     max_iters=max(1, num_iters) + (gn['polish_max'] + 8 if gn else 0), span_points=span_points)
     return win, supp_node, src_ids
 
 

@@ -437,3 +437,62 @@ class PoseWindow:
 
     def edge_poses(self):
         return self.pose_slots.reshape(-1, 4, 4).clone()
+
+
+class PoseWindowBatch:
+    """S independent windows optimised SIDE BY SIDE by Gauss-Newton (config 3's throughput form -- S sequences at once -- as ``PairBatch`` is
+    config 2's; include/sp_hip.h ``sp_window_gn_run_multi``).  One window's iteration is four small dependent launches (cost pass over a
+    few dozen edges, per-edge reduce, per-keyframe Schur terms, one update workgroup) that leave the chip empty; here every launch covers
+    ALL the windows (window = blockIdx.z; the cost pass walks the S work lists in one grid) and one host loop polls all states with one
+    copy.  ``windows``: built ``PoseWindow`` objects (any mix of sizes below 192 camera unknowns, or all above).  Per window the arithmetic
+    is that of ``PoseWindow.run_gn`` -- bitwise (tests/test_gpu_window_gn.py)."""
+
+    def __init__(self, windows):
+        assert len(windows) >= 1
+        self.windows = list(windows)
+        self.lib = windows[0].lib
+        self.device = windows[0].device
+        S = len(self.windows)
+        for w in self.windows:
+            w._gn_state()
+        self.args_dev = torch.empty(S * self.lib.sp_window_gn_multi_bytes() + 64, dtype=torch.uint8, device=self.device)
+        self.states_dev = torch.zeros(S * 16, dtype=torch.float32, device=self.device)
+        self.states_host = torch.zeros(S * 16, dtype=torch.float32).pin_memory()
+        self._desc = {}
+
+    def _records(self, level):
+        if level not in self._desc:
+            arr = (_lib.SpWindowGn * len(self.windows))()
+            for i, w in enumerate(self.windows):
+                gn, d, a = w._gn_state(), w.desc[level], arr[i]
+                a.pairs, a.chunks, a.spans, a.edges, a.nodes, a.blocks = d.data_ptr(), w.chunks.data_ptr(), w.spans.data_ptr(), w.edges.data_ptr(), w.nodes.data_ptr(), w.blocks.data_ptr()
+                a.span_partials, a.seg_partials, a.scratch = w.partials.data_ptr(), w.seg_partials.data_ptr(), gn['scratch'].data_ptr()
+                a.nodes_backup, a.kld_backup, a.state, a.losses = gn['nodes_backup'].data_ptr(), gn['kld_backup'].data_ptr(), gn['state'].data_ptr(), gn['losses'].data_ptr()
+                a.n_spans, a.n_edges, a.n_nodes, a.n_blocks = w.n_spans, w.n_edges, w.n_nodes, w.n_sources
+                a.sum_N, a.max_N, a.n_unknowns, a.max_losses = gn['sum_N'], w.max_N, gn['n_y'], w.max_iters
+            self._desc[level] = arr
+        return self._desc[level]
+
+    def reset_gn(self, lam=1e-4):
+        for w in self.windows:
+            w.reset_gn(lam)
+
+    def run_gn(self, level, max_iters, irls_eps=1e-3, conv_tol=2e-3, pose_only=False, check_every=None, lm_up=8.0, lm_down=0.5, lm_min=1e-7,
+               predicted_exit=None):
+        """One Gauss-Newton phase of EVERY window (``PoseWindow.run_gn``'s arguments); ends when every window has converged or after
+        ``max_iters``.  Returns the rounds launched."""
+        if check_every is None:
+            check_every = GN_CHECK_EVERY
+        if predicted_exit is None:
+            predicted_exit = GN_PREDICTED_EXIT
+        for w in self.windows:
+            w.begin_gn_phase()
+        arr = self._records(level)
+        rc = self.lib.sp_window_gn_run_multi(ctypes.addressof(arr), len(self.windows), float(irls_eps), (1 if pose_only else 0) | (2 if predicted_exit else 0),
+                                             float(lm_up), float(lm_down), float(lm_min), float(conv_tol), int(max_iters), int(check_every),
+                                             _lib.ptr(self.args_dev), _lib.ptr(self.states_dev), self.states_host.data_ptr(), _lib.stream_ptr())
+        if rc < 0:
+            _lib.check(rc, "sp_window_gn_run_multi")
+        for i, w in enumerate(self.windows):
+            w._gn['state_host'].copy_(self.states_host[16 * i: 16 * i + 16])
+        return rc

@@ -373,3 +373,47 @@ def test_mono_init_mapping_by_gauss_newton_reaches_the_reference_minimiser():
           f"scale removed: rot {rot:.2e} rad, t {tt:.2e}, depth {dd:.2e}; the reference's settled state vs ground truth {g['err_gt_scale_removed']}")
     assert np.array_equal(npy(out["kf_poses"][0]), poses0[0])               # first keyframe fixed
     assert rot <= 1e-4 and tt <= 1e-4 and dd <= 1e-3
+
+
+def test_windows_side_by_side_are_bitwise_the_windows_one_at_a_time():
+    """``PoseWindowBatch`` (sp_window_gn_run_multi: every launch of a Gauss-Newton iteration covers ALL the windows,
+    window = blockIdx.z, the cost pass walks the windows' work lists in one grid) on windows of DIFFERENT extent -- 3 keyframes x 1
+    supporting frame (40 camera unknowns), 5 x 2 + 2 running (112), 4 x 1 + 2 (64), affine pairs on, other scenes -- against the same
+    windows optimised one at a time (``PoseWindow.run_gn``): poses, affine pairs, log-depths, loss histories and iteration counts of
+    every window are BITWISE equal, whichever instantiation of the update kernel the largest window of the batch selects."""
+    from super_primitive_amd.odometery.loops import MAP_GN_SCHEDULE, _build_map_window
+    from super_primitive_amd.optim.window import PoseWindowBatch
+    shapes = [(301, 3, 1, 0), (302, 5, 2, 2), (303, 4, 1, 2), (304, 3, 1, 0), (305, 5, 2, 2)]
+    gn = dict(MAP_GN_SCHEDULE)
+
+    def build():
+        wins = []
+        for seed, n_kf, n_supp, n_run in shapes:
+            frames, kfi, si, est, klds, affs, kfs, supp = _extent_window(seed, n_kf, n_supp, n_run, H=96, W=128, N=12)
+            win, _, _ = _build_map_window(kfs, [T(est[i]) for i in kfi], [T(k) for k in klds], [T(affs[i]) for i in kfi], supp, 25, 1e-4, n_kf == 5, True, True,
+                                          1e-8, 'map', gn)
+            wins.append(win)
+        return wins
+
+    def phases(run):
+        n = run(0, gn['max_iters'], irls_eps=gn['irls_eps'], conv_tol=gn['conv_tol'])
+        return n + run(0, gn['polish_max'], irls_eps=gn['polish_eps'], conv_tol=gn['polish_tol'])
+
+    alone = build()
+    its = []
+    for w in alone:
+        w.reset_gn()
+        its.append(phases(w.run_gn))
+    together = build()
+    batch = PoseWindowBatch(together)
+    batch.reset_gn()
+    rounds = phases(batch.run_gn)
+    torch.cuda.synchronize()
+    n_y = [w._gn['n_y'] for w in together]
+    print(f"\n{len(shapes)} windows of {n_y} camera unknowns side by side: {rounds} rounds for the batch; alone {its} iterations")
+    assert len(set(n_y)) >= 3 and max(n_y) > 64 > min(n_y)
+    for a, b in zip(alone, together):
+        assert torch.equal(a.nodes, b.nodes) and torch.equal(a.kld, b.kld)
+        assert a.gn_iterations() == b.gn_iterations() and torch.equal(a.gn_losses(), b.gn_losses())
+        assert a.gn_converged() == b.gn_converged()
+    assert max(its) <= rounds <= max(its) + 2 * 4                 # (the batch runs until its slowest window has been SEEN converged: polled every 4th round)
