@@ -446,7 +446,10 @@ typedef struct SpVerdict {
     float seg_mean_ratio;        /* judged (of the pair's first SP_VERDICT_SEGMENTS segments); pairs with fewer than SP_VERDICT_MIN_SEGMENTS judged segments are not tested */
     int32_t* evals;              /* [pairs * SP_MAX_PHASES] or NULL, zeroed by the caller: cost evaluations of every pair in every phase (diagnostics:
                                   * bench.py prices a scheduled run's algorithmic bytes with it, roofline_schedule) */
-} SpVerdict;             /* 96 bytes */
+    float seg_product;           /* <= 0: not tested.  (cost / median - 1) x (worst / median) above this: a moderately raised cost TOGETHER WITH a clear
+                                  * outlier segment -- neither ratio alone separates such a pair from a converged one with noisy small segments */
+    float pad_;
+} SpVerdict;             /* 104 bytes */
 #define SP_VERDICT_SEGMENTS 2048
 #define SP_VERDICT_SEGMENT_POINTS 64
 #define SP_VERDICT_MIN_SEGMENTS 8

@@ -165,7 +165,8 @@ class SpVerdict(ctypes.Structure):
     """Mirror of ``struct SpVerdict`` (include/sp_hip.h): the per-pair verdict of a scheduled run and its later attempts."""
     _fields_ = [("status", c_void_p), ("diag", c_void_p), ("attempts", c_void_p), ("pose0", c_void_p), ("kld0", c_void_p),
                 ("pose_base", c_void_p), ("kld_base", c_void_p), ("kld_bound", c_float), ("cost_bound", c_float), ("cost_ratio", c_float),
-                ("valid_min", c_float), ("retry_mask", c_int), ("lam0", c_float), ("seg_max_ratio", c_float), ("seg_mean_ratio", c_float), ("evals", c_void_p)]
+                ("valid_min", c_float), ("retry_mask", c_int), ("lam0", c_float), ("seg_max_ratio", c_float), ("seg_mean_ratio", c_float), ("evals", c_void_p),
+                ("seg_product", c_float), ("pad_", c_float)]
 
 
 class SpQueue(ctypes.Structure):

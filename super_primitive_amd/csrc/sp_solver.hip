@@ -17,7 +17,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn(const SpPair* __restrict_
     solve_gn(pairs, blockIdx.x, partials, seg_partials, h);
 }
 
-static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 800 && sizeof(SpVerdict) == 96 && sizeof(SpQueue) == 296 && sizeof(SpPair) == 136,
+static_assert(sizeof(SpPhase) == 64 && sizeof(SpSchedule) == 800 && sizeof(SpVerdict) == 104 && sizeof(SpQueue) == 296 && sizeof(SpPair) == 136,
               "SpSchedule / SpVerdict / SpQueue / SpPair are part of the ABI");
 
 // per-pair schedules: the pair's current phase selects the level descriptors, the partial records of that level's work list,
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(SP_BLOCK) void k_pairs_gn_sched(SpSchedule sched, G
             if ((v.cost_bound > 0.f && cost > v.cost_bound) || (v.cost_ratio > 0.f && first > 0.f && cost > v.cost_ratio * first)) st |= SP_STATUS_COST;
             if (v.valid_min > 0.f && ls[6] < v.valid_min) st |= SP_STATUS_VALID;
             const float seg_med = seg_med_s, seg_max = fmaxf(fmaxf(seg_max_s[0], seg_max_s[1]), fmaxf(seg_max_s[2], seg_max_s[3]));
-            if (seg_med > 0.f && ((v.seg_max_ratio > 0.f && seg_max > v.seg_max_ratio * seg_med) || (v.seg_mean_ratio > 0.f && cost > v.seg_mean_ratio * seg_med)))
+            if (seg_med > 0.f && ((v.seg_max_ratio > 0.f && seg_max > v.seg_max_ratio * seg_med) || (v.seg_mean_ratio > 0.f && cost > v.seg_mean_ratio * seg_med) ||
+                                  (v.seg_product > 0.f && (cost / seg_med - 1.f) * (seg_max / seg_med) > v.seg_product)))
                 st |= SP_STATUS_SEGMENTS;
             // attempts[pair]: 0 = first attempt, 1 = restarted at retry_entry, 2 = restarted at retry2_entry (the last one there is)
             const int attempt = v.attempts ? v.attempts[pid] : 2;

@@ -134,9 +134,12 @@ REFERENCE_START_SCHEDULE = dict(FRAME_PAIR_SCHEDULE, pose_first_iters=15, pose_f
 # 2.75 / 2.96 / 3.34 / 3.78, cost / median at most 1.09 / 1.14 / 1.10 / 1.11.  Shipped: 8 and 1.3 -- the cost ratio does the work (a
 # third above the largest converged value, a seventh below 9847's), the worst-segment ratio only catches the grossly uneven.  It needs
 # no second pair: a batch of ONE is judged like a batch of thousands.  (The three misses below 1.3 -- 2437, 35432 and one more -- carry
-# run-away depths, SP_STATUS_DEPTH_RANGE.)
+# run-away depths, SP_STATUS_DEPTH_RANGE.)  ``seg_product`` = 0.9 on (cost / median - 1) x (worst / median): HELD-OUT SAM-realistic scenes
+# (seeds 7000..., profiles/r06_reference_start_heldout_*) produced a wrong-basin end state at 1.27 / 4.75 -- under both single thresholds, which
+# cannot come down: converged pairs reach 1.19 (sam) and 3.78 (1200 small segments).  Its product is 1.28 (9847: 2.2) where the PRODUCT OF THE
+# MAXIMA over every converged pair of every sweep is 0.51: a moderately raised cost together with a clear outlier segment.
 COST_OUTLIER_MIN_PAIRS = 8
-VERDICT_DEFAULTS = dict(kld_bound=2.0, cost_bound=0.0, cost_ratio=0.0, valid_min=0.5, cost_outlier=4.0, seg_max_ratio=8.0, seg_mean_ratio=1.3,
+VERDICT_DEFAULTS = dict(kld_bound=2.0, cost_bound=0.0, cost_ratio=0.0, valid_min=0.5, cost_outlier=4.0, seg_max_ratio=8.0, seg_mean_ratio=1.3, seg_product=0.9,
                         retry_on=_lib.SP_STATUS_NONFINITE | _lib.SP_STATUS_LAST_CAP | _lib.SP_STATUS_DEPTH_RANGE | _lib.SP_STATUS_VALID | _lib.SP_STATUS_COST
                         | _lib.SP_STATUS_SEGMENTS)
 
@@ -790,7 +793,7 @@ class PairBatch:
         v.kld_bound, v.cost_bound, v.cost_ratio, v.valid_min = float(opt["kld_bound"]), float(opt["cost_bound"]), float(opt["cost_ratio"]), float(opt["valid_min"])
         v.retry_mask = int(opt["retry_on"]) if (sched.retry_entry >= 0 or sched.retry2_entry >= 0) else 0
         v.lam0 = float(getattr(self, "_lam0", 1e-4))
-        v.seg_max_ratio, v.seg_mean_ratio = float(opt["seg_max_ratio"]), float(opt["seg_mean_ratio"])
+        v.seg_max_ratio, v.seg_mean_ratio, v.seg_product = float(opt["seg_max_ratio"]), float(opt["seg_mean_ratio"]), float(opt["seg_product"])
         # (diagnostics, ``count_evaluations=True`` in the verdict options: cost evaluations per pair and phase -> ``self.evals`` (M, SP_MAX_PHASES))
         self.evals = None
         if opt.get("count_evaluations", False):

@@ -299,6 +299,21 @@ def make_pair(H=60, W=80, N=6, seed=0, *, overlap=0, shape="grid",
     )
 
 
+def observable_segments(p, min_points=16):
+    """(N,) bool: segments with at least ``min_points`` pixels whose ground-truth re-projection lands inside the target's validity band (0.99 of
+    the normalised frame, core/dense_optim.py:128-162).  A segment that the target frame does not see has NO depth to converge to -- the
+    reference's Adam leaves it at its seed (zero gradient), Gauss-Newton likewise -- so it must not count as a depth error (SAM-realistic
+    scenes have 30-pixel masks at the image border)."""
+    H, W = p.depth.shape
+    fx, fy, cx, cy = float(p.K[0, 0]), float(p.K[1, 1]), float(p.K[0, 2]), float(p.K[1, 2])
+    cols, rows = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    d = p.depth.astype(np.float64)
+    X = np.stack(((cols - cx) / fx * d, (rows - cy) / fy * d, d), -1) @ p.pose_gt[:3, :3].astype(np.float64).T + p.pose_gt[:3, 3].astype(np.float64)
+    u, v = fx * X[..., 0] / X[..., 2] + cx, fy * X[..., 1] / X[..., 2] + cy
+    ok = (np.abs(2 * u / (W - 1) - 1) <= 0.99) & (np.abs(2 * v / (H - 1) - 1) <= 0.99) & (X[..., 2] > 1e-6)
+    return (p.keypoint_regions & ok[None]).reshape(p.N, -1).sum(1) >= min_points
+
+
 def stepped_logdepth(pair, seed=0, n_boxes=3, factor=(0.55, 0.75)):
     """Per-segment log-depths of ``pair`` after pulling a few axis-aligned boxes towards the camera: depth steps
     inside segments, the situation ``frontend/segment/post_processer.py`` exists for.  Returns (N,H,W) f32."""

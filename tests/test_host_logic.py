@@ -54,7 +54,7 @@ def test_abi_constants_and_struct_layout_match_header():
     # (ABI 13: 12 phases, the third attempt's entry, the Adam phases' rates and moments; the within-pair thresholds of the verdict)
     assert ctypes.sizeof(_lib.SpSchedule) == 800 and _lib.SpSchedule.n_phases.offset == 768 and _lib.SpSchedule.retry_entry.offset == 776
     assert _lib.SpSchedule.retry2_entry.offset == 780 and _lib.SpSchedule.adam_lr_pose.offset == 784 and _lib.SpSchedule.adam_state.offset == 792
-    assert ctypes.sizeof(_lib.SpVerdict) == 96 and _lib.SpVerdict.evals.offset == 88 and _lib.SpVerdict.kld_bound.offset == 56 and _lib.SpVerdict.lam0.offset == 76
+    assert ctypes.sizeof(_lib.SpVerdict) == 104 and _lib.SpVerdict.evals.offset == 88 and _lib.SpVerdict.seg_product.offset == 96 and _lib.SpVerdict.kld_bound.offset == 56 and _lib.SpVerdict.lam0.offset == 76
     assert _lib.SpVerdict.seg_max_ratio.offset == 80 and _lib.SpVerdict.seg_mean_ratio.offset == 84
     assert ctypes.sizeof(_lib.SpQueue) == 296 and _lib.SpQueue.active.offset == 288 and _lib.SpQueue.max_spans.offset == 192 and _lib.SpQueue.head.offset == 248
     for macro in ("SP_GN_SEG_FLOATS", "SP_GNA_SEG_FLOATS", "SP_PHASE_ADAM", "SP_VERDICT_SEGMENTS", "SP_VERDICT_SEGMENT_POINTS", "SP_VERDICT_MIN_SEGMENTS"):
@@ -489,5 +489,5 @@ def test_schedule_lays_out_three_attempts_and_picks_the_damping_from_the_segment
     # only the third attempt (no second): it still joins, and the verdict's thresholds are the documented ones
     s4 = pb.PairBatch.schedule(fake, **dict(kw, retry_phases=None))
     assert (s4.entry, s4.retry_entry, s4.retry2_entry) == (n2, -1, 0) and s4.phase[n2 - 1].next == n2 + 4
-    assert pb.VERDICT_DEFAULTS["seg_mean_ratio"] == 1.3 and pb.VERDICT_DEFAULTS["seg_max_ratio"] == 8.0
+    assert pb.VERDICT_DEFAULTS["seg_mean_ratio"] == 1.3 and pb.VERDICT_DEFAULTS["seg_max_ratio"] == 8.0 and pb.VERDICT_DEFAULTS["seg_product"] == 0.9
     assert pb.VERDICT_DEFAULTS["retry_on"] & _lib.SP_STATUS_SEGMENTS

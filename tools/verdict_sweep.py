@@ -71,11 +71,18 @@ def _render(a):
     return synth.make_pair(H, W, a[2], seed=a[0], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
 
 
-def errors(P, K, poses_gt, klds_gt):
-    """(n, 3): rotation [rad], translation [max abs, scale gauge removed], depth [max relative] against the ground truth."""
+observable_segments = synth.observable_segments
+
+
+def errors(P, K, poses_gt, klds_gt, observable=None):
+    """(n, 3): rotation [rad], translation [max abs, scale gauge removed], depth [max relative over the segments the target frame sees]
+    against the ground truth."""
     out = np.zeros((len(P), 3))
     for m in range(len(P)):
         gt_T, gt_k = poses_gt[m], klds_gt[m]
+        if observable is not None:
+            gt_k, Km = gt_k[observable[m]], K[m][observable[m]]
+            K = list(K); K[m] = Km
         ls = float(np.mean(gt_k - K[m]))
         Rm = P[m][:3, :3].T @ gt_T[:3, :3]
         out[m] = (float(np.arctan2(0.5 * np.linalg.norm([Rm[2, 1] - Rm[1, 2], Rm[0, 2] - Rm[2, 0], Rm[1, 0] - Rm[0, 1]]), 0.5 * (np.trace(Rm) - 1))),
@@ -93,6 +100,8 @@ def main(argv=None):
     ap.add_argument("--npz", default=None)
     ap.add_argument("--segments", type=int, default=N, help="segments per keyframe (bench.py --segments)")
     ap.add_argument("--alone", default="105,1380,1482", help="pairs also run as batches of ONE (order independence of the verdict and the retry)")
+    ap.add_argument("--seed0", type=int, default=5000, help="first scene seed (5000 = bench.py's scenes, what the schedule and the verdict's thresholds were "
+                                                            "tuned on; any other value = HELD-OUT scenes)")
     ap.add_argument("--streams", type=int, default=1, help="run_scheduled(streams=...): groups of slots on their own HIP streams, one queue")
     ap.add_argument("--verdict", default="", help="overrides of VERDICT_DEFAULTS, e.g. seg_max_ratio=4,seg_mean_ratio=1.3,cost_outlier=0")
     ap.add_argument("--only-batches", default="", help="comma list of batch indices to run (the others are skipped): the known hard starts' batches")
@@ -100,8 +109,8 @@ def main(argv=None):
     dev = torch.device("cuda:0")
     t0 = time.time()
     with Pool(min(G, 8)) as pool:
-        scenes = pool.map(_render, [(5000 + s, args.shape, args.segments) for s in range(G)])
-    print(f"rendered {G} scenes ({args.shape}) in {time.time() - t0:.1f} s", flush=True)
+        scenes = pool.map(_render, [(args.seed0 + s, args.shape, args.segments) for s in range(G)])
+    print(f"rendered {G} scenes ({args.shape}, seeds {args.seed0} .. {args.seed0 + G - 1}{'' if args.seed0 == 5000 else ': HELD OUT -- not the scenes anything was tuned on'}) in {time.time() - t0:.1f} s", flush=True)
     rng = np.random.default_rng(77)
     n_batches = -(-args.starts // args.batch)
     total = n_batches * args.batch
@@ -113,6 +122,8 @@ def main(argv=None):
             else:
                 poses.append((p.pose_gt.astype(np.float64) @ synth.se3_exp_np(0.05 * rng.standard_normal(6))).astype(np.float32))
                 klds.append(np.log(2.0 + 2.0 * rng.uniform(size=p.N)).astype(np.float32))
+    seen = [observable_segments(p) for p in scenes]
+    print("segments the target frame does not see (left out of the depth error): " + ", ".join(f"scene {args.seed0 + i}: {int((~o).sum())} of {len(o)}" for i, o in enumerate(seen)), flush=True)
     poses_gt = [scenes[m % G].pose_gt.astype(np.float64) for m in range(total)]
     klds_gt = [scenes[m % G].kld_gt.astype(np.float64) for m in range(total)]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -141,7 +152,7 @@ def main(argv=None):
                 dt = time.perf_counter() - t1
             P, K = batch.poses().double().cpu().numpy(), [k.double().cpu().numpy() for k in batch.klds()]
             k = keep[v]
-            k["err"].append(errors(P, K, poses_gt[lo: lo + args.batch], klds_gt[lo: lo + args.batch]))
+            k["err"].append(errors(P, K, poses_gt[lo: lo + args.batch], klds_gt[lo: lo + args.batch], [seen[(lo + i) % G] for i in range(args.batch)]))
             k["status"].append(batch.status.cpu().numpy().copy()); k["diag"].append(batch.diag.cpu().numpy().copy())
             k["attempts"].append(batch.attempts.cpu().numpy().copy())
             k["kld"].extend(K)
@@ -195,9 +206,11 @@ def main(argv=None):
             r_max, r_mean = dg[:, 7] / np.maximum(dg[:, 6], 1e-30), dg[:, 0] / np.maximum(dg[:, 6], 1e-30)
             good = judged & conv & ~flagged
             q = lambda a: "p50 %.2f p99 %.2f p99.9 %.2f p99.99 %.2f max %.2f" % tuple(np.percentile(a, [50, 99, 99.9, 99.99, 100])) if len(a) else "--"
-            print(f"   segment costs, converged unflagged pairs ({int(good.sum())}): worst / median {q(r_max[good])}; cost / median {q(r_mean[good])}\n"
+            score = (r_mean - 1.0) * r_max
+            print(f"   segment costs, converged unflagged pairs ({int(good.sum())}): worst / median {q(r_max[good])}; cost / median {q(r_mean[good])}; "
+                  f"(cost / median - 1) x (worst / median) {q(score[good])}\n"
                   f"   ... pairs that END away from the ground truth ({int((judged & miss).sum())}): worst / median {np.sort(r_max[judged & miss])[:16].round(2).tolist()}; "
-                  f"cost / median {np.sort(r_mean[judged & miss])[:16].round(2).tolist()}", flush=True)
+                  f"cost / median {np.sort(r_mean[judged & miss])[:16].round(2).tolist()}; product {np.sort(score[judged & miss])[:16].round(2).tolist()}", flush=True)
         kl = k["kld"]
         for m in list(silent[:8]) + list(np.nonzero(flagged & ~miss)[0][:4]):
             sc = scenes[m % G]
