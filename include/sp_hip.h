@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 13
+#define SP_ABI_VERSION 14
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -744,6 +744,83 @@ int sp_kth_mask_pixel(const uint8_t* masks, const int32_t* row_off, int K, int H
  * inv(pose_src) pose_trg in degrees}. */
 int sp_kf_criterion(const float* depth, int n, float thresh, const float* pose_src, const float* pose_trg, float* out,
                     void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * ONE CALL PER FRAME of the monocular-odometry chain (ABI 14; BASELINE configs[2] as a sequence).  The reference's driver loop
+ * (odometery/odometery.py:1018-1075) does, for every frame that is not a keyframe: track_frame against the latest keyframe (:323-449),
+ * mapping(mode='supp') -- the latest keyframe's depths against its two running supporting frames (:1038-1042) -- and is_kf (:986-1016:
+ * the keyframe's depth rendered in the tracked pose, validity ratio / scaled translation).  Behind Gauss-Newton windows that are built
+ * once per keyframe (sp_window_gn_run) the interpreter between those steps -- three dozen small tensor operations, node arrays read back
+ * and re-uploaded, a host synchronisation per step -- costs more than the kernels.  sp_chain_step runs the stages named in `stages` with
+ * ALL state on the device -- poses, affine pairs and depths are read from and written to device buffers the caller names -- and the only
+ * values that reach the host are the windows' 16-float LM states (the polls of sp_window_gn_run) and the 4 floats of the criterion.
+ *   SP_CHAIN_TRACK     : pyramid of `image` (sp_blur_decimate) packed (sp_pack_rgb) into the tracker's target buffers; the target node's
+ *                        pose / affine pair <- track_target.pose / .aff, tangents and moments cleared, edges recomposed; fresh LM state; the
+ *                        phases of `track`; out_pose <- renormalise_se3(the node's pose) (lie/lie_algebra.py:41-47), out_aff <- its pair
+ *   SP_CHAIN_SUPP      : (supp_images bit 0) the packed levels of supp_target[1] move to supp_target[0]; (bit 1) the tracker's packed levels
+ *                        are copied into supp_target[1]; both nodes <- their pose / aff; fresh LM state; the phases of `supp`; then
+ *                        kld_n floats kld_src -> kld_dst (the mapped depths into the tracker's block)
+ *   SP_CHAIN_CRITERION : rel <- inv(out_pose) kf_pose; sp_depth_splat of the keyframe under rel into depth_out; sp_kf_criterion(depth_out,
+ *                        out_pose, kf_pose) -> crit (device) -> crit_host (pinned), and this stream is synchronised
+ * Stages run in that order on `stream`.  The struct lives in HOST memory; iterations the phases took are written back to track_iters /
+ * supp_iters.  Returns 0, SP_EINVAL, or what the stage's own entry point returned.
+ * ---------------------------------------------------------------------------------------------------- */
+#define SP_CHAIN_LEVELS 4
+#define SP_CHAIN_PHASES 6
+#define SP_CHAIN_TRACK 1
+#define SP_CHAIN_SUPP 2
+#define SP_CHAIN_CRITERION 4
+typedef struct SpChainPhase {
+    int32_t level;                     /* pyramid level (index into SpChainWindow.gn) */
+    int32_t max_iters;
+    float irls_eps, conv_tol;
+} SpChainPhase;                        /* 16 bytes */
+typedef struct SpChainWindow {         /* a built window with its Gauss-Newton schedule */
+    SpWindowGn gn[SP_CHAIN_LEVELS];    /* the window at pyramid level l (pairs == NULL: the window has no descriptors there) */
+    SpChainPhase phase[SP_CHAIN_PHASES];
+    int32_t n_phases;
+    int32_t check_every;               /* sp_window_gn_run's */
+    int32_t flags;                     /* sp_window_gn_step's (bit 1: predicted exit) */
+    float lam0;                        /* LM damping every frame starts from */
+    float lm_up, lm_down, lm_min;
+    int32_t pad_;
+    float* state_host;                 /* host, pinned: 16 floats */
+} SpChainWindow;                       /* 680 bytes */
+typedef struct SpChainTarget {         /* a target node whose frame the step replaces */
+    float* packed[SP_CHAIN_LEVELS];    /* the node's packed (H_l, W_l, 3) image at pyramid level l, where the window has that level */
+    const float* pose;                 /* 16 floats: the node's new camera-to-world pose */
+    const float* aff;                  /* 2 floats, or NULL (no affine compensation) */
+    int32_t node;
+    int32_t pad_;
+} SpChainTarget;                       /* 56 bytes */
+typedef struct SpChainStep {
+    int32_t stages;
+    int32_t H, W, n_levels;            /* the frame; pyramid levels to build (level 0 = the image itself) */
+    const float* image;                /* planar (3,H,W) */
+    float* level[SP_CHAIN_LEVELS];     /* planar scratch of levels 1 .. n_levels - 1 ([0] unused) */
+    SpChainWindow track;
+    SpChainTarget track_target;
+    float* out_pose;                   /* 16 floats */
+    float* out_aff;                    /* 2 floats or NULL */
+    SpChainWindow supp;
+    SpChainTarget supp_target[2];      /* the latest keyframe's two running supporting frames, older first */
+    int32_t supp_images;               /* bit 0: slot 1 -> slot 0; bit 1: this frame -> slot 1 */
+    int32_t kld_n;
+    const float* kld_src;
+    float* kld_dst;
+    /* the keyframe the criterion renders (sp_depth_splat's arguments) */
+    const uint32_t* pix; const float* baseL; const int32_t* seg_off; const float* kp_L; const float* kld;
+    const float* K; const float* kf_pose;
+    int32_t N, P;
+    unsigned long long* keys; float* depth_out;
+    float* rel_pose;                   /* 16 floats scratch */
+    float* crit;                       /* 4 floats */
+    float* crit_host;                  /* host, pinned: 4 floats */
+    float valid_thresh;
+    int32_t track_iters, supp_iters;   /* out (host) */
+    int32_t pad_;
+} SpChainStep;
+int sp_chain_step(SpChainStep* step, void* stream);
 
 #ifdef __cplusplus
 }

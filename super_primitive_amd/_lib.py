@@ -66,6 +66,7 @@ SIGNATURES = {
     "sp_depth_accumulate": [P, P, P, P, P, P, I, I, I, I, P, P],
     "sp_depth_average_finish": [P, I, I, P, P, P],
     "sp_kf_criterion": [P, I, F, P, P, P, P],
+    "sp_chain_step": [P, P],
     "sp_se3_retract": [P, P, I, P, P, P, P],
     "sp_renormalise_se3": [P, I, P],
     "sp_depth_discontinuity": [P, P, I, I, I, I, F, P, P, P, P],
@@ -75,7 +76,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 13
+SP_ABI_VERSION = 14
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GNA_PARTIAL_FLOATS = 48
@@ -183,6 +184,38 @@ class SpWindowGn(ctypes.Structure):
                 ("span_partials", c_void_p), ("seg_partials", c_void_p), ("scratch", c_void_p), ("nodes_backup", c_void_p), ("kld_backup", c_void_p),
                 ("state", c_void_p), ("losses", c_void_p), ("n_spans", c_int), ("n_edges", c_int), ("n_nodes", c_int), ("n_blocks", c_int),
                 ("sum_N", c_int), ("max_N", c_int), ("n_unknowns", c_int), ("max_losses", c_int)]
+
+
+SP_CHAIN_LEVELS, SP_CHAIN_PHASES = 4, 6
+SP_CHAIN_TRACK, SP_CHAIN_SUPP, SP_CHAIN_CRITERION = 1, 2, 4
+
+
+class SpChainPhase(ctypes.Structure):
+    _fields_ = [("level", c_int), ("max_iters", c_int), ("irls_eps", c_float), ("conv_tol", c_float)]
+
+
+class SpChainWindow(ctypes.Structure):
+    """Mirror of ``struct SpChainWindow`` (include/sp_hip.h): a built window with its Gauss-Newton schedule; 680 bytes."""
+    _fields_ = [("gn", SpWindowGn * SP_CHAIN_LEVELS), ("phase", SpChainPhase * SP_CHAIN_PHASES), ("n_phases", c_int), ("check_every", c_int),
+                ("flags", c_int), ("lam0", c_float), ("lm_up", c_float), ("lm_down", c_float), ("lm_min", c_float), ("pad_", c_int),
+                ("state_host", c_void_p)]
+
+
+class SpChainTarget(ctypes.Structure):
+    """Mirror of ``struct SpChainTarget``; 56 bytes."""
+    _fields_ = [("packed", c_void_p * SP_CHAIN_LEVELS), ("pose", c_void_p), ("aff", c_void_p), ("node", c_int), ("pad_", c_int)]
+
+
+class SpChainStep(ctypes.Structure):
+    """Mirror of ``struct SpChainStep`` (include/sp_hip.h): the arguments of one frame of the odometry chain."""
+    _fields_ = [("stages", c_int), ("H", c_int), ("W", c_int), ("n_levels", c_int), ("image", c_void_p), ("level", c_void_p * SP_CHAIN_LEVELS),
+                ("track", SpChainWindow), ("track_target", SpChainTarget), ("out_pose", c_void_p), ("out_aff", c_void_p),
+                ("supp", SpChainWindow), ("supp_target", SpChainTarget * 2), ("supp_images", c_int), ("kld_n", c_int), ("kld_src", c_void_p),
+                ("kld_dst", c_void_p),
+                ("pix", c_void_p), ("baseL", c_void_p), ("seg_off", c_void_p), ("kp_L", c_void_p), ("kld", c_void_p), ("K", c_void_p),
+                ("kf_pose", c_void_p), ("N", c_int), ("P", c_int), ("keys", c_void_p), ("depth_out", c_void_p), ("rel_pose", c_void_p),
+                ("crit", c_void_p), ("crit_host", c_void_p), ("valid_thresh", c_float), ("track_iters", c_int), ("supp_iters", c_int),
+                ("pad_", c_int)]
 
 
 class SpWindowNode(ctypes.Structure):

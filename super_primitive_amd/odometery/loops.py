@@ -260,22 +260,51 @@ class GnSuppMapper:
     points under the depths the window was built with; tests/test_gpu_sequence.py)."""
 
     def __init__(self, kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, window_size=5, gn_schedule=None):
-        assert len(supp[-1]) == 2, "built once the latest keyframe has its two running supporting frames"
+        """``supp[-1]``: the latest keyframe's running supporting frames -- two, or ONE (the first frame after a keyframe or after a scheduled
+        mapping has emptied the pool, odometery.py:1046-1055): the window is built with two slots either way; with one running frame both
+        slots hold it and the first slot's edge carries weight ZERO, the others 1 / (targets - 1) -- the sums of the one-frame window
+        with an exact zero added (``edges_one``)."""
+        assert len(supp[-1]) in (1, 2), "built once the latest keyframe has a running supporting frame"
         self.K = K = len(kfs)
         self.affine = kf_affs is not None
         self.gn = dict(MAP_GN_SCHEDULE, **(gn_schedule or {}))
         self.num_iters = int(num_iters)
-        self.win, self.supp_node, src_ids = _build_map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, 1e-4, K == window_size, self.affine, True,
+        rows = list(supp[:-1]) + [list(supp[-1]) * (3 - len(supp[-1]))]
+        self.win, self.supp_node, src_ids = _build_map_window(kfs, kf_poses, kf_klds, kf_affs, rows, num_iters, 1e-4, K == window_size, self.affine, True,
                                                               1e-8, 'supp', self.gn)
         assert src_ids == [K - 1]
         self.slots = [self.supp_node[(K - 1, 0)], self.supp_node[(K - 1, 1)]]
-        self.frames = [supp[-1][0][0], supp[-1][1][0]]               # the frame objects whose images sit in the slots
+        self.frames = [rows[-1][0][0], rows[-1][1][0]]               # the frame objects whose images sit in the slots
+        # the edge records for ONE running frame: same graph, the first slot's edge switched off
+        win = self.win
+        E = win.n_edges
+        w = win.edges.clone().view(torch.float32).reshape(E, 4)
+        idle = [e for e, (_, node, _, _) in enumerate(win.edge_list) if node == self.slots[0]]
+        assert len(idle) == 1 and E >= 2
+        w[:, 3] = 1.0 / (E - 1)
+        w[idle[0], 3] = 0.0
+        self.edges_two, self.edges_one = win.edges, w.reshape(-1).view(torch.uint8)
+
+    def refresh(self, kf_poses, kf_klds, kf_affs, supp):
+        """After a mapping that moved keyframes / stored supporting frames (``mapping(mode='map')``): their poses, affine pairs and the
+        latest keyframe's depths into the window (the graph -- which frames support which keyframe -- is unchanged until the next keyframe)."""
+        up = {k: dict(T=kf_poses[k], aff=kf_affs[k] if self.affine else None) for k in range(self.K)}
+        for (k, j), node in self.supp_node.items():
+            if k < self.K - 1:
+                up[node] = dict(T=supp[k][j][1], aff=supp[k][j][2] if self.affine else None)
+        self.win.set_nodes(up)
+        self.win.set_klds([kf_klds[-1]])
 
     def __call__(self, running):
-        """running: the latest keyframe's two running supporting frames [(frame, pose, aff)], older first.  Returns (the latest keyframe's
-        new log-depths, losses, iterations)."""
+        """running: the latest keyframe's running supporting frames [(frame, pose, aff)], older first (two, or one).  Returns (the latest
+        keyframe's new log-depths, losses, iterations)."""
         win, gn = self.win, self.gn
-        assert len(running) == 2
+        assert len(running) in (1, 2)
+        if len(running) == 1:
+            running = [running[0], running[0]]
+            win.edges = self.edges_one
+        else:
+            win.edges = self.edges_two
         if running[0][0] is self.frames[1] and running[1][0] is not self.frames[1]:
             win.copy_target_image(self.slots[0], self.slots[1])      # yesterday's newest frame is today's older one
             self.frames[0] = self.frames[1]

@@ -38,7 +38,8 @@ from .loops import GnSuppMapper, GnTracker, map_window, track_frame_fused, track
 # config/tum/odom_desk.yaml (aligment.track / aligment.mapping / kf / window_size)
 DEFAULTS = dict(track_steps=(0, 0, 300), track_levels=(0, 3), track_lr=5e-3, map_steps=500, continual_steps=10, init_steps=1000,
                 map_lr_pose=1e-4, window_size=5, supp_every_n=3, depth_validity_ratio=0.60, translation_thresh=0.2,
-                affine_compensation=True, mono_init=False, init_frames=7, motion_prior=False, persistent_supp=True, map_rel_tol=1e-8)
+                affine_compensation=True, mono_init=False, init_frames=7, motion_prior=False, persistent_supp=True, map_rel_tol=1e-8,
+                native_step=True)
 
 
 class _Supp:
@@ -69,6 +70,10 @@ class MonoVO:
         self.tracker = None                   # (Gauss-Newton engine: one window per keyframe, re-used for every frame tracked against it)
         self.supp_mapper = None               # (... and one window per latest keyframe for the supplementary mapping after every frame)
         self.current_aff = torch.zeros(2, device=self.dev)
+        # engine 'gn': one foreign call per frame (sp_chain_step; odometery/chain.py) instead of the Python steps below -- same stages, same
+        # arithmetic, the state on the device.  ``native_step=False`` keeps the step-by-step path (the two are compared in tests/test_gpu_sequence.py)
+        self.chain = None
+        self.native = bool(self.c['native_step']) and engine == "gn" and not self.c['motion_prior'] and self.dev.type == "cuda"
         self.add_kf(to_keyframe(0), pose0.clone(), kld0.clone(), 0, self.current_aff.clone())
         self.update_track_pose('init')
         self.track = [pose0.clone()]
@@ -166,9 +171,10 @@ class MonoVO:
         rows = [(self.curr_supp if k == K - 1 else self.supp_opt[k]) if self.initialised else [] for k in range(K)]
         supp = [[(s.frame, s.pose, s.aff) for s in row] for row in rows]
         lr_pose = 1e-2 if (mode == 'init' and c['mono_init']) else c['map_lr_pose']
-        if mode == 'supp' and self.engine == "gn" and c['persistent_supp'] and self.initialised and len(self.curr_supp) == 2:
-            # the supplementary mapping between two keyframes is the same window every frame but for the two running supporting frames:
-            # ONE window per latest keyframe, re-pointed in place (loops.GnSuppMapper) -- same arithmetic, same result as the branch below
+        if mode == 'supp' and self.engine == "gn" and c['persistent_supp'] and self.initialised and len(self.curr_supp) in (1, 2):
+            # the supplementary mapping between two keyframes is the same window every frame but for the running supporting frames (two; one
+            # right after a keyframe or a scheduled mapping): ONE window per latest keyframe, re-pointed in place (loops.GnSuppMapper) --
+            # same arithmetic, same result as the branch below
             torch.cuda.synchronize(); t0 = time.perf_counter()
             if self.supp_mapper is None:
                 self.supp_mapper = GnSuppMapper(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, supp, num_iters,
@@ -181,7 +187,10 @@ class MonoVO:
                 self.tracker.update_keyframe(self.kf_klds[-1])
             self.update_track_pose(mode)
             return
-        self.supp_mapper = None                                   # (whatever follows moves poses / depths the persistent window holds)
+        # (whatever follows moves poses / depths the persistent window holds: a scheduled mapping leaves its GRAPH as it is -- the window is
+        #  refreshed with the mapped values below; anything else drops it)
+        keep_mapper = self.supp_mapper if mode == 'map' and c['persistent_supp'] else None
+        self.supp_mapper = None
         torch.cuda.synchronize(); t0 = time.perf_counter()
         out = map_window(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, supp, num_iters, lr_pose=lr_pose,
                          window_size=c['window_size'], initialised=self.initialised, optimiser="gn" if self.engine == "gn" else "adam", mode=mode,
@@ -202,6 +211,10 @@ class MonoVO:
                     if self.affine:
                         s.aff = out['supp_affs'][k][j].clone()
         self.n_map[mode] += 1
+        if keep_mapper is not None and keep_mapper.K == K:
+            keep_mapper.refresh(self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None,
+                                [[(s.frame, s.pose, s.aff) for s in self.supp_opt[k]] for k in range(K)])
+            self.supp_mapper = keep_mapper
         if self.tracker is not None:                              # the latest keyframe moved
             self.tracker.update_keyframe(self.kf_klds[-1], self.kf_poses[-1], self.kf_affs[-1] if self.affine else None)
         if self.log is not None and mode != 'supp':
@@ -245,6 +258,8 @@ class MonoVO:
     # ---- the driver loop (odometery.py:1018-1075) -----------------------------------------------------------------------
     def step(self, i):
         c = self.c
+        if self.native and self.initialised:
+            return self._step_native(i)
         self.track_frame(i)
         if self.initialised and c['continual_steps'] > 0:
             self.mapping(c['continual_steps'], mode='supp')
@@ -255,6 +270,90 @@ class MonoVO:
             self.reset_running_supp_kfs()
         assert self.current_ts == i
         self.keyframe_stage(i)
+
+    def _step_native(self, i):
+        """``step`` with the per-frame stages in ONE foreign call (``sp_chain_step``): tracking, the supplementary mapping against the two
+        running supporting frames and the keyframe criterion, all on the device.  What stays in Python is what happens once per keyframe:
+        building the windows, the scheduled mapping, the new keyframe."""
+        from .chain import CRITERION, SUPP, TRACK, ChainStep
+        c, f = self.c, self.frames[i]
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        if self.chain is None:
+            H, W = f.image.shape[-2:]
+            self.chain = ChainStep(len(self.frames), H, W, c['track_levels'][1], self.dev)
+        ch = self.chain
+        aff_kf = self.kf_affs[-1] if self.affine else None
+        if self.tracker is None:
+            self.tracker = GnTracker(self.kfs[-1], self.kf_klds[-1], self.kf_poses[-1], f, c['track_levels'], kf_aff=aff_kf)
+        if ch.tracker is not self.tracker:
+            ch.bind_tracker(self.tracker, self.kfs[-1], self.affine)
+        want_supp = c['continual_steps'] > 0
+        native_supp = want_supp and c['persistent_supp']
+        images, prev = 0, (self.tracked[-1] if self.tracked else None)      # (no ``prev``: this frame is the keyframe's only running supporting frame)
+        if native_supp:
+            if self.supp_mapper is None:
+                # the window of the supplementary mapping, built with the running frames in its slots (their poses are overwritten by the call)
+                K = len(self.kfs)
+                rows = [[(s.frame, s.pose, s.aff) for s in self.supp_opt[k]] for k in range(K - 1)]
+                rows.append(([(prev.frame, prev.pose, prev.aff)] if prev is not None else []) + [(f, self.current_track, self.current_aff)])
+                self.supp_mapper = GnSuppMapper(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, rows, c['continual_steps'],
+                                                window_size=c['window_size'])
+            m = self.supp_mapper
+            if ch.mapper is not m:
+                ch.bind_mapper(m)
+            if prev is None:
+                images = 0 if m.frames[1] is f else 2                # (slot 0's edge is switched off: whatever frame sits there)
+                m.frames[1] = f
+            else:
+                if m.frames[0] is prev.frame and m.frames[1] is f:
+                    images = 0
+                elif m.frames[1] is prev.frame:
+                    images = 3                                       # yesterday's newest frame moves to slot 0, this frame into slot 1
+                else:
+                    m.win.set_target_image(m.slots[0], prev.frame.image)
+                    images = 2
+                m.frames = [prev.frame, f]
+        map_now = self.mapping_scheduled                                  # (mapping(mode='map') may move the keyframe before the criterion looks at it)
+        stages = TRACK | (SUPP if native_supp else 0) | (CRITERION if (native_supp or not want_supp) and not map_now else 0)
+        _, _, crit = ch.run(stages, i=i, image=f.image, start_pose=self.current_track, start_aff=self.current_aff if self.affine else None,
+                            prev=(prev.ts if prev is not None else i) if native_supp else None, supp_images=images, supp_one=prev is None)
+        self.secs['track'] += time.perf_counter() - t0
+        # ---- the bookkeeping of track_frame (:323-449) ...
+        self.current_track = ch.hist_pose[i]
+        if self.affine:
+            self.current_aff = ch.hist_aff[i]
+        self.current_ts = i
+        self.tracked.append(_Supp(f, self.current_track, self.current_aff, i))
+        self.track.append(self.current_track)
+        # ---- ... and of mapping(mode='supp') (:1038-1042)
+        if native_supp:
+            self.tracked_poses_to_supp()
+            self.kf_klds[-1] = self.supp_mapper.win.kld.clone()
+            self.n_map['supp'] += 1
+            self.update_track_pose('supp')
+        elif want_supp:
+            self.mapping(c['continual_steps'], mode='supp')
+        if self.mapping_scheduled and len(self.curr_supp) >= 2:
+            self.mapping(c['map_steps'], mode='map')
+            self.mapping_scheduled = False
+            self.reset_tracked_poses()
+            self.reset_running_supp_kfs()
+        assert self.current_ts == i
+        t0 = time.perf_counter()
+        if crit is None:
+            if ch.tracker is not self.tracker:                            # (cannot happen: mapping keeps the tracker; guards the binding)
+                ch.bind_tracker(self.tracker, self.kfs[-1], self.affine)
+            _, _, crit = ch.run(CRITERION, pose=self.current_track)
+        new_kf = crit[0] < c['depth_validity_ratio'] or crit[2] > c['translation_thresh']
+        if new_kf:
+            self.flush_tracked_poses_to_supp()
+            self.init_keyframe(i, (ch.depth, crit))
+            self.reset_tracked_poses()
+            self.reset_running_supp_kfs()
+            torch.cuda.synchronize()
+            self.mapping_scheduled = True
+        self.secs['keyframe'] += time.perf_counter() - t0
+        return new_kf, crit
 
     def keyframe_stage(self, i):
         """The tail of one pass of the driver loop (odometery.py:1056-1075): keyframe decision, creation, what it schedules.  Returns

@@ -424,3 +424,28 @@ def test_persistent_supplementary_mapping_window_equals_a_rebuilt_one():
           f"chain {(n - 1) / sum(sa.values()):.0f} -> {(n - 1) / sum(sb.values()):.0f} frames/s; largest differences: tracked poses {dp[0]:.1e}, keyframe poses {dp[1]:.1e}, "
           f"log-depths {dk:.1e}")
     # (the timing is a printed diagnostic, not an assertion: ADVICE r05; what the persistent window must do is give the same chain)
+
+
+def test_one_call_per_frame_gives_the_chain_of_the_python_steps():
+    """``sp_chain_step`` (include/sp_hip.h; odometery/chain.py) -- tracking, the supplementary mapping against the two
+    running supporting frames and the keyframe criterion of one frame as ONE foreign call with the state on the device -- against the
+    step-by-step Python driver (``native_step=False``: ``GnTracker.track`` -> ``GnSuppMapper`` -> ``is_kf``, odometery/odometery.py:1018-1075):
+    the same launches in the same order on the same data, so the same chain -- keyframe decisions, supporting frames, iteration for
+    iteration -- with poses and depths equal to the round-off of inv(T) T' (one kernel here, three torch launches there)."""
+    from super_primitive_amd.odometery.sequence import run_sequence
+    n = 40
+    seq, frames, to_kf = make_sequence_inputs(n, rot_scale=0.3)
+    run_sequence(frames[:4], to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn")
+    outs = {}
+    for native in (False, True):
+        outs[native] = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn", translation_thresh=0.095, window_size=5,
+                                    depth_of=lambda i: T(seq[i].kld_gt), native_step=native)
+    a, b = outs[False], outs[True]
+    assert a["all_kf_ids"] == b["all_kf_ids"] and a["supp_ids"] == b["supp_ids"], (a["all_kf_ids"], b["all_kf_ids"])
+    assert a["n_supp_mappings"] == b["n_supp_mappings"] == n - 1 and a["n_mappings"] == b["n_mappings"]
+    dp = float((a["track_poses"] - b["track_poses"]).abs().max()), float((a["kf_poses"] - b["kf_poses"]).abs().max())
+    dk = max(float((x - y).abs().max()) for x, y in zip(a["kf_klds"], b["kf_klds"]))
+    sa, sb = a["seconds"], b["seconds"]
+    print(f"\nchain of {n} frames: python steps {(n - 1) / sum(sa.values()):.0f} frames/s, one call per frame {(n - 1) / sum(sb.values()):.0f} frames/s; "
+          f"largest differences: tracked poses {dp[0]:.1e}, keyframe poses {dp[1]:.1e}, log-depths {dk:.1e}")
+    assert dp[0] <= 5e-6 and dp[1] <= 5e-6 and dk <= 5e-5, (dp, dk)

@@ -13,6 +13,10 @@ kw = dict(engine="gn", translation_thresh=0.095, window_size=5, depth_of=lambda 
 run_sequence(frames[:4], to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn")
 run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **kw)
 out = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **kw)
+for native in (False, True):
+    o = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **dict(kw, native_step=native))
+    o = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **dict(kw, native_step=native))
+    print(f"native_step={native}: stages [ms per frame]:", {k: round(1e3 * v / (n - 1), 3) for k, v in o["seconds"].items()}, "chain", round((n - 1) / sum(o["seconds"].values())), "frames/s")
 sec = out["seconds"]
 print("stages [ms per frame]:", {k: round(1e3 * v / (n - 1), 3) for k, v in sec.items()}, "chain", round((n - 1) / sum(sec.values())), "frames/s")
 pr = cProfile.Profile()

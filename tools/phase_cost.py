@@ -33,8 +33,11 @@ batch = PairBatch(src, [t(p.trg_image) for p in scenes], [t(p.K) for p in scenes
 sync = torch.cuda.synchronize
 IT = 16
 print(f"{M} resident pairs ({args.shape}); per phase: {IT} iterations of every pair, no convergence test")
+ONLY = os.environ.get("SP_PHASES", "")
 for name, spec in (("pose-only L2 stride 4", dict(level=2, stride=4, pose_only=True)), ("joint L2 stride 4", dict(level=2, stride=4)), ("joint L1 stride 2", dict(level=1, stride=2)),
                    ("joint L0 stride 2", dict(level=0, stride=2)), ("polish L0 all points", dict(level=0, stride=1)), ("Adam L2 stride 4", dict(level=2, stride=4, adam=True))):
+    if ONLY and not any(k in name for k in ONLY.split(",")):
+        continue
     ph = dict(spec, max_iters=IT, irls_eps=1e-3, conv_tol=0.0)
     lay = batch.coarse[(ph["level"], ph["stride"])] if ph["stride"] > 1 else None
     pts = np.asarray(lay.points if lay is not None else batch.Ps, dtype=np.float64)
@@ -46,7 +49,7 @@ for name, spec in (("pose-only L2 stride 4", dict(level=2, stride=4, pose_only=T
             sync(); t0 = time.perf_counter()
             rounds = batch.run_scheduled(phases=[ph], verdict=False, check_every=8, **kw)
             sync(); dt = time.perf_counter() - t0
-        print(f"  {name:24s} {how:22s}: {1e6 * dt / (M * IT):7.3f} us per pair-iteration, {rounds} rounds; {pts.mean():9.0f} points, {nbytes / M / 1e6:6.2f} MB per pair-iteration "
+        print(f"  {name:24s} {how:22s} [{(lay.n_spans if lay is not None else batch.n_spans)} spans]: {1e6 * dt / (M * IT):7.3f} us per pair-iteration, {rounds} rounds; {pts.mean():9.0f} points, {nbytes / M / 1e6:6.2f} MB per pair-iteration "
               f"-> {nbytes * IT / dt / 1e12:5.2f} TB/s = {nbytes * IT / dt / 8e12:5.3f} of HBM; {1e12 * dt / (IT * pts.sum()):6.2f} ps per point", flush=True)
 kw = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
 for slots in (768, 384):
