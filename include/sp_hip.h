@@ -595,6 +595,8 @@ int sp_window_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edges, 
  * latest keyframe's depths are free).  flags bit 0: pose-only step (all depth blocks treated as frozen); bit 1 (ABI 13): PREDICTED EXIT --
  * with conv_tol > 0 the window also freezes right after a step that is predicted to buy less than conv_tol of the loss (the first-order
  * change b . delta along the step; lambda <= 1e-2 only), without the evaluation that would confirm it: see SP_PHASE_PREDICTED_EXIT.
+ * Bit 2 (ABI 14): the caller's word that NO depth block moves (every SpWindowBlock.lr is 0: frame-to-keyframe tracking) -- like bit 0 the
+ * Schur-term launch is then left out (its terms are all zero): three launches per iteration instead of four.
  * LM: lambda adapts on the device exactly like sp_pairs_gn_step (loss up -> previous step undone from nodes_backup / kld_backup,
  * lambda *= lm_up, re-evaluated next call; loss down -> lambda = max(lambda lm_down, lm_min); a failed factorisation counts as a
  * rejected step: lambda *= lm_up, the same point is evaluated and solved again); conv_tol > 0: an accepted step that
@@ -744,6 +746,11 @@ int sp_kth_mask_pixel(const uint8_t* masks, const int32_t* row_off, int K, int H
  * inv(pose_src) pose_trg in degrees}. */
 int sp_kf_criterion(const float* depth, int n, float thresh, const float* pose_src, const float* pose_trg, float* out,
                     void* stream);
+/* The same four values -- bit for bit -- from a grid of workgroups instead of one (one launch per radix pass; 102 -> 17 us on a 640 x 480
+ * render): ws = sp_kf_criterion_ws_words() uint32 of scratch, any content. */
+int sp_kf_criterion_ws_words(void);
+int sp_kf_criterion_ws(const float* depth, int n, float thresh, const float* pose_src, const float* pose_trg, uint32_t* ws, float* out,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * ONE CALL PER FRAME of the monocular-odometry chain (ABI 14; BASELINE configs[2] as a sequence).  The reference's driver loop
@@ -760,7 +767,7 @@ int sp_kf_criterion(const float* depth, int n, float thresh, const float* pose_s
  *   SP_CHAIN_SUPP      : (supp_images bit 0) the packed levels of supp_target[1] move to supp_target[0]; (bit 1) the tracker's packed levels
  *                        are copied into supp_target[1]; both nodes <- their pose / aff; fresh LM state; the phases of `supp`; then
  *                        kld_n floats kld_src -> kld_dst (the mapped depths into the tracker's block)
- *   SP_CHAIN_CRITERION : rel <- inv(out_pose) kf_pose; sp_depth_splat of the keyframe under rel into depth_out; sp_kf_criterion(depth_out,
+ *   SP_CHAIN_CRITERION : rel <- inv(out_pose) kf_pose; sp_depth_splat of the keyframe under rel into depth_out; sp_kf_criterion_ws(depth_out,
  *                        out_pose, kf_pose) -> crit (device) -> crit_host (pinned), and this stream is synchronised
  * Stages run in that order on `stream`.  The struct lives in HOST memory; iterations the phases took are written back to track_iters /
  * supp_iters.  Returns 0, SP_EINVAL, or what the stage's own entry point returned.
@@ -780,10 +787,11 @@ typedef struct SpChainWindow {         /* a built window with its Gauss-Newton s
     SpChainPhase phase[SP_CHAIN_PHASES];
     int32_t n_phases;
     int32_t check_every;               /* sp_window_gn_run's */
-    int32_t flags;                     /* sp_window_gn_step's (bit 1: predicted exit) */
+    int32_t flags;                     /* sp_window_gn_step's (bit 1: predicted exit, bit 2: no depth block moves) */
     float lam0;                        /* LM damping every frame starts from */
     float lm_up, lm_down, lm_min;
-    int32_t pad_;
+    int32_t check_first;               /* > 0: every phase looks at the state after this many iterations for the first time (a window that
+                                        * usually converges at once -- the supplementary mapping -- should not run check_every iterations blind) */
     float* state_host;                 /* host, pinned: 16 floats */
 } SpChainWindow;                       /* 680 bytes */
 typedef struct SpChainTarget {         /* a target node whose frame the step replaces */
@@ -815,6 +823,7 @@ typedef struct SpChainStep {
     unsigned long long* keys; float* depth_out;
     float* rel_pose;                   /* 16 floats scratch */
     float* crit;                       /* 4 floats */
+    uint32_t* crit_ws;                 /* sp_kf_criterion_ws_words() uint32 of scratch */
     float* crit_host;                  /* host, pinned: 4 floats */
     float valid_thresh;
     int32_t track_iters, supp_iters;   /* out (host) */

@@ -67,6 +67,8 @@ SIGNATURES = {
     "sp_depth_average_finish": [P, I, I, P, P, P],
     "sp_kf_criterion": [P, I, F, P, P, P, P],
     "sp_chain_step": [P, P],
+    "sp_kf_criterion_ws_words": [],
+    "sp_kf_criterion_ws": [P, I, F, P, P, P, P, P],
     "sp_se3_retract": [P, P, I, P, P, P, P],
     "sp_renormalise_se3": [P, I, P],
     "sp_depth_discontinuity": [P, P, I, I, I, I, F, P, P, P, P],
@@ -197,7 +199,7 @@ class SpChainPhase(ctypes.Structure):
 class SpChainWindow(ctypes.Structure):
     """Mirror of ``struct SpChainWindow`` (include/sp_hip.h): a built window with its Gauss-Newton schedule; 680 bytes."""
     _fields_ = [("gn", SpWindowGn * SP_CHAIN_LEVELS), ("phase", SpChainPhase * SP_CHAIN_PHASES), ("n_phases", c_int), ("check_every", c_int),
-                ("flags", c_int), ("lam0", c_float), ("lm_up", c_float), ("lm_down", c_float), ("lm_min", c_float), ("pad_", c_int),
+                ("flags", c_int), ("lam0", c_float), ("lm_up", c_float), ("lm_down", c_float), ("lm_min", c_float), ("check_first", c_int),
                 ("state_host", c_void_p)]
 
 
@@ -214,7 +216,7 @@ class SpChainStep(ctypes.Structure):
                 ("kld_dst", c_void_p),
                 ("pix", c_void_p), ("baseL", c_void_p), ("seg_off", c_void_p), ("kp_L", c_void_p), ("kld", c_void_p), ("K", c_void_p),
                 ("kf_pose", c_void_p), ("N", c_int), ("P", c_int), ("keys", c_void_p), ("depth_out", c_void_p), ("rel_pose", c_void_p),
-                ("crit", c_void_p), ("crit_host", c_void_p), ("valid_thresh", c_float), ("track_iters", c_int), ("supp_iters", c_int),
+                ("crit", c_void_p), ("crit_ws", c_void_p), ("crit_host", c_void_p), ("valid_thresh", c_float), ("track_iters", c_int), ("supp_iters", c_int),
                 ("pad_", c_int)]
 
 

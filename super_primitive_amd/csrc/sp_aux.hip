@@ -323,6 +323,73 @@ __global__ __launch_bounds__(KF_BLOCK) void k_kf_criterion(const float* __restri
     }
 }
 
+// The same four values from a GRID of workgroups (sp_kf_criterion_ws): one launch per radix pass -- every workgroup histograms its slice
+// of the image in LDS and adds it to the pass's global histogram; the workgroup that finishes last picks the digit (and, after the last
+// pass, writes out[]).  ws: KF_WS_WORDS uint32, zeroed by the entry point: [pass * 256 + bin] histograms, then {prefix, k, count, -} and
+// the four passes' tickets.  Exactly k_kf_criterion's selection -- the k-th smallest key -- so the same bits come out.
+constexpr int KF_WS_WORDS = 4 * 256 + 8;
+constexpr int KF_GRID_BLOCK = 256, KF_PER_THREAD = 16;
+__global__ __launch_bounds__(KF_GRID_BLOCK) void k_kf_select_pass(const float* __restrict__ depth, int n, float thresh, int pass, uint32_t* __restrict__ ws,
+                                                                  const float* __restrict__ pose_src, const float* __restrict__ pose_trg,
+                                                                  float* __restrict__ out) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t last;
+    uint32_t* g_hist = ws + pass * 256;
+    uint32_t* st = ws + 4 * 256;                         // [0] prefix, [1] k, [2] count, [4 + pass] ticket
+    const int shift = 24 - 8 * pass;
+    const uint32_t prefix = pass ? st[0] : 0u, mask = pass ? (0xffffffffu << (shift + 8)) : 0u;
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * (KF_GRID_BLOCK * KF_PER_THREAD);
+#pragma unroll 4
+    for (int j = 0; j < KF_PER_THREAD; ++j) {
+        const int i = base + j * KF_GRID_BLOCK + threadIdx.x;
+        if (i < n) {
+            const float v = depth[i];
+            const uint32_t key = __float_as_uint(v);
+            if (v > thresh && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xffu], 1u);
+        }
+    }
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&g_hist[threadIdx.x], hist[threadIdx.x]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&st[4 + pass], 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    hist[threadIdx.x] = __hip_atomic_load(&g_hist[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    uint32_t cnt = st[2], k = st[1];
+    if (pass == 0) {
+        cnt = 0;
+        for (int b = 0; b < 256; ++b) cnt += hist[b];
+        k = cnt ? (cnt - 1u) / 2u : 0u;
+        st[2] = cnt;
+    }
+    uint32_t run = 0; int b = 0;
+    for (; b < 255; ++b) { if (run + hist[b] > k) break; run += hist[b]; }
+    const uint32_t pre = prefix | ((uint32_t)b << shift);
+    st[0] = pre; st[1] = k - run;
+    if (pass != 3) return;
+    const float scale = cnt ? __uint_as_float(pre) : __builtin_nanf("");
+    out[0] = (float)cnt / (float)n;
+    out[1] = scale;
+    const float dx = pose_src[3] - pose_trg[3], dy = pose_src[7] - pose_trg[7], dz = pose_src[11] - pose_trg[11];
+    out[2] = sqrtf(dx * dx + dy * dy + dz * dz) / (scale + 1e-6f);
+    double D[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double a = 0.0;
+            for (int m = 0; m < 3; ++m) a += (double)pose_src[4 * m + i] * (double)pose_trg[4 * m + j];
+            D[3 * i + j] = a;
+        }
+    const double ax = D[7] - D[5], ay = D[2] - D[6], az = D[3] - D[1];
+    const double sn = 0.5 * sqrt(ax * ax + ay * ay + az * az), cs = 0.5 * (D[0] + D[4] + D[8] - 1.0);
+    out[3] = (float)(atan2(sn, cs) * 57.29577951308232);
+}
+
 }  // namespace
 
 extern "C" {
@@ -429,6 +496,22 @@ int sp_kf_criterion(const float* depth, int n, float thresh, const float* pose_s
     hipLaunchKernelGGL(k_kf_criterion, dim3(1), dim3(KF_BLOCK), 0, static_cast<hipStream_t>(stream), depth, n, thresh,
                        pose_src, pose_trg, out);
     SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_kf_criterion_ws_words(void) { return KF_WS_WORDS; }
+
+int sp_kf_criterion_ws(const float* depth, int n, float thresh, const float* pose_src, const float* pose_trg, uint32_t* ws, float* out,
+                       void* stream) {
+    if (!depth || !pose_src || !pose_trg || !out || !ws || n <= 0 || !(thresh >= 0.f)) return SP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = hipMemsetAsync(ws, 0, sizeof(uint32_t) * KF_WS_WORDS, s);
+    if (e != hipSuccess) return (int)e;
+    const int grid = (n + KF_GRID_BLOCK * KF_PER_THREAD - 1) / (KF_GRID_BLOCK * KF_PER_THREAD);
+    for (int pass = 0; pass < 4; ++pass) {
+        hipLaunchKernelGGL(k_kf_select_pass, dim3(grid), dim3(KF_GRID_BLOCK), 0, s, depth, n, thresh, pass, ws, pose_src, pose_trg, out);
+        SP_CHECK_LAUNCH();
+    }
     return 0;
 }
 

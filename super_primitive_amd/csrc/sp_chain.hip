@@ -13,6 +13,9 @@
 
 #define SP_CHAIN_STATE 16   // floats of a window's LM state (sp_window_gn_step)
 
+static_assert(sizeof(SpChainPhase) == 16 && sizeof(SpChainWindow) == 680 && sizeof(SpChainTarget) == 56 && sizeof(SpChainStep) == 1752,
+              "SpChain* layouts are part of the ABI (super_primitive_amd/_lib.py mirrors them)");
+
 namespace {
 
 // the node's pose / affine pair from device buffers; tangent and Adam moments cleared (optim/window.py set_nodes)
@@ -81,11 +84,19 @@ int run_phases(const SpChainWindow& w, void* stream) {
         if (ph.max_iters <= 0) continue;
         const SpWindowGn& g = w.gn[ph.level];
         hipLaunchKernelGGL(k_chain_state, dim3(1), dim3(64), 0, s, state, 0.f, 0);
-        const int rc = sp_window_gn_run(g.pairs, g.chunks, g.spans, g.n_spans, ph.irls_eps, g.edges, g.n_edges, g.nodes, g.n_nodes, g.blocks, g.n_blocks,
-                                        g.sum_N, g.max_N, g.n_unknowns, g.span_partials, g.seg_partials, g.scratch, g.nodes_backup, g.kld_backup, w.flags,
-                                        w.lm_up, w.lm_down, w.lm_min, ph.conv_tol, g.state, g.losses, g.max_losses, ph.max_iters, w.check_every,
-                                        w.state_host, stream);
-        if (rc < 0) return rc;
+        // (check_first: a first look after that many iterations, then every check_every as sp_window_gn_run does)
+        int done = 0;
+        const int first = (w.check_first > 0 && w.check_first < ph.max_iters && ph.conv_tol > 0.f) ? w.check_first : 0;
+        for (int leg = first ? 0 : 1; leg < 2; ++leg) {
+            const int n = leg == 0 ? first : ph.max_iters - done;
+            const int rc = sp_window_gn_run(g.pairs, g.chunks, g.spans, g.n_spans, ph.irls_eps, g.edges, g.n_edges, g.nodes, g.n_nodes, g.blocks, g.n_blocks,
+                                            g.sum_N, g.max_N, g.n_unknowns, g.span_partials, g.seg_partials, g.scratch, g.nodes_backup, g.kld_backup, w.flags,
+                                            w.lm_up, w.lm_down, w.lm_min, ph.conv_tol, g.state, g.losses, g.max_losses, n, leg == 0 ? first : w.check_every,
+                                            w.state_host, stream);
+            if (rc < 0) return rc;
+            done += rc;
+            if (ph.conv_tol > 0.f && static_cast<volatile float*>(w.state_host)[6] != 0.f) break;
+        }
     }
     return (int)static_cast<volatile float*>(w.state_host)[5];
 }
@@ -166,13 +177,13 @@ extern "C" int sp_chain_step(SpChainStep* st, void* stream) {
     }
 
     if (stages & SP_CHAIN_CRITERION) {
-        if (!st->out_pose || !st->kf_pose || !st->rel_pose || !st->crit || !st->crit_host || !st->depth_out || !st->keys) return SP_EINVAL;
+        if (!st->out_pose || !st->kf_pose || !st->rel_pose || !st->crit || !st->crit_ws || !st->crit_host || !st->depth_out || !st->keys) return SP_EINVAL;
         hipLaunchKernelGGL(k_chain_rel_pose, dim3(1), dim3(64), 0, s, (const float*)st->out_pose, st->kf_pose, st->rel_pose);
         SP_CHECK_LAUNCH();
         if (int rc = sp_depth_splat(st->pix, st->baseL, st->seg_off, st->kp_L, st->kld, st->N, st->P, st->H, st->W, st->K, st->rel_pose, st->keys,
                                     st->depth_out, stream))
             return rc;
-        if (int rc = sp_kf_criterion(st->depth_out, st->H * st->W, st->valid_thresh, st->out_pose, st->kf_pose, st->crit, stream)) return rc;
+        if (int rc = sp_kf_criterion_ws(st->depth_out, st->H * st->W, st->valid_thresh, st->out_pose, st->kf_pose, st->crit_ws, st->crit, stream)) return rc;
         hipError_t e = hipMemcpyAsync(st->crit_host, st->crit, 4 * sizeof(float), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return (int)e;

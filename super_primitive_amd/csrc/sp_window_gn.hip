@@ -259,7 +259,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w, const W
     __shared__ double lam_s;
     const int tid = threadIdx.x, b = blockIdx.x, tile = blockIdx.y;
     const SpWindowBlock bk = w.blocks[b];
-    const bool frozen = (w.flags & 1) || !(bk.lr > 0.f);
+    const bool frozen = (w.flags & 5) || !(bk.lr > 0.f);
     __shared__ int bN[SP_WGN_MAX_NODES];          // a block's N, negative if its depths are fixed
     for (int i = tid; i < w.n_nodes; i += SP_BLOCK) { aff_off[i] = wgn_node_flags(w.nodes[i]); lpose[i] = -1; laff[i] = -1; }
     for (int q = tid; q < w.n_blocks; q += SP_BLOCK) { const SpWindowBlock bq = w.blocks[q]; bN[q] = bq.lr > 0.f ? bq.N : -bq.N; }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w, const W
         for (int q = 0; q < w.n_blocks; ++q) {
             if (q == b) row0_s = off;
             off += abs(bN[q]);
-            if (!(w.flags & 1) && bN[q] > 0) free_depths += bN[q];
+            if (!(w.flags & 5) && bN[q] > 0) free_depths += bN[q];
         }
         const WGnDecision d = wgn_decide(w, ny, SP_WGN_MAX_Y, loss, free_depths);
         dec_s = d.dec;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
     __shared__ __align__(16) double panel[PANELS > 0 ? PANELS : 1][LDS_Y > 0 ? LDS_Y : 1][4];      // [row][column of the panel]
     __shared__ int pose_off[SP_WGN_MAX_NODES], aff_off[SP_WGN_MAX_NODES];
     __shared__ int blk_off[SP_WGN_MAX_NODES + 1];
-    __shared__ int n_y_s, decision, fail_s;
+    __shared__ int n_y_s, decision, fail_s, free_s;
     __shared__ double lam_s;
     double* H;
     if constexpr (LDS_Y > 0) H = Hs; else H = w.Hg;
@@ -516,11 +516,12 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
         int off = 0, free_depths = 0;
         for (int b = 0; b < w.n_blocks; ++b) {
             const int N = blk_off[b];
-            if (!(w.flags & 1) && N > 0) free_depths += N;
+            if (!(w.flags & 5) && N > 0) free_depths += N;
             blk_off[b] = off;
             off += abs(N);
         }
         blk_off[w.n_blocks] = off;
+        free_s = free_depths;
         // ---- loss, LM decision (the one k_window_gn_schur took), committed to the state ---------------------------------
         const WGnDecision d = wgn_decide(w, ny, CAP, loss_now, free_depths);
         if (d.too_many) { st[9] = 1.f; st[6] = 1.f; }
@@ -602,7 +603,10 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
     // ---- LM damping of the camera block, then minus the blocks' Schur terms (k_window_gn_schur), block after block ----
     for (int i = tid; i < n_y; i += NTHR) { H[ltri(i, i)] = H[ltri(i, i)] * (1.0 + lam) + 1e-12; g0[i] = g[i]; g[i] = -g[i]; }
     __syncthreads();
-    for (int b = 0; b < w.n_blocks; ++b) {
+    // (no depth may move -- a pose-only phase, or the caller's word that every block is fixed, flags bit 2: k_window_gn_schur was not launched,
+    //  its terms would all be zero)
+    const int n_schur_blocks = free_s > 0 ? w.n_blocks : 0;
+    for (int b = 0; b < n_schur_blocks; ++b) {
         const int nc = w.nc[b];
         const int* cb = w.cols + (size_t)b * ldc;
         const double* Sb = w.S + (size_t)b * w.lds;
@@ -912,7 +916,7 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
     double gain = 0.0;                     // -(b . delta): what the step is predicted to buy (first-order change of the loss, flags bit 1)
     if (!fail) {
         for (int i = tid; i < n_y; i += NTHR) gain -= g0[i] * dy[i];
-        for (int b = 0; b < w.n_blocks; ++b) {
+        for (int b = 0; b < n_schur_blocks; ++b) {
             const SpWindowBlock bk = w.blocks[b];
             const int nc = w.nc[b];
             const int* cb = w.cols + (size_t)b * ldc;
@@ -1073,8 +1077,10 @@ int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edge
     SP_CHECK_LAUNCH();
     const int tiles = max(1, (w.lds + SP_BLOCK * SP_WGN_PPT - 1) / (SP_BLOCK * SP_WGN_PPT));
     const WGnArgs* none = nullptr;
-    hipLaunchKernelGGL(k_window_gn_schur, dim3(n_blocks, tiles), dim3(SP_BLOCK), 0, s, w, none);
-    SP_CHECK_LAUNCH();
+    if (!(flags & 5)) {                // (flags bit 0 / bit 2: no depth moves -- every Schur term is zero and the update kernel does not read them)
+        hipLaunchKernelGGL(k_window_gn_schur, dim3(n_blocks, tiles), dim3(SP_BLOCK), 0, s, w, none);
+        SP_CHECK_LAUNCH();
+    }
     if (n_unknowns <= 64) hipLaunchKernelGGL(k_window_gn_update<64>, dim3(1), dim3(wgn_update_threads(64)), 0, s, w, none);
     else if (n_unknowns <= 128) hipLaunchKernelGGL(k_window_gn_update<128>, dim3(1), dim3(wgn_update_threads(128)), 0, s, w, none);
     else if (n_unknowns <= SP_WGN_LDS_Y) hipLaunchKernelGGL(k_window_gn_update<SP_WGN_LDS_Y>, dim3(1), dim3(wgn_update_threads(SP_WGN_LDS_Y)), 0, s, w, none);
@@ -1158,7 +1164,7 @@ int sp_window_gn_run_multi(const SpWindowGn* windows, int n_windows, float irls_
             int rc = cost_pairs_multi(lists_dev, n_windows, total_blocks, 2, irls_eps, stream);
             if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
             hipLaunchKernelGGL(k_window_gn_reduce_multi, dim3(max_edges, 1, n_windows), dim3(SP_BLOCK), 0, s, (const WGnArgs*)wins);
-            hipLaunchKernelGGL(k_window_gn_schur, dim3(max_blocks, tiles, n_windows), dim3(SP_BLOCK), 0, s, dummy, (const WGnArgs*)wins);
+            if (!(flags & 5)) hipLaunchKernelGGL(k_window_gn_schur, dim3(max_blocks, tiles, n_windows), dim3(SP_BLOCK), 0, s, dummy, (const WGnArgs*)wins);
             if (max_y <= 64) hipLaunchKernelGGL(k_window_gn_update<64>, dim3(1, 1, n_windows), dim3(wgn_update_threads(64)), 0, s, dummy, (const WGnArgs*)wins);
             else if (max_y <= 128) hipLaunchKernelGGL(k_window_gn_update<128>, dim3(1, 1, n_windows), dim3(wgn_update_threads(128)), 0, s, dummy, (const WGnArgs*)wins);
             else if (max_y <= SP_WGN_LDS_Y) hipLaunchKernelGGL(k_window_gn_update<SP_WGN_LDS_Y>, dim3(1, 1, n_windows), dim3(wgn_update_threads(SP_WGN_LDS_Y)), 0, s, dummy, (const WGnArgs*)wins);

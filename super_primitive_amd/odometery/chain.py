@@ -16,6 +16,8 @@ from .. import _lib
 from ..optim import window as _window
 from ..segment_table import table_of
 
+import os as _os
+SUPP_CHECK_FIRST = int(_os.environ.get("SP_SUPP_CHECK_FIRST", "1"))
 TRACK, SUPP, CRITERION = _lib.SP_CHAIN_TRACK, _lib.SP_CHAIN_SUPP, _lib.SP_CHAIN_CRITERION
 
 
@@ -29,7 +31,7 @@ def _gn_record(rec, win, level):
     rec.sum_N, rec.max_N, rec.n_unknowns, rec.max_losses = gn['sum_N'], win.max_N, gn['n_y'], win.max_iters
 
 
-def _bind_window(cw, win, phases):
+def _bind_window(cw, win, phases, check_first=0):
     """phases: [(pyramid level, max iterations, irls_eps, conv_tol)] -- the schedule ``run_gn`` is called with, phase by phase."""
     assert len(phases) <= _lib.SP_CHAIN_PHASES and max(win.level_ids) < _lib.SP_CHAIN_LEVELS
     for l in range(_lib.SP_CHAIN_LEVELS):
@@ -40,7 +42,8 @@ def _bind_window(cw, win, phases):
         cw.phase[p].level, cw.phase[p].max_iters, cw.phase[p].irls_eps, cw.phase[p].conv_tol = int(level), int(n), float(eps), float(tol)
     cw.n_phases = len(phases)
     cw.check_every = _window.GN_CHECK_EVERY
-    cw.flags = 2 if _window.GN_PREDICTED_EXIT else 0
+    cw.check_first = int(check_first)
+    cw.flags = (2 if _window.GN_PREDICTED_EXIT else 0) | (4 if win.depths_fixed else 0)
     cw.lam0, cw.lm_up, cw.lm_down, cw.lm_min = 1e-4, 8.0, 0.5, 1e-7          # (PoseWindow.reset_gn / run_gn defaults)
     cw.state_host = win._gn_state()['state_host'].data_ptr()
 
@@ -67,6 +70,8 @@ class ChainStep:
         self.rel_pose = torch.empty(16, dtype=torch.float32, device=device)
         self.crit = torch.empty(4, dtype=torch.float32, device=device)
         self.crit_host = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self.crit_ws = torch.zeros(self.lib.sp_kf_criterion_ws_words(), dtype=torch.int32, device=device)
+        st.crit_ws = self.crit_ws.data_ptr()
         st.keys, st.depth_out, st.rel_pose, st.crit, st.crit_host = self.keys.data_ptr(), self.depth.data_ptr(), self.rel_pose.data_ptr(), self.crit.data_ptr(), self.crit_host.data_ptr()
         st.valid_thresh = 1e-6
         self.tracker = self.mapper = None
@@ -103,7 +108,7 @@ class ChainStep:
         phases = [(0, min(mapper.num_iters, gn['max_iters']), gn['irls_eps'], gn['conv_tol'])]
         if gn['polish_max'] > 0 and mapper.num_iters > gn['max_iters'] // 2:
             phases.append((0, gn['polish_max'], gn['polish_eps'], gn['polish_tol']))
-        _bind_window(st.supp, win, phases)
+        _bind_window(st.supp, win, phases, check_first=SUPP_CHECK_FIRST)      # (the depths of a keyframe that has been mapped every frame move in one step)
         for j in range(2):
             tg = st.supp_target[j]
             tg.node = mapper.slots[j]

@@ -2,7 +2,7 @@
 
 ``translation_difference`` needs the median of the valid rendered depths (``torch.median`` over a boolean-indexed
 image: a compaction + a sort + a host sync in the reference) and ``rotation_difference`` round-trips both poses
-through numpy/scipy.  Here one launch (``sp_kf_criterion``: count + 4-pass radix select in one workgroup + the two
+through numpy/scipy.  Here four launches (``sp_kf_criterion_ws``: count + 4-pass radix select over a grid of workgroups + the two
 pose differences) fills a 4-vector that stays on the device; the functions below slice it with the reference's
 signatures and return types.  ``keyframe_criterion`` exposes the whole vector, including the depth-validity ratio of
 ``odometery/odometery.py:1003-1004``, for drivers that want a single read-back per frame."""
@@ -24,8 +24,9 @@ def keyframe_criterion(pose_src, pose_target, depth, valid_thresh=1e-6):
     pt = pose_target.detach().to(dev).contiguous().float()
     assert ps.shape[-2:] == (4, 4) and pt.shape[-2:] == (4, 4) and ps.numel() == 16 and pt.numel() == 16
     out = torch.empty(4, dtype=torch.float32, device=dev)
-    _lib.check(lib.sp_kf_criterion(_lib.ptr(d), d.numel(), float(valid_thresh), _lib.ptr(ps), _lib.ptr(pt), _lib.ptr(out),
-                                   _lib.stream_ptr()), "sp_kf_criterion")
+    ws = torch.empty(lib.sp_kf_criterion_ws_words(), dtype=torch.int32, device=dev)
+    _lib.check(lib.sp_kf_criterion_ws(_lib.ptr(d), d.numel(), float(valid_thresh), _lib.ptr(ps), _lib.ptr(pt), _lib.ptr(ws), _lib.ptr(out),
+                                      _lib.stream_ptr()), "sp_kf_criterion_ws")
     return out
 
 

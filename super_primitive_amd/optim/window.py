@@ -87,6 +87,7 @@ class PoseWindow:
             blocks[k].N = self.Ns[k]
             blocks[k].lr = float(s.get('lr', 0.0))
         self._blocks_host = blocks
+        self.depths_fixed = all(float(s_.get('lr', 0.0)) == 0.0 for s_ in sources)     # (sp_window_gn_step flags bit 2: no Schur launch)
         # ---- pose nodes ----------------------------------------------------------------------------------------
         arr = (_lib.SpWindowNode * self.n_nodes)()
         # (ONE read-back for all poses and one for all affine pairs: a .cpu() per node was a host synchronisation each)
@@ -291,7 +292,7 @@ class PoseWindow:
         _lib.check(self.lib.sp_window_gn_step(_lib.ptr(d), _lib.ptr(self.edges), self.n_edges, _lib.ptr(self.nodes), self.n_nodes,
                                               _lib.ptr(self.blocks), self.n_sources, gn['sum_N'], self.max_N, gn['n_y'], _lib.ptr(self.partials),
                                               _lib.ptr(self.seg_partials), _lib.ptr(gn['scratch']), _lib.ptr(gn['nodes_backup']),
-                                              _lib.ptr(gn['kld_backup']), 1 if pose_only else 0, float(lm_up), float(lm_down), float(lm_min),
+                                              _lib.ptr(gn['kld_backup']), (1 if pose_only else 0) | (4 if self.depths_fixed else 0), float(lm_up), float(lm_down), float(lm_min),
                                               float(conv_tol), _lib.ptr(gn['state']), _lib.ptr(gn['losses']), self.max_iters,
                                               _lib.stream_ptr()), "sp_window_gn_step")
         gn['host_stale'] = True
@@ -317,7 +318,7 @@ class PoseWindow:
         rc = self.lib.sp_window_gn_run(_lib.ptr(d), _lib.ptr(self.chunks), _lib.ptr(self.spans), self.n_spans, float(irls_eps), _lib.ptr(self.edges),
                                        self.n_edges, _lib.ptr(self.nodes), self.n_nodes, _lib.ptr(self.blocks), self.n_sources, gn['sum_N'],
                                        self.max_N, gn['n_y'], _lib.ptr(self.partials), _lib.ptr(self.seg_partials), _lib.ptr(gn['scratch']),
-                                       _lib.ptr(gn['nodes_backup']), _lib.ptr(gn['kld_backup']), (1 if pose_only else 0) | (2 if predicted_exit else 0), float(lm_up),
+                                       _lib.ptr(gn['nodes_backup']), _lib.ptr(gn['kld_backup']), (1 if pose_only else 0) | (2 if predicted_exit else 0) | (4 if self.depths_fixed else 0), float(lm_up),
                                        float(lm_down), float(lm_min), float(conv_tol), _lib.ptr(gn['state']), _lib.ptr(gn['losses']),
                                        self.max_iters, int(max_iters), int(check_every), gn['state_host'].data_ptr(), _lib.stream_ptr())
         if rc < 0:

@@ -118,6 +118,13 @@ def test_kf_criteria_match_reference():
     # nothing valid: the reference's torch.median raises on an empty tensor; the kernel reports NaN without syncing
     out = npy(keyframe_criterion(a, b, torch.zeros(64, 64, device=d.device)))
     assert out[0] == 0.0 and np.isnan(out[1]) and np.isnan(out[2])
+    # the grid form (sp_kf_criterion_ws: what keyframe_criterion calls since round 6) against the one-workgroup form, bit for bit
+    from super_primitive_amd import _lib
+    lib = _lib.load()
+    for img in (d, T(g["even_depth"]), T(g["one_depth"]), torch.zeros(64, 64, device=d.device)):
+        one = torch.empty(4, dtype=torch.float32, device=d.device)
+        _lib.check(lib.sp_kf_criterion(_lib.ptr(img.contiguous()), img.numel(), 1e-6, _lib.ptr(a.contiguous()), _lib.ptr(b.contiguous()), _lib.ptr(one), _lib.stream_ptr()), "sp_kf_criterion")
+        np.testing.assert_array_equal(npy(one).view(np.uint32), npy(keyframe_criterion(a, b, img)).view(np.uint32))
 
 
 def test_infer_depth_seeds_matches_oracle():

@@ -417,3 +417,24 @@ def test_windows_side_by_side_are_bitwise_the_windows_one_at_a_time():
         assert a.gn_iterations() == b.gn_iterations() and torch.equal(a.gn_losses(), b.gn_losses())
         assert a.gn_converged() == b.gn_converged()
     assert max(its) <= rounds <= max(its) + 2 * 4                 # (the batch runs until its slowest window has been SEEN converged: polled every 4th round)
+
+
+def test_leaving_out_the_schur_launch_of_a_window_without_free_depths_changes_no_bit():
+    """Round 6 (the config-3 chain's per-frame launches): a window whose depth blocks are all fixed -- frame-to-keyframe tracking -- says so in
+    ``sp_window_gn_step``'s flags (bit 2, ``PoseWindow.depths_fixed``) and the Schur-term kernel is not launched: its terms are exact zeros,
+    so poses, affine pairs, losses and iteration counts are those of the four-launch iteration, bit for bit."""
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.odometery.loops import GnTracker
+    g = load_golden("g17_config3_tum_shaped")
+    frames, est, klds, affs, kfs = _config3(g)
+    z2 = torch.zeros(2, device=kfs[0].image.device)
+    f = KeyFrame(T(frames[1].image), T(frames[1].K))
+    out = {}
+    for fixed in (True, False):
+        trk = GnTracker(kfs[0], T(frames[0].kld_gt), T(est[0]), f, (0, 3), kf_aff=z2)
+        assert trk.win.depths_fixed
+        trk.win.depths_fixed = fixed
+        res = trk.track(f, T(est[1]), z2)
+        out[fixed] = (res[0].clone(), res[1].clone(), torch.stack(res[2]), res[3], trk.win.nodes.clone())
+    a, b = out[True], out[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] and torch.equal(a[4], b[4])

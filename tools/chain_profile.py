@@ -13,6 +13,15 @@ kw = dict(engine="gn", translation_thresh=0.095, window_size=5, depth_of=lambda 
 run_sequence(frames[:4], to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn")
 run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **kw)
 out = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **kw)
+if len(sys.argv) > 2 and sys.argv[2] == "native":        # (for rocprofv3 --kernel-trace --stats: the one-call-per-frame chain only, 5 times)
+    import time
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        o = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **dict(kw, native_step=True))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"native chain: {(n - 1) / dt:.0f} frames/s wall ({1e3 * dt / (n - 1):.3f} ms per frame); stages", {k: round(1e3 * v / (n - 1), 3) for k, v in o["seconds"].items()},
+              "keyframes", len(o["all_kf_ids"]), "mappings", o["n_mappings"])
+    sys.exit(0)
 for native in (False, True):
     o = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **dict(kw, native_step=native))
     o = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **dict(kw, native_step=native))
