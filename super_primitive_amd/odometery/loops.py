@@ -168,7 +168,7 @@ class GnTracker:
                       image=frame.image, K=frame.K)]
         self.phases = [(int(l), int(n)) for l, n in self.sch['phases'] if levels[0] <= int(l) < levels[1]]
         self.win = PoseWindow([dict(kf=kf, kld=kld, lr=0.0, node=0)], nodes, [(0, 1, 1.0, dense_optim.Z_MIN_SINGLE)], levels, abs_loss=False,
-                              use_affine=self.affine, max_iters=sum(n for _, n in self.phases) + self.sch['polish_max'] + 8)
+                              use_affine=self.affine, max_iters=sum(n for _, n in self.phases) + self.sch['polish_max'] + 8, share_sources=True)
         self._first_image = frame.image
 
     def update_keyframe(self, kld=None, kf_pose=None, kf_aff=None):
@@ -348,8 +348,12 @@ def _build_map_window(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose,
         return None, supp_node, src_ids
     # (``span_points``: points per workgroup of the window's cost pass.  Default: sized for ONE window's latency -- ~2300 workgroups however
     #  few the points; windows optimised side by side, ``PoseWindowBatch``, want the throughput size, 4096-16384)
+    # (the only images such a window replaces in place are those of the latest keyframe's running supporting frames in 'supp' mode --
+    #  GnSuppMapper's slots; every other target reads the packed image cached on its frame)
+    private = [supp_node[(K - 1, j)] for j in range(len(supp[K - 1]))] if mode == 'supp' else []
     win = PoseWindow(sources, nodes, edges, (0, 1), abs_loss=False, rel_tol=rel_tol if initialised else 0.0, use_affine=affine,
-                     max_iters=max(1, num_iters) + (gn['polish_max'] + 8 if gn else 0), span_points=span_points)
+                     max_iters=max(1, num_iters) + (gn['polish_max'] + 8 if gn else 0), span_points=span_points, private_targets=private,
+                     share_sources=gn is not None)
     return win, supp_node, src_ids
 
 

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..segment_table import table_of
+from ..segment_table import _Ident, _same, packed_target, table_of
 from .batch_prepare import flat_work_list, stage
 from .pair_batch import DEFAULT_BATCH_TILE_POINTS, DEFAULT_SPAN_POINTS, GRANULE, MIN_SPANS, _level_images, pad_layout, pad_points
 
@@ -45,12 +45,19 @@ GN_PREDICTED_EXIT = _os.environ.get("SP_GN_PREDICTED_EXIT", "1") != "0"
 
 class PoseWindow:
     def __init__(self, sources, nodes, edges, levels, abs_loss=False, skip_first=False, rel_tol=0.0, use_affine=False,
-                 max_iters=4096, tile_points=DEFAULT_BATCH_TILE_POINTS, span_points=None):
+                 max_iters=4096, tile_points=DEFAULT_BATCH_TILE_POINTS, span_points=None, private_targets=None,
+                 share_sources=False):
         """sources: list of dict(kf=KeyFrame, kld=(N,) tensor, lr=float [0 = frozen], node=int [-1 = identity pose]);
         nodes:   list of dict(T=(4,4), kind=KIND_WINDOW|KIND_DIRECT, lr_pose=float, lr_aff=float, aff=(2,)|None,
                               renorm=bool, image=(3,H,W)|None, K=(3,3)|None)  -- image/K needed when the node is a target;
         edges:   list of (source index, target node, weight, zmin);
-        levels:  (pyramid_min, pyramid_max) like ``config['aligment']`` (max exclusive)."""
+        levels:  (pyramid_min, pyramid_max) like ``config['aligment']`` (max exclusive);
+        private_targets: target nodes whose images this window REPLACES in place (``set_target_image`` / ``copy_target_image`` / the slots of
+                 ``sp_chain_step``): they get buffers of their own.  None = all of them.  Every other target node at pyramid level 0 reads
+                 the packed image cached on the frame's tensor (``segment_table.packed_target``), shared by all windows the frame is part of;
+        share_sources: keep / re-use the padded source samples of every source keyframe with its segment table (see below; the Gauss-Newton
+                 windows of the odometry chain -- a keyframe is the source of a dozen windows while it lives).  Off, every window samples
+                 its own under the depths it is built with, as the reference does per iteration."""
         lib = _lib.load()
         self.lib = lib
         dev = sources[0]['kf'].image.device
@@ -65,13 +72,30 @@ class PoseWindow:
         tables = [table_of(s['kf']) for s in sources]
         self.Ns = [t.N for t in tables]
         self.max_N = max(self.Ns)
-        pads = [pad_layout(t.counts, dev) for t in tables]
-        self.src4 = {}
+        # (what of this is a property of the KEYFRAME is kept with its table: the padded layout, the padded points, and the padded source
+        #  samples per level.  A keyframe is the source of several windows while it lives -- its tracker, its supplementary-mapping window,
+        #  every scheduled mapping it takes part in -- and the samples do not depend on the depths beyond the last bit of the re-projected
+        #  pixel (core/dense_optim.py:143-162; the tolerance the persistent windows already carry, tests/test_gpu_sequence.py))
+        pads, self.src4, self.pix = [], {}, []
         for k, (s, tab) in enumerate(zip(sources, tables)):
-            lv = _level_images(s['kf'].image[:3].float(), max_level)
+            kfk = s['kf']
+            wc = getattr(tab, '_window_cache', None) if share_sources else None
+            if wc is None or not _same(wc['idents'], (kfk.image, kfk.K)):
+                wc = dict(idents=(_Ident(kfk.image), _Ident(kfk.K)), pads=pad_layout(tab.counts, dev))
+                if share_sources:
+                    tab._window_cache = wc
+            pads.append(wc['pads'])
+            lv = None
             for l in self.level_ids:
-                self.src4[(k, l)] = pad_points(tab.source_level(lv[l], s['kf'].K, s['kld'].to(dev), cache=False).reshape(-1, 4), pads[k]).reshape(-1)
-        self.pix = [pad_points(t.pix, pd) for t, pd in zip(tables, pads)]          # after source_level(): validity bits set
+                hit = wc.get(l)
+                if hit is None:
+                    if lv is None:
+                        lv = _level_images(kfk.image[:3].float(), max_level)
+                    hit = wc[l] = pad_points(tab.source_level(lv[l], kfk.K, s['kld'].to(dev), cache=False).reshape(-1, 4), wc['pads']).reshape(-1)
+                self.src4[(k, l)] = hit
+            if 'pix' not in wc:
+                wc['pix'] = pad_points(tab.pix, wc['pads'])                         # after source_level(): validity bits set
+            self.pix.append(wc['pix'])
         self.kp_L = [t.kp_L for t in tables]
         # ---- log-depth blocks ----------------------------------------------------------------------------------
         n_off = np.concatenate(([0], np.cumsum(self.Ns)))
@@ -106,9 +130,15 @@ class PoseWindow:
         # ---- target images: packed per level -------------------------------------------------------------------
         self.trg3, self.level_hw = {}, {}
         targets = sorted({e[1] for e in edges})
+        self._shared_targets = set()
         for i in targets:
             img = nodes[i]['image']
             assert img is not None and nodes[i].get('K') is not None, f"node {i} is a target but has no image / K"
+            if private_targets is not None and i not in private_targets and self.level_ids == [0] and img.is_cuda and img.dim() == 3:
+                self.trg3[(i, 0)] = packed_target(img).reshape(-1)
+                self.level_hw[(i, 0)] = tuple(img.shape[-2:])
+                self._shared_targets.add(i)
+                continue
             lv = _level_images(img[:3].float().to(dev), max_level)
             for l in self.level_ids:
                 Hl, Wl = lv[l].shape[-2:]
@@ -216,6 +246,7 @@ class PoseWindow:
         """Replace the image of target node ``node`` IN PLACE (same size, same intrinsics): its pyramid levels are rebuilt and
         packed into the buffers the edge descriptors already point to -- a tracker keeps ONE window per keyframe and feeds it the
         frames (the source tables, samples, work list and descriptors are a per-keyframe cost, not a per-frame one)."""
+        assert node not in self._shared_targets, "set_target_image: the node reads a shared image (name it in private_targets)"
         lv = _level_images(image[:3].float().to(self.device), max(self.level_ids))
         for l in self.level_ids:
             Hl, Wl = lv[l].shape[-2:]
@@ -225,6 +256,7 @@ class PoseWindow:
     def copy_target_image(self, dst_node, src_node):
         """The packed pyramid of target node ``src_node`` into ``dst_node``'s buffers (same size): a frame that moves from one slot of
         a persistent window to another is not packed twice."""
+        assert dst_node not in self._shared_targets
         for l in self.level_ids:
             assert self.level_hw[(dst_node, l)] == self.level_hw[(src_node, l)]
             self.trg3[(dst_node, l)].copy_(self.trg3[(src_node, l)])

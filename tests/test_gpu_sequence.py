@@ -387,7 +387,8 @@ def test_config3_at_sequence_length():
           f"ms per frame (track / supplementary mapping / keyframe work) frames 100-300: {early['track']:.2f} / {early['supp_mapping']:.2f} / {early['keyframe']:.2f}, "
           f"frames 300-{n - 1}: {late['track']:.2f} / {late['supp_mapping']:.2f} / {late['keyframe']:.2f}; scheduled mapping {1e3 * vo.secs['mapping'] / max(n_map, 1):.1f} ms per window; "
           f"device memory (allocated / reserved MB) at frame 100: {mem[100][0] / 1e6:.0f} / {mem[100][1] / 1e6:.0f}, 300: {mem[300][0] / 1e6:.0f} / {mem[300][1] / 1e6:.0f}, "
-          f"{n - 1}: {mem[n - 1][0] / 1e6:.0f} / {mem[n - 1][1] / 1e6:.0f}")
+          f"{n - 1}: {mem[n - 1][0] / 1e6:.0f} / {mem[n - 1][1] / 1e6:.0f}; the frontend's share (to_keyframe: synthesis and upload of the keyframes, not the chain's) "
+          f"{1e3 * vo.frontend_secs / max(len(out['all_kf_ids']) - 1, 1):.1f} ms per keyframe")
     assert len(out["all_kf_ids"]) >= 40 and len(out["kf_ids"]) == 5 and n_map >= 35
     assert rel_rot <= 1e-3 and rel_t <= 2e-3, (rel_rot, rel_t)                      # every frame tracked
     assert rot <= 2e-2 and tt <= 6e-2 and abs(s - 1.0) <= 0.1, (rot, tt, s)         # drift over 640 frames and ~60 keyframe hand-overs: bounded
