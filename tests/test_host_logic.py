@@ -63,6 +63,16 @@ def test_abi_constants_and_struct_layout_match_header():
                   "SP_STATUS_RETRIED", "SP_STATUS_ADAM", "SP_STATUS_UNFINISHED", "SP_DIAG_FLOATS"):
         assert int(re.search(r"#define\s+" + macro + r"\s+(0x[0-9a-fA-F]+|\d+)", header).group(1), 0) == getattr(_lib, macro), macro
     assert int(re.search(r"#define\s+SP_PHASE_POSE_ONLY\s+(\d+)", header).group(1)) == _lib.SP_PHASE_POSE_ONLY
+    # (ABI 14: the argument record of sp_chain_step; static_assert-ed in sp_chain.hip)
+    assert ctypes.sizeof(_lib.SpChainPhase) == 16 and ctypes.sizeof(_lib.SpChainWindow) == 680 and ctypes.sizeof(_lib.SpChainTarget) == 56
+    assert ctypes.sizeof(_lib.SpChainStep) == 1752 and _lib.SpChainStep.track.offset == 56 and _lib.SpChainStep.supp.offset == 808
+    assert _lib.SpChainWindow.state_host.offset == 672 and _lib.SpChainWindow.check_first.offset == 668 and _lib.SpChainStep.crit_ws.offset == 1720
+    for macro in ("SP_CHAIN_LEVELS", "SP_CHAIN_PHASES", "SP_CHAIN_TRACK", "SP_CHAIN_SUPP", "SP_CHAIN_CRITERION"):
+        assert int(re.search(r"#define\s+" + macro + r"\s+(\d+)", header).group(1)) == getattr(_lib, macro), macro
+    lib = _lib.load()
+    assert lib.sp_chain_step(None, None) == -1 and lib.sp_kf_criterion_ws_words() == 4 * 256 + 8
+    step = _lib.SpChainStep()
+    assert lib.sp_chain_step(ctypes.byref(step), None) == -1               # (no frame size, no stage's pointers: refused before any launch)
 
 
 def test_new_entry_points_validate_arguments_and_sizes():

@@ -1,3 +1,5 @@
+"""Developer tool: what building the three per-keyframe Gauss-Newton windows of the config-3 chain costs on the host (tracker, supplementary-mapping
+window, scheduled-mapping window; ms per build + cProfile by own time).   python tools/window_build_profile.py"""
 import sys, os, cProfile, pstats, io, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
