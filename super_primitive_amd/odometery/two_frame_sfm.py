@@ -205,9 +205,18 @@ class SfM:
         ``mode='adam'``: Adam with the reset-tangent pose parameterisation of the reference's tracking / mapping
         loops (``odometery/odometery.py:394-403``); it differs from ``run()``'s accumulated tangent only in the
         second-order terms of Exp and in not skipping the very first update.  ``mode='gn'``: Gauss-Newton / LM on the
-        same L1 cost (IRLS).  One supporting frame only (several frames share the log-depths and are not
-        independent pairs).  Results are written back so ``poses()`` / ``keypoint_logdepths()`` work as after ``run()``."""
-        from ..optim.pair_batch import PairBatch
+        same L1 cost (IRLS) -- without ``iters_per_level`` the CONVERGING per-pair schedule of ``PairBatch.run_scheduled`` with its
+        verdict and further attempts (at 640 x 480 and three levels: ``REFERENCE_START_SCHEDULE``, the schedule ``frame_pairs_per_sec`` is
+        quoted on, third attempt = the reference's own Adam), whose outcome is kept in ``device_status`` / ``device_attempts`` /
+        ``device_diag`` (``converged()``; a flagged pair raises a ``RuntimeWarning``: a wrong pose never comes back silently -- the
+        reference only asserts finiteness, core/dense_optim.py:311,321,340-343).  ``verdict=dict(cost_bound=...)`` hands the run the one
+        yardstick a pair ALONE cannot have: what a converged pair's cost is (a tracker knows it from its previous frames).  With
+        ``iters_per_level`` a fixed number of LM iterations per level, no verdict.  One supporting frame only (several frames share the
+        log-depths and are not independent pairs).  Results are written back so ``poses()`` / ``keypoint_logdepths()`` work as after
+        ``run()``."""
+        from .. import _lib
+        from ..optim.pair_batch import (FRAME_PAIR_SCHEDULE, REFERENCE_START_LEVELS, REFERENCE_START_POINT_STRIDE, REFERENCE_START_SCHEDULE,
+                                        PairBatch)
         if len(self.supp_frames) != 1:
             raise NotImplementedError("run_on_device handles one supporting frame; use run() for several")
         al = self.config['aligment']
@@ -215,9 +224,27 @@ class SfM:
         frame, current_T, pose_to_mat = self.supp_frames[0]
         with torch.no_grad():
             pose0 = pose_to_mat(current_T).detach().clone()
-        batch = PairBatch([self.src_keyframe], [frame.image], [frame.K], pose0[None], [self.src_depth_keypoints_opt.detach()],
-                          levels=(al['pyramid_min'], al['pyramid_max']), tile_points=2048)
-        batch.run(iters_per_level or self.num_iters, mode=mode, use_graph=use_graph, **kw)
+        levels = (al['pyramid_min'], al['pyramid_max'])
+        self.device_status = self.device_attempts = self.device_diag = None
+        if mode == "gn" and iters_per_level is None:
+            H, W = frame.image.shape[-2:]
+            if levels == REFERENCE_START_LEVELS and H * W >= 480 * 640 // 2:
+                build, sched = dict(point_stride=REFERENCE_START_POINT_STRIDE, granule=64), dict(REFERENCE_START_SCHEDULE)
+            else:               # (small frames / other pyramids: every level on all its points, two Gauss-Newton attempts)
+                build = dict(tile_points=2048)
+                sched = dict(FRAME_PAIR_SCHEDULE, use_coarse=False, pose_first_iters=15, pose_first_eps=1e-2, retry_pose_first=((levels[1] - 1, 30),))
+            batch = PairBatch([self.src_keyframe], [frame.image], [frame.K], pose0[None], [self.src_depth_keypoints_opt.detach()], levels=levels, **build)
+            batch.run_scheduled(**dict(sched, **kw))
+            self.device_status, self.device_attempts = int(batch.status[0]), int(batch.attempts[0]) + 1
+            self.device_diag = batch.diag[0].detach().cpu()
+            if self.device_status & _lib.SP_STATUS_FAILED:
+                import warnings
+                warnings.warn(f"SfM.run_on_device: the pair failed its verdict after {self.device_attempts} attempt(s) (status {self.device_status:#x}, "
+                              "include/sp_hip.h SP_STATUS_*): the returned pose / depths are the end state of the last attempt", RuntimeWarning)
+        else:
+            batch = PairBatch([self.src_keyframe], [frame.image], [frame.K], pose0[None], [self.src_depth_keypoints_opt.detach()], levels=levels,
+                              tile_points=2048)
+            batch.run(iters_per_level or self.num_iters, mode=mode, use_graph=use_graph, **kw)
         self.losses.append(batch.evaluate(al['pyramid_min'])[0].detach())
         with torch.no_grad():
             self.src_depth_keypoints_opt.data.copy_(batch.klds()[0])
@@ -230,6 +257,12 @@ class SfM:
         return self
 
     # -- results -------------------------------------------------------------------------------------
+    def converged(self):
+        """After ``run_on_device(mode='gn')``: True = the pair passed its verdict, False = flagged, None = no verdict was taken."""
+        from .. import _lib
+        st = getattr(self, "device_status", None)
+        return None if st is None else not (st & _lib.SP_STATUS_FAILED)
+
     def poses(self):
         with torch.no_grad():
             return [fn(T).detach().clone() for _, T, fn in self.supp_frames]
