@@ -35,6 +35,12 @@ from .depth_init import segment_based_depth_reinit
 from .kf_criteria import keyframe_criterion
 from .loops import GnSuppMapper, GnTracker, map_window, track_frame_fused, track_frame_gn  # noqa: F401
 
+def _sync():
+    """Wait for THIS thread's stream (the timers' fences): several sequences may run side by side, each on its own stream and host thread
+    (tools/chain_throughput.py) -- a device-wide synchronisation would make every one of them wait for all the others."""
+    torch.cuda.current_stream().synchronize()
+
+
 # config/tum/odom_desk.yaml (aligment.track / aligment.mapping / kf / window_size)
 DEFAULTS = dict(track_steps=(0, 0, 300), track_levels=(0, 3), track_lr=5e-3, map_steps=500, continual_steps=10, init_steps=1000,
                 map_lr_pose=1e-4, window_size=5, supp_every_n=3, depth_validity_ratio=0.60, translation_thresh=0.2,
@@ -142,7 +148,7 @@ class MonoVO:
         if c['motion_prior'] and len(self.tracked) >= 2:            # apply_motion_prior, :314-321 (the reference switches it off, :324)
             supp_T = (self.current_track @ invertSE3(self.tracked[-2].pose)) @ supp_T
         aff_kf = self.kf_affs[-1] if self.affine else None
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _sync(); t0 = time.perf_counter()
         if self.engine == "gn":
             if self.tracker is None:
                 self.tracker = GnTracker(self.kfs[-1], self.kf_klds[-1], self.kf_poses[-1], f, c['track_levels'], kf_aff=aff_kf)
@@ -150,7 +156,7 @@ class MonoVO:
         else:
             T, aff, _ = track_frame_fused(self.kfs[-1], self.kf_klds[-1], f, supp_T, self.kf_poses[-1], list(c['track_steps']), c['track_levels'],
                                           lr=c['track_lr'], prev_aff=aff_kf, curr_aff=self.current_aff if self.affine else None)
-        torch.cuda.synchronize(); self.secs['track'] += time.perf_counter() - t0
+        _sync(); self.secs['track'] += time.perf_counter() - t0
         self.current_track = T.detach().clone()
         if self.affine:
             self.current_aff = aff.detach().clone()
@@ -176,12 +182,12 @@ class MonoVO:
             # the supplementary mapping between two keyframes is the same window every frame but for the running supporting frames (two; one
             # right after a keyframe or a scheduled mapping): ONE window per latest keyframe, re-pointed in place (loops.GnSuppMapper) --
             # same arithmetic, same result as the branch below
-            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _sync(); t0 = time.perf_counter()
             if self.supp_mapper is None:
                 self.supp_mapper = GnSuppMapper(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, supp, num_iters,
                                                 window_size=c['window_size'])
             kld, _, _ = self.supp_mapper([(s.frame, s.pose, s.aff) for s in self.curr_supp])
-            torch.cuda.synchronize(); self.secs['supp_mapping'] += time.perf_counter() - t0
+            _sync(); self.secs['supp_mapping'] += time.perf_counter() - t0
             self.kf_klds[-1] = kld
             self.n_map[mode] += 1
             if self.tracker is not None:
@@ -192,11 +198,11 @@ class MonoVO:
         #  refreshed with the mapped values below; anything else drops it)
         keep_mapper = self.supp_mapper if mode == 'map' and c['persistent_supp'] else None
         self.supp_mapper = None
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _sync(); t0 = time.perf_counter()
         out = map_window(self.kfs, self.kf_poses, self.kf_klds, self.kf_affs if self.affine else None, supp, num_iters, lr_pose=lr_pose,
                          window_size=c['window_size'], initialised=self.initialised, optimiser="gn" if self.engine == "gn" else "adam", mode=mode,
                          rel_tol=c['map_rel_tol'])
-        torch.cuda.synchronize(); self.secs['supp_mapping' if mode == 'supp' else 'mapping'] += time.perf_counter() - t0
+        _sync(); self.secs['supp_mapping' if mode == 'supp' else 'mapping'] += time.perf_counter() - t0
         self.kf_poses = [p.clone() for p in out['kf_poses']]
         self.kf_klds = [k.clone() for k in out['klds']]
         if self.affine:
@@ -241,9 +247,9 @@ class MonoVO:
     def init_keyframe(self, i, info):
         # (``to_keyframe`` is the FRONTEND -- segmentation and per-segment depth shapes, out of the hot path's scope: its time is kept apart
         #  from the chain's 'keyframe' stage, which the caller's timer would otherwise charge it to)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _sync(); t0 = time.perf_counter()
         kf = self.to_keyframe(i)
-        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        _sync(); dt = time.perf_counter() - t0
         self.frontend_secs += dt
         self.secs['keyframe'] -= dt
         if len(self.kfs) < 2 and self.c['mono_init']:
@@ -284,7 +290,7 @@ class MonoVO:
         building the windows, the scheduled mapping, the new keyframe."""
         from .chain import CRITERION, SUPP, TRACK, ChainStep
         c, f = self.c, self.frames[i]
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _sync(); t0 = time.perf_counter()
         if self.chain is None:
             H, W = f.image.shape[-2:]
             self.chain = ChainStep(len(self.frames), H, W, c['track_levels'][1], self.dev)
@@ -357,7 +363,7 @@ class MonoVO:
             self.init_keyframe(i, (ch.depth, crit))
             self.reset_tracked_poses()
             self.reset_running_supp_kfs()
-            torch.cuda.synchronize()
+            _sync()
             self.mapping_scheduled = True
         self.secs['keyframe'] += time.perf_counter() - t0
         return new_kf, crit
@@ -366,14 +372,14 @@ class MonoVO:
         """The tail of one pass of the driver loop (odometery.py:1056-1075): keyframe decision, creation, what it schedules.  Returns
         (new keyframe?, the criterion's values or None)."""
         c = self.c
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _sync(); t0 = time.perf_counter()
         new_kf, info = self.is_kf(i)
         if new_kf:
             self.flush_tracked_poses_to_supp()
             self.init_keyframe(i, info)
             self.reset_tracked_poses()
             self.reset_running_supp_kfs()
-        torch.cuda.synchronize(); self.secs['keyframe'] += time.perf_counter() - t0
+        _sync(); self.secs['keyframe'] += time.perf_counter() - t0
         if new_kf:
             if not self.initialised:
                 self.mapping(c['init_steps'], mode='init')
