@@ -159,5 +159,6 @@ class ChainStep:
         _lib.check(rc, "sp_chain_step")
         for w in ((self.tracker.win,) if stages & TRACK else ()) + ((self.mapper.win,) if stages & SUPP else ()):
             w._gn.pop('host_stale', None)                # (the call left the pinned copy of the LM state current)
+            w._gn['host_seen'] = True
         crit = self.crit_host.tolist() if stages & CRITERION else None
         return st.track_iters, st.supp_iters, crit

@@ -370,7 +370,9 @@ def _map_window_fused(kfs, kf_poses, kf_klds, kf_affs, supp, num_iters, lr_pose,
         if gn['polish_max'] > 0 and num_iters > gn['max_iters'] // 2:      # (a short budget -- the supplementary mapping -- gets no polish)
             n += win.run_gn(0, gn['polish_max'], irls_eps=gn['polish_eps'], conv_tol=gn['polish_tol'])
         poses, affs, losses = win.node_poses(), win.node_affines(), win.gn_losses()
-        stopped, extra = n, dict(gn=win.gn_stats(), gn_profile=win.gn_profile())
+        stopped, extra = n, dict(gn=win.gn_stats())
+        if gn.get('profile', False):                               # (phase time stamps of the last update kernel: a read-back, diagnostics only)
+            extra['gn_profile'] = win.gn_profile()
     else:
         win.run(0, num_iters)
         poses, affs, losses = win.node_poses(), win.node_affines(), win.losses()

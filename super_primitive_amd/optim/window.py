@@ -127,6 +127,7 @@ class PoseWindow:
         for j, i in enumerate(with_aff):
             arr[i].aff = (ctypes.c_float * 2)(*affs[j])
         nodes_host = arr
+        self._all_kind0 = all(int(nd.get('kind', KIND_WINDOW)) == KIND_WINDOW for nd in nodes)
         # ---- target images: packed per level -------------------------------------------------------------------
         self.trg3, self.level_hw = {}, {}
         targets = sorted({e[1] for e in edges})
@@ -261,18 +262,27 @@ class PoseWindow:
             assert self.level_hw[(dst_node, l)] == self.level_hw[(src_node, l)]
             self.trg3[(dst_node, l)].copy_(self.trg3[(src_node, l)])
 
+    def _nodes_f32(self):
+        """The node array as (n_nodes, 44) floats ON THE DEVICE (SpWindowNode: T 0..15, a 16..21, m 22..27, v 28..33, aff 34..35, aff_m 36..37,
+        aff_v 38..39, lr_pose 40, lr_aff 41, kind / flags 42..43 as raw bits)."""
+        return self.nodes.view(torch.float32).view(self.n_nodes, 44)
+
     def set_nodes(self, updates):
         """updates: {node index: dict(T=(4,4) [, aff=(2,)])}: overwrite poses / affine pairs (tangents and Adam moments cleared), then
-        re-compose every edge's relative pose.  One small upload."""
-        arr = self._node_array()
-        for i, u in updates.items():
-            nd = arr[i]
-            nd.T = (ctypes.c_float * 16)(*u['T'].detach().float().cpu().numpy().reshape(16))
-            if u.get('aff') is not None:
-                nd.aff = (ctypes.c_float * 2)(*u['aff'].detach().float().cpu().numpy().reshape(2))
-            nd.a = (ctypes.c_float * 6)(); nd.m = (ctypes.c_float * 6)(); nd.v = (ctypes.c_float * 6)()
-            nd.aff_m = (ctypes.c_float * 2)(); nd.aff_v = (ctypes.c_float * 2)()
-        self.nodes.copy_(_upload_struct_array(arr, self.device))
+        re-compose every edge's relative pose.  On the device: the node array is neither read back nor uploaded (round 6; the host round
+        trip -- a synchronisation per pose -- was a third of a scheduled mapping's bookkeeping in the config-3 chain)."""
+        if not updates:
+            return
+        nf = self._nodes_f32()
+        ids = list(updates)
+        idx = torch.tensor(ids, dtype=torch.long).to(self.device, non_blocking=True)
+        nf[idx, :16] = torch.stack([updates[i]['T'].detach().to(self.device, torch.float32).reshape(16) for i in ids])
+        nf[idx, 16:34] = 0.0
+        nf[idx, 36:40] = 0.0
+        with_aff = [i for i in ids if updates[i].get('aff') is not None]
+        if with_aff:
+            ia = idx if len(with_aff) == len(ids) else torch.tensor(with_aff, dtype=torch.long).to(self.device, non_blocking=True)
+            nf[ia, 34:36] = torch.stack([updates[i]['aff'].detach().to(self.device, torch.float32).reshape(2) for i in with_aff])
         self.compose()
 
     def set_klds(self, klds):
@@ -307,12 +317,14 @@ class PoseWindow:
         gn['state'][0] = lam
         gn['state'][1] = -1.0
         gn['state_host'].zero_()
+        gn['host_seen'] = False
 
     def begin_gn_phase(self):
         """A new phase of a schedule (another pyramid level / IRLS epsilon): losses of different phases are not comparable, so
         the accept test and the convergence test start afresh; lambda and the iteration count carry over."""
         gn = self._gn_state()
         gn['state'].mul_(gn['phase_keep']).add_(gn['phase_set'])          # [1] = -1, [4] = [6] = 0 in two launches, no host value involved
+        gn['host_seen'] = False
 
     def gn_step(self, level, irls_eps=1e-3, pose_only=False, conv_tol=0.0, lm_up=8.0, lm_down=0.5, lm_min=1e-7):
         """One Gauss-Newton / LM iteration of the whole window at pyramid ``level`` (3 launches, nothing returns to the host):
@@ -355,13 +367,24 @@ class PoseWindow:
                                        self.max_iters, int(max_iters), int(check_every), gn['state_host'].data_ptr(), _lib.stream_ptr())
         if rc < 0:
             _lib.check(rc, "sp_window_gn_run")
+        gn['host_seen'] = int(max_iters) > 0            # (the run's last poll left the pinned copy current)
         return int(gn['state_host'][5]) - n0
 
+    def _gn_host_state(self):
+        """The 16-float LM state on the host: the pinned copy ``run_gn`` / ``sp_chain_step`` left behind when nothing has moved the device's
+        since (no read-back, no synchronisation), else a fresh copy."""
+        gn = self._gn_state()
+        if gn.get('host_stale', False) or not gn.get('host_seen', False):
+            gn['state_host'].copy_(gn['state'])
+            gn.pop('host_stale', None)
+            gn['host_seen'] = True
+        return gn['state_host']
+
     def gn_converged(self):
-        return bool(self._gn_state()['state'][6].item() != 0)
+        return bool(float(self._gn_host_state()[6]) != 0)
 
     def gn_iterations(self):
-        return int(self._gn_state()['state'][5].item())
+        return int(self._gn_host_state()[5])
 
     def gn_losses(self):
         gn = self._gn_state()
@@ -380,7 +403,7 @@ class PoseWindow:
         return out
 
     def gn_stats(self):
-        st = self._gn_state()['state'].cpu().numpy()
+        st = self._gn_host_state().numpy()
         return dict(lam=float(st[0]), accepted=int(st[2]), rejected=int(st[3]), iterations=int(st[5]), converged=bool(st[6]), failed_solves=int(st[8]),
                     too_many_unknowns=bool(st[9]))
 
@@ -449,6 +472,8 @@ class PoseWindow:
 
     def node_poses(self):
         """(n_nodes,4,4): kind 0 -> the folded-in pose T; kind 1 -> Exp(a) X."""
+        if self._all_kind0:                      # (tracking / mapping windows: the poses are a slice of the node array, no read-back)
+            return self._nodes_f32()[:, :16].reshape(self.n_nodes, 4, 4).clone()
         arr = self._node_array()
         out = []
         for nd in arr:
@@ -463,7 +488,7 @@ class PoseWindow:
         return torch.tensor([list(nd.a) for nd in self._node_array()], dtype=torch.float32, device=self.device)
 
     def node_affines(self):
-        return torch.tensor([list(nd.aff) for nd in self._node_array()], dtype=torch.float32, device=self.device)
+        return self._nodes_f32()[:, 34:36].clone()
 
     def klds(self):
         return [self.kld[self.n_off[k]: self.n_off[k + 1]].clone() for k in range(self.n_sources)]

@@ -226,7 +226,7 @@ def test_reference_extent_window_by_gauss_newton_reaches_the_minimiser_of_the_re
     n_kf, n_supp, n_run = (int(v) for v in gm["window"])
     frames, kfi, si, est, klds, affs, kfs, supp = _extent_window(int(gm["seed"]), n_kf, n_supp, n_run)
     out = map_window(kfs, [T(est[i]) for i in kfi], [T(k) for k in klds], [T(affs[i]) for i in kfi], supp, 40, window_size=5, initialised=True,
-                     optimiser="gn")
+                     optimiser="gn", gn_schedule=dict(profile=True))
     L = np.array([float(l) for l in out["losses"]])
     rot, tt, dd = _window_errors(out, gm["min_kf_poses"], gm["min_supp_poses"], gm["min_klds"])
     print(f"\nreference-extent window (112 camera unknowns) by Gauss-Newton: {out['stopped']} iterations ({out['gn']}), loss {L[0]:.7f} -> {L[-1]:.7f} "

@@ -57,7 +57,7 @@ def main():
                                 bgc = bga @ bgb
                     torch.cuda.synchronize() if not os.environ.get("SP_BG") else time.sleep(0.05)
                     t0 = time.perf_counter()
-                    out = map_window(kfs, poses, klds, affs, supp, iters, window_size=5, optimiser=opt)
+                    out = map_window(kfs, poses, klds, affs, supp, iters, window_size=5, optimiser=opt, gn_schedule=dict(profile=True) if opt == "gn" else None)
                     torch.cuda.current_stream().synchronize(); dt = time.perf_counter() - t0
                     torch.cuda.synchronize()
                 e = errors(out, frames, kfi, si)
