@@ -70,35 +70,45 @@ int first_level(const SpChainWindow& w) {
     return -1;
 }
 
-// fresh LM state, then the phases of the window's schedule; returns the iterations taken (device counter) or a negative error
-int run_phases(const SpChainWindow& w, void* stream) {
+// fresh LM state, then the phases of the window's schedule.  The loop of sp_window_gn_run with the polls that decide nothing left out: a look
+// at the state only BETWEEN the iterations of a phase (the last iteration of a phase is followed by the next phase whatever the state says), and
+// ONE asynchronous copy of the final state at the end (*state_pending: the caller synchronises before it reads the iteration count).
+int run_phases(const SpChainWindow& w, void* stream, bool* state_pending) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int l0 = first_level(w);
     if (l0 < 0 || !w.state_host || w.n_phases < 0 || w.n_phases > SP_CHAIN_PHASES || w.check_every <= 0) return SP_EINVAL;
     float* state = w.gn[l0].state;
     hipLaunchKernelGGL(k_chain_state, dim3(1), dim3(64), 0, s, state, w.lam0, 1);
-    for (int i = 0; i < SP_CHAIN_STATE; ++i) w.state_host[i] = 0.f;
     for (int p = 0; p < w.n_phases; ++p) {
         const SpChainPhase& ph = w.phase[p];
         if (ph.level < 0 || ph.level >= SP_CHAIN_LEVELS || !w.gn[ph.level].pairs) return SP_EINVAL;
         if (ph.max_iters <= 0) continue;
         const SpWindowGn& g = w.gn[ph.level];
         hipLaunchKernelGGL(k_chain_state, dim3(1), dim3(64), 0, s, state, 0.f, 0);
-        // (check_first: a first look after that many iterations, then every check_every as sp_window_gn_run does)
-        int done = 0;
-        const int first = (w.check_first > 0 && w.check_first < ph.max_iters && ph.conv_tol > 0.f) ? w.check_first : 0;
-        for (int leg = first ? 0 : 1; leg < 2; ++leg) {
-            const int n = leg == 0 ? first : ph.max_iters - done;
-            const int rc = sp_window_gn_run(g.pairs, g.chunks, g.spans, g.n_spans, ph.irls_eps, g.edges, g.n_edges, g.nodes, g.n_nodes, g.blocks, g.n_blocks,
-                                            g.sum_N, g.max_N, g.n_unknowns, g.span_partials, g.seg_partials, g.scratch, g.nodes_backup, g.kld_backup, w.flags,
-                                            w.lm_up, w.lm_down, w.lm_min, ph.conv_tol, g.state, g.losses, g.max_losses, n, leg == 0 ? first : w.check_every,
-                                            w.state_host, stream);
-            if (rc < 0) return rc;
-            done += rc;
-            if (ph.conv_tol > 0.f && static_cast<volatile float*>(w.state_host)[6] != 0.f) break;
+        int it = 0;
+        int look = (w.check_first > 0 && ph.conv_tol > 0.f) ? w.check_first : w.check_every;
+        while (it < ph.max_iters) {
+            const int n = (ph.max_iters - it) < look ? (ph.max_iters - it) : look;
+            for (int k = 0; k < n; ++k, ++it) {
+                int rc = sp_pairs_cost(g.pairs, g.chunks, g.spans, g.n_spans, 2, ph.irls_eps, g.span_partials, g.seg_partials, stream);
+                if (rc == 0)
+                    rc = sp_window_gn_step(g.pairs, g.edges, g.n_edges, g.nodes, g.n_nodes, g.blocks, g.n_blocks, g.sum_N, g.max_N, g.n_unknowns, g.span_partials,
+                                           g.seg_partials, g.scratch, g.nodes_backup, g.kld_backup, w.flags, w.lm_up, w.lm_down, w.lm_min, ph.conv_tol, g.state,
+                                           g.losses, g.max_losses, stream);
+                if (rc != 0) return rc < 0 ? rc : -(1000 + rc);
+            }
+            if (it >= ph.max_iters || !(ph.conv_tol > 0.f)) continue;          // (nothing to decide: the phase is over, or it has no convergence test)
+            hipError_t e = hipMemcpyAsync(w.state_host, state, SP_CHAIN_STATE * sizeof(float), hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipStreamSynchronize(s);
+            if (e != hipSuccess) return -(1000 + (int)e);
+            if (static_cast<volatile float*>(w.state_host)[6] != 0.f) break;
+            look = w.check_every;
         }
     }
-    return (int)static_cast<volatile float*>(w.state_host)[5];
+    const hipError_t e = hipMemcpyAsync(w.state_host, state, SP_CHAIN_STATE * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return -(1000 + (int)e);
+    *state_pending = true;
+    return 0;
 }
 
 }  // namespace
@@ -109,6 +119,7 @@ extern "C" int sp_chain_step(SpChainStep* st, void* stream) {
     const int stages = st->stages;
     if (stages & ~(SP_CHAIN_TRACK | SP_CHAIN_SUPP | SP_CHAIN_CRITERION)) return SP_EINVAL;
     if (st->n_levels < 1 || st->n_levels > SP_CHAIN_LEVELS || st->H <= 0 || st->W <= 0) return SP_EINVAL;
+    bool track_pending = false, supp_pending = false, synced = false;
     int Hl[SP_CHAIN_LEVELS], Wl[SP_CHAIN_LEVELS];
     Hl[0] = st->H; Wl[0] = st->W;
     for (int l = 1; l < SP_CHAIN_LEVELS; ++l) { Hl[l] = (Hl[l - 1] + 1) / 2; Wl[l] = (Wl[l - 1] + 1) / 2; }
@@ -133,9 +144,7 @@ extern "C" int sp_chain_step(SpChainStep* st, void* stream) {
         hipLaunchKernelGGL(k_chain_set_nodes, dim3(1), dim3(64), 0, s, g.nodes, 1, tg.node, tg.pose, tg.aff, 0, (const float*)nullptr, (const float*)nullptr);
         SP_CHECK_LAUNCH();
         if (int rc = sp_window_compose(g.pairs, g.edges, g.n_edges, g.nodes, g.n_nodes, stream)) return rc;
-        const int its = run_phases(w, stream);
-        if (its < 0) return its;
-        st->track_iters = its;
+        if (int rc = run_phases(w, stream, &track_pending)) return rc;
         hipLaunchKernelGGL(k_chain_read_node, dim3(1), dim3(64), 0, s, (const SpWindowNode*)g.nodes, tg.node, st->out_pose, st->out_aff);
         SP_CHECK_LAUNCH();
         if (int rc = sp_renormalise_se3(st->out_pose, 1, stream)) return rc;
@@ -166,9 +175,7 @@ extern "C" int sp_chain_step(SpChainStep* st, void* stream) {
         hipLaunchKernelGGL(k_chain_set_nodes, dim3(1), dim3(64), 0, s, g.nodes, 2, a.node, a.pose, a.aff, b.node, b.pose, b.aff);
         SP_CHECK_LAUNCH();
         if (int rc = sp_window_compose(g.pairs, g.edges, g.n_edges, g.nodes, g.n_nodes, stream)) return rc;
-        const int its = run_phases(w, stream);
-        if (its < 0) return its;
-        st->supp_iters = its;
+        if (int rc = run_phases(w, stream, &supp_pending)) return rc;
         if (st->kld_n > 0) {
             if (!st->kld_src || !st->kld_dst) return SP_EINVAL;
             hipError_t e = hipMemcpyAsync(st->kld_dst, st->kld_src, sizeof(float) * (size_t)st->kld_n, hipMemcpyDeviceToDevice, s);
@@ -187,6 +194,14 @@ extern "C" int sp_chain_step(SpChainStep* st, void* stream) {
         hipError_t e = hipMemcpyAsync(st->crit_host, st->crit, 4 * sizeof(float), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return (int)e;
+        synced = true;
     }
+    // the windows' final LM states were copied asynchronously: the iteration counts are read behind a synchronisation
+    if ((track_pending || supp_pending) && !synced) {
+        const hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (track_pending) st->track_iters = (int)static_cast<volatile float*>(st->track.state_host)[5];
+    if (supp_pending) st->supp_iters = (int)static_cast<volatile float*>(st->supp.state_host)[5];
     return 0;
 }
