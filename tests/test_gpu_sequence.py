@@ -427,7 +427,9 @@ def test_persistent_supplementary_mapping_window_equals_a_rebuilt_one():
     # (the timing is a printed diagnostic, not an assertion: ADVICE r05; what the persistent window must do is give the same chain)
 
 
-def test_one_call_per_frame_gives_the_chain_of_the_python_steps():
+@pytest.mark.parametrize("cfg", [dict(), dict(affine_compensation=False), dict(continual_steps=0), dict(window_size=3, supp_every_n=2)],
+                         ids=["reference extent", "no affine compensation", "no supplementary mapping", "window of 3"])
+def test_one_call_per_frame_gives_the_chain_of_the_python_steps(cfg):
     """``sp_chain_step`` (include/sp_hip.h; odometery/chain.py) -- tracking, the supplementary mapping against the two
     running supporting frames and the keyframe criterion of one frame as ONE foreign call with the state on the device -- against the
     step-by-step Python driver (``native_step=False``: ``GnTracker.track`` -> ``GnSuppMapper`` -> ``is_kf``, odometery/odometery.py:1018-1075):
@@ -439,11 +441,12 @@ def test_one_call_per_frame_gives_the_chain_of_the_python_steps():
     run_sequence(frames[:4], to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn")
     outs = {}
     for native in (False, True):
-        outs[native] = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn", translation_thresh=0.095, window_size=5,
-                                    depth_of=lambda i: T(seq[i].kld_gt), native_step=native)
+        outs[native] = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn", depth_of=lambda i: T(seq[i].kld_gt), native_step=native,
+                                    **dict(dict(translation_thresh=0.095, window_size=5), **cfg))
     a, b = outs[False], outs[True]
     assert a["all_kf_ids"] == b["all_kf_ids"] and a["supp_ids"] == b["supp_ids"], (a["all_kf_ids"], b["all_kf_ids"])
-    assert a["n_supp_mappings"] == b["n_supp_mappings"] == n - 1 and a["n_mappings"] == b["n_mappings"]
+    assert a["n_supp_mappings"] == b["n_supp_mappings"] == (0 if cfg.get("continual_steps", 10) == 0 else n - 1) and a["n_mappings"] == b["n_mappings"]
+    assert len(a["all_kf_ids"]) >= 3
     dp = float((a["track_poses"] - b["track_poses"]).abs().max()), float((a["kf_poses"] - b["kf_poses"]).abs().max())
     dk = max(float((x - y).abs().max()) for x, y in zip(a["kf_klds"], b["kf_klds"]))
     sa, sb = a["seconds"], b["seconds"]
