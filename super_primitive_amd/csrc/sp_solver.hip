@@ -371,9 +371,13 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
     int n_active = 0;
     const uint32_t adam_mask = adam_phases(sched);
     uint32_t occupied = 1u << sched->entry;           // (what the last poll saw; before the first one every slot is at the entry)
+    uint32_t seen = 0;                                // ... without the entry's bit: where the busy slots really are
     while (it < max_rounds) {
-        const int n = (max_rounds - it) < check_every ? (max_rounds - it) : check_every;
         const bool tail = queue->active && n_active > 0 && 8 * n_active <= n_slots;
+        // a tail of third attempts only -- every busy slot in an SP_PHASE_ADAM phase, hundreds of rounds from leaving it: the host looks in
+        // four times less often (a poll is a fifth of such a round's 25 us; finishing is noticed at most a dozen empty rounds late)
+        const int every = (tail && seen != 0 && (seen & ~adam_mask) == 0) ? 4 * check_every : check_every;
+        const int n = (max_rounds - it) < every ? (max_rounds - it) : every;
         const uint32_t idle = adam_mask & ~occupied;
         GnArgs ga{max_N, lm_up, lm_down, lm_min, lm_state, backup, costs, 0.f, nullptr, phase, iters, 0, 0, 0};
         ga.idle_mask = idle;
@@ -392,7 +396,8 @@ int sp_pairs_schedule_run_queue(const SpSchedule* sched, const SpQueue* queue, i
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e != hipSuccess) return -(1000 + (int)e);
         min_phase = static_cast<volatile int32_t*>(flag_host)[0];
-        occupied = (uint32_t)static_cast<volatile int32_t*>(flag_host)[4] | (1u << sched->entry);      // (a refilled slot starts at the entry)
+        seen = (uint32_t)static_cast<volatile int32_t*>(flag_host)[4];
+        occupied = seen | (1u << sched->entry);           // (a refilled slot starts at the entry)
         const int head = static_cast<volatile int32_t*>(flag_host)[1];
         n_active = head >= queue->n_queue ? static_cast<volatile int32_t*>(flag_host)[3] : 0;       // (while pairs wait, every slot is busy)
         const bool first_attempts_left = static_cast<volatile int32_t*>(flag_host)[2] != 0;
