@@ -97,6 +97,7 @@ int sp_blur_decimate(const float* in, int C, int H, int W, float* out, void* str
  *   sp_prepare_fill  : pix / baseL at seg_off[n] + rank inside the segment; kp_L[N] where kp_L != NULL
  *   sp_prepare_blur  : one pyramid step (sp_blur_decimate) of every job image
  *   sp_prepare_pack  : planar (3,H,W) -> HWC3 of every job image
+ *   sp_prepare_blur_pack: both at once for three-channel images (the target frames)
  *   sp_prepare_gather: n small float vectors, one DEVICE pointer each (src[i], off[i + 1] - off[i] floats), into one flat array
  *                      (out + off[i]); src and off are device arrays.  What the host side otherwise does with one torch.cat /
  *                      torch.stack over hundreds of per-pair tensors (the intrinsics and initial log-depths of a batch: 0.7 us of
@@ -165,6 +166,17 @@ int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int m
 int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream);
 int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixels, void* stream);
 int sp_prepare_pack(const SpPrepImage* jobs, int n_jobs, int max_pixels, void* stream);
+/* One pyramid step of THREE-CHANNEL images together with their packed forms (ABI 14): what sp_prepare_blur followed by sp_prepare_pack
+ * computes, bit for bit, without the packing pass's re-read of the planar levels.  out (planar level l + 1), packed_out (level l + 1 as
+ * HWC3) and packed_in (level l as HWC3) may each be NULL. */
+typedef struct SpPrepImagePack {
+    const float* in;             /* (3,H,W) planar, level l */
+    float* out;
+    float* packed_in;
+    float* packed_out;
+    int32_t H, W;
+} SpPrepImagePack;               /* 40 bytes */
+int sp_prepare_blur_pack(const SpPrepImagePack* jobs, int n_jobs, int max_out_pixels, void* stream);
 int sp_prepare_gather(const float* const* src, const long long* off, int n, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------

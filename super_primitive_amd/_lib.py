@@ -39,6 +39,7 @@ SIGNATURES = {
     "sp_prepare_sample": [P, I, I, P],
     "sp_prepare_blur": [P, I, I, I, P],
     "sp_prepare_pack": [P, I, I, P],
+    "sp_prepare_blur_pack": [P, I, I, P],
     "sp_prepare_gather": [P, P, I, P, P],
     "sp_host_work_list_chunks": [P, I, I, I],
     "sp_host_layout": [P, I, I, P, I, I, P, P, P, P, P],
@@ -134,6 +135,11 @@ class SpPrepSample(ctypes.Structure):
 
 class SpPrepImage(ctypes.Structure):
     _fields_ = [("inp", c_void_p), ("out", c_void_p), ("H", c_int), ("W", c_int)]
+
+
+class SpPrepImagePack(ctypes.Structure):
+    """Mirror of ``struct SpPrepImagePack`` (include/sp_hip.h): a pyramid step with the packed forms of its input / output level; 40 bytes."""
+    _fields_ = [("inp", c_void_p), ("out", c_void_p), ("packed_in", c_void_p), ("packed_out", c_void_p), ("H", c_int), ("W", c_int)]
 
 
 class SpPhase(ctypes.Structure):

@@ -1093,6 +1093,90 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_blur(const SpPrepImage* __res
     for (int o = i; o < Ho * Wo; o += n_threads) out[o] = blur_decimate_at(generic(in), j.H, j.W, Wo, o);
 }
 
+// One pyramid step of a batch of THREE-CHANNEL images AND their packed (HWC3) forms in the same pass (round 6): the target frames of a
+// batch are blurred level by level and every level is also packed for the cost kernel -- as two passes the packing re-reads what the pyramid
+// step has just had in registers (12 B per pixel and level of the set-up's traffic, one launch).  A thread makes two neighbouring outputs of
+// all three channels exactly like k_prep_blur (same loads, products and summation order) and, from the same registers, writes
+//   out        planar level l + 1 (may be NULL: nobody blurs the last level further)
+//   packed_out level l + 1 packed (or NULL)
+//   packed_in  level l packed (or NULL): rows 2 yo, 2 yo + 1, columns 4 t .. 4 t + 3 -- the 2 x 4 pixels of its 3 x 5 window that no other thread owns
+// Pure copies and the same fused multiply-adds: bit-identical to sp_prepare_blur followed by sp_prepare_pack.
+struct PrepImagePack {
+    const SP_GLOBAL float* in;
+    SP_GLOBAL float* out;
+    SP_GLOBAL float* packed_in;
+    SP_GLOBAL float* packed_out;
+    int32_t H, W;
+};
+static_assert(sizeof(PrepImagePack) == sizeof(SpPrepImagePack), "device view of the job record");
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_blur_pack(const SpPrepImagePack* __restrict__ jobs) {
+    const PrepImagePack& j = reinterpret_cast<const PrepImagePack*>(jobs)[blockIdx.z];
+    const int H = j.H, W = j.W, Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t HW = (size_t)H * W, HWo = (size_t)Ho * Wo;
+    const int i = blockIdx.x * SP_BLOCK + threadIdx.x;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    if ((W & 3) == 0 && ((uintptr_t)j.in & 15) == 0 && ((uintptr_t)j.out & 7) == 0 && ((uintptr_t)j.packed_in & 15) == 0 && ((uintptr_t)j.packed_out & 7) == 0) {
+        const int half = Wo >> 1;
+        if (i >= Ho * half) return;
+        const int yo = i / half, t = i - yo * half;
+        const float wgt[3] = {1.f, 2.f, 1.f};
+        float a0[3] = {0.f, 0.f, 0.f}, a1[3] = {0.f, 0.f, 0.f};
+        float4 own[2][3];                                   // rows 2 yo and 2 yo + 1 of the window, per channel
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const SP_GLOBAL float* in = j.in + c * HW;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const SP_GLOBAL float* row = in + (size_t)reflect1(2 * yo + dy - 1, H) * W;
+                const float4 v = load4((const SP_GLOBAL f32x4*)(row + 4 * t));
+                const float left = row[max(4 * t - 1, 0)];
+                const float c0 = t > 0 ? left : v.y;            // column -1 reflects onto column 1
+                const float w0 = wgt[dy] * wgt[0] * (1.f / 16.f), w1 = wgt[dy] * wgt[1] * (1.f / 16.f), w2 = wgt[dy] * wgt[2] * (1.f / 16.f);
+                a0[c] = fmaf(w0, c0, a0[c]);  a0[c] = fmaf(w1, v.x, a0[c]);  a0[c] = fmaf(w2, v.y, a0[c]);
+                a1[c] = fmaf(w0, v.y, a1[c]); a1[c] = fmaf(w1, v.z, a1[c]);  a1[c] = fmaf(w2, v.w, a1[c]);
+                if (dy > 0) own[dy - 1][c] = v;
+            }
+        }
+        if (j.out) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const f32x2 o = {a0[c], a1[c]};
+                *(SP_GLOBAL f32x2*)(j.out + c * HWo + (size_t)yo * Wo + 2 * t) = o;
+            }
+        }
+        if (j.packed_out) {                                 // two texels = 24 contiguous bytes
+            SP_GLOBAL f32x2* q = (SP_GLOBAL f32x2*)(j.packed_out + ((size_t)yo * Wo + 2 * t) * SP_TEXEL_FLOATS);
+            const f32x2 q0 = {a0[0], a0[1]}, q1 = {a0[2], a1[0]}, q2 = {a1[1], a1[2]};
+            q[0] = q0; q[1] = q1; q[2] = q2;
+        }
+        if (j.packed_in) {                                  // four texels of each owned row = 48 contiguous bytes
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int y = 2 * yo + r;
+                if (y >= H) break;                          // (odd H: the window's last row is a reflection, nobody's own)
+                const float4 R = own[r][0], G = own[r][1], B = own[r][2];
+                SP_GLOBAL f32x4* q = (SP_GLOBAL f32x4*)(j.packed_in + ((size_t)y * W + 4 * t) * SP_TEXEL_FLOATS);
+                store4(q, make_float4(R.x, G.x, B.x, R.y));
+                store4(q + 1, make_float4(G.y, B.y, R.z, G.z));
+                store4(q + 2, make_float4(B.z, R.w, G.w, B.w));
+            }
+        }
+        return;
+    }
+    // other shapes: an output / a texel per thread and trip
+    const int n_threads = gridDim.x * SP_BLOCK;
+    for (int o = i; o < Ho * Wo; o += n_threads) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = blur_decimate_at(generic(j.in) + c * HW, H, W, Wo, o);
+            if (j.out) j.out[c * HWo + o] = v;
+            if (j.packed_out) j.packed_out[(size_t)o * SP_TEXEL_FLOATS + c] = v;
+        }
+    }
+    if (j.packed_in)
+        for (int o = i; o < H * W; o += n_threads) pack_texel(generic(j.in), H * W, o, generic(j.packed_in));
+}
+
 // many small float vectors (one pointer each) -> one flat array: out[off[i] .. off[i + 1]) = src[i][0 .. off[i + 1] - off[i])
 __global__ __launch_bounds__(64) void k_prep_gather(const float* const* __restrict__ src, const long long* __restrict__ off, float* __restrict__ out) {
     const float* p = src[blockIdx.x];
@@ -1215,6 +1299,14 @@ int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixe
     if (!jobs || check_grid(max_out_pixels, n_jobs) || C <= 0 || C > 65535) return SP_EINVAL;
     const int threads = (max_out_pixels + 1) / 2;          // (k_prep_blur: two outputs per thread)
     hipLaunchKernelGGL(k_prep_blur, dim3((threads + SP_BLOCK - 1) / SP_BLOCK, C, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_prepare_blur_pack(const SpPrepImagePack* jobs, int n_jobs, int max_out_pixels, void* stream) {
+    if (!jobs || check_grid(max_out_pixels, n_jobs)) return SP_EINVAL;
+    const int threads = (max_out_pixels + 1) / 2;          // (two outputs of three channels per thread)
+    hipLaunchKernelGGL(k_prep_blur_pack, dim3((threads + SP_BLOCK - 1) / SP_BLOCK, 1, n_jobs), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs);
     SP_CHECK_LAUNCH();
     return 0;
 }

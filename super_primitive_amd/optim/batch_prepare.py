@@ -259,6 +259,7 @@ class PreparedTables:
 
 
 _TABLE_DT, _SAMPLE_DT, _IMAGE_DT = np.dtype(_lib.SpPrepTable), np.dtype(_lib.SpPrepSample), np.dtype(_lib.SpPrepImage)
+_IMAGE_PACK_DT = np.dtype(_lib.SpPrepImagePack)
 
 
 _TORCH_OF = {np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32, np.dtype(np.uint8): torch.uint8}
@@ -435,39 +436,51 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     timer.mark('image handles')
     simg_ptr = frec['image']
     max_level = max(level_ids)
-    pyramid, blur_jobs = [], []
-    ptr_lv = {0: (simg_ptr, timg_ptr)}                                          # level -> (source, target) image pointers
+    # (Round 6: ONE pass per pyramid step makes the next level of both frames AND the packed forms of the target's levels
+    #  (sp_prepare_blur_pack): as a separate pass the packing re-read every planar target level the step had just had in registers --
+    #  12 B per target pixel and level and a launch; bit-identical.  A batch without a pyramid (one level) still packs by sp_prepare_pack.)
     hw = {0: np.stack((Hs, Ws), axis=1)}
     for l in range(1, max_level + 1):
         hw[l] = (hw[l - 1] + 1) // 2
+    trg, packed_ptr = {}, {}
+    for l in level_ids:
+        sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
+        off = np.concatenate(([0], np.cumsum(sizes)))
+        buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
+        packed_ptr[l] = buf.data_ptr() + 4 * off[:-1]
+        trg[l] = (buf, off, hw[l])                   # (flat packed targets, their offsets, (M0, 2) level sizes)
+    pyramid, blur_jobs = [], []
+    ptr_lv = {0: (simg_ptr, timg_ptr)}                                          # level -> (source, target) image pointers
+    for l in range(1, max_level + 1):
         sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
         off = np.concatenate(([0], np.cumsum(np.tile(sizes, 2))))
         buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
-        jobs = np.zeros(2 * M0, dtype=_IMAGE_DT)
+        jobs = np.zeros(2 * M0, dtype=_IMAGE_PACK_DT)
         jobs['inp'] = np.concatenate(ptr_lv[l - 1])
         jobs['out'] = buf.data_ptr() + 4 * off[:-1]
         jobs['H'], jobs['W'] = np.tile(hw[l - 1][:, 0], 2), np.tile(hw[l - 1][:, 1], 2)
         ptr_lv[l] = (jobs['out'][:M0].copy(), jobs['out'][M0:].copy())
+        if l in packed_ptr:
+            jobs['packed_out'][M0:] = packed_ptr[l]
+        if l == 1 and 0 in packed_ptr:
+            jobs['packed_in'][M0:] = packed_ptr[0]
+        if l == max_level:
+            jobs['out'][M0:] = 0                     # (nothing reads the targets' last planar level)
         blur_jobs.append(jobs)
         pyramid.append(buf)                  # read by later launches: must not return to the allocator before they are enqueued
-    trg = {}
-    pack_jobs = np.zeros(len(level_ids) * M0, dtype=_IMAGE_DT)
-    for li, l in enumerate(level_ids):
-        sizes = 3 * hw[l][:, 0] * hw[l][:, 1]
-        off = np.concatenate(([0], np.cumsum(sizes)))
-        buf = torch.empty(int(off[-1]), dtype=torch.float32, device=dev)
-        jb = pack_jobs[li * M0: (li + 1) * M0]
-        jb['inp'], jb['out'] = ptr_lv[l][1], buf.data_ptr() + 4 * off[:-1]
-        jb['H'], jb['W'] = hw[l][:, 0], hw[l][:, 1]
-        trg[l] = (buf, off, hw[l])                   # (flat packed targets, their offsets, (M0, 2) level sizes)
+    pack_jobs = np.zeros(M0 if max_level == 0 else 0, dtype=_IMAGE_DT)
+    if max_level == 0:
+        pack_jobs['inp'], pack_jobs['out'] = timg_ptr, packed_ptr[0]
+        pack_jobs['H'], pack_jobs['W'] = hw[0][:, 0], hw[0][:, 1]
     staged = stage([pack_jobs] + blur_jobs, dev)
     timer.mark('pyramid jobs staged')
-    with timer('pyramid'):
-        for l in range(1, max_level + 1):
-            _lib.check(lib.sp_prepare_blur(_lib.ptr(staged[l]), 2 * M0, 3, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur")
-    with timer('pack'):
-        _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), len(level_ids) * M0, int((hw[min(level_ids)][:, 0] * hw[min(level_ids)][:, 1]).max()), s_ptr),
-                   "sp_prepare_pack")
+    if max_level > 0:
+        with timer('pyramid'):
+            for l in range(1, max_level + 1):
+                _lib.check(lib.sp_prepare_blur_pack(_lib.ptr(staged[l]), 2 * M0, int((hw[l][:, 0] * hw[l][:, 1]).max()), s_ptr), "sp_prepare_blur_pack")
+    else:
+        with timer('pack'):
+            _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), M0, int((hw[0][:, 0] * hw[0][:, 1]).max()), s_ptr), "sp_prepare_pack")
 
     # ---- host: padded layouts; device: fill straight into them ----
     timer.mark('wait for counts')
@@ -586,8 +599,10 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
             'fill': (4 * sum(n_pts.values()) + n_pts[1] // 4) if dense_L else (4 * n_pts[1] + 8 * sum(n_pts.values()) + n_pts[1] // 4),
             'sample': sum((12 + 16 * len(lv)) * n_pts[s] for s, lv in levels_of.items())     # pix + baseL in, pix out, one src4 per sampled level out
                       + sum(12 * img_px[l] for l in sampled_levels),                         # ... and every sampled source level read once
-            'pyramid': sum(2 * 12 * (img_px[l - 1] + img_px[l]) for l in range(1, max_level + 1)),      # both frames: level l-1 in, level l out
-            'pack': sum(2 * 12 * img_px[l] for l in level_ids),                              # targets: planar in, HWC3 out
+            # both frames: level l-1 in, level l out (the targets' last planar level is not written); + the targets' packed levels out
+            'pyramid': (sum(2 * 12 * (img_px[l - 1] + img_px[l]) for l in range(1, max_level + 1)) - (12 * img_px[max_level] if max_level > 0 else 0)
+                        + (sum(12 * img_px[l] for l in level_ids) if max_level > 0 else 0)),
+            'pack': sum(2 * 12 * img_px[l] for l in level_ids) if max_level == 0 else 0,     # (a batch without a pyramid: planar in, HWC3 out)
         }
 
     del pyramid

@@ -200,3 +200,47 @@ def test_idempotence_properties():
     assert torch.equal(a.baseL, src.logdepth_perseg[seg, row, col])
     counts = torch.bincount(seg, minlength=9)
     assert torch.equal(a.seg_off[1:].long() - a.seg_off[:-1].long(), counts)
+
+
+@pytest.mark.parametrize("H,W", [(480, 640), (45, 52), (33, 50), (2, 4)])
+def test_fused_pyramid_step_and_packing_equals_the_two_passes(H, W):
+    """Round 6 (set-up): ``sp_prepare_blur_pack`` -- one pyramid step of three-channel images together with the packed forms of its input and output
+    levels -- against ``sp_prepare_blur`` followed by ``sp_prepare_pack``: bit for bit, on the 16-byte fast path (W a multiple of 4, even and odd
+    H), on the general path, and with each optional output left out."""
+    from super_primitive_amd import _lib
+    from super_primitive_amd.optim.batch_prepare import stage
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(H * 1000 + W)
+    imgs = [torch.rand(3, H, W, generator=g).to(dev) for _ in range(3)]
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    s = _lib.stream_ptr()
+    # the two passes
+    want_out = [torch.empty(3, Ho, Wo, device=dev) for _ in imgs]
+    want_pin = [torch.empty(H, W, 3, device=dev) for _ in imgs]
+    want_pout = [torch.empty(Ho, Wo, 3, device=dev) for _ in imgs]
+    jb = np.zeros(len(imgs), dtype=np.dtype(_lib.SpPrepImage))
+    jb['inp'], jb['out'], jb['H'], jb['W'] = [t.data_ptr() for t in imgs], [t.data_ptr() for t in want_out], H, W
+    jp = np.zeros(2 * len(imgs), dtype=np.dtype(_lib.SpPrepImage))
+    jp['inp'] = [t.data_ptr() for t in imgs] + [t.data_ptr() for t in want_out]
+    jp['out'] = [t.data_ptr() for t in want_pin] + [t.data_ptr() for t in want_pout]
+    jp['H'], jp['W'] = [H] * 3 + [Ho] * 3, [W] * 3 + [Wo] * 3
+    st = stage([jb, jp], dev)
+    _lib.check(lib.sp_prepare_blur(_lib.ptr(st[0]), 3, 3, Ho * Wo, s), "sp_prepare_blur")
+    _lib.check(lib.sp_prepare_pack(_lib.ptr(st[1]), 6, H * W, s), "sp_prepare_pack")
+    # the fused pass: job 0 everything, job 1 without the planar output, job 2 without the packed forms
+    out = [torch.full((3, Ho, Wo), -1.0, device=dev) for _ in imgs]
+    pin = [torch.full((H, W, 3), -1.0, device=dev) for _ in imgs]
+    pout = [torch.full((Ho, Wo, 3), -1.0, device=dev) for _ in imgs]
+    jf = np.zeros(len(imgs), dtype=np.dtype(_lib.SpPrepImagePack))
+    jf['inp'], jf['H'], jf['W'] = [t.data_ptr() for t in imgs], H, W
+    jf['out'] = [out[0].data_ptr(), 0, out[2].data_ptr()]
+    jf['packed_in'] = [pin[0].data_ptr(), pin[1].data_ptr(), 0]
+    jf['packed_out'] = [pout[0].data_ptr(), pout[1].data_ptr(), 0]
+    sf = stage([jf], dev)
+    _lib.check(lib.sp_prepare_blur_pack(_lib.ptr(sf[0]), 3, Ho * Wo, s), "sp_prepare_blur_pack")
+    torch.cuda.synchronize()
+    for k, (has_out, has_packed) in enumerate(((True, True), (False, True), (True, False))):
+        assert torch.equal(out[k], want_out[k]) if has_out else bool((out[k] == -1.0).all())
+        assert torch.equal(pin[k], want_pin[k]) if has_packed else bool((pin[k] == -1.0).all())
+        assert torch.equal(pout[k], want_pout[k]) if has_packed else bool((pout[k] == -1.0).all())
