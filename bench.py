@@ -43,6 +43,45 @@ HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s mea
 H, W = 480, 640
 
 
+def config3_chain_leg(dev, n=64):
+    """The odometry chain of BASELINE configs[2] on a synthetic sequence (a textured plane, smooth trajectory with jitter; keyframes every ~8
+    frames): tracking, supplementary mapping, keyframe criterion per frame in ONE foreign call (sp_chain_step), scheduled mappings and new
+    keyframes in between.  Frames and keyframe inputs are resident before the clock starts; the frontend's share (building a KeyFrame
+    object from resident arrays) is reported apart."""
+    from super_primitive_amd import synth
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.odometery.sequence import run_sequence
+    rng = np.random.default_rng(31)
+    base = 0.6 * np.array([0.05, -0.02, 0.015, 0.003, -0.0045, 0.0024])
+    twists = [k * base + 0.003 * rng.standard_normal(6) * (k > 0) for k in range(n)]
+    seq = synth.make_sequence(224, 288, 40, twists, keyframe_ids=list(range(n)), seed=31, overlap=1)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    frames = [KeyFrame(T(f.image), T(f.K)) for f in seq]
+    res = [(T(f.image), T(f.K), T(f.logdepth_perseg), T(f.keypoints), T(f.keypoint_regions)) for f in seq]
+    to_kf = lambda i: KeyFrame(*res[i])
+    kw = dict(engine="gn", translation_thresh=0.095, window_size=5, depth_of=lambda i: T(seq[i].kld_gt))
+    run_sequence(frames[:4], to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), engine="gn")
+    run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **kw)
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = run_sequence(frames, to_kf, T(seq[0].T_wc), T(seq[0].kld_gt), **kw)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, out)
+    dt, out = best
+    P = out["track_poses"].double().cpu().numpy()
+    G = np.stack([f.T_wc for f in seq]).astype(np.float64)
+    sc = float((P[:, :3, 3] * G[:, :3, 3]).sum() / max((P[:, :3, 3] ** 2).sum(), 1e-30))
+    rot = max(float(np.arccos(np.clip((np.trace(a[:3, :3].T @ b[:3, :3]) - 1) / 2, -1, 1))) for a, b in zip(P, G))
+    return {"frames": n, "frames_per_sec": (n - 1) / dt, "frames_per_sec_by_stage_timers": (n - 1) / sum(out["seconds"].values()),
+            "ms_per_frame_by_stage": {k: 1e3 * v / (n - 1) for k, v in out["seconds"].items()}, "frontend_ms_per_frame": 1e3 * out["frontend_seconds"] / (n - 1),
+            "keyframes": len(out["all_kf_ids"]), "scheduled_mappings": out["n_mappings"], "supplementary_mappings": out["n_supp_mappings"],
+            "worst_rotation_error_rad": rot, "worst_translation_error_scale_aligned": float(np.abs(sc * P[:, :3, 3] - G[:, :3, 3]).max()),
+            "what": "MonoVO chain, Gauss-Newton engine, 224 x 288 x 40 segments, window 5, two supporting frames per keyframe, supplementary mapping after every "
+                    "frame; wall clock over the whole sequence (best of 3), frames and keyframe inputs resident"}
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -982,6 +1021,12 @@ def main(argv=None):
                         del b2
                         torch.cuda.empty_cache()
                     line["roofline_by_shape"] = by_shape
+                    # (g) BASELINE configs[2] as a sequence: 64 frames through the MonoVO chain (odometery/sequence.py, engine 'gn': one foreign call
+                    #     per frame, sp_chain_step), synthetic plane, 224 x 288, 40 segments -- tools/chain_profile.py's workload
+                    try:
+                        line["config3_chain"] = config3_chain_leg(dev)
+                    except Exception as exc:           # (a side measurement: the headline line does not depend on it)
+                        line["config3_chain"] = {"error": repr(exc)}
                 line["frame_pairs_per_sec_what"] = ("reference start (pose T_gt Exp(0.05 randn), depth seeds log(2 + 2 rand), multi-octave texture), "
                                                     "REFERENCE_START_SCHEDULE, slot-level continuous batching on one stream; frame_pairs_per_sec_near_start = "
                                                     "round 3's sigma-0.004 figure")
