@@ -131,11 +131,13 @@ class ChainStep:
             img = image[:3].detach().float().contiguous()
             assert img.shape[-2:] == (self.H, self.W) and img.device == self.hist_pose.device
             sp = start_pose.detach().float().contiguous()
+            assert sp.device == self.hist_pose.device and sp.numel() == 16, "the start pose lives on the chain's device"
             keep += [img, sp]
             st.image = img.data_ptr()
             st.track_target.pose = sp.data_ptr()
             if self.affine:
                 sa = start_aff.detach().float().contiguous()
+                assert sa.device == self.hist_pose.device and sa.numel() == 2
                 keep.append(sa)
                 st.track_target.aff = sa.data_ptr()
                 st.out_aff = self.hist_aff[i].data_ptr()
@@ -144,6 +146,7 @@ class ChainStep:
             st.out_pose = self.hist_pose[i].data_ptr()
         elif stages & CRITERION:
             p = pose.detach().float().contiguous()
+            assert p.device == self.hist_pose.device and p.numel() == 16
             keep.append(p)
             st.out_pose = p.data_ptr()
         if stages & SUPP:
