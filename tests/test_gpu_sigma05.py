@@ -203,7 +203,7 @@ def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
     # round 6 flagged after all three attempts, through the real reference loop)
     paths += sorted(glob.glob(os.path.join(GOLDEN, "g20z_sigma05_sam_pair*.npz")))
     sched = {k: v for k, v in REFERENCE_START_SCHEDULE.items() if k != "check_every"}
-    n_conv = n_third = n_yardstick = 0
+    n_conv = n_third = n_yardstick = n_beyond = 0
     for path in paths:
         gx = np.load(path)
         ref_converged = bool(gx["converged"])
@@ -279,13 +279,16 @@ def test_ragged_masks_where_the_reference_converges_so_does_the_schedule():
                 else:
                     assert inside == (not flagged), (path, what, hex(st), e)
             else:
-                assert flagged, (path, what, hex(st), e_gt)
-                if what == "alone":
+                # the reference itself ends in the wrong basin from this start: what is asked is "home or flagged" (asserted above) -- the
+                # third attempt does bring some of them home (sam 3372 alone: 5e-6 rad from the ground truth where the reference ends 2.2e-2 away)
+                n_beyond += int(home and not flagged)
+                if flagged and what == "alone":
                     assert st & (_lib.SP_STATUS_SEGMENTS | _lib.SP_STATUS_DEPTH_RANGE | _lib.SP_STATUS_LAST_CAP | _lib.SP_STATUS_COST), hex(st)     # (by what the pair sees of itself)
             del batch
     # (with the predicted exit of round 6 every one of these comes home at its first or second attempt; the third attempt has its own test below)
     print(f"{n_conv} starts the reference converges from: all inside the bar with a clean status, {n_third} of them through the third attempt; "
-          f"{n_yardstick} start(s) the reference loses as well that a batch of ONE only flags with a yardstick of the cost (cost_bound)")
+          f"{n_yardstick} start(s) the reference loses as well that a batch of ONE only flags with a yardstick of the cost (cost_bound); "
+          f"{n_beyond} run(s) home, clean, from starts the reference does not converge from")
 
 
 def test_third_attempt_brings_home_what_two_gauss_newton_attempts_lose():
