@@ -396,10 +396,19 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     recs['boxes'] = np.where(fast, frec['boxes'], 0).astype(np.uint64)         # (the segment-box hint: fast path only)
     recs['logdepth'], recs['keypoints'] = frec['logdepth'], frec['keypoints']
     timer.mark('count records')
-    # the per-pair inputs: initial log-depths and target intrinsics (FIRST on the stream: the intrinsics come back to the host for the
-    # descriptors, and a copy enqueued behind the count and pyramid passes would make the host wait for those).  The intrinsics of
-    # both frames and the log-depths (one flat array, the optimisation variable) are collected by ONE gather launch each from the
-    # pointer lists -- torch.stack / torch.cat over hundreds of small tensors cost 0.7 us of interpreter time per tensor
+    staged = stage([recs], dev)
+    timer.mark('count launch')
+    with timer('count'):
+        _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
+    counts_pinned = torch.empty(nS * S, dtype=torch.int32, pin_memory=True)
+    counts_pinned.copy_(counts_d, non_blocking=True)
+    counts_ready = torch.cuda.Event()
+    counts_ready.record()
+    # the per-pair inputs: initial log-depths and target intrinsics -- behind the COUNT pass, which is launched first (round 6: the GPU waited
+    # 0.25 ms for the handles below before it got anything to do) and in front of the pyramids: the intrinsics come back to the host for the
+    # descriptors, which are built after the counts have arrived anyway; a copy enqueued behind the pyramid passes would make the host wait
+    # for those.  The intrinsics of both frames and the log-depths (one flat array, the optimisation variable) are collected by ONE gather
+    # launch from the pointer lists -- torch.stack / torch.cat over hundreds of small tensors cost 0.7 us of interpreter time per tensor
     kld_ptr, kld = handles(klds, dev)
     Ktrg_ptr, Ktrg = handles(trg_Ks, dev)
     timer.mark('kld / K handles')
@@ -421,14 +430,6 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     #  pyramid 0.82 -> 1.25, pack 0.68 -> 1.57, the whole set-up 5.94 -> 6.07 ms per 384 pairs (profiles/r06_setup_side_stream.txt).  The
     #  set-up as a whole runs at the rate the memory system sustains for its mix of reads and writes, 0.56-0.58 of the HBM peak; what is
     #  left to gain is in its BYTES, not in its scheduling.)
-    staged = stage([recs], dev)
-    timer.mark('count launch')
-    with timer('count'):
-        _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
-    counts_pinned = torch.empty(nS * S, dtype=torch.int32, pin_memory=True)
-    counts_pinned.copy_(counts_d, non_blocking=True)
-    counts_ready = torch.cuda.Event()
-    counts_ready.record()
 
     # image pyramids of both frames and packed targets: independent of the counts, enqueued right behind the count pass
     # (the first three channels of a contiguous (C, H, W) image start where the image starts: no slicing of images with extra channels)
