@@ -31,6 +31,8 @@ namespace {
 #define SP_WGN_MAX_Y (8 * SP_WGN_MAX_NODES)      // unknowns of the reduced camera system (6 per free pose + 2 per free affine pair)
 #define SP_WGN_LDS_Y 192         // ... of which LDS holds this many (packed lower triangle, fp64); larger systems go through global scratch
 #define SP_WGN_STATE 16
+#define SP_WGN_INLINE_REDUCE 0x100   // (internal flag bit, set by sp_window_gn_step: k_window_gn_update reduces the edges itself)
+#define SP_WGN_INLINE_EDGES 4        // ... for depth-less windows of at most this many edges
 
 __device__ __forceinline__ int tri8(int i, int j) { return i * 8 - i * (i - 1) / 2 + (j - i); }      // (i <= j) in the upper triangle of an 8x8
 
@@ -48,7 +50,9 @@ __device__ __forceinline__ void wgn_gcol(const double* __restrict__ Ad, int col,
 __device__ __forceinline__ void wgn_reduce_edge(const SpPair* __restrict__ pairs, const SpWindowEdge* __restrict__ edges,
                                                 const float* __restrict__ partials, const float* __restrict__ seg_partials,
                                                 double* __restrict__ scratch, int stride, double* __restrict__ Ad_all,
-                                                double* __restrict__ loc_all, int e) {
+                                                double* __restrict__ loc_all, int e, bool with_segments) {
+    // (callable from a workgroup of MORE than SP_BLOCK threads -- the update kernel's, when it reduces a depth-less window's edges itself:
+    //  the threads beyond SP_BLOCK only take part in the barriers and in the segment loop)
     constexpr int NV = SP_GNA_PARTIAL_FLOATS, NS = SP_GNA_SEG_FLOATS;
     __shared__ double sums[NV];
     __shared__ double red[(SP_BLOCK / NV) * NV];
@@ -94,7 +98,7 @@ __device__ __forceinline__ void wgn_reduce_edge(const SpPair* __restrict__ pairs
     }
     __syncthreads();
     if (threadIdx.x < 36) Ad_all[(size_t)e * 36 + threadIdx.x] = Ads[threadIdx.x];
-    {
+    if (threadIdx.x < SP_BLOCK) {
         // the edge's system in node coordinates: z_e = G [y_trg ; y_src], thread (li, lj) of the 16 x 16 block G^T H_z G (row-major), and
         // G^T b_z from the threads of column 0 -- the update kernel only scatters these into the camera system
         const int li = threadIdx.x >> 4, lj = threadIdx.x & 15;
@@ -118,8 +122,10 @@ __device__ __forceinline__ void wgn_reduce_edge(const SpPair* __restrict__ pairs
             loc[256 + li] = t;
         }
     }
+    // (the per-segment sums feed the Schur terms only: a step in which no depth may move -- flags bits 0 / 2 -- never reads them)
+    if (!with_segments) return;
     const float* sp = seg_partials + (size_t)pr.rec0 * NS;
-    for (int n = threadIdx.x; n < pr.N; n += SP_BLOCK) {
+    for (int n = threadIdx.x; n < pr.N; n += blockDim.x) {
         double c[8] = {0, 0, 0, 0, 0, 0, 0, 0}, D = 0.0, bd = 0.0;
         const int t0 = pr.seg_tile_off[n], t1 = pr.seg_tile_off[n + 1];
         for (int t = t0; t < t1; ++t) {              // summed in record order (fixed)
@@ -140,8 +146,8 @@ __device__ __forceinline__ void wgn_reduce_edge(const SpPair* __restrict__ pairs
 __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_reduce(const SpPair* __restrict__ pairs, const SpWindowEdge* __restrict__ edges,
                                                                const float* __restrict__ partials, const float* __restrict__ seg_partials,
                                                                double* __restrict__ scratch, int stride, double* __restrict__ Ad_all,
-                                                               double* __restrict__ loc_all) {
-    wgn_reduce_edge(pairs, edges, partials, seg_partials, scratch, stride, Ad_all, loc_all, blockIdx.x);
+                                                               double* __restrict__ loc_all, int with_segments) {
+    wgn_reduce_edge(pairs, edges, partials, seg_partials, scratch, stride, Ad_all, loc_all, blockIdx.x, with_segments != 0);
 }
 
 struct WGnArgs {
@@ -246,7 +252,7 @@ __device__ __forceinline__ int ltri_row(int t) {
 __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_reduce_multi(const WGnArgs* __restrict__ wins) {
     const WGnArgs& w = wins[blockIdx.z];
     if ((int)blockIdx.x >= w.n_edges) return;
-    wgn_reduce_edge(w.pairs, w.edges, w.span_partials, w.seg_partials, w.scratch, w.stride, w.Ad, w.loc, blockIdx.x);
+    wgn_reduce_edge(w.pairs, w.edges, w.span_partials, w.seg_partials, w.scratch, w.stride, w.Ad, w.loc, blockIdx.x, !(w.flags & 5));
 }
 
 __global__ __launch_bounds__(SP_BLOCK) void k_window_gn_schur(WGnArgs w, const WGnArgs* __restrict__ wins) {
@@ -505,6 +511,14 @@ __global__ __launch_bounds__(wgn_update_threads(LDS_Y)) void k_window_gn_update(
     const int tid = threadIdx.x;
     float* st = w.state;
     WGN_STAMP(0);
+    if constexpr (LDS_Y == 64) if (w.flags & SP_WGN_INLINE_REDUCE) {      // (the smallest instantiation only: the routine's LDS buffers come on top)
+        // a depth-less window of a few edges (the tracker's: one edge, eight unknowns): the edges' reductions HERE instead of in a launch of
+        // their own in front of this one -- same routine, same sums; a launch boundary less per iteration of a chain of small dependent launches
+        for (int e = 0; e < w.n_edges; ++e) {
+            wgn_reduce_edge(w.pairs, w.edges, w.span_partials, w.seg_partials, w.scratch, w.stride, w.Ad, w.loc, e, false);
+            __syncthreads();                  // (the routine's LDS buffers, before the next edge overwrites them)
+        }
+    }
     for (int i = tid; i < w.n_nodes; i += NTHR) aff_off[i] = wgn_node_flags(w.nodes[i]);
     for (int b = tid; b < w.n_blocks; b += NTHR) { const SpWindowBlock bq = w.blocks[b]; blk_off[b] = bq.lr > 0.f ? bq.N : -bq.N; }
     const double loss_now = wgn_loss_sum<64>(w, tid, g);
@@ -1073,8 +1087,14 @@ int sp_window_gn_step(const SpPair* pairs, const SpWindowEdge* edges, int n_edge
         return rc;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int stride = w.stride;
-    hipLaunchKernelGGL(k_window_gn_reduce, dim3(n_edges), dim3(SP_BLOCK), 0, s, pairs, edges, span_partials, seg_partials, scratch, stride, w.Ad, w.loc);
-    SP_CHECK_LAUNCH();
+    // (no depth moves and a handful of edges -- the tracker: the update kernel reduces them itself, one launch less per iteration)
+    const bool inline_reduce = (flags & 5) && n_edges <= SP_WGN_INLINE_EDGES && n_unknowns <= 64 && !getenv("SP_WGN_NO_INLINE");
+    if (inline_reduce) w.flags |= SP_WGN_INLINE_REDUCE;
+    else {
+        hipLaunchKernelGGL(k_window_gn_reduce, dim3(n_edges), dim3(SP_BLOCK), 0, s, pairs, edges, span_partials, seg_partials, scratch, stride, w.Ad, w.loc,
+                           (flags & 5) ? 0 : 1);
+        SP_CHECK_LAUNCH();
+    }
     const int tiles = max(1, (w.lds + SP_BLOCK * SP_WGN_PPT - 1) / (SP_BLOCK * SP_WGN_PPT));
     const WGnArgs* none = nullptr;
     if (!(flags & 5)) {                // (flags bit 0 / bit 2: no depth moves -- every Schur term is zero and the update kernel does not read them)
