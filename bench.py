@@ -155,7 +155,7 @@ def _render_sigma05(a):
     return synth.make_pair(H, W, a[0], seed=a[1], init_sigma=0.05, texture="octaves", init_mode="reference", **shape_kw)
 
 
-def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue_factor=4, slot_only=False):
+def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue_factor=4, slot_only=False, sustained=0):
     """frame pairs per second FROM THE REFERENCE'S OWN STARTING DISTRIBUTION (odometery/two_frame_sfm.py:77-81,103-105): every
     resident pair starts at T_gt Exp(0.05 randn(6)) with depth seeds log(2 + 2 rand) on a multi-octave (~1/f) texture
     (synth.make_pair(texture='octaves', init_mode='reference')); the schedule is optim.pair_batch.REFERENCE_START_SCHEDULE
@@ -296,6 +296,30 @@ def reference_start_leg(args, rank, dev, M, barrier=None, reduce_max=None, queue
                                   "the slots that stand empty once the queue has run dry (the tail of ONE batch: 2 pairs per slot here)"),
         "what": "sum over pairs and phases of (cost evaluations) x (20 B per point of the phase's lattice + 12 B per pixel of its target level), / wall time of "
                 "the quoted run / 8 TB/s; per-phase kernel times when every pair is in the same phase: profiles/r06_phase_cost.txt"}
+    if sustained:
+        # SUSTAINED: `sustained` batches of these pairs in flight at a time, each a scheduled run over its own slots on its own HIP stream and
+        # host thread (optim.pair_stream.PairStream.optimise), two passes over `sustained` distinct batches back to back.  What a run of ONE
+        # batch cannot do -- put the fixed tail of a third attempt (the reference's 3 x 500 Adam iterations, one after the other) under
+        # work -- the next batch's bulk does.  Per pair bitwise the one-batch result: the statuses must be the quoted run's.
+        from super_primitive_amd.optim.pair_stream import PairStream
+        st_ref = batch.status.clone()
+        copies = [batch] + [PairBatch(src, [t(p.trg_image) for p in scenes], [t(p.K) for p in scenes], torch.from_numpy(np.stack(poses)),
+                                      [t(k) for k in klds], levels=REFERENCE_START_LEVELS, tile_points=args.tile_points, replicate=R,
+                                      point_stride=REFERENCE_START_POINT_STRIDE, granule=args.granule) for _ in range(sustained - 1)]
+        pipe = PairStream(levels=REFERENCE_START_LEVELS, point_stride=REFERENCE_START_POINT_STRIDE, schedule=dict(kw, slots=S), optimisers=sustained)
+        pipe.optimise(copies, restore=True)              # (untimed pass first)
+        barrier()
+        t0 = time.perf_counter()
+        pipe.optimise(copies, restore=True)
+        pipe.optimise(copies, restore=True)
+        barrier()
+        dt_s = reduce_max(time.perf_counter() - t0)
+        same = all(bool((c.status == st_ref).all()) for c in copies)
+        rec_q["sustained"] = {"batches_in_flight": sustained, "runs": 2 * sustained, "pairs": 2 * sustained * Qb, "frame_pairs_per_sec": 2 * sustained * Qb / dt_s,
+                              "slots_per_batch": S, "statuses_equal_the_one_batch_run": same,
+                              "what": "two passes over `batches_in_flight` distinct batches of the same pairs, each batch a scheduled run over its own slots on "
+                                      "its own HIP stream and host thread (PairStream.optimise); set-up excluded"}
+        del copies, pipe
     if slot_only:
         del batch
         torch.cuda.empty_cache()
@@ -1005,8 +1029,9 @@ def main(argv=None):
                     # per keyframe: synth.make_pair(shape='sam'))
                     sam_args = copy.copy(args)
                     sam_args.shape, sam_args.coverage = "sam", 1.2
-                    rsam = reference_start_leg(sam_args, rank, dev, M, slot_only=True)
+                    rsam = reference_start_leg(sam_args, rank, dev, M, slot_only=True, sustained=3)
                     line["frame_pairs_per_sec_sam_masks"] = rsam["frame_pairs_per_sec"]
+                    line["frame_pairs_per_sec_sam_masks_sustained"] = rsam["sustained"]["frame_pairs_per_sec"]
                     line["reference_start_sam_masks"] = rsam
                     # ... and with FOUR TIMES the resident set behind the same slots (6144 pairs on 768 slots; replicas share their scenes'
                     # tables, the unknowns are their own): a pair that needs its third attempt -- the reference's 3 x 500 Adam iterations, one after
