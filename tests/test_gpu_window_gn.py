@@ -438,3 +438,34 @@ def test_leaving_out_the_schur_launch_of_a_window_without_free_depths_changes_no
         out[fixed] = (res[0].clone(), res[1].clone(), torch.stack(res[2]), res[3], trk.win.nodes.clone())
     a, b = out[True], out[False]
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] and torch.equal(a[4], b[4])
+
+
+def test_reducing_the_trackers_edge_inside_the_update_kernel_changes_no_bit():
+    """Round 6, late: a depth-less window of a few edges (the tracker) has its edges reduced INSIDE ``k_window_gn_update`` instead of in a
+    ``k_window_gn_reduce`` launch in front of it, and the per-segment sums -- read by the Schur terms only -- are not made.  Same routine, same
+    order of the sums: poses, affine pairs, losses, iteration counts and the whole node array bit for bit those of the separate launch
+    (``SP_WGN_NO_INLINE=1``, read by the library per call)."""
+    import os
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.odometery.loops import GnTracker
+    g = load_golden("g17_config3_tum_shaped")
+    frames, est, klds, affs, kfs = _config3(g)
+    z2 = torch.zeros(2, device=kfs[0].image.device)
+    f = KeyFrame(T(frames[1].image), T(frames[1].K))
+    out = {}
+    try:
+        for separate in (False, True):
+            if separate:
+                os.environ["SP_WGN_NO_INLINE"] = "1"
+            else:
+                os.environ.pop("SP_WGN_NO_INLINE", None)
+            trk = GnTracker(kfs[0], T(frames[0].kld_gt), T(est[0]), f, (0, 3), kf_aff=z2)
+            assert trk.win.depths_fixed
+            res = trk.track(f, T(est[1]), z2)
+            torch.cuda.synchronize()
+            out[separate] = (res[0].clone(), res[1].clone(), torch.stack(res[2]), res[3], trk.win.nodes.clone())
+    finally:
+        os.environ.pop("SP_WGN_NO_INLINE", None)
+    a, b = out[False], out[True]
+    assert a[3] > 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3] and torch.equal(a[4], b[4])

@@ -14,7 +14,7 @@ args = bench.parse(["--no-cpu-baseline", "--no-pmc", "--shape", "blobs"])
 p = bench._render_sigma05((64, 5000, "blobs", 1.2))
 sync = torch.cuda.synchronize
 IT = 400
-for copies in (1, 8, 64, 512):
+for copies in ((1,) if os.environ.get("SP_LONE_ONLY") else (1, 8, 64, 512)):
     b = PairBatch.from_synth([p] * copies, levels=REFERENCE_START_LEVELS, point_stride=REFERENCE_START_POINT_STRIDE, granule=64)
     for name, spec in (("Adam L2 stride 4", dict(level=2, stride=4, adam=True)), ("Adam L0 stride 2", dict(level=0, stride=2, adam=True)), ("GN joint L2 stride 4", dict(level=2, stride=4))):
         ph = dict(spec, max_iters=IT, irls_eps=1e-5, conv_tol=0.0)
