@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define SP_ABI_VERSION 14
+#define SP_ABI_VERSION 15
 
 #define SP_EINVAL (-1)   /* bad argument (null pointer, non-positive size, ...) */
 #define SP_ELIMIT (-2)   /* size outside what the kernels support (H or W > 32767, N > 65535, ...) */
@@ -162,6 +162,11 @@ typedef struct SpPrepImage {
     int32_t H, W;
 } SpPrepImage;                   /* 24 bytes */
 int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream);
+/* (ABI 15) sp_prepare_count for batches whose keyframes ALL carry the segment-box hint (SpPrepTable.boxes; mask_generation.py:93,155-180 computes
+ * the boxes of SAM's masks): same outputs, bit for bit; a workgroup tests 64 blocks of 64 rows against the boxes at once and only walks those
+ * that meet one (the pass is otherwise bound by the latency of 184 k two-load chains per 384 keyframes).  Keyframes without boxes are handled
+ * too, correctly but slowly. */
+int sp_prepare_count_boxed(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream);
 int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream);
 int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream);
 int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixels, void* stream);

@@ -35,6 +35,7 @@ SIGNATURES = {
     "sp_pairs_cost_active": [P, P, P, I, I, F, P, P, P, P],
     "sp_pairs_gn_step_conv": [P, I, I, P, P, F, F, F, P, P, P, F, P, P],
     "sp_prepare_count": [P, I, I, I, P],
+    "sp_prepare_count_boxed": [P, I, I, I, P],
     "sp_prepare_fill": [P, I, I, I, P],
     "sp_prepare_sample": [P, I, I, P],
     "sp_prepare_blur": [P, I, I, I, P],
@@ -79,7 +80,7 @@ SIGNATURES = {
     "sp_kth_mask_pixel": [P, P, I, I, I, P, P, P],
 }
 
-SP_ABI_VERSION = 14
+SP_ABI_VERSION = 15
 SP_GRAD_PARTIAL_FLOATS = 16
 SP_GN_PARTIAL_FLOATS = 32
 SP_GNA_PARTIAL_FLOATS = 48

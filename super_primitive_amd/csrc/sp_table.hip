@@ -377,13 +377,33 @@ __device__ __forceinline__ bool prep_fast_path(const PrepTable& t) {
     return fixed && (t.W & 15) == 0 && ((uintptr_t)t.masks & 15) == 0 && t.W <= 1024;
 }
 
-__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable* __restrict__ tables) {
-    const PrepTable& t = table_of(tables, blockIdx.y);
-    if (!prep_fast_path(t)) return;          // (k_prep_row_counts_general takes those keyframes)
+// What the count pass needs of a keyframe's record, as a PRIVATE copy made once per workgroup: through a reference to the record in device
+// memory the compiler re-reads a field after every store (it cannot know the stores leave the record alone) -- a chain of scalar-load round
+// trips inside every block of rows, and most of a block's time when the segment boxes leave it 96 pieces to read.
+struct CountTable {
+    const SP_GLOBAL uint8_t* masks;
+    const SP_GLOBAL float* logdepth;
+    SP_GLOBAL int32_t* row_counts[SP_PREP_MAX_STRIDES];
+    int32_t stride[SP_PREP_MAX_STRIDES];
+    int32_t N, H, W, n_strides;
+    SP_GLOBAL uint32_t* bits;
+    const SP_GLOBAL int32_t* boxes;
+};
+__device__ __forceinline__ CountTable count_table(const PrepTable& g) {
+    CountTable t;
+    t.masks = g.masks; t.logdepth = g.logdepth; t.N = g.N; t.H = g.H; t.W = g.W; t.n_strides = g.n_strides; t.bits = g.bits; t.boxes = g.boxes;
+#pragma unroll
+    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) { t.row_counts[k] = g.row_counts[k]; t.stride[k] = g.stride[k]; }
+    return t;
+}
+
+// (one block of SP_WAVES x SP_PREP_WAVE_ROWS rows; every early return is taken by the whole workgroup)
+__device__ __forceinline__ void prep_row_counts_block(const CountTable& t, int vb) {
     const int rows = t.N * t.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int qpr = t.W >> 4;
     constexpr int BLOCK_ROWS = SP_WAVES * SP_PREP_WAVE_ROWS;
+    if (vb * BLOCK_ROWS >= rows) return;
     // (the box hint only counts pixels INSIDE the boxes; the fill pass honours that only on its bit-word path (it then fills
     //  from the bit words this pass writes) -- a keyframe that k_prep_fill will scan mask by mask ignores the hint, so that a mask pixel
     //  outside its box, a contract violation, is still counted before it is filled)
@@ -393,7 +413,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
         // SEGMENT BOXES (SpPrepTable.boxes), the whole workgroup first (its 64 rows lie in at most two segments): most workgroups of
         // a boxed keyframe are outside every box -- a segment covers a small part of the image -- and leave with three coalesced
         // stores of zero counts, before any LDS
-        const int B0 = blockIdx.x * BLOCK_ROWS, B1 = min(B0 + BLOCK_ROWS, rows) - 1;
+        const int B0 = vb * BLOCK_ROWS, B1 = min(B0 + BLOCK_ROWS, rows) - 1;
         if (B0 >= rows) return;
         const int H = t.H, n0 = B0 / H, n1 = B1 / H;
         bool any = false;
@@ -419,7 +439,7 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
             return;
         }
     }
-    const int row_base = (blockIdx.x * SP_WAVES + wave) * SP_PREP_WAVE_ROWS;
+    const int row_base = (vb * SP_WAVES + wave) * SP_PREP_WAVE_ROWS;
     const int n_rows = min(SP_PREP_WAVE_ROWS, rows - row_base);          // (<= 0: a wave past the end, which still meets the barrier)
     // ... then per wave: lane r < n_rows holds the box of the wave's row r -- is the row inside its segment's box rows, and which
     // columns.  A wave none of whose rows is inside any box reads nothing and writes zero counts; the others walk only the 16-pixel
@@ -511,6 +531,111 @@ __global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable*
 #pragma unroll
         for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
             if (k < t.n_strides) t.row_counts[k][row] = (r % t.stride[k] == 0) ? cnt[k] : 0;
+    }
+}
+
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts(const SpPrepTable* __restrict__ tables) {
+    const PrepTable& g = table_of(tables, blockIdx.y);
+    if (!prep_fast_path(g)) return;          // (k_prep_row_counts_general takes those keyframes)
+    const CountTable t = count_table(g);
+    prep_row_counts_block(t, (int)blockIdx.x);
+}
+
+// The count pass of BOXED keyframes (sp_prepare_count_boxed; round 6, late): ONE WORKGROUP PER SEGMENT.  With the segment-box hint
+// k_prep_row_counts reads 1.15 MB of a keyframe's 19.7 MB of masks, but stays organised by blocks of 64 (segment,row) rows: 480 workgroups per
+// keyframe, most of which leave after a test behind two dependent scalar loads, the others walking 16 rows x ~6 pieces per wave behind three
+// more round trips -- 0.33-0.49 ms per 384 keyframes at 0.10 of the HBM roofline, bound by the LATENCY of its chains (several blocks per
+// workgroup, tested a block per lane at once: 0.31-0.42 ms; a private copy of the record against scalar re-loads: no change).  A segment's
+// box is one rectangle: its workgroup loads the box, has ALL the rectangle's 16-byte pieces in flight at once (68 rows x 7 pieces for a grid
+// segment: two loads per thread), writes their bit words (zeros for the rest of the box rows' words: the fill pass reads whole rows) and adds
+// the pieces' lattice counts to their rows' counters in LDS (integer adds: any order gives the same sums), then stores the counts of the
+// segment's H rows -- zeros outside the box rows.  Same row counts, same bit words as k_prep_row_counts, bit for bit.  A keyframe without
+// boxes (or whose fill pass does not read the bit words) takes the whole frame as every segment's box: correct, but meant for batches whose
+// keyframes all carry boxes.
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_row_counts_boxed(const SpPrepTable* __restrict__ tables) {
+    const PrepTable& g = table_of(tables, blockIdx.y);
+    if (!prep_fast_path(g)) return;          // (k_prep_row_counts_general takes those keyframes)
+    const CountTable t = count_table(g);
+    const int n = (int)blockIdx.x;
+    if (n >= t.N) return;
+    const int H = t.H, W = t.W, qpr = W >> 4;
+    const bool fill_reads_bits = t.bits && ((uintptr_t)t.logdepth & 15) == 0 && (long long)t.N * H < (1ll << 22) && H <= 1024;
+    int r0 = 0, r1 = H, c0 = 0, c1 = W;
+    if (fill_reads_bits && t.boxes) {
+        r0 = min(max(t.boxes[4 * n], 0), H); c0 = max(t.boxes[4 * n + 1], 0);
+        r1 = min(max(t.boxes[4 * n + 2], r0), H); c1 = min(t.boxes[4 * n + 3], W);
+        if (c0 >= c1) r1 = r0;               // (an empty box: no row is inside)
+    }
+    const int q0 = c0 >> 4, q1 = r1 > r0 ? (c1 + 15) >> 4 : q0, nq = q1 - q0;
+    constexpr int CHUNK = 1024;              // box rows per pass over the LDS counters (one pass unless H > 1024)
+    __shared__ uint32_t s_a[2][CHUNK];       // per row of the box: the four lattice counts as 16-bit fields of two words (a row holds <= 1024 pixels)
+    uint32_t sel[SP_PREP_MAX_STRIDES];
+#pragma unroll
+    for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k) sel[k] = k < t.n_strides ? lattice_piece(t.stride[k]) : 0u;
+    const size_t row0 = (size_t)n * H;
+    const SP_GLOBAL u32x4* const mq = (const SP_GLOBAL u32x4*)t.masks + row0 * qpr;
+    SP_GLOBAL uint32_t* const bits = t.bits ? t.bits + row0 * qpr : nullptr;
+    // the box rows' bit words outside [q0, q1): zeros (rows outside the box are found empty through lattice 0's row counts and their words are
+    // never read -- unless the first lattice is not the full one: then every row's words must be there)
+    if (bits) {
+        const bool all_rows = t.stride[0] != 1;
+        const int ra = all_rows ? 0 : r0, rb = all_rows ? H : r1;
+        for (int p = threadIdx.x; p < (rb - ra) * qpr; p += SP_BLOCK) {
+            const int r = ra + p / qpr, xq = p - (r - ra) * qpr;
+            if (r < r0 || r >= r1 || xq < q0 || xq >= q1) bits[(size_t)r * qpr + xq] = 0u;
+        }
+    }
+    // the rows outside the box: zero counts
+    for (int r = threadIdx.x; r < H; r += SP_BLOCK) {
+        if (r >= r0 && r < r1) continue;
+#pragma unroll
+        for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+            if (k < t.n_strides) t.row_counts[k][row0 + r] = 0;
+    }
+    const uint32_t nq_magic = nq > 1 ? (0xffffffffu / (uint32_t)nq + 1u) : 0u;
+    for (int ra = r0; ra < r1; ra += CHUNK) {
+        const int rows_c = min(CHUNK, r1 - ra), n_pieces = rows_c * nq;
+        __syncthreads();                     // (the previous chunk's counters have been read)
+        for (int r = threadIdx.x; r < rows_c; r += SP_BLOCK) { s_a[0][r] = 0u; s_a[1][r] = 0u; }
+        __syncthreads();
+        for (int p0 = 0; p0 < n_pieces; p0 += SP_PREP_LOADS * SP_BLOCK) {
+            uint4 w[SP_PREP_LOADS];
+            int rl[SP_PREP_LOADS], xq[SP_PREP_LOADS];
+#pragma unroll
+            for (int u = 0; u < SP_PREP_LOADS; ++u) {
+                const int p = p0 + u * SP_BLOCK + (int)threadIdx.x;
+                const int pc = min(p, n_pieces - 1);
+                int q = pc;                                      // row of the piece inside the chunk: pc / nq
+                if (nq > 1) {
+                    q = (int)__umulhi((uint32_t)pc, nq_magic);
+                    if ((q + 1) * nq <= pc) ++q;                 // (the magic quotient is exact or one off)
+                    if (q * nq > pc) --q;
+                }
+                rl[u] = q; xq[u] = q0 + (pc - q * nq);
+                w[u] = p < n_pieces ? load4_once(mq + (size_t)(ra + rl[u]) * qpr + xq[u]) : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < SP_PREP_LOADS; ++u) {
+                const int p = p0 + u * SP_BLOCK + (int)threadIdx.x;
+                if (p < n_pieces) {
+                    const uint32_t m = piece_bits(nonzero_bytes(w[u].x), nonzero_bytes(w[u].y), nonzero_bytes(w[u].z), nonzero_bytes(w[u].w));
+                    if (bits) bits[(size_t)(ra + rl[u]) * qpr + xq[u]] = m;
+                    const uint32_t a0 = (uint32_t)__popc(m & sel[0]) | ((uint32_t)__popc(m & sel[1]) << 16);
+                    const uint32_t a1 = (uint32_t)__popc(m & sel[2]) | ((uint32_t)__popc(m & sel[3]) << 16);
+                    if (a0) atomicAdd(&s_a[0][rl[u]], a0);
+                    if (a1) atomicAdd(&s_a[1][rl[u]], a1);
+                }
+            }
+        }
+        __syncthreads();
+        for (int rr = threadIdx.x; rr < rows_c; rr += SP_BLOCK) {
+            const int r = ra + rr;
+            const uint32_t a0 = s_a[0][rr], a1 = s_a[1][rr];
+            const int cnt[SP_PREP_MAX_STRIDES] = {(int)(a0 & 0xffffu), (int)(a0 >> 16), (int)(a1 & 0xffffu), (int)(a1 >> 16)};
+#pragma unroll
+            for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
+                if (k < t.n_strides) t.row_counts[k][row0 + r] = (r % t.stride[k] == 0) ? cnt[k] : 0;
+        }
     }
 }
 
@@ -1259,11 +1384,13 @@ static_assert(sizeof(SpPrepTable) == 240 && sizeof(SpPrepSample) == 176 && sizeo
 // ---- batched preparation ----
 static int check_grid(long x, long y) { return (x <= 0 || y <= 0 || y > 65535) ? SP_EINVAL : 0; }
 
-int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
+static int prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, bool boxed, void* stream) {
     if (!tables || check_grid(max_rows, n_tables) || max_N <= 0) return SP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int per_block = SP_WAVES * SP_PREP_WAVE_ROWS;
-    hipLaunchKernelGGL(k_prep_row_counts, dim3((max_rows + per_block - 1) / per_block, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    if (boxed) {
+        hipLaunchKernelGGL(k_prep_row_counts_boxed, dim3(max_N, n_tables), dim3(SP_BLOCK), 0, s, tables);
+    } else hipLaunchKernelGGL(k_prep_row_counts, dim3((max_rows + per_block - 1) / per_block, n_tables), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     const int general_rows = SP_WAVES * SP_PREP_ROWS;
     hipLaunchKernelGGL(k_prep_row_counts_general, dim3(std::min((max_rows + general_rows - 1) / general_rows, SP_PREP_GENERAL_BLOCKS), n_tables), dim3(SP_BLOCK), 0, s, tables);
@@ -1271,6 +1398,14 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
     hipLaunchKernelGGL(k_prep_row_scan, dim3((max_N + SP_WAVES - 1) / SP_WAVES, n_tables, SP_PREP_MAX_STRIDES), dim3(SP_BLOCK), 0, s, tables);
     SP_CHECK_LAUNCH();
     return 0;
+}
+
+int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
+    return prepare_count(tables, n_tables, max_rows, max_N, false, stream);
+}
+
+int sp_prepare_count_boxed(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {
+    return prepare_count(tables, n_tables, max_rows, max_N, true, stream);
 }
 
 int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream) {

@@ -399,32 +399,13 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     staged = stage([recs], dev)
     timer.mark('count launch')
     with timer('count'):
-        _lib.check(lib.sp_prepare_count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
+        # (every keyframe of the batch on the fast path WITH the segment-box hint: the count pass that tests 64 blocks of rows against the boxes at once)
+        count = lib.sp_prepare_count_boxed if bool((recs['boxes'] != 0).all()) else lib.sp_prepare_count
+        _lib.check(count(_lib.ptr(staged[0]), M0, max_rows, max_N, s_ptr), "sp_prepare_count")
     counts_pinned = torch.empty(nS * S, dtype=torch.int32, pin_memory=True)
     counts_pinned.copy_(counts_d, non_blocking=True)
     counts_ready = torch.cuda.Event()
     counts_ready.record()
-    # the per-pair inputs: initial log-depths and target intrinsics -- behind the COUNT pass, which is launched first (round 6: the GPU waited
-    # 0.25 ms for the handles below before it got anything to do) and in front of the pyramids: the intrinsics come back to the host for the
-    # descriptors, which are built after the counts have arrived anyway; a copy enqueued behind the pyramid passes would make the host wait
-    # for those.  The intrinsics of both frames and the log-depths (one flat array, the optimisation variable) are collected by ONE gather
-    # launch from the pointer lists -- torch.stack / torch.cat over hundreds of small tensors cost 0.7 us of interpreter time per tensor
-    kld_ptr, kld = handles(klds, dev)
-    Ktrg_ptr, Ktrg = handles(trg_Ks, dev)
-    timer.mark('kld / K handles')
-    if sum(map(_numel, klds)) != S or sum(map(_numel, trg_Ks)) != 9 * M0:
-        raise ValueError("one (N_m,) log-depth vector and one (3,3) target intrinsics matrix per pair")
-    # (one output buffer -- the 2 M0 intrinsics matrices, then the S log-depths -- and ONE launch over the 3 M0 sources)
-    gathered = torch.empty(18 * M0 + S, dtype=torch.float32, device=dev)
-    Ks_d, kld_flat = gathered[:18 * M0].view(2 * M0, 3, 3), gathered[18 * M0:]
-    g = stage([np.concatenate((frec['K'], Ktrg_ptr, kld_ptr)), np.concatenate((9 * np.arange(2 * M0, dtype=np.int64), 18 * M0 + n_off.astype(np.int64)))], dev)
-    _lib.check(lib.sp_prepare_gather(_lib.ptr(g[0]), _lib.ptr(g[1]), 3 * M0, _lib.ptr(gathered), s_ptr), "sp_prepare_gather")
-    Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)      # complete once the counts have been waited for
-    Ks_pinned.copy_(Ks_d, non_blocking=True)
-    Ks_ready = torch.cuda.Event()
-    Ks_ready.record()
-
-    timer.mark('gathers enqueued')
     # (Round 6, measured and NOT kept: the image passes -- pyramids, packed targets -- on a side stream next to the count and fill passes,
     #  which they do not depend on.  The passes then overlap and take as long together as one after the other: count 1.84 -> 3.18 ms,
     #  pyramid 0.82 -> 1.25, pack 0.68 -> 1.57, the whole set-up 5.94 -> 6.07 ms per 384 pairs (profiles/r06_setup_side_stream.txt).  The
@@ -482,6 +463,29 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
     else:
         with timer('pack'):
             _lib.check(lib.sp_prepare_pack(_lib.ptr(staged[0]), M0, int((hw[0][:, 0] * hw[0][:, 1]).max()), s_ptr), "sp_prepare_pack")
+
+    # the per-pair inputs: initial log-depths and target intrinsics -- behind the count AND the pyramid passes, which are launched first
+    # (round 6: the GPU waited 0.25 ms for the handles below before it got anything to do; with the segment-box hint the count pass is over
+    # after 0.25 ms and the GPU waited again, for the pyramid jobs).  The intrinsics come back to the host for the descriptors: the host
+    # waits for them at the end of this function, by when every pass has been enqueued.  The intrinsics of both frames and the log-depths
+    # (one flat array, the optimisation variable) are collected by ONE gather launch from the pointer lists -- torch.stack / torch.cat over
+    # hundreds of small tensors cost 0.7 us of interpreter time per tensor
+    kld_ptr, kld = handles(klds, dev)
+    Ktrg_ptr, Ktrg = handles(trg_Ks, dev)
+    timer.mark('kld / K handles')
+    if sum(map(_numel, klds)) != S or sum(map(_numel, trg_Ks)) != 9 * M0:
+        raise ValueError("one (N_m,) log-depth vector and one (3,3) target intrinsics matrix per pair")
+    # (one output buffer -- the 2 M0 intrinsics matrices, then the S log-depths -- and ONE launch over the 3 M0 sources)
+    gathered = torch.empty(18 * M0 + S, dtype=torch.float32, device=dev)
+    Ks_d, kld_flat = gathered[:18 * M0].view(2 * M0, 3, 3), gathered[18 * M0:]
+    g = stage([np.concatenate((frec['K'], Ktrg_ptr, kld_ptr)), np.concatenate((9 * np.arange(2 * M0, dtype=np.int64), 18 * M0 + n_off.astype(np.int64)))], dev)
+    _lib.check(lib.sp_prepare_gather(_lib.ptr(g[0]), _lib.ptr(g[1]), 3 * M0, _lib.ptr(gathered), s_ptr), "sp_prepare_gather")
+    Ks_pinned = torch.empty(2 * M0, 3, 3, dtype=torch.float32, pin_memory=True)      # complete once the counts have been waited for
+    Ks_pinned.copy_(Ks_d, non_blocking=True)
+    Ks_ready = torch.cuda.Event()
+    Ks_ready.record()
+
+    timer.mark('gathers enqueued')
 
     # ---- host: padded layouts; device: fill straight into them ----
     timer.mark('wait for counts')

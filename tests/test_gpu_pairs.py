@@ -1014,6 +1014,67 @@ def test_segment_box_hint_builds_the_same_tables(granule):
         build(bad)
 
 
+@pytest.mark.parametrize("granule", [256, 64])
+def test_boxed_count_pass_builds_the_same_tables(granule):
+    """Round 6 (ABI 15): a batch whose keyframes ALL carry the segment-box hint goes through ``sp_prepare_count_boxed`` -- one workgroup per
+    segment, the box's pieces in flight at once, row counts summed by integer adds in LDS -- instead of the row-block pass.  Tables, sampled
+    levels and work lists are BITWISE those of the full scan without boxes: grid tiles, ragged blobs, SAM-realistic sets (areas over decades,
+    nested masks, holes), boxes tight / grown / reaching over the image, an empty segment with an inverted box, and a keyframe of more than
+    1024 rows (its hint is ignored: the whole frame is every segment's box, in passes of 1024 rows)."""
+    from super_primitive_amd import _lib, synth
+    from super_primitive_amd.image.keyframe import KeyFrame
+    from super_primitive_amd.optim import batch_prepare
+    from super_primitive_amd.optim.pair_batch import PairBatch
+    dev = torch.device("cuda:0")
+    prs = [synth.make_pair(96, 128, 6, seed=401, overlap=2), synth.make_pair(96, 128, 9, seed=402, shape="blobs", blob_coverage=1.1),
+           synth.make_pair(128, 160, 7, seed=404, shape="blobs", blob_coverage=0.8), synth.make_pair(240, 320, 24, seed=405, shape="sam"),
+           synth.make_pair(1104, 32, 3, seed=406)]
+    prs[1].keypoint_regions[3] = False                      # an empty segment
+    t = lambda a: T(a).to(dev)
+
+    def frames(with_boxes, grow=0):
+        out = []
+        for i, p in enumerate(prs):
+            kf = KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions))
+            if with_boxes:
+                b = _mask_boxes(kf.keypoint_regions)
+                b[:, :2] -= grow; b[:, 2:] += grow
+                if i == 1:
+                    b[3] = torch.tensor([40, 50, 10, 20], dtype=torch.int32)      # inverted: an empty segment
+                kf.segment_boxes = b.to(dev)
+            out.append(kf)
+        return out
+
+    rest = ([t(p.trg_image) for p in prs], [t(p.K) for p in prs], torch.stack([t(p.pose_init) for p in prs]), [t(p.kld_init) for p in prs])
+    calls = []
+    lib = _lib.load()
+    real = lib.sp_prepare_count_boxed
+
+    class _Spy:                                  # (which entry point the set-up took)
+        def __getattr__(self, name):
+            if name == "sp_prepare_count_boxed":
+                return lambda *a: (calls.append(1), real(*a))[1]
+            return getattr(lib, name)
+
+    for stride in ((2, 2, 4), (1, 2, 4)):
+        build = lambda fr: PairBatch(fr, *rest, levels=(0, 3), point_stride=stride, granule=granule, tile_points=1024)
+        ref = build(frames(False))
+        for grow in (0, 5, 1000):
+            n0 = len(calls)
+            orig = batch_prepare._lib.load
+            batch_prepare._lib.load = lambda: _Spy()
+            try:
+                got = build(frames(True, grow))
+            finally:
+                batch_prepare._lib.load = orig
+            assert len(calls) == n0 + 1, "the boxed count pass was not taken"
+            assert got.Ps == ref.Ps and torch.equal(got.pix, ref.pix) and torch.equal(got.kp_L, ref.kp_L)
+            bits = lambda x: x.contiguous().view(torch.int32)          # (bit patterns: the tall keyframe's synthetic depths hold NaNs)
+            assert torch.equal(bits(got.src4[0]), bits(ref.src4[0])) and torch.equal(got.chunks, ref.chunks) and torch.equal(got.spans, ref.spans)
+            for key, lay in ref.coarse.items():
+                assert torch.equal(got.coarse[key].pix, lay.pix) and torch.equal(bits(got.coarse[key].src4), bits(lay.src4)), (stride, grow, key)
+
+
 def test_keyframe_record_of_the_set_up_follows_replaced_and_edited_tensors():
     """The batched set-up finds the device addresses of a keyframe's tensors on the keyframe (optim.batch_prepare.frame_records).  A build
     after one of them was REPLACED reads the new tensor, a build after an IN-PLACE edit reads the edited values -- both equal to a build from

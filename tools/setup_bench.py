@@ -15,6 +15,10 @@ t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 base = [synth.make_pair(480, 640, 64, seed=7000 + s, overlap=4, init_sigma=0.004) for s in range(4)]
 pairs = [base[i % len(base)] for i in range(G)]
 src = [KeyFrame(t(p.src_image), t(p.K), t(p.logdepth_perseg), t(p.keypoints), t(p.keypoint_regions)) for p in pairs]
+if os.environ.get("SP_BOXES"):                 # the segment-box hint on every keyframe (KeyFrame.segment_boxes)
+    from super_primitive_amd.optim.batch_prepare import segment_boxes_of
+    for kf in src:
+        kf.segment_boxes = segment_boxes_of(kf.keypoint_regions)
 trg, Ks, klds = [t(p.trg_image) for p in pairs], [t(p.K) for p in pairs], [t(p.kld_init) for p in pairs]
 poses = torch.stack([t(p.pose_init) for p in pairs])
 GRAN = int(os.environ.get('SP_GRANULE', '256'))
