@@ -169,6 +169,10 @@ int sp_prepare_count(const SpPrepTable* tables, int n_tables, int max_rows, int 
 int sp_prepare_count_boxed(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream);
 int sp_prepare_fill(const SpPrepTable* tables, int n_tables, int max_rows, int max_N, void* stream);
 int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* stream);
+/* (ABI 15) sp_prepare_sample for TWO tables of every keyframe in one launch: jobs_a[i] and jobs_b[i] (i < n_jobs) belong to the same keyframe and
+ * take consecutive workgroups, so that a source image both tables gather from (the all-points table and the stride-2 lattice, both sampled at
+ * level 0) is fetched from memory once.  Same outputs as two sp_prepare_sample calls, bit for bit. */
+int sp_prepare_sample_pairs(const SpPrepSample* jobs_a, int max_P_a, const SpPrepSample* jobs_b, int max_P_b, int n_jobs, void* stream);
 int sp_prepare_blur(const SpPrepImage* jobs, int n_jobs, int C, int max_out_pixels, void* stream);
 int sp_prepare_pack(const SpPrepImage* jobs, int n_jobs, int max_pixels, void* stream);
 /* One pyramid step of THREE-CHANNEL images together with their packed forms (ABI 14): what sp_prepare_blur followed by sp_prepare_pack

@@ -38,6 +38,7 @@ SIGNATURES = {
     "sp_prepare_count_boxed": [P, I, I, I, P],
     "sp_prepare_fill": [P, I, I, I, P],
     "sp_prepare_sample": [P, I, I, P],
+    "sp_prepare_sample_pairs": [P, I, P, I, I, P],
     "sp_prepare_blur": [P, I, I, I, P],
     "sp_prepare_pack": [P, I, I, P],
     "sp_prepare_blur_pack": [P, I, I, P],

@@ -1102,14 +1102,33 @@ __global__ void k_prep_keypoint_L(const SpPrepTable* __restrict__ tables) {
 // SP_SAMPLE_BLOCKS consecutive 256-point blocks: the scalar segment search (a chain of dependent loads) is repeated only when a
 // block leaves the current segment's padded run.
 template <int SP_SAMPLE_BLOCKS>
-__global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs, int blocks_per_job, int total_blocks) {
+__global__ __launch_bounds__(SP_BLOCK) void k_prep_sample(const SpPrepSample* __restrict__ jobs, int blocks_per_job, int total_blocks,
+                                                          const SpPrepSample* __restrict__ jobs_b, int blocks_per_job_b) {
     // One-dimensional grid over (table, block) pairs, rounded up to a multiple of 8.  Workgroups are dealt to the 8 XCDs round robin
     // in dispatch order: taken as they come, the blocks of one table -- which gather from the same source image -- run on all
     // eight and every XCD's L2 fetches that image.  Chunked order: every XCD gets a contiguous range of the pairs.
     const int v = xcd_chunked_tile(blockIdx.x, total_blocks);
     if (v >= total_blocks) return;
-    const int job = v / blocks_per_job, bx = v - job * blocks_per_job;
-    const PrepSample& j = reinterpret_cast<const PrepSample*>(jobs)[job];
+    // TWO TABLES OF A KEYFRAME IN ONE LAUNCH (sp_prepare_sample_pairs, jobs_b != NULL): record i of `jobs` and record i of `jobs_b` belong to the
+    // same keyframe and take consecutive workgroups -- both tables gather from the same source image (the all-points table and the stride-2
+    // lattice are both sampled at level 0), which a launch per table fetches from memory twice: 3.7 MB of the sampling pass's ~24 MB per pair
+    // ... INTERLEAVED: the tables list their segments in the same order and in the same proportions, so workgroup g of the smaller one and
+    // workgroups r g .. r g + r - 1 of the larger (r = the ratio of their sizes, rounded up) gather from the same region of the image: they take
+    // consecutive workgroups, close in time on one XCD (the image of a pair is as large as an XCD's L2: a table after the other finds it gone)
+    int job, bx;
+    bool second = false;
+    if (blocks_per_job_b > 0) {
+        const int r = (blocks_per_job + blocks_per_job_b - 1) / blocks_per_job_b, per = blocks_per_job_b * (r + 1);
+        job = v / per;
+        const int rem = v - job * per, grp = rem / (r + 1), within = rem - grp * (r + 1);
+        second = within == r;
+        bx = second ? grp : grp * r + within;
+        if (!second && bx >= blocks_per_job) return;
+    } else {
+        job = v / blocks_per_job;
+        bx = v - job * blocks_per_job;
+    }
+    const PrepSample& j = reinterpret_cast<const PrepSample*>(second ? jobs_b : jobs)[job];
     // padding granule of the table: 256 (a whole 256-point block lies in one segment) or 64 (wave spans: every WAVE's 64 points
     // do; the search then runs per wave)
     const int lane_off = (j.granule & 0xffff) == 64 ? (int)(threadIdx.x & ~63u) : 0;
@@ -1425,7 +1444,20 @@ int sp_prepare_sample(const SpPrepSample* jobs, int n_jobs, int max_P, void* str
     constexpr int K = 4;               // points per thread (384 pairs of 640x480x64: 1 -> 1.86 ms, 2 -> 1.46-1.51, 3 -> 1.40, 4 -> 1.40-1.42)
     const long per_job = (max_P + SP_BLOCK * K - 1) / (SP_BLOCK * K), total = per_job * n_jobs;
     if (total + 7 > 0x7fffffffL) return SP_ELIMIT;
-    hipLaunchKernelGGL((k_prep_sample<K>), dim3((unsigned)((total + 7) / 8 * 8)), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs, (int)per_job, (int)total);
+    hipLaunchKernelGGL((k_prep_sample<K>), dim3((unsigned)((total + 7) / 8 * 8)), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs, (int)per_job, (int)total,
+                       (const SpPrepSample*)nullptr, 0);
+    SP_CHECK_LAUNCH();
+    return 0;
+}
+
+int sp_prepare_sample_pairs(const SpPrepSample* jobs_a, int max_P_a, const SpPrepSample* jobs_b, int max_P_b, int n_jobs, void* stream) {
+    if (!jobs_a || !jobs_b || check_grid(max_P_a, n_jobs) || max_P_b <= 0) return SP_EINVAL;
+    constexpr int K = 4;
+    const long per_a = (max_P_a + SP_BLOCK * K - 1) / (SP_BLOCK * K), per_b = (max_P_b + SP_BLOCK * K - 1) / (SP_BLOCK * K);
+    const long total = per_b * ((per_a + per_b - 1) / per_b + 1) * n_jobs;             // (k_prep_sample's interleaved order: per_b groups of r + 1 workgroups)
+    if (total + 7 > 0x7fffffffL) return SP_ELIMIT;
+    hipLaunchKernelGGL((k_prep_sample<K>), dim3((unsigned)((total + 7) / 8 * 8)), dim3(SP_BLOCK), 0, static_cast<hipStream_t>(stream), jobs_a, (int)per_a, (int)total,
+                       jobs_b, (int)per_b);
     SP_CHECK_LAUNCH();
     return 0;
 }

@@ -13,6 +13,7 @@ order as the per-keyframe kernels (shared device functions, sp_table.hip)."""
 from __future__ import annotations
 
 import ctypes
+import os
 import operator
 import time
 
@@ -284,6 +285,9 @@ def stage(arrays, dev):
         tt = _TORCH_OF.get(a.dtype)
         out.append(v.view(tt).reshape(a.shape) if tt is not None and tt != torch.uint8 else v)
     return out
+
+
+_NO_PAIRED_SAMPLE = os.environ.get('SP_NO_PAIRED_SAMPLE', '0') == '1'       # (A/B switch of tools/setup_bench.py)
 
 
 class _Timer:
@@ -564,9 +568,25 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
         # one launch per lattice: the grid is (blocks of the LARGEST table, jobs), and a stride-4 table has 1/16 of the points of
         # a stride-1 table -- in one launch over all lattices two thirds of the workgroups would start only to find nothing to do
         rec_bytes = _SAMPLE_DT.itemsize
-        for ji, s_ in enumerate(levels_of):
-            grp_P = max(int(np.diff(tabs[s_].p_off).max()), 1)
-            _lib.check(lib.sp_prepare_sample(ctypes.c_void_p(staged[1].data_ptr() + ji * M0 * rec_bytes), M0, grp_P, s_ptr), "sp_prepare_sample")
+        order = list(levels_of)
+        grp_P = {s_: max(int(np.diff(tabs[s_].p_off).max()), 1) for s_ in order}
+        job_ptr = lambda s_: ctypes.c_void_p(staged[1].data_ptr() + order.index(s_) * M0 * rec_bytes)
+        # (round 6, late: two tables that gather from the SAME source level -- the all-points table and the stride-2 lattice, both at level 0 --
+        #  in ONE launch, a keyframe's two records on consecutive workgroups: a launch per table fetches that level from memory twice)
+        paired = None
+        if not _NO_PAIRED_SAMPLE:
+            for a in order:
+                b = next((b for b in order if b != a and set(levels_of[a]) & set(levels_of[b])), None)
+                if b is not None:
+                    paired = (a, b)
+                    break
+        if paired:
+            a, b = paired
+            _lib.check(lib.sp_prepare_sample_pairs(job_ptr(a), grp_P[a], job_ptr(b), grp_P[b], M0, s_ptr), "sp_prepare_sample_pairs")
+        for s_ in order:
+            if paired and s_ in paired:
+                continue
+            _lib.check(lib.sp_prepare_sample(job_ptr(s_), M0, grp_P[s_], s_ptr), "sp_prepare_sample")
 
     def sample_full(levels):
         """Sample the stride-1 tables at further pyramid levels (those left out of ``full_levels``): {level: (sum Ppad, 4)}.
