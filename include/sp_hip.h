@@ -128,7 +128,9 @@ typedef struct SpPrepTable {     /* one keyframe: its masks are read once per pa
                                     its fast path (W a multiple of 16 up to 1024, masks 16-byte aligned, strides in {1,2,4,8,16}) and
                                     read by sp_prepare_fill INSTEAD of the masks (4 instead of 16 bytes per 16 pixels); NULL, or a
                                     keyframe off the fast path: the fill pass reads the masks.  logdepth must be 16-byte aligned
-                                    when bits is given */
+                                    when bits is given.  The words of rows WITHOUT a set pixel are left unwritten when stride[0] is 1
+                                    (the fill pass finds such rows empty through their counts and never reads their words): scratch
+                                    between the two passes, not an output */
     const int32_t* boxes;        /* NULL, or N x {row0, col0, row1, col1} (half open, pixels): a HINT from whoever made the masks -- SAM's
                                     frontend computes and NMS-filters exactly these (frontend/segment/mask_generation.py:93,155-180) --
                                     that segment n has no set pixel outside its box.  The count pass then reads the masks inside

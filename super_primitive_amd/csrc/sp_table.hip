@@ -478,7 +478,19 @@ __device__ __forceinline__ void prep_row_counts_block(const CountTable& t, int v
     if (boxes && bits && !skip && lane < qpr && (lane < q0 || lane >= q1)) {      // the walked rows' bit words outside [q0, q1): zeros
         for (int r = 0; r < n_rows; ++r) bits[r * qpr + lane] = 0u;
     }
-    for (int p0 = 0; p0 < n_pieces; p0 += SP_PREP_LOADS * 64) {
+    // The bit words of EMPTY rows are never read when lattice 0 is the full one (the fill pass finds those rows empty through their counts):
+    // without boxes -- every piece of every row is walked -- they are 85 % of the words, 1.6 of the pass's 9.5 GB per 384 keyframes.  A
+    // row's emptiness is known only once all its pieces are counted, so the words are KEPT in registers (at most 1024 pieces per wave: 16
+    // per lane) and stored after the row sums, for the non-empty rows only.
+    constexpr int TRIPS = (SP_PREP_WAVE_ROWS * 64 + SP_PREP_LOADS * 64 - 1) / (SP_PREP_LOADS * 64);
+    const bool lazy_bits = bits && !boxes && t.stride[0] == 1;               // (wave-uniform)
+    uint32_t mk[TRIPS][SP_PREP_LOADS];
+#pragma unroll
+    for (int tr = 0; tr < TRIPS; ++tr) {
+        const int p0 = tr * SP_PREP_LOADS * 64;
+#pragma unroll
+        for (int u = 0; u < SP_PREP_LOADS; ++u) mk[tr][u] = 0u;
+        if (p0 >= n_pieces) continue;
         uint4 w[SP_PREP_LOADS];
 #pragma unroll
         for (int u = 0; u < SP_PREP_LOADS; ++u) {
@@ -499,7 +511,8 @@ __device__ __forceinline__ void prep_row_counts_block(const CountTable& t, int v
             if (p0 + u * 64 >= n_pieces) break;
             const uint32_t m = piece_bits(nonzero_bytes(w[u].x), nonzero_bytes(w[u].y), nonzero_bytes(w[u].z), nonzero_bytes(w[u].w));
             if (p < n_pieces) {
-                if (bits) {
+                mk[tr][u] = m;
+                if (bits && !lazy_bits) {
                     int at = p;
                     if (boxes) { const int row_l = (int)(((uint32_t)p * q_magic) >> 20); at = row_l * qpr + q0 + (p - row_l * nq); }
                     bits[at] = m;
@@ -531,6 +544,22 @@ __device__ __forceinline__ void prep_row_counts_block(const CountTable& t, int v
 #pragma unroll
         for (int k = 0; k < SP_PREP_MAX_STRIDES; ++k)
             if (k < t.n_strides) t.row_counts[k][row] = (r % t.stride[k] == 0) ? cnt[k] : 0;
+    }
+    if (lazy_bits) {
+        // (bit 4 r of the ballot: row r of the wave holds a pixel -- lattice 0 is the full one here, its count is the row's)
+        const unsigned long long full = __ballot(sub == 0 && row_l < n_rows && (a0 & 0xffffu) != 0u);
+        if (full != 0ull) {
+#pragma unroll
+            for (int tr = 0; tr < TRIPS; ++tr)
+#pragma unroll
+                for (int u = 0; u < SP_PREP_LOADS; ++u) {
+                    const int p = tr * SP_PREP_LOADS * 64 + u * 64 + lane;
+                    if (p < n_pieces) {
+                        const int rl = (int)(((uint32_t)p * q_magic) >> 20);
+                        if ((full >> (4 * rl)) & 1ull) bits[p] = mk[tr][u];
+                    }
+                }
+        }
     }
 }
 

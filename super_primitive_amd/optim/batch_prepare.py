@@ -616,6 +616,11 @@ def prepare_pairs(src_frames, trg_images, trg_Ks, klds, level_ids, coarse, dev, 
                 box_rows = np.where((r1 > r0) & (c1 > c0), r1 - r0, 0)
                 pieces = np.where(c1 > c0, -(-c1 // 16) - c0 // 16, 0)
                 count_bytes += int((box_rows * pieces * 16).sum()) + 4 * int(box_rows.sum()) * int(Ws[i] // 16)
+            elif fast[i] and all_strides[0] == 1:
+                # (round 6, late: without boxes the bit words of EMPTY rows are not written -- the fill pass never reads them: a row's words
+                #  are kept in registers until its count is known.  Rows that hold a pixel: counted here from the masks, on demand)
+                full_rows = int(own[0].view(torch.uint8).reshape(int(Ns[i]), int(Hs[i]), int(Ws[i])).amax(dim=2).ne(0).sum())
+                count_bytes += int(Ns[i] * Hs[i] * Ws[i]) + 4 * full_rows * int(Ws[i] // 16)
             else:
                 count_bytes += int(Ns[i] * Hs[i] * Ws[i]) + 4 * int(words[i])
         return {
