@@ -179,7 +179,7 @@ def main(argv=None):
                 del one
         del batch
         torch.cuda.empty_cache()
-        print(f"batch {b + 1}/{n_batches} done ({time.time() - t0:.0f} s)", flush=True)
+        print(f"batch {b + 1}/{n_batches} done ({time.time() - t0:.0f} s; last timed run {1e3 * dt:.1f} ms, {rounds} rounds)", flush=True)
     out = {}
     F = _lib.SP_STATUS_FAILED
     index = np.concatenate([np.arange(b * args.batch, (b + 1) * args.batch) for b in ran])      # global pair index of every row
